@@ -1,0 +1,745 @@
+// C-ABI runtime of the MI355X particle hot path (see include/hanabi_amd.h).
+//
+// Replaces the render-world resource management the hot path depends on
+// (EffectCache slabs src/render/effect_cache.rs:232-356, metadata init src/render/mod.rs:6048-6070,
+// per-frame spawner upload src/render/mod.rs:4437-4445,4679-4687) and the `simulate` dispatch
+// sequence (src/render/mod.rs:6942-7613) with: one hipMalloc'd SoA slab per effect instance,
+// device-resident double-buffered counters, one H2D copy + at most two kernel launches per
+// program per frame. There is no CPU fallback: without a HIP device every entry point that
+// needs one fails with HNB_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hnb_kernels.hip.h"
+
+using namespace hnb;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? HNB_ERR_OUT_OF_MEMORY : HNB_ERR_HIP, "%s failed: %s", #expr, \
+                        hipGetErrorString(e_));                                                  \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct TimingPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct HnbContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<HnbProgram*> programs;
+    HnbSimParams sim{};
+    bool timing = false;
+    std::vector<TimingPair> t_update, t_init;
+};
+
+struct HnbProgram {
+    HnbContext* ctx = nullptr;
+    HnbProgramHeader hdr{};
+    std::vector<HnbAttrEntry> attrs;
+    std::vector<HnbPropEntry> props;
+    DevProgram dev{};
+    Ins* d_code = nullptr;
+    size_t slab_bytes = 0;
+    bool update_streams = false;  // update stream runs on the streaming kernel (macro ops, U operands)
+    std::vector<Ins> uniform_code;  // evaluated on the host per instance per frame
+    std::vector<HnbEffect*> effects;
+    // device tables, sized for `table_cap` instances
+    uint32_t table_cap = 0;
+    uint64_t* d_inst_base = nullptr;
+    DevMeta* d_meta[2] = {nullptr, nullptr};
+    uint64_t* d_status = nullptr;
+    uint32_t* d_ticket = nullptr;  // [2] tickets + [1] fault word
+    void* h_frame[2] = {nullptr, nullptr};
+    void* d_frame[2] = {nullptr, nullptr};
+    hipEvent_t frame_done[2] = {nullptr, nullptr};
+    size_t frame_bytes = 0;
+    uint32_t parity = 0;
+    uint32_t epoch = 1;
+};
+
+struct HnbEffect {
+    HnbProgram* prog = nullptr;
+    uint32_t index = 0;
+    void* slab = nullptr;
+    uint32_t slot_base = 0;
+    uint32_t spawn_count = 0;
+    uint32_t seed = 0;
+    float xf[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    std::vector<uint32_t> props;
+};
+
+namespace {
+
+// Operand span check: V operands must stay inside the V file, U operands inside the
+// parameter block.
+bool operand_ok(uint32_t operand, uint32_t span, uint32_t nregs, uint32_t n_uregs, bool ustream) {
+    if (ustream) return operand + span <= n_uregs;
+    if (operand & HNB_OPERAND_U) return (operand & 0x7fu) + span <= n_uregs;
+    return operand + span <= nregs;
+}
+
+int validate_stream(const uint8_t* code, uint32_t len, uint32_t nregs, const HnbProgramHeader& h, int which) {
+    const bool ustream = which == 0;
+    const char* sname = which == 0 ? "uniform" : which == 1 ? "init" : "update";
+    const uint32_t file_regs = ustream ? h.n_uregs : nregs;
+    for (uint32_t i = 0; i < len; ++i) {
+        uint32_t w[2];
+        memcpy(w, code + (size_t)i * 8, 8);
+        const uint32_t op = w[0] & 0xff, d = (w[0] >> 8) & 0xff, a = (w[0] >> 16) & 0xff, b = w[0] >> 24;
+        const uint32_t c = w[1] & 0xff, wd = ((w[1] >> 8) & 3u) + 1u;
+        const bool ba = (w[1] >> 10) & 1u, bb = (w[1] >> 11) & 1u, bc = (w[1] >> 12) & 1u;
+#define BAD(msg) return fail(HNB_ERR_BAD_PROGRAM, "%s stream, instruction %u (op %u): %s", sname, i, op, msg)
+        if (op >= HNB_OP_COUNT || op == HNB_OP_NOP) BAD("invalid opcode");
+        if (op == HNB_OP_LOADK || op == HNB_OP_LDB || op == HNB_OP_LDP) {
+            if (!ustream) BAD("uniform-only opcode in a per-particle stream");
+            const uint32_t span = op == HNB_OP_LDP ? (a & 3u) + 1u : 1u;
+            if (d + span > file_regs) BAD("destination out of range");
+            if (op == HNB_OP_LDB && a > 5) BAD("bad sim-params field");
+            if (op == HNB_OP_LDP && w[1] + span > h.prop_words) BAD("property offset out of range");
+            continue;
+        }
+        if (ustream && !(vm_op_is_elementwise(op) || (op >= HNB_OP_ALL && op <= HNB_OP_UNPACK4SNORM)))
+            BAD("per-particle opcode in the uniform stream");
+        if (op == HNB_OP_LDPARENT || op == HNB_OP_M_EMIT_EVENTS) BAD("GPU spawn events are not supported by this build");
+        if (!ustream && (d & HNB_OPERAND_U)) BAD("destination must be a V register");
+        auto OK = [&](uint32_t operand, uint32_t span) { return operand_ok(operand, span, nregs, h.n_uregs, ustream); };
+        if (vm_op_is_elementwise(op)) {
+            const bool two = (op >= HNB_OP_FADD && op <= HNB_OP_FPOW) || (op >= HNB_OP_FLT && op <= HNB_OP_FGE) ||
+                             (op >= HNB_OP_FMIX && op <= HNB_OP_FSMOOTH) || (op >= HNB_OP_IADD && op <= HNB_OP_UGE);
+            const bool three = (op >= HNB_OP_FMIX && op <= HNB_OP_FSMOOTH) || op == HNB_OP_ICLAMP || op == HNB_OP_UCLAMP;
+            if (d + wd > file_regs) BAD("destination out of range");
+            if (!OK(a, ba ? 1 : wd)) BAD("operand a out of range");
+            // b and c are read unconditionally by the interpreter: they must always be addressable
+            if (!OK(b, (two && !bb) ? wd : 1)) BAD("operand b out of range");
+            if (!OK(c, (three && !bc) ? wd : 1)) BAD("operand c out of range");
+            continue;
+        }
+        switch (op) {
+            case HNB_OP_LDID: case HNB_OP_LDPC: case HNB_OP_LDALIVE:
+                if (d >= file_regs) BAD("destination out of range");
+                break;
+            case HNB_OP_ALL: case HNB_OP_ANY: case HNB_OP_LENGTH:
+                if (d >= file_regs || !OK(a, wd)) BAD("operand out of range");
+                break;
+            case HNB_OP_DOT: case HNB_OP_DISTANCE:
+                if (d >= file_regs || !OK(a, wd) || !OK(b, wd)) BAD("operand out of range");
+                break;
+            case HNB_OP_NORMALIZE:
+                if (d + wd > file_regs || !OK(a, wd)) BAD("operand out of range");
+                break;
+            case HNB_OP_CROSS:
+                if (d + 3 > file_regs || !OK(a, 3) || !OK(b, 3)) BAD("operand out of range");
+                break;
+            case HNB_OP_PACK4UNORM: case HNB_OP_PACK4SNORM:
+                if (d >= file_regs || !OK(a, 4)) BAD("operand out of range");
+                break;
+            case HNB_OP_UNPACK4UNORM: case HNB_OP_UNPACK4SNORM:
+                if (d + 4 > file_regs || !OK(a, 1)) BAD("operand out of range");
+                break;
+            case HNB_OP_FRAND:
+                if (d + wd > file_regs) BAD("destination out of range");
+                break;
+            case HNB_OP_RANDU: case HNB_OP_RANDN:
+                if (d + wd > file_regs || !OK(a, ba ? 1 : wd) || !OK(b, bb ? 1 : wd)) BAD("operand out of range");
+                break;
+            case HNB_OP_ALIVE_SET: case HNB_OP_ALIVE_AND: case HNB_OP_KILL_IF:
+            case HNB_OP_M_AGE_TICK: case HNB_OP_M_EULER: case HNB_OP_M_VEL_SCALE:
+                if (!OK(a, 1)) BAD("operand out of range");
+                break;
+            case HNB_OP_M_VEL_ADD:
+                if (!OK(a, 3)) BAD("operand out of range");
+                break;
+            case HNB_OP_M_PIN_SET:
+                if (!(d == HNB_REG_POSITION || d == HNB_REG_VELOCITY || d == HNB_REG_AGE || d == HNB_REG_LIFETIME)) BAD("M_PIN_SET needs a pinned destination");
+                if (!OK(a, (d == HNB_REG_POSITION || d == HNB_REG_VELOCITY) ? 3 : 1)) BAD("operand out of range");
+                break;
+            case HNB_OP_M_RADIAL_ACCEL: case HNB_OP_M_KILL_SPHERE: case HNB_OP_M_VEL_SPHERE:
+                if (!OK(a, 3) || !OK(b, 1)) BAD("operand out of range");
+                break;
+            case HNB_OP_M_TANGENT_ACCEL:
+                if (!OK(a, 3) || !OK(b, 3) || !OK(c, 1)) BAD("operand out of range");
+                break;
+            case HNB_OP_M_CONFORM_SPHERE:
+                if (!OK(a, 9) || !OK(b, 1)) BAD("operand out of range");
+                break;
+            case HNB_OP_M_KILL_AABB:
+                if (!OK(a, 3) || !OK(b, 3)) BAD("operand out of range");
+                break;
+            case HNB_OP_M_POS_CIRCLE: case HNB_OP_M_VEL_CIRCLE: case HNB_OP_M_VEL_TANGENT:
+                if (!OK(a, 7)) BAD("operand out of range");
+                break;
+            case HNB_OP_M_POS_SPHERE:
+                if (!OK(a, 4)) BAD("operand out of range");
+                break;
+            case HNB_OP_M_POS_CONE3D:
+                if (!OK(a, 3)) BAD("operand out of range");
+                break;
+            case HNB_OP_M_ADD_XLATE: break;
+            default: BAD("unhandled opcode");
+        }
+#undef BAD
+    }
+    return HNB_OK;
+}
+
+int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
+    if (!blob || size < sizeof(HnbProgramHeader)) return fail(HNB_ERR_BAD_PROGRAM, "program blob too small");
+    HnbProgramHeader h;
+    memcpy(&h, blob, sizeof h);
+    if (h.magic != HNB_PROGRAM_MAGIC) return fail(HNB_ERR_BAD_PROGRAM, "bad program magic 0x%08x", h.magic);
+    if (h.version != HNB_PROGRAM_VERSION) return fail(HNB_ERR_BAD_PROGRAM, "unsupported program version %u", h.version);
+    if (h.total_size != size) return fail(HNB_ERR_BAD_PROGRAM, "program size mismatch (%u vs %zu)", h.total_size, size);
+    if (h.capacity == 0) return fail(HNB_ERR_BAD_PROGRAM, "capacity must be > 0");
+    if (h.n_attrs == 0 || h.n_attrs > kMaxAttrs) return fail(HNB_ERR_BAD_PROGRAM, "invalid attribute count %u", h.n_attrs);
+    auto in_range = [&](uint64_t off, uint64_t bytes) { return off <= size && bytes <= size - off; };
+    if (!in_range(h.attrs_off, (uint64_t)h.n_attrs * sizeof(HnbAttrEntry)) ||
+        !in_range(h.props_off, (uint64_t)h.n_props * sizeof(HnbPropEntry)) ||
+        !in_range(h.uniform_off, (uint64_t)h.uniform_len * 8) || !in_range(h.init_off, (uint64_t)h.init_len * 8) ||
+        !in_range(h.update_off, (uint64_t)h.update_len * 8))
+        return fail(HNB_ERR_BAD_PROGRAM, "program section out of bounds");
+    if ((h.uniform_off & 7) || (h.init_off & 7) || (h.update_off & 7)) return fail(HNB_ERR_BAD_PROGRAM, "code sections must be 8-byte aligned");
+    if (h.init_regs > HNB_VM_MAX_REGS || h.update_regs > HNB_VM_MAX_REGS)
+        return fail(HNB_ERR_BAD_PROGRAM, "program needs %u V registers, the VM has %u", std::max(h.init_regs, h.update_regs),
+                    HNB_VM_MAX_REGS);
+    if (h.n_uregs > HNB_VM_MAX_UREGS) return fail(HNB_ERR_BAD_PROGRAM, "program needs %u U registers, limit %u", h.n_uregs, HNB_VM_MAX_UREGS);
+    const uint8_t* p = static_cast<const uint8_t*>(blob);
+    bool has_position = false;
+    for (uint32_t i = 0; i < h.n_attrs; ++i) {
+        HnbAttrEntry a;
+        memcpy(&a, p + h.attrs_off + i * sizeof a, sizeof a);
+        if (a.attr >= HNB_ATTR_COUNT || a.attr < HNB_ATTR_POSITION) return fail(HNB_ERR_BAD_PROGRAM, "attribute %u is not storable", a.attr);
+        if (a.ncomp < 1 || a.ncomp > 4 || a.reg + a.ncomp > HNB_VM_MAX_REGS) return fail(HNB_ERR_BAD_PROGRAM, "bad attribute entry %u", i);
+        if (a.attr == HNB_ATTR_POSITION) has_position = true;
+        const bool pinned = a.attr == HNB_ATTR_POSITION || a.attr == HNB_ATTR_VELOCITY || a.attr == HNB_ATTR_AGE ||
+                            a.attr == HNB_ATTR_LIFETIME;
+        const uint32_t want = a.attr == HNB_ATTR_POSITION ? HNB_REG_POSITION
+                              : a.attr == HNB_ATTR_VELOCITY ? HNB_REG_VELOCITY
+                              : a.attr == HNB_ATTR_AGE ? HNB_REG_AGE : HNB_REG_LIFETIME;
+        if (pinned && a.reg != want) return fail(HNB_ERR_BAD_PROGRAM, "pinned attribute %u in register %u", a.attr, a.reg);
+        if (!pinned && a.reg < HNB_REG_FIRST_FREE) return fail(HNB_ERR_BAD_PROGRAM, "attribute %u overlaps pinned registers", a.attr);
+        if (a.reg + a.ncomp > std::max<uint32_t>(h.init_regs, 1u)) return fail(HNB_ERR_BAD_PROGRAM, "attribute %u outside init register range", a.attr);
+    }
+    // The POSITION attribute is mandatory (src/lib.rs:838-845).
+    if (!has_position) return fail(HNB_ERR_BAD_PROGRAM, "the particle layout is missing the POSITION attribute");
+    for (uint32_t i = 0; i < h.n_props; ++i) {
+        HnbPropEntry pe;
+        memcpy(&pe, p + h.props_off + i * sizeof pe, sizeof pe);
+        if (pe.ncomp < 1 || pe.ncomp > 4 || pe.word_offset + pe.ncomp > h.prop_words) return fail(HNB_ERR_BAD_PROGRAM, "bad property entry %u", i);
+        if (!memchr(pe.name, 0, sizeof pe.name)) return fail(HNB_ERR_BAD_PROGRAM, "unterminated property name %u", i);
+    }
+    int rc = validate_stream(p + h.uniform_off, h.uniform_len, 0, h, 0);
+    if (rc != HNB_OK) return rc;
+    rc = validate_stream(p + h.init_off, h.init_len, h.init_regs, h, 1);
+    if (rc != HNB_OK) return rc;
+    rc = validate_stream(p + h.update_off, h.update_len, h.update_regs, h, 2);
+    if (rc != HNB_OK) return rc;
+    if (out_hdr) *out_hdr = h;
+    return HNB_OK;
+}
+
+void free_tables(HnbProgram* p) {
+    hipFree(p->d_inst_base); p->d_inst_base = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        hipFree(p->d_meta[i]); p->d_meta[i] = nullptr;
+        hipFree(p->d_frame[i]); p->d_frame[i] = nullptr;
+        if (p->h_frame[i]) hipHostFree(p->h_frame[i]);
+        p->h_frame[i] = nullptr;
+    }
+    hipFree(p->d_status); p->d_status = nullptr;
+    hipFree(p->d_ticket); p->d_ticket = nullptr;
+    p->table_cap = 0;
+}
+
+size_t frame_bytes_for(const HnbProgram* p, uint32_t n) {
+    return (size_t)n * sizeof(DevFrameInst) + (size_t)n * p->dev.n_uregs * 4 + 16;
+}
+
+// Grow the per-program device tables to hold `need` instances, preserving state.
+int ensure_tables(HnbProgram* p, uint32_t need) {
+    if (need <= p->table_cap) return HNB_OK;
+    HnbContext* ctx = p->ctx;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint32_t cap = std::max<uint32_t>(need, std::max<uint32_t>(4, p->table_cap * 2));
+    uint64_t* nb = nullptr;
+    DevMeta* nm[2] = {nullptr, nullptr};
+    uint64_t* ns = nullptr;
+    HIP_TRY(hipMalloc(&nb, (size_t)cap * 8));
+    HIP_TRY(hipMemset(nb, 0, (size_t)cap * 8));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMalloc(&nm[i], (size_t)cap * sizeof(DevMeta)));
+        HIP_TRY(hipMemset(nm[i], 0, (size_t)cap * sizeof(DevMeta)));
+    }
+    const size_t n_status = (size_t)cap * p->dev.chunks_per_inst;
+    HIP_TRY(hipMalloc(&ns, n_status * 8));
+    HIP_TRY(hipMemset(ns, 0, n_status * 8));
+    if (p->table_cap) {
+        HIP_TRY(hipMemcpy(nb, p->d_inst_base, (size_t)p->table_cap * 8, hipMemcpyDeviceToDevice));
+        for (int i = 0; i < 2; ++i)
+            HIP_TRY(hipMemcpy(nm[i], p->d_meta[i], (size_t)p->table_cap * sizeof(DevMeta), hipMemcpyDeviceToDevice));
+    }
+    hipFree(p->d_inst_base);
+    hipFree(p->d_meta[0]);
+    hipFree(p->d_meta[1]);
+    hipFree(p->d_status);
+    p->d_inst_base = nb;
+    p->d_meta[0] = nm[0];
+    p->d_meta[1] = nm[1];
+    p->d_status = ns;
+    if (!p->d_ticket) {
+        HIP_TRY(hipMalloc(&p->d_ticket, 16));
+        HIP_TRY(hipMemset(p->d_ticket, 0, 16));
+    }
+    const size_t fb = frame_bytes_for(p, cap);
+    for (int i = 0; i < 2; ++i) {
+        hipFree(p->d_frame[i]);
+        if (p->h_frame[i]) hipHostFree(p->h_frame[i]);
+        p->d_frame[i] = nullptr; p->h_frame[i] = nullptr;
+        HIP_TRY(hipMalloc(&p->d_frame[i], fb));
+        HIP_TRY(hipHostMalloc(&p->h_frame[i], fb, hipHostMallocDefault));
+        if (!p->frame_done[i]) HIP_TRY(hipEventCreateWithFlags(&p->frame_done[i], hipEventDisableTiming));
+    }
+    p->frame_bytes = fb;
+    p->table_cap = cap;
+    return HNB_OK;
+}
+
+int find_attr(const HnbProgram* p, uint32_t attr) {
+    for (size_t i = 0; i < p->attrs.size(); ++i)
+        if (p->attrs[i].attr == attr) return (int)i;
+    return -1;
+}
+
+int read_meta(HnbEffect* fx, DevMeta* out, uint32_t* fault_word) {
+    HnbProgram* p = fx->prog;
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    HIP_TRY(hipMemcpy(out, p->d_meta[p->parity] + fx->index, sizeof(DevMeta), hipMemcpyDeviceToHost));
+    uint32_t t[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(t, p->d_ticket, 16, hipMemcpyDeviceToHost));
+    if (fault_word) *fault_word = t[2];
+    return HNB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hnb_last_error(void) { return g_last_error.c_str(); }
+const char* hnb_version(void) { return "bevy_hanabi_amd 0.1.0 (gfx950)"; }
+
+int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
+    if (!out_ctx) return fail(HNB_ERR_INVALID_ARG, "out_ctx is NULL");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(HNB_ERR_NO_DEVICE, "no HIP device available (the hanabi hot path has no CPU fallback)");
+    if (device_id < 0 || device_id >= count) return fail(HNB_ERR_INVALID_ARG, "device %d out of range [0,%d)", device_id, count);
+    HIP_TRY(hipSetDevice(device_id));
+    HnbContext* ctx = new HnbContext();
+    ctx->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail(HNB_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    ctx->own_stream = true;
+    *out_ctx = ctx;
+    return HNB_OK;
+}
+
+int hnb_ctx_destroy(HnbContext* ctx) {
+    if (!ctx) return HNB_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    while (!ctx->programs.empty()) hnb_program_destroy(ctx->programs.back());
+    for (auto& t : ctx->t_update) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    for (auto& t : ctx->t_init) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return HNB_OK;
+}
+
+int hnb_ctx_set_stream(HnbContext* ctx, void* hip_stream) {
+    if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (hip_stream) {
+        if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+        ctx->stream = static_cast<hipStream_t>(hip_stream);
+        ctx->own_stream = false;
+    }
+    return HNB_OK;
+}
+
+int hnb_ctx_synchronize(HnbContext* ctx) {
+    if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return HNB_OK;
+}
+
+int hnb_program_validate(const void* blob, size_t blob_size) { return validate_blob(blob, blob_size, nullptr); }
+
+int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbProgram** out_prog) {
+    if (!ctx || !out_prog) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    HnbProgramHeader h;
+    int rc = validate_blob(blob, blob_size, &h);
+    if (rc != HNB_OK) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint8_t* b = static_cast<const uint8_t*>(blob);
+    HnbProgram* p = new HnbProgram();
+    p->ctx = ctx;
+    p->hdr = h;
+    p->attrs.resize(h.n_attrs);
+    memcpy(p->attrs.data(), b + h.attrs_off, h.n_attrs * sizeof(HnbAttrEntry));
+    p->props.resize(h.n_props);
+    if (h.n_props) memcpy(p->props.data(), b + h.props_off, h.n_props * sizeof(HnbPropEntry));
+
+    DevProgram& d = p->dev;
+    d.capacity = h.capacity;
+    d.n_attrs = h.n_attrs;
+    d.n_uregs = h.n_uregs;
+    d.chunks_per_inst = (h.capacity + kChunk - 1) / kChunk;
+    d.init_len = h.init_len;
+    d.update_len = h.update_len;
+    // Slab layout: [alive ping][alive pong][dead][attribute planes...], 256-byte aligned planes.
+    size_t off = 0;
+    const size_t list_bytes = align_up((size_t)h.capacity * 4, 256);
+    d.alive_off[0] = (uint32_t)off; off += list_bytes;
+    d.alive_off[1] = (uint32_t)off; off += list_bytes;
+    d.dead_off = (uint32_t)off; off += list_bytes;
+    for (uint32_t i = 0; i < h.n_attrs; ++i) {
+        if (off > 0xffffffffull) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB"); }
+        d.attrs[i].plane_off = (uint32_t)off;
+        d.attrs[i].ncomp = p->attrs[i].ncomp;
+        d.attrs[i].reg = p->attrs[i].reg;
+        d.attrs[i].upd_flags = p->attrs[i].update_flags;
+        off += align_up((size_t)h.capacity * p->attrs[i].ncomp * 4, 256);
+    }
+    p->slab_bytes = off;
+    p->uniform_code.resize(h.uniform_len);
+    if (h.uniform_len) memcpy(p->uniform_code.data(), b + h.uniform_off, (size_t)h.uniform_len * 8);
+    // Streaming eligibility: only macro ops on pinned registers, every operand in the
+    // parameter block, and no non-pinned attribute touched by the update program.
+    p->update_streams = true;
+    for (uint32_t i = 0; i < h.update_len; ++i) {
+        uint32_t w[2];
+        memcpy(w, b + h.update_off + (size_t)i * 8, 8);
+        const uint32_t op = w[0] & 0xffu, a = (w[0] >> 16) & 0xffu, bb = w[0] >> 24, c = w[1] & 0xffu;
+        bool ok = vm_op_is_streamable(op) && (a & HNB_OPERAND_U);
+        if (ok && (op == HNB_OP_M_RADIAL_ACCEL || op == HNB_OP_M_TANGENT_ACCEL || op == HNB_OP_M_CONFORM_SPHERE ||
+                   op == HNB_OP_M_KILL_SPHERE || op == HNB_OP_M_KILL_AABB))
+            ok = (bb & HNB_OPERAND_U) != 0;
+        if (ok && op == HNB_OP_M_TANGENT_ACCEL) ok = (c & HNB_OPERAND_U) != 0;
+        if (!ok) p->update_streams = false;
+    }
+    for (uint32_t i = 0; i < h.n_attrs; ++i)
+        if (p->attrs[i].update_flags && p->attrs[i].reg >= HNB_REG_FIRST_FREE) p->update_streams = false;
+    const size_t code_bytes = ((size_t)h.init_len + h.update_len) * 8;
+    hipError_t e = hipMalloc(&p->d_code, std::max<size_t>(code_bytes, 8));
+    if (e != hipSuccess) { delete p; return fail(HNB_ERR_OUT_OF_MEMORY, "hipMalloc(code) failed: %s", hipGetErrorString(e)); }
+    if (h.init_len) hipMemcpy(p->d_code, b + h.init_off, (size_t)h.init_len * 8, hipMemcpyHostToDevice);
+    if (h.update_len) hipMemcpy(p->d_code + h.init_len, b + h.update_off, (size_t)h.update_len * 8, hipMemcpyHostToDevice);
+    d.init_code = p->d_code;
+    d.update_code = p->d_code + h.init_len;
+    ctx->programs.push_back(p);
+    *out_prog = p;
+    return HNB_OK;
+}
+
+int hnb_program_destroy(HnbProgram* p) {
+    if (!p) return HNB_OK;
+    HnbContext* ctx = p->ctx;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    while (!p->effects.empty()) hnb_effect_destroy(p->effects.back());
+    free_tables(p);
+    for (int i = 0; i < 2; ++i) if (p->frame_done[i]) hipEventDestroy(p->frame_done[i]);
+    hipFree(p->d_code);
+    ctx->programs.erase(std::remove(ctx->programs.begin(), ctx->programs.end(), p), ctx->programs.end());
+    delete p;
+    return HNB_OK;
+}
+
+int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
+    if (!p || !out_fx) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    HnbContext* ctx = p->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t index = (uint32_t)p->effects.size();
+    int rc = ensure_tables(p, index + 1);
+    if (rc != HNB_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HnbEffect* fx = new HnbEffect();
+    fx->prog = p;
+    fx->index = index;
+    fx->slot_base = slot_base;
+    hipError_t e = hipMalloc(&fx->slab, p->slab_bytes);
+    if (e != hipSuccess) { delete fx; return fail(HNB_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes) for effect slab failed: %s", p->slab_bytes, hipGetErrorString(e)); }
+    char* base = static_cast<char*>(fx->slab);
+    const uint32_t cap = p->dev.capacity;
+    k_reset_lists<<<(cap + 255) / 256, 256, 0, ctx->stream>>>(reinterpret_cast<uint32_t*>(base + p->dev.dead_off),
+                                                              reinterpret_cast<uint32_t*>(base + p->dev.alive_off[0]),
+                                                              reinterpret_cast<uint32_t*>(base + p->dev.alive_off[1]), cap);
+    // Attribute planes start zeroed (the reference pre-fills with 0xFF only in debug builds).
+    HIP_TRY(hipMemsetAsync(base + p->dev.attrs[0].plane_off, 0, p->slab_bytes - p->dev.attrs[0].plane_off, ctx->stream));
+    // alive_count = 0, max_spawn = capacity, indirect_write_index = 0 (src/render/mod.rs:6048-6070)
+    DevMeta m{};
+    uint64_t slab_addr = reinterpret_cast<uint64_t>(fx->slab);
+    HIP_TRY(hipMemcpyAsync(p->d_inst_base + index, &slab_addr, 8, hipMemcpyHostToDevice, ctx->stream));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipMemcpyAsync(p->d_meta[i] + index, &m, sizeof m, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    fx->props.assign(p->hdr.prop_words, 0u);
+    for (const HnbPropEntry& pe : p->props)
+        for (uint32_t c = 0; c < pe.ncomp; ++c) fx->props[pe.word_offset + c] = pe.default_bits[c];
+    p->effects.push_back(fx);
+    p->dev.n_inst = (uint32_t)p->effects.size();
+    *out_fx = fx;
+    return HNB_OK;
+}
+
+int hnb_effect_destroy(HnbEffect* fx) {
+    if (!fx) return HNB_OK;
+    HnbProgram* p = fx->prog;
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    // swap-remove: move the last instance's table rows into the freed index
+    const uint32_t last = (uint32_t)p->effects.size() - 1;
+    if (fx->index != last) {
+        HnbEffect* moved = p->effects[last];
+        hipMemcpy(p->d_inst_base + fx->index, p->d_inst_base + last, 8, hipMemcpyDeviceToDevice);
+        for (int i = 0; i < 2; ++i) hipMemcpy(p->d_meta[i] + fx->index, p->d_meta[i] + last, sizeof(DevMeta), hipMemcpyDeviceToDevice);
+        moved->index = fx->index;
+        p->effects[fx->index] = moved;
+    }
+    p->effects.pop_back();
+    p->dev.n_inst = (uint32_t)p->effects.size();
+    hipFree(fx->slab);
+    delete fx;
+    return HNB_OK;
+}
+
+int hnb_effect_set_parent(HnbEffect*, HnbEffect*, uint32_t, uint32_t) {
+    return fail(HNB_ERR_INVALID_ARG, "GPU spawn events are not implemented yet (SURVEY.md §8f-1)");
+}
+
+int hnb_frame_begin(HnbContext* ctx, const HnbSimParams* params) {
+    if (!ctx || !params) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    ctx->sim = *params;
+    return HNB_OK;
+}
+
+int hnb_effect_set_frame(HnbEffect* fx, uint32_t spawn_count, uint32_t seed, const float* transform3x4) {
+    if (!fx) return fail(HNB_ERR_INVALID_ARG, "fx is NULL");
+    fx->spawn_count = spawn_count;
+    fx->seed = seed;
+    if (transform3x4) memcpy(fx->xf, transform3x4, sizeof fx->xf);
+    return HNB_OK;
+}
+
+int hnb_effect_set_property(HnbEffect* fx, const char* name, const void* value, uint32_t n_words) {
+    if (!fx || !name || !value) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    for (const HnbPropEntry& pe : fx->prog->props) {
+        if (strncmp(pe.name, name, sizeof pe.name) == 0) {
+            if (n_words != pe.ncomp) return fail(HNB_ERR_INVALID_ARG, "property '%s' has %u components, got %u", name, pe.ncomp, n_words);
+            memcpy(&fx->props[pe.word_offset], value, (size_t)n_words * 4);
+            return HNB_OK;
+        }
+    }
+    return fail(HNB_ERR_NOT_FOUND, "unknown property '%s'", name);
+}
+
+int hnb_simulate(HnbContext* ctx) {
+    if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (HnbProgram* p : ctx->programs) {
+        const uint32_t n = (uint32_t)p->effects.size();
+        if (n == 0) continue;
+        const uint32_t par = p->parity;
+        // the staging buffer of this parity was last used two frames ago
+        HIP_TRY(hipEventSynchronize(p->frame_done[par]));
+        char* h = static_cast<char*>(p->h_frame[par]);
+        DevFrameInst* fi = reinterpret_cast<DevFrameInst*>(h);
+        uint32_t* ublocks = reinterpret_cast<uint32_t*>(h + (size_t)n * sizeof(DevFrameInst));
+        const float sim[6] = {ctx->sim.time, ctx->sim.delta_time, ctx->sim.virtual_time, ctx->sim.virtual_delta_time,
+                              ctx->sim.real_time, ctx->sim.real_delta_time};
+        const uint32_t nu = p->dev.n_uregs;
+        uint32_t blocks = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            HnbEffect* fx = p->effects[i];
+            fi[i].spawn_count = fx->spawn_count;
+            fi[i].seed = fx->seed;
+            fi[i].slot_base = fx->slot_base;
+            fi[i].init_block_start = blocks;
+            // never launch more init workgroups than the capacity allows (max_spawn <= capacity)
+            const uint32_t cap_spawn = std::min(fx->spawn_count, p->dev.capacity);
+            blocks += (cap_spawn + kInitBlock - 1) / kInitBlock;
+            memcpy(fi[i].xf, fx->xf, sizeof fx->xf);
+            // Parameter block: the uniform stream (literals, properties, sim params and every
+            // expression built only from them) evaluated here, once per instance per frame.
+            if (nu) uniform_run(p->uniform_code.data(), (uint32_t)p->uniform_code.size(), fx->props.data(), sim,
+                                ublocks + (size_t)i * nu, nu);
+            fx->spawn_count = 0;  // a spawn request is consumed by exactly one frame
+        }
+        const size_t bytes = (size_t)n * sizeof(DevFrameInst) + (size_t)n * nu * 4;
+        HIP_TRY(hipMemcpyAsync(p->d_frame[par], h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipEventRecord(p->frame_done[par], ctx->stream));
+        const char* d = static_cast<const char*>(p->d_frame[par]);
+        const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
+        const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
+        p->dev.n_inst = n;
+        TimingPair ti{}, tu{};
+        if (blocks) {
+            if (ctx->timing) { hipEventCreate(&ti.a); hipEventCreate(&ti.b); hipEventRecord(ti.a, ctx->stream); }
+            k_init<<<blocks, kInitBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub);
+            if (ctx->timing) { hipEventRecord(ti.b, ctx->stream); ctx->t_init.push_back(ti); }
+        }
+        const uint32_t grid = n * p->dev.chunks_per_inst;
+        if (ctx->timing) { hipEventCreate(&tu.a); hipEventCreate(&tu.b); hipEventRecord(tu.a, ctx->stream); }
+        if (p->update_streams)
+            k_update<true><<<grid, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, dub,
+                                                             p->d_status, p->d_ticket, par, p->epoch);
+        else
+            k_update<false><<<grid, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, dub,
+                                                              p->d_status, p->d_ticket, par, p->epoch);
+        if (ctx->timing) { hipEventRecord(tu.b, ctx->stream); ctx->t_update.push_back(tu); }
+        HIP_TRY(hipGetLastError());
+        p->parity ^= 1u;
+        p->epoch += 1u;
+        if (p->epoch >= (1u << 30)) {  // epoch tag wrap: clear the look-back words
+            HIP_TRY(hipMemsetAsync(p->d_status, 0, (size_t)p->table_cap * p->dev.chunks_per_inst * 8, ctx->stream));
+            p->epoch = 1;
+        }
+    }
+    return HNB_OK;
+}
+
+int hnb_effect_metadata(HnbEffect* fx, HnbEffectMetadata* out) {
+    if (!fx || !out) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    DevMeta m;
+    uint32_t fault = 0;
+    int rc = read_meta(fx, &m, &fault);
+    if (rc != HNB_OK) return rc;
+    const uint32_t cap = fx->prog->dev.capacity;
+    out->capacity = cap;
+    out->alive_count = m.alive_count;
+    out->max_update = m.max_update;
+    out->max_spawn = cap - m.alive_count;
+    out->indirect_write_index = m.write_index ^ 1u;
+    out->particle_counter = m.particle_counter;
+    out->instance_count = m.instance_count;
+    out->dispatch_x = (m.alive_count + 63u) >> 6;
+    out->dead_count = m.dead_count;
+    out->spawned = m.spawned;
+    out->fault = m.fault | fault;
+    out->reserved = 0;
+    if (out->fault) return fail(HNB_ERR_DEVICE_FAULT, "device-side look-back watchdog fired");
+    return HNB_OK;
+}
+
+int hnb_effect_alive_count(HnbEffect* fx, uint32_t* out) {
+    if (!fx || !out) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    DevMeta m;
+    int rc = read_meta(fx, &m, nullptr);
+    if (rc != HNB_OK) return rc;
+    *out = m.alive_count;
+    return HNB_OK;
+}
+
+int hnb_effect_read_attr(HnbEffect* fx, uint32_t attr, void* dst, size_t dst_size) {
+    if (!fx || !dst) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    HnbProgram* p = fx->prog;
+    const int ai = find_attr(p, attr);
+    if (ai < 0) return fail(HNB_ERR_NOT_FOUND, "attribute %u is not part of the particle layout", attr);
+    const size_t bytes = (size_t)p->dev.capacity * p->attrs[ai].ncomp * 4;
+    if (dst_size < bytes) return fail(HNB_ERR_INVALID_ARG, "destination too small (%zu < %zu)", dst_size, bytes);
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    HIP_TRY(hipMemcpy(dst, static_cast<char*>(fx->slab) + p->dev.attrs[ai].plane_off, bytes, hipMemcpyDeviceToHost));
+    return HNB_OK;
+}
+
+int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t src_size) {
+    if (!fx || !src) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    HnbProgram* p = fx->prog;
+    const int ai = find_attr(p, attr);
+    if (ai < 0) return fail(HNB_ERR_NOT_FOUND, "attribute %u is not part of the particle layout", attr);
+    const size_t bytes = (size_t)p->dev.capacity * p->attrs[ai].ncomp * 4;
+    if (src_size != bytes) return fail(HNB_ERR_INVALID_ARG, "source size %zu != plane size %zu", src_size, bytes);
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    HIP_TRY(hipMemcpy(static_cast<char*>(fx->slab) + p->dev.attrs[ai].plane_off, src, bytes, hipMemcpyHostToDevice));
+    return HNB_OK;
+}
+
+int hnb_effect_read_alive_list(HnbEffect* fx, uint32_t* dst, size_t dst_count) {
+    if (!fx || !dst) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    HnbProgram* p = fx->prog;
+    DevMeta m;
+    int rc = read_meta(fx, &m, nullptr);
+    if (rc != HNB_OK) return rc;
+    if (dst_count < m.alive_count) return fail(HNB_ERR_INVALID_ARG, "destination too small");
+    // the column the last update wrote is the one the next init appends to: meta.write_index
+    HIP_TRY(hipMemcpy(dst, static_cast<char*>(fx->slab) + p->dev.alive_off[m.write_index], (size_t)m.alive_count * 4,
+                      hipMemcpyDeviceToHost));
+    return HNB_OK;
+}
+
+int hnb_effect_read_dead_list(HnbEffect* fx, uint32_t* dst, size_t dst_count) {
+    if (!fx || !dst) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    HnbProgram* p = fx->prog;
+    DevMeta m;
+    int rc = read_meta(fx, &m, nullptr);
+    if (rc != HNB_OK) return rc;
+    const uint32_t nd = p->dev.capacity - m.alive_count;
+    if (dst_count < nd) return fail(HNB_ERR_INVALID_ARG, "destination too small");
+    // rows [alive_count, capacity) hold the free slots; row alive_count is the top of the stack
+    HIP_TRY(hipMemcpy(dst, static_cast<char*>(fx->slab) + p->dev.dead_off + (size_t)m.alive_count * 4, (size_t)nd * 4,
+                      hipMemcpyDeviceToHost));
+    return HNB_OK;
+}
+
+int hnb_effect_sort_ribbons(HnbEffect*) {
+    return fail(HNB_ERR_INVALID_ARG, "ribbon sort is not implemented yet (SURVEY.md §8f-2)");
+}
+
+int hnb_ctx_enable_kernel_timing(HnbContext* ctx, int enable) {
+    if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto& t : ctx->t_update) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    for (auto& t : ctx->t_init) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    ctx->t_update.clear();
+    ctx->t_init.clear();
+    ctx->timing = enable != 0;
+    return HNB_OK;
+}
+
+int hnb_ctx_kernel_timing(HnbContext* ctx, double* update_ms_avg, double* init_ms_avg, uint32_t* frames) {
+    if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    double su = 0, si = 0;
+    for (auto& t : ctx->t_update) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); su += ms; }
+    for (auto& t : ctx->t_init) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); si += ms; }
+    if (update_ms_avg) *update_ms_avg = ctx->t_update.empty() ? 0.0 : su / ctx->t_update.size();
+    if (init_ms_avg) *init_ms_avg = ctx->t_init.empty() ? 0.0 : si / ctx->t_init.size();
+    if (frames) *frames = (uint32_t)ctx->t_update.size();
+    return HNB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Device-side data contracts shared by the kernels and the runtime.
+// Counterparts of the reference's GPU structs:
+//   GpuSpawnerParams   src/render/mod.rs:381-449   -> DevFrameInst (+ parameter block), re-uploaded per frame
+//   GpuEffectMetadata  src/render/mod.rs:566-622   -> DevMeta (double-buffered, device-resident)
+//   GpuIndirectIndex   src/render/mod.rs:139-146   -> three separate u32 arrays (ping, pong, dead)
+//   Particle AoS       src/attributes.rs:1516-1670 -> one packed plane per attribute (SoA)
+#pragma once
+#include <stdint.h>
+#include "hnb_vm.h"
+
+namespace hnb {
+
+constexpr uint32_t kMaxAttrs = 40;
+constexpr uint32_t kBlock = 256;      // threads per workgroup (4 waves)
+constexpr uint32_t kChunk = 4096;     // particles per workgroup = unit of the cross-chunk scan
+constexpr uint32_t kInitBlock = 256;  // init: one particle per thread
+
+struct DevAttr {
+    uint32_t plane_off;   // byte offset of the attribute plane from the instance slab base
+    uint8_t ncomp;        // 32-bit components per particle (packed, vec3 = 12 B)
+    uint8_t reg;          // first V register
+    uint8_t upd_flags;    // HNB_ATTR_UPD_*
+    uint8_t pad;
+};
+
+struct DevProgram {
+    uint32_t capacity;
+    uint32_t n_attrs;          // stored attributes (all written by init)
+    uint32_t n_uregs;          // parameter-block words per instance
+    uint32_t chunks_per_inst;  // ceil(capacity / kChunk)
+    uint32_t alive_off[2];     // byte offsets of the ping/pong alive lists
+    uint32_t dead_off;         // byte offset of the dead list
+    uint32_t init_len, update_len;
+    uint32_t n_inst;
+    DevAttr attrs[kMaxAttrs];
+    const Ins* init_code;
+    const Ins* update_code;
+};
+
+// Per instance, per frame (uploaded with one memcpy per program per frame).
+struct DevFrameInst {
+    uint32_t spawn_count;       // GpuSpawnerParams::spawn
+    uint32_t seed;              // GpuSpawnerParams::seed
+    uint32_t slot_base;         // particle index offset for PRNG / ID (capacity-slab sharding)
+    uint32_t init_block_start;  // first init workgroup of this instance (CPU prefix sum, batch.rs:348-386)
+    float xf[12];               // row-major 3x4 transform
+};
+static_assert(sizeof(DevFrameInst) == 64, "DevFrameInst layout");
+
+// Device-resident per-instance counters; frame f reads [f&1] and writes [(f+1)&1].
+struct DevMeta {
+    uint32_t alive_count;
+    uint32_t particle_counter;
+    uint32_t write_index;     // alive-list column the init pass appends to / the update pass READS
+    uint32_t max_update;
+    uint32_t dead_count;
+    uint32_t spawned;
+    uint32_t fault;
+    uint32_t instance_count;
+};
+static_assert(sizeof(DevMeta) == 32, "DevMeta layout");
+
+// Decoupled look-back status word: [63:34] epoch, [33:32] state, [31:0] value.
+constexpr uint64_t kStateAggregate = 1, kStatePrefix = 2;
+
+}  // namespace hnb

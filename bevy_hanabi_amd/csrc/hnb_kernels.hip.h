@@ -1,0 +1,419 @@
+// HIP kernels of the particle hot path for gfx950 (MI355X, CDNA4).
+//
+//   k_init    replaces vfx_init.wgsl:101-196      (spawn: pop dead slot, run INIT program, append to alive list)
+//   k_update  replaces vfx_indirect.wgsl:30-90 + vfx_prefix_sum.wgsl:13-43 + vfx_update.wgsl:105-167
+//             (age/reap/modifiers/Euler, kill, and alive/dead list rebuild)
+//
+// Design notes (MI355X-first):
+//  * SoA: one packed plane per attribute. In the streaming kernel a lane owns 4 consecutive
+//    alive-list entries, so on the dense path every access is a 16-byte dwordx4.
+//  * Uniform sub-expressions never reach the GPU as code: the host evaluates them into a
+//    per-instance parameter block that the kernels read with scalar loads.
+//  * The reference rebuilds the alive list with 1-3 global atomics per particle
+//    (vfx_update.wgsl:148-166). Here each 4096-particle chunk compacts survivors and
+//    casualties in LDS (wave prefix scan via cross-lane shuffles + 4-wave LDS combine), then a
+//    single-pass decoupled look-back across chunks gives the global offsets; the lists
+//    are written coalesced and in serial (stable) order. No per-particle atomics.
+//  * HIP has no indirect dispatch: chunks are handed out by a ticket counter (forward
+//    progress under any dispatch order) and sized from device-resident counters, so no
+//    readback and no vfx_indirect / vfx_prefix_sum launches are needed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hnb_dev.h"
+
+namespace hnb {
+
+struct u2_t { uint32_t x, y; };
+struct u3_t { uint32_t x, y, z; };
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+
+// ---- reset: dead_index[i] = i (effect_cache.rs:298-323) ------------------------------------
+__global__ void k_reset_lists(uint32_t* __restrict__ dead, uint32_t* __restrict__ alive0, uint32_t* __restrict__ alive1,
+                              uint32_t capacity) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < capacity) { dead[i] = i; alive0[i] = 0u; alive1[i] = 0u; }
+}
+
+// ---- V-file attribute access (generic kernels, one particle per lane) -----------------------
+__device__ __forceinline__ void vfile_store_attr(const vreg_file_t& r, uint32_t ncomp, uint32_t reg, char* plane, uint32_t slot) {
+    switch (ncomp) {
+        case 1: reinterpret_cast<uint32_t*>(plane)[slot] = r[reg]; break;
+        case 2: reinterpret_cast<u2_t*>(plane)[slot] = u2_t{r[reg], r[reg + 1]}; break;
+        case 3: reinterpret_cast<u3_t*>(plane)[slot] = u3_t{r[reg], r[reg + 1], r[reg + 2]}; break;
+        default: reinterpret_cast<uint4*>(plane)[slot] = make_uint4(r[reg], r[reg + 1], r[reg + 2], r[reg + 3]); break;
+    }
+}
+// Returns the loaded components; the caller writes them at ONE indexed store site.
+__device__ __forceinline__ Out4 vfile_load_attr(uint32_t ncomp, const char* plane, uint32_t slot) {
+    Out4 o = Out4{0u, 0u, 0u, 0u};
+    switch (ncomp) {
+        case 1: o.v0 = reinterpret_cast<const uint32_t*>(plane)[slot]; break;
+        case 2: { const u2_t t = reinterpret_cast<const u2_t*>(plane)[slot]; o.v0 = t.x; o.v1 = t.y; } break;
+        case 3: { const u3_t t = reinterpret_cast<const u3_t*>(plane)[slot]; o.v0 = t.x; o.v1 = t.y; o.v2 = t.z; } break;
+        default: { const uint4 t = reinterpret_cast<const uint4*>(plane)[slot]; o.v0 = t.x; o.v1 = t.y; o.v2 = t.z; o.v3 = t.w; } break;
+    }
+    return o;
+}
+
+// ---- init -----------------------------------------------------------------------------------
+// One thread per spawned particle. Thread i of instance k (serial order == thread order):
+//   slot = dead[alive0 + i]; seed = pcg_hash(slot ^ spawner.seed); run INIT; alive[w][alive0+i] = slot.
+// vfx_init.wgsl:141-143 uses atomicAdd(alive_count): under serial execution thread i gets
+// alive0 + i, which is what is computed here without atomics. Counters are advanced by k_update.
+__global__ void __launch_bounds__(kInitBlock)
+k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+       const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks) {
+    // Find the instance owning this workgroup: binary search over the CPU prefix sum of
+    // init workgroups (find_location_from_particle, vfx_init.wgsl:51-72, at workgroup granularity).
+    const uint32_t blk = blockIdx.x;
+    uint32_t lo = 0, hi = prog.n_inst;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (blk >= fi[mid].init_block_start) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t k = lo - 1;
+    const uint32_t i = (blk - fi[k].init_block_start) * kInitBlock + threadIdx.x;
+
+    const uint32_t alive0 = meta_in[k].alive_count;
+    const uint32_t max_spawn = prog.capacity - alive0;
+    const uint32_t spawn = fi[k].spawn_count;
+    const uint32_t n_spawn = spawn < max_spawn ? spawn : max_spawn;
+    if (i >= n_spawn) return;
+
+    char* base = reinterpret_cast<char*>(inst_base[k]);
+    const uint32_t wi = meta_in[k].write_index;
+    const uint32_t* dead = reinterpret_cast<const uint32_t*>(base + prog.dead_off);
+    uint32_t* alive = reinterpret_cast<uint32_t*>(base + prog.alive_off[wi]);
+
+    const uint32_t slot = dead[alive0 + i];
+
+    VmUniforms U;
+    U.u = ublocks + (size_t)k * prog.n_uregs;
+    U.xf = fi[k].xf;
+    VmState<vreg_file_t> S;
+    S.r = vreg_file_t{};  // var particle = Particle();  (vfx_init.wgsl:174)
+    S.pindex = slot + fi[k].slot_base;
+    S.seed = pcg_hash(S.pindex ^ fi[k].seed);
+    S.pcounter = meta_in[k].particle_counter + i;
+    S.alive = true;
+
+    vm_run<true, false>(prog.init_code, prog.init_len, S, U, nullptr, nullptr);
+
+    alive[alive0 + i] = slot;
+    for (uint32_t a = 0; a < prog.n_attrs; ++a)
+        vfile_store_attr(S.r, prog.attrs[a].ncomp, prog.attrs[a].reg, base + prog.attrs[a].plane_off, slot);
+}
+
+// ---- streaming-kernel pinned attribute access (P = 4) -------------------------------------------
+template <int P>
+__device__ __forceinline__ void pin_load3(V3 (&dst)[P], const char* plane, const uint32_t (&slot)[P], const bool (&valid)[P], bool dense) {
+    if constexpr (P == 4) {
+        if (dense) {
+            const u4v* src = reinterpret_cast<const u4v*>(plane) + (size_t)(slot[0] >> 2) * 3;
+            const u4v q0 = __builtin_nontemporal_load(src), q1 = __builtin_nontemporal_load(src + 1), q2 = __builtin_nontemporal_load(src + 2);
+            dst[0] = V3{u2f(q0.x), u2f(q0.y), u2f(q0.z)};
+            dst[1] = V3{u2f(q0.w), u2f(q1.x), u2f(q1.y)};
+            dst[2] = V3{u2f(q1.z), u2f(q1.w), u2f(q2.x)};
+            dst[3] = V3{u2f(q2.y), u2f(q2.z), u2f(q2.w)};
+            return;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        dst[p] = V3{0.0f, 0.0f, 0.0f};
+        if (valid[p]) {
+            const u3_t t = reinterpret_cast<const u3_t*>(plane)[slot[p]];
+            dst[p] = V3{u2f(t.x), u2f(t.y), u2f(t.z)};
+        }
+    }
+}
+template <int P>
+__device__ __forceinline__ void pin_store3(const V3 (&src)[P], char* plane, const uint32_t (&slot)[P], const bool (&valid)[P], bool dense) {
+    if constexpr (P == 4) {
+        if (dense) {
+            u4v* dst = reinterpret_cast<u4v*>(plane) + (size_t)(slot[0] >> 2) * 3;
+            __builtin_nontemporal_store(u4v{f2u(src[0].x), f2u(src[0].y), f2u(src[0].z), f2u(src[1].x)}, dst);
+            __builtin_nontemporal_store(u4v{f2u(src[1].y), f2u(src[1].z), f2u(src[2].x), f2u(src[2].y)}, dst + 1);
+            __builtin_nontemporal_store(u4v{f2u(src[2].z), f2u(src[3].x), f2u(src[3].y), f2u(src[3].z)}, dst + 2);
+            return;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+        if (valid[p]) reinterpret_cast<u3_t*>(plane)[slot[p]] = u3_t{f2u(src[p].x), f2u(src[p].y), f2u(src[p].z)};
+}
+template <int P>
+__device__ __forceinline__ void pin_load1(float (&dst)[P], const char* plane, const uint32_t (&slot)[P], const bool (&valid)[P], bool dense) {
+    if constexpr (P == 4) {
+        if (dense) {
+            const u4v q = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(plane) + (slot[0] >> 2));
+            dst[0] = u2f(q.x); dst[1] = u2f(q.y); dst[2] = u2f(q.z); dst[3] = u2f(q.w);
+            return;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) dst[p] = valid[p] ? reinterpret_cast<const float*>(plane)[slot[p]] : 0.0f;
+}
+template <int P>
+__device__ __forceinline__ void pin_store1(const float (&src)[P], char* plane, const uint32_t (&slot)[P], const bool (&valid)[P], bool dense) {
+    if constexpr (P == 4) {
+        if (dense) {
+            __builtin_nontemporal_store(u4v{f2u(src[0]), f2u(src[1]), f2u(src[2]), f2u(src[3])}, reinterpret_cast<u4v*>(plane) + (slot[0] >> 2));
+            return;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+        if (valid[p]) reinterpret_cast<float*>(plane)[slot[p]] = src[p];
+}
+
+// ---- update + kill + compaction ----------------------------------------------------------------
+__device__ __forceinline__ uint64_t pack_status(uint32_t epoch, uint64_t state, uint32_t value) {
+    return ((uint64_t)epoch << 34) | (state << 32) | value;
+}
+
+// STREAM=true : macro-op update streams with U operands; named registers, 4 particles per lane.
+// STREAM=false: any update stream; V register file, 1 particle per lane (correctness tier).
+template <bool STREAM>
+__global__ void __launch_bounds__(kBlock)
+k_update(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+         DevMeta* __restrict__ meta_out, const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks,
+         uint64_t* status, uint32_t* ticket, uint32_t parity, uint32_t epoch) {
+    constexpr int PPL = STREAM ? 4 : 1;
+    constexpr uint32_t kTile = kBlock * PPL;        // particles per sub-tile
+    constexpr uint32_t kSubTiles = kChunk / kTile;  // sub-tiles per chunk
+    __shared__ uint32_t s_list[kChunk];  // survivors grow from the front, casualties from the back
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_bcast[2];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+
+    // Ticket: chunk ids are handed out in launch-independent order, so every chunk with a
+    // smaller id has already started when this one waits on it (no dispatch-order assumption).
+    if (tid == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(&ticket[parity], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) __hip_atomic_store(&ticket[parity ^ 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_bcast[0] = t;
+    }
+    __syncthreads();
+    const uint32_t chunk = s_bcast[0];
+    const uint32_t k = chunk / prog.chunks_per_inst;
+    const uint32_t j = chunk - k * prog.chunks_per_inst;
+    if (k >= prog.n_inst) return;
+
+    // vfx_indirect.wgsl:57-85 folded in: max_update = alive_count after init.
+    const DevMeta m = meta_in[k];
+    const uint32_t spawn = fi[k].spawn_count;
+    const uint32_t max_spawn = prog.capacity - m.alive_count;
+    const uint32_t n_spawn = spawn < max_spawn ? spawn : max_spawn;
+    const uint32_t n = m.alive_count + n_spawn;  // max_update
+    const uint32_t start = j * kChunk;
+
+    if (n == 0) {
+        if (j == 0 && tid == 0) {
+            DevMeta o = m;
+            o.write_index = m.write_index ^ 1u; o.max_update = 0; o.dead_count = 0; o.spawned = 0; o.instance_count = 0;
+            meta_out[k] = o;
+        }
+        return;
+    }
+    if (start >= n) return;
+
+    char* base = reinterpret_cast<char*>(inst_base[k]);
+    const uint32_t* alive_rd = reinterpret_cast<const uint32_t*>(base + prog.alive_off[m.write_index]);
+    uint32_t* alive_wr = reinterpret_cast<uint32_t*>(base + prog.alive_off[m.write_index ^ 1u]);
+    uint32_t* dead = reinterpret_cast<uint32_t*>(base + prog.dead_off);
+    const uint32_t seed_k = fi[k].seed, slot_base = fi[k].slot_base;
+
+    VmUniforms U;
+    U.u = ublocks + (size_t)k * prog.n_uregs;
+    U.xf = fi[k].xf;
+
+    uint32_t local_alive = 0, local_dead = 0;  // block-uniform running totals of this chunk
+
+    for (uint32_t sub = 0; sub < kSubTiles; ++sub) {
+        const uint32_t sbase = start + sub * kTile;
+        if (sbase >= n) break;
+        const uint32_t li = sbase + tid * PPL;
+
+        uint32_t slot[PPL];
+        bool valid[PPL], alive_f[PPL];
+        bool full = false;
+        if constexpr (PPL == 4) {
+            if (li + 4u <= n) {
+                const uint4 q = *reinterpret_cast<const uint4*>(alive_rd + li);
+                slot[0] = q.x; slot[1] = q.y; slot[2] = q.z; slot[3] = q.w;
+#pragma unroll
+                for (int p = 0; p < PPL; ++p) valid[p] = true;
+                full = true;
+            }
+        }
+        if (!full) {
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                valid[p] = li + p < n;
+                slot[p] = valid[p] ? alive_rd[li + p] : 0u;
+            }
+        }
+
+        if constexpr (STREAM) {
+            const bool quad = valid[3] && ((slot[0] & 3u) == 0u) && slot[1] == slot[0] + 1u && slot[2] == slot[0] + 2u &&
+                              slot[3] == slot[0] + 3u;
+            const bool dense = __all(quad);  // wave-uniform: all 64 lanes own an aligned run of 4 slots
+            Pinned<PPL> X;
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                X.pos[p] = V3{0, 0, 0}; X.vel[p] = V3{0, 0, 0}; X.age[p] = 0.0f; X.lifetime[p] = 0.0f; X.alive[p] = true;
+            }
+            for (uint32_t a = 0; a < prog.n_attrs; ++a) {
+                const DevAttr at = prog.attrs[a];
+                if (!(at.upd_flags & HNB_ATTR_UPD_LOAD)) continue;
+                const char* plane = base + at.plane_off;
+                if (at.reg == HNB_REG_POSITION) pin_load3<PPL>(X.pos, plane, slot, valid, dense);
+                else if (at.reg == HNB_REG_VELOCITY) pin_load3<PPL>(X.vel, plane, slot, valid, dense);
+                else if (at.reg == HNB_REG_AGE) pin_load1<PPL>(X.age, plane, slot, valid, dense);
+                else if (at.reg == HNB_REG_LIFETIME) pin_load1<PPL>(X.lifetime, plane, slot, valid, dense);
+            }
+            fast_run<PPL>(prog.update_code, prog.update_len, X, U);
+            for (uint32_t a = 0; a < prog.n_attrs; ++a) {
+                const DevAttr at = prog.attrs[a];
+                if (!(at.upd_flags & HNB_ATTR_UPD_STORE)) continue;
+                char* plane = base + at.plane_off;
+                if (at.reg == HNB_REG_POSITION) pin_store3<PPL>(X.pos, plane, slot, valid, dense);
+                else if (at.reg == HNB_REG_VELOCITY) pin_store3<PPL>(X.vel, plane, slot, valid, dense);
+                else if (at.reg == HNB_REG_AGE) pin_store1<PPL>(X.age, plane, slot, valid, dense);
+                else if (at.reg == HNB_REG_LIFETIME) pin_store1<PPL>(X.lifetime, plane, slot, valid, dense);
+            }
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) alive_f[p] = X.alive[p];
+        } else {
+            VmState<vreg_file_t> S;
+            S.r = vreg_file_t{};
+            for (uint32_t a = 0; a < prog.n_attrs; ++a) {
+                const DevAttr at = prog.attrs[a];
+                if (!(at.upd_flags & HNB_ATTR_UPD_LOAD)) continue;
+                Out4 o = Out4{0u, 0u, 0u, 0u};
+                if (valid[0]) o = vfile_load_attr(at.ncomp, base + at.plane_off, slot[0]);
+                for (uint32_t c = 0; c < at.ncomp; ++c) S.r[at.reg + c] = out4_get(o, c);  // single indexed store site
+            }
+            S.pindex = slot[0] + slot_base;
+            S.seed = pcg_hash(S.pindex ^ seed_k);  // vfx_update.wgsl:138
+            S.pcounter = 0u;
+            S.alive = true;
+            vm_run<true, false>(prog.update_code, prog.update_len, S, U, nullptr, nullptr);
+            if (valid[0]) {
+                for (uint32_t a = 0; a < prog.n_attrs; ++a) {
+                    const DevAttr at = prog.attrs[a];
+                    if (at.upd_flags & HNB_ATTR_UPD_STORE) vfile_store_attr(S.r, at.ncomp, at.reg, base + at.plane_off, slot[0]);
+                }
+            }
+            alive_f[0] = S.alive;
+        }
+
+        // ---- chunk-local stable compaction in LDS -------------------------------------------
+        uint32_t na = 0, nd = 0;
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+            na += (valid[p] && alive_f[p]) ? 1u : 0u;
+            nd += (valid[p] && !alive_f[p]) ? 1u : 0u;
+        }
+        const uint32_t x = na | (nd << 16);
+        uint32_t incl = x;
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += y;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kBlock / 64; ++w) {
+            const uint32_t t = s_wave[w];
+            if (w < wave) wbase += t;
+            total += t;
+        }
+        const uint32_t excl = wbase + incl - x;
+        uint32_t ra = local_alive + (excl & 0xffffu);
+        uint32_t rd = local_dead + (excl >> 16);
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+            if (!valid[p]) continue;
+            if (alive_f[p]) s_list[ra++] = slot[p];
+            else s_list[kChunk - 1u - (rd++)] = slot[p];
+        }
+        local_alive += total & 0xffffu;
+        local_dead += total >> 16;
+        __syncthreads();
+    }
+
+    // ---- decoupled look-back over the chunks of this instance ------------------------------
+    uint64_t* st = status + (size_t)k * prog.chunks_per_inst;
+    if (wave == 0) {
+        uint32_t excl_prefix = 0;
+        uint32_t fault = 0;
+        if (j == 0) {
+            if (lane == 0)
+                __hip_atomic_store(&st[0], pack_status(epoch, kStatePrefix, local_alive), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0)
+                __hip_atomic_store(&st[j], pack_status(epoch, kStateAggregate, local_alive), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int hi = (int)j - 1;
+            while (hi >= 0) {
+                const int idx = hi - (int)lane;
+                uint64_t s = pack_status(epoch, kStatePrefix, 0u);  // virtual predecessor before chunk 0
+                uint32_t spins = 0;
+                for (;;) {
+                    if (idx >= 0) s = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ready = (uint32_t)(s >> 34) == epoch;
+                    if (__all(ready)) break;
+                    if (++spins > (1u << 22)) { fault = 1u; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (fault) break;
+                const bool is_prefix = ((s >> 32) & 3u) == kStatePrefix;
+                const uint64_t pmask = __ballot(is_prefix);
+                const uint32_t first = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
+                uint32_t v = (lane <= first) ? (uint32_t)s : 0u;
+#pragma unroll
+                for (uint32_t off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                excl_prefix += v;
+                if (pmask) break;
+                hi -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&st[j], pack_status(epoch, kStatePrefix, excl_prefix + local_alive), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_bcast[0] = excl_prefix; s_bcast[1] = fault;
+            if (fault) atomicOr(&ticket[2], 1u);  // watchdog word, reported by hnb_effect_metadata
+        }
+    }
+    __syncthreads();
+    const uint32_t excl_prefix = s_bcast[0];
+
+    // Survivors: stable order (vfx_update.wgsl:161-165 under serial execution).
+    for (uint32_t i = tid; i < local_alive; i += kBlock) alive_wr[excl_prefix + i] = s_list[i];
+    // Casualties: the d-th dead particle in serial order lands on dead row n-1-d
+    // (vfx_update.wgsl:150-151: atomicSub(alive_count)-1).
+    const uint32_t dead_before = start - excl_prefix;
+    for (uint32_t i = tid; i < local_dead; i += kBlock) dead[n - 1u - (dead_before + i)] = s_list[kChunk - 1u - i];
+
+    if (tid == 0 && start + kChunk >= n) {
+        const uint32_t survivors = excl_prefix + local_alive;
+        DevMeta o;
+        o.alive_count = survivors;
+        o.particle_counter = m.particle_counter + n_spawn;
+        o.write_index = m.write_index ^ 1u;
+        o.max_update = n;
+        o.dead_count = n - survivors;
+        o.spawned = n_spawn;
+        o.fault = m.fault | s_bcast[1];
+        o.instance_count = survivors;
+        meta_out[k] = o;
+    }
+}
+
+}  // namespace hnb

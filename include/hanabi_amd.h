@@ -1,0 +1,307 @@
+/* hanabi_amd.h — C ABI of the MI355X-native particle simulation hot path.
+ *
+ * This is the drop-in boundary for bevy_hanabi's GPU simulation path. The reference has
+ * no FFI for this path; the seam it sits behind is:
+ *   (1) `EffectShaderSources::generate()`            src/lib.rs:805        -> hnb_program_create()
+ *   (2) effect slab + metadata allocation            src/render/effect_cache.rs:232-356,
+ *                                                    src/render/mod.rs:6048-6070 -> hnb_effect_create()
+ *   (3) per-frame GpuSimParams / GpuSpawnerParams    src/render/mod.rs:218-243,381-449 -> hnb_frame_begin(),
+ *                                                                                          hnb_effect_set_frame()
+ *   (4) the `simulate` render-graph system           src/render/mod.rs:6942-7613 -> hnb_simulate()
+ * A host crate (Rust in the reference; C++17 `hanabi::` in this repo) lowers an EffectAsset's
+ * modifier/expression graph to an HnbProgram blob (bytecode + attribute table) and drives
+ * these entry points. Plain pointers and sizes only; no C++/torch types.
+ *
+ * All functions return HNB_OK (0) or a negative HnbStatus; hnb_last_error() gives text.
+ * Thread model: one context per GPU, externally synchronised; hnb_simulate() is
+ * asynchronous on the context's stream, everything that reads back synchronises.
+ */
+#ifndef HANABI_AMD_H
+#define HANABI_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------- */
+/* Status codes                                                                       */
+/* ---------------------------------------------------------------------------------- */
+typedef enum HnbStatus {
+    HNB_OK = 0,
+    HNB_ERR_INVALID_ARG = -1,
+    HNB_ERR_BAD_PROGRAM = -2,   /* malformed / unsupported HnbProgram blob */
+    HNB_ERR_HIP = -3,           /* a HIP runtime call failed */
+    HNB_ERR_NO_DEVICE = -4,     /* no gfx950 device: the product path never falls back to CPU */
+    HNB_ERR_OUT_OF_MEMORY = -5,
+    HNB_ERR_NOT_FOUND = -6,     /* unknown attribute / property */
+    HNB_ERR_DEVICE_FAULT = -7   /* a kernel reported a watchdog / consistency fault */
+} HnbStatus;
+
+/* ---------------------------------------------------------------------------------- */
+/* Attributes (reference: src/attributes.rs:549-675, ALL list at :1338-1378)           */
+/* ---------------------------------------------------------------------------------- */
+typedef enum HnbAttr {
+    HNB_ATTR_ID = 0, HNB_ATTR_PARTICLE_COUNTER = 1,  /* pseudo attributes, never stored */
+    HNB_ATTR_POSITION = 2, HNB_ATTR_VELOCITY = 3, HNB_ATTR_AGE = 4, HNB_ATTR_LIFETIME = 5,
+    HNB_ATTR_COLOR = 6, HNB_ATTR_HDR_COLOR = 7, HNB_ATTR_ALPHA = 8,
+    HNB_ATTR_SIZE = 9, HNB_ATTR_SIZE2 = 10, HNB_ATTR_SIZE3 = 11,
+    HNB_ATTR_PREV = 12, HNB_ATTR_NEXT = 13,
+    HNB_ATTR_AXIS_X = 14, HNB_ATTR_AXIS_Y = 15, HNB_ATTR_AXIS_Z = 16,
+    HNB_ATTR_SPRITE_INDEX = 17,
+    HNB_ATTR_F32_0 = 18, HNB_ATTR_F32_1 = 19, HNB_ATTR_F32_2 = 20, HNB_ATTR_F32_3 = 21,
+    HNB_ATTR_F32X2_0 = 22, HNB_ATTR_F32X2_1 = 23, HNB_ATTR_F32X2_2 = 24, HNB_ATTR_F32X2_3 = 25,
+    HNB_ATTR_F32X3_0 = 26, HNB_ATTR_F32X3_1 = 27, HNB_ATTR_F32X3_2 = 28, HNB_ATTR_F32X3_3 = 29,
+    HNB_ATTR_F32X4_0 = 30, HNB_ATTR_F32X4_1 = 31, HNB_ATTR_F32X4_2 = 32, HNB_ATTR_F32X4_3 = 33,
+    HNB_ATTR_U32_0 = 34, HNB_ATTR_U32_1 = 35, HNB_ATTR_U32_2 = 36, HNB_ATTR_U32_3 = 37,
+    HNB_ATTR_RIBBON_ID = 38,
+    HNB_ATTR_COUNT = 39
+} HnbAttr;
+
+typedef enum HnbScalarType { HNB_BOOL = 0, HNB_F32 = 1, HNB_I32 = 2, HNB_U32 = 3 } HnbScalarType;
+
+/* ---------------------------------------------------------------------------------- */
+/* Lowered effect program                                                             */
+/* What `Modifier::apply()` + `Expr::eval()` emit as WGSL text (src/modifier/mod.rs:154-181,*/
+/* src/graph/expr.rs:1121-1258) is lowered by the host into three instruction streams: */
+/*   uniform : everything that depends only on literals, properties and sim params.   */
+/*             Evaluated ON THE HOST once per instance per frame into a parameter     */
+/*             block of "U registers" that the kernels read with scalar loads.        */
+/*   init    : per-particle spawn program (INIT_CODE of vfx_init.wgsl).               */
+/*   update  : per-particle update program (AGE/REAP/UPDATE_CODE of vfx_update.wgsl). */
+/* ---------------------------------------------------------------------------------- */
+/* Instruction = two little-endian u32 words:
+ *   w0: op[7:0] dst[15:8] a[23:16] b[31:24]
+ *   w1: c[7:0] width-1[9:8] bcast_a[10] bcast_b[11] bcast_c[12] aux[31:16]
+ *   (HNB_OP_LOADK: w1 is the 32-bit immediate; HNB_OP_LDP: w1 = property word offset,
+ *    width-1 in a[1:0]).
+ * Operand bytes: bit 7 set = U register (parameter block, index in bits 6:0), clear = V
+ * register (per-particle, 32 x 32-bit). In the uniform stream every operand is a U
+ * register and bit 7 is not set. A vector operand occupies `width` consecutive
+ * registers; an operand with its bcast bit set is a scalar broadcast.                  */
+#define HNB_VM_MAX_REGS 32u    /* V registers per particle */
+#define HNB_VM_MAX_UREGS 128u  /* U registers per instance */
+#define HNB_OPERAND_U 0x80u
+
+typedef enum HnbOp {
+    HNB_OP_NOP = 0,
+    /* uniform stream only */
+    HNB_OP_LOADK,
+    HNB_OP_LDB,      /* dst = sim_params field a: 0 time,1 delta_time,2 virtual_time,3 virtual_delta_time,4 real_time,5 real_delta_time */
+    HNB_OP_LDP,      /* dst[..w] = properties[w1 ..] */
+    /* varying streams only */
+    HNB_OP_LDID,     /* dst = particle_index (slot + slot_base) — Attribute::ID, expr.rs:1353-1360 */
+    HNB_OP_LDPC,     /* dst = particle_counter — Attribute::PARTICLE_COUNTER, expr.rs:1361-1363 */
+    HNB_OP_LDALIVE,  /* dst = is_alive (bool) — BuiltInOperator::IsAlive */
+    HNB_OP_LDPARENT, /* dst[..w] = parent particle attribute (plane index in aux) */
+    HNB_OP_MOV,
+    /* f32 unary */
+    HNB_OP_FABS, HNB_OP_FCEIL, HNB_OP_FFLOOR, HNB_OP_FROUND, HNB_OP_FFRACT, HNB_OP_FSQRT, HNB_OP_FRSQ,
+    HNB_OP_FSIGN, HNB_OP_FSAT, HNB_OP_FSIN, HNB_OP_FCOS, HNB_OP_FTAN, HNB_OP_FASIN, HNB_OP_FACOS,
+    HNB_OP_FATAN, HNB_OP_FEXP, HNB_OP_FEXP2, HNB_OP_FLOG, HNB_OP_FLOG2,
+    /* f32 binary */
+    HNB_OP_FADD, HNB_OP_FSUB, HNB_OP_FMUL, HNB_OP_FDIV, HNB_OP_FREM, HNB_OP_FMIN, HNB_OP_FMAX,
+    HNB_OP_FSTEP,    /* dst = step(edge=a, x=b) */
+    HNB_OP_FATAN2, HNB_OP_FPOW,
+    /* f32 ternary */
+    HNB_OP_FMIX, HNB_OP_FCLAMP, HNB_OP_FSMOOTH,   /* smoothstep(lo=a, hi=b, x=c) */
+    /* f32 compare -> bool */
+    HNB_OP_FLT, HNB_OP_FLE, HNB_OP_FGT, HNB_OP_FGE,
+    /* i32 */
+    HNB_OP_IADD, HNB_OP_ISUB, HNB_OP_IMUL, HNB_OP_IDIV, HNB_OP_IREM, HNB_OP_IMIN, HNB_OP_IMAX,
+    HNB_OP_IABS, HNB_OP_ISIGN, HNB_OP_ICLAMP, HNB_OP_ILT, HNB_OP_ILE, HNB_OP_IGT, HNB_OP_IGE,
+    /* u32 (add/sub/mul share the i32 opcodes) */
+    HNB_OP_UDIV, HNB_OP_UREM, HNB_OP_UMIN, HNB_OP_UMAX, HNB_OP_UCLAMP,
+    HNB_OP_ULT, HNB_OP_ULE, HNB_OP_UGT, HNB_OP_UGE,
+    /* conversions */
+    HNB_OP_F2I, HNB_OP_F2U, HNB_OP_I2F, HNB_OP_U2F, HNB_OP_B2F, HNB_OP_F2B, HNB_OP_I2B,
+    /* reductions / vector ops (input width = `width`) */
+    HNB_OP_ALL, HNB_OP_ANY,
+    HNB_OP_DOT, HNB_OP_LENGTH, HNB_OP_DISTANCE, HNB_OP_NORMALIZE, HNB_OP_CROSS,
+    HNB_OP_PACK4UNORM, HNB_OP_PACK4SNORM, HNB_OP_UNPACK4UNORM, HNB_OP_UNPACK4SNORM,
+    /* PRNG (reference src/render/vfx_common.wgsl:278-343), varying only */
+    HNB_OP_FRAND,    /* width 1: frand(); 2/3: frand2/3(); 4: frand4() */
+    HNB_OP_RANDU,    /* rand_uniform_{f,vecN}(a, b) */
+    HNB_OP_RANDN,    /* rand_normal_{f,vecN}(mean=a, std_dev=b) */
+    /* alive flag, varying only */
+    HNB_OP_ALIVE_SET, HNB_OP_ALIVE_AND, HNB_OP_KILL_IF,
+    /* Macro ops: closed-form statement/modifier bodies acting on the pinned POSITION /
+     * VELOCITY / AGE / LIFETIME registers. Operands a/b/c name the first register of a
+     * value (U or V space). An update stream made only of the HNB_OP_M_AGE_TICK ..
+     * HNB_OP_M_KILL_AABB ops with U operands runs on the streaming kernel.            */
+    HNB_OP_M_AGE_TICK,       /* age = age + r[a]; if aux&1: is_alive = age < lifetime      (src/lib.rs:1223-1258) */
+    HNB_OP_M_EULER,          /* position += velocity * r[a]                                (src/lib.rs:1106-1120) */
+    HNB_OP_M_VEL_SCALE,      /* velocity *= r[a]                  (LinearDragModifier, modifier/force.rs:284-297) */
+    HNB_OP_M_VEL_ADD,        /* velocity += r[a..a+2]             (AccelModifier, modifier/accel.rs:79-86) */
+    HNB_OP_M_PIN_SET,        /* pinned register dst[..width] = r[a..]        (SetAttributeModifier on a pinned attribute) */
+    HNB_OP_M_RADIAL_ACCEL,   /* velocity += normalize(position - r[a..]) * r[b]            (modifier/accel.rs:162-189) */
+    HNB_OP_M_TANGENT_ACCEL,  /* velocity += normalize(cross(r[b..], normalize(position - r[a..]))) * r[c] (accel.rs:281-307) */
+    HNB_OP_M_CONFORM_SPHERE, /* a: origin[3] radius influence_dist shell_half_thickness max_attraction_speed attraction_accel sticky_factor; b = delta_time (modifier/force.rs:175-238) */
+    HNB_OP_M_KILL_SPHERE,    /* a: center[3], b: sqr_radius, aux&1 = kill_inside           (modifier/kill.rs:76-96) */
+    HNB_OP_M_KILL_AABB,      /* a: center[3], b: half_size[3], aux&1 = kill_inside         (modifier/kill.rs:156-181) */
+    /* generic-kernel-only macro ops */
+    HNB_OP_M_VEL_SPHERE,     /* velocity = normalize(position - (r[a..])) * (r[b])         (modifier/velocity.rs:124-139) */
+    HNB_OP_M_POS_CIRCLE,     /* a: center[3] axis[3] radius[1]; aux&1 = Volume             (modifier/position.rs:52-108) */
+    HNB_OP_M_POS_SPHERE,     /* a: center[3] radius[1];         aux&1 = Volume             (modifier/position.rs:152-210) */
+    HNB_OP_M_POS_CONE3D,     /* a: height[1] top_radius[1] base_radius[1]                  (modifier/position.rs:267-324) */
+    HNB_OP_M_VEL_CIRCLE,     /* a: center[3] axis[3] speed[1]                              (modifier/velocity.rs:45-80) */
+    HNB_OP_M_VEL_TANGENT,    /* a: origin[3] axis[3] speed[1]                              (modifier/velocity.rs:188-223) */
+    HNB_OP_M_ADD_XLATE,      /* position += transform[3].xyz (SimulationSpace::Global, src/lib.rs:518-531) */
+    HNB_OP_M_EMIT_EVENTS,    /* append r[a] spawn events to child channel aux (src/lib.rs:976-993) */
+    HNB_OP_COUNT
+} HnbOp;
+
+/* Pinned V registers (component registers). Other attributes follow from r8. */
+#define HNB_REG_POSITION 0u
+#define HNB_REG_VELOCITY 3u
+#define HNB_REG_AGE 6u
+#define HNB_REG_LIFETIME 7u
+#define HNB_REG_FIRST_FREE 8u
+
+/* Program flags */
+#define HNB_PROG_GLOBAL_SPACE 0x1u      /* informational: init stream ends with M_ADD_XLATE */
+#define HNB_PROG_HAS_RIBBONS 0x2u       /* layout contains RIBBON_ID (post-update sort stage) */
+#define HNB_PROG_CONSUMES_EVENTS 0x4u   /* init is driven by GPU spawn events, not the CPU spawner */
+#define HNB_PROG_EMITS_EVENTS 0x8u
+
+/* Per-attribute update flags */
+#define HNB_ATTR_UPD_LOAD 0x1u   /* the update program references the attribute: load it */
+#define HNB_ATTR_UPD_STORE 0x2u  /* the update program writes it: store it back */
+
+#define HNB_PROGRAM_MAGIC 0x32424e48u /* "HNB2" */
+#define HNB_PROGRAM_VERSION 2u
+
+typedef struct HnbAttrEntry {
+    uint16_t attr;        /* HnbAttr */
+    uint8_t ncomp;        /* 1..4 components of 4 bytes (vec3 is packed 12 B, no padding) */
+    uint8_t reg;          /* first V register of the attribute */
+    uint8_t scalar_type;  /* HnbScalarType */
+    uint8_t update_flags; /* HNB_ATTR_UPD_* */
+    uint16_t reserved;
+} HnbAttrEntry;
+
+typedef struct HnbPropEntry {
+    char name[48];        /* NUL-terminated property name (Module::add_property) */
+    uint8_t scalar_type;  /* HnbScalarType */
+    uint8_t ncomp;        /* 1..4 */
+    uint16_t word_offset; /* offset into the per-instance property block, in 32-bit words */
+    uint32_t default_bits[4];
+} HnbPropEntry;
+
+/* Flat program blob: header, then attrs[], props[], uniform code, init code, update code. */
+typedef struct HnbProgramHeader {
+    uint32_t magic, version, total_size;
+    uint32_t capacity;          /* EffectAsset::capacity (src/asset.rs:391) */
+    uint32_t flags;             /* HNB_PROG_* */
+    uint32_t n_attrs, n_props, prop_words;
+    uint32_t uniform_len, init_len, update_len;  /* instruction counts */
+    uint32_t n_uregs;                            /* U registers (parameter block words) */
+    uint32_t init_regs, update_regs;             /* highest V register used + 1 */
+    uint32_t attrs_off, props_off, uniform_off, init_off, update_off; /* byte offsets from blob start */
+    uint32_t n_event_channels;  /* number of child event channels this program appends to */
+    uint32_t parent_n_attrs;    /* for HNB_PROG_CONSUMES_EVENTS: parent attribute table follows props */
+    uint32_t parent_attrs_off;
+    uint32_t reserved[2];
+} HnbProgramHeader;
+
+/* ---------------------------------------------------------------------------------- */
+/* Per-frame inputs                                                                   */
+/* ---------------------------------------------------------------------------------- */
+/* Mirrors GpuSimParams (src/render/mod.rs:218-243, vfx_common.wgsl:3-20). */
+typedef struct HnbSimParams {
+    float delta_time, time;
+    float virtual_delta_time, virtual_time;
+    float real_delta_time, real_time;
+} HnbSimParams;
+
+/* Mirrors the readable part of GpuEffectMetadata + DispatchIndirectArgs
+ * (vfx_common.wgsl:186-255, src/render/mod.rs:566-622). */
+typedef struct HnbEffectMetadata {
+    uint32_t capacity;
+    uint32_t alive_count;          /* after the last simulated frame */
+    uint32_t max_update;           /* particles the last update pass processed */
+    uint32_t max_spawn;            /* capacity - alive_count: spawn cap of the next init pass */
+    uint32_t indirect_write_index; /* ping-pong column the NEXT update will write */
+    uint32_t particle_counter;
+    uint32_t instance_count;       /* render instance count == survivors of the last update */
+    uint32_t dispatch_x;           /* ceil(alive_count / 64): indirect args of the next update */
+    uint32_t dead_count;           /* particles killed by the last update */
+    uint32_t spawned;              /* particles spawned by the last init */
+    uint32_t fault;                /* non-zero if a device-side watchdog fired */
+    uint32_t reserved;
+} HnbEffectMetadata;
+
+typedef struct HnbContext HnbContext;
+typedef struct HnbProgram HnbProgram;
+typedef struct HnbEffect HnbEffect;
+
+/* ---------------------------------------------------------------------------------- */
+/* Entry points                                                                       */
+/* ---------------------------------------------------------------------------------- */
+const char* hnb_last_error(void);
+const char* hnb_version(void);
+
+/* One context per GPU. Replaces the render-world resources (EffectCache, EffectsMeta,
+ * src/render/mod.rs:2553-2880). Fails with HNB_ERR_NO_DEVICE when no HIP device exists. */
+int hnb_ctx_create(int device_id, HnbContext** out_ctx);
+int hnb_ctx_destroy(HnbContext* ctx);
+/* Stream used by hnb_simulate (a hipStream_t; NULL selects the context's own stream). */
+int hnb_ctx_set_stream(HnbContext* ctx, void* hip_stream);
+int hnb_ctx_synchronize(HnbContext* ctx);
+
+/* Replaces EffectShaderSources::generate + pipeline specialisation (src/lib.rs:805-1336). */
+int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbProgram** out_prog);
+int hnb_program_destroy(HnbProgram* prog);
+/* Validate a blob without a device (structure, register bounds, opcode range). */
+int hnb_program_validate(const void* blob, size_t blob_size);
+
+/* Replaces slab allocation + initial metadata (effect_cache.rs:298-323, mod.rs:6048-6070):
+ * dead_index[i] = i, alive_count = 0, max_spawn = capacity, indirect_write_index = 0.
+ * `slot_base` offsets the particle index used for PRNG seeding / Attribute::ID so that a
+ * capacity slab of a larger logical effect reproduces the single-GPU result. */
+int hnb_effect_create(HnbProgram* prog, uint32_t slot_base, HnbEffect** out_fx);
+int hnb_effect_destroy(HnbEffect* fx);
+/* Parent -> child link for GPU spawn events (EffectParent, src/render/event.rs). */
+int hnb_effect_set_parent(HnbEffect* child, HnbEffect* parent, uint32_t channel, uint32_t event_capacity);
+
+/* Per-frame inputs (ExtractSchedule data, src/render/mod.rs:2670-2691,4437-4445):
+ * sim clocks for every effect of the context ... */
+int hnb_frame_begin(HnbContext* ctx, const HnbSimParams* params);
+/* ... and per effect: CPU spawn count (EffectSpawner::tick), PRNG seed, row-major 3x4
+ * emitter transform (NULL = identity). */
+int hnb_effect_set_frame(HnbEffect* fx, uint32_t spawn_count, uint32_t seed, const float* transform3x4);
+/* Properties (EffectProperties::set, src/properties.rs:216-395). `n_words` 32-bit words. */
+int hnb_effect_set_property(HnbEffect* fx, const char* name, const void* value, uint32_t n_words);
+
+/* Enqueue one simulation frame for every effect of the context:
+ * init -> (indirect/prefix-sum folded) -> update+kill+compaction. Replaces `simulate`
+ * (src/render/mod.rs:6942-7613). Asynchronous. */
+int hnb_simulate(HnbContext* ctx);
+
+/* Readback (synchronising; reporting / parity only, never on the frame path). */
+int hnb_effect_metadata(HnbEffect* fx, HnbEffectMetadata* out);
+int hnb_effect_alive_count(HnbEffect* fx, uint32_t* out);
+/* Copy one attribute plane, indexed by slot: `dst` receives capacity * ncomp * 4 bytes. */
+int hnb_effect_read_attr(HnbEffect* fx, uint32_t attr, void* dst, size_t dst_size);
+/* Copy the alive list (alive_count slot indices, in list order) and the dead list
+ * (capacity - alive_count free slots, stack order from the top). */
+int hnb_effect_read_alive_list(HnbEffect* fx, uint32_t* dst, size_t dst_count);
+int hnb_effect_read_dead_list(HnbEffect* fx, uint32_t* dst, size_t dst_count);
+/* Overwrite an attribute plane / force counters (tests and state restore). */
+int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t src_size);
+
+/* Ribbon post-update sort by (RIBBON_ID, AGE bits) ascending (src/render/mod.rs:7372-7612,
+ * vfx_sort*.wgsl); rewrites the alive list column the renderer reads. */
+int hnb_effect_sort_ribbons(HnbEffect* fx);
+
+/* Timing helper: average device time in ms of the `update` kernel over the frames
+ * simulated since the last reset (HIP events on the simulation stream). */
+int hnb_ctx_enable_kernel_timing(HnbContext* ctx, int enable);
+int hnb_ctx_kernel_timing(HnbContext* ctx, double* update_ms_avg, double* init_ms_avg, uint32_t* frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HANABI_AMD_H */
