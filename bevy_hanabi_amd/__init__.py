@@ -1,0 +1,17 @@
+"""bevy_hanabi_amd — MI355X-native particle simulation hot path behind bevy_hanabi's effect API.
+
+Layout:
+  csrc/            HIP kernels + C ABI (libhanabi_amd.so), deterministic math, program interpreters
+  csrc/host/       hanabi:: C++ mirror of the reference authoring API + lowering, exposed as `_hanabi_host`
+  runtime.py       ctypes binding of include/hanabi_amd.h
+  effects.py       the reference's example assets restated as SURVEY.md §8(d) configurations
+"""
+from . import build  # noqa: F401
+
+try:
+    from ._hanabi_host import *  # noqa: F401,F403
+    from . import _hanabi_host as host  # noqa: F401
+except ImportError as _e:  # pragma: no cover
+    raise ImportError("bevy_hanabi_amd._hanabi_host is not built: run `python -m bevy_hanabi_amd.build`") from _e
+
+from .runtime import Context, Effect, EffectMetadata, HanabiError, Program, SimParams, validate_program  # noqa: F401,E402

@@ -104,7 +104,7 @@ bool operand_ok(uint32_t operand, uint32_t span, uint32_t nregs, uint32_t n_ureg
     return operand + span <= nregs;
 }
 
-int validate_stream(const uint8_t* code, uint32_t len, uint32_t nregs, const HnbProgramHeader& h, int which) {
+int validate_stream(const uint8_t* blob_base, const uint8_t* code, uint32_t len, uint32_t nregs, const HnbProgramHeader& h, int which) {
     const bool ustream = which == 0;
     const char* sname = which == 0 ? "uniform" : which == 1 ? "init" : "update";
     const uint32_t file_regs = ustream ? h.n_uregs : nregs;
@@ -144,6 +144,15 @@ int validate_stream(const uint8_t* code, uint32_t len, uint32_t nregs, const Hnb
             case HNB_OP_LDID: case HNB_OP_LDPC: case HNB_OP_LDALIVE:
                 if (d >= file_regs) BAD("destination out of range");
                 break;
+            case HNB_OP_LDA: case HNB_OP_STA: {
+                const uint32_t ai = w[1] >> 16;
+                if (ai >= h.n_attrs) BAD("attribute index out of range");
+                HnbAttrEntry ae;
+                memcpy(&ae, blob_base + h.attrs_off + ai * sizeof ae, sizeof ae);
+                if (ae.reg != HNB_REG_NONE || ae.ncomp != wd) BAD("LDA/STA must address a whole non-pinned attribute");
+                if (op == HNB_OP_LDA) { if (d + wd > file_regs) BAD("destination out of range"); }
+                else if (!OK(a, ba ? 1 : wd)) BAD("operand out of range");
+            } break;
             case HNB_OP_ALL: case HNB_OP_ANY: case HNB_OP_LENGTH:
                 if (d >= file_regs || !OK(a, wd)) BAD("operand out of range");
                 break;
@@ -227,6 +236,8 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
     if (h.init_regs > HNB_VM_MAX_REGS || h.update_regs > HNB_VM_MAX_REGS)
         return fail(HNB_ERR_BAD_PROGRAM, "program needs %u V registers, the VM has %u", std::max(h.init_regs, h.update_regs),
                     HNB_VM_MAX_REGS);
+    if (h.init_regs < HNB_REG_FIRST_FREE || h.update_regs < HNB_REG_FIRST_FREE)
+        return fail(HNB_ERR_BAD_PROGRAM, "register counts must cover the pinned registers");
     if (h.n_uregs > HNB_VM_MAX_UREGS) return fail(HNB_ERR_BAD_PROGRAM, "program needs %u U registers, limit %u", h.n_uregs, HNB_VM_MAX_UREGS);
     const uint8_t* p = static_cast<const uint8_t*>(blob);
     bool has_position = false;
@@ -234,7 +245,7 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
         HnbAttrEntry a;
         memcpy(&a, p + h.attrs_off + i * sizeof a, sizeof a);
         if (a.attr >= HNB_ATTR_COUNT || a.attr < HNB_ATTR_POSITION) return fail(HNB_ERR_BAD_PROGRAM, "attribute %u is not storable", a.attr);
-        if (a.ncomp < 1 || a.ncomp > 4 || a.reg + a.ncomp > HNB_VM_MAX_REGS) return fail(HNB_ERR_BAD_PROGRAM, "bad attribute entry %u", i);
+        if (a.ncomp < 1 || a.ncomp > 4) return fail(HNB_ERR_BAD_PROGRAM, "bad attribute entry %u", i);
         if (a.attr == HNB_ATTR_POSITION) has_position = true;
         const bool pinned = a.attr == HNB_ATTR_POSITION || a.attr == HNB_ATTR_VELOCITY || a.attr == HNB_ATTR_AGE ||
                             a.attr == HNB_ATTR_LIFETIME;
@@ -242,8 +253,7 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
                               : a.attr == HNB_ATTR_VELOCITY ? HNB_REG_VELOCITY
                               : a.attr == HNB_ATTR_AGE ? HNB_REG_AGE : HNB_REG_LIFETIME;
         if (pinned && a.reg != want) return fail(HNB_ERR_BAD_PROGRAM, "pinned attribute %u in register %u", a.attr, a.reg);
-        if (!pinned && a.reg < HNB_REG_FIRST_FREE) return fail(HNB_ERR_BAD_PROGRAM, "attribute %u overlaps pinned registers", a.attr);
-        if (a.reg + a.ncomp > std::max<uint32_t>(h.init_regs, 1u)) return fail(HNB_ERR_BAD_PROGRAM, "attribute %u outside init register range", a.attr);
+        if (!pinned && a.reg != HNB_REG_NONE) return fail(HNB_ERR_BAD_PROGRAM, "attribute %u must be a memory operand", a.attr);
     }
     // The POSITION attribute is mandatory (src/lib.rs:838-845).
     if (!has_position) return fail(HNB_ERR_BAD_PROGRAM, "the particle layout is missing the POSITION attribute");
@@ -253,11 +263,11 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
         if (pe.ncomp < 1 || pe.ncomp > 4 || pe.word_offset + pe.ncomp > h.prop_words) return fail(HNB_ERR_BAD_PROGRAM, "bad property entry %u", i);
         if (!memchr(pe.name, 0, sizeof pe.name)) return fail(HNB_ERR_BAD_PROGRAM, "unterminated property name %u", i);
     }
-    int rc = validate_stream(p + h.uniform_off, h.uniform_len, 0, h, 0);
+    int rc = validate_stream(p, p + h.uniform_off, h.uniform_len, 0, h, 0);
     if (rc != HNB_OK) return rc;
-    rc = validate_stream(p + h.init_off, h.init_len, h.init_regs, h, 1);
+    rc = validate_stream(p, p + h.init_off, h.init_len, h.init_regs, h, 1);
     if (rc != HNB_OK) return rc;
-    rc = validate_stream(p + h.update_off, h.update_len, h.update_regs, h, 2);
+    rc = validate_stream(p, p + h.update_off, h.update_len, h.update_regs, h, 2);
     if (rc != HNB_OK) return rc;
     if (out_hdr) *out_hdr = h;
     return HNB_OK;
@@ -453,7 +463,7 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
         if (!ok) p->update_streams = false;
     }
     for (uint32_t i = 0; i < h.n_attrs; ++i)
-        if (p->attrs[i].update_flags && p->attrs[i].reg >= HNB_REG_FIRST_FREE) p->update_streams = false;
+        if (p->attrs[i].update_flags && p->attrs[i].reg == HNB_REG_NONE) p->update_streams = false;
     const size_t code_bytes = ((size_t)h.init_len + h.update_len) * 8;
     hipError_t e = hipMalloc(&p->d_code, std::max<size_t>(code_bytes, 8));
     if (e != hipSuccess) { delete p; return fail(HNB_ERR_OUT_OF_MEMORY, "hipMalloc(code) failed: %s", hipGetErrorString(e)); }
@@ -643,7 +653,7 @@ int hnb_effect_metadata(HnbEffect* fx, HnbEffectMetadata* out) {
     out->alive_count = m.alive_count;
     out->max_update = m.max_update;
     out->max_spawn = cap - m.alive_count;
-    out->indirect_write_index = m.write_index ^ 1u;
+    out->indirect_write_index = m.write_index;  // column the last update wrote (= vfx_indirect.wgsl:80-85 after its flip)
     out->particle_counter = m.particle_counter;
     out->instance_count = m.instance_count;
     out->dispatch_x = (m.alive_count + 63u) >> 6;

@@ -15,13 +15,7 @@ constexpr uint32_t kBlock = 256;      // threads per workgroup (4 waves)
 constexpr uint32_t kChunk = 4096;     // particles per workgroup = unit of the cross-chunk scan
 constexpr uint32_t kInitBlock = 256;  // init: one particle per thread
 
-struct DevAttr {
-    uint32_t plane_off;   // byte offset of the attribute plane from the instance slab base
-    uint8_t ncomp;        // 32-bit components per particle (packed, vec3 = 12 B)
-    uint8_t reg;          // first V register
-    uint8_t upd_flags;    // HNB_ATTR_UPD_*
-    uint8_t pad;
-};
+typedef AttrDesc DevAttr;
 
 struct DevProgram {
     uint32_t capacity;

@@ -97,11 +97,21 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
     S.pcounter = meta_in[k].particle_counter + i;
     S.alive = true;
 
-    vm_run<true, false>(prog.init_code, prog.init_len, S, U, nullptr, nullptr);
+    VmAttrIO io;
+    io.slab = base; io.attrs = prog.attrs; io.slot = slot;
+    // var particle = Particle(): attributes the INIT program never assigns are stored as zero
+    for (uint32_t a = 0; a < prog.n_attrs; ++a) {
+        if (prog.attrs[a].reg != HNB_REG_NONE) continue;
+        uint32_t* p = vm_attr_ptr(io, a);
+        for (uint32_t c = 0; c < prog.attrs[a].ncomp; ++c) p[c] = 0u;
+    }
+
+    vm_run<true, false>(prog.init_code, prog.init_len, S, U, nullptr, nullptr, io);
 
     alive[alive0 + i] = slot;
     for (uint32_t a = 0; a < prog.n_attrs; ++a)
-        vfile_store_attr(S.r, prog.attrs[a].ncomp, prog.attrs[a].reg, base + prog.attrs[a].plane_off, slot);
+        if (prog.attrs[a].reg != HNB_REG_NONE)
+            vfile_store_attr(S.r, prog.attrs[a].ncomp, prog.attrs[a].reg, base + prog.attrs[a].plane_off, slot);
 }
 
 // ---- streaming-kernel pinned attribute access (P = 4) -------------------------------------------
@@ -292,7 +302,7 @@ k_update(const DevProgram prog, const uint64_t* __restrict__ inst_base, const De
             S.r = vreg_file_t{};
             for (uint32_t a = 0; a < prog.n_attrs; ++a) {
                 const DevAttr at = prog.attrs[a];
-                if (!(at.upd_flags & HNB_ATTR_UPD_LOAD)) continue;
+                if (!(at.upd_flags & HNB_ATTR_UPD_LOAD) || at.reg == HNB_REG_NONE) continue;
                 Out4 o = Out4{0u, 0u, 0u, 0u};
                 if (valid[0]) o = vfile_load_attr(at.ncomp, base + at.plane_off, slot[0]);
                 for (uint32_t c = 0; c < at.ncomp; ++c) S.r[at.reg + c] = out4_get(o, c);  // single indexed store site
@@ -301,11 +311,13 @@ k_update(const DevProgram prog, const uint64_t* __restrict__ inst_base, const De
             S.seed = pcg_hash(S.pindex ^ seed_k);  // vfx_update.wgsl:138
             S.pcounter = 0u;
             S.alive = true;
-            vm_run<true, false>(prog.update_code, prog.update_len, S, U, nullptr, nullptr);
+            VmAttrIO io;
+            io.slab = base; io.attrs = prog.attrs; io.slot = slot[0];
+            if (valid[0]) vm_run<true, false>(prog.update_code, prog.update_len, S, U, nullptr, nullptr, io);
             if (valid[0]) {
                 for (uint32_t a = 0; a < prog.n_attrs; ++a) {
                     const DevAttr at = prog.attrs[a];
-                    if (at.upd_flags & HNB_ATTR_UPD_STORE) vfile_store_attr(S.r, at.ncomp, at.reg, base + at.plane_off, slot[0]);
+                    if ((at.upd_flags & HNB_ATTR_UPD_STORE) && at.reg != HNB_REG_NONE) vfile_store_attr(S.r, at.ncomp, at.reg, base + at.plane_off, slot[0]);
                 }
             }
             alive_f[0] = S.alive;

@@ -28,8 +28,8 @@ typedef uint32_t vreg_file_t __attribute__((vector_size(HNB_VM_MAX_REGS * 4)));
 // U register file on the host.
 struct UFile {
     uint32_t v[HNB_VM_MAX_UREGS];
-    HNB_HD uint32_t& operator[](uint32_t i) { return v[i]; }
-    HNB_HD const uint32_t& operator[](uint32_t i) const { return v[i]; }
+    HNB_HD_MEMBER uint32_t& operator[](uint32_t i) { return v[i]; }
+    HNB_HD_MEMBER const uint32_t& operator[](uint32_t i) const { return v[i]; }
 };
 
 // Wave-uniform inputs of one effect instance for one frame (pointers into uniform memory:
@@ -38,6 +38,24 @@ struct VmUniforms {
     const uint32_t* u;   // parameter block: U registers produced by the uniform stream
     const float* xf;     // [12] emitter transform, row-major 3x4 (GpuSpawnerParams::transform)
 };
+
+// Attribute table entry as the kernels see it, and the per-particle window onto the SoA planes
+// used by HNB_OP_LDA / HNB_OP_STA (non-pinned attributes are memory operands).
+struct AttrDesc {
+    uint32_t plane_off;   // byte offset of the attribute plane from the instance slab base
+    uint8_t ncomp;        // 32-bit components per particle (packed, vec3 = 12 B)
+    uint8_t reg;          // first V register (pinned attributes) or HNB_REG_NONE
+    uint8_t upd_flags;    // HNB_ATTR_UPD_*
+    uint8_t pad;
+};
+struct VmAttrIO {
+    char* slab;              // instance slab base
+    const AttrDesc* attrs;   // attribute table (uniform memory)
+    uint32_t slot;           // this particle's slot
+};
+HNB_HD uint32_t* vm_attr_ptr(const VmAttrIO& io, uint32_t idx) {
+    return reinterpret_cast<uint32_t*>(io.slab + io.attrs[idx].plane_off) + (size_t)io.slot * io.attrs[idx].ncomp;
+}
 
 template <class FILE_T>
 struct VmState {
@@ -351,7 +369,7 @@ template <class ST> HNB_HD V3 vm_pin3(const ST& S, uint32_t reg) { return V3{u2f
 
 template <bool HEAVY, bool USTREAM, class ST>
 HNB_HD void vm_run(const Ins* __restrict__ code, uint32_t n_ins, ST& S, const VmUniforms& U, const uint32_t* props,
-                   const float* sim) {
+                   const float* sim, const VmAttrIO& io) {
     for (uint32_t pc = 0; pc < n_ins; ++pc) {
         const Ins ins = code[pc];
         const uint32_t op = ins.x & 0xffu, d = (ins.x >> 8) & 0xffu, a = (ins.x >> 16) & 0xffu, b = ins.x >> 24;
@@ -382,6 +400,22 @@ HNB_HD void vm_run(const Ins* __restrict__ code, uint32_t n_ins, ST& S, const Vm
                         o.v1 = nout > 1 ? props[ins.y + 1] : 0u;
                         o.v2 = nout > 2 ? props[ins.y + 2] : 0u;
                         o.v3 = nout > 3 ? props[ins.y + 3] : 0u;
+                    }
+                    break;
+                case HNB_OP_LDA:
+                    if constexpr (!USTREAM) {
+                        const uint32_t* p = vm_attr_ptr(io, aux);
+                        nout = w;
+                        o.v0 = p[0];
+                        o.v1 = w > 1 ? p[1] : 0u;
+                        o.v2 = w > 2 ? p[2] : 0u;
+                        o.v3 = w > 3 ? p[3] : 0u;
+                    }
+                    break;
+                case HNB_OP_STA:
+                    if constexpr (!USTREAM) {
+                        uint32_t* p = vm_attr_ptr(io, aux);
+                        for (uint32_t k = 0; k < w; ++k) p[k] = vm_rd<false>(S, U, a + k * sa);
                     }
                     break;
                 case HNB_OP_LDID: nout = 1; o.v0 = S.pindex; break;
@@ -603,7 +637,9 @@ static inline void uniform_run(const Ins* code, uint32_t n_ins, const uint32_t* 
     S.seed = 0; S.pindex = 0; S.pcounter = 0; S.alive = true;
     VmUniforms U;
     U.u = nullptr; U.xf = nullptr;
-    vm_run<true, true>(code, n_ins, S, U, props, sim);
+    VmAttrIO io;
+    io.slab = nullptr; io.attrs = nullptr; io.slot = 0;
+    vm_run<true, true>(code, n_ins, S, U, props, sim, io);
     for (uint32_t i = 0; i < n_uregs; ++i) out_u[i] = S.r.v[i];
 }
 

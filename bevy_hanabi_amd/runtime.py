@@ -1,0 +1,227 @@
+"""ctypes binding of the C ABI (include/hanabi_amd.h): the only way Python reaches the GPU path.
+
+There is no CPU fallback here: if libhanabi_amd.so is missing or no HIP device exists the
+calls raise HanabiError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+HNB_OK = 0
+HNB_ERR_NO_DEVICE = -4
+
+ATTR_COMPONENTS = [1, 1, 3, 3, 1, 1, 1, 4, 1, 1, 2, 3, 1, 1, 3, 3, 3, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 1, 1, 1, 1, 1]
+ATTR_IS_FLOAT = [0, 0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0] + [1] * 16 + [0] * 5
+
+# every entry point include/hanabi_amd.h declares
+ABI_SYMBOLS = [
+    "hnb_last_error", "hnb_version", "hnb_ctx_create", "hnb_ctx_destroy", "hnb_ctx_set_stream", "hnb_ctx_synchronize",
+    "hnb_program_create", "hnb_program_destroy", "hnb_program_validate", "hnb_effect_create", "hnb_effect_destroy",
+    "hnb_effect_set_parent", "hnb_frame_begin", "hnb_effect_set_frame", "hnb_effect_set_property", "hnb_simulate",
+    "hnb_effect_metadata", "hnb_effect_alive_count", "hnb_effect_read_attr", "hnb_effect_read_alive_list",
+    "hnb_effect_read_dead_list", "hnb_effect_write_attr", "hnb_effect_sort_ribbons", "hnb_ctx_enable_kernel_timing",
+    "hnb_ctx_kernel_timing",
+]
+
+
+class HanabiError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+
+
+class SimParams(C.Structure):
+    _fields_ = [("delta_time", C.c_float), ("time", C.c_float), ("virtual_delta_time", C.c_float), ("virtual_time", C.c_float),
+                ("real_delta_time", C.c_float), ("real_time", C.c_float)]
+
+
+class EffectMetadata(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("capacity", "alive_count", "max_update", "max_spawn", "indirect_write_index",
+                                          "particle_counter", "instance_count", "dispatch_x", "dead_count", "spawned", "fault",
+                                          "reserved")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+
+_lib = None
+
+
+def load_library():
+    """Load libhanabi_amd.so (in-tree). Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        path = _build.runtime_lib_path()
+        if not os.path.exists(path):
+            raise HanabiError(-1, f"{path} not found: run `python -m bevy_hanabi_amd.build` (needs hipcc)")
+        lib = C.CDLL(path)
+        lib.hnb_last_error.restype = C.c_char_p
+        lib.hnb_version.restype = C.c_char_p
+        lib.hnb_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.hnb_ctx_destroy.argtypes = [C.c_void_p]
+        lib.hnb_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        lib.hnb_ctx_synchronize.argtypes = [C.c_void_p]
+        lib.hnb_program_create.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        lib.hnb_program_destroy.argtypes = [C.c_void_p]
+        lib.hnb_program_validate.argtypes = [C.c_char_p, C.c_size_t]
+        lib.hnb_effect_create.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.hnb_effect_destroy.argtypes = [C.c_void_p]
+        lib.hnb_effect_set_parent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.hnb_frame_begin.argtypes = [C.c_void_p, C.POINTER(SimParams)]
+        lib.hnb_effect_set_frame.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.hnb_effect_set_property.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32]
+        lib.hnb_simulate.argtypes = [C.c_void_p]
+        lib.hnb_effect_metadata.argtypes = [C.c_void_p, C.POINTER(EffectMetadata)]
+        lib.hnb_effect_alive_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        lib.hnb_effect_read_attr.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+        lib.hnb_effect_write_attr.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+        lib.hnb_effect_read_alive_list.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.hnb_effect_read_dead_list.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.hnb_effect_sort_ribbons.argtypes = [C.c_void_p]
+        lib.hnb_ctx_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+        lib.hnb_ctx_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != HNB_OK:
+        raise HanabiError(rc, load_library().hnb_last_error().decode())
+
+
+def validate_program(blob: bytes):
+    """Structural validation of a program blob; works without a GPU."""
+    _check(load_library().hnb_program_validate(blob, len(blob)))
+
+
+class Context:
+    """One simulation context per GPU (`hnb_ctx_*`)."""
+
+    def __init__(self, device_id=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        _check(self._lib.hnb_ctx_create(device_id, C.byref(self._h)))
+        self._programs = []
+
+    def close(self):
+        if self._h:
+            for p in list(self._programs):
+                p._h = None
+                for e in p._effects:
+                    e._h = None
+            self._lib.hnb_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        _check(self._lib.hnb_ctx_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def synchronize(self):
+        _check(self._lib.hnb_ctx_synchronize(self._h))
+
+    def create_program(self, blob: bytes):
+        return Program(self, blob)
+
+    def frame_begin(self, dt, time=0.0, virtual_dt=None, virtual_time=None, real_dt=None, real_time=None):
+        sp = SimParams(dt, time, dt if virtual_dt is None else virtual_dt, time if virtual_time is None else virtual_time,
+                       dt if real_dt is None else real_dt, time if real_time is None else real_time)
+        _check(self._lib.hnb_frame_begin(self._h, C.byref(sp)))
+
+    def simulate(self):
+        _check(self._lib.hnb_simulate(self._h))
+
+    def enable_kernel_timing(self, enable=True):
+        _check(self._lib.hnb_ctx_enable_kernel_timing(self._h, int(enable)))
+
+    def kernel_timing(self):
+        u, i, n = C.c_double(), C.c_double(), C.c_uint32()
+        _check(self._lib.hnb_ctx_kernel_timing(self._h, C.byref(u), C.byref(i), C.byref(n)))
+        return {"update_ms_avg": u.value, "init_ms_avg": i.value, "frames": n.value}
+
+
+class Program:
+    def __init__(self, ctx: Context, blob: bytes):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        self._h = C.c_void_p()
+        _check(self._lib.hnb_program_create(ctx._h, blob, len(blob), C.byref(self._h)))
+        self._effects = []
+        ctx._programs.append(self)
+
+    def create_effect(self, slot_base=0):
+        return Effect(self, slot_base)
+
+    def destroy(self):
+        if self._h:
+            for e in self._effects:
+                e._h = None
+            _check(self._lib.hnb_program_destroy(self._h))
+            self._h = None
+            self._ctx._programs.remove(self)
+
+
+class Effect:
+    def __init__(self, prog: Program, slot_base=0):
+        self._prog = prog
+        self._lib = prog._lib
+        self._h = C.c_void_p()
+        _check(self._lib.hnb_effect_create(prog._h, slot_base, C.byref(self._h)))
+        prog._effects.append(self)
+        self.capacity = self.metadata()["capacity"]
+
+    def destroy(self):
+        if self._h:
+            _check(self._lib.hnb_effect_destroy(self._h))
+            self._h = None
+            self._prog._effects.remove(self)
+
+    def set_frame(self, spawn_count, seed, transform=None):
+        xf = None
+        if transform is not None:
+            xf = np.ascontiguousarray(np.asarray(transform, dtype=np.float32).reshape(12))
+        _check(self._lib.hnb_effect_set_frame(self._h, int(spawn_count), int(seed) & 0xFFFFFFFF, None if xf is None else xf.ctypes.data))
+
+    def set_property(self, name, values):
+        v = np.atleast_1d(np.asarray(values))
+        words = v.astype(np.float32).view(np.uint32) if v.dtype.kind == "f" else v.astype(np.uint32)
+        words = np.ascontiguousarray(words)
+        _check(self._lib.hnb_effect_set_property(self._h, name.encode(), words.ctypes.data, len(words)))
+
+    def metadata(self):
+        m = EffectMetadata()
+        _check(self._lib.hnb_effect_metadata(self._h, C.byref(m)))
+        return m.as_dict()
+
+    def alive_count(self):
+        n = C.c_uint32()
+        _check(self._lib.hnb_effect_alive_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def read_attr(self, attr_id):
+        attr_id = int(attr_id)
+        out = np.zeros((self.capacity, ATTR_COMPONENTS[attr_id]), dtype=np.uint32)
+        _check(self._lib.hnb_effect_read_attr(self._h, attr_id, out.ctypes.data, out.nbytes))
+        return out.view(np.float32) if ATTR_IS_FLOAT[attr_id] else out
+
+    def write_attr(self, attr_id, array):
+        a = np.ascontiguousarray(array)
+        _check(self._lib.hnb_effect_write_attr(self._h, int(attr_id), a.ctypes.data, a.nbytes))
+
+    def alive_list(self):
+        out = np.zeros(max(self.alive_count(), 1), dtype=np.uint32)
+        _check(self._lib.hnb_effect_read_alive_list(self._h, out.ctypes.data, len(out)))
+        return out[: self.alive_count()]
+
+    def dead_list(self):
+        n = self.capacity - self.alive_count()
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        _check(self._lib.hnb_effect_read_dead_list(self._h, out.ctypes.data, len(out)))
+        return out[:n]

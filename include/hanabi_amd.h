@@ -96,6 +96,8 @@ typedef enum HnbOp {
     HNB_OP_LDPC,     /* dst = particle_counter — Attribute::PARTICLE_COUNTER, expr.rs:1361-1363 */
     HNB_OP_LDALIVE,  /* dst = is_alive (bool) — BuiltInOperator::IsAlive */
     HNB_OP_LDPARENT, /* dst[..w] = parent particle attribute (plane index in aux) */
+    HNB_OP_LDA,      /* dst[..w] = particle.<attribute table entry aux> (non-pinned attributes live in memory) */
+    HNB_OP_STA,      /* particle.<attribute table entry aux> = r[a..a+w] */
     HNB_OP_MOV,
     /* f32 unary */
     HNB_OP_FABS, HNB_OP_FCEIL, HNB_OP_FFLOOR, HNB_OP_FROUND, HNB_OP_FFRACT, HNB_OP_FSQRT, HNB_OP_FRSQ,
@@ -153,7 +155,9 @@ typedef enum HnbOp {
     HNB_OP_COUNT
 } HnbOp;
 
-/* Pinned V registers (component registers). Other attributes follow from r8. */
+/* Pinned V registers (component registers). Every other attribute is a memory operand
+ * (HNB_OP_LDA / HNB_OP_STA); registers from r8 up are temporaries. */
+#define HNB_REG_NONE 0xffu
 #define HNB_REG_POSITION 0u
 #define HNB_REG_VELOCITY 3u
 #define HNB_REG_AGE 6u
@@ -176,7 +180,7 @@ typedef enum HnbOp {
 typedef struct HnbAttrEntry {
     uint16_t attr;        /* HnbAttr */
     uint8_t ncomp;        /* 1..4 components of 4 bytes (vec3 is packed 12 B, no padding) */
-    uint8_t reg;          /* first V register of the attribute */
+    uint8_t reg;          /* first V register of a pinned attribute, HNB_REG_NONE otherwise */
     uint8_t scalar_type;  /* HnbScalarType */
     uint8_t update_flags; /* HNB_ATTR_UPD_* */
     uint16_t reserved;
@@ -223,7 +227,7 @@ typedef struct HnbEffectMetadata {
     uint32_t alive_count;          /* after the last simulated frame */
     uint32_t max_update;           /* particles the last update pass processed */
     uint32_t max_spawn;            /* capacity - alive_count: spawn cap of the next init pass */
-    uint32_t indirect_write_index; /* ping-pong column the NEXT update will write */
+    uint32_t indirect_write_index; /* ping-pong column the last update wrote (EffectMetadata::indirect_write_index) */
     uint32_t particle_counter;
     uint32_t instance_count;       /* render instance count == survivors of the last update */
     uint32_t dispatch_x;           /* ceil(alive_count / 64): indirect args of the next update */

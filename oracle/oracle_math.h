@@ -1,32 +1,19 @@
-// hanabi-math: the arithmetic definition of every WGSL builtin the hot path uses.
-//
-// The reference executes `sin/cos/acos/pow/log/normalize/smoothstep/...` as WGSL
-// builtins whose accuracy is implementation-defined (naga -> driver; see SURVEY.md
-// §8(c) "third-party arithmetic"). This header pins ONE definition so that the HIP
-// kernels and the CPU oracle produce bit-identical particles:
-//
-//   * f32 + - * / sqrt, comparisons, floor/ceil/trunc/roundEven: IEEE-754 binary32,
-//     one rounding per source-level operation (everything is built with
-//     -ffp-contract=off and correctly rounded f32 divide/sqrt).
-//   * transcendental functions: evaluated in binary64 with only + - * / and bit
-//     manipulation (no libm, no hardware approximations), then rounded once to
-//     binary32. Error before the final rounding is < 1e-15 relative, i.e. the result
-//     is the correctly rounded f32 value except in astronomically rare near-ties.
-//     Trigonometric arguments with |x| > 2^40 are defined as x = 0 (sin 0, cos 1).
-//
-// Compiles as plain C++ (host) and as HIP device code (HNB_HD).
-#pragma once
+/* TEST INFRASTRUCTURE — CPU oracle arithmetic (plain C).
+ *
+ * The oracle's own copy of the "hanabi-math" arithmetic definition: IEEE binary32 for
+ * + - * / sqrt, and binary64 polynomial kernels (no libm) for the transcendental WGSL
+ * builtins, so that oracle and HIP kernels agree bit for bit. The definition is stated in
+ * DESIGN.md; tests/test_math.py checks it against libm (<= 1 ulp) independently.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use anything under
+ * oracle/; the product never includes this file.
+ */
+#ifndef HANABI_ORACLE_MATH_H
+#define HANABI_ORACLE_MATH_H
+#include <stdbool.h>
 #include <stdint.h>
 
-#if defined(__HIPCC__)
-#define HNB_HD __host__ __device__ __forceinline__
-#define HNB_HD_MEMBER __host__ __device__ __forceinline__
-#else
 #define HNB_HD static inline
-#define HNB_HD_MEMBER inline
-#endif
 
-namespace hnb {
 
 HNB_HD uint32_t f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 HNB_HD float u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
@@ -346,4 +333,4 @@ HNB_HD uint32_t pcg_hash(uint32_t input) {
 }
 HNB_HD float to_float01(uint32_t u) { return u2f((u & 0x007fffffu) | 0x3f800000u) - 1.0f; }
 
-}  // namespace hnb
+#endif

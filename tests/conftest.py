@@ -1,0 +1,48 @@
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Native pieces are built in-tree; on the GPU box the prebuilt .so files travel with the snapshot.
+    from bevy_hanabi_amd import build as hb
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if os.path.exists(hipcc) or shutil.which("hipcc"):
+        hb.build_runtime()
+    hb.build_host()
+    import oracle
+
+    oracle.build()
+    cvm_dir = os.path.join(ROOT, "tests", "cpu_vm")
+    so = os.path.join(cvm_dir, "libcpu_vm.so")
+    src = os.path.join(cvm_dir, "cpu_vm.cpp")
+    deps = [src] + [os.path.join(ROOT, "bevy_hanabi_amd", "csrc", f) for f in ("hnb_vm.h", "hnb_math.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas", src, "-o", so])
+
+
+def _has_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this environment")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

@@ -1,0 +1,176 @@
+"""Shared test plumbing: three executors of the same frame script with one interface.
+
+  OracleRunner  oracle/ (C restatement of the reference's WGSL semantics)     -- the checker
+  CpuVmRunner   tests/cpu_vm (product interpreters compiled for the host)     -- CPU-only lowering check
+  GpuRunner     the product: lowering -> C ABI -> HIP kernels                 -- what ships
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+import bevy_hanabi_amd as bh
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+A = bh.Attribute
+
+IDENTITY = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float32)
+
+
+def translation(x, y, z):
+    t = IDENTITY.copy()
+    t[3], t[7], t[11] = x, y, z
+    return t
+
+
+def frame_seed(f, base=0xC0FFEE):
+    return oracle.pcg_hash(base + f)
+
+
+class Frame:
+    def __init__(self, dt=1.0 / 60.0, spawn=0, seed=0, transform=None, time=0.0, props=None):
+        self.dt, self.spawn, self.seed, self.transform, self.time, self.props = dt, spawn, seed, transform, time, props or {}
+
+
+def stored_attrs(asset):
+    return [a for a in asset.particle_layout() if a.id >= 2]
+
+
+class OracleRunner:
+    name = "oracle"
+
+    def __init__(self, asset, slot_base=0, omp=False):
+        self.asset = asset
+        self.fx = oracle.OracleEffect(bh.serialize_asset(asset), slot_base, omp=omp)
+
+    def step(self, fr: Frame):
+        for k, v in fr.props.items():
+            self.fx.set_property(k, v)
+        self.fx.step(fr.dt, fr.spawn, fr.seed, time=fr.time, transform=fr.transform)
+
+    def state(self):
+        return {"counters": self.fx.counters(), "alive": self.fx.alive_list(), "dead": self.fx.dead_list(),
+                "attrs": {a.name: self.fx.read_attr(a.id).view(np.uint32) for a in stored_attrs(self.asset)}}
+
+
+_cvm = None
+
+
+def _cvm_lib():
+    global _cvm
+    if _cvm is None:
+        lib = C.CDLL(os.path.join(ROOT, "tests", "cpu_vm", "libcpu_vm.so"))
+        lib.cvm_create.restype = C.c_void_p
+        lib.cvm_create.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
+        lib.cvm_destroy.argtypes = [C.c_void_p]
+        lib.cvm_streamable.argtypes = [C.c_void_p]
+        lib.cvm_set_property.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32]
+        lib.cvm_step.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]
+        lib.cvm_counters.argtypes = [C.c_void_p, C.c_void_p]
+        lib.cvm_read_attr.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.cvm_read_alive_list.argtypes = [C.c_void_p, C.c_void_p]
+        lib.cvm_read_dead_list.argtypes = [C.c_void_p, C.c_void_p]
+        _cvm = lib
+    return _cvm
+
+
+class CpuVmRunner:
+    name = "cpu_vm"
+
+    def __init__(self, asset, slot_base=0, force_generic=False):
+        self.asset = asset
+        self.blob = bh.lower(asset)
+        bh.validate_program(self.blob)
+        self.lib = _cvm_lib()
+        self.h = self.lib.cvm_create(self.blob, len(self.blob), slot_base)
+        assert self.h, "cpu_vm rejected the program blob"
+        self.force_generic = force_generic
+        self.capacity = asset.capacity
+
+    @property
+    def streamable(self):
+        return bool(self.lib.cvm_streamable(self.h))
+
+    def step(self, fr: Frame):
+        for k, v in fr.props.items():
+            w = np.atleast_1d(np.asarray(v))
+            w = w.astype(np.float32).view(np.uint32) if w.dtype.kind == "f" else w.astype(np.uint32)
+            w = np.ascontiguousarray(w)
+            assert self.lib.cvm_set_property(self.h, k.encode(), w.ctypes.data, len(w)) == 0
+        sim = np.array([fr.time, fr.dt, fr.time, fr.dt, fr.time, fr.dt], dtype=np.float32)
+        xf = None if fr.transform is None else np.ascontiguousarray(np.asarray(fr.transform, dtype=np.float32))
+        self.lib.cvm_step(self.h, sim.ctypes.data, fr.spawn, fr.seed & 0xFFFFFFFF, None if xf is None else xf.ctypes.data, int(self.force_generic))
+
+    def state(self):
+        c = np.zeros(8, dtype=np.uint32)
+        self.lib.cvm_counters(self.h, c.ctypes.data)
+        keys = ["capacity", "alive_count", "max_update", "max_spawn", "indirect_write_index", "particle_counter", "instance_count", "dead_count"]
+        counters = dict(zip(keys, (int(x) for x in c)))
+        alive = np.zeros(counters["alive_count"], dtype=np.uint32)
+        dead = np.zeros(self.capacity - counters["alive_count"], dtype=np.uint32)
+        if len(alive):
+            self.lib.cvm_read_alive_list(self.h, alive.ctypes.data)
+        if len(dead):
+            self.lib.cvm_read_dead_list(self.h, dead.ctypes.data)
+        attrs = {}
+        for a in stored_attrs(self.asset):
+            buf = np.zeros((self.capacity, a.value_type.count), dtype=np.uint32)
+            assert self.lib.cvm_read_attr(self.h, a.id, buf.ctypes.data) == a.value_type.count
+            attrs[a.name] = buf
+        return {"counters": counters, "alive": alive, "dead": dead, "attrs": attrs}
+
+    def __del__(self):
+        try:
+            self.lib.cvm_destroy(self.h)
+        except Exception:
+            pass
+
+
+class GpuRunner:
+    name = "gpu"
+
+    def __init__(self, asset, slot_base=0, ctx=None):
+        self.asset = asset
+        self.blob = bh.lower(asset)
+        self.ctx = ctx or bh.Context(0)
+        self.prog = self.ctx.create_program(self.blob)
+        self.fx = self.prog.create_effect(slot_base)
+
+    def step(self, fr: Frame):
+        for k, v in fr.props.items():
+            self.fx.set_property(k, v)
+        self.ctx.frame_begin(fr.dt, fr.time)
+        self.fx.set_frame(fr.spawn, fr.seed, fr.transform)
+        self.ctx.simulate()
+
+    def state(self):
+        m = self.fx.metadata()
+        keys = ["capacity", "alive_count", "max_update", "max_spawn", "indirect_write_index", "particle_counter", "instance_count", "dead_count"]
+        return {"counters": {k: m[k] for k in keys}, "alive": self.fx.alive_list(), "dead": self.fx.dead_list(),
+                "attrs": {a.name: self.fx.read_attr(a.id).view(np.uint32) for a in stored_attrs(self.asset)}}
+
+
+def assert_same_state(ref, got, what=""):
+    """Bit-exact comparison of counters, alive/dead lists and every attribute plane."""
+    assert ref["counters"] == got["counters"], f"{what}: counters differ\n ref {ref['counters']}\n got {got['counters']}"
+    np.testing.assert_array_equal(ref["alive"], got["alive"], err_msg=f"{what}: alive list differs")
+    np.testing.assert_array_equal(ref["dead"], got["dead"], err_msg=f"{what}: dead list differs")
+    assert ref["attrs"].keys() == got["attrs"].keys()
+    for k in ref["attrs"]:
+        a, b = ref["attrs"][k], got["attrs"][k]
+        if not np.array_equal(a, b):
+            bad = np.argwhere(a != b)
+            i = bad[0][0]
+            raise AssertionError(f"{what}: attribute '{k}' differs at {len(bad)} components; first slot {i}: "
+                                 f"ref {a[i].view(np.float32)} ({a[i]}) got {b[i].view(np.float32)} ({b[i]})")
+
+
+def run_script(runner, frames, check_against=None, every=1):
+    for i, fr in enumerate(frames):
+        runner.step(fr)
+        if check_against is not None:
+            check_against.step(fr)
+            if (i + 1) % every == 0 or i == len(frames) - 1:
+                assert_same_state(check_against.state(), runner.state(), f"frame {i}")
+    return runner.state()
