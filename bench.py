@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particle-updates/sec of the firework effect (BASELINE.json configs[1]).
+
+A "step" is one simulated frame (one pass of the hot path) over a resident 16,777,216-particle
+effect: frame inputs upload + k_update (age, LinearDrag, Accel, Euler, kill test, alive/dead list
+rebuild). The burst spawn frame (k_init) runs during warm-up; all particles stay alive during the
+timed frames (minimum lifetime 0.8 s > (warmup + steps)/60 s for the default step counts).
+
+N > 1: one process per GPU (torch.distributed / RCCL). The effect is sharded by capacity slab:
+rank g simulates slots [g*C, (g+1)*C) of a logical N*C-particle effect (global slot index feeds the
+PRNG, so the union equals a single-GPU run); there is no data-path collective, only an all-reduce of
+the alive counters for reporting. Weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import bevy_hanabi_amd as bh  # noqa: E402
+from bevy_hanabi_amd import effects  # noqa: E402
+
+CAPACITY = 1 << 24
+BYTES_PER_UPDATE = 68  # reads pos12+vel12+age4+lifetime4, writes pos12+vel12+age4, + 8 B alive-list entry
+HBM_PEAK_GBS = 8000.0  # MI355X spec (guides/MI355X_MICROARCH.md)
+DT = 1.0 / 60.0
+
+
+def frame_seed(f):
+    # harness-defined per-frame seed list: pcg_hash(0xC0FFEE + f)
+    x = (0xC0FFEE + f) & 0xFFFFFFFF
+    state = (x * 747796405 + 2891336453) & 0xFFFFFFFF
+    word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & 0xFFFFFFFF
+    return ((word >> 22) ^ word) & 0xFFFFFFFF
+
+
+def cpu_baseline(sample_capacity=1 << 20, frames=8):
+    """The oracle (a restatement of the reference's WGSL semantics; the reference has no CPU
+    simulation path) timed with OpenMP on the host cores, on a bounded sample of the same workload."""
+    import oracle
+
+    oracle.build()
+    asset = effects.firework_trails(sample_capacity)
+    fx = oracle.OracleEffect(bh.serialize_asset(asset), omp=True)
+    fx.step(DT, sample_capacity, frame_seed(0))  # spawn frame (not timed)
+    t0 = time.perf_counter()
+    for f in range(1, frames + 1):
+        fx.step(DT, 0, frame_seed(f), time=f * DT)
+    t = time.perf_counter() - t0
+    assert fx.alive_count() == sample_capacity
+    return {"value": sample_capacity * frames / t, "unit": "particle-updates/s", "cores": oracle.omp_threads(), "kind": "port",
+            "sample": f"{sample_capacity} particles x {frames} frames of the same firework effect ({t:.1f} s wall, OpenMP oracle)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--capacity", type=int, default=CAPACITY)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    n_gpus = world if distributed else 1
+    if args.gpus != n_gpus and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1", file=sys.stderr)
+
+    cap = args.capacity
+    asset = effects.firework_trails(cap)
+    ctx = bh.Context(local_rank)
+    prog = ctx.create_program(bh.lower(asset))
+    fx = prog.create_effect(slot_base=rank * cap)
+
+    def step(f, spawn=0):
+        ctx.frame_begin(DT, f * DT)
+        fx.set_frame(spawn, frame_seed(f))
+        ctx.simulate()
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+
+    # warm-up: frame 0 is the burst (k_init + k_update), then untimed update frames
+    step(0, cap)
+    for f in range(1, args.warmup + 1):
+        step(f)
+    barrier()
+    ctx.enable_kernel_timing(True)
+    t0 = time.perf_counter()
+    for f in range(args.warmup + 1, args.warmup + 1 + args.steps):
+        step(f)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timing = ctx.kernel_timing()
+    ctx.enable_kernel_timing(False)
+
+    alive = fx.alive_count()
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the only collective of the design: alive-particle counters, for reporting
+        a = torch.tensor([alive], dtype=torch.int64, device="cuda")
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        alive_total = int(a.item())
+    else:
+        alive_total = alive
+    assert alive_total == cap * n_gpus, f"expected every particle alive during the timed frames, got {alive_total}"
+
+    if rank == 0:
+        updates = float(cap) * n_gpus * args.steps
+        value = updates / elapsed
+        k_ms = timing["update_ms_avg"]
+        achieved = cap * BYTES_PER_UPDATE / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "particle-updates/sec", "value": value, "unit": "particle-updates/s", "n_gpus": n_gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "firework.rs trails EffectAsset, capacity=16_777_216 per GPU, burst spawner, all particles alive",
+                       "capacity_per_gpu": cap, "dt": DT, "sharding": f"capacity slab x{n_gpus}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_update<true>", "kernel_ms_avg": k_ms, "bytes_per_update": BYTES_PER_UPDATE,
+                         "hbm_gbs_whole_step": updates / n_gpus * BYTES_PER_UPDATE / elapsed / 1e9},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    ctx.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
