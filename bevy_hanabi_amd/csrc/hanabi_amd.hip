@@ -48,6 +48,48 @@ struct TimingPair { hipEvent_t a, b; };
 
 }  // namespace
 
+// ---- streaming kernel instantiations ------------------------------------------------------------------
+// Statically specialised op sequences for the common modifier stacks (the reference's example
+// effects), plus the interpreter for every other streamable sequence.
+typedef void (*StreamLaunchFn)(uint32_t grid, hipStream_t stream, const StreamArgs& sa, const uint64_t* inst_base, const DevMeta* meta_in,
+                               DevMeta* meta_out, const DevFrameInst* fi, const uint32_t* ublocks, uint64_t* status, uint32_t* ticket,
+                               uint32_t parity, uint32_t epoch);
+template <class PROG, int WAVES>
+void launch_stream(uint32_t grid, hipStream_t stream, const StreamArgs& sa, const uint64_t* inst_base, const DevMeta* meta_in, DevMeta* meta_out,
+                   const DevFrameInst* fi, const uint32_t* ublocks, uint64_t* status, uint32_t* ticket, uint32_t parity, uint32_t epoch) {
+    k_update_stream<PROG, WAVES><<<grid, kBlock, 0, stream>>>(sa, inst_base, meta_in, meta_out, fi, ublocks, status, ticket, parity, epoch);
+}
+#define OP_(x) (uint32_t)HNB_OP_M_##x
+typedef ProgStatic<OP_(AGE_TICK)> ProgAge;                                                        // ribbon.rs
+typedef ProgStatic<OP_(AGE_TICK), OP_(EULER)> ProgAgeEuler;                                       // instancing.rs
+typedef ProgStatic<OP_(AGE_TICK), OP_(VEL_ADD), OP_(EULER)> ProgAccel;                            // AccelModifier stacks
+typedef ProgStatic<OP_(AGE_TICK), OP_(VEL_SCALE), OP_(EULER)> ProgDrag;
+typedef ProgStatic<OP_(AGE_TICK), OP_(VEL_SCALE), OP_(VEL_ADD), OP_(EULER)> ProgDragAccel;        // firework.rs
+typedef ProgStatic<OP_(AGE_TICK), OP_(VEL_ADD), OP_(VEL_SCALE), OP_(EULER)> ProgAccelDrag;
+typedef ProgStatic<OP_(AGE_TICK), OP_(VEL_ADD), OP_(KILL_AABB), OP_(EULER)> ProgAccelKillAabb;    // activate.rs / spawn_on_command.rs
+typedef ProgStatic<OP_(AGE_TICK), OP_(RADIAL_ACCEL), OP_(EULER)> ProgRadial;                      // instancing.rs (2nd asset)
+typedef ProgStatic<OP_(AGE_TICK), OP_(CONFORM_SPHERE), OP_(CONFORM_SPHERE), OP_(KILL_AABB), OP_(KILL_SPHERE), OP_(EULER)> ProgForceField;  // force_field.rs
+#undef OP_
+#ifndef HNB_STREAM_WAVES_INTERP
+#define HNB_STREAM_WAVES_INTERP 5
+#endif
+
+void select_stream_kernel(const Ins* code, uint32_t n, StreamLaunchFn* fn, const char** name) {
+#define TRY_(PROG, WAVES) if (PROG::matches(code, n)) { *fn = &launch_stream<PROG, WAVES>; *name = #PROG; return; }
+    TRY_(ProgAge, HNB_STREAM_WAVES)
+    TRY_(ProgAgeEuler, HNB_STREAM_WAVES)
+    TRY_(ProgAccel, HNB_STREAM_WAVES)
+    TRY_(ProgDrag, HNB_STREAM_WAVES)
+    TRY_(ProgDragAccel, HNB_STREAM_WAVES)
+    TRY_(ProgAccelDrag, HNB_STREAM_WAVES)
+    TRY_(ProgAccelKillAabb, HNB_STREAM_WAVES)
+    TRY_(ProgRadial, HNB_STREAM_WAVES)
+    TRY_(ProgForceField, HNB_STREAM_WAVES_FULL)
+#undef TRY_
+    *fn = &launch_stream<ProgInterp, HNB_STREAM_WAVES_INTERP>;
+    *name = "ProgInterp";
+}
+
 struct HnbContext {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -67,6 +109,8 @@ struct HnbProgram {
     Ins* d_code = nullptr;
     size_t slab_bytes = 0;
     bool update_streams = false;  // update stream runs on the streaming kernel (macro ops, U operands)
+    StreamLaunchFn stream_launch = nullptr;  // specialised (or interpreted) streaming kernel for this update stream
+    const char* stream_kernel_name = "";
     std::vector<Ins> uniform_code;  // evaluated on the host per instance per frame
     std::vector<HnbEffect*> effects;
     // device tables, sized for `table_cap` instances
@@ -464,6 +508,7 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     }
     for (uint32_t i = 0; i < h.n_attrs; ++i)
         if (p->attrs[i].update_flags && p->attrs[i].reg == HNB_REG_NONE) p->update_streams = false;
+    if (p->update_streams) select_stream_kernel(reinterpret_cast<const Ins*>(b + h.update_off), h.update_len, &p->stream_launch, &p->stream_kernel_name);
     const size_t code_bytes = ((size_t)h.init_len + h.update_len) * 8;
     hipError_t e = hipMalloc(&p->d_code, std::max<size_t>(code_bytes, 8));
     if (e != hipSuccess) { delete p; return fail(HNB_ERR_OUT_OF_MEMORY, "hipMalloc(code) failed: %s", hipGetErrorString(e)); }
@@ -624,12 +669,26 @@ int hnb_simulate(HnbContext* ctx) {
         }
         const uint32_t grid = n * p->dev.chunks_per_inst;
         if (ctx->timing) { hipEventCreate(&tu.a); hipEventCreate(&tu.b); hipEventRecord(tu.a, ctx->stream); }
-        if (p->update_streams)
-            k_update<true><<<grid, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, dub,
-                                                             p->d_status, p->d_ticket, par, p->epoch);
+        if (p->update_streams) {
+            StreamArgs sa{};
+            sa.capacity = p->dev.capacity; sa.n_uregs = p->dev.n_uregs; sa.chunks_per_inst = p->dev.chunks_per_inst; sa.n_inst = n;
+            sa.alive_off[0] = p->dev.alive_off[0]; sa.alive_off[1] = p->dev.alive_off[1]; sa.dead_off = p->dev.dead_off;
+            sa.update_len = p->dev.update_len;
+            sa.update_code = p->dev.update_code;
+            for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
+                const DevAttr& at = p->dev.attrs[a];
+                const int pi = at.reg == HNB_REG_POSITION ? 0 : at.reg == HNB_REG_VELOCITY ? 1 : at.reg == HNB_REG_AGE ? 2 : at.reg == HNB_REG_LIFETIME ? 3 : -1;
+                if (pi < 0) continue;
+                sa.plane_off[pi] = at.plane_off;
+                if (at.upd_flags & HNB_ATTR_UPD_LOAD) sa.flags |= 1u << pi;
+                if (at.upd_flags & HNB_ATTR_UPD_STORE) sa.flags |= 16u << pi;
+            }
+            p->stream_launch(grid, ctx->stream, sa, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, dub, p->d_status, p->d_ticket, par,
+                             p->epoch);
+        }
         else
-            k_update<false><<<grid, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, dub,
-                                                              p->d_status, p->d_ticket, par, p->epoch);
+            k_update_generic<<<grid, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, dub,
+                                                               p->d_status, p->d_ticket, par, p->epoch);
         if (ctx->timing) { hipEventRecord(tu.b, ctx->stream); ctx->t_update.push_back(tu); }
         HIP_TRY(hipGetLastError());
         p->parity ^= 1u;

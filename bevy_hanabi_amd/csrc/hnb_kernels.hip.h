@@ -26,6 +26,15 @@ namespace hnb {
 struct u2_t { uint32_t x, y; };
 struct u3_t { uint32_t x, y, z; };
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+// Streaming accesses use the default cache policy: `nontemporal` hints measured 13 % SLOWER on
+// MI355X for this kernel (profiles/r01_variants.md).
+#ifdef HNB_NONTEMPORAL
+#define HNB_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define HNB_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define HNB_NT_LOAD(p) (*(p))
+#define HNB_NT_STORE(v, p) (*(p) = (v))
+#endif
 
 // ---- reset: dead_index[i] = i (effect_cache.rs:298-323) ------------------------------------
 __global__ void k_reset_lists(uint32_t* __restrict__ dead, uint32_t* __restrict__ alive0, uint32_t* __restrict__ alive1,
@@ -120,7 +129,7 @@ __device__ __forceinline__ void pin_load3(V3 (&dst)[P], const char* plane, const
     if constexpr (P == 4) {
         if (dense) {
             const u4v* src = reinterpret_cast<const u4v*>(plane) + (size_t)(slot[0] >> 2) * 3;
-            const u4v q0 = __builtin_nontemporal_load(src), q1 = __builtin_nontemporal_load(src + 1), q2 = __builtin_nontemporal_load(src + 2);
+            const u4v q0 = HNB_NT_LOAD(src), q1 = HNB_NT_LOAD(src + 1), q2 = HNB_NT_LOAD(src + 2);
             dst[0] = V3{u2f(q0.x), u2f(q0.y), u2f(q0.z)};
             dst[1] = V3{u2f(q0.w), u2f(q1.x), u2f(q1.y)};
             dst[2] = V3{u2f(q1.z), u2f(q1.w), u2f(q2.x)};
@@ -142,9 +151,9 @@ __device__ __forceinline__ void pin_store3(const V3 (&src)[P], char* plane, cons
     if constexpr (P == 4) {
         if (dense) {
             u4v* dst = reinterpret_cast<u4v*>(plane) + (size_t)(slot[0] >> 2) * 3;
-            __builtin_nontemporal_store(u4v{f2u(src[0].x), f2u(src[0].y), f2u(src[0].z), f2u(src[1].x)}, dst);
-            __builtin_nontemporal_store(u4v{f2u(src[1].y), f2u(src[1].z), f2u(src[2].x), f2u(src[2].y)}, dst + 1);
-            __builtin_nontemporal_store(u4v{f2u(src[2].z), f2u(src[3].x), f2u(src[3].y), f2u(src[3].z)}, dst + 2);
+            HNB_NT_STORE((u4v{f2u(src[0].x), f2u(src[0].y), f2u(src[0].z), f2u(src[1].x)}), dst);
+            HNB_NT_STORE((u4v{f2u(src[1].y), f2u(src[1].z), f2u(src[2].x), f2u(src[2].y)}), dst + 1);
+            HNB_NT_STORE((u4v{f2u(src[2].z), f2u(src[3].x), f2u(src[3].y), f2u(src[3].z)}), dst + 2);
             return;
         }
     }
@@ -156,7 +165,7 @@ template <int P>
 __device__ __forceinline__ void pin_load1(float (&dst)[P], const char* plane, const uint32_t (&slot)[P], const bool (&valid)[P], bool dense) {
     if constexpr (P == 4) {
         if (dense) {
-            const u4v q = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(plane) + (slot[0] >> 2));
+            const u4v q = HNB_NT_LOAD(reinterpret_cast<const u4v*>(plane) + (slot[0] >> 2));
             dst[0] = u2f(q.x); dst[1] = u2f(q.y); dst[2] = u2f(q.z); dst[3] = u2f(q.w);
             return;
         }
@@ -168,7 +177,7 @@ template <int P>
 __device__ __forceinline__ void pin_store1(const float (&src)[P], char* plane, const uint32_t (&slot)[P], const bool (&valid)[P], bool dense) {
     if constexpr (P == 4) {
         if (dense) {
-            __builtin_nontemporal_store(u4v{f2u(src[0]), f2u(src[1]), f2u(src[2]), f2u(src[3])}, reinterpret_cast<u4v*>(plane) + (slot[0] >> 2));
+            HNB_NT_STORE((u4v{f2u(src[0]), f2u(src[1]), f2u(src[2]), f2u(src[3])}), reinterpret_cast<u4v*>(plane) + (slot[0] >> 2));
             return;
         }
     }
@@ -182,25 +191,26 @@ __device__ __forceinline__ uint64_t pack_status(uint32_t epoch, uint64_t state, 
     return ((uint64_t)epoch << 34) | (state << 32) | value;
 }
 
-// STREAM=true : macro-op update streams with U operands; named registers, 4 particles per lane.
-// STREAM=false: any update stream; V register file, 1 particle per lane (correctness tier).
-template <bool STREAM>
-__global__ void __launch_bounds__(kBlock)
-k_update(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
-         DevMeta* __restrict__ meta_out, const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks,
-         uint64_t* status, uint32_t* ticket, uint32_t parity, uint32_t epoch) {
-    constexpr int PPL = STREAM ? 4 : 1;
-    constexpr uint32_t kTile = kBlock * PPL;        // particles per sub-tile
-    constexpr uint32_t kSubTiles = kChunk / kTile;  // sub-tiles per chunk
-    __shared__ uint32_t s_list[kChunk];  // survivors grow from the front, casualties from the back
-    __shared__ uint32_t s_wave[kBlock / 64];
-    __shared__ uint32_t s_bcast[2];
+// Per-chunk bookkeeping shared by the two update kernels.
+struct ChunkCtx {
+    uint32_t k, j;          // instance, chunk within instance
+    uint32_t n;             // max_update of the instance
+    uint32_t n_spawn;
+    uint32_t start;         // first alive-list row of this chunk
+    DevMeta m;
+    char* base;
+    const uint32_t* alive_rd;
+    uint32_t* alive_wr;
+    uint32_t* dead;
+};
 
+// Ticket + counters. Returns false when this workgroup has nothing to do.
+// Ticket: chunk ids are handed out in launch-independent order, so every chunk with a smaller
+// id has already started when this one waits on it (no dispatch-order assumption).
+__device__ __forceinline__ bool chunk_begin(ChunkCtx& c, const DevProgram& prog, const uint64_t* inst_base, const DevMeta* meta_in,
+                                            DevMeta* meta_out, const DevFrameInst* fi, uint32_t* ticket, uint32_t parity,
+                                            uint32_t* s_bcast) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-
-    // Ticket: chunk ids are handed out in launch-independent order, so every chunk with a
-    // smaller id has already started when this one waits on it (no dispatch-order assumption).
     if (tid == 0) {
         const uint32_t t = __hip_atomic_fetch_add(&ticket[parity], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == 0) __hip_atomic_store(&ticket[parity ^ 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -208,160 +218,40 @@ k_update(const DevProgram prog, const uint64_t* __restrict__ inst_base, const De
     }
     __syncthreads();
     const uint32_t chunk = s_bcast[0];
-    const uint32_t k = chunk / prog.chunks_per_inst;
-    const uint32_t j = chunk - k * prog.chunks_per_inst;
-    if (k >= prog.n_inst) return;
-
+    c.k = chunk / prog.chunks_per_inst;
+    c.j = chunk - c.k * prog.chunks_per_inst;
+    if (c.k >= prog.n_inst) return false;
     // vfx_indirect.wgsl:57-85 folded in: max_update = alive_count after init.
-    const DevMeta m = meta_in[k];
-    const uint32_t spawn = fi[k].spawn_count;
-    const uint32_t max_spawn = prog.capacity - m.alive_count;
-    const uint32_t n_spawn = spawn < max_spawn ? spawn : max_spawn;
-    const uint32_t n = m.alive_count + n_spawn;  // max_update
-    const uint32_t start = j * kChunk;
-
-    if (n == 0) {
-        if (j == 0 && tid == 0) {
-            DevMeta o = m;
-            o.write_index = m.write_index ^ 1u; o.max_update = 0; o.dead_count = 0; o.spawned = 0; o.instance_count = 0;
-            meta_out[k] = o;
+    c.m = meta_in[c.k];
+    const uint32_t spawn = fi[c.k].spawn_count;
+    const uint32_t max_spawn = prog.capacity - c.m.alive_count;
+    c.n_spawn = spawn < max_spawn ? spawn : max_spawn;
+    c.n = c.m.alive_count + c.n_spawn;
+    c.start = c.j * kChunk;
+    if (c.n == 0) {
+        if (c.j == 0 && tid == 0) {
+            DevMeta o = c.m;
+            o.write_index = c.m.write_index ^ 1u; o.max_update = 0; o.dead_count = 0; o.spawned = 0; o.instance_count = 0;
+            meta_out[c.k] = o;
         }
-        return;
+        return false;
     }
-    if (start >= n) return;
+    if (c.start >= c.n) return false;
+    c.base = reinterpret_cast<char*>(inst_base[c.k]);
+    c.alive_rd = reinterpret_cast<const uint32_t*>(c.base + prog.alive_off[c.m.write_index]);
+    c.alive_wr = reinterpret_cast<uint32_t*>(c.base + prog.alive_off[c.m.write_index ^ 1u]);
+    c.dead = reinterpret_cast<uint32_t*>(c.base + prog.dead_off);
+    return true;
+}
 
-    char* base = reinterpret_cast<char*>(inst_base[k]);
-    const uint32_t* alive_rd = reinterpret_cast<const uint32_t*>(base + prog.alive_off[m.write_index]);
-    uint32_t* alive_wr = reinterpret_cast<uint32_t*>(base + prog.alive_off[m.write_index ^ 1u]);
-    uint32_t* dead = reinterpret_cast<uint32_t*>(base + prog.dead_off);
-    const uint32_t seed_k = fi[k].seed, slot_base = fi[k].slot_base;
-
-    VmUniforms U;
-    U.u = ublocks + (size_t)k * prog.n_uregs;
-    U.xf = fi[k].xf;
-
-    uint32_t local_alive = 0, local_dead = 0;  // block-uniform running totals of this chunk
-
-    for (uint32_t sub = 0; sub < kSubTiles; ++sub) {
-        const uint32_t sbase = start + sub * kTile;
-        if (sbase >= n) break;
-        const uint32_t li = sbase + tid * PPL;
-
-        uint32_t slot[PPL];
-        bool valid[PPL], alive_f[PPL];
-        bool full = false;
-        if constexpr (PPL == 4) {
-            if (li + 4u <= n) {
-                const uint4 q = *reinterpret_cast<const uint4*>(alive_rd + li);
-                slot[0] = q.x; slot[1] = q.y; slot[2] = q.z; slot[3] = q.w;
-#pragma unroll
-                for (int p = 0; p < PPL; ++p) valid[p] = true;
-                full = true;
-            }
-        }
-        if (!full) {
-#pragma unroll
-            for (int p = 0; p < PPL; ++p) {
-                valid[p] = li + p < n;
-                slot[p] = valid[p] ? alive_rd[li + p] : 0u;
-            }
-        }
-
-        if constexpr (STREAM) {
-            const bool quad = valid[3] && ((slot[0] & 3u) == 0u) && slot[1] == slot[0] + 1u && slot[2] == slot[0] + 2u &&
-                              slot[3] == slot[0] + 3u;
-            const bool dense = __all(quad);  // wave-uniform: all 64 lanes own an aligned run of 4 slots
-            Pinned<PPL> X;
-#pragma unroll
-            for (int p = 0; p < PPL; ++p) {
-                X.pos[p] = V3{0, 0, 0}; X.vel[p] = V3{0, 0, 0}; X.age[p] = 0.0f; X.lifetime[p] = 0.0f; X.alive[p] = true;
-            }
-            for (uint32_t a = 0; a < prog.n_attrs; ++a) {
-                const DevAttr at = prog.attrs[a];
-                if (!(at.upd_flags & HNB_ATTR_UPD_LOAD)) continue;
-                const char* plane = base + at.plane_off;
-                if (at.reg == HNB_REG_POSITION) pin_load3<PPL>(X.pos, plane, slot, valid, dense);
-                else if (at.reg == HNB_REG_VELOCITY) pin_load3<PPL>(X.vel, plane, slot, valid, dense);
-                else if (at.reg == HNB_REG_AGE) pin_load1<PPL>(X.age, plane, slot, valid, dense);
-                else if (at.reg == HNB_REG_LIFETIME) pin_load1<PPL>(X.lifetime, plane, slot, valid, dense);
-            }
-            fast_run<PPL>(prog.update_code, prog.update_len, X, U);
-            for (uint32_t a = 0; a < prog.n_attrs; ++a) {
-                const DevAttr at = prog.attrs[a];
-                if (!(at.upd_flags & HNB_ATTR_UPD_STORE)) continue;
-                char* plane = base + at.plane_off;
-                if (at.reg == HNB_REG_POSITION) pin_store3<PPL>(X.pos, plane, slot, valid, dense);
-                else if (at.reg == HNB_REG_VELOCITY) pin_store3<PPL>(X.vel, plane, slot, valid, dense);
-                else if (at.reg == HNB_REG_AGE) pin_store1<PPL>(X.age, plane, slot, valid, dense);
-                else if (at.reg == HNB_REG_LIFETIME) pin_store1<PPL>(X.lifetime, plane, slot, valid, dense);
-            }
-#pragma unroll
-            for (int p = 0; p < PPL; ++p) alive_f[p] = X.alive[p];
-        } else {
-            VmState<vreg_file_t> S;
-            S.r = vreg_file_t{};
-            for (uint32_t a = 0; a < prog.n_attrs; ++a) {
-                const DevAttr at = prog.attrs[a];
-                if (!(at.upd_flags & HNB_ATTR_UPD_LOAD) || at.reg == HNB_REG_NONE) continue;
-                Out4 o = Out4{0u, 0u, 0u, 0u};
-                if (valid[0]) o = vfile_load_attr(at.ncomp, base + at.plane_off, slot[0]);
-                for (uint32_t c = 0; c < at.ncomp; ++c) S.r[at.reg + c] = out4_get(o, c);  // single indexed store site
-            }
-            S.pindex = slot[0] + slot_base;
-            S.seed = pcg_hash(S.pindex ^ seed_k);  // vfx_update.wgsl:138
-            S.pcounter = 0u;
-            S.alive = true;
-            VmAttrIO io;
-            io.slab = base; io.attrs = prog.attrs; io.slot = slot[0];
-            if (valid[0]) vm_run<true, false>(prog.update_code, prog.update_len, S, U, nullptr, nullptr, io);
-            if (valid[0]) {
-                for (uint32_t a = 0; a < prog.n_attrs; ++a) {
-                    const DevAttr at = prog.attrs[a];
-                    if ((at.upd_flags & HNB_ATTR_UPD_STORE) && at.reg != HNB_REG_NONE) vfile_store_attr(S.r, at.ncomp, at.reg, base + at.plane_off, slot[0]);
-                }
-            }
-            alive_f[0] = S.alive;
-        }
-
-        // ---- chunk-local stable compaction in LDS -------------------------------------------
-        uint32_t na = 0, nd = 0;
-#pragma unroll
-        for (int p = 0; p < PPL; ++p) {
-            na += (valid[p] && alive_f[p]) ? 1u : 0u;
-            nd += (valid[p] && !alive_f[p]) ? 1u : 0u;
-        }
-        const uint32_t x = na | (nd << 16);
-        uint32_t incl = x;
-#pragma unroll
-        for (uint32_t off = 1; off < 64; off <<= 1) {
-            const uint32_t y = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += y;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t wbase = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < kBlock / 64; ++w) {
-            const uint32_t t = s_wave[w];
-            if (w < wave) wbase += t;
-            total += t;
-        }
-        const uint32_t excl = wbase + incl - x;
-        uint32_t ra = local_alive + (excl & 0xffffu);
-        uint32_t rd = local_dead + (excl >> 16);
-#pragma unroll
-        for (int p = 0; p < PPL; ++p) {
-            if (!valid[p]) continue;
-            if (alive_f[p]) s_list[ra++] = slot[p];
-            else s_list[kChunk - 1u - (rd++)] = slot[p];
-        }
-        local_alive += total & 0xffffu;
-        local_dead += total >> 16;
-        __syncthreads();
-    }
-
-    // ---- decoupled look-back over the chunks of this instance ------------------------------
-    uint64_t* st = status + (size_t)k * prog.chunks_per_inst;
+// Decoupled look-back over the chunks of the instance, then the coalesced list writes.
+// s_list holds the chunk's survivors from the front and its casualties from the back.
+__device__ __forceinline__ void chunk_finish(const ChunkCtx& c, const DevProgram& prog, DevMeta* meta_out, uint64_t* status, uint32_t* ticket,
+                                             uint32_t epoch, uint32_t local_alive, uint32_t local_dead, const uint32_t* s_list,
+                                             uint32_t* s_bcast) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint64_t* st = status + (size_t)c.k * prog.chunks_per_inst;
+    const uint32_t j = c.j;
     if (wave == 0) {
         uint32_t excl_prefix = 0;
         uint32_t fault = 0;
@@ -407,12 +297,332 @@ k_update(const DevProgram prog, const uint64_t* __restrict__ inst_base, const De
     const uint32_t excl_prefix = s_bcast[0];
 
     // Survivors: stable order (vfx_update.wgsl:161-165 under serial execution).
-    for (uint32_t i = tid; i < local_alive; i += kBlock) alive_wr[excl_prefix + i] = s_list[i];
+    for (uint32_t i = tid; i < local_alive; i += kBlock) c.alive_wr[excl_prefix + i] = s_list[i];
     // Casualties: the d-th dead particle in serial order lands on dead row n-1-d
     // (vfx_update.wgsl:150-151: atomicSub(alive_count)-1).
-    const uint32_t dead_before = start - excl_prefix;
-    for (uint32_t i = tid; i < local_dead; i += kBlock) dead[n - 1u - (dead_before + i)] = s_list[kChunk - 1u - i];
+    const uint32_t dead_before = c.start - excl_prefix;
+    for (uint32_t i = tid; i < local_dead; i += kBlock) c.dead[c.n - 1u - (dead_before + i)] = s_list[kChunk - 1u - i];
 
+    if (tid == 0 && c.start + kChunk >= c.n) {
+        const uint32_t survivors = excl_prefix + local_alive;
+        DevMeta o;
+        o.alive_count = survivors;
+        o.particle_counter = c.m.particle_counter + c.n_spawn;
+        o.write_index = c.m.write_index ^ 1u;
+        o.max_update = c.n;
+        o.dead_count = c.n - survivors;
+        o.spawned = c.n_spawn;
+        o.fault = c.m.fault | s_bcast[1];
+        o.instance_count = survivors;
+        meta_out[c.k] = o;
+    }
+}
+
+// ---- generic update kernel: any update stream, V register file, one particle per lane ----------
+__global__ void __launch_bounds__(kBlock)
+k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+                 DevMeta* __restrict__ meta_out, const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks,
+                 uint64_t* status, uint32_t* ticket, uint32_t parity, uint32_t epoch) {
+    __shared__ uint32_t s_list[kChunk];
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_bcast[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    ChunkCtx c;
+    if (!chunk_begin(c, prog, inst_base, meta_in, meta_out, fi, ticket, parity, s_bcast)) return;
+    const uint32_t seed_k = fi[c.k].seed, slot_base = fi[c.k].slot_base;
+    VmUniforms U;
+    U.u = ublocks + (size_t)c.k * prog.n_uregs;
+    U.xf = fi[c.k].xf;
+    uint32_t local_alive = 0, local_dead = 0;
+
+    for (uint32_t sub = 0; sub < kChunk / kBlock; ++sub) {
+        const uint32_t li = c.start + sub * kBlock + tid;
+        if (c.start + sub * kBlock >= c.n) break;
+        const bool valid = li < c.n;
+        const uint32_t slot = valid ? c.alive_rd[li] : 0u;
+        VmState<vreg_file_t> S;
+        S.r = vreg_file_t{};
+        for (uint32_t a = 0; a < prog.n_attrs; ++a) {
+            const DevAttr at = prog.attrs[a];
+            if (!(at.upd_flags & HNB_ATTR_UPD_LOAD) || at.reg == HNB_REG_NONE) continue;
+            Out4 o = Out4{0u, 0u, 0u, 0u};
+            if (valid) o = vfile_load_attr(at.ncomp, c.base + at.plane_off, slot);
+            for (uint32_t cc = 0; cc < at.ncomp; ++cc) S.r[at.reg + cc] = out4_get(o, cc);  // single indexed store site
+        }
+        S.pindex = slot + slot_base;
+        S.seed = pcg_hash(S.pindex ^ seed_k);  // vfx_update.wgsl:138
+        S.pcounter = 0u;
+        S.alive = true;
+        VmAttrIO io;
+        io.slab = c.base; io.attrs = prog.attrs; io.slot = slot;
+        if (valid) vm_run<true, false>(prog.update_code, prog.update_len, S, U, nullptr, nullptr, io);
+        if (valid) {
+            for (uint32_t a = 0; a < prog.n_attrs; ++a) {
+                const DevAttr at = prog.attrs[a];
+                if ((at.upd_flags & HNB_ATTR_UPD_STORE) && at.reg != HNB_REG_NONE) vfile_store_attr(S.r, at.ncomp, at.reg, c.base + at.plane_off, slot);
+            }
+        }
+        // chunk-local stable compaction in LDS
+        const uint32_t x = (valid && S.alive ? 1u : 0u) | ((valid && !S.alive ? 1u : 0u) << 16);
+        uint32_t incl = x;
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += y;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kBlock / 64; ++w) {
+            const uint32_t t = s_wave[w];
+            if (w < wave) wbase += t;
+            total += t;
+        }
+        const uint32_t excl = wbase + incl - x;
+        if (valid) {
+            if (S.alive) s_list[local_alive + (excl & 0xffffu)] = slot;
+            else s_list[kChunk - 1u - (local_dead + (excl >> 16))] = slot;
+        }
+        local_alive += total & 0xffffu;
+        local_dead += total >> 16;
+        __syncthreads();
+    }
+    chunk_finish(c, prog, meta_out, status, ticket, epoch, local_alive, local_dead, s_list, s_bcast);
+}
+
+// ---- streaming update kernel ---------------------------------------------------------------------
+// Macro-op update streams with U operands, named registers, 4 particles per lane.
+//
+// Work decomposition (all choices measured on MI355X):
+//  * a workgroup owns a 4096-row chunk of the alive list; each of its 4 WAVES owns a private,
+//    contiguous 1024-row quarter and walks it in 4 steps of 256 rows (64 lanes x 4 rows, so the
+//    dense path moves 16 B per lane per access);
+//  * survivors / casualties are ranked inside the wave with ballots (no shuffles, no LDS) and go
+//    straight into the wave's own LDS segment, so the loop contains NO workgroup barrier and
+//    keeps only 4 slot indices live: registers stay low enough for 8 waves per SIMD;
+//  * the workgroup synchronises once, combines the 4 wave totals, runs the cross-chunk
+//    look-back and writes both lists coalesced.
+struct StreamArgs {
+    uint32_t capacity, n_uregs, chunks_per_inst, n_inst;
+    uint32_t alive_off[2], dead_off, update_len;
+    uint32_t plane_off[4];   // position, velocity, age, lifetime
+    uint32_t flags;          // bit i: load pinned attr i; bit 4+i: store pinned attr i
+    const Ins* update_code;
+};
+
+#ifndef HNB_STREAM_WAVES
+#define HNB_STREAM_WAVES 8   // waves per SIMD the lean streaming kernel is register-budgeted for
+#endif
+#ifndef HNB_STREAM_WAVES_FULL
+#define HNB_STREAM_WAVES_FULL 5
+#endif
+constexpr uint32_t kWaveRows = kChunk / (kBlock / 64);  // 1024 rows per wave
+constexpr uint32_t kStepRows = 64 * 4;                  // 256 rows per wave step
+
+// PROBE (tools/stream_probe.hip only; 0 in the product): ablation bits used to attribute the kernel's
+// time: 1 = no ticket (chunk = blockIdx), 2 = skip look-back + list writes, 4 = skip stores,
+// 8 = skip the program, 16 = skip the alive-list read (assume identity).
+template <class PROG, int WAVES, int PROBE = 0>
+__global__ void __launch_bounds__(kBlock, WAVES)
+k_update_stream(const StreamArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+                DevMeta* __restrict__ meta_out, const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks,
+                uint64_t* status, uint32_t* ticket, uint32_t parity, uint32_t epoch) {
+    __shared__ uint32_t s_list[kChunk];
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_bcast[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+
+    // ---- ticket + counters (vfx_indirect.wgsl:57-85 folded in) ------------------------------------
+    uint32_t chunk;
+    if constexpr (PROBE & 1) {
+        chunk = blockIdx.x;
+    } else {
+        if (tid == 0) {
+            const uint32_t t = __hip_atomic_fetch_add(&ticket[parity], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 0) __hip_atomic_store(&ticket[parity ^ 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_bcast[0] = t;
+        }
+        __syncthreads();
+        chunk = s_bcast[0];
+    }
+    const uint32_t k = chunk / args.chunks_per_inst;
+    const uint32_t j = chunk - k * args.chunks_per_inst;
+    if (k >= args.n_inst) return;
+    const DevMeta m = meta_in[k];
+    const uint32_t spawn = fi[k].spawn_count;
+    const uint32_t max_spawn = args.capacity - m.alive_count;
+    const uint32_t n_spawn = spawn < max_spawn ? spawn : max_spawn;
+    const uint32_t n = m.alive_count + n_spawn;  // max_update
+    const uint32_t start = j * kChunk;
+    if (n == 0) {
+        if (j == 0 && tid == 0) {
+            DevMeta o = m;
+            o.write_index = m.write_index ^ 1u; o.max_update = 0; o.dead_count = 0; o.spawned = 0; o.instance_count = 0;
+            meta_out[k] = o;
+        }
+        return;
+    }
+    if (start >= n) return;
+    char* base = reinterpret_cast<char*>(inst_base[k]);
+    const uint32_t* alive_rd = reinterpret_cast<const uint32_t*>(base + args.alive_off[m.write_index]);
+
+    VmUniforms U;
+    U.u = ublocks + (size_t)k * args.n_uregs;
+    U.xf = fi[k].xf;
+    char* p_pos = base + args.plane_off[0];
+    char* p_vel = base + args.plane_off[1];
+    char* p_age = base + args.plane_off[2];
+    char* p_life = base + args.plane_off[3];
+    const uint32_t fl = args.flags;
+
+    // ---- the wave's private quarter ------------------------------------------------------------------
+    const uint32_t wstart = start + wave * kWaveRows;
+    uint32_t* seg = s_list + wave * kWaveRows;
+    uint32_t wa = 0, wd = 0;  // wave-uniform survivor / casualty counts of this quarter
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll 1
+    for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
+        const uint32_t sbase = wstart + step * kStepRows;
+        if (sbase >= n) break;
+        const uint32_t li = sbase + lane * 4u;
+        uint32_t slot[4];
+        bool valid[4];
+        if constexpr (PROBE & 16) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { valid[p] = li + p < n; slot[p] = li + p; }
+        } else if (li + 4u <= n) {
+            const uint4 q = *reinterpret_cast<const uint4*>(alive_rd + li);
+            slot[0] = q.x; slot[1] = q.y; slot[2] = q.z; slot[3] = q.w;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) valid[p] = true;
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                valid[p] = li + p < n;
+                slot[p] = valid[p] ? alive_rd[li + p] : 0u;
+            }
+        }
+        const bool quad = valid[3] && ((slot[0] & 3u) == 0u) && slot[1] == slot[0] + 1u && slot[2] == slot[0] + 2u && slot[3] == slot[0] + 3u;
+        const bool dense = __all(quad);  // wave-uniform: all 64 lanes own an aligned run of 4 slots
+
+        Pinned<4> X;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { X.pos[p] = V3{0, 0, 0}; X.vel[p] = V3{0, 0, 0}; X.age[p] = 0.0f; X.lifetime[p] = 0.0f; X.alive[p] = true; }
+        if (fl & 1u) pin_load3<4>(X.pos, p_pos, slot, valid, dense);
+        if (fl & 2u) pin_load3<4>(X.vel, p_vel, slot, valid, dense);
+        if (fl & 4u) pin_load1<4>(X.age, p_age, slot, valid, dense);
+        if (fl & 8u) pin_load1<4>(X.lifetime, p_life, slot, valid, dense);
+
+        if constexpr (!(PROBE & 8)) PROG::template run<4>(args.update_code, args.update_len, X, U);
+
+        if constexpr (!(PROBE & 4)) {
+            if (fl & 16u) pin_store3<4>(X.pos, p_pos, slot, valid, dense);
+            if (fl & 32u) pin_store3<4>(X.vel, p_vel, slot, valid, dense);
+            if (fl & 64u) pin_store1<4>(X.age, p_age, slot, valid, dense);
+            if (fl & 128u) pin_store1<4>(X.lifetime, p_life, slot, valid, dense);
+        } else {
+            // keep the loads alive
+            float acc = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc += X.pos[p].x + X.pos[p].y + X.pos[p].z + X.vel[p].x + X.vel[p].y + X.vel[p].z + X.age[p] + X.lifetime[p];
+            if (acc == 123.456f) X.alive[0] = false;
+        }
+
+        // wave-local stable ranks from ballots: rows are lane-major (lane l owns rows 4l..4l+3)
+        uint32_t before_a = 0, before_v = 0, tot_a = 0, tot_v = 0;
+        bool al[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            al[p] = valid[p] && X.alive[p];
+            const uint64_t ma = __ballot(al[p]), mv = __ballot(valid[p]);
+            before_a += (uint32_t)__popcll(ma & below); tot_a += (uint32_t)__popcll(ma);
+            before_v += (uint32_t)__popcll(mv & below); tot_v += (uint32_t)__popcll(mv);
+        }
+        uint32_t ra = wa + before_a;                 // survivors of this quarter before my first row
+        uint32_t rd = wd + (before_v - before_a);    // casualties before my first row
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (!valid[p]) continue;
+            if (al[p]) seg[ra++] = slot[p];
+            else seg[kWaveRows - 1u - (rd++)] = slot[p];
+        }
+        wa += tot_a;
+        wd += tot_v - tot_a;
+    }
+    if (lane == 0) s_wave[wave] = wa | (wd << 16);
+    __syncthreads();
+    if constexpr (PROBE & 2) {
+        if (s_wave[0] == 0xffffffffu) meta_out[k].fault = 1;
+        return;
+    }
+
+    // ---- combine the 4 quarters, look back across chunks, write the lists ---------------------------
+    uint32_t a_w[kBlock / 64], d_w[kBlock / 64];
+    uint32_t local_alive = 0, local_dead = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64; ++w) {
+        const uint32_t t = s_wave[w];
+        a_w[w] = t & 0xffffu; d_w[w] = t >> 16;
+        local_alive += a_w[w]; local_dead += d_w[w];
+    }
+    uint64_t* st = status + (size_t)k * args.chunks_per_inst;
+    if (wave == 0) {
+        uint32_t excl_prefix = 0;
+        uint32_t fault = 0;
+        if (j == 0) {
+            if (lane == 0)
+                __hip_atomic_store(&st[0], pack_status(epoch, kStatePrefix, local_alive), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0)
+                __hip_atomic_store(&st[j], pack_status(epoch, kStateAggregate, local_alive), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int hi = (int)j - 1;
+            while (hi >= 0) {
+                const int idx = hi - (int)lane;
+                uint64_t s = pack_status(epoch, kStatePrefix, 0u);  // virtual predecessor before chunk 0
+                uint32_t spins = 0;
+                for (;;) {
+                    if (idx >= 0) s = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ready = (uint32_t)(s >> 34) == epoch;
+                    if (__all(ready)) break;
+                    if (++spins > (1u << 22)) { fault = 1u; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (fault) break;
+                const bool is_prefix = ((s >> 32) & 3u) == kStatePrefix;
+                const uint64_t pmask = __ballot(is_prefix);
+                const uint32_t first = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
+                uint32_t v = (lane <= first) ? (uint32_t)s : 0u;
+#pragma unroll
+                for (uint32_t off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                excl_prefix += v;
+                if (pmask) break;
+                hi -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&st[j], pack_status(epoch, kStatePrefix, excl_prefix + local_alive), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_bcast[0] = excl_prefix; s_bcast[1] = fault;
+            if (fault) atomicOr(&ticket[2], 1u);  // watchdog word, reported by hnb_effect_metadata
+        }
+    }
+    __syncthreads();
+    const uint32_t excl_prefix = s_bcast[0];
+    uint32_t* alive_wr = reinterpret_cast<uint32_t*>(base + args.alive_off[m.write_index ^ 1u]);
+    uint32_t* dead = reinterpret_cast<uint32_t*>(base + args.dead_off);
+    // Survivors in stable (serial) order: quarter 0's, then quarter 1's, ... (vfx_update.wgsl:161-165).
+    // The d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151).
+    uint32_t abase = excl_prefix, dbase = start - excl_prefix;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64; ++w) {
+        const uint32_t* sg = s_list + w * kWaveRows;
+        for (uint32_t i = tid; i < a_w[w]; i += kBlock) alive_wr[abase + i] = sg[i];
+        for (uint32_t i = tid; i < d_w[w]; i += kBlock) dead[n - 1u - (dbase + i)] = sg[kWaveRows - 1u - i];
+        abase += a_w[w];
+        dbase += d_w[w];
+    }
     if (tid == 0 && start + kChunk >= n) {
         const uint32_t survivors = excl_prefix + local_alive;
         DevMeta o;

@@ -653,7 +653,14 @@ struct Pinned {
 HNB_HD float uf(const VmUniforms& U, uint32_t operand) { return u2f(U.u[operand & 0x7fu]); }
 HNB_HD V3 uf3(const VmUniforms& U, uint32_t operand) { return V3{uf(U, operand), uf(U, operand + 1), uf(U, operand + 2)}; }
 
-template <int P>
+// Ops of the "lean" streaming variant; the rest (normalize / cross / smoothstep heavy) only exist
+// in the FULL variant so that the common programs keep a small register footprint.
+HNB_HD bool vm_op_is_lean(uint32_t op) {
+    return op == HNB_OP_M_AGE_TICK || op == HNB_OP_M_EULER || op == HNB_OP_M_VEL_SCALE || op == HNB_OP_M_VEL_ADD || op == HNB_OP_M_PIN_SET ||
+           op == HNB_OP_M_KILL_SPHERE || op == HNB_OP_M_KILL_AABB;
+}
+
+template <int P, bool FULL>
 HNB_HD void fast_run(const Ins* __restrict__ code, uint32_t n_ins, Pinned<P>& X, const VmUniforms& U) {
     for (uint32_t pc = 0; pc < n_ins; ++pc) {
         const Ins ins = code[pc];
@@ -691,27 +698,33 @@ HNB_HD void fast_run(const Ins* __restrict__ code, uint32_t n_ins, Pinned<P>& X,
                     for (int p = 0; p < P; ++p) { if (d == HNB_REG_AGE) X.age[p] = s; else X.lifetime[p] = s; }
                 }
             } break;
-            case HNB_OP_M_RADIAL_ACCEL: {
-                const V3 origin = uf3(U, a);
-                const float s = uf(U, b);
+            case HNB_OP_M_RADIAL_ACCEL:
+                if constexpr (FULL) {
+                    const V3 origin = uf3(U, a);
+                    const float s = uf(U, b);
 #pragma unroll
-                for (int p = 0; p < P; ++p) mac_radial_accel(X.pos[p], X.vel[p], origin, s);
-            } break;
-            case HNB_OP_M_TANGENT_ACCEL: {
-                const V3 origin = uf3(U, a), axis = uf3(U, b);
-                const float s = uf(U, c);
+                    for (int p = 0; p < P; ++p) mac_radial_accel(X.pos[p], X.vel[p], origin, s);
+                }
+                break;
+            case HNB_OP_M_TANGENT_ACCEL:
+                if constexpr (FULL) {
+                    const V3 origin = uf3(U, a), axis = uf3(U, b);
+                    const float s = uf(U, c);
 #pragma unroll
-                for (int p = 0; p < P; ++p) mac_tangent_accel(X.pos[p], X.vel[p], origin, axis, s);
-            } break;
-            case HNB_OP_M_CONFORM_SPHERE: {
-                ConformParams q;
-                q.c = uf3(U, a);
-                q.radius = uf(U, a + 3); q.influence_dist = uf(U, a + 4); q.shell_half_thickness = uf(U, a + 5);
-                q.max_attraction_speed = uf(U, a + 6); q.attraction_accel = uf(U, a + 7); q.sticky_factor = uf(U, a + 8);
-                const float dt = uf(U, b);
+                    for (int p = 0; p < P; ++p) mac_tangent_accel(X.pos[p], X.vel[p], origin, axis, s);
+                }
+                break;
+            case HNB_OP_M_CONFORM_SPHERE:
+                if constexpr (FULL) {
+                    ConformParams q;
+                    q.c = uf3(U, a);
+                    q.radius = uf(U, a + 3); q.influence_dist = uf(U, a + 4); q.shell_half_thickness = uf(U, a + 5);
+                    q.max_attraction_speed = uf(U, a + 6); q.attraction_accel = uf(U, a + 7); q.sticky_factor = uf(U, a + 8);
+                    const float dt = uf(U, b);
 #pragma unroll
-                for (int p = 0; p < P; ++p) mac_conform_sphere(X.pos[p], X.vel[p], q, dt);
-            } break;
+                    for (int p = 0; p < P; ++p) mac_conform_sphere(X.pos[p], X.vel[p], q, dt);
+                }
+                break;
             case HNB_OP_M_KILL_SPHERE: {
                 const V3 center = uf3(U, a);
                 const float r2 = uf(U, b);
@@ -727,5 +740,87 @@ HNB_HD void fast_run(const Ins* __restrict__ code, uint32_t n_ins, Pinned<P>& X,
         }
     }
 }
+
+
+// ---- statically specialised op sequences ------------------------------------------------------------
+// The hottest update programs are short, fixed sequences of macro ops. Compiling a sequence as a
+// template pack gives straight-line code (no per-op scalar branch, no phi webs over the named
+// registers); operands still come from the parameter block at run time, so one instantiation
+// serves every effect whose update stream has the same opcode sequence.
+template <uint32_t OP, int P>
+HNB_HD void apply_static(const Ins ins, Pinned<P>& X, const VmUniforms& U) {
+    const uint32_t a = (ins.x >> 16) & 0xffu, b = ins.x >> 24, c = ins.y & 0xffu, aux = ins.y >> 16;
+    if constexpr (OP == HNB_OP_M_AGE_TICK) {
+        const float dt = uf(U, a);
+        const bool has_lifetime = (aux & 1u) != 0u;
+#pragma unroll
+        for (int p = 0; p < P; ++p) mac_age_tick(X.age[p], X.lifetime[p], dt, has_lifetime, X.alive[p]);
+    } else if constexpr (OP == HNB_OP_M_EULER) {
+        const float dt = uf(U, a);
+#pragma unroll
+        for (int p = 0; p < P; ++p) mac_euler(X.pos[p], X.vel[p], dt);
+    } else if constexpr (OP == HNB_OP_M_VEL_SCALE) {
+        const float s = uf(U, a);
+#pragma unroll
+        for (int p = 0; p < P; ++p) mac_vel_scale(X.vel[p], s);
+    } else if constexpr (OP == HNB_OP_M_VEL_ADD) {
+        const V3 v = uf3(U, a);
+#pragma unroll
+        for (int p = 0; p < P; ++p) mac_vel_add(X.vel[p], v);
+    } else if constexpr (OP == HNB_OP_M_RADIAL_ACCEL) {
+        const V3 origin = uf3(U, a);
+        const float s = uf(U, b);
+#pragma unroll
+        for (int p = 0; p < P; ++p) mac_radial_accel(X.pos[p], X.vel[p], origin, s);
+    } else if constexpr (OP == HNB_OP_M_TANGENT_ACCEL) {
+        const V3 origin = uf3(U, a), axis = uf3(U, b);
+        const float s = uf(U, c);
+#pragma unroll
+        for (int p = 0; p < P; ++p) mac_tangent_accel(X.pos[p], X.vel[p], origin, axis, s);
+    } else if constexpr (OP == HNB_OP_M_CONFORM_SPHERE) {
+        ConformParams q;
+        q.c = uf3(U, a);
+        q.radius = uf(U, a + 3); q.influence_dist = uf(U, a + 4); q.shell_half_thickness = uf(U, a + 5);
+        q.max_attraction_speed = uf(U, a + 6); q.attraction_accel = uf(U, a + 7); q.sticky_factor = uf(U, a + 8);
+        const float dt = uf(U, b);
+#pragma unroll
+        for (int p = 0; p < P; ++p) mac_conform_sphere(X.pos[p], X.vel[p], q, dt);
+    } else if constexpr (OP == HNB_OP_M_KILL_SPHERE) {
+        const V3 center = uf3(U, a);
+        const float r2 = uf(U, b);
+        const bool inside = (aux & 1u) != 0u;
+#pragma unroll
+        for (int p = 0; p < P; ++p) mac_kill_sphere(X.pos[p], center, r2, inside, X.alive[p]);
+    } else if constexpr (OP == HNB_OP_M_KILL_AABB) {
+        const V3 center = uf3(U, a), half = uf3(U, b);
+        const bool inside = (aux & 1u) != 0u;
+#pragma unroll
+        for (int p = 0; p < P; ++p) mac_kill_aabb(X.pos[p], center, half, inside, X.alive[p]);
+    }
+}
+
+// Interpreted program (any streamable sequence).
+struct ProgInterp {
+    static constexpr uint32_t kLen = 0;
+    template <int P> HNB_HD_MEMBER static void run(const Ins* __restrict__ code, uint32_t n_ins, Pinned<P>& X, const VmUniforms& U) {
+        fast_run<P, true>(code, n_ins, X, U);
+    }
+};
+// Fixed opcode sequence.
+template <uint32_t... OPS>
+struct ProgStatic {
+    static constexpr uint32_t kLen = sizeof...(OPS);
+    template <int P> HNB_HD_MEMBER static void run(const Ins* __restrict__ code, uint32_t, Pinned<P>& X, const VmUniforms& U) {
+        uint32_t i = 0;
+        ((apply_static<OPS, P>(code[i++], X, U)), ...);
+    }
+    static bool matches(const Ins* code, uint32_t n_ins) {
+        const uint32_t ops[] = {OPS...};
+        if (n_ins != kLen) return false;
+        for (uint32_t i = 0; i < kLen; ++i)
+            if ((code[i].x & 0xffu) != ops[i]) return false;
+        return true;
+    }
+};
 
 }  // namespace hnb

@@ -54,7 +54,7 @@ def load_library():
     """Load libhanabi_amd.so (in-tree). Raises if it has not been built."""
     global _lib
     if _lib is None:
-        path = _build.runtime_lib_path()
+        path = os.environ.get("HNB_LIB") or _build.runtime_lib_path()  # HNB_LIB: kernel-variant A/B runs
         if not os.path.exists(path):
             raise HanabiError(-1, f"{path} not found: run `python -m bevy_hanabi_amd.build` (needs hipcc)")
         lib = C.CDLL(path)

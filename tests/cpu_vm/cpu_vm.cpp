@@ -132,7 +132,7 @@ void cvm_step(CpuVm* v, const float* sim, uint32_t spawn_count, uint32_t seed, c
                 else if (at.reg == HNB_REG_AGE) X.age[0] = u2f(p[0]);
                 else if (at.reg == HNB_REG_LIFETIME) X.lifetime[0] = u2f(p[0]);
             }
-            fast_run<1>(v->ucode_update.data(), (uint32_t)v->ucode_update.size(), X, U);
+            fast_run<1, true>(v->ucode_update.data(), (uint32_t)v->ucode_update.size(), X, U);
             for (size_t a = 0; a < v->attrs.size(); ++a) {
                 const HnbAttrEntry& at = v->attrs[a];
                 if (!(at.update_flags & HNB_ATTR_UPD_STORE)) continue;
