@@ -52,12 +52,11 @@ struct TimingPair { hipEvent_t a, b; };
 // Statically specialised op sequences for the common modifier stacks (the reference's example
 // effects), plus the interpreter for every other streamable sequence.
 typedef void (*StreamLaunchFn)(uint32_t grid, hipStream_t stream, const StreamArgs& sa, const uint64_t* inst_base, const DevMeta* meta_in,
-                               DevMeta* meta_out, const DevFrameInst* fi, const uint32_t* ublocks, uint64_t* status, uint32_t* ticket,
-                               uint32_t parity, uint32_t epoch);
+                               DevMeta* meta_out, const DevFrameInst* fi, const uint32_t* ublocks, const ScanBufs& sb);
 template <class PROG, int WAVES>
 void launch_stream(uint32_t grid, hipStream_t stream, const StreamArgs& sa, const uint64_t* inst_base, const DevMeta* meta_in, DevMeta* meta_out,
-                   const DevFrameInst* fi, const uint32_t* ublocks, uint64_t* status, uint32_t* ticket, uint32_t parity, uint32_t epoch) {
-    k_update_stream<PROG, WAVES><<<grid, kBlock, 0, stream>>>(sa, inst_base, meta_in, meta_out, fi, ublocks, status, ticket, parity, epoch);
+                   const DevFrameInst* fi, const uint32_t* ublocks, const ScanBufs& sb) {
+    k_update_stream<PROG, WAVES><<<grid, kBlock, 0, stream>>>(sa, inst_base, meta_in, meta_out, fi, ublocks, sb);
 }
 #define OP_(x) (uint32_t)HNB_OP_M_##x
 typedef ProgStatic<OP_(AGE_TICK)> ProgAge;                                                        // ribbon.rs
@@ -94,6 +93,7 @@ struct HnbContext {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    uint32_t num_cus = 256;
     std::vector<HnbProgram*> programs;
     HnbSimParams sim{};
     bool timing = false;
@@ -117,7 +117,10 @@ struct HnbProgram {
     uint32_t table_cap = 0;
     uint64_t* d_inst_base = nullptr;
     DevMeta* d_meta[2] = {nullptr, nullptr};
-    uint64_t* d_status = nullptr;
+    uint64_t* d_status = nullptr;        // per chunk
+    uint64_t* d_group_status = nullptr;  // per look-back group
+    uint32_t* d_arrive = nullptr;        // [2][groups]: arrival counters, frame-parity double-buffered
+    uint32_t groups_per_inst = 1;
     uint32_t* d_ticket = nullptr;  // [2] tickets + [1] fault word
     void* h_frame[2] = {nullptr, nullptr};
     void* d_frame[2] = {nullptr, nullptr};
@@ -326,6 +329,8 @@ void free_tables(HnbProgram* p) {
         p->h_frame[i] = nullptr;
     }
     hipFree(p->d_status); p->d_status = nullptr;
+    hipFree(p->d_group_status); p->d_group_status = nullptr;
+    hipFree(p->d_arrive); p->d_arrive = nullptr;
     hipFree(p->d_ticket); p->d_ticket = nullptr;
     p->table_cap = 0;
 }
@@ -352,6 +357,14 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
     const size_t n_status = (size_t)cap * p->dev.chunks_per_inst;
     HIP_TRY(hipMalloc(&ns, n_status * 8));
     HIP_TRY(hipMemset(ns, 0, n_status * 8));
+    p->groups_per_inst = (p->dev.chunks_per_inst + kGroup - 1) / kGroup;
+    const size_t n_groups = (size_t)cap * p->groups_per_inst;
+    hipFree(p->d_group_status);
+    hipFree(p->d_arrive);
+    HIP_TRY(hipMalloc(&p->d_group_status, n_groups * 8));
+    HIP_TRY(hipMemset(p->d_group_status, 0, n_groups * 8));
+    HIP_TRY(hipMalloc(&p->d_arrive, 2 * n_groups * 4));
+    HIP_TRY(hipMemset(p->d_arrive, 0, 2 * n_groups * 4));
     if (p->table_cap) {
         HIP_TRY(hipMemcpy(nb, p->d_inst_base, (size_t)p->table_cap * 8, hipMemcpyDeviceToDevice));
         for (int i = 0; i < 2; ++i)
@@ -418,6 +431,8 @@ int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(HNB_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     ctx->own_stream = true;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     *out_ctx = ctx;
     return HNB_OK;
 }
@@ -478,8 +493,8 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     // Slab layout: [alive ping][alive pong][dead][attribute planes...], 256-byte aligned planes.
     size_t off = 0;
     const size_t list_bytes = align_up((size_t)h.capacity * 4, 256);
-    d.alive_off[0] = (uint32_t)off; off += list_bytes;
-    d.alive_off[1] = (uint32_t)off; off += list_bytes;
+    d.alive_off[0] = (uint32_t)off; off += list_bytes;  // one alive list, compacted in place (no ping-pong column)
+    d.alive_off[1] = d.alive_off[0];
     d.dead_off = (uint32_t)off; off += list_bytes;
     for (uint32_t i = 0; i < h.n_attrs; ++i) {
         if (off > 0xffffffffull) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB"); }
@@ -552,8 +567,7 @@ int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
     char* base = static_cast<char*>(fx->slab);
     const uint32_t cap = p->dev.capacity;
     k_reset_lists<<<(cap + 255) / 256, 256, 0, ctx->stream>>>(reinterpret_cast<uint32_t*>(base + p->dev.dead_off),
-                                                              reinterpret_cast<uint32_t*>(base + p->dev.alive_off[0]),
-                                                              reinterpret_cast<uint32_t*>(base + p->dev.alive_off[1]), cap);
+                                                              reinterpret_cast<uint32_t*>(base + p->dev.alive_off[0]), cap);
     // Attribute planes start zeroed (the reference pre-fills with 0xFF only in debug builds).
     HIP_TRY(hipMemsetAsync(base + p->dev.attrs[0].plane_off, 0, p->slab_bytes - p->dev.attrs[0].plane_off, ctx->stream));
     // alive_count = 0, max_spawn = capacity, indirect_write_index = 0 (src/render/mod.rs:6048-6070)
@@ -667,7 +681,18 @@ int hnb_simulate(HnbContext* ctx) {
             k_init<<<blocks, kInitBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub);
             if (ctx->timing) { hipEventRecord(ti.b, ctx->stream); ctx->t_init.push_back(ti); }
         }
-        const uint32_t grid = n * p->dev.chunks_per_inst;
+        const uint32_t total_chunks = n * p->dev.chunks_per_inst;
+        // persistent workgroups: enough to fill the chip, never more than there are chunks
+        const uint32_t grid = std::min<uint32_t>(total_chunks, ctx->num_cus * 8u);
+        ScanBufs sb;
+        sb.chunk_status = p->d_status;
+        sb.group_status = p->d_group_status;
+        sb.arrive = p->d_arrive;
+        sb.ticket = p->d_ticket;
+        sb.groups_per_inst = p->groups_per_inst;
+        sb.n_groups_total = p->table_cap * p->groups_per_inst;
+        sb.parity = par;
+        sb.epoch = p->epoch;
         if (ctx->timing) { hipEventCreate(&tu.a); hipEventCreate(&tu.b); hipEventRecord(tu.a, ctx->stream); }
         if (p->update_streams) {
             StreamArgs sa{};
@@ -683,18 +708,17 @@ int hnb_simulate(HnbContext* ctx) {
                 if (at.upd_flags & HNB_ATTR_UPD_LOAD) sa.flags |= 1u << pi;
                 if (at.upd_flags & HNB_ATTR_UPD_STORE) sa.flags |= 16u << pi;
             }
-            p->stream_launch(grid, ctx->stream, sa, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, dub, p->d_status, p->d_ticket, par,
-                             p->epoch);
+            p->stream_launch(grid, ctx->stream, sa, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, dub, sb);
+        } else {
+            k_update_generic<<<grid, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, dub, sb);
         }
-        else
-            k_update_generic<<<grid, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, dub,
-                                                               p->d_status, p->d_ticket, par, p->epoch);
         if (ctx->timing) { hipEventRecord(tu.b, ctx->stream); ctx->t_update.push_back(tu); }
         HIP_TRY(hipGetLastError());
         p->parity ^= 1u;
         p->epoch += 1u;
         if (p->epoch >= (1u << 30)) {  // epoch tag wrap: clear the look-back words
             HIP_TRY(hipMemsetAsync(p->d_status, 0, (size_t)p->table_cap * p->dev.chunks_per_inst * 8, ctx->stream));
+            HIP_TRY(hipMemsetAsync(p->d_group_status, 0, (size_t)p->table_cap * p->groups_per_inst * 8, ctx->stream));
             p->epoch = 1;
         }
     }
@@ -764,9 +788,7 @@ int hnb_effect_read_alive_list(HnbEffect* fx, uint32_t* dst, size_t dst_count) {
     int rc = read_meta(fx, &m, nullptr);
     if (rc != HNB_OK) return rc;
     if (dst_count < m.alive_count) return fail(HNB_ERR_INVALID_ARG, "destination too small");
-    // the column the last update wrote is the one the next init appends to: meta.write_index
-    HIP_TRY(hipMemcpy(dst, static_cast<char*>(fx->slab) + p->dev.alive_off[m.write_index], (size_t)m.alive_count * 4,
-                      hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dst, static_cast<char*>(fx->slab) + p->dev.alive_off[0], (size_t)m.alive_count * 4, hipMemcpyDeviceToHost));
     return HNB_OK;
 }
 

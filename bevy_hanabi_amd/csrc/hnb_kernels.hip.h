@@ -37,10 +37,9 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 #endif
 
 // ---- reset: dead_index[i] = i (effect_cache.rs:298-323) ------------------------------------
-__global__ void k_reset_lists(uint32_t* __restrict__ dead, uint32_t* __restrict__ alive0, uint32_t* __restrict__ alive1,
-                              uint32_t capacity) {
+__global__ void k_reset_lists(uint32_t* __restrict__ dead, uint32_t* __restrict__ alive, uint32_t capacity) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < capacity) { dead[i] = i; alive0[i] = 0u; alive1[i] = 0u; }
+    if (i < capacity) { dead[i] = i; alive[i] = 0u; }
 }
 
 // ---- V-file attribute access (generic kernels, one particle per lane) -----------------------
@@ -90,9 +89,8 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
     if (i >= n_spawn) return;
 
     char* base = reinterpret_cast<char*>(inst_base[k]);
-    const uint32_t wi = meta_in[k].write_index;
     const uint32_t* dead = reinterpret_cast<const uint32_t*>(base + prog.dead_off);
-    uint32_t* alive = reinterpret_cast<uint32_t*>(base + prog.alive_off[wi]);
+    uint32_t* alive = reinterpret_cast<uint32_t*>(base + prog.alive_off[0]);  // single list, compacted in place by k_update
 
     const uint32_t slot = dead[alive0 + i];
 
@@ -187,11 +185,35 @@ __device__ __forceinline__ void pin_store1(const float (&src)[P], char* plane, c
 }
 
 // ---- update + kill + compaction ----------------------------------------------------------------
+// Cross-chunk machinery shared by the two update kernels.
+//
+//  * Persistent workgroups claim chunks from a ticket counter; the next ticket is requested
+//    before the current chunk is processed, so its latency is hidden. Tickets are handed out in
+//    order: every chunk with a smaller id has been claimed by a running workgroup, which makes
+//    all waits below deadlock-free under any dispatch order (no residency assumption).
+//  * The alive list is compacted IN PLACE (stable): chunk c writes rows [E, E+A) with E <= its first
+//    row, and only learns E after every earlier chunk has published, i.e. finished reading its rows.
+//    When nothing before or inside the chunk died, the rows are already in place and nothing is written.
+//  * E comes from a two-level decoupled look-back: chunks publish aggregates; the last chunk to
+//    arrive in a group of 64 publishes the group aggregate and resolves the group prefix from the
+//    (few) earlier groups. A chunk then needs one 64-wide read of its group's aggregates plus the
+//    previous group's prefix, instead of walking thousands of simultaneously-finishing chunks.
 __device__ __forceinline__ uint64_t pack_status(uint32_t epoch, uint64_t state, uint32_t value) {
     return ((uint64_t)epoch << 34) | (state << 32) | value;
 }
+constexpr uint32_t kGroup = 64;  // chunks per look-back group
 
-// Per-chunk bookkeeping shared by the two update kernels.
+struct ScanBufs {
+    uint64_t* chunk_status;   // [n_inst * chunks_per_inst]
+    uint64_t* group_status;   // [n_inst * groups_per_inst]
+    uint32_t* arrive;         // [2][n_inst * groups_per_inst], frame parity double-buffered
+    uint32_t* ticket;         // [0..1] ticket per parity, [2] watchdog word
+    uint32_t groups_per_inst;
+    uint32_t n_groups_total;
+    uint32_t parity;
+    uint32_t epoch;
+};
+
 struct ChunkCtx {
     uint32_t k, j;          // instance, chunk within instance
     uint32_t n;             // max_update of the instance
@@ -199,37 +221,36 @@ struct ChunkCtx {
     uint32_t start;         // first alive-list row of this chunk
     DevMeta m;
     char* base;
-    const uint32_t* alive_rd;
-    uint32_t* alive_wr;
+    uint32_t* alive;        // the instance's alive list (compacted in place)
     uint32_t* dead;
 };
 
-// Ticket + counters. Returns false when this workgroup has nothing to do.
-// Ticket: chunk ids are handed out in launch-independent order, so every chunk with a smaller
-// id has already started when this one waits on it (no dispatch-order assumption).
-__device__ __forceinline__ bool chunk_begin(ChunkCtx& c, const DevProgram& prog, const uint64_t* inst_base, const DevMeta* meta_in,
-                                            DevMeta* meta_out, const DevFrameInst* fi, uint32_t* ticket, uint32_t parity,
-                                            uint32_t* s_bcast) {
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) {
-        const uint32_t t = __hip_atomic_fetch_add(&ticket[parity], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == 0) __hip_atomic_store(&ticket[parity ^ 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_bcast[0] = t;
-    }
-    __syncthreads();
-    const uint32_t chunk = s_bcast[0];
-    c.k = chunk / prog.chunks_per_inst;
-    c.j = chunk - c.k * prog.chunks_per_inst;
-    if (c.k >= prog.n_inst) return false;
+__device__ __forceinline__ uint32_t claim_ticket(const ScanBufs& sb) {
+    return __hip_atomic_fetch_add(&sb.ticket[sb.parity], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Whoever draws ticket 0 prepares the counters of the NEXT frame (other parity): nothing of this
+// launch or the previous one touches them.
+__device__ __forceinline__ void reset_next_frame(const ScanBufs& sb) {
+    uint32_t* a = sb.arrive + (size_t)(sb.parity ^ 1u) * sb.n_groups_total;
+    for (uint32_t i = threadIdx.x; i < sb.n_groups_total; i += kBlock) a[i] = 0u;
+    if (threadIdx.x == 0) __hip_atomic_store(&sb.ticket[sb.parity ^ 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Decode a chunk id; false when the chunk has no rows (nothing to do, nobody waits on it).
+template <class ARGS>
+__device__ __forceinline__ bool chunk_setup(ChunkCtx& c, uint32_t chunk, const ARGS& args, const uint64_t* inst_base, const DevMeta* meta_in,
+                                            DevMeta* meta_out, const DevFrameInst* fi) {
+    c.k = chunk / args.chunks_per_inst;
+    c.j = chunk - c.k * args.chunks_per_inst;
     // vfx_indirect.wgsl:57-85 folded in: max_update = alive_count after init.
     c.m = meta_in[c.k];
     const uint32_t spawn = fi[c.k].spawn_count;
-    const uint32_t max_spawn = prog.capacity - c.m.alive_count;
+    const uint32_t max_spawn = args.capacity - c.m.alive_count;
     c.n_spawn = spawn < max_spawn ? spawn : max_spawn;
     c.n = c.m.alive_count + c.n_spawn;
     c.start = c.j * kChunk;
     if (c.n == 0) {
-        if (c.j == 0 && tid == 0) {
+        if (c.j == 0 && threadIdx.x == 0) {
             DevMeta o = c.m;
             o.write_index = c.m.write_index ^ 1u; o.max_update = 0; o.dead_count = 0; o.spawned = 0; o.instance_count = 0;
             meta_out[c.k] = o;
@@ -238,71 +259,135 @@ __device__ __forceinline__ bool chunk_begin(ChunkCtx& c, const DevProgram& prog,
     }
     if (c.start >= c.n) return false;
     c.base = reinterpret_cast<char*>(inst_base[c.k]);
-    c.alive_rd = reinterpret_cast<const uint32_t*>(c.base + prog.alive_off[c.m.write_index]);
-    c.alive_wr = reinterpret_cast<uint32_t*>(c.base + prog.alive_off[c.m.write_index ^ 1u]);
-    c.dead = reinterpret_cast<uint32_t*>(c.base + prog.dead_off);
+    c.alive = reinterpret_cast<uint32_t*>(c.base + args.alive_off[0]);
+    c.dead = reinterpret_cast<uint32_t*>(c.base + args.dead_off);
     return true;
 }
 
-// Decoupled look-back over the chunks of the instance, then the coalesced list writes.
-// s_list holds the chunk's survivors from the front and its casualties from the back.
-__device__ __forceinline__ void chunk_finish(const ChunkCtx& c, const DevProgram& prog, DevMeta* meta_out, uint64_t* status, uint32_t* ticket,
-                                             uint32_t epoch, uint32_t local_alive, uint32_t local_dead, const uint32_t* s_list,
-                                             uint32_t* s_bcast) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint64_t* st = status + (size_t)c.k * prog.chunks_per_inst;
-    const uint32_t j = c.j;
-    if (wave == 0) {
-        uint32_t excl_prefix = 0;
-        uint32_t fault = 0;
-        if (j == 0) {
-            if (lane == 0)
-                __hip_atomic_store(&st[0], pack_status(epoch, kStatePrefix, local_alive), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (lane == 0)
-                __hip_atomic_store(&st[j], pack_status(epoch, kStateAggregate, local_alive), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int hi = (int)j - 1;
-            while (hi >= 0) {
-                const int idx = hi - (int)lane;
-                uint64_t s = pack_status(epoch, kStatePrefix, 0u);  // virtual predecessor before chunk 0
-                uint32_t spins = 0;
-                for (;;) {
-                    if (idx >= 0) s = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool ready = (uint32_t)(s >> 34) == epoch;
-                    if (__all(ready)) break;
-                    if (++spins > (1u << 22)) { fault = 1u; break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (fault) break;
-                const bool is_prefix = ((s >> 32) & 3u) == kStatePrefix;
-                const uint64_t pmask = __ballot(is_prefix);
-                const uint32_t first = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
-                uint32_t v = (lane <= first) ? (uint32_t)s : 0u;
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
-                for (uint32_t off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-                excl_prefix += v;
-                if (pmask) break;
+    for (uint32_t off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// Spin until the 64-bit word carries this frame's epoch (bounded: the watchdog reports a fault
+// instead of hanging the GPU). Wave-uniform exit.
+__device__ __forceinline__ uint64_t wait_word(const uint64_t* w, bool active, uint32_t epoch, uint32_t& fault) {
+    uint64_t s = pack_status(epoch, kStatePrefix, 0u);
+    uint32_t spins = 0;
+    for (;;) {
+        if (active) s = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ready = (uint32_t)(s >> 34) == epoch;
+        if (__all(ready)) break;
+        if (++spins > (1u << 22)) { fault = 1u; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return s;
+}
+
+// Publish this chunk's survivor count and resolve its exclusive prefix (survivors of all earlier
+// chunks of the instance). Called by wave 0 only; returns the prefix in every lane.
+__device__ __forceinline__ uint32_t resolve_prefix(const ChunkCtx& c, const ScanBufs& sb, uint32_t chunks_per_inst, uint32_t local_alive,
+                                                   uint32_t& fault) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t* cst = sb.chunk_status + (size_t)c.k * chunks_per_inst;
+    uint64_t* gst = sb.group_status + (size_t)c.k * sb.groups_per_inst;
+    const uint32_t j = c.j, g = j / kGroup, jg = j - g * kGroup;
+    const uint32_t n_chunks = (c.n + kChunk - 1) / kChunk;                     // chunks of this instance that have rows
+    const uint32_t g_count = (n_chunks - g * kGroup) < kGroup ? (n_chunks - g * kGroup) : kGroup;
+    uint32_t old = 0;
+    if (lane == 0) {
+        __hip_atomic_store(&cst[j], pack_status(sb.epoch, kStateAggregate, local_alive), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __hip_atomic_fetch_add(&sb.arrive[(size_t)sb.parity * sb.n_groups_total + (size_t)c.k * sb.groups_per_inst + g], 1u, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+    }
+    old = __shfl(old, 0, 64);
+    const bool leader = old + 1u == g_count;  // last chunk of the group to arrive (election only: data is polled below)
+
+    // aggregates of my group: lanes < jg are my predecessors; the leader needs all g_count
+    const uint32_t need = leader ? g_count : jg;
+    const uint64_t s = wait_word(&cst[g * kGroup + lane], lane < need, sb.epoch, fault);
+    const uint32_t agg = (lane < need) ? (uint32_t)s : 0u;
+    const uint32_t intra = wave_sum(lane < jg ? agg : 0u);
+
+    uint32_t group_excl = 0;
+    if (leader) {
+        const uint32_t group_sum = wave_sum(agg);
+        if (g == 0) {
+            if (lane == 0) __hip_atomic_store(&gst[0], pack_status(sb.epoch, kStatePrefix, group_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&gst[g], pack_status(sb.epoch, kStateAggregate, group_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // decoupled look-back over earlier GROUPS (lanes past the first group carry a virtual prefix 0)
+            int hi = (int)g - 1;
+            while (hi >= 0 && !fault) {
+                const int idx = hi - (int)lane;
+                const uint64_t q = wait_word(&gst[idx >= 0 ? idx : 0], idx >= 0, sb.epoch, fault);
+                const bool is_prefix = idx < 0 || ((q >> 32) & 3u) == kStatePrefix;
+                const uint32_t val = idx >= 0 ? (uint32_t)q : 0u;
+                const uint64_t pmask = __ballot(is_prefix);
+                if (pmask) {
+                    const uint32_t first = (uint32_t)__builtin_ctzll(pmask);
+                    group_excl += wave_sum(lane <= first ? val : 0u);
+                    break;
+                }
+                group_excl += wave_sum(val);
                 hi -= 64;
             }
-            if (lane == 0)
-                __hip_atomic_store(&st[j], pack_status(epoch, kStatePrefix, excl_prefix + local_alive), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&gst[g], pack_status(sb.epoch, kStatePrefix, group_excl + group_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    } else if (g > 0) {
+        // inclusive prefix of the previous group
+        uint64_t q;
+        uint32_t spins = 0;
+        for (;;) {
+            q = __hip_atomic_load(&gst[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(q >> 34) == sb.epoch && ((q >> 32) & 3u) == kStatePrefix) break;
+            if (++spins > (1u << 22)) { fault = 1u; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        group_excl = (uint32_t)q;
+    }
+    return group_excl + intra;
+}
+
+// After the chunk's survivors (front) and casualties (back) are staged per segment in LDS.
+// seg_rows: rows per LDS segment; a[w], d[w]: survivor / casualty counts of segment w.
+template <int NSEG>
+__device__ __forceinline__ void chunk_finish(const ChunkCtx& c, const ScanBufs& sb, uint32_t chunks_per_inst, DevMeta* meta_out, const uint32_t* s_list,
+                                             uint32_t seg_rows, const uint32_t (&a)[NSEG], const uint32_t (&d)[NSEG], uint32_t* s_bcast) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t local_alive = 0, local_dead = 0;
+#pragma unroll
+    for (int w = 0; w < NSEG; ++w) { local_alive += a[w]; local_dead += d[w]; }
+    if (wave == 0) {
+        uint32_t fault = 0;
+        const uint32_t excl = resolve_prefix(c, sb, chunks_per_inst, local_alive, fault);
         if (lane == 0) {
-            s_bcast[0] = excl_prefix; s_bcast[1] = fault;
-            if (fault) atomicOr(&ticket[2], 1u);  // watchdog word, reported by hnb_effect_metadata
+            s_bcast[0] = excl; s_bcast[1] = fault;
+            if (fault) atomicOr(&sb.ticket[2], 1u);  // watchdog word, reported by hnb_effect_metadata
         }
     }
     __syncthreads();
     const uint32_t excl_prefix = s_bcast[0];
-
-    // Survivors: stable order (vfx_update.wgsl:161-165 under serial execution).
-    for (uint32_t i = tid; i < local_alive; i += kBlock) c.alive_wr[excl_prefix + i] = s_list[i];
-    // Casualties: the d-th dead particle in serial order lands on dead row n-1-d
-    // (vfx_update.wgsl:150-151: atomicSub(alive_count)-1).
-    const uint32_t dead_before = c.start - excl_prefix;
-    for (uint32_t i = tid; i < local_dead; i += kBlock) c.dead[c.n - 1u - (dead_before + i)] = s_list[kChunk - 1u - i];
-
+    // Survivors in stable (serial) order (vfx_update.wgsl:161-165). Rows already in place are not rewritten.
+    if (!(excl_prefix == c.start && local_dead == 0u)) {
+        uint32_t abase = excl_prefix;
+#pragma unroll
+        for (int w = 0; w < NSEG; ++w) {
+            const uint32_t* sg = s_list + w * seg_rows;
+            for (uint32_t i = tid; i < a[w]; i += kBlock) c.alive[abase + i] = sg[i];
+            abase += a[w];
+        }
+    }
+    // The d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151).
+    if (local_dead) {
+        uint32_t dbase = c.start - excl_prefix;
+#pragma unroll
+        for (int w = 0; w < NSEG; ++w) {
+            const uint32_t* sg = s_list + w * seg_rows;
+            for (uint32_t i = tid; i < d[w]; i += kBlock) c.dead[c.n - 1u - (dbase + i)] = sg[seg_rows - 1u - i];
+            dbase += d[w];
+        }
+    }
     if (tid == 0 && c.start + kChunk >= c.n) {
         const uint32_t survivors = excl_prefix + local_alive;
         DevMeta o;
@@ -318,28 +403,41 @@ __device__ __forceinline__ void chunk_finish(const ChunkCtx& c, const DevProgram
     }
 }
 
+// Persistent-workgroup driver: BODY(chunk) processes one chunk; the next ticket is in flight meanwhile.
+#define HNB_PERSISTENT_LOOP(sb, total_chunks, s_bcast, BODY)                                     \
+    {                                                                                            \
+        uint32_t t_next_ = 0;                                                                    \
+        if (threadIdx.x == 0) s_bcast[2] = claim_ticket(sb);                                     \
+        __syncthreads();                                                                         \
+        uint32_t chunk_ = s_bcast[2];                                                            \
+        if (chunk_ == 0) reset_next_frame(sb);                                                   \
+        while (chunk_ < (total_chunks)) {                                                        \
+            if (threadIdx.x == 0) t_next_ = claim_ticket(sb);                                    \
+            BODY(chunk_);                                                                        \
+            __syncthreads();                                                                     \
+            if (threadIdx.x == 0) s_bcast[2] = t_next_;                                          \
+            __syncthreads();                                                                     \
+            chunk_ = s_bcast[2];                                                                 \
+        }                                                                                        \
+    }
+
 // ---- generic update kernel: any update stream, V register file, one particle per lane ----------
-__global__ void __launch_bounds__(kBlock)
-k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
-                 DevMeta* __restrict__ meta_out, const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks,
-                 uint64_t* status, uint32_t* ticket, uint32_t parity, uint32_t epoch) {
-    __shared__ uint32_t s_list[kChunk];
-    __shared__ uint32_t s_wave[kBlock / 64];
-    __shared__ uint32_t s_bcast[2];
+__device__ __forceinline__ void generic_chunk(uint32_t chunk, const DevProgram& prog, const uint64_t* inst_base, const DevMeta* meta_in,
+                                              DevMeta* meta_out, const DevFrameInst* fi, const uint32_t* ublocks, const ScanBufs& sb,
+                                              uint32_t* s_list, uint32_t* s_wave, uint32_t* s_bcast) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     ChunkCtx c;
-    if (!chunk_begin(c, prog, inst_base, meta_in, meta_out, fi, ticket, parity, s_bcast)) return;
+    if (!chunk_setup(c, chunk, prog, inst_base, meta_in, meta_out, fi)) return;
     const uint32_t seed_k = fi[c.k].seed, slot_base = fi[c.k].slot_base;
     VmUniforms U;
     U.u = ublocks + (size_t)c.k * prog.n_uregs;
     U.xf = fi[c.k].xf;
     uint32_t local_alive = 0, local_dead = 0;
-
     for (uint32_t sub = 0; sub < kChunk / kBlock; ++sub) {
         const uint32_t li = c.start + sub * kBlock + tid;
         if (c.start + sub * kBlock >= c.n) break;
         const bool valid = li < c.n;
-        const uint32_t slot = valid ? c.alive_rd[li] : 0u;
+        const uint32_t slot = valid ? c.alive[li] : 0u;
         VmState<vreg_file_t> S;
         S.r = vreg_file_t{};
         for (uint32_t a = 0; a < prog.n_attrs; ++a) {
@@ -388,7 +486,20 @@ k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, 
         local_dead += total >> 16;
         __syncthreads();
     }
-    chunk_finish(c, prog, meta_out, status, ticket, epoch, local_alive, local_dead, s_list, s_bcast);
+    const uint32_t a1[1] = {local_alive}, d1[1] = {local_dead};
+    chunk_finish<1>(c, sb, prog.chunks_per_inst, meta_out, s_list, kChunk, a1, d1, s_bcast);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+                 DevMeta* __restrict__ meta_out, const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks, const ScanBufs sb) {
+    __shared__ uint32_t s_list[kChunk];
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_bcast[3];
+    const uint32_t total = prog.n_inst * prog.chunks_per_inst;
+#define BODY_(ch) generic_chunk(ch, prog, inst_base, meta_in, meta_out, fi, ublocks, sb, s_list, s_wave, s_bcast)
+    HNB_PERSISTENT_LOOP(sb, total, s_bcast, BODY_)
+#undef BODY_
 }
 
 // ---- streaming update kernel ---------------------------------------------------------------------
@@ -401,8 +512,8 @@ k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, 
 //  * survivors / casualties are ranked inside the wave with ballots (no shuffles, no LDS) and go
 //    straight into the wave's own LDS segment, so the loop contains NO workgroup barrier and
 //    keeps only 4 slot indices live: registers stay low enough for 8 waves per SIMD;
-//  * the workgroup synchronises once, combines the 4 wave totals, runs the cross-chunk
-//    look-back and writes both lists coalesced.
+//  * the workgroup synchronises once, combines the 4 wave totals, resolves the cross-chunk prefix
+//    and writes the lists coalesced (or not at all when nothing moved).
 struct StreamArgs {
     uint32_t capacity, n_uregs, chunks_per_inst, n_inst;
     uint32_t alive_off[2], dead_off, update_len;
@@ -421,63 +532,28 @@ constexpr uint32_t kWaveRows = kChunk / (kBlock / 64);  // 1024 rows per wave
 constexpr uint32_t kStepRows = 64 * 4;                  // 256 rows per wave step
 
 // PROBE (tools/stream_probe.hip only; 0 in the product): ablation bits used to attribute the kernel's
-// time: 1 = no ticket (chunk = blockIdx), 2 = skip look-back + list writes, 4 = skip stores,
-// 8 = skip the program, 16 = skip the alive-list read (assume identity).
-template <class PROG, int WAVES, int PROBE = 0>
-__global__ void __launch_bounds__(kBlock, WAVES)
-k_update_stream(const StreamArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
-                DevMeta* __restrict__ meta_out, const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks,
-                uint64_t* status, uint32_t* ticket, uint32_t parity, uint32_t epoch) {
-    __shared__ uint32_t s_list[kChunk];
-    __shared__ uint32_t s_wave[kBlock / 64];
-    __shared__ uint32_t s_bcast[2];
+// time: 2 = skip prefix resolution + list writes, 4 = skip stores, 8 = skip the program,
+// 16 = skip the alive-list read (assume identity).
+template <class PROG, int PROBE>
+__device__ __forceinline__ void stream_chunk(uint32_t chunk, const StreamArgs& args, const uint64_t* inst_base, const DevMeta* meta_in,
+                                             DevMeta* meta_out, const DevFrameInst* fi, const uint32_t* ublocks, const ScanBufs& sb,
+                                             uint32_t* s_list, uint32_t* s_wave, uint32_t* s_bcast) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-
-    // ---- ticket + counters (vfx_indirect.wgsl:57-85 folded in) ------------------------------------
-    uint32_t chunk;
-    if constexpr (PROBE & 1) {
-        chunk = blockIdx.x;
-    } else {
-        if (tid == 0) {
-            const uint32_t t = __hip_atomic_fetch_add(&ticket[parity], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == 0) __hip_atomic_store(&ticket[parity ^ 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_bcast[0] = t;
-        }
-        __syncthreads();
-        chunk = s_bcast[0];
-    }
-    const uint32_t k = chunk / args.chunks_per_inst;
-    const uint32_t j = chunk - k * args.chunks_per_inst;
-    if (k >= args.n_inst) return;
-    const DevMeta m = meta_in[k];
-    const uint32_t spawn = fi[k].spawn_count;
-    const uint32_t max_spawn = args.capacity - m.alive_count;
-    const uint32_t n_spawn = spawn < max_spawn ? spawn : max_spawn;
-    const uint32_t n = m.alive_count + n_spawn;  // max_update
-    const uint32_t start = j * kChunk;
-    if (n == 0) {
-        if (j == 0 && tid == 0) {
-            DevMeta o = m;
-            o.write_index = m.write_index ^ 1u; o.max_update = 0; o.dead_count = 0; o.spawned = 0; o.instance_count = 0;
-            meta_out[k] = o;
-        }
-        return;
-    }
-    if (start >= n) return;
-    char* base = reinterpret_cast<char*>(inst_base[k]);
-    const uint32_t* alive_rd = reinterpret_cast<const uint32_t*>(base + args.alive_off[m.write_index]);
-
+    ChunkCtx c;
+    if (!chunk_setup(c, chunk, args, inst_base, meta_in, meta_out, fi)) return;
+    const uint32_t n = c.n;
     VmUniforms U;
-    U.u = ublocks + (size_t)k * args.n_uregs;
-    U.xf = fi[k].xf;
-    char* p_pos = base + args.plane_off[0];
-    char* p_vel = base + args.plane_off[1];
-    char* p_age = base + args.plane_off[2];
-    char* p_life = base + args.plane_off[3];
+    U.u = ublocks + (size_t)c.k * args.n_uregs;
+    U.xf = fi[c.k].xf;
+    char* p_pos = c.base + args.plane_off[0];
+    char* p_vel = c.base + args.plane_off[1];
+    char* p_age = c.base + args.plane_off[2];
+    char* p_life = c.base + args.plane_off[3];
     const uint32_t fl = args.flags;
+    const uint32_t* alive_rd = c.alive;
 
     // ---- the wave's private quarter ------------------------------------------------------------------
-    const uint32_t wstart = start + wave * kWaveRows;
+    const uint32_t wstart = c.start + wave * kWaveRows;
     uint32_t* seg = s_list + wave * kWaveRows;
     uint32_t wa = 0, wd = 0;  // wave-uniform survivor / casualty counts of this quarter
     const uint64_t below = (1ull << lane) - 1ull;
@@ -522,8 +598,7 @@ k_update_stream(const StreamArgs args, const uint64_t* __restrict__ inst_base, c
             if (fl & 64u) pin_store1<4>(X.age, p_age, slot, valid, dense);
             if (fl & 128u) pin_store1<4>(X.lifetime, p_life, slot, valid, dense);
         } else {
-            // keep the loads alive
-            float acc = 0.0f;
+            float acc = 0.0f;  // keep the loads alive
 #pragma unroll
             for (int p = 0; p < 4; ++p) acc += X.pos[p].x + X.pos[p].y + X.pos[p].z + X.vel[p].x + X.vel[p].y + X.vel[p].z + X.age[p] + X.lifetime[p];
             if (acc == 123.456f) X.alive[0] = false;
@@ -553,88 +628,32 @@ k_update_stream(const StreamArgs args, const uint64_t* __restrict__ inst_base, c
     if (lane == 0) s_wave[wave] = wa | (wd << 16);
     __syncthreads();
     if constexpr (PROBE & 2) {
-        if (s_wave[0] == 0xffffffffu) meta_out[k].fault = 1;
+        if (s_wave[0] == 0xffffffffu) meta_out[c.k].fault = 1;
         return;
     }
-
-    // ---- combine the 4 quarters, look back across chunks, write the lists ---------------------------
     uint32_t a_w[kBlock / 64], d_w[kBlock / 64];
-    uint32_t local_alive = 0, local_dead = 0;
 #pragma unroll
     for (uint32_t w = 0; w < kBlock / 64; ++w) {
         const uint32_t t = s_wave[w];
         a_w[w] = t & 0xffffu; d_w[w] = t >> 16;
-        local_alive += a_w[w]; local_dead += d_w[w];
     }
-    uint64_t* st = status + (size_t)k * args.chunks_per_inst;
-    if (wave == 0) {
-        uint32_t excl_prefix = 0;
-        uint32_t fault = 0;
-        if (j == 0) {
-            if (lane == 0)
-                __hip_atomic_store(&st[0], pack_status(epoch, kStatePrefix, local_alive), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (lane == 0)
-                __hip_atomic_store(&st[j], pack_status(epoch, kStateAggregate, local_alive), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int hi = (int)j - 1;
-            while (hi >= 0) {
-                const int idx = hi - (int)lane;
-                uint64_t s = pack_status(epoch, kStatePrefix, 0u);  // virtual predecessor before chunk 0
-                uint32_t spins = 0;
-                for (;;) {
-                    if (idx >= 0) s = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool ready = (uint32_t)(s >> 34) == epoch;
-                    if (__all(ready)) break;
-                    if (++spins > (1u << 22)) { fault = 1u; break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (fault) break;
-                const bool is_prefix = ((s >> 32) & 3u) == kStatePrefix;
-                const uint64_t pmask = __ballot(is_prefix);
-                const uint32_t first = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
-                uint32_t v = (lane <= first) ? (uint32_t)s : 0u;
-#pragma unroll
-                for (uint32_t off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-                excl_prefix += v;
-                if (pmask) break;
-                hi -= 64;
-            }
-            if (lane == 0)
-                __hip_atomic_store(&st[j], pack_status(epoch, kStatePrefix, excl_prefix + local_alive), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) {
-            s_bcast[0] = excl_prefix; s_bcast[1] = fault;
-            if (fault) atomicOr(&ticket[2], 1u);  // watchdog word, reported by hnb_effect_metadata
-        }
-    }
-    __syncthreads();
-    const uint32_t excl_prefix = s_bcast[0];
-    uint32_t* alive_wr = reinterpret_cast<uint32_t*>(base + args.alive_off[m.write_index ^ 1u]);
-    uint32_t* dead = reinterpret_cast<uint32_t*>(base + args.dead_off);
-    // Survivors in stable (serial) order: quarter 0's, then quarter 1's, ... (vfx_update.wgsl:161-165).
-    // The d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151).
-    uint32_t abase = excl_prefix, dbase = start - excl_prefix;
-#pragma unroll
-    for (uint32_t w = 0; w < kBlock / 64; ++w) {
-        const uint32_t* sg = s_list + w * kWaveRows;
-        for (uint32_t i = tid; i < a_w[w]; i += kBlock) alive_wr[abase + i] = sg[i];
-        for (uint32_t i = tid; i < d_w[w]; i += kBlock) dead[n - 1u - (dbase + i)] = sg[kWaveRows - 1u - i];
-        abase += a_w[w];
-        dbase += d_w[w];
-    }
-    if (tid == 0 && start + kChunk >= n) {
-        const uint32_t survivors = excl_prefix + local_alive;
-        DevMeta o;
-        o.alive_count = survivors;
-        o.particle_counter = m.particle_counter + n_spawn;
-        o.write_index = m.write_index ^ 1u;
-        o.max_update = n;
-        o.dead_count = n - survivors;
-        o.spawned = n_spawn;
-        o.fault = m.fault | s_bcast[1];
-        o.instance_count = survivors;
-        meta_out[k] = o;
+    chunk_finish<kBlock / 64>(c, sb, args.chunks_per_inst, meta_out, s_list, kWaveRows, a_w, d_w, s_bcast);
+}
+
+template <class PROG, int WAVES, int PROBE = 0>
+__global__ void __launch_bounds__(kBlock, WAVES)
+k_update_stream(const StreamArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+                DevMeta* __restrict__ meta_out, const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks, const ScanBufs sb) {
+    __shared__ uint32_t s_list[kChunk];
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_bcast[3];
+    const uint32_t total = args.n_inst * args.chunks_per_inst;
+    if constexpr (PROBE & 1) {  // no ticket: one chunk per workgroup, id = blockIdx
+        stream_chunk<PROG, PROBE>(blockIdx.x, args, inst_base, meta_in, meta_out, fi, ublocks, sb, s_list, s_wave, s_bcast);
+    } else {
+#define BODY_(ch) stream_chunk<PROG, PROBE>(ch, args, inst_base, meta_in, meta_out, fi, ublocks, sb, s_list, s_wave, s_bcast)
+        HNB_PERSISTENT_LOOP(sb, total, s_bcast, BODY_)
+#undef BODY_
     }
 }
 

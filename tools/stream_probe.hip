@@ -95,6 +95,14 @@ int main(int argc, char** argv) {
     uint64_t base_addr = (uint64_t)slab; uint64_t* dbase; CK(hipMalloc(&dbase, 8)); CK(hipMemcpy(dbase, &base_addr, 8, hipMemcpyHostToDevice));
     uint64_t* status; CK(hipMalloc(&status, (size_t)sa.chunks_per_inst * 8)); CK(hipMemset(status, 0, (size_t)sa.chunks_per_inst * 8));
     uint32_t* ticket; CK(hipMalloc(&ticket, 16)); CK(hipMemset(ticket, 0, 16));
+    ScanBufs sb;
+    sb.groups_per_inst = (sa.chunks_per_inst + kGroup - 1) / kGroup;
+    sb.n_groups_total = sb.groups_per_inst;
+    sb.chunk_status = status;
+    CK(hipMalloc(&sb.group_status, (size_t)sb.n_groups_total * 8)); CK(hipMemset(sb.group_status, 0, (size_t)sb.n_groups_total * 8));
+    CK(hipMalloc(&sb.arrive, (size_t)sb.n_groups_total * 8)); CK(hipMemset(sb.arrive, 0, (size_t)sb.n_groups_total * 8));
+    sb.ticket = ticket; sb.parity = 0; sb.epoch = 1;
+    int dev_cus = 256; { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, 0) == hipSuccess) dev_cus = pr.multiProcessorCount; }
     const double bytes = (double)cap * 68.0;
     uint32_t epoch = 1;
     const uint32_t grid = sa.chunks_per_inst;
@@ -102,13 +110,18 @@ int main(int argc, char** argv) {
     {                                                                                                                            \
         float ms = time_ms(iters, [&] {                                                                                          \
             CK(hipMemsetAsync(ticket, 0, 8));                                                                                    \
-            k_update_stream<ProgDragAccel, WAVES, PROBE><<<grid, kBlock>>>(sa, dbase, dmeta, dmeta + 1, dfi, dub, status, ticket, 0, epoch++); \
+            CK(hipMemsetAsync(sb.arrive, 0, (size_t)sb.n_groups_total * 8));                                                     \
+            sb.epoch = epoch++;                                                                                                  \
+            const uint32_t g_ = ((PROBE) & 1) ? grid : (grid < (uint32_t)dev_cus * 8u ? grid : (uint32_t)dev_cus * 8u);          \
+            k_update_stream<ProgDragAccel, WAVES, PROBE><<<g_, kBlock>>>(sa, dbase, dmeta, dmeta + 1, dfi, dub, sb);              \
         });                                                                                                                      \
         printf("%-44s %8.3f ms  %7.1f GB/s (68 B/particle)\n", NAME, ms, bytes / ms / 1e6);                                       \
     }
     RUN("full kernel (waves 8)", 0, 8)
+    RUN("full kernel (waves 6)", 0, 6)
+    RUN("full kernel (waves 5)", 0, 5)
     RUN("full kernel (waves 4)", 0, 4)
-    RUN("no ticket", 1, 8)
+    RUN("no ticket (1 chunk per block)", 1, 8)
     RUN("no finish (look-back + list writes)", 2, 8)
     RUN("no ticket, no finish", 3, 8)
     RUN("no ticket, no finish, no stores", 7, 8)
