@@ -284,15 +284,15 @@ __device__ __forceinline__ uint64_t wait_word(const uint64_t* w, bool active, ui
     return s;
 }
 
-// Publish this chunk's survivor count and resolve its exclusive prefix (survivors of all earlier
-// chunks of the instance). Called by wave 0 only; returns the prefix in every lane.
-__device__ __forceinline__ uint32_t resolve_prefix(const ChunkCtx& c, const ScanBufs& sb, uint32_t chunks_per_inst, uint32_t local_alive,
-                                                   uint32_t& fault) {
+// Publish this chunk's survivor count (wave 0). The last chunk of a group to arrive also publishes
+// the group aggregate and resolves the group's prefix from the earlier groups. Nothing here waits on
+// a chunk that has not been claimed, and processing a claimed chunk never waits at all.
+__device__ __forceinline__ void publish_chunk(const ChunkCtx& c, const ScanBufs& sb, uint32_t chunks_per_inst, uint32_t local_alive, uint32_t& fault) {
     const uint32_t lane = threadIdx.x & 63u;
     uint64_t* cst = sb.chunk_status + (size_t)c.k * chunks_per_inst;
     uint64_t* gst = sb.group_status + (size_t)c.k * sb.groups_per_inst;
-    const uint32_t j = c.j, g = j / kGroup, jg = j - g * kGroup;
-    const uint32_t n_chunks = (c.n + kChunk - 1) / kChunk;                     // chunks of this instance that have rows
+    const uint32_t j = c.j, g = j / kGroup;
+    const uint32_t n_chunks = (c.n + kChunk - 1) / kChunk;  // chunks of this instance that have rows
     const uint32_t g_count = (n_chunks - g * kGroup) < kGroup ? (n_chunks - g * kGroup) : kGroup;
     uint32_t old = 0;
     if (lane == 0) {
@@ -301,41 +301,44 @@ __device__ __forceinline__ uint32_t resolve_prefix(const ChunkCtx& c, const Scan
                                      __HIP_MEMORY_SCOPE_AGENT);
     }
     old = __shfl(old, 0, 64);
-    const bool leader = old + 1u == g_count;  // last chunk of the group to arrive (election only: data is polled below)
-
-    // aggregates of my group: lanes < jg are my predecessors; the leader needs all g_count
-    const uint32_t need = leader ? g_count : jg;
-    const uint64_t s = wait_word(&cst[g * kGroup + lane], lane < need, sb.epoch, fault);
-    const uint32_t agg = (lane < need) ? (uint32_t)s : 0u;
-    const uint32_t intra = wave_sum(lane < jg ? agg : 0u);
-
+    if (old + 1u != g_count) return;  // not the last arriver (election only: the data itself is polled)
+    const uint64_t s = wait_word(&cst[g * kGroup + lane], lane < g_count, sb.epoch, fault);
+    const uint32_t group_sum = wave_sum(lane < g_count ? (uint32_t)s : 0u);
+    if (g == 0) {
+        if (lane == 0) __hip_atomic_store(&gst[0], pack_status(sb.epoch, kStatePrefix, group_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (lane == 0) __hip_atomic_store(&gst[g], pack_status(sb.epoch, kStateAggregate, group_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // decoupled look-back over earlier GROUPS (lanes past the first group carry a virtual prefix 0)
     uint32_t group_excl = 0;
-    if (leader) {
-        const uint32_t group_sum = wave_sum(agg);
-        if (g == 0) {
-            if (lane == 0) __hip_atomic_store(&gst[0], pack_status(sb.epoch, kStatePrefix, group_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (lane == 0) __hip_atomic_store(&gst[g], pack_status(sb.epoch, kStateAggregate, group_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // decoupled look-back over earlier GROUPS (lanes past the first group carry a virtual prefix 0)
-            int hi = (int)g - 1;
-            while (hi >= 0 && !fault) {
-                const int idx = hi - (int)lane;
-                const uint64_t q = wait_word(&gst[idx >= 0 ? idx : 0], idx >= 0, sb.epoch, fault);
-                const bool is_prefix = idx < 0 || ((q >> 32) & 3u) == kStatePrefix;
-                const uint32_t val = idx >= 0 ? (uint32_t)q : 0u;
-                const uint64_t pmask = __ballot(is_prefix);
-                if (pmask) {
-                    const uint32_t first = (uint32_t)__builtin_ctzll(pmask);
-                    group_excl += wave_sum(lane <= first ? val : 0u);
-                    break;
-                }
-                group_excl += wave_sum(val);
-                hi -= 64;
-            }
-            if (lane == 0) __hip_atomic_store(&gst[g], pack_status(sb.epoch, kStatePrefix, group_excl + group_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int hi = (int)g - 1;
+    while (hi >= 0 && !fault) {
+        const int idx = hi - (int)lane;
+        const uint64_t q = wait_word(&gst[idx >= 0 ? idx : 0], idx >= 0, sb.epoch, fault);
+        const bool is_prefix = idx < 0 || ((q >> 32) & 3u) == kStatePrefix;
+        const uint32_t val = idx >= 0 ? (uint32_t)q : 0u;
+        const uint64_t pmask = __ballot(is_prefix);
+        if (pmask) {
+            const uint32_t first = (uint32_t)__builtin_ctzll(pmask);
+            group_excl += wave_sum(lane <= first ? val : 0u);
+            break;
         }
-    } else if (g > 0) {
-        // inclusive prefix of the previous group
+        group_excl += wave_sum(val);
+        hi -= 64;
+    }
+    if (lane == 0) __hip_atomic_store(&gst[g], pack_status(sb.epoch, kStatePrefix, group_excl + group_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Exclusive prefix of a published chunk (wave 0): survivors of all earlier chunks of the instance.
+__device__ __forceinline__ uint32_t resolve_chunk(const ChunkCtx& c, const ScanBufs& sb, uint32_t chunks_per_inst, uint32_t& fault) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t* cst = sb.chunk_status + (size_t)c.k * chunks_per_inst;
+    const uint64_t* gst = sb.group_status + (size_t)c.k * sb.groups_per_inst;
+    const uint32_t g = c.j / kGroup, jg = c.j - g * kGroup;
+    const uint64_t s = wait_word(&cst[g * kGroup + lane], lane < jg, sb.epoch, fault);
+    const uint32_t intra = wave_sum(lane < jg ? (uint32_t)s : 0u);
+    uint32_t group_excl = 0;
+    if (g > 0) {  // inclusive prefix of the previous group
         uint64_t q;
         uint32_t spins = 0;
         for (;;) {
@@ -349,21 +352,33 @@ __device__ __forceinline__ uint32_t resolve_prefix(const ChunkCtx& c, const Scan
     return group_excl + intra;
 }
 
-// After the chunk's survivors (front) and casualties (back) are staged per segment in LDS.
-// seg_rows: rows per LDS segment; a[w], d[w]: survivor / casualty counts of segment w.
+// Staged chunk: survivors (front) and casualties (back) of NSEG LDS segments of seg_rows rows each;
+// s_cnt[w] = survivors | casualties << 16 of segment w.
 template <int NSEG>
-__device__ __forceinline__ void chunk_finish(const ChunkCtx& c, const ScanBufs& sb, uint32_t chunks_per_inst, DevMeta* meta_out, const uint32_t* s_list,
-                                             uint32_t seg_rows, const uint32_t (&a)[NSEG], const uint32_t (&d)[NSEG], uint32_t* s_bcast) {
+__device__ __forceinline__ void chunk_publish(const ChunkCtx& c, const ScanBufs& sb, uint32_t chunks_per_inst, const uint32_t* s_cnt, uint32_t* s_bcast) {
+    if ((threadIdx.x >> 6) != 0) return;
+    uint32_t local_alive = 0;
+#pragma unroll
+    for (int w = 0; w < NSEG; ++w) local_alive += s_cnt[w] & 0xffffu;
+    uint32_t fault = 0;
+    publish_chunk(c, sb, chunks_per_inst, local_alive, fault);
+    if ((threadIdx.x & 63u) == 0 && fault) atomicOr(&sb.ticket[2], 1u);  // watchdog word, reported by hnb_effect_metadata
+}
+
+template <int NSEG>
+__device__ __forceinline__ void chunk_commit(const ChunkCtx& c, const ScanBufs& sb, uint32_t chunks_per_inst, DevMeta* meta_out, const uint32_t* s_list,
+                                             uint32_t seg_rows, const uint32_t* s_cnt, uint32_t* s_bcast) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t a[NSEG], d[NSEG];
     uint32_t local_alive = 0, local_dead = 0;
 #pragma unroll
-    for (int w = 0; w < NSEG; ++w) { local_alive += a[w]; local_dead += d[w]; }
+    for (int w = 0; w < NSEG; ++w) { a[w] = s_cnt[w] & 0xffffu; d[w] = s_cnt[w] >> 16; local_alive += a[w]; local_dead += d[w]; }
     if (wave == 0) {
         uint32_t fault = 0;
-        const uint32_t excl = resolve_prefix(c, sb, chunks_per_inst, local_alive, fault);
+        const uint32_t excl = resolve_chunk(c, sb, chunks_per_inst, fault);
         if (lane == 0) {
             s_bcast[0] = excl; s_bcast[1] = fault;
-            if (fault) atomicOr(&sb.ticket[2], 1u);  // watchdog word, reported by hnb_effect_metadata
+            if (fault) atomicOr(&sb.ticket[2], 1u);
         }
     }
     __syncthreads();
@@ -403,31 +418,39 @@ __device__ __forceinline__ void chunk_finish(const ChunkCtx& c, const ScanBufs& 
     }
 }
 
-// Persistent-workgroup driver: BODY(chunk) processes one chunk; the next ticket is in flight meanwhile.
-#define HNB_PERSISTENT_LOOP(sb, total_chunks, s_bcast, BODY)                                     \
+// Persistent-workgroup driver, software-pipelined at chunk granularity:
+//   PROCESS(chunk, buf) -> bool : stage the chunk into LDS buffer `buf` and publish its aggregate
+//   COMMIT(chunk, buf)          : resolve the prefix and write the lists of a chunk staged earlier
+// The commit of chunk i runs after chunk i+1 has been processed, so the look-back words it needs
+// were published a whole chunk-time ago, and the next ticket (requested before processing) has
+// long arrived: neither latency is exposed except once at the tail.
+#define HNB_PERSISTENT_LOOP(sb, total_chunks, s_bcast, PROCESS, COMMIT)                          \
     {                                                                                            \
-        uint32_t t_next_ = 0;                                                                    \
+        uint32_t t_next_ = 0, prev_ = 0xffffffffu, buf_ = 0;                                     \
         if (threadIdx.x == 0) s_bcast[2] = claim_ticket(sb);                                     \
         __syncthreads();                                                                         \
         uint32_t chunk_ = s_bcast[2];                                                            \
         if (chunk_ == 0) reset_next_frame(sb);                                                   \
         while (chunk_ < (total_chunks)) {                                                        \
             if (threadIdx.x == 0) t_next_ = claim_ticket(sb);                                    \
-            BODY(chunk_);                                                                        \
+            const bool staged_ = PROCESS(chunk_, buf_);                                          \
+            if (prev_ != 0xffffffffu) { COMMIT(prev_, buf_ ^ 1u); }                              \
+            if (staged_) { prev_ = chunk_; buf_ ^= 1u; } else { prev_ = 0xffffffffu; }           \
             __syncthreads();                                                                     \
             if (threadIdx.x == 0) s_bcast[2] = t_next_;                                          \
             __syncthreads();                                                                     \
             chunk_ = s_bcast[2];                                                                 \
         }                                                                                        \
+        if (prev_ != 0xffffffffu) { COMMIT(prev_, buf_ ^ 1u); }                                  \
     }
 
 // ---- generic update kernel: any update stream, V register file, one particle per lane ----------
-__device__ __forceinline__ void generic_chunk(uint32_t chunk, const DevProgram& prog, const uint64_t* inst_base, const DevMeta* meta_in,
-                                              DevMeta* meta_out, const DevFrameInst* fi, const uint32_t* ublocks, const ScanBufs& sb,
-                                              uint32_t* s_list, uint32_t* s_wave, uint32_t* s_bcast) {
+__device__ __forceinline__ bool generic_process(uint32_t chunk, const DevProgram& prog, const uint64_t* inst_base, const DevMeta* meta_in,
+                                                DevMeta* meta_out, const DevFrameInst* fi, const uint32_t* ublocks, const ScanBufs& sb,
+                                                uint32_t* s_list, uint32_t* s_cnt, uint32_t* s_wave, uint32_t* s_bcast) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     ChunkCtx c;
-    if (!chunk_setup(c, chunk, prog, inst_base, meta_in, meta_out, fi)) return;
+    if (!chunk_setup(c, chunk, prog, inst_base, meta_in, meta_out, fi)) return false;
     const uint32_t seed_k = fi[c.k].seed, slot_base = fi[c.k].slot_base;
     VmUniforms U;
     U.u = ublocks + (size_t)c.k * prog.n_uregs;
@@ -486,20 +509,31 @@ __device__ __forceinline__ void generic_chunk(uint32_t chunk, const DevProgram& 
         local_dead += total >> 16;
         __syncthreads();
     }
-    const uint32_t a1[1] = {local_alive}, d1[1] = {local_dead};
-    chunk_finish<1>(c, sb, prog.chunks_per_inst, meta_out, s_list, kChunk, a1, d1, s_bcast);
+    if (tid == 0) s_cnt[0] = local_alive | (local_dead << 16);
+    __syncthreads();
+    chunk_publish<1>(c, sb, prog.chunks_per_inst, s_cnt, s_bcast);
+    return true;
 }
 
 __global__ void __launch_bounds__(kBlock)
 k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
                  DevMeta* __restrict__ meta_out, const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks, const ScanBufs sb) {
-    __shared__ uint32_t s_list[kChunk];
+    // 65536-row chunks would not fit twice: the generic kernel stages 4096 rows per buffer like the streaming one
+    __shared__ uint32_t s_list[2][kChunk];
+    __shared__ uint32_t s_cnt[2][1];
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_bcast[3];
     const uint32_t total = prog.n_inst * prog.chunks_per_inst;
-#define BODY_(ch) generic_chunk(ch, prog, inst_base, meta_in, meta_out, fi, ublocks, sb, s_list, s_wave, s_bcast)
-    HNB_PERSISTENT_LOOP(sb, total, s_bcast, BODY_)
-#undef BODY_
+#define PROCESS_(ch, buf) generic_process(ch, prog, inst_base, meta_in, meta_out, fi, ublocks, sb, s_list[buf], s_cnt[buf], s_wave, s_bcast)
+#define COMMIT_(ch, buf)                                                                                     \
+    {                                                                                                        \
+        ChunkCtx pc_;                                                                                        \
+        chunk_setup(pc_, ch, prog, inst_base, meta_in, meta_out, fi);                                        \
+        chunk_commit<1>(pc_, sb, prog.chunks_per_inst, meta_out, s_list[buf], kChunk, s_cnt[buf], s_bcast);  \
+    }
+    HNB_PERSISTENT_LOOP(sb, total, s_bcast, PROCESS_, COMMIT_)
+#undef PROCESS_
+#undef COMMIT_
 }
 
 // ---- streaming update kernel ---------------------------------------------------------------------
@@ -535,12 +569,12 @@ constexpr uint32_t kStepRows = 64 * 4;                  // 256 rows per wave ste
 // time: 2 = skip prefix resolution + list writes, 4 = skip stores, 8 = skip the program,
 // 16 = skip the alive-list read (assume identity).
 template <class PROG, int PROBE>
-__device__ __forceinline__ void stream_chunk(uint32_t chunk, const StreamArgs& args, const uint64_t* inst_base, const DevMeta* meta_in,
-                                             DevMeta* meta_out, const DevFrameInst* fi, const uint32_t* ublocks, const ScanBufs& sb,
-                                             uint32_t* s_list, uint32_t* s_wave, uint32_t* s_bcast) {
+__device__ __forceinline__ bool stream_process(uint32_t chunk, const StreamArgs& args, const uint64_t* inst_base, const DevMeta* meta_in,
+                                               DevMeta* meta_out, const DevFrameInst* fi, const uint32_t* ublocks, const ScanBufs& sb,
+                                               uint32_t* s_list, uint32_t* s_wave, uint32_t* s_bcast) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     ChunkCtx c;
-    if (!chunk_setup(c, chunk, args, inst_base, meta_in, meta_out, fi)) return;
+    if (!chunk_setup(c, chunk, args, inst_base, meta_in, meta_out, fi)) return false;
     const uint32_t n = c.n;
     VmUniforms U;
     U.u = ublocks + (size_t)c.k * args.n_uregs;
@@ -629,32 +663,34 @@ __device__ __forceinline__ void stream_chunk(uint32_t chunk, const StreamArgs& a
     __syncthreads();
     if constexpr (PROBE & 2) {
         if (s_wave[0] == 0xffffffffu) meta_out[c.k].fault = 1;
-        return;
+        return false;
     }
-    uint32_t a_w[kBlock / 64], d_w[kBlock / 64];
-#pragma unroll
-    for (uint32_t w = 0; w < kBlock / 64; ++w) {
-        const uint32_t t = s_wave[w];
-        a_w[w] = t & 0xffffu; d_w[w] = t >> 16;
-    }
-    chunk_finish<kBlock / 64>(c, sb, args.chunks_per_inst, meta_out, s_list, kWaveRows, a_w, d_w, s_bcast);
+    chunk_publish<kBlock / 64>(c, sb, args.chunks_per_inst, s_wave, s_bcast);
+    return true;
 }
 
 template <class PROG, int WAVES, int PROBE = 0>
 __global__ void __launch_bounds__(kBlock, WAVES)
 k_update_stream(const StreamArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
                 DevMeta* __restrict__ meta_out, const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks, const ScanBufs sb) {
-    __shared__ uint32_t s_list[kChunk];
-    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_list[2][kChunk];           // two staged chunks: commit of one overlaps processing of the next
+    __shared__ uint32_t s_wave[2][kBlock / 64];
     __shared__ uint32_t s_bcast[3];
     const uint32_t total = args.n_inst * args.chunks_per_inst;
-    if constexpr (PROBE & 1) {  // no ticket: one chunk per workgroup, id = blockIdx
-        stream_chunk<PROG, PROBE>(blockIdx.x, args, inst_base, meta_in, meta_out, fi, ublocks, sb, s_list, s_wave, s_bcast);
-    } else {
-#define BODY_(ch) stream_chunk<PROG, PROBE>(ch, args, inst_base, meta_in, meta_out, fi, ublocks, sb, s_list, s_wave, s_bcast)
-        HNB_PERSISTENT_LOOP(sb, total, s_bcast, BODY_)
-#undef BODY_
+#define PROCESS_(ch, buf) stream_process<PROG, PROBE>(ch, args, inst_base, meta_in, meta_out, fi, ublocks, sb, s_list[buf], s_wave[buf], s_bcast)
+#define COMMIT_(ch, buf)                                                                                                      \
+    {                                                                                                                         \
+        ChunkCtx pc_;                                                                                                         \
+        chunk_setup(pc_, ch, args, inst_base, meta_in, meta_out, fi);                                                         \
+        chunk_commit<kBlock / 64>(pc_, sb, args.chunks_per_inst, meta_out, s_list[buf], kWaveRows, s_wave[buf], s_bcast);     \
     }
+    if constexpr (PROBE & 1) {  // no ticket: one chunk per workgroup, id = blockIdx
+        if (PROCESS_(blockIdx.x, 0)) { COMMIT_(blockIdx.x, 0) }
+    } else {
+        HNB_PERSISTENT_LOOP(sb, total, s_bcast, PROCESS_, COMMIT_)
+    }
+#undef PROCESS_
+#undef COMMIT_
 }
 
 }  // namespace hnb
