@@ -52,11 +52,11 @@ struct TimingPair { hipEvent_t a, b; };
 // Statically specialised op sequences for the common modifier stacks (the reference's example
 // effects), plus the interpreter for every other streamable sequence.
 typedef void (*StreamLaunchFn)(uint32_t grid, hipStream_t stream, const StreamArgs& sa, const uint64_t* inst_base, const DevMeta* meta_in,
-                               DevMeta* meta_out, const DevFrameInst* fi, const uint32_t* ublocks, const ScanBufs& sb);
+                               const DevFrameInst* fi, const uint32_t* ublocks, const CompactBufs& cb);
 template <class PROG, int WAVES>
-void launch_stream(uint32_t grid, hipStream_t stream, const StreamArgs& sa, const uint64_t* inst_base, const DevMeta* meta_in, DevMeta* meta_out,
-                   const DevFrameInst* fi, const uint32_t* ublocks, const ScanBufs& sb) {
-    k_update_stream<PROG, WAVES><<<grid, kBlock, 0, stream>>>(sa, inst_base, meta_in, meta_out, fi, ublocks, sb);
+void launch_stream(uint32_t grid, hipStream_t stream, const StreamArgs& sa, const uint64_t* inst_base, const DevMeta* meta_in,
+                   const DevFrameInst* fi, const uint32_t* ublocks, const CompactBufs& cb) {
+    k_update_stream<PROG, WAVES><<<grid, kBlock, 0, stream>>>(sa, inst_base, meta_in, fi, ublocks, cb);
 }
 #define OP_(x) (uint32_t)HNB_OP_M_##x
 typedef ProgStatic<OP_(AGE_TICK)> ProgAge;                                                        // ribbon.rs
@@ -93,11 +93,13 @@ struct HnbContext {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t upload_stream = nullptr;  // per-frame parameter uploads, overlapped with the previous frame's kernels
     uint32_t num_cus = 256;
     std::vector<HnbProgram*> programs;
     HnbSimParams sim{};
-    bool timing = false;
-    std::vector<TimingPair> t_update, t_init;
+    uint32_t timing = 0;        // 0 = off, n = time every n-th simulated frame
+    uint32_t timing_tick = 0;
+    std::vector<TimingPair> t_update, t_init, t_compact;
 };
 
 struct HnbProgram {
@@ -117,17 +119,14 @@ struct HnbProgram {
     uint32_t table_cap = 0;
     uint64_t* d_inst_base = nullptr;
     DevMeta* d_meta[2] = {nullptr, nullptr};
-    uint64_t* d_status = nullptr;        // per chunk
-    uint64_t* d_group_status = nullptr;  // per look-back group
-    uint32_t* d_arrive = nullptr;        // [2][groups]: arrival counters, frame-parity double-buffered
-    uint32_t groups_per_inst = 1;
-    uint32_t* d_ticket = nullptr;  // [2] tickets + [1] fault word
+    uint32_t* d_counts = nullptr;  // per chunk: survivors this frame
+    uint32_t* d_deaths = nullptr;  // [2][table_cap]: casualties per instance, frame-parity double-buffered
     void* h_frame[2] = {nullptr, nullptr};
     void* d_frame[2] = {nullptr, nullptr};
-    hipEvent_t frame_done[2] = {nullptr, nullptr};
+    hipEvent_t upload_done[2] = {nullptr, nullptr};   // recorded on the upload stream
+    hipEvent_t kernels_done[2] = {nullptr, nullptr};  // recorded on the simulation stream
     size_t frame_bytes = 0;
     uint32_t parity = 0;
-    uint32_t epoch = 1;
 };
 
 struct HnbEffect {
@@ -328,10 +327,8 @@ void free_tables(HnbProgram* p) {
         if (p->h_frame[i]) hipHostFree(p->h_frame[i]);
         p->h_frame[i] = nullptr;
     }
-    hipFree(p->d_status); p->d_status = nullptr;
-    hipFree(p->d_group_status); p->d_group_status = nullptr;
-    hipFree(p->d_arrive); p->d_arrive = nullptr;
-    hipFree(p->d_ticket); p->d_ticket = nullptr;
+    hipFree(p->d_counts); p->d_counts = nullptr;
+    hipFree(p->d_deaths); p->d_deaths = nullptr;
     p->table_cap = 0;
 }
 
@@ -347,24 +344,20 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
     const uint32_t cap = std::max<uint32_t>(need, std::max<uint32_t>(4, p->table_cap * 2));
     uint64_t* nb = nullptr;
     DevMeta* nm[2] = {nullptr, nullptr};
-    uint64_t* ns = nullptr;
+    uint32_t* ns = nullptr;
+    uint32_t* nd = nullptr;
     HIP_TRY(hipMalloc(&nb, (size_t)cap * 8));
     HIP_TRY(hipMemset(nb, 0, (size_t)cap * 8));
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipMalloc(&nm[i], (size_t)cap * sizeof(DevMeta)));
         HIP_TRY(hipMemset(nm[i], 0, (size_t)cap * sizeof(DevMeta)));
     }
-    const size_t n_status = (size_t)cap * p->dev.chunks_per_inst;
-    HIP_TRY(hipMalloc(&ns, n_status * 8));
-    HIP_TRY(hipMemset(ns, 0, n_status * 8));
-    p->groups_per_inst = (p->dev.chunks_per_inst + kGroup - 1) / kGroup;
-    const size_t n_groups = (size_t)cap * p->groups_per_inst;
-    hipFree(p->d_group_status);
-    hipFree(p->d_arrive);
-    HIP_TRY(hipMalloc(&p->d_group_status, n_groups * 8));
-    HIP_TRY(hipMemset(p->d_group_status, 0, n_groups * 8));
-    HIP_TRY(hipMalloc(&p->d_arrive, 2 * n_groups * 4));
-    HIP_TRY(hipMemset(p->d_arrive, 0, 2 * n_groups * 4));
+    const size_t n_counts = (size_t)cap * p->dev.chunks_per_inst;
+    HIP_TRY(hipMalloc(&ns, n_counts * 4));
+    HIP_TRY(hipMemset(ns, 0, n_counts * 4));
+    // casualty counters are zero between frames (k_compact re-arms them), so a fresh table is valid
+    HIP_TRY(hipMalloc(&nd, (size_t)2 * cap * 4));
+    HIP_TRY(hipMemset(nd, 0, (size_t)2 * cap * 4));
     if (p->table_cap) {
         HIP_TRY(hipMemcpy(nb, p->d_inst_base, (size_t)p->table_cap * 8, hipMemcpyDeviceToDevice));
         for (int i = 0; i < 2; ++i)
@@ -373,15 +366,13 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
     hipFree(p->d_inst_base);
     hipFree(p->d_meta[0]);
     hipFree(p->d_meta[1]);
-    hipFree(p->d_status);
+    hipFree(p->d_counts);
+    hipFree(p->d_deaths);
     p->d_inst_base = nb;
     p->d_meta[0] = nm[0];
     p->d_meta[1] = nm[1];
-    p->d_status = ns;
-    if (!p->d_ticket) {
-        HIP_TRY(hipMalloc(&p->d_ticket, 16));
-        HIP_TRY(hipMemset(p->d_ticket, 0, 16));
-    }
+    p->d_counts = ns;
+    p->d_deaths = nd;
     const size_t fb = frame_bytes_for(p, cap);
     for (int i = 0; i < 2; ++i) {
         hipFree(p->d_frame[i]);
@@ -389,7 +380,8 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
         p->d_frame[i] = nullptr; p->h_frame[i] = nullptr;
         HIP_TRY(hipMalloc(&p->d_frame[i], fb));
         HIP_TRY(hipHostMalloc(&p->h_frame[i], fb, hipHostMallocDefault));
-        if (!p->frame_done[i]) HIP_TRY(hipEventCreateWithFlags(&p->frame_done[i], hipEventDisableTiming));
+        if (!p->upload_done[i]) HIP_TRY(hipEventCreateWithFlags(&p->upload_done[i], hipEventDisableTiming));
+        if (!p->kernels_done[i]) HIP_TRY(hipEventCreateWithFlags(&p->kernels_done[i], hipEventDisableTiming));
     }
     p->frame_bytes = fb;
     p->table_cap = cap;
@@ -402,13 +394,10 @@ int find_attr(const HnbProgram* p, uint32_t attr) {
     return -1;
 }
 
-int read_meta(HnbEffect* fx, DevMeta* out, uint32_t* fault_word) {
+int read_meta(HnbEffect* fx, DevMeta* out) {
     HnbProgram* p = fx->prog;
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     HIP_TRY(hipMemcpy(out, p->d_meta[p->parity] + fx->index, sizeof(DevMeta), hipMemcpyDeviceToHost));
-    uint32_t t[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(t, p->d_ticket, 16, hipMemcpyDeviceToHost));
-    if (fault_word) *fault_word = t[2];
     return HNB_OK;
 }
 
@@ -431,6 +420,8 @@ int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(HNB_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     ctx->own_stream = true;
+    e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return fail(HNB_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     *out_ctx = ctx;
@@ -445,6 +436,7 @@ int hnb_ctx_destroy(HnbContext* ctx) {
     for (auto& t : ctx->t_update) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (auto& t : ctx->t_init) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    if (ctx->upload_stream) hipStreamDestroy(ctx->upload_stream);
     delete ctx;
     return HNB_OK;
 }
@@ -490,11 +482,12 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     d.chunks_per_inst = (h.capacity + kChunk - 1) / kChunk;
     d.init_len = h.init_len;
     d.update_len = h.update_len;
-    // Slab layout: [alive ping][alive pong][dead][attribute planes...], 256-byte aligned planes.
+    // Slab layout: [alive list column 0][column 1][dead list][attribute planes...], 256-byte aligned.
+    // The alive list moves to the other column only in frames where particles died (k_compact).
     size_t off = 0;
     const size_t list_bytes = align_up((size_t)h.capacity * 4, 256);
-    d.alive_off[0] = (uint32_t)off; off += list_bytes;  // one alive list, compacted in place (no ping-pong column)
-    d.alive_off[1] = d.alive_off[0];
+    d.alive_off[0] = (uint32_t)off; off += list_bytes;
+    d.alive_off[1] = (uint32_t)off; off += list_bytes;
     d.dead_off = (uint32_t)off; off += list_bytes;
     for (uint32_t i = 0; i < h.n_attrs; ++i) {
         if (off > 0xffffffffull) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB"); }
@@ -543,7 +536,10 @@ int hnb_program_destroy(HnbProgram* p) {
     hipStreamSynchronize(ctx->stream);
     while (!p->effects.empty()) hnb_effect_destroy(p->effects.back());
     free_tables(p);
-    for (int i = 0; i < 2; ++i) if (p->frame_done[i]) hipEventDestroy(p->frame_done[i]);
+    for (int i = 0; i < 2; ++i) {
+        if (p->upload_done[i]) hipEventDestroy(p->upload_done[i]);
+        if (p->kernels_done[i]) hipEventDestroy(p->kernels_done[i]);
+    }
     hipFree(p->d_code);
     ctx->programs.erase(std::remove(ctx->programs.begin(), ctx->programs.end(), p), ctx->programs.end());
     delete p;
@@ -567,7 +563,8 @@ int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
     char* base = static_cast<char*>(fx->slab);
     const uint32_t cap = p->dev.capacity;
     k_reset_lists<<<(cap + 255) / 256, 256, 0, ctx->stream>>>(reinterpret_cast<uint32_t*>(base + p->dev.dead_off),
-                                                              reinterpret_cast<uint32_t*>(base + p->dev.alive_off[0]), cap);
+                                                              reinterpret_cast<uint32_t*>(base + p->dev.alive_off[0]),
+                                                              reinterpret_cast<uint32_t*>(base + p->dev.alive_off[1]), cap);
     // Attribute planes start zeroed (the reference pre-fills with 0xFF only in debug builds).
     HIP_TRY(hipMemsetAsync(base + p->dev.attrs[0].plane_off, 0, p->slab_bytes - p->dev.attrs[0].plane_off, ctx->stream));
     // alive_count = 0, max_spawn = capacity, indirect_write_index = 0 (src/render/mod.rs:6048-6070)
@@ -643,8 +640,8 @@ int hnb_simulate(HnbContext* ctx) {
         const uint32_t n = (uint32_t)p->effects.size();
         if (n == 0) continue;
         const uint32_t par = p->parity;
-        // the staging buffer of this parity was last used two frames ago
-        HIP_TRY(hipEventSynchronize(p->frame_done[par]));
+        // the host staging buffer of this parity was last used two frames ago
+        HIP_TRY(hipEventSynchronize(p->upload_done[par]));
         char* h = static_cast<char*>(p->h_frame[par]);
         DevFrameInst* fi = reinterpret_cast<DevFrameInst*>(h);
         uint32_t* ublocks = reinterpret_cast<uint32_t*>(h + (size_t)n * sizeof(DevFrameInst));
@@ -669,31 +666,32 @@ int hnb_simulate(HnbContext* ctx) {
             fx->spawn_count = 0;  // a spawn request is consumed by exactly one frame
         }
         const size_t bytes = (size_t)n * sizeof(DevFrameInst) + (size_t)n * nu * 4;
-        HIP_TRY(hipMemcpyAsync(p->d_frame[par], h, bytes, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipEventRecord(p->frame_done[par], ctx->stream));
+        // The upload runs on its own stream so that it overlaps the previous frame's kernels: it only
+        // waits for the kernels that last read this parity's device block (two frames ago).
+        HIP_TRY(hipStreamWaitEvent(ctx->upload_stream, p->kernels_done[par], 0));
+        HIP_TRY(hipMemcpyAsync(p->d_frame[par], h, bytes, hipMemcpyHostToDevice, ctx->upload_stream));
+        HIP_TRY(hipEventRecord(p->upload_done[par], ctx->upload_stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, p->upload_done[par], 0));
         const char* d = static_cast<const char*>(p->d_frame[par]);
         const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
         const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
         p->dev.n_inst = n;
         TimingPair ti{}, tu{};
+        const bool timed = ctx->timing && (ctx->timing_tick % ctx->timing) == 0;
         if (blocks) {
-            if (ctx->timing) { hipEventCreate(&ti.a); hipEventCreate(&ti.b); hipEventRecord(ti.a, ctx->stream); }
+            if (timed) { hipEventCreate(&ti.a); hipEventCreate(&ti.b); hipEventRecord(ti.a, ctx->stream); }
             k_init<<<blocks, kInitBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub);
-            if (ctx->timing) { hipEventRecord(ti.b, ctx->stream); ctx->t_init.push_back(ti); }
+            if (timed) { hipEventRecord(ti.b, ctx->stream); ctx->t_init.push_back(ti); }
         }
+        // one workgroup per 4096-row chunk of every instance's alive list
         const uint32_t total_chunks = n * p->dev.chunks_per_inst;
-        // persistent workgroups: enough to fill the chip, never more than there are chunks
-        const uint32_t grid = std::min<uint32_t>(total_chunks, ctx->num_cus * 8u);
-        ScanBufs sb;
-        sb.chunk_status = p->d_status;
-        sb.group_status = p->d_group_status;
-        sb.arrive = p->d_arrive;
-        sb.ticket = p->d_ticket;
-        sb.groups_per_inst = p->groups_per_inst;
-        sb.n_groups_total = p->table_cap * p->groups_per_inst;
-        sb.parity = par;
-        sb.epoch = p->epoch;
-        if (ctx->timing) { hipEventCreate(&tu.a); hipEventCreate(&tu.b); hipEventRecord(tu.a, ctx->stream); }
+        CompactBufs cb;
+        cb.counts = p->d_counts;
+        cb.deaths = p->d_deaths;
+        cb.table_cap = p->table_cap;
+        cb.parity = par;
+        TimingPair tc{};
+        if (timed) { hipEventCreate(&tu.a); hipEventCreate(&tu.b); hipEventCreate(&tc.b); hipEventRecord(tu.a, ctx->stream); }
         if (p->update_streams) {
             StreamArgs sa{};
             sa.capacity = p->dev.capacity; sa.n_uregs = p->dev.n_uregs; sa.chunks_per_inst = p->dev.chunks_per_inst; sa.n_inst = n;
@@ -708,50 +706,49 @@ int hnb_simulate(HnbContext* ctx) {
                 if (at.upd_flags & HNB_ATTR_UPD_LOAD) sa.flags |= 1u << pi;
                 if (at.upd_flags & HNB_ATTR_UPD_STORE) sa.flags |= 16u << pi;
             }
-            p->stream_launch(grid, ctx->stream, sa, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, dub, sb);
+            p->stream_launch(total_chunks, ctx->stream, sa, p->d_inst_base, p->d_meta[par], dfi, dub, cb);
         } else {
-            k_update_generic<<<grid, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, dub, sb);
+            k_update_generic<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub, cb);
         }
-        if (ctx->timing) { hipEventRecord(tu.b, ctx->stream); ctx->t_update.push_back(tu); }
+        if (timed) { hipEventRecord(tu.b, ctx->stream); ctx->t_update.push_back(tu); }
+        CompactArgs ca{};
+        ca.capacity = p->dev.capacity; ca.chunks_per_inst = p->dev.chunks_per_inst;
+        ca.alive_off[0] = p->dev.alive_off[0]; ca.alive_off[1] = p->dev.alive_off[1]; ca.dead_off = p->dev.dead_off;
+        k_compact<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
+        if (timed) { tc.a = tu.b; hipEventRecord(tc.b, ctx->stream); ctx->t_compact.push_back(tc); }
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(p->kernels_done[par], ctx->stream));
         p->parity ^= 1u;
-        p->epoch += 1u;
-        if (p->epoch >= (1u << 30)) {  // epoch tag wrap: clear the look-back words
-            HIP_TRY(hipMemsetAsync(p->d_status, 0, (size_t)p->table_cap * p->dev.chunks_per_inst * 8, ctx->stream));
-            HIP_TRY(hipMemsetAsync(p->d_group_status, 0, (size_t)p->table_cap * p->groups_per_inst * 8, ctx->stream));
-            p->epoch = 1;
-        }
     }
+    if (ctx->timing) ctx->timing_tick += 1;
     return HNB_OK;
 }
 
 int hnb_effect_metadata(HnbEffect* fx, HnbEffectMetadata* out) {
     if (!fx || !out) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
     DevMeta m;
-    uint32_t fault = 0;
-    int rc = read_meta(fx, &m, &fault);
+    int rc = read_meta(fx, &m);
     if (rc != HNB_OK) return rc;
     const uint32_t cap = fx->prog->dev.capacity;
     out->capacity = cap;
     out->alive_count = m.alive_count;
     out->max_update = m.max_update;
     out->max_spawn = cap - m.alive_count;
-    out->indirect_write_index = m.write_index;  // column the last update wrote (= vfx_indirect.wgsl:80-85 after its flip)
+    out->indirect_write_index = m.ref_write_index;  // as the reference counts it: flips every frame (vfx_indirect.wgsl:80-85)
     out->particle_counter = m.particle_counter;
     out->instance_count = m.instance_count;
     out->dispatch_x = (m.alive_count + 63u) >> 6;
     out->dead_count = m.dead_count;
     out->spawned = m.spawned;
-    out->fault = m.fault | fault;
+    out->fault = 0;
     out->reserved = 0;
-    if (out->fault) return fail(HNB_ERR_DEVICE_FAULT, "device-side look-back watchdog fired");
     return HNB_OK;
 }
 
 int hnb_effect_alive_count(HnbEffect* fx, uint32_t* out) {
     if (!fx || !out) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
     DevMeta m;
-    int rc = read_meta(fx, &m, nullptr);
+    int rc = read_meta(fx, &m);
     if (rc != HNB_OK) return rc;
     *out = m.alive_count;
     return HNB_OK;
@@ -785,10 +782,10 @@ int hnb_effect_read_alive_list(HnbEffect* fx, uint32_t* dst, size_t dst_count) {
     if (!fx || !dst) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
     HnbProgram* p = fx->prog;
     DevMeta m;
-    int rc = read_meta(fx, &m, nullptr);
+    int rc = read_meta(fx, &m);
     if (rc != HNB_OK) return rc;
     if (dst_count < m.alive_count) return fail(HNB_ERR_INVALID_ARG, "destination too small");
-    HIP_TRY(hipMemcpy(dst, static_cast<char*>(fx->slab) + p->dev.alive_off[0], (size_t)m.alive_count * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dst, static_cast<char*>(fx->slab) + p->dev.alive_off[m.write_index & 1u], (size_t)m.alive_count * 4, hipMemcpyDeviceToHost));
     return HNB_OK;
 }
 
@@ -796,7 +793,7 @@ int hnb_effect_read_dead_list(HnbEffect* fx, uint32_t* dst, size_t dst_count) {
     if (!fx || !dst) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
     HnbProgram* p = fx->prog;
     DevMeta m;
-    int rc = read_meta(fx, &m, nullptr);
+    int rc = read_meta(fx, &m);
     if (rc != HNB_OK) return rc;
     const uint32_t nd = p->dev.capacity - m.alive_count;
     if (dst_count < nd) return fail(HNB_ERR_INVALID_ARG, "destination too small");
@@ -815,16 +812,21 @@ int hnb_ctx_enable_kernel_timing(HnbContext* ctx, int enable) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (auto& t : ctx->t_update) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (auto& t : ctx->t_init) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    for (auto& t : ctx->t_compact) hipEventDestroy(t.b);
+    ctx->t_compact.clear();
     ctx->t_update.clear();
     ctx->t_init.clear();
-    ctx->timing = enable != 0;
+    ctx->timing = enable > 0 ? (uint32_t)enable : 0u;
+    ctx->timing_tick = 0;
     return HNB_OK;
 }
 
-int hnb_ctx_kernel_timing(HnbContext* ctx, double* update_ms_avg, double* init_ms_avg, uint32_t* frames) {
+int hnb_ctx_kernel_timing(HnbContext* ctx, double* update_ms_avg, double* compact_ms_avg, double* init_ms_avg, uint32_t* frames) {
     if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    double su = 0, si = 0;
+    double su = 0, si = 0, sc = 0;
+    for (auto& t : ctx->t_compact) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); sc += ms; }
+    if (compact_ms_avg) *compact_ms_avg = ctx->t_compact.empty() ? 0.0 : sc / ctx->t_compact.size();
     for (auto& t : ctx->t_update) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); su += ms; }
     for (auto& t : ctx->t_init) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); si += ms; }
     if (update_ms_avg) *update_ms_avg = ctx->t_update.empty() ? 0.0 : su / ctx->t_update.size();

@@ -12,7 +12,10 @@ namespace hnb {
 
 constexpr uint32_t kMaxAttrs = 40;
 constexpr uint32_t kBlock = 256;      // threads per workgroup (4 waves)
-constexpr uint32_t kChunk = 4096;     // particles per workgroup = unit of the cross-chunk scan
+#ifndef HNB_CHUNK
+#define HNB_CHUNK 4096
+#endif
+constexpr uint32_t kChunk = HNB_CHUNK;  // alive-list rows per claimed chunk = unit of the cross-chunk scan
 constexpr uint32_t kInitBlock = 256;  // init: one particle per thread
 
 typedef AttrDesc DevAttr;
@@ -45,16 +48,14 @@ static_assert(sizeof(DevFrameInst) == 64, "DevFrameInst layout");
 struct DevMeta {
     uint32_t alive_count;
     uint32_t particle_counter;
-    uint32_t write_index;     // alive-list column the init pass appends to / the update pass READS
+    uint32_t write_index;     // list column that currently holds the alive list (flips only when particles died)
     uint32_t max_update;
     uint32_t dead_count;
     uint32_t spawned;
-    uint32_t fault;
+    uint32_t ref_write_index; // EffectMetadata::indirect_write_index as the reference would report it (flips every frame)
     uint32_t instance_count;
 };
 static_assert(sizeof(DevMeta) == 32, "DevMeta layout");
 
-// Decoupled look-back status word: [63:34] epoch, [33:32] state, [31:0] value.
-constexpr uint64_t kStateAggregate = 1, kStatePrefix = 2;
 
 }  // namespace hnb

@@ -37,9 +37,9 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 #endif
 
 // ---- reset: dead_index[i] = i (effect_cache.rs:298-323) ------------------------------------
-__global__ void k_reset_lists(uint32_t* __restrict__ dead, uint32_t* __restrict__ alive, uint32_t capacity) {
+__global__ void k_reset_lists(uint32_t* __restrict__ dead, uint32_t* __restrict__ alive0, uint32_t* __restrict__ alive1, uint32_t capacity) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < capacity) { dead[i] = i; alive[i] = 0u; }
+    if (i < capacity) { dead[i] = i; alive0[i] = 0u; alive1[i] = 0u; }
 }
 
 // ---- V-file attribute access (generic kernels, one particle per lane) -----------------------
@@ -90,7 +90,7 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
 
     char* base = reinterpret_cast<char*>(inst_base[k]);
     const uint32_t* dead = reinterpret_cast<const uint32_t*>(base + prog.dead_off);
-    uint32_t* alive = reinterpret_cast<uint32_t*>(base + prog.alive_off[0]);  // single list, compacted in place by k_update
+    uint32_t* alive = reinterpret_cast<uint32_t*>(base + prog.alive_off[meta_in[k].write_index]);  // the column holding the list
 
     const uint32_t slot = dead[alive0 + i];
 
@@ -185,35 +185,18 @@ __device__ __forceinline__ void pin_store1(const float (&src)[P], char* plane, c
 }
 
 // ---- update + kill + compaction ----------------------------------------------------------------
-// Cross-chunk machinery shared by the two update kernels.
-//
-//  * Persistent workgroups claim chunks from a ticket counter; the next ticket is requested
-//    before the current chunk is processed, so its latency is hidden. Tickets are handed out in
-//    order: every chunk with a smaller id has been claimed by a running workgroup, which makes
-//    all waits below deadlock-free under any dispatch order (no residency assumption).
-//  * The alive list is compacted IN PLACE (stable): chunk c writes rows [E, E+A) with E <= its first
-//    row, and only learns E after every earlier chunk has published, i.e. finished reading its rows.
-//    When nothing before or inside the chunk died, the rows are already in place and nothing is written.
-//  * E comes from a two-level decoupled look-back: chunks publish aggregates; the last chunk to
-//    arrive in a group of 64 publishes the group aggregate and resolves the group prefix from the
-//    (few) earlier groups. A chunk then needs one 64-wide read of its group's aggregates plus the
-//    previous group's prefix, instead of walking thousands of simultaneously-finishing chunks.
-__device__ __forceinline__ uint64_t pack_status(uint32_t epoch, uint64_t state, uint32_t value) {
-    return ((uint64_t)epoch << 34) | (state << 32) | value;
-}
-constexpr uint32_t kGroup = 64;  // chunks per look-back group
-
-struct ScanBufs {
-    uint64_t* chunk_status;   // [n_inst * chunks_per_inst]
-    uint64_t* group_status;   // [n_inst * groups_per_inst]
-    uint32_t* arrive;         // [2][n_inst * groups_per_inst], frame parity double-buffered
-    uint32_t* ticket;         // [0..1] ticket per parity, [2] watchdog word
-    uint32_t groups_per_inst;
-    uint32_t n_groups_total;
-    uint32_t parity;
-    uint32_t epoch;
-};
-
+// Two launches per frame, no inter-workgroup communication (measured alternatives: a single-pass
+// decoupled look-back with ticketed persistent workgroups was 10-13 % slower on this short kernel
+// because of its scheduling tail and spin-waits):
+//   k_update_*  one workgroup per 4096-row chunk of the alive list: runs the UPDATE program, ranks
+//               survivors / casualties inside each wave with ballots, and — only if something in
+//               the chunk died — rewrites the chunk's own rows as [survivors | casualties]. It
+//               records the chunk's survivor count and adds its casualties to the instance total.
+//   k_compact   per chunk: if the instance had no casualty this frame the alive list is already
+//               final and the workgroup exits; otherwise it sums the survivor counts of the earlier
+//               chunks (exclusive prefix), moves its survivors to the other list column and pushes
+//               its casualties on the dead list in serial order. It also rotates the counters
+//               (vfx_indirect.wgsl:57-85).
 struct ChunkCtx {
     uint32_t k, j;          // instance, chunk within instance
     uint32_t n;             // max_update of the instance
@@ -221,25 +204,19 @@ struct ChunkCtx {
     uint32_t start;         // first alive-list row of this chunk
     DevMeta m;
     char* base;
-    uint32_t* alive;        // the instance's alive list (compacted in place)
-    uint32_t* dead;
 };
 
-__device__ __forceinline__ uint32_t claim_ticket(const ScanBufs& sb) {
-    return __hip_atomic_fetch_add(&sb.ticket[sb.parity], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Whoever draws ticket 0 prepares the counters of the NEXT frame (other parity): nothing of this
-// launch or the previous one touches them.
-__device__ __forceinline__ void reset_next_frame(const ScanBufs& sb) {
-    uint32_t* a = sb.arrive + (size_t)(sb.parity ^ 1u) * sb.n_groups_total;
-    for (uint32_t i = threadIdx.x; i < sb.n_groups_total; i += kBlock) a[i] = 0u;
-    if (threadIdx.x == 0) __hip_atomic_store(&sb.ticket[sb.parity ^ 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+struct CompactBufs {
+    uint32_t* counts;   // [n_inst * chunks_per_inst] survivors per chunk (this frame)
+    uint32_t* deaths;   // [2][table_cap] casualties per instance, frame-parity double-buffered
+    uint32_t table_cap;
+    uint32_t parity;
+};
 
-// Decode a chunk id; false when the chunk has no rows (nothing to do, nobody waits on it).
+// Decode a chunk id; false when the chunk has no rows.
 template <class ARGS>
 __device__ __forceinline__ bool chunk_setup(ChunkCtx& c, uint32_t chunk, const ARGS& args, const uint64_t* inst_base, const DevMeta* meta_in,
-                                            DevMeta* meta_out, const DevFrameInst* fi) {
+                                            const DevFrameInst* fi) {
     c.k = chunk / args.chunks_per_inst;
     c.j = chunk - c.k * args.chunks_per_inst;
     // vfx_indirect.wgsl:57-85 folded in: max_update = alive_count after init.
@@ -249,208 +226,119 @@ __device__ __forceinline__ bool chunk_setup(ChunkCtx& c, uint32_t chunk, const A
     c.n_spawn = spawn < max_spawn ? spawn : max_spawn;
     c.n = c.m.alive_count + c.n_spawn;
     c.start = c.j * kChunk;
-    if (c.n == 0) {
-        if (c.j == 0 && threadIdx.x == 0) {
-            DevMeta o = c.m;
-            o.write_index = c.m.write_index ^ 1u; o.max_update = 0; o.dead_count = 0; o.spawned = 0; o.instance_count = 0;
-            meta_out[c.k] = o;
-        }
-        return false;
-    }
-    if (c.start >= c.n) return false;
     c.base = reinterpret_cast<char*>(inst_base[c.k]);
-    c.alive = reinterpret_cast<uint32_t*>(c.base + args.alive_off[0]);
-    c.dead = reinterpret_cast<uint32_t*>(c.base + args.dead_off);
-    return true;
+    return c.start < c.n;
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (uint32_t off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-// Spin until the 64-bit word carries this frame's epoch (bounded: the watchdog reports a fault
-// instead of hanging the GPU). Wave-uniform exit.
-__device__ __forceinline__ uint64_t wait_word(const uint64_t* w, bool active, uint32_t epoch, uint32_t& fault) {
-    uint64_t s = pack_status(epoch, kStatePrefix, 0u);
-    uint32_t spins = 0;
-    for (;;) {
-        if (active) s = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool ready = (uint32_t)(s >> 34) == epoch;
-        if (__all(ready)) break;
-        if (++spins > (1u << 22)) { fault = 1u; break; }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return s;
-}
-
-// Publish this chunk's survivor count (wave 0). The last chunk of a group to arrive also publishes
-// the group aggregate and resolves the group's prefix from the earlier groups. Nothing here waits on
-// a chunk that has not been claimed, and processing a claimed chunk never waits at all.
-__device__ __forceinline__ void publish_chunk(const ChunkCtx& c, const ScanBufs& sb, uint32_t chunks_per_inst, uint32_t local_alive, uint32_t& fault) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint64_t* cst = sb.chunk_status + (size_t)c.k * chunks_per_inst;
-    uint64_t* gst = sb.group_status + (size_t)c.k * sb.groups_per_inst;
-    const uint32_t j = c.j, g = j / kGroup;
-    const uint32_t n_chunks = (c.n + kChunk - 1) / kChunk;  // chunks of this instance that have rows
-    const uint32_t g_count = (n_chunks - g * kGroup) < kGroup ? (n_chunks - g * kGroup) : kGroup;
-    uint32_t old = 0;
-    if (lane == 0) {
-        __hip_atomic_store(&cst[j], pack_status(sb.epoch, kStateAggregate, local_alive), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        old = __hip_atomic_fetch_add(&sb.arrive[(size_t)sb.parity * sb.n_groups_total + (size_t)c.k * sb.groups_per_inst + g], 1u, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-    }
-    old = __shfl(old, 0, 64);
-    if (old + 1u != g_count) return;  // not the last arriver (election only: the data itself is polled)
-    const uint64_t s = wait_word(&cst[g * kGroup + lane], lane < g_count, sb.epoch, fault);
-    const uint32_t group_sum = wave_sum(lane < g_count ? (uint32_t)s : 0u);
-    if (g == 0) {
-        if (lane == 0) __hip_atomic_store(&gst[0], pack_status(sb.epoch, kStatePrefix, group_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    if (lane == 0) __hip_atomic_store(&gst[g], pack_status(sb.epoch, kStateAggregate, group_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // decoupled look-back over earlier GROUPS (lanes past the first group carry a virtual prefix 0)
-    uint32_t group_excl = 0;
-    int hi = (int)g - 1;
-    while (hi >= 0 && !fault) {
-        const int idx = hi - (int)lane;
-        const uint64_t q = wait_word(&gst[idx >= 0 ? idx : 0], idx >= 0, sb.epoch, fault);
-        const bool is_prefix = idx < 0 || ((q >> 32) & 3u) == kStatePrefix;
-        const uint32_t val = idx >= 0 ? (uint32_t)q : 0u;
-        const uint64_t pmask = __ballot(is_prefix);
-        if (pmask) {
-            const uint32_t first = (uint32_t)__builtin_ctzll(pmask);
-            group_excl += wave_sum(lane <= first ? val : 0u);
-            break;
-        }
-        group_excl += wave_sum(val);
-        hi -= 64;
-    }
-    if (lane == 0) __hip_atomic_store(&gst[g], pack_status(sb.epoch, kStatePrefix, group_excl + group_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Exclusive prefix of a published chunk (wave 0): survivors of all earlier chunks of the instance.
-__device__ __forceinline__ uint32_t resolve_chunk(const ChunkCtx& c, const ScanBufs& sb, uint32_t chunks_per_inst, uint32_t& fault) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t* cst = sb.chunk_status + (size_t)c.k * chunks_per_inst;
-    const uint64_t* gst = sb.group_status + (size_t)c.k * sb.groups_per_inst;
-    const uint32_t g = c.j / kGroup, jg = c.j - g * kGroup;
-    const uint64_t s = wait_word(&cst[g * kGroup + lane], lane < jg, sb.epoch, fault);
-    const uint32_t intra = wave_sum(lane < jg ? (uint32_t)s : 0u);
-    uint32_t group_excl = 0;
-    if (g > 0) {  // inclusive prefix of the previous group
-        uint64_t q;
-        uint32_t spins = 0;
-        for (;;) {
-            q = __hip_atomic_load(&gst[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(q >> 34) == sb.epoch && ((q >> 32) & 3u) == kStatePrefix) break;
-            if (++spins > (1u << 22)) { fault = 1u; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        group_excl = (uint32_t)q;
-    }
-    return group_excl + intra;
-}
-
-// Staged chunk: survivors (front) and casualties (back) of NSEG LDS segments of seg_rows rows each;
-// s_cnt[w] = survivors | casualties << 16 of segment w.
+// The chunk's survivors (front) and casualties (back) are staged in NSEG LDS segments of seg_rows
+// rows; s_cnt[w] = survivors | casualties << 16 of segment w. Called by the whole workgroup.
 template <int NSEG>
-__device__ __forceinline__ void chunk_publish(const ChunkCtx& c, const ScanBufs& sb, uint32_t chunks_per_inst, const uint32_t* s_cnt, uint32_t* s_bcast) {
-    if ((threadIdx.x >> 6) != 0) return;
-    uint32_t local_alive = 0;
-#pragma unroll
-    for (int w = 0; w < NSEG; ++w) local_alive += s_cnt[w] & 0xffffu;
-    uint32_t fault = 0;
-    publish_chunk(c, sb, chunks_per_inst, local_alive, fault);
-    if ((threadIdx.x & 63u) == 0 && fault) atomicOr(&sb.ticket[2], 1u);  // watchdog word, reported by hnb_effect_metadata
-}
-
-template <int NSEG>
-__device__ __forceinline__ void chunk_commit(const ChunkCtx& c, const ScanBufs& sb, uint32_t chunks_per_inst, DevMeta* meta_out, const uint32_t* s_list,
-                                             uint32_t seg_rows, const uint32_t* s_cnt, uint32_t* s_bcast) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+__device__ __forceinline__ void chunk_record(const ChunkCtx& c, uint32_t chunk, const CompactBufs& cb, uint32_t* list, const uint32_t* s_list,
+                                             uint32_t seg_rows, const uint32_t* s_cnt) {
+    const uint32_t tid = threadIdx.x;
     uint32_t a[NSEG], d[NSEG];
     uint32_t local_alive = 0, local_dead = 0;
 #pragma unroll
     for (int w = 0; w < NSEG; ++w) { a[w] = s_cnt[w] & 0xffffu; d[w] = s_cnt[w] >> 16; local_alive += a[w]; local_dead += d[w]; }
-    if (wave == 0) {
-        uint32_t fault = 0;
-        const uint32_t excl = resolve_chunk(c, sb, chunks_per_inst, fault);
-        if (lane == 0) {
-            s_bcast[0] = excl; s_bcast[1] = fault;
-            if (fault) atomicOr(&sb.ticket[2], 1u);
-        }
+    if (tid == 0) {
+        cb.counts[chunk] = local_alive;
+        if (local_dead) atomicAdd(&cb.deaths[(size_t)cb.parity * cb.table_cap + c.k], local_dead);
     }
+    if (!local_dead) return;  // rows are already [survivors]: nothing to rewrite
+    uint32_t abase = c.start, dbase = c.start + local_alive;
+#pragma unroll
+    for (int w = 0; w < NSEG; ++w) {
+        const uint32_t* sg = s_list + w * seg_rows;
+        for (uint32_t i = tid; i < a[w]; i += kBlock) list[abase + i] = sg[i];
+        for (uint32_t i = tid; i < d[w]; i += kBlock) list[dbase + i] = sg[seg_rows - 1u - i];  // casualties in serial order
+        abase += a[w];
+        dbase += d[w];
+    }
+}
+
+// ---- k_compact -----------------------------------------------------------------------------------
+template <class ARGS>
+__device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* inst_base, const DevMeta* meta_in, DevMeta* meta_out,
+                                              const DevFrameInst* fi, const CompactBufs& cb) {
+    __shared__ uint32_t s_red[kBlock / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t chunk = blockIdx.x;
+    ChunkCtx c;
+    const bool has_rows = chunk_setup(c, chunk, args, inst_base, meta_in, fi);
+    uint32_t* deaths_cur = cb.deaths + (size_t)cb.parity * cb.table_cap;
+    const uint32_t total_dead = deaths_cur[c.k];
+    if (c.j == 0 && tid == 0) cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + c.k] = 0u;  // next frame's counter
+    const bool last = c.n == 0 ? c.j == 0 : (c.start < c.n && c.start + kChunk >= c.n);
+    if (total_dead == 0u) {
+        if (last && tid == 0) {
+            DevMeta o = c.m;
+            o.alive_count = c.n;
+            o.particle_counter = c.m.particle_counter + c.n_spawn;
+            o.ref_write_index = c.m.ref_write_index ^ 1u;
+            o.max_update = c.n; o.dead_count = 0; o.spawned = c.n_spawn; o.instance_count = c.n;
+            meta_out[c.k] = o;
+        }
+        return;
+    }
+    if (!has_rows) return;
+    // exclusive prefix of the survivor counts of the earlier chunks of this instance
+    const uint32_t* cnt = cb.counts + (size_t)c.k * args.chunks_per_inst;
+    uint32_t part = 0;
+    for (uint32_t i = tid; i < c.j; i += kBlock) part += cnt[i];
+#pragma unroll
+    for (uint32_t off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (lane == 0) s_red[wave] = part;
     __syncthreads();
-    const uint32_t excl_prefix = s_bcast[0];
-    // Survivors in stable (serial) order (vfx_update.wgsl:161-165). Rows already in place are not rewritten.
-    if (!(excl_prefix == c.start && local_dead == 0u)) {
-        uint32_t abase = excl_prefix;
+    uint32_t excl = 0;
 #pragma unroll
-        for (int w = 0; w < NSEG; ++w) {
-            const uint32_t* sg = s_list + w * seg_rows;
-            for (uint32_t i = tid; i < a[w]; i += kBlock) c.alive[abase + i] = sg[i];
-            abase += a[w];
-        }
-    }
-    // The d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151).
-    if (local_dead) {
-        uint32_t dbase = c.start - excl_prefix;
-#pragma unroll
-        for (int w = 0; w < NSEG; ++w) {
-            const uint32_t* sg = s_list + w * seg_rows;
-            for (uint32_t i = tid; i < d[w]; i += kBlock) c.dead[c.n - 1u - (dbase + i)] = sg[seg_rows - 1u - i];
-            dbase += d[w];
-        }
-    }
-    if (tid == 0 && c.start + kChunk >= c.n) {
-        const uint32_t survivors = excl_prefix + local_alive;
-        DevMeta o;
+    for (uint32_t w = 0; w < kBlock / 64; ++w) excl += s_red[w];
+    const uint32_t rows = (c.n - c.start) < kChunk ? (c.n - c.start) : kChunk;
+    const uint32_t a = cnt[c.j];
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(c.base + args.alive_off[c.m.write_index]) + c.start;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(c.base + args.alive_off[c.m.write_index ^ 1u]) + excl;
+    uint32_t* dead = reinterpret_cast<uint32_t*>(c.base + args.dead_off);
+    // survivors keep their (stable, serial) order (vfx_update.wgsl:161-165)
+    for (uint32_t i = tid; i < a; i += kBlock) dst[i] = src[i];
+    // the d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151)
+    const uint32_t dead_before = c.start - excl;
+    for (uint32_t i = tid; i < rows - a; i += kBlock) dead[c.n - 1u - (dead_before + i)] = src[a + i];
+    if (last && tid == 0) {
+        const uint32_t survivors = excl + a;
+        DevMeta o = c.m;
         o.alive_count = survivors;
         o.particle_counter = c.m.particle_counter + c.n_spawn;
-        o.write_index = c.m.write_index ^ 1u;
+        o.write_index = c.m.write_index ^ 1u;  // the list now lives in the other column
+        o.ref_write_index = c.m.ref_write_index ^ 1u;
         o.max_update = c.n;
         o.dead_count = c.n - survivors;
         o.spawned = c.n_spawn;
-        o.fault = c.m.fault | s_bcast[1];
         o.instance_count = survivors;
         meta_out[c.k] = o;
     }
 }
 
-// Persistent-workgroup driver, software-pipelined at chunk granularity:
-//   PROCESS(chunk, buf) -> bool : stage the chunk into LDS buffer `buf` and publish its aggregate
-//   COMMIT(chunk, buf)          : resolve the prefix and write the lists of a chunk staged earlier
-// The commit of chunk i runs after chunk i+1 has been processed, so the look-back words it needs
-// were published a whole chunk-time ago, and the next ticket (requested before processing) has
-// long arrived: neither latency is exposed except once at the tail.
-#define HNB_PERSISTENT_LOOP(sb, total_chunks, s_bcast, PROCESS, COMMIT)                          \
-    {                                                                                            \
-        uint32_t t_next_ = 0, prev_ = 0xffffffffu, buf_ = 0;                                     \
-        if (threadIdx.x == 0) s_bcast[2] = claim_ticket(sb);                                     \
-        __syncthreads();                                                                         \
-        uint32_t chunk_ = s_bcast[2];                                                            \
-        if (chunk_ == 0) reset_next_frame(sb);                                                   \
-        while (chunk_ < (total_chunks)) {                                                        \
-            if (threadIdx.x == 0) t_next_ = claim_ticket(sb);                                    \
-            const bool staged_ = PROCESS(chunk_, buf_);                                          \
-            if (prev_ != 0xffffffffu) { COMMIT(prev_, buf_ ^ 1u); }                              \
-            if (staged_) { prev_ = chunk_; buf_ ^= 1u; } else { prev_ = 0xffffffffu; }           \
-            __syncthreads();                                                                     \
-            if (threadIdx.x == 0) s_bcast[2] = t_next_;                                          \
-            __syncthreads();                                                                     \
-            chunk_ = s_bcast[2];                                                                 \
-        }                                                                                        \
-        if (prev_ != 0xffffffffu) { COMMIT(prev_, buf_ ^ 1u); }                                  \
-    }
+struct CompactArgs {
+    uint32_t capacity, chunks_per_inst;
+    uint32_t alive_off[2], dead_off;
+};
+__global__ void __launch_bounds__(kBlock)
+k_compact(const CompactArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in, DevMeta* __restrict__ meta_out,
+          const DevFrameInst* __restrict__ fi, const CompactBufs cb) {
+    compact_chunk(args, inst_base, meta_in, meta_out, fi, cb);
+}
 
 // ---- generic update kernel: any update stream, V register file, one particle per lane ----------
-__device__ __forceinline__ bool generic_process(uint32_t chunk, const DevProgram& prog, const uint64_t* inst_base, const DevMeta* meta_in,
-                                                DevMeta* meta_out, const DevFrameInst* fi, const uint32_t* ublocks, const ScanBufs& sb,
-                                                uint32_t* s_list, uint32_t* s_cnt, uint32_t* s_wave, uint32_t* s_bcast) {
+__global__ void __launch_bounds__(kBlock)
+k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+                 const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
+    __shared__ uint32_t s_list[kChunk];
+    __shared__ uint32_t s_cnt[1];
+    __shared__ uint32_t s_wave[kBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t chunk = blockIdx.x;
     ChunkCtx c;
-    if (!chunk_setup(c, chunk, prog, inst_base, meta_in, meta_out, fi)) return false;
+    if (!chunk_setup(c, chunk, prog, inst_base, meta_in, fi)) return;
+    uint32_t* list = reinterpret_cast<uint32_t*>(c.base + prog.alive_off[c.m.write_index]);
     const uint32_t seed_k = fi[c.k].seed, slot_base = fi[c.k].slot_base;
     VmUniforms U;
     U.u = ublocks + (size_t)c.k * prog.n_uregs;
@@ -460,7 +348,7 @@ __device__ __forceinline__ bool generic_process(uint32_t chunk, const DevProgram
         const uint32_t li = c.start + sub * kBlock + tid;
         if (c.start + sub * kBlock >= c.n) break;
         const bool valid = li < c.n;
-        const uint32_t slot = valid ? c.alive[li] : 0u;
+        const uint32_t slot = valid ? list[li] : 0u;
         VmState<vreg_file_t> S;
         S.r = vreg_file_t{};
         for (uint32_t a = 0; a < prog.n_attrs; ++a) {
@@ -511,43 +399,16 @@ __device__ __forceinline__ bool generic_process(uint32_t chunk, const DevProgram
     }
     if (tid == 0) s_cnt[0] = local_alive | (local_dead << 16);
     __syncthreads();
-    chunk_publish<1>(c, sb, prog.chunks_per_inst, s_cnt, s_bcast);
-    return true;
-}
-
-__global__ void __launch_bounds__(kBlock)
-k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
-                 DevMeta* __restrict__ meta_out, const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks, const ScanBufs sb) {
-    // 65536-row chunks would not fit twice: the generic kernel stages 4096 rows per buffer like the streaming one
-    __shared__ uint32_t s_list[2][kChunk];
-    __shared__ uint32_t s_cnt[2][1];
-    __shared__ uint32_t s_wave[kBlock / 64];
-    __shared__ uint32_t s_bcast[3];
-    const uint32_t total = prog.n_inst * prog.chunks_per_inst;
-#define PROCESS_(ch, buf) generic_process(ch, prog, inst_base, meta_in, meta_out, fi, ublocks, sb, s_list[buf], s_cnt[buf], s_wave, s_bcast)
-#define COMMIT_(ch, buf)                                                                                     \
-    {                                                                                                        \
-        ChunkCtx pc_;                                                                                        \
-        chunk_setup(pc_, ch, prog, inst_base, meta_in, meta_out, fi);                                        \
-        chunk_commit<1>(pc_, sb, prog.chunks_per_inst, meta_out, s_list[buf], kChunk, s_cnt[buf], s_bcast);  \
-    }
-    HNB_PERSISTENT_LOOP(sb, total, s_bcast, PROCESS_, COMMIT_)
-#undef PROCESS_
-#undef COMMIT_
+    chunk_record<1>(c, chunk, cb, list, s_list, kChunk, s_cnt);
 }
 
 // ---- streaming update kernel ---------------------------------------------------------------------
 // Macro-op update streams with U operands, named registers, 4 particles per lane.
-//
-// Work decomposition (all choices measured on MI355X):
 //  * a workgroup owns a 4096-row chunk of the alive list; each of its 4 WAVES owns a private,
 //    contiguous 1024-row quarter and walks it in 4 steps of 256 rows (64 lanes x 4 rows, so the
-//    dense path moves 16 B per lane per access);
-//  * survivors / casualties are ranked inside the wave with ballots (no shuffles, no LDS) and go
-//    straight into the wave's own LDS segment, so the loop contains NO workgroup barrier and
-//    keeps only 4 slot indices live: registers stay low enough for 8 waves per SIMD;
-//  * the workgroup synchronises once, combines the 4 wave totals, resolves the cross-chunk prefix
-//    and writes the lists coalesced (or not at all when nothing moved).
+//    dense path moves 16 B per lane per access); the quarter's list rows are fetched up front;
+//  * survivors / casualties are ranked inside the wave with ballots (no shuffles) and staged in
+//    the wave's own LDS segment: the loop contains no workgroup barrier.
 struct StreamArgs {
     uint32_t capacity, n_uregs, chunks_per_inst, n_inst;
     uint32_t alive_off[2], dead_off, update_len;
@@ -557,7 +418,10 @@ struct StreamArgs {
 };
 
 #ifndef HNB_STREAM_WAVES
-#define HNB_STREAM_WAVES 8   // waves per SIMD the lean streaming kernel is register-budgeted for
+// Waves per SIMD the lean streaming kernels are register-budgeted for. Measured on MI355X (16M
+// firework): 8 (<= 64 VGPRs) 0.266 ms, 6 (<= 80 VGPRs, what the kernel wants) 0.230 ms: the tighter
+// budget serialises the 8 loads per lane that should all be in flight.
+#define HNB_STREAM_WAVES 6
 #endif
 #ifndef HNB_STREAM_WAVES_FULL
 #define HNB_STREAM_WAVES_FULL 5
@@ -565,16 +429,18 @@ struct StreamArgs {
 constexpr uint32_t kWaveRows = kChunk / (kBlock / 64);  // 1024 rows per wave
 constexpr uint32_t kStepRows = 64 * 4;                  // 256 rows per wave step
 
-// PROBE (tools/stream_probe.hip only; 0 in the product): ablation bits used to attribute the kernel's
-// time: 2 = skip prefix resolution + list writes, 4 = skip stores, 8 = skip the program,
-// 16 = skip the alive-list read (assume identity).
-template <class PROG, int PROBE>
-__device__ __forceinline__ bool stream_process(uint32_t chunk, const StreamArgs& args, const uint64_t* inst_base, const DevMeta* meta_in,
-                                               DevMeta* meta_out, const DevFrameInst* fi, const uint32_t* ublocks, const ScanBufs& sb,
-                                               uint32_t* s_list, uint32_t* s_wave, uint32_t* s_bcast) {
+// PROBE (tools/stream_probe.hip only; 0 in the product): ablation bits: 2 = skip the chunk record,
+// 4 = skip stores, 8 = skip the program, 16 = skip the alive-list read (assume identity).
+template <class PROG, int WAVES, int PROBE = 0>
+__global__ void __launch_bounds__(kBlock, WAVES)
+k_update_stream(const StreamArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+                const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
+    __shared__ uint32_t s_list[kChunk];
+    __shared__ uint32_t s_wave[kBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t chunk = blockIdx.x;
     ChunkCtx c;
-    if (!chunk_setup(c, chunk, args, inst_base, meta_in, meta_out, fi)) return false;
+    if (!chunk_setup(c, chunk, args, inst_base, meta_in, fi)) return;
     const uint32_t n = c.n;
     VmUniforms U;
     U.u = ublocks + (size_t)c.k * args.n_uregs;
@@ -584,34 +450,43 @@ __device__ __forceinline__ bool stream_process(uint32_t chunk, const StreamArgs&
     char* p_age = c.base + args.plane_off[2];
     char* p_life = c.base + args.plane_off[3];
     const uint32_t fl = args.flags;
-    const uint32_t* alive_rd = c.alive;
+    uint32_t* list = reinterpret_cast<uint32_t*>(c.base + args.alive_off[c.m.write_index]);
+    const uint32_t* alive_rd = list;
 
     // ---- the wave's private quarter ------------------------------------------------------------------
     const uint32_t wstart = c.start + wave * kWaveRows;
     uint32_t* seg = s_list + wave * kWaveRows;
     uint32_t wa = 0, wd = 0;  // wave-uniform survivor / casualty counts of this quarter
     const uint64_t below = (1ull << lane) - 1ull;
-#pragma unroll 1
+    // alive-list rows of the whole quarter: one round trip instead of one per step
+    uint4 rows[kWaveRows / kStepRows];
+#pragma unroll
+    for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
+        const uint32_t li = wstart + step * kStepRows + lane * 4u;
+        rows[step] = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (!(PROBE & 16)) {
+            if (li + 4u <= n) rows[step] = *reinterpret_cast<const uint4*>(alive_rd + li);
+            else {
+                if (li < n) rows[step].x = alive_rd[li];
+                if (li + 1u < n) rows[step].y = alive_rd[li + 1u];
+                if (li + 2u < n) rows[step].z = alive_rd[li + 2u];
+            }
+        }
+    }
+#pragma unroll
     for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
         const uint32_t sbase = wstart + step * kStepRows;
         if (sbase >= n) break;
         const uint32_t li = sbase + lane * 4u;
         uint32_t slot[4];
         bool valid[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) valid[p] = li + p < n;
         if constexpr (PROBE & 16) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) { valid[p] = li + p < n; slot[p] = li + p; }
-        } else if (li + 4u <= n) {
-            const uint4 q = *reinterpret_cast<const uint4*>(alive_rd + li);
-            slot[0] = q.x; slot[1] = q.y; slot[2] = q.z; slot[3] = q.w;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) valid[p] = true;
+            for (int p = 0; p < 4; ++p) slot[p] = li + p;
         } else {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                valid[p] = li + p < n;
-                slot[p] = valid[p] ? alive_rd[li + p] : 0u;
-            }
+            slot[0] = rows[step].x; slot[1] = rows[step].y; slot[2] = rows[step].z; slot[3] = rows[step].w;
         }
         const bool quad = valid[3] && ((slot[0] & 3u) == 0u) && slot[1] == slot[0] + 1u && slot[2] == slot[0] + 2u && slot[3] == slot[0] + 3u;
         const bool dense = __all(quad);  // wave-uniform: all 64 lanes own an aligned run of 4 slots
@@ -662,35 +537,10 @@ __device__ __forceinline__ bool stream_process(uint32_t chunk, const StreamArgs&
     if (lane == 0) s_wave[wave] = wa | (wd << 16);
     __syncthreads();
     if constexpr (PROBE & 2) {
-        if (s_wave[0] == 0xffffffffu) meta_out[c.k].fault = 1;
-        return false;
+        if (s_wave[0] == 0xffffffffu) cb.counts[chunk] = 1;
+        return;
     }
-    chunk_publish<kBlock / 64>(c, sb, args.chunks_per_inst, s_wave, s_bcast);
-    return true;
-}
-
-template <class PROG, int WAVES, int PROBE = 0>
-__global__ void __launch_bounds__(kBlock, WAVES)
-k_update_stream(const StreamArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
-                DevMeta* __restrict__ meta_out, const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks, const ScanBufs sb) {
-    __shared__ uint32_t s_list[2][kChunk];           // two staged chunks: commit of one overlaps processing of the next
-    __shared__ uint32_t s_wave[2][kBlock / 64];
-    __shared__ uint32_t s_bcast[3];
-    const uint32_t total = args.n_inst * args.chunks_per_inst;
-#define PROCESS_(ch, buf) stream_process<PROG, PROBE>(ch, args, inst_base, meta_in, meta_out, fi, ublocks, sb, s_list[buf], s_wave[buf], s_bcast)
-#define COMMIT_(ch, buf)                                                                                                      \
-    {                                                                                                                         \
-        ChunkCtx pc_;                                                                                                         \
-        chunk_setup(pc_, ch, args, inst_base, meta_in, meta_out, fi);                                                         \
-        chunk_commit<kBlock / 64>(pc_, sb, args.chunks_per_inst, meta_out, s_list[buf], kWaveRows, s_wave[buf], s_bcast);     \
-    }
-    if constexpr (PROBE & 1) {  // no ticket: one chunk per workgroup, id = blockIdx
-        if (PROCESS_(blockIdx.x, 0)) { COMMIT_(blockIdx.x, 0) }
-    } else {
-        HNB_PERSISTENT_LOOP(sb, total, s_bcast, PROCESS_, COMMIT_)
-    }
-#undef PROCESS_
-#undef COMMIT_
+    chunk_record<kBlock / 64>(c, chunk, cb, list, s_list, kWaveRows, s_wave);
 }
 
 }  // namespace hnb

@@ -82,7 +82,7 @@ def load_library():
         lib.hnb_effect_read_dead_list.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.hnb_effect_sort_ribbons.argtypes = [C.c_void_p]
         lib.hnb_ctx_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
-        lib.hnb_ctx_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        lib.hnb_ctx_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         _lib = lib
     return _lib
 
@@ -138,13 +138,14 @@ class Context:
     def simulate(self):
         _check(self._lib.hnb_simulate(self._h))
 
-    def enable_kernel_timing(self, enable=True):
-        _check(self._lib.hnb_ctx_enable_kernel_timing(self._h, int(enable)))
+    def enable_kernel_timing(self, every_n_frames=1):
+        """0/False = off; n = bracket the kernels of every n-th simulated frame with HIP events."""
+        _check(self._lib.hnb_ctx_enable_kernel_timing(self._h, int(every_n_frames)))
 
     def kernel_timing(self):
-        u, i, n = C.c_double(), C.c_double(), C.c_uint32()
-        _check(self._lib.hnb_ctx_kernel_timing(self._h, C.byref(u), C.byref(i), C.byref(n)))
-        return {"update_ms_avg": u.value, "init_ms_avg": i.value, "frames": n.value}
+        u, c, i, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint32()
+        _check(self._lib.hnb_ctx_kernel_timing(self._h, C.byref(u), C.byref(c), C.byref(i), C.byref(n)))
+        return {"update_ms_avg": u.value, "compact_ms_avg": c.value, "init_ms_avg": i.value, "frames": n.value}
 
 
 class Program:

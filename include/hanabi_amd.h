@@ -233,7 +233,7 @@ typedef struct HnbEffectMetadata {
     uint32_t dispatch_x;           /* ceil(alive_count / 64): indirect args of the next update */
     uint32_t dead_count;           /* particles killed by the last update */
     uint32_t spawned;              /* particles spawned by the last init */
-    uint32_t fault;                /* non-zero if a device-side watchdog fired */
+    uint32_t fault;                /* reserved (0): the kernels have no device-side waits */
     uint32_t reserved;
 } HnbEffectMetadata;
 
@@ -300,10 +300,11 @@ int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t 
  * vfx_sort*.wgsl); rewrites the alive list column the renderer reads. */
 int hnb_effect_sort_ribbons(HnbEffect* fx);
 
-/* Timing helper: average device time in ms of the `update` kernel over the frames
- * simulated since the last reset (HIP events on the simulation stream). */
-int hnb_ctx_enable_kernel_timing(HnbContext* ctx, int enable);
-int hnb_ctx_kernel_timing(HnbContext* ctx, double* update_ms_avg, double* init_ms_avg, uint32_t* frames);
+/* Timing helper: average device time in ms of the update kernel, of the compaction kernel that
+ * follows it (event after update -> event after compact, i.e. including the launch gap) and of the
+ * init kernel, over the frames simulated since the last reset (HIP events on the simulation stream). */
+int hnb_ctx_enable_kernel_timing(HnbContext* ctx, int every_n_frames); /* 0 = off; n: time every n-th hnb_simulate (events cost ~20 us of stream bubbles per timed frame) */
+int hnb_ctx_kernel_timing(HnbContext* ctx, double* update_ms_avg, double* compact_ms_avg, double* init_ms_avg, uint32_t* frames);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,7 @@ template <class F> float time_ms(int iters, F f) {
 int main(int argc, char** argv) {
     const uint32_t cap = argc > 1 ? (uint32_t)atol(argv[1]) : (1u << 24);
     const int iters = argc > 2 ? atoi(argv[2]) : 20;
+    const int blocks_per_cu = argc > 3 ? atoi(argv[3]) : 8;
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     StreamArgs sa{};
     sa.capacity = cap; sa.n_uregs = 8; sa.chunks_per_inst = (cap + kChunk - 1) / kChunk; sa.n_inst = 1;
@@ -93,41 +94,43 @@ int main(int argc, char** argv) {
     DevMeta m{}; m.alive_count = cap;
     DevMeta* dmeta; CK(hipMalloc(&dmeta, 2 * sizeof m)); CK(hipMemcpy(dmeta, &m, sizeof m, hipMemcpyHostToDevice)); CK(hipMemcpy(dmeta + 1, &m, sizeof m, hipMemcpyHostToDevice));
     uint64_t base_addr = (uint64_t)slab; uint64_t* dbase; CK(hipMalloc(&dbase, 8)); CK(hipMemcpy(dbase, &base_addr, 8, hipMemcpyHostToDevice));
-    uint64_t* status; CK(hipMalloc(&status, (size_t)sa.chunks_per_inst * 8)); CK(hipMemset(status, 0, (size_t)sa.chunks_per_inst * 8));
-    uint32_t* ticket; CK(hipMalloc(&ticket, 16)); CK(hipMemset(ticket, 0, 16));
-    ScanBufs sb;
-    sb.groups_per_inst = (sa.chunks_per_inst + kGroup - 1) / kGroup;
-    sb.n_groups_total = sb.groups_per_inst;
-    sb.chunk_status = status;
-    CK(hipMalloc(&sb.group_status, (size_t)sb.n_groups_total * 8)); CK(hipMemset(sb.group_status, 0, (size_t)sb.n_groups_total * 8));
-    CK(hipMalloc(&sb.arrive, (size_t)sb.n_groups_total * 8)); CK(hipMemset(sb.arrive, 0, (size_t)sb.n_groups_total * 8));
-    sb.ticket = ticket; sb.parity = 0; sb.epoch = 1;
-    int dev_cus = 256; { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, 0) == hipSuccess) dev_cus = pr.multiProcessorCount; }
+    CompactBufs cb;
+    CK(hipMalloc(&cb.counts, (size_t)sa.chunks_per_inst * 4)); CK(hipMemset(cb.counts, 0, (size_t)sa.chunks_per_inst * 4));
+    CK(hipMalloc(&cb.deaths, 2 * 4 * 4)); CK(hipMemset(cb.deaths, 0, 2 * 4 * 4));
+    cb.table_cap = 4; cb.parity = 0;
+    uint32_t* ticket = cb.deaths;
+    CompactArgs ca{};
+    ca.capacity = cap; ca.chunks_per_inst = sa.chunks_per_inst; ca.alive_off[0] = sa.alive_off[0]; ca.alive_off[1] = sa.alive_off[1]; ca.dead_off = sa.dead_off;
     const double bytes = (double)cap * 68.0;
-    uint32_t epoch = 1;
     const uint32_t grid = sa.chunks_per_inst;
-#define RUN(NAME, PROBE, WAVES)                                                                                                  \
+    (void)blocks_per_cu;
+#define RUN(NAME, PROBE, WAVES, COMPACT)                                                                                         \
     {                                                                                                                            \
         float ms = time_ms(iters, [&] {                                                                                          \
-            CK(hipMemsetAsync(ticket, 0, 8));                                                                                    \
-            CK(hipMemsetAsync(sb.arrive, 0, (size_t)sb.n_groups_total * 8));                                                     \
-            sb.epoch = epoch++;                                                                                                  \
-            const uint32_t g_ = ((PROBE) & 1) ? grid : (grid < (uint32_t)dev_cus * 8u ? grid : (uint32_t)dev_cus * 8u);          \
-            k_update_stream<ProgDragAccel, WAVES, PROBE><<<g_, kBlock>>>(sa, dbase, dmeta, dmeta + 1, dfi, dub, sb);              \
+            k_update_stream<ProgDragAccel, WAVES, PROBE><<<grid, kBlock>>>(sa, dbase, dmeta, dfi, dub, cb);                       \
+            if (COMPACT) k_compact<<<grid, kBlock>>>(ca, dbase, dmeta, dmeta + 1, dfi, cb);                                       \
         });                                                                                                                      \
         printf("%-44s %8.3f ms  %7.1f GB/s (68 B/particle)\n", NAME, ms, bytes / ms / 1e6);                                       \
     }
-    RUN("full kernel (waves 8)", 0, 8)
-    RUN("full kernel (waves 6)", 0, 6)
-    RUN("full kernel (waves 5)", 0, 5)
-    RUN("full kernel (waves 4)", 0, 4)
-    RUN("no ticket (1 chunk per block)", 1, 8)
-    RUN("no finish (look-back + list writes)", 2, 8)
-    RUN("no ticket, no finish", 3, 8)
-    RUN("no ticket, no finish, no stores", 7, 8)
-    RUN("no ticket, no finish, no program", 11, 8)
-    RUN("no ticket, no finish, identity list", 19, 8)
-    RUN("no ticket, no finish, no stores, identity", 23, 8)
+    RUN("k_update (waves 8)", 0, 8, 0)
+    RUN("k_update + k_compact (waves 8)", 0, 8, 1)
+    RUN("k_update (waves 7)", 0, 7, 0)
+    RUN("k_update (waves 6)", 0, 6, 0)
+    RUN("k_update + k_compact (waves 6)", 0, 6, 1)
+    RUN("k_update (waves 5)", 0, 5, 0)
+    RUN("k_update (waves 4)", 0, 4, 0)
+    RUN("k_update (waves 3)", 0, 3, 0)
+    RUN("k_update (waves 2)", 0, 2, 0)
+    RUN("no chunk record (waves 6)", 2, 6, 0)
+    RUN("no chunk record", 2, 8, 0)
+    RUN("no record, no stores", 6, 8, 0)
+    RUN("no record, no program", 10, 8, 0)
+    RUN("no record, identity list", 18, 8, 0)
+    RUN("no record, no stores, identity", 22, 8, 0)
+    {
+        float ms = time_ms(iters, [&] { k_compact<<<grid, kBlock>>>(ca, dbase, dmeta, dmeta + 1, dfi, cb); });
+        printf("%-44s %8.3f ms\n", "k_compact alone (no deaths)", ms);
+    }
     {
         float ms = time_ms(iters, [&] { k_ideal<<<cap / 4 / 256, 256>>>((uint32_t*)(slab + sa.alive_off[0]), (float*)(slab + sa.plane_off[0]), (float*)(slab + sa.plane_off[1]), (float*)(slab + sa.plane_off[2]), (float*)(slab + sa.plane_off[3]), (uint32_t*)(slab + sa.alive_off[1]), cap, 1.f / 60, 0.93f, -0.26f); });
         printf("%-44s %8.3f ms  %7.1f GB/s\n", "hand-written ideal (no compaction)", ms, bytes / ms / 1e6);
