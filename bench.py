@@ -30,6 +30,11 @@ from bevy_hanabi_amd import effects  # noqa: E402
 CAPACITY = 1 << 24
 BYTES_PER_UPDATE = 68  # reads pos12+vel12+age4+lifetime4, writes pos12+vel12+age4, + 8 B alive-list entry
 HBM_PEAK_GBS = 8000.0  # MI355X spec (guides/MI355X_MICROARCH.md)
+# HBM bytes per k_update_stream launch at capacity 16,777,216 from the PMC passes committed under
+# profiles/ (r01b_summary.md: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate rocprofv3 runs).
+# Counters cannot be collected from inside this script; the figure is per launch of this workload.
+PMC_TRAFFIC_BYTES = {1 << 24: 1.0786e9}
+PMC_TRAFFIC_SOURCE = "profiles/r01b_summary.md"
 DT = 1.0 / 60.0
 MIN_LIFETIME = 0.8  # firework.rs: lifetime = uniform(0.8, 1.2)
 TIMING_PERIOD = 3   # HIP events bracket the kernels of every 3rd timed frame (each costs ~20 us of stream bubbles)
@@ -146,7 +151,7 @@ def main():
             "config": {"workload": "firework.rs trails EffectAsset, capacity=16_777_216 per GPU, burst spawner, all particles alive",
                        "capacity_per_gpu": cap, "dt": dt, "sharding": f"capacity slab x{n_gpus}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_update_stream<ProgDragAccel>", "kernel_ms_avg": k_ms, "compact_ms_avg": timing["compact_ms_avg"],
+                         "traffic": PMC_TRAFFIC_BYTES.get(cap), "traffic_unit": "B/launch", "traffic_source": PMC_TRAFFIC_SOURCE, "kernel": "k_update_stream<ProgDragAccel>", "kernel_ms_avg": k_ms, "compact_ms_avg": timing["compact_ms_avg"],
                          "kernel_samples": timing["frames"], "timing": f"HIP events on the simulation stream, every {TIMING_PERIOD}rd timed frame", "bytes_per_update": BYTES_PER_UPDATE,
                          "hbm_gbs_whole_step": updates / n_gpus * BYTES_PER_UPDATE / elapsed / 1e9},
         }
