@@ -25,7 +25,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import bevy_hanabi_amd as bh  # noqa: E402
-from bevy_hanabi_amd import effects  # noqa: E402
+from bevy_hanabi_amd import effects, sharding  # noqa: E402
 
 CAPACITY = 1 << 24
 BYTES_PER_UPDATE = 68  # reads pos12+vel12+age4+lifetime4, writes pos12+vel12+age4, + 8 B alive-list entry
@@ -97,7 +97,8 @@ def main():
     asset = effects.firework_trails(cap)
     ctx = bh.Context(local_rank)
     prog = ctx.create_program(bh.lower(asset))
-    fx = prog.create_effect(slot_base=rank * cap)
+    slot_base, _ = sharding.slab_plan(cap * n_gpus, n_gpus)[rank]  # rank g owns global slots [g*cap, (g+1)*cap)
+    fx = prog.create_effect(slot_base=slot_base)
 
     dt = frame_dt(1 + args.warmup + args.steps)
 
@@ -132,9 +133,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the only collective of the design: alive-particle counters, for reporting
-        a = torch.tensor([alive], dtype=torch.int64, device="cuda")
-        dist.all_reduce(a, op=dist.ReduceOp.SUM)
-        alive_total = int(a.item())
+        alive_total = sharding.allreduce_alive([alive], device="cuda")[0]
     else:
         alive_total = alive
     assert alive_total == cap * n_gpus, f"expected every particle alive during the timed frames, got {alive_total}"

@@ -1,0 +1,108 @@
+"""The drop-in boundary without a GPU: libhanabi_amd.so loads, exports every entry point that
+include/hanabi_amd.h declares (and nothing in the header is missing from the binding), validates
+program blobs, and fails loudly instead of falling back when no HIP device exists."""
+import ctypes as C
+import os
+import re
+import struct
+
+import pytest
+import torch
+
+import bevy_hanabi_amd as bh
+from bevy_hanabi_amd import effects, runtime
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "hanabi_amd.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hnb_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = runtime.load_library()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/hanabi_amd.h but not exported"
+    assert sorted(runtime.ABI_SYMBOLS) == names, "python binding list and header disagree"
+
+
+def test_library_is_in_tree_and_has_no_torch_or_oracle_dependency():
+    path = bh.build.runtime_lib_path()
+    assert path.startswith(ROOT)
+    needed = os.popen(f"readelf -d {path} 2>/dev/null").read()
+    assert "libamdhip64" in needed
+    assert "torch" not in needed and "oracle" not in needed and "python" not in needed
+
+
+def test_version_string():
+    assert b"gfx950" in runtime.load_library().hnb_version()
+
+
+def test_validate_accepts_lowered_programs():
+    for asset in (effects.single_particle(16), effects.firework_trails(1000), effects.force_field(1000), effects.instancing(1000), effects.ribbon(1000)):
+        bh.validate_program(bh.lower(asset))
+
+
+def test_validate_rejects_corrupt_blobs():
+    blob = bytearray(bh.lower(effects.firework_trails(1000)))
+    with pytest.raises(bh.HanabiError):
+        bh.validate_program(bytes(blob[:40]))            # truncated header
+    bad = bytearray(blob); bad[0:4] = b"XXXX"
+    with pytest.raises(bh.HanabiError):
+        bh.validate_program(bytes(bad))                  # wrong magic
+    bad = bytearray(blob); struct.pack_into("<I", bad, 4, 999)
+    with pytest.raises(bh.HanabiError):
+        bh.validate_program(bytes(bad))                  # wrong version
+    with pytest.raises(bh.HanabiError):
+        bh.validate_program(bytes(blob[:-8]))            # code stream runs past the end
+    with pytest.raises(bh.HanabiError):
+        bh.validate_program(b"")
+
+
+def test_validate_rejects_bad_instruction_operands():
+    from bevy_hanabi_amd.runtime import load_library
+    blob = bytearray(bh.lower(effects.firework_trails(1000)))
+    # find the update stream (header: see HnbProgramHeader) and poison the first opcode
+    hdr = struct.unpack_from("<24I", blob, 0)
+    lib = load_library()
+    ok = 0
+    for off in range(len(blob) - 8, 64, -8):
+        bad = bytearray(blob)
+        bad[off] = 0xFE  # opcode byte of some instruction (or table data -> may stay valid)
+        if lib.hnb_program_validate(bytes(bad), len(bad)) != 0:
+            ok += 1
+            break
+    assert ok, "no corrupted opcode was rejected"
+    assert hdr[0] == struct.unpack("<I", b"HNB2")[0]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box without a GPU")
+def test_no_device_is_a_loud_error_not_a_fallback():
+    with pytest.raises(bh.HanabiError) as ei:
+        bh.Context(0)
+    assert ei.value.code in (runtime.HNB_ERR_NO_DEVICE, -5)
+    assert b"" != runtime.load_library().hnb_last_error()
+
+
+def test_null_arguments_are_rejected():
+    lib = runtime.load_library()
+    assert lib.hnb_ctx_create(0, None) != 0
+    assert lib.hnb_simulate(None) != 0
+    assert lib.hnb_frame_begin(None, None) != 0
+    assert lib.hnb_effect_set_frame(None, 0, 0, None) != 0
+    assert lib.hnb_ctx_destroy(None) == 0 and lib.hnb_program_destroy(None) == 0 and lib.hnb_effect_destroy(None) == 0
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under bevy_hanabi_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "bevy_hanabi_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                assert not re.search(r"^\s*(import oracle|from oracle)|#include[^\n]*oracle|libhanabi_oracle|dlopen", src, flags=re.M), os.path.join(dp, f)

@@ -1,0 +1,138 @@
+"""The authoring API mirrored from the reference: names, defaults and
+failure modes that existing effect definitions rely on. Reference file:line in each test."""
+import numpy as np
+import pytest
+
+import bevy_hanabi_amd as bh
+from bevy_hanabi_amd import effects
+
+A = bh.Attribute
+
+
+def test_attribute_table():
+    # attributes.rs:549-675,1338-1378: 39 public attributes, names, types, defaults
+    allattrs = A.all()
+    assert len(allattrs) == 39
+    assert [a.name for a in allattrs[:8]] == ["id", "particle_counter", "position", "velocity", "age", "lifetime", "color", "hdr_color"]
+    assert str(A.POSITION.value_type) == "vec3<f32>" and A.POSITION.size == 12
+    assert str(A.COLOR.value_type) == "u32" and A.COLOR.default_value.to_py() == 0xFFFFFFFF
+    assert A.LIFETIME.default_value.to_py() == 1.0 and A.AGE.default_value.to_py() == 0.0
+    assert A.PREV.default_value.to_py() == 0xFFFFFFFF and A.NEXT.default_value.to_py() == 0xFFFFFFFF
+    assert str(A.SPRITE_INDEX.value_type) == "i32" and str(A.HDR_COLOR.value_type) == "vec4<f32>"
+    assert str(A.F32X2_3.value_type) == "vec2<f32>" and str(A.U32_2.value_type) == "u32" and str(A.RIBBON_ID.value_type) == "u32"
+    for a in allattrs:
+        assert A.from_name(a.name).id == a.id
+
+
+def test_pseudo_attributes_are_read_only():
+    # attr.rs:81-88
+    m = bh.Module()
+    for a in (A.ID, A.PARTICLE_COUNTER):
+        with pytest.raises(bh.PanicError, match="read-only"):
+            bh.SetAttributeModifier(a, m.lit(1.0))
+
+
+def test_modifier_context_is_enforced():
+    # asset.rs:482,499: init()/update() panic when the modifier's context lacks the phase
+    m = bh.Module()
+    asset = bh.EffectAsset(16, bh.SpawnerSettings.once(1.0), bh.Module())
+    with pytest.raises(bh.PanicError, match="Init"):
+        asset.init(bh.AccelModifier(m.lit((0.0, 1.0, 0.0))))
+    with pytest.raises(bh.PanicError, match="Update"):
+        asset.update(bh.InheritAttributeModifier(A.POSITION))
+    with pytest.raises(bh.PanicError):
+        asset.render(bh.AccelModifier(m.lit((0.0, 1.0, 0.0))))
+
+
+def test_asset_defaults():
+    # asset.rs:272-646
+    a = bh.EffectAsset(256, bh.SpawnerSettings.once(1.0), bh.Module())
+    assert a.capacity == 256 and a.prng_seed == 0
+    assert a.simulation_space == bh.SimulationSpace.Global
+    assert a.simulation_condition == bh.SimulationCondition.WhenVisible
+    assert a.motion_integration == bh.MotionIntegration.PostUpdate
+    d = bh.SpawnerSettings()  # Default = once(1.0) (spawn.rs:255-275)
+    assert d.is_once() and list(d.count().range()) == [1.0, 1.0]
+
+
+def test_particle_layout_contains_what_modifiers_touch():
+    # asset.rs particle_layout(): union of modifier attributes (+ implicit ones)
+    names = {a.name for a in effects.firework_trails(16).particle_layout()}
+    assert {"position", "velocity", "age", "lifetime", "color"} <= names
+    names = {a.name for a in effects.ribbon(16).particle_layout()}
+    assert {"position", "age", "lifetime", "size", "ribbon_id"} <= names
+
+
+def test_expression_from_another_module_is_rejected():
+    # expr.rs:785-825 ExprError::InvalidExprHandleError
+    w = bh.ExprWriter()
+    w2 = bh.ExprWriter()
+    foreign = (w2.lit(1.0) + w2.lit(2.0) + w2.lit(3.0) + w2.lit(4.0)).expr()
+    pos = w.lit((0.0, 0.0, 0.0)).expr()
+    asset = (bh.EffectAsset(16, bh.SpawnerSettings.once(1.0), w.finish())
+             .init(bh.SetAttributeModifier(A.POSITION, pos))
+             .init(bh.SetAttributeModifier(A.F32_0, foreign)))
+    with pytest.raises(bh.ExprError, match="InvalidExprHandleError"):
+        bh.lower(asset)
+
+
+def test_uniform_requires_equal_float_types():
+    # expr.rs:1162-1190: rand_uniform/rand_normal need statically known, equal float types
+    w = bh.ExprWriter()
+    bad = w.lit(1.0).uniform(w.lit((1.0, 2.0, 3.0))).expr()
+    pos = w.lit((0.0, 0.0, 0.0)).expr()
+    asset = (bh.EffectAsset(16, bh.SpawnerSettings.once(1.0), w.finish())
+             .init(bh.SetAttributeModifier(A.POSITION, pos))
+             .init(bh.SetAttributeModifier(A.F32_0, bad)))
+    with pytest.raises(bh.ExprError, match="TypeError"):
+        bh.lower(asset)
+
+
+def test_set_attribute_type_mismatch_is_an_error():
+    # attr.rs:92-115: static type check of the assigned expression
+    w = bh.ExprWriter()
+    scalar = w.lit(1.0).expr()
+    asset = (bh.EffectAsset(16, bh.SpawnerSettings.once(1.0), w.finish())
+             .init(bh.SetAttributeModifier(A.POSITION, scalar)))
+    with pytest.raises((bh.ExprError, bh.ShaderGenerateError)):
+        bh.lower(asset)
+
+
+def test_properties_declared_on_the_module():
+    # expr.rs add_property / properties.rs:216-395
+    asset = effects.force_field(64)
+    names = list(asset.module().property_names)
+    assert names == ["repulsor_accel", "repulsor_position", "attraction_accel", "max_attraction_speed", "sticky_factor", "shell_half_thickness"]
+
+
+def test_literal_values_and_builtin_module_api():
+    m = bh.Module()
+    a = m.lit(3.0)
+    b = m.lit((1.0, 2.0, 3.0))
+    assert m.is_const(a) and m.is_const(b)
+    r = m.builtin(bh.BuiltInOperator.Rand, bh.ValueType(bh.ScalarType.Float))
+    assert m.has_side_effect(r) and not m.is_const(r)  # expr.rs:1730-1738: rand() is re-evaluated, never const
+    t = m.builtin(bh.BuiltInOperator.Time)
+    assert not m.has_side_effect(t) and not m.is_const(t)
+    s = m.add(a, a)
+    assert m.is_const(s) and not m.has_side_effect(s)
+    assert m.num_expressions >= 3
+
+
+def test_lowered_program_is_deterministic_and_disassembles():
+    blob1 = bh.lower(effects.firework_trails(1000))
+    blob2 = bh.lower(effects.firework_trails(1000))
+    assert blob1 == blob2
+    txt = bh.disassemble(blob1)
+    assert "M_AGE_TICK" in txt and "M_VEL_SCALE" in txt and "M_VEL_ADD" in txt and "M_EULER" in txt
+    # update order: drag before accel (firework.rs:239-240), Euler last (PostUpdate)
+    upd = txt[txt.index("update"):]
+    assert upd.index("M_AGE_TICK") < upd.index("M_VEL_SCALE") < upd.index("M_VEL_ADD") < upd.index("M_EULER")
+
+
+def test_pcg32_is_deterministic_per_seed():
+    # spawn.rs:17-27 uses rand_pcg::Pcg32; only determinism is asserted (values are unpinned upstream)
+    a, b = bh.Pcg32(7, 11), bh.Pcg32(7, 11)
+    va = [bh.CpuValue.Uniform(1.0, 3.0).sample(a) for _ in range(8)]
+    vb = [bh.CpuValue.Uniform(1.0, 3.0).sample(b) for _ in range(8)]
+    assert va == vb and all(1.0 <= v <= 3.0 for v in va) and len(set(va)) > 1

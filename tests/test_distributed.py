@@ -1,0 +1,109 @@
+"""The N > 1 path on CPU: two gloo processes, each simulating its capacity slab (through the
+oracle, since there is no GPU here), the alive counters all-reduced exactly as bench.py does on
+RCCL. Checks that the union of the slabs is bit-identical to one single-device run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import bevy_hanabi_amd as bh
+from bevy_hanabi_amd import effects, sharding
+
+
+def test_slab_plan_and_spawn_split():
+    assert sharding.slab_plan(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    assert sharding.slab_plan(1 << 24, 8)[3] == (3 << 21, 1 << 21)
+    assert sharding.split_spawn(10, [3, 3, 2, 2]) == [3, 3, 2, 2]
+    assert sharding.split_spawn(5, [3, 3, 2, 2]) == [3, 2, 0, 0]
+    assert sharding.split_spawn(100, [3, 0, 2]) == [3, 0, 2]
+    assert sharding.instance_plan(10, 4) == [[0, 4, 8], [1, 5, 9], [2, 6], [3, 7]]
+    with pytest.raises(ValueError):
+        sharding.slab_plan(8, 0)
+    assert sharding.allreduce_alive([5, 7]) == [5, 7]  # no process group: identity
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+TOTAL = 6000
+FRAMES = 70
+
+
+def _script(total_free_by_rank=None):
+    from helpers import frame_seed
+    # burst of the whole capacity, die-off, a partial re-spawn that only fits the first slab(s)
+    out = [(TOTAL, frame_seed(0))] + [(0, frame_seed(f)) for f in range(1, 60)] + [(1000, frame_seed(60))]
+    out += [(0, frame_seed(f)) for f in range(61, FRAMES)]
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import Frame, OracleRunner
+    plan = sharding.slab_plan(TOTAL, world)
+    slot_base, cap = plan[rank]
+    r = OracleRunner(effects.firework_trails(cap), slot_base=slot_base)
+    import torch
+    for f, (spawn, seed) in enumerate(_script()):
+        # every rank derives the same split from the all-gathered free capacities
+        free = torch.zeros(world, dtype=torch.int64)
+        free[rank] = cap - r.fx.alive_count()
+        dist.all_reduce(free)
+        mine = sharding.split_spawn(spawn, free.tolist())[rank]
+        r.step(Frame(1 / 60, mine, seed, time=f / 60))
+    total_alive = sharding.allreduce_alive([r.fx.alive_count()])[0]
+    st = r.state()
+    q.put((rank, slot_base, cap, total_alive, st["alive"], {k: v for k, v in st["attrs"].items()}, st["counters"]["alive_count"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_slabs_equal_single_device_run():
+    from helpers import Frame, OracleRunner
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    # single-device reference over the burst + die-off part (the re-spawn reuses slots in
+    # last-killed-first order per slab, which a single list would order differently: §8e only
+    # promises union == single run for bursts that fill capacity, so compare up to frame 59)
+    single = OracleRunner(effects.firework_trails(TOTAL))
+    shards = [OracleRunner(effects.firework_trails(c), slot_base=b) for b, c in sharding.slab_plan(TOTAL, world)]
+    for f, (spawn, seed) in enumerate(_script()[:60]):
+        single.step(Frame(1 / 60, spawn, seed, time=f / 60))
+        split = sharding.split_spawn(spawn, [s.asset.capacity - s.fx.alive_count() for s in shards])
+        for s, n in zip(shards, split):
+            s.step(Frame(1 / 60, n, seed, time=f / 60))
+    ref = single.state()
+    union_alive = np.concatenate([s.state()["alive"] + b for s, (b, _) in zip(shards, sharding.slab_plan(TOTAL, world))])
+    np.testing.assert_array_equal(ref["alive"], union_alive)
+    for name, plane in ref["attrs"].items():
+        union = np.concatenate([s.state()["attrs"][name] for s in shards])
+        np.testing.assert_array_equal(plane, union, err_msg=name)
+    assert 0 < ref["counters"]["alive_count"] < TOTAL  # the die-off is in progress: compaction was exercised
+
+    # the two gloo ranks agree on the all-reduced counter, and it is the sum of their slabs
+    totals = {t[3] for t in results}
+    assert len(totals) == 1
+    assert totals.pop() == sum(t[6] for t in results)
+    assert [t[1] for t in results] == [0, TOTAL // 2]

@@ -1,0 +1,86 @@
+"""hanabi-math (oracle/oracle_math.h == bevy_hanabi_amd/csrc/hnb_math.h): the transcendental
+functions are defined as "evaluate in binary64 with + - * / only, round once to binary32".
+Checked here against numpy's binary64 libm rounded to f32: at most 1 ulp apart (in practice 0),
+and exact on the special values WGSL defines. The product copy of the same header is compared
+bit-for-bit against this one through tests/test_lowering_cpu.py (host build) and the GPU tests."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+
+RNG = np.random.default_rng(1234)
+N = 4000
+
+FN1 = {
+    "sin": (0, np.sin, lambda: RNG.uniform(-50, 50, N)),
+    "cos": (1, np.cos, lambda: RNG.uniform(-50, 50, N)),
+    "tan": (2, np.tan, lambda: RNG.uniform(-1.5, 1.5, N)),
+    "exp": (3, np.exp, lambda: RNG.uniform(-80, 80, N)),
+    "log": (4, np.log, lambda: np.exp(RNG.uniform(-80, 80, N))),
+    "log2": (5, np.log2, lambda: np.exp(RNG.uniform(-80, 80, N))),
+    "atan": (6, np.arctan, lambda: RNG.uniform(-1e3, 1e3, N)),
+    "asin": (7, np.arcsin, lambda: RNG.uniform(-1, 1, N)),
+    "acos": (8, np.arccos, lambda: RNG.uniform(-1, 1, N)),
+    "exp2": (9, np.exp2, lambda: RNG.uniform(-120, 120, N)),
+    "sqrt": (10, np.sqrt, lambda: np.exp(RNG.uniform(-80, 80, N))),
+    "inverseSqrt": (11, lambda x: 1.0 / np.sqrt(x), lambda: np.exp(RNG.uniform(-80, 80, N))),
+}
+
+
+def ulp_diff(a, b):
+    a = np.float32(a).view(np.int32).astype(np.int64)
+    b = np.float32(b).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)
+
+
+@pytest.mark.parametrize("name", sorted(FN1))
+def test_unary_within_one_ulp_of_libm(name):
+    code, ref, gen = FN1[name]
+    xs = gen().astype(np.float32)
+    got = np.array([oracle.math1(code, float(x)) for x in xs], dtype=np.float32)
+    want = ref(xs.astype(np.float64)).astype(np.float32)
+    finite = np.isfinite(want)
+    d = ulp_diff(got[finite], want[finite])
+    assert d.max() <= 1, f"{name}: max {d.max()} ulp at x={xs[finite][d.argmax()]!r}"
+    assert (np.isfinite(got) == finite).all()
+
+
+def test_pow_and_atan2_within_one_ulp():
+    xs = np.exp(RNG.uniform(-10, 10, N)).astype(np.float32)
+    ys = RNG.uniform(-8, 8, N).astype(np.float32)
+    got = np.array([oracle.math2(0, float(x), float(y)) for x, y in zip(xs, ys)], dtype=np.float32)
+    want = np.power(xs.astype(np.float64), ys.astype(np.float64)).astype(np.float32)
+    ok = np.isfinite(want) & (want != 0)
+    assert ulp_diff(got[ok], want[ok]).max() <= 1
+    a = RNG.uniform(-100, 100, N).astype(np.float32)
+    b = RNG.uniform(-100, 100, N).astype(np.float32)
+    got = np.array([oracle.math2(1, float(x), float(y)) for x, y in zip(a, b)], dtype=np.float32)
+    want = np.arctan2(a.astype(np.float64), b.astype(np.float64)).astype(np.float32)
+    assert ulp_diff(got, want).max() <= 1
+
+
+def test_special_values():
+    m1, m2 = oracle.math1, oracle.math2
+    assert m1(0, 0.0) == 0.0 and m1(1, 0.0) == 1.0 and m1(3, 0.0) == 1.0 and m1(9, 0.0) == 1.0
+    assert m1(4, 1.0) == 0.0 and m1(5, 1.0) == 0.0 and m1(5, 8.0) == 3.0 and m1(9, 10.0) == 1024.0
+    assert m1(7, 1.0) == float(np.float32(math.pi / 2)) and m1(8, -1.0) == float(np.float32(math.pi)) and m1(8, 1.0) == 0.0
+    assert math.isnan(m1(7, 1.5)) and math.isnan(m1(8, -1.5)) and math.isnan(m1(4, -1.0)) and math.isnan(m1(10, -1.0))
+    assert m1(4, 0.0) == -math.inf and m1(3, 1000.0) == math.inf and m1(3, -1000.0) == 0.0
+    assert m1(10, 4.0) == 2.0 and m1(11, 4.0) == 0.5
+    assert m2(0, 2.0, 10.0) == 1024.0 and m2(0, 8.0, 1.0 / 3.0) == 2.0 and m2(0, 0.0, 0.5) == 0.0 and m2(0, 5.0, 0.0) == 1.0
+    assert m2(1, 0.0, 1.0) == 0.0 and m2(1, 1.0, 0.0) == float(np.float32(math.pi / 2)) and m2(1, 0.0, -1.0) == float(np.float32(math.pi))
+    # WGSL `%` on floats is truncated remainder: sign follows the dividend
+    assert m2(2, 5.5, 2.0) == 1.5 and m2(2, -5.5, 2.0) == -1.5 and m2(2, 5.5, -2.0) == 1.5
+
+
+def test_large_argument_reduction():
+    # Cody-Waite/Payne-Hanek range: sin/cos stay within 1 ulp far from zero
+    for x in (1e4, 12345.678, 1e6, 3.4e7, -7.7e6):
+        x32 = float(np.float32(x))
+        for code, ref in ((0, math.sin), (1, math.cos)):
+            got, want = np.float32(oracle.math1(code, x32)), np.float32(ref(x32))
+            assert ulp_diff(got, want) <= 1, (x, code, got, want)
