@@ -458,18 +458,20 @@ k_update_stream(const StreamArgs args, const uint64_t* __restrict__ inst_base, c
     uint32_t* seg = s_list + wave * kWaveRows;
     uint32_t wa = 0, wd = 0;  // wave-uniform survivor / casualty counts of this quarter
     const uint64_t below = (1ull << lane) - 1ull;
-    // alive-list rows of the whole quarter: one round trip instead of one per step
-    uint4 rows[kWaveRows / kStepRows];
+    // Alive-list rows of the whole quarter, fetched up front (one round trip instead of one per
+    // step) in ROW-major order: rowsT[step][p] = row step*256 + p*64 + lane, so every load
+    // instruction reads 64 consecutive rows.
+    uint32_t rowsT[kWaveRows / kStepRows][4];
 #pragma unroll
     for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
-        const uint32_t li = wstart + step * kStepRows + lane * 4u;
-        rows[step] = make_uint4(0u, 0u, 0u, 0u);
-        if constexpr (!(PROBE & 16)) {
-            if (li + 4u <= n) rows[step] = *reinterpret_cast<const uint4*>(alive_rd + li);
-            else {
-                if (li < n) rows[step].x = alive_rd[li];
-                if (li + 1u < n) rows[step].y = alive_rd[li + 1u];
-                if (li + 2u < n) rows[step].z = alive_rd[li + 2u];
+#pragma unroll
+        for (uint32_t p = 0; p < 4; ++p) {
+            const uint32_t li = wstart + step * kStepRows + p * 64u + lane;
+            rowsT[step][p] = 0u;
+            if constexpr (!(PROBE & 16)) {
+                if (li < n) rowsT[step][p] = alive_rd[li];
+            } else {
+                rowsT[step][p] = li;
             }
         }
     }
@@ -477,19 +479,24 @@ k_update_stream(const StreamArgs args, const uint64_t* __restrict__ inst_base, c
     for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
         const uint32_t sbase = wstart + step * kStepRows;
         if (sbase >= n) break;
-        const uint32_t li = sbase + lane * 4u;
+        // Two row->lane mappings, chosen per step (wave-uniform):
+        //  dense  the 256 rows hold 256 consecutive slots starting at a multiple of 4 (a burst that
+        //         has not lost anyone yet): lane l owns rows 4l..4l+3 = 4 consecutive slots, and
+        //         every plane access is a 16-byte load / store;
+        //  sparse lane l owns rows l, 64+l, 128+l, 192+l, so each per-particle access instruction
+        //         touches 64 consecutive list rows (neighbouring slots while the list is sorted).
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowsT[step][0]);
+        bool run_ok = sbase + kStepRows <= n && (s0 & 3u) == 0u;
+#pragma unroll
+        for (uint32_t p = 0; p < 4; ++p) run_ok = run_ok && rowsT[step][p] == s0 + p * 64u + lane;
+        const bool dense = __all(run_ok);
         uint32_t slot[4];
         bool valid[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) valid[p] = li + p < n;
-        if constexpr (PROBE & 16) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) slot[p] = li + p;
-        } else {
-            slot[0] = rows[step].x; slot[1] = rows[step].y; slot[2] = rows[step].z; slot[3] = rows[step].w;
+        for (uint32_t p = 0; p < 4; ++p) {
+            slot[p] = dense ? s0 + lane * 4u + p : rowsT[step][p];
+            valid[p] = dense || (sbase + p * 64u + lane < n);
         }
-        const bool quad = valid[3] && ((slot[0] & 3u) == 0u) && slot[1] == slot[0] + 1u && slot[2] == slot[0] + 2u && slot[3] == slot[0] + 3u;
-        const bool dense = __all(quad);  // wave-uniform: all 64 lanes own an aligned run of 4 slots
 
         Pinned<4> X;
 #pragma unroll
@@ -513,23 +520,41 @@ k_update_stream(const StreamArgs args, const uint64_t* __restrict__ inst_base, c
             if (acc == 123.456f) X.alive[0] = false;
         }
 
-        // wave-local stable ranks from ballots: rows are lane-major (lane l owns rows 4l..4l+3)
-        uint32_t before_a = 0, before_v = 0, tot_a = 0, tot_v = 0;
+        // wave-local stable ranks from ballots (no shuffles), in the row order of the mapping
+        uint32_t tot_a = 0, tot_v = 0;
         bool al[4];
+        uint64_t ma[4], mv[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             al[p] = valid[p] && X.alive[p];
-            const uint64_t ma = __ballot(al[p]), mv = __ballot(valid[p]);
-            before_a += (uint32_t)__popcll(ma & below); tot_a += (uint32_t)__popcll(ma);
-            before_v += (uint32_t)__popcll(mv & below); tot_v += (uint32_t)__popcll(mv);
+            ma[p] = __ballot(al[p]);
+            mv[p] = __ballot(valid[p]);
+            tot_a += (uint32_t)__popcll(ma[p]);
+            tot_v += (uint32_t)__popcll(mv[p]);
         }
-        uint32_t ra = wa + before_a;                 // survivors of this quarter before my first row
-        uint32_t rd = wd + (before_v - before_a);    // casualties before my first row
+        if (dense) {  // lane-major rows: everything the lower lanes own comes first
+            uint32_t before_a = 0, before_v = 0;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            if (!valid[p]) continue;
-            if (al[p]) seg[ra++] = slot[p];
-            else seg[kWaveRows - 1u - (rd++)] = slot[p];
+            for (int p = 0; p < 4; ++p) { before_a += (uint32_t)__popcll(ma[p] & below); before_v += (uint32_t)__popcll(mv[p] & below); }
+            uint32_t ra = wa + before_a;                 // survivors of this quarter before my first row
+            uint32_t rd = wd + (before_v - before_a);    // casualties before my first row
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (al[p]) seg[ra++] = slot[p];
+                else seg[kWaveRows - 1u - (rd++)] = slot[p];
+            }
+        } else {      // row-major rows: group p comes after all of groups < p
+            uint32_t base_a = wa, base_d = wd;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t ba = (uint32_t)__popcll(ma[p] & below), bv = (uint32_t)__popcll(mv[p] & below);
+                if (valid[p]) {
+                    if (al[p]) seg[base_a + ba] = slot[p];
+                    else seg[kWaveRows - 1u - (base_d + (bv - ba))] = slot[p];
+                }
+                base_a += (uint32_t)__popcll(ma[p]);
+                base_d += (uint32_t)__popcll(mv[p]) - (uint32_t)__popcll(ma[p]);
+            }
         }
         wa += tot_a;
         wd += tot_v - tot_a;

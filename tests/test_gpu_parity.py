@@ -36,7 +36,7 @@ def test_c1_single_particle(ctx):
 
 
 def test_c2_firework_life_cycle(ctx):
-    cap = 20000  # 5 chunks: exercises the cross-chunk look-back
+    cap = 20000  # 5 chunks: exercises the cross-chunk prefix of k_compact
     asset = effects.firework_trails(cap)
     frames = burst_then_run(cap, 80) + [Frame(1 / 60, 7777, frame_seed(100))] + [Frame(1 / 60, 0, frame_seed(101 + f)) for f in range(30)]
     st = run_script(GpuRunner(asset, ctx=ctx), frames, OracleRunner(asset), every=6)
@@ -52,7 +52,7 @@ def test_c3_force_field(ctx):
 
 
 def test_c4_instancing_batch_of_instances(ctx):
-    """Several instances of one program: one init + one update launch for the whole batch."""
+    """Several instances of one program: one init + one update + one compact launch for the whole batch."""
     cap, n_inst = 9000, 5
     asset = effects.instancing(cap, rate=cap / 0.25)
     blob = bh.lower(asset)
@@ -145,5 +145,93 @@ def test_large_burst_properties(ctx):
     ref = orc.state()
     for a in (A.POSITION, A.VELOCITY, A.LIFETIME, A.COLOR):
         np.testing.assert_array_equal(ref["attrs"][a.name], r.fx.read_attr(a.id).view(np.uint32)[base:base + 4096])
+    r.fx.destroy()
+    r.prog.destroy()
+
+
+def test_committed_golden_fixtures(ctx):
+    """The product against tests/golden/states_small.npz (made by tests/golden/make_golden.py from
+    the oracle); the oracle is not called here."""
+    import os
+    from golden.make_golden import SMALL, scripts
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "states_small.npz"))
+    sc = scripts()
+    for name in SMALL:
+        asset, frames = sc[name]
+        r = GpuRunner(asset, ctx=ctx)
+        for fr in frames:
+            r.step(fr)
+        st = r.state()
+        np.testing.assert_array_equal(gold[f"{name}/alive"], st["alive"], err_msg=name)
+        np.testing.assert_array_equal(gold[f"{name}/dead"], st["dead"], err_msg=name)
+        np.testing.assert_array_equal(gold[f"{name}/counters"], np.array([st["counters"][k] for k in sorted(st["counters"])], dtype=np.uint32), err_msg=name)
+        for an, v in st["attrs"].items():
+            np.testing.assert_array_equal(gold[f"{name}/attr/{an}"], v, err_msg=f"{name}/{an}")
+        r.fx.destroy()
+        r.prog.destroy()
+
+
+def test_many_chunks_die_off_and_respawn(ctx):
+    """318 chunks (> one workgroup's worth of chunk counts): k_compact's strided prefix, the
+    other-column move and the last-killed-first slot reuse, against the (OpenMP) oracle."""
+    cap = 1_300_000
+    asset = effects.firework_trails(cap)
+    g, o = GpuRunner(asset, ctx=ctx), OracleRunner(asset, omp=True)
+    frames = [Frame(1 / 60, cap, frame_seed(0))] + [Frame(1 / 60, 0, frame_seed(f), time=f / 60) for f in range(1, 58)]
+    frames += [Frame(1 / 60, 400_000, frame_seed(58), time=58 / 60)] + [Frame(1 / 60, 0, frame_seed(f), time=f / 60) for f in range(59, 66)]
+    for i, fr in enumerate(frames):
+        g.step(fr)
+        o.step(fr)
+        if i in (47, 50, 55, 57, 58, 61, 65):
+            assert_same_state(o.state(), g.state(), f"frame {i}")
+    assert 0 < g.fx.alive_count() < cap
+    g.fx.destroy()
+    g.prog.destroy()
+
+
+def test_full_size_die_off_invariants(ctx):
+    """BASELINE config size (16,777,216) through the die-off, checked with size-independent
+    properties computed in numpy (no oracle): stable compaction (the alive list stays strictly
+    increasing), survivors == particles with age < lifetime, the k-th casualty in list order lands
+    on dead row n-1-k (vfx_update.wgsl:150-151), alive + dead is a partition of the slots."""
+    cap = 1 << 24
+    asset = effects.firework_trails(cap)
+    r = GpuRunner(asset, ctx=ctx)
+    r.step(Frame(1 / 60, cap, frame_seed(0)))
+    for f in range(1, 46):
+        r.step(Frame(1 / 60, 0, frame_seed(f), time=f / 60))
+    life = r.fx.read_attr(A.LIFETIME.id)[:, 0]
+    assert r.fx.alive_count() == cap
+    checked = 0
+    check_frames = {48, 54, 60, 66, 72, 75}
+    for f in range(46, 76):
+        if f in check_frames:
+            prev_alive = r.fx.alive_list()
+        r.step(Frame(1 / 60, 0, frame_seed(f), time=f / 60))
+        if f not in check_frames:
+            continue
+        n = len(prev_alive)
+        age = r.fx.read_attr(A.AGE.id)[:, 0]
+        alive = r.fx.alive_list()
+        dead = r.fx.dead_list()
+        keep = age[prev_alive] < life[prev_alive]
+        np.testing.assert_array_equal(alive, prev_alive[keep])
+        cas = prev_alive[~keep]
+        # dead rows [alive_count, n) hold this frame's casualties, last casualty on top of the stack
+        np.testing.assert_array_equal(dead[: n - len(alive)], cas[::-1])
+        assert len(alive) + len(dead) == cap
+        if len(alive) > 1:
+            assert (np.diff(alive.astype(np.int64)) > 0).all()
+        m = r.fx.metadata()
+        assert m["alive_count"] == len(alive) and m["max_update"] == n and m["dead_count"] == n - len(alive)
+        checked += 1
+    assert checked == len(check_frames)
+    assert r.fx.alive_count() == 0 or r.fx.alive_count() < cap // 100
+    # all slots are free again: the dead list is a permutation of [0, cap)
+    for f in range(76, 80):
+        r.step(Frame(1 / 60, 0, frame_seed(f), time=f / 60))
+    assert r.fx.alive_count() == 0
+    dead = r.fx.dead_list()
+    assert len(dead) == cap and np.array_equal(np.sort(dead), np.arange(cap, dtype=np.uint32))
     r.fx.destroy()
     r.prog.destroy()

@@ -1,0 +1,85 @@
+"""Development tool: throughput of the other BASELINE.json configs (C3 force_field, C4 instancing,
+C5 ribbon churn) and of the firework die-off (compaction-heavy frames). Not the headline bench."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bevy_hanabi_amd as bh
+from bevy_hanabi_amd import effects
+from bench import frame_seed, DT
+
+which = sys.argv[1:] or ["c2die", "c3", "c4", "c5"]
+ctx = bh.Context(0)
+
+def run(label, prog, fxs, frames, spawn_fn, bytes_per_update, warm=3):
+    f = 0
+    def step(timed):
+        nonlocal f
+        ctx.frame_begin(DT, f * DT)
+        for i, fx in enumerate(fxs):
+            fx.set_frame(spawn_fn(f, i), frame_seed(f * 4099 + i))
+        ctx.simulate(); f += 1
+    for _ in range(warm): step(False)
+    ctx.synchronize()
+    a0 = sum(fx.alive_count() for fx in fxs) if len(fxs) <= 8 else None
+    ctx.enable_kernel_timing(1)
+    t0 = time.perf_counter()
+    for _ in range(frames): step(True)
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    tm = ctx.kernel_timing(); ctx.enable_kernel_timing(0)
+    a1 = sum(fx.alive_count() for fx in fxs[:8])
+    print(f"{label}: {el/frames*1e3:.3f} ms/frame wall (events on), update {tm['update_ms_avg']:.4f} ms, compact {tm['compact_ms_avg']:.4f} ms, init {tm['init_ms_avg']:.4f} ms; alive(first 8 inst) {a1}", flush=True)
+    return tm
+
+if "c2die" in which:
+    cap = 1 << 24
+    prog = ctx.create_program(bh.lower(effects.firework_trails(cap))); fx = prog.create_effect()
+    ctx.frame_begin(DT, 0); fx.set_frame(cap, frame_seed(0)); ctx.simulate()
+    f = 1
+    for _ in range(46):
+        ctx.frame_begin(DT, f * DT); fx.set_frame(0, frame_seed(f)); ctx.simulate(); f += 1
+    ctx.synchronize()
+    ctx.enable_kernel_timing(1)
+    rows = []
+    for _ in range(26):
+        a0 = fx.alive_count()
+        ctx.enable_kernel_timing(1)
+        ctx.frame_begin(DT, f * DT); fx.set_frame(0, frame_seed(f)); ctx.simulate(); f += 1
+        tm = ctx.kernel_timing(); a1 = fx.alive_count()
+        rows.append((a0, a0 - a1, tm["update_ms_avg"], tm["compact_ms_avg"]))
+    ctx.enable_kernel_timing(0)
+    print("firework die-off: alive_in, died, update_ms, compact_ms")
+    for r in rows: print("   %9d %9d  %.4f  %.4f   -> %.1f GB/s @68B" % (r[0], r[1], r[2], r[3], r[0] * 68 / ((r[2] + r[3]) * 1e-3) / 1e9 if r[0] else 0))
+    prog.destroy()
+
+if "c3" in which:
+    cap = 1 << 23
+    prog = ctx.create_program(bh.lower(effects.force_field(cap))); fx = prog.create_effect()
+    tm = run("C3 force_field 8M", prog, [fx], 60, lambda f, i: cap if f == 0 else 0, 68, warm=3)
+    a = fx.alive_count()
+    print(f"   -> {a * 68 / (tm['update_ms_avg'] * 1e-3) / 1e9:.1f} GB/s @68B on {a} alive")
+    prog.destroy()
+
+if "c5" in which:
+    cap = 1 << 22
+    asset = effects.ribbon(cap)
+    prog = ctx.create_program(bh.lower(asset)); fx = prog.create_effect()
+    sp = bh.EffectSpawner(asset.spawner); rng = bh.Pcg32()
+    counts = [sp.tick(DT, rng) for _ in range(400)]
+    tm = run("C5 ribbon 4M churn", prog, [fx], 200, lambda f, i: counts[f], 20, warm=120)
+    a = fx.alive_count()
+    print(f"   -> steady alive {a}; update+compact {(tm['update_ms_avg'] + tm['compact_ms_avg']) * 1e3:.1f} us, {a * 20 / ((tm['update_ms_avg'] + tm['compact_ms_avg']) * 1e-3) / 1e9:.1f} GB/s @20B")
+    prog.destroy()
+
+if "c4" in which:
+    cap, n_inst = 65536, int(os.environ.get("C4_INST", "4096"))
+    asset = effects.instancing(cap)
+    prog = ctx.create_program(bh.lower(asset))
+    t0 = time.perf_counter()
+    fxs = [prog.create_effect() for _ in range(n_inst)]
+    print(f"C4: created {n_inst} instances in {time.perf_counter() - t0:.1f} s")
+    tm = run(f"C4 instancing {n_inst}x65536 (burst, all alive)", prog, fxs, 20, lambda f, i: cap if f == 0 else 0, 68, warm=3)
+    tot = cap * n_inst
+    print(f"   -> {tot * 68 / (tm['update_ms_avg'] * 1e-3) / 1e9:.1f} GB/s @68B, {tot / ((tm['update_ms_avg'] + tm['compact_ms_avg']) * 1e-3):.3e} updates/s (kernels)")
+    prog.destroy()
+ctx.close()
