@@ -14,4 +14,4 @@ try:
 except ImportError as _e:  # pragma: no cover
     raise ImportError("bevy_hanabi_amd._hanabi_host is not built: run `python -m bevy_hanabi_amd.build`") from _e
 
-from .runtime import Context, Effect, EffectMetadata, HanabiError, Program, SimParams, validate_program  # noqa: F401,E402
+from .runtime import Context, Effect, EffectMetadata, HanabiError, Program, SimParams, jit_precompile, validate_program  # noqa: F401,E402

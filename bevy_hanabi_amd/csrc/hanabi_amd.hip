@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "hnb_kernels.hip.h"
+#include "hnb_jit.h"
 
 using namespace hnb;
 
@@ -75,6 +76,7 @@ typedef ProgStatic<OP_(AGE_TICK), OP_(CONFORM_SPHERE), OP_(CONFORM_SPHERE), OP_(
 
 void select_stream_kernel(const Ins* code, uint32_t n, StreamLaunchFn* fn, const char** name) {
 #define TRY_(PROG, WAVES) if (PROG::matches(code, n)) { *fn = &launch_stream<PROG, WAVES>; *name = #PROG; return; }
+    TRY_(ProgNone, HNB_STREAM_WAVES)
     TRY_(ProgAge, HNB_STREAM_WAVES)
     TRY_(ProgAgeEuler, HNB_STREAM_WAVES)
     TRY_(ProgAccel, HNB_STREAM_WAVES)
@@ -113,6 +115,10 @@ struct HnbProgram {
     bool update_streams = false;  // update stream runs on the streaming kernel (macro ops, U operands)
     StreamLaunchFn stream_launch = nullptr;  // specialised (or interpreted) streaming kernel for this update stream
     const char* stream_kernel_name = "";
+    // kernels specialised for this program at creation (hnb_jit.h); null = the ahead-of-time kernels run
+    hipModule_t jit_module = nullptr;
+    hipFunction_t jit_init = nullptr, jit_update = nullptr;
+    std::string kernel_info, jit_log;
     std::vector<Ins> uniform_code;  // evaluated on the host per instance per frame
     std::vector<HnbEffect*> effects;
     // device tables, sized for `table_cap` instances
@@ -401,6 +407,41 @@ int read_meta(HnbEffect* fx, DevMeta* out) {
     return HNB_OK;
 }
 
+// Streaming eligibility of an update stream: only macro ops on pinned registers, every operand in
+// the parameter block, and no non-pinned attribute touched by the update program.
+bool update_is_streamable(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs) {
+    bool streams = true;
+    for (uint32_t i = 0; i < h.update_len; ++i) {
+        uint32_t w[2];
+        memcpy(w, b + h.update_off + (size_t)i * 8, 8);
+        const uint32_t op = w[0] & 0xffu, a = (w[0] >> 16) & 0xffu, bb = w[0] >> 24, c = w[1] & 0xffu;
+        bool ok = vm_op_is_streamable(op) && (a & HNB_OPERAND_U);
+        if (ok && (op == HNB_OP_M_RADIAL_ACCEL || op == HNB_OP_M_TANGENT_ACCEL || op == HNB_OP_M_CONFORM_SPHERE ||
+                   op == HNB_OP_M_KILL_SPHERE || op == HNB_OP_M_KILL_AABB))
+            ok = (bb & HNB_OPERAND_U) != 0;
+        if (ok && op == HNB_OP_M_TANGENT_ACCEL) ok = (c & HNB_OPERAND_U) != 0;
+        if (!ok) streams = false;
+    }
+    for (uint32_t i = 0; i < h.n_attrs; ++i)
+        if (attrs[i].update_flags && attrs[i].reg == HNB_REG_NONE) streams = false;
+    return streams;
+}
+
+// What to specialise for a program (see hnb_jit.h). `aot_static`: a pre-built ProgStatic kernel matches.
+jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams, bool aot_static) {
+    jit::Request rq;
+    rq.attrs = attrs; rq.n_attrs = h.n_attrs;
+    rq.init = reinterpret_cast<const Ins*>(b + h.init_off); rq.init_len = h.init_len;
+    rq.update = reinterpret_cast<const Ins*>(b + h.update_off); rq.update_len = h.update_len;
+    rq.want_init = h.init_len > 0;
+    rq.want_update_stream = streams && !aot_static && h.update_len > 0;
+    rq.want_update_generic = !streams && h.update_len > 0;
+    bool lean = true;
+    for (uint32_t i = 0; i < h.update_len; ++i) lean = lean && vm_op_is_lean(rq.update[i].x & 0xffu);
+    rq.stream_waves = lean ? HNB_STREAM_WAVES : HNB_STREAM_WAVES_FULL;
+    return rq;
+}
+
 }  // namespace
 
 extern "C" {
@@ -500,23 +541,32 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     p->slab_bytes = off;
     p->uniform_code.resize(h.uniform_len);
     if (h.uniform_len) memcpy(p->uniform_code.data(), b + h.uniform_off, (size_t)h.uniform_len * 8);
-    // Streaming eligibility: only macro ops on pinned registers, every operand in the
-    // parameter block, and no non-pinned attribute touched by the update program.
-    p->update_streams = true;
-    for (uint32_t i = 0; i < h.update_len; ++i) {
-        uint32_t w[2];
-        memcpy(w, b + h.update_off + (size_t)i * 8, 8);
-        const uint32_t op = w[0] & 0xffu, a = (w[0] >> 16) & 0xffu, bb = w[0] >> 24, c = w[1] & 0xffu;
-        bool ok = vm_op_is_streamable(op) && (a & HNB_OPERAND_U);
-        if (ok && (op == HNB_OP_M_RADIAL_ACCEL || op == HNB_OP_M_TANGENT_ACCEL || op == HNB_OP_M_CONFORM_SPHERE ||
-                   op == HNB_OP_M_KILL_SPHERE || op == HNB_OP_M_KILL_AABB))
-            ok = (bb & HNB_OPERAND_U) != 0;
-        if (ok && op == HNB_OP_M_TANGENT_ACCEL) ok = (c & HNB_OPERAND_U) != 0;
-        if (!ok) p->update_streams = false;
-    }
-    for (uint32_t i = 0; i < h.n_attrs; ++i)
-        if (p->attrs[i].update_flags && p->attrs[i].reg == HNB_REG_NONE) p->update_streams = false;
+    p->update_streams = update_is_streamable(b, h, p->attrs.data());
     if (p->update_streams) select_stream_kernel(reinterpret_cast<const Ins*>(b + h.update_off), h.update_len, &p->stream_launch, &p->stream_kernel_name);
+    const bool aot_static = p->update_streams && strcmp(p->stream_kernel_name, "ProgInterp") != 0;
+    p->kernel_info = std::string("init=") + (h.init_len ? "interp" : "none") + " update=" +
+                     (p->update_streams ? (aot_static ? std::string("aot-stream:") + p->stream_kernel_name : std::string("interp-stream")) : std::string("interp-generic"));
+    if (jit::enabled()) {
+        const jit::Request rq = make_jit_request(b, h, p->attrs.data(), p->update_streams, aot_static);
+        jit::Result res;
+        if (jit::build(rq, res)) {
+            hipError_t je = hipModuleLoadData(&p->jit_module, res.code.data());
+            if (je == hipSuccess && !res.init_name.empty()) je = hipModuleGetFunction(&p->jit_init, p->jit_module, res.init_name.c_str());
+            if (je == hipSuccess && !res.update_name.empty()) je = hipModuleGetFunction(&p->jit_update, p->jit_module, res.update_name.c_str());
+            if (je != hipSuccess) {
+                p->jit_log = std::string("loading the specialised code object failed: ") + hipGetErrorString(je);
+                p->jit_init = p->jit_update = nullptr;
+            } else {
+                p->kernel_info = std::string("init=") + (p->jit_init ? "jit" : (h.init_len ? "interp" : "none")) + " update=" +
+                                 (p->jit_update ? (p->update_streams ? "jit-stream" : "jit-generic")
+                                                : (p->update_streams ? (aot_static ? std::string("aot-stream:") + p->stream_kernel_name : std::string("interp-stream"))
+                                                                     : std::string("interp-generic")));
+                if (res.from_cache) p->kernel_info += " (jit cache hit)";
+            }
+        } else if (!res.log.empty()) {
+            p->jit_log = res.log;
+        }
+    }
     const size_t code_bytes = ((size_t)h.init_len + h.update_len) * 8;
     hipError_t e = hipMalloc(&p->d_code, std::max<size_t>(code_bytes, 8));
     if (e != hipSuccess) { delete p; return fail(HNB_ERR_OUT_OF_MEMORY, "hipMalloc(code) failed: %s", hipGetErrorString(e)); }
@@ -540,6 +590,7 @@ int hnb_program_destroy(HnbProgram* p) {
         if (p->upload_done[i]) hipEventDestroy(p->upload_done[i]);
         if (p->kernels_done[i]) hipEventDestroy(p->kernels_done[i]);
     }
+    if (p->jit_module) hipModuleUnload(p->jit_module);
     hipFree(p->d_code);
     ctx->programs.erase(std::remove(ctx->programs.begin(), ctx->programs.end(), p), ctx->programs.end());
     delete p;
@@ -680,7 +731,13 @@ int hnb_simulate(HnbContext* ctx) {
         const bool timed = ctx->timing && (ctx->timing_tick % ctx->timing) == 0;
         if (blocks) {
             if (timed) { hipEventCreate(&ti.a); hipEventCreate(&ti.b); hipEventRecord(ti.a, ctx->stream); }
-            k_init<<<blocks, kInitBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub);
+            if (p->jit_init) {
+                const DevMeta* mi = p->d_meta[par];
+                void* ka[] = {&p->dev, &p->d_inst_base, &mi, &dfi, &dub};
+                HIP_TRY(hipModuleLaunchKernel(p->jit_init, blocks, 1, 1, kInitBlock, 1, 1, 0, ctx->stream, ka, nullptr));
+            } else {
+                k_init<InterpCode><<<blocks, kInitBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub);
+            }
             if (timed) { hipEventRecord(ti.b, ctx->stream); ctx->t_init.push_back(ti); }
         }
         // one workgroup per 4096-row chunk of every instance's alive list
@@ -706,9 +763,19 @@ int hnb_simulate(HnbContext* ctx) {
                 if (at.upd_flags & HNB_ATTR_UPD_LOAD) sa.flags |= 1u << pi;
                 if (at.upd_flags & HNB_ATTR_UPD_STORE) sa.flags |= 16u << pi;
             }
-            p->stream_launch(total_chunks, ctx->stream, sa, p->d_inst_base, p->d_meta[par], dfi, dub, cb);
+            if (p->jit_update) {
+                const DevMeta* mi = p->d_meta[par];
+                void* ka[] = {&sa, &p->d_inst_base, &mi, &dfi, &dub, &cb};
+                HIP_TRY(hipModuleLaunchKernel(p->jit_update, total_chunks, 1, 1, kBlock, 1, 1, 0, ctx->stream, ka, nullptr));
+            } else {
+                p->stream_launch(total_chunks, ctx->stream, sa, p->d_inst_base, p->d_meta[par], dfi, dub, cb);
+            }
+        } else if (p->jit_update) {
+            const DevMeta* mi = p->d_meta[par];
+            void* ka[] = {&p->dev, &p->d_inst_base, &mi, &dfi, &dub, &cb};
+            HIP_TRY(hipModuleLaunchKernel(p->jit_update, total_chunks, 1, 1, kBlock, 1, 1, 0, ctx->stream, ka, nullptr));
         } else {
-            k_update_generic<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub, cb);
+            k_update_generic<InterpCode><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub, cb);
         }
         if (timed) { hipEventRecord(tu.b, ctx->stream); ctx->t_update.push_back(tu); }
         CompactArgs ca{};
@@ -805,6 +872,36 @@ int hnb_effect_read_dead_list(HnbEffect* fx, uint32_t* dst, size_t dst_count) {
 
 int hnb_effect_sort_ribbons(HnbEffect*) {
     return fail(HNB_ERR_INVALID_ARG, "ribbon sort is not implemented yet (SURVEY.md §8f-2)");
+}
+
+int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
+    if (!prog || !buf || !buf_size) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    std::string s = prog->kernel_info;
+    if (!prog->jit_log.empty()) s += "\njit log: " + prog->jit_log;
+    snprintf(buf, buf_size, "%s", s.c_str());
+    return HNB_OK;
+}
+
+int hnb_jit_precompile(const void* blob, size_t blob_size) {
+    HnbProgramHeader h;
+    int rc = validate_blob(blob, blob_size, &h);
+    if (rc != HNB_OK) return rc;
+    const uint8_t* b = static_cast<const uint8_t*>(blob);
+    std::vector<HnbAttrEntry> attrs(h.n_attrs);
+    memcpy(attrs.data(), b + h.attrs_off, h.n_attrs * sizeof(HnbAttrEntry));
+    const bool streams = update_is_streamable(b, h, attrs.data());
+    bool aot_static = false;
+    if (streams) {
+        StreamLaunchFn fn = nullptr;
+        const char* name = "";
+        select_stream_kernel(reinterpret_cast<const Ins*>(b + h.update_off), h.update_len, &fn, &name);
+        aot_static = strcmp(name, "ProgInterp") != 0;
+    }
+    const jit::Request rq = make_jit_request(b, h, attrs.data(), streams, aot_static);
+    if (!rq.want_init && !rq.want_update_generic && !rq.want_update_stream) return HNB_OK;
+    jit::Result res;
+    if (!jit::build(rq, res)) return fail(HNB_ERR_BAD_PROGRAM, "kernel specialisation failed: %s", res.log.c_str());
+    return HNB_OK;
 }
 
 int hnb_ctx_enable_kernel_timing(HnbContext* ctx, int enable) {

@@ -5,7 +5,9 @@
 //   GpuIndirectIndex   src/render/mod.rs:139-146   -> three separate u32 arrays (ping, pong, dead)
 //   Particle AoS       src/attributes.rs:1516-1670 -> one packed plane per attribute (SoA)
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 #include "hnb_vm.h"
 
 namespace hnb {

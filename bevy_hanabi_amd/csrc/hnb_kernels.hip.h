@@ -18,7 +18,9 @@
 //    progress under any dispatch order) and sized from device-resident counters, so no
 //    readback and no vfx_indirect / vfx_prefix_sum launches are needed.
 #pragma once
+#ifndef __HIPCC_RTC__  // hiprtc (hnb_jit) provides the runtime declarations itself
 #include <hip/hip_runtime.h>
+#endif
 #include "hnb_dev.h"
 
 namespace hnb {
@@ -37,10 +39,12 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 #endif
 
 // ---- reset: dead_index[i] = i (effect_cache.rs:298-323) ------------------------------------
+#ifndef HNB_JIT_TU
 __global__ void k_reset_lists(uint32_t* __restrict__ dead, uint32_t* __restrict__ alive0, uint32_t* __restrict__ alive1, uint32_t capacity) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < capacity) { dead[i] = i; alive0[i] = 0u; alive1[i] = 0u; }
 }
+#endif
 
 // ---- V-file attribute access (generic kernels, one particle per lane) -----------------------
 __device__ __forceinline__ void vfile_store_attr(const vreg_file_t& r, uint32_t ncomp, uint32_t reg, char* plane, uint32_t slot) {
@@ -63,11 +67,58 @@ __device__ __forceinline__ Out4 vfile_load_attr(uint32_t ncomp, const char* plan
     return o;
 }
 
+// ---- code policies -----------------------------------------------------------------------------
+// How the generic kernels run a program. InterpCode interprets the bytecode (always available, any
+// program). The kernels specialised at program creation (hnb_jit.h) supply a policy with the same
+// interface whose bodies are straight-line code generated from the same bytecode: every decode,
+// switch and register index folds at compile time.
+struct InterpCode {
+    template <class ST>
+    static __device__ __forceinline__ void run_init(const DevProgram& p, ST& S, const VmUniforms& U, const VmAttrIO& io) {
+        vm_run<true, false>(p.init_code, p.init_len, S, U, nullptr, nullptr, io);
+    }
+    template <class ST>
+    static __device__ __forceinline__ void run_update(const DevProgram& p, ST& S, const VmUniforms& U, const VmAttrIO& io) {
+        vm_run<true, false>(p.update_code, p.update_len, S, U, nullptr, nullptr, io);
+    }
+    // var particle = Particle(): attributes the INIT program never assigns are stored as zero
+    static __device__ __forceinline__ void zero_unassigned(const DevProgram& p, const VmAttrIO& io) {
+        for (uint32_t a = 0; a < p.n_attrs; ++a) {
+            if (p.attrs[a].reg != HNB_REG_NONE) continue;
+            uint32_t* q = vm_attr_ptr(io, a);
+            for (uint32_t c = 0; c < p.attrs[a].ncomp; ++c) q[c] = 0u;
+        }
+    }
+    template <class ST>
+    static __device__ __forceinline__ void store_init(const DevProgram& p, const ST& S, char* base, uint32_t slot) {
+        for (uint32_t a = 0; a < p.n_attrs; ++a)
+            if (p.attrs[a].reg != HNB_REG_NONE) vfile_store_attr(S.r, p.attrs[a].ncomp, p.attrs[a].reg, base + p.attrs[a].plane_off, slot);
+    }
+    template <class ST>
+    static __device__ __forceinline__ void load_update(const DevProgram& p, ST& S, const char* base, uint32_t slot, bool valid) {
+        for (uint32_t a = 0; a < p.n_attrs; ++a) {
+            const DevAttr at = p.attrs[a];
+            if (!(at.upd_flags & HNB_ATTR_UPD_LOAD) || at.reg == HNB_REG_NONE) continue;
+            Out4 o = Out4{0u, 0u, 0u, 0u};
+            if (valid) o = vfile_load_attr(at.ncomp, base + at.plane_off, slot);
+            for (uint32_t cc = 0; cc < at.ncomp; ++cc) S.r[at.reg + cc] = out4_get(o, cc);  // single indexed store site
+        }
+    }
+    template <class ST>
+    static __device__ __forceinline__ void store_update(const DevProgram& p, const ST& S, char* base, uint32_t slot) {
+        for (uint32_t a = 0; a < p.n_attrs; ++a) {
+            const DevAttr at = p.attrs[a];
+            if ((at.upd_flags & HNB_ATTR_UPD_STORE) && at.reg != HNB_REG_NONE) vfile_store_attr(S.r, at.ncomp, at.reg, base + at.plane_off, slot);
+        }
+    }
+};
+
 // ---- init -----------------------------------------------------------------------------------
 // One thread per spawned particle. Thread i of instance k (serial order == thread order):
 //   slot = dead[alive0 + i]; seed = pcg_hash(slot ^ spawner.seed); run INIT; alive[w][alive0+i] = slot.
 // vfx_init.wgsl:141-143 uses atomicAdd(alive_count): under serial execution thread i gets
-// alive0 + i, which is what is computed here without atomics. Counters are advanced by k_update.
+// alive0 + i, which is what is computed here without atomics. Counters are advanced by k_compact.
+template <class CODE>
 __global__ void __launch_bounds__(kInitBlock)
 k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
        const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks) {
@@ -106,21 +157,11 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
 
     VmAttrIO io;
     io.slab = base; io.attrs = prog.attrs; io.slot = slot;
-    // var particle = Particle(): attributes the INIT program never assigns are stored as zero
-    for (uint32_t a = 0; a < prog.n_attrs; ++a) {
-        if (prog.attrs[a].reg != HNB_REG_NONE) continue;
-        uint32_t* p = vm_attr_ptr(io, a);
-        for (uint32_t c = 0; c < prog.attrs[a].ncomp; ++c) p[c] = 0u;
-    }
-
-    vm_run<true, false>(prog.init_code, prog.init_len, S, U, nullptr, nullptr, io);
-
+    CODE::zero_unassigned(prog, io);
+    CODE::run_init(prog, S, U, io);
     alive[alive0 + i] = slot;
-    for (uint32_t a = 0; a < prog.n_attrs; ++a)
-        if (prog.attrs[a].reg != HNB_REG_NONE)
-            vfile_store_attr(S.r, prog.attrs[a].ncomp, prog.attrs[a].reg, base + prog.attrs[a].plane_off, slot);
+    CODE::store_init(prog, S, base, slot);
 }
-
 // ---- streaming-kernel pinned attribute access (P = 4) -------------------------------------------
 template <int P>
 __device__ __forceinline__ void pin_load3(V3 (&dst)[P], const char* plane, const uint32_t (&slot)[P], const bool (&valid)[P], bool dense) {
@@ -321,13 +362,16 @@ struct CompactArgs {
     uint32_t capacity, chunks_per_inst;
     uint32_t alive_off[2], dead_off;
 };
+#ifndef HNB_JIT_TU
 __global__ void __launch_bounds__(kBlock)
 k_compact(const CompactArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in, DevMeta* __restrict__ meta_out,
           const DevFrameInst* __restrict__ fi, const CompactBufs cb) {
     compact_chunk(args, inst_base, meta_in, meta_out, fi, cb);
 }
+#endif
 
 // ---- generic update kernel: any update stream, V register file, one particle per lane ----------
+template <class CODE>
 __global__ void __launch_bounds__(kBlock)
 k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
                  const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
@@ -351,25 +395,16 @@ k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, 
         const uint32_t slot = valid ? list[li] : 0u;
         VmState<vreg_file_t> S;
         S.r = vreg_file_t{};
-        for (uint32_t a = 0; a < prog.n_attrs; ++a) {
-            const DevAttr at = prog.attrs[a];
-            if (!(at.upd_flags & HNB_ATTR_UPD_LOAD) || at.reg == HNB_REG_NONE) continue;
-            Out4 o = Out4{0u, 0u, 0u, 0u};
-            if (valid) o = vfile_load_attr(at.ncomp, c.base + at.plane_off, slot);
-            for (uint32_t cc = 0; cc < at.ncomp; ++cc) S.r[at.reg + cc] = out4_get(o, cc);  // single indexed store site
-        }
+        CODE::load_update(prog, S, c.base, slot, valid);
         S.pindex = slot + slot_base;
         S.seed = pcg_hash(S.pindex ^ seed_k);  // vfx_update.wgsl:138
         S.pcounter = 0u;
         S.alive = true;
         VmAttrIO io;
         io.slab = c.base; io.attrs = prog.attrs; io.slot = slot;
-        if (valid) vm_run<true, false>(prog.update_code, prog.update_len, S, U, nullptr, nullptr, io);
         if (valid) {
-            for (uint32_t a = 0; a < prog.n_attrs; ++a) {
-                const DevAttr at = prog.attrs[a];
-                if ((at.upd_flags & HNB_ATTR_UPD_STORE) && at.reg != HNB_REG_NONE) vfile_store_attr(S.r, at.ncomp, at.reg, c.base + at.plane_off, slot);
-            }
+            CODE::run_update(prog, S, U, io);
+            CODE::store_update(prog, S, c.base, slot);
         }
         // chunk-local stable compaction in LDS
         const uint32_t x = (valid && S.alive ? 1u : 0u) | ((valid && !S.alive ? 1u : 0u) << 16);
@@ -401,7 +436,6 @@ k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, 
     __syncthreads();
     chunk_record<1>(c, chunk, cb, list, s_list, kChunk, s_cnt);
 }
-
 // ---- streaming update kernel ---------------------------------------------------------------------
 // Macro-op update streams with U operands, named registers, 4 particles per lane.
 //  * a workgroup owns a 4096-row chunk of the alive list; each of its 4 WAVES owns a private,
@@ -567,5 +601,4 @@ k_update_stream(const StreamArgs args, const uint64_t* __restrict__ inst_base, c
     }
     chunk_record<kBlock / 64>(c, chunk, cb, list, s_list, kWaveRows, s_wave);
 }
-
 }  // namespace hnb

@@ -16,7 +16,12 @@
 //
 // Compiles as plain C++ (host) and as HIP device code (HNB_HD).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#else  // hiprtc keeps the fixed-width types in __hip_internal
+using __hip_internal::int8_t; using __hip_internal::uint8_t; using __hip_internal::int16_t; using __hip_internal::uint16_t;
+using __hip_internal::int32_t; using __hip_internal::uint32_t; using __hip_internal::int64_t; using __hip_internal::uint64_t;
+#endif
 
 #if defined(__HIPCC__)
 #define HNB_HD __host__ __device__ __forceinline__

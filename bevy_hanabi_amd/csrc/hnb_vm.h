@@ -15,7 +15,11 @@
 // Arithmetic is defined by hnb_math.h.
 #pragma once
 #include "hnb_math.h"
+#ifdef __HIPCC_RTC__
+#include "hanabi_amd.h"
+#else
 #include "../../include/hanabi_amd.h"
+#endif
 
 namespace hnb {
 
@@ -367,266 +371,270 @@ template <bool USTREAM, class ST> HNB_HD V3 vm_rd3(const ST& S, const VmUniforms
 }
 template <class ST> HNB_HD V3 vm_pin3(const ST& S, uint32_t reg) { return V3{u2f(S.r[reg]), u2f(S.r[reg + 1]), u2f(S.r[reg + 2])}; }
 
+// One instruction. With a compile-time constant `ins` (the specialised kernels built at program
+// creation, hnb_jit.h) every decode, switch and register index below folds away.
+template <bool HEAVY, bool USTREAM, class ST>
+HNB_HD void vm_exec(const Ins ins, ST& S, const VmUniforms& U, const uint32_t* props, const float* sim, const VmAttrIO& io) {
+    const uint32_t op = ins.x & 0xffu, d = (ins.x >> 8) & 0xffu, a = (ins.x >> 16) & 0xffu, b = ins.x >> 24;
+    const uint32_t c = ins.y & 0xffu, w = ((ins.y >> 8) & 3u) + 1u;
+    const uint32_t sa = (ins.y >> 10) & 1u ? 0u : 1u, sb = (ins.y >> 11) & 1u ? 0u : 1u, sc = (ins.y >> 12) & 1u ? 0u : 1u;
+    const uint32_t aux = ins.y >> 16;
+    const bool elementwise = vm_op_is_elementwise(op);
+    uint32_t nout = w;  // registers written by the common store loop
+    Out4 o = Out4{0u, 0u, 0u, 0u};
+    // results of macro ops that rewrite pinned registers (stored with static indices)
+    V3 npos = V3{0, 0, 0}, nvel = V3{0, 0, 0};
+    float nage = 0.0f;
+    bool wpos = false, wvel = false, wage = false;
+
+    if (!elementwise) {
+        nout = 0;
+        switch (op) {
+            case HNB_OP_LOADK:
+                if constexpr (USTREAM) { nout = 1; o.v0 = ins.y; }
+                break;
+            case HNB_OP_LDB:
+                if constexpr (USTREAM) { nout = 1; o.v0 = f2u(sim[a]); }
+                break;
+            case HNB_OP_LDP:
+                if constexpr (USTREAM) {
+                    nout = (a & 3u) + 1u;
+                    o.v0 = props[ins.y];
+                    o.v1 = nout > 1 ? props[ins.y + 1] : 0u;
+                    o.v2 = nout > 2 ? props[ins.y + 2] : 0u;
+                    o.v3 = nout > 3 ? props[ins.y + 3] : 0u;
+                }
+                break;
+            case HNB_OP_LDA:
+                if constexpr (!USTREAM) {
+                    const uint32_t* p = vm_attr_ptr(io, aux);
+                    nout = w;
+                    o.v0 = p[0];
+                    o.v1 = w > 1 ? p[1] : 0u;
+                    o.v2 = w > 2 ? p[2] : 0u;
+                    o.v3 = w > 3 ? p[3] : 0u;
+                }
+                break;
+            case HNB_OP_STA:
+                if constexpr (!USTREAM) {
+                    uint32_t* p = vm_attr_ptr(io, aux);
+                    for (uint32_t k = 0; k < w; ++k) p[k] = vm_rd<false>(S, U, a + k * sa);
+                }
+                break;
+            case HNB_OP_LDID: nout = 1; o.v0 = S.pindex; break;
+            case HNB_OP_LDPC: nout = 1; o.v0 = S.pcounter; break;
+            case HNB_OP_LDALIVE: nout = 1; o.v0 = S.alive ? 1u : 0u; break;
+            case HNB_OP_ALL: {
+                nout = 1;
+                uint32_t v = 1u;
+                for (uint32_t k = 0; k < w; ++k) v &= (vm_rd<USTREAM>(S, U, a + k) != 0u) ? 1u : 0u;
+                o.v0 = v;
+            } break;
+            case HNB_OP_ANY: {
+                nout = 1;
+                uint32_t v = 0u;
+                for (uint32_t k = 0; k < w; ++k) v |= (vm_rd<USTREAM>(S, U, a + k) != 0u) ? 1u : 0u;
+                o.v0 = v;
+            } break;
+            case HNB_OP_DOT: {
+                nout = 1;
+                float s = vm_rdf<USTREAM>(S, U, a) * vm_rdf<USTREAM>(S, U, b);
+                for (uint32_t k = 1; k < w; ++k) s = s + vm_rdf<USTREAM>(S, U, a + k) * vm_rdf<USTREAM>(S, U, b + k);
+                o.v0 = f2u(s);
+            } break;
+            case HNB_OP_LENGTH: {
+                nout = 1;
+                const float x0 = vm_rdf<USTREAM>(S, U, a);
+                float s = x0 * x0;
+                for (uint32_t k = 1; k < w; ++k) { const float x = vm_rdf<USTREAM>(S, U, a + k); s = s + x * x; }
+                o.v0 = f2u(f_sqrt(s));
+            } break;
+            case HNB_OP_DISTANCE: {
+                nout = 1;
+                const float t0 = vm_rdf<USTREAM>(S, U, a) - vm_rdf<USTREAM>(S, U, b);
+                float s = t0 * t0;
+                for (uint32_t k = 1; k < w; ++k) {
+                    const float t = vm_rdf<USTREAM>(S, U, a + k) - vm_rdf<USTREAM>(S, U, b + k);
+                    s = s + t * t;
+                }
+                o.v0 = f2u(f_sqrt(s));
+            } break;
+            case HNB_OP_NORMALIZE: {
+                nout = w;
+                const float x0 = vm_rdf<USTREAM>(S, U, a), x1 = w > 1 ? vm_rdf<USTREAM>(S, U, a + 1) : 0.0f;
+                const float x2 = w > 2 ? vm_rdf<USTREAM>(S, U, a + 2) : 0.0f, x3 = w > 3 ? vm_rdf<USTREAM>(S, U, a + 3) : 0.0f;
+                float s = x0 * x0;
+                if (w > 1) s = s + x1 * x1;
+                if (w > 2) s = s + x2 * x2;
+                if (w > 3) s = s + x3 * x3;
+                const float l = f_sqrt(s);
+                o = Out4{f2u(x0 / l), f2u(x1 / l), f2u(x2 / l), f2u(x3 / l)};
+            } break;
+            case HNB_OP_CROSS: {
+                nout = 3;
+                const V3 r = cross3(vm_rd3<USTREAM>(S, U, a), vm_rd3<USTREAM>(S, U, b));
+                o = Out4{f2u(r.x), f2u(r.y), f2u(r.z), 0u};
+            } break;
+            case HNB_OP_ALIVE_SET: S.alive = vm_rd<USTREAM>(S, U, a) != 0u; break;
+            case HNB_OP_ALIVE_AND: S.alive = S.alive && (vm_rd<USTREAM>(S, U, a) != 0u); break;
+            case HNB_OP_KILL_IF: S.alive = S.alive && (vm_rd<USTREAM>(S, U, a) == 0u); break;
+            default:
+                if constexpr (!USTREAM) {
+                    const V3 pos = vm_pin3(S, HNB_REG_POSITION), vel = vm_pin3(S, HNB_REG_VELOCITY);
+                    switch (op) {
+                        case HNB_OP_M_AGE_TICK: {
+                            float age = u2f(S.r[HNB_REG_AGE]);
+                            mac_age_tick(age, u2f(S.r[HNB_REG_LIFETIME]), vm_rdf<false>(S, U, a), (aux & 1u) != 0u, S.alive);
+                            nage = age; wage = true;
+                        } break;
+                        case HNB_OP_M_EULER: npos = pos; mac_euler(npos, vel, vm_rdf<false>(S, U, a)); wpos = true; break;
+                        case HNB_OP_M_VEL_SCALE: nvel = vel; mac_vel_scale(nvel, vm_rdf<false>(S, U, a)); wvel = true; break;
+                        case HNB_OP_M_VEL_ADD: nvel = vel; mac_vel_add(nvel, vm_rd3<false>(S, U, a)); wvel = true; break;
+                        case HNB_OP_M_PIN_SET:  // dst is a pinned register: route through the pinned write-back
+                            if (d == HNB_REG_POSITION) { npos = vm_rd3<false>(S, U, a); wpos = true; }
+                            else if (d == HNB_REG_VELOCITY) { nvel = vm_rd3<false>(S, U, a); wvel = true; }
+                            else if (d == HNB_REG_AGE) { nage = vm_rdf<false>(S, U, a); wage = true; }
+                            else { nout = 1; o.v0 = vm_rd<false>(S, U, a); }  // LIFETIME: d == 7 via the common store
+                            break;
+                        case HNB_OP_M_RADIAL_ACCEL:
+                            nvel = vel; mac_radial_accel(pos, nvel, vm_rd3<false>(S, U, a), vm_rdf<false>(S, U, b)); wvel = true;
+                            break;
+                        case HNB_OP_M_TANGENT_ACCEL:
+                            nvel = vel;
+                            mac_tangent_accel(pos, nvel, vm_rd3<false>(S, U, a), vm_rd3<false>(S, U, b), vm_rdf<false>(S, U, c));
+                            wvel = true;
+                            break;
+                        case HNB_OP_M_CONFORM_SPHERE: {
+                            ConformParams q;
+                            q.c = vm_rd3<false>(S, U, a);
+                            q.radius = vm_rdf<false>(S, U, a + 3); q.influence_dist = vm_rdf<false>(S, U, a + 4);
+                            q.shell_half_thickness = vm_rdf<false>(S, U, a + 5); q.max_attraction_speed = vm_rdf<false>(S, U, a + 6);
+                            q.attraction_accel = vm_rdf<false>(S, U, a + 7); q.sticky_factor = vm_rdf<false>(S, U, a + 8);
+                            nvel = vel; mac_conform_sphere(pos, nvel, q, vm_rdf<false>(S, U, b)); wvel = true;
+                        } break;
+                        case HNB_OP_M_KILL_SPHERE:
+                            mac_kill_sphere(pos, vm_rd3<false>(S, U, a), vm_rdf<false>(S, U, b), (aux & 1u) != 0u, S.alive);
+                            break;
+                        case HNB_OP_M_KILL_AABB:
+                            mac_kill_aabb(pos, vm_rd3<false>(S, U, a), vm_rd3<false>(S, U, b), (aux & 1u) != 0u, S.alive);
+                            break;
+                        case HNB_OP_M_VEL_SPHERE:
+                            nvel = mac_vel_sphere(pos, vm_rd3<false>(S, U, a), vm_rdf<false>(S, U, b)); wvel = true;
+                            break;
+                        case HNB_OP_M_ADD_XLATE:
+                            npos = V3{pos.x + U.xf[3], pos.y + U.xf[7], pos.z + U.xf[11]}; wpos = true;
+                            break;
+                        default: break;
+                    }
+                }
+                if constexpr (HEAVY && !USTREAM) {
+                    const V3 pos = vm_pin3(S, HNB_REG_POSITION);
+                    switch (op) {
+                        case HNB_OP_FRAND: {
+                            nout = w;
+                            const Rand4 v = vm_frand_n(S.seed, w);
+                            o = Out4{f2u(v.v0), f2u(v.v1), f2u(v.v2), f2u(v.v3)};
+                        } break;
+                        case HNB_OP_RANDU: {  // a + frandN() * (b - a)
+                            nout = w;
+                            const Rand4 v = vm_frand_n(S.seed, w);
+                            uint32_t t[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k)
+                                if (k < w) {
+                                    const float lo = vm_rdf<false>(S, U, a + k * sa), hi = vm_rdf<false>(S, U, b + k * sb);
+                                    t[k] = f2u(lo + rand4_get(v, k) * (hi - lo));
+                                }
+                            o = Out4{t[0], t[1], t[2], t[3]};
+                        } break;
+                        case HNB_OP_RANDN: {  // mean + std_dev * r * cos(tau * v), r = sqrt(-2 log u)
+                            nout = w;
+                            const float u = vm_frand(S.seed);
+                            const Rand4 v = vm_frand_n(S.seed, w);
+                            const float rr = f_sqrt(-2.0f * f_log(u));
+                            uint32_t t[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k)
+                                if (k < w) {
+                                    const float mean = vm_rdf<false>(S, U, a + k * sa), sd = vm_rdf<false>(S, U, b + k * sb);
+                                    t[k] = f2u(mean + sd * rr * f_cos(HNB_TAU * rand4_get(v, k)));
+                                }
+                            o = Out4{t[0], t[1], t[2], t[3]};
+                        } break;
+                        case HNB_OP_M_POS_CIRCLE:
+                            npos = mac_pos_circle(S.seed, vm_rd3<false>(S, U, a), vm_rd3<false>(S, U, a + 3), vm_rdf<false>(S, U, a + 6),
+                                                  (aux & 1u) != 0u);
+                            wpos = true;
+                            break;
+                        case HNB_OP_M_POS_SPHERE:
+                            npos = mac_pos_sphere(S.seed, vm_rd3<false>(S, U, a), vm_rdf<false>(S, U, a + 3), (aux & 1u) != 0u);
+                            wpos = true;
+                            break;
+                        case HNB_OP_M_POS_CONE3D:
+                            npos = mac_pos_cone3d(S.seed, vm_rdf<false>(S, U, a), vm_rdf<false>(S, U, a + 1), vm_rdf<false>(S, U, a + 2), U.xf);
+                            wpos = true;
+                            break;
+                        case HNB_OP_M_VEL_CIRCLE:
+                            nvel = mac_vel_circle(pos, vm_rd3<false>(S, U, a), vm_rd3<false>(S, U, a + 3), vm_rdf<false>(S, U, a + 6), U.xf);
+                            wvel = true;
+                            break;
+                        case HNB_OP_M_VEL_TANGENT:
+                            nvel = mac_vel_tangent(pos, vm_rd3<false>(S, U, a), vm_rd3<false>(S, U, a + 3), vm_rdf<false>(S, U, a + 6), U.xf);
+                            wvel = true;
+                            break;
+                        default: break;
+                    }
+                }
+                if constexpr (HEAVY) {
+                    switch (op) {
+                        case HNB_OP_PACK4UNORM:
+                            nout = 1;
+                            o.v0 = pack_unorm8(vm_rdf<USTREAM>(S, U, a)) | (pack_unorm8(vm_rdf<USTREAM>(S, U, a + 1)) << 8) |
+                                   (pack_unorm8(vm_rdf<USTREAM>(S, U, a + 2)) << 16) | (pack_unorm8(vm_rdf<USTREAM>(S, U, a + 3)) << 24);
+                            break;
+                        case HNB_OP_PACK4SNORM:
+                            nout = 1;
+                            o.v0 = pack_snorm8(vm_rdf<USTREAM>(S, U, a)) | (pack_snorm8(vm_rdf<USTREAM>(S, U, a + 1)) << 8) |
+                                   (pack_snorm8(vm_rdf<USTREAM>(S, U, a + 2)) << 16) | (pack_snorm8(vm_rdf<USTREAM>(S, U, a + 3)) << 24);
+                            break;
+                        case HNB_OP_UNPACK4UNORM: {
+                            nout = 4;
+                            const uint32_t v = vm_rd<USTREAM>(S, U, a);
+                            o = Out4{f2u(unpack_unorm8(v)), f2u(unpack_unorm8(v >> 8)), f2u(unpack_unorm8(v >> 16)), f2u(unpack_unorm8(v >> 24))};
+                        } break;
+                        case HNB_OP_UNPACK4SNORM: {
+                            nout = 4;
+                            const uint32_t v = vm_rd<USTREAM>(S, U, a);
+                            o = Out4{f2u(unpack_snorm8(v)), f2u(unpack_snorm8(v >> 8)), f2u(unpack_snorm8(v >> 16)), f2u(unpack_snorm8(v >> 24))};
+                        } break;
+                        default: break;
+                    }
+                }
+                break;
+        }
+    }
+
+    // pinned write-back: compile-time register numbers
+    if constexpr (!USTREAM) {
+        if (wpos) { S.r[HNB_REG_POSITION] = f2u(npos.x); S.r[HNB_REG_POSITION + 1] = f2u(npos.y); S.r[HNB_REG_POSITION + 2] = f2u(npos.z); }
+        if (wvel) { S.r[HNB_REG_VELOCITY] = f2u(nvel.x); S.r[HNB_REG_VELOCITY + 1] = f2u(nvel.y); S.r[HNB_REG_VELOCITY + 2] = f2u(nvel.z); }
+        if (wage) S.r[HNB_REG_AGE] = f2u(nage);
+    }
+    // The one dynamically indexed store site.
+    for (uint32_t k = 0; k < nout; ++k) {
+        uint32_t out;
+        if (elementwise)
+            out = vm_elementwise<HEAVY>(op, vm_rd<USTREAM>(S, U, a + k * sa), vm_rd<USTREAM>(S, U, b + k * sb),
+                                        vm_rd<USTREAM>(S, U, c + k * sc));
+        else out = out4_get(o, k);
+        S.r[d + k] = out;
+    }
+}
+
 template <bool HEAVY, bool USTREAM, class ST>
 HNB_HD void vm_run(const Ins* __restrict__ code, uint32_t n_ins, ST& S, const VmUniforms& U, const uint32_t* props,
                    const float* sim, const VmAttrIO& io) {
-    for (uint32_t pc = 0; pc < n_ins; ++pc) {
-        const Ins ins = code[pc];
-        const uint32_t op = ins.x & 0xffu, d = (ins.x >> 8) & 0xffu, a = (ins.x >> 16) & 0xffu, b = ins.x >> 24;
-        const uint32_t c = ins.y & 0xffu, w = ((ins.y >> 8) & 3u) + 1u;
-        const uint32_t sa = (ins.y >> 10) & 1u ? 0u : 1u, sb = (ins.y >> 11) & 1u ? 0u : 1u, sc = (ins.y >> 12) & 1u ? 0u : 1u;
-        const uint32_t aux = ins.y >> 16;
-        const bool elementwise = vm_op_is_elementwise(op);
-        uint32_t nout = w;  // registers written by the common store loop
-        Out4 o = Out4{0u, 0u, 0u, 0u};
-        // results of macro ops that rewrite pinned registers (stored with static indices)
-        V3 npos = V3{0, 0, 0}, nvel = V3{0, 0, 0};
-        float nage = 0.0f;
-        bool wpos = false, wvel = false, wage = false;
-
-        if (!elementwise) {
-            nout = 0;
-            switch (op) {
-                case HNB_OP_LOADK:
-                    if constexpr (USTREAM) { nout = 1; o.v0 = ins.y; }
-                    break;
-                case HNB_OP_LDB:
-                    if constexpr (USTREAM) { nout = 1; o.v0 = f2u(sim[a]); }
-                    break;
-                case HNB_OP_LDP:
-                    if constexpr (USTREAM) {
-                        nout = (a & 3u) + 1u;
-                        o.v0 = props[ins.y];
-                        o.v1 = nout > 1 ? props[ins.y + 1] : 0u;
-                        o.v2 = nout > 2 ? props[ins.y + 2] : 0u;
-                        o.v3 = nout > 3 ? props[ins.y + 3] : 0u;
-                    }
-                    break;
-                case HNB_OP_LDA:
-                    if constexpr (!USTREAM) {
-                        const uint32_t* p = vm_attr_ptr(io, aux);
-                        nout = w;
-                        o.v0 = p[0];
-                        o.v1 = w > 1 ? p[1] : 0u;
-                        o.v2 = w > 2 ? p[2] : 0u;
-                        o.v3 = w > 3 ? p[3] : 0u;
-                    }
-                    break;
-                case HNB_OP_STA:
-                    if constexpr (!USTREAM) {
-                        uint32_t* p = vm_attr_ptr(io, aux);
-                        for (uint32_t k = 0; k < w; ++k) p[k] = vm_rd<false>(S, U, a + k * sa);
-                    }
-                    break;
-                case HNB_OP_LDID: nout = 1; o.v0 = S.pindex; break;
-                case HNB_OP_LDPC: nout = 1; o.v0 = S.pcounter; break;
-                case HNB_OP_LDALIVE: nout = 1; o.v0 = S.alive ? 1u : 0u; break;
-                case HNB_OP_ALL: {
-                    nout = 1;
-                    uint32_t v = 1u;
-                    for (uint32_t k = 0; k < w; ++k) v &= (vm_rd<USTREAM>(S, U, a + k) != 0u) ? 1u : 0u;
-                    o.v0 = v;
-                } break;
-                case HNB_OP_ANY: {
-                    nout = 1;
-                    uint32_t v = 0u;
-                    for (uint32_t k = 0; k < w; ++k) v |= (vm_rd<USTREAM>(S, U, a + k) != 0u) ? 1u : 0u;
-                    o.v0 = v;
-                } break;
-                case HNB_OP_DOT: {
-                    nout = 1;
-                    float s = vm_rdf<USTREAM>(S, U, a) * vm_rdf<USTREAM>(S, U, b);
-                    for (uint32_t k = 1; k < w; ++k) s = s + vm_rdf<USTREAM>(S, U, a + k) * vm_rdf<USTREAM>(S, U, b + k);
-                    o.v0 = f2u(s);
-                } break;
-                case HNB_OP_LENGTH: {
-                    nout = 1;
-                    const float x0 = vm_rdf<USTREAM>(S, U, a);
-                    float s = x0 * x0;
-                    for (uint32_t k = 1; k < w; ++k) { const float x = vm_rdf<USTREAM>(S, U, a + k); s = s + x * x; }
-                    o.v0 = f2u(f_sqrt(s));
-                } break;
-                case HNB_OP_DISTANCE: {
-                    nout = 1;
-                    const float t0 = vm_rdf<USTREAM>(S, U, a) - vm_rdf<USTREAM>(S, U, b);
-                    float s = t0 * t0;
-                    for (uint32_t k = 1; k < w; ++k) {
-                        const float t = vm_rdf<USTREAM>(S, U, a + k) - vm_rdf<USTREAM>(S, U, b + k);
-                        s = s + t * t;
-                    }
-                    o.v0 = f2u(f_sqrt(s));
-                } break;
-                case HNB_OP_NORMALIZE: {
-                    nout = w;
-                    const float x0 = vm_rdf<USTREAM>(S, U, a), x1 = w > 1 ? vm_rdf<USTREAM>(S, U, a + 1) : 0.0f;
-                    const float x2 = w > 2 ? vm_rdf<USTREAM>(S, U, a + 2) : 0.0f, x3 = w > 3 ? vm_rdf<USTREAM>(S, U, a + 3) : 0.0f;
-                    float s = x0 * x0;
-                    if (w > 1) s = s + x1 * x1;
-                    if (w > 2) s = s + x2 * x2;
-                    if (w > 3) s = s + x3 * x3;
-                    const float l = f_sqrt(s);
-                    o = Out4{f2u(x0 / l), f2u(x1 / l), f2u(x2 / l), f2u(x3 / l)};
-                } break;
-                case HNB_OP_CROSS: {
-                    nout = 3;
-                    const V3 r = cross3(vm_rd3<USTREAM>(S, U, a), vm_rd3<USTREAM>(S, U, b));
-                    o = Out4{f2u(r.x), f2u(r.y), f2u(r.z), 0u};
-                } break;
-                case HNB_OP_ALIVE_SET: S.alive = vm_rd<USTREAM>(S, U, a) != 0u; break;
-                case HNB_OP_ALIVE_AND: S.alive = S.alive && (vm_rd<USTREAM>(S, U, a) != 0u); break;
-                case HNB_OP_KILL_IF: S.alive = S.alive && (vm_rd<USTREAM>(S, U, a) == 0u); break;
-                default:
-                    if constexpr (!USTREAM) {
-                        const V3 pos = vm_pin3(S, HNB_REG_POSITION), vel = vm_pin3(S, HNB_REG_VELOCITY);
-                        switch (op) {
-                            case HNB_OP_M_AGE_TICK: {
-                                float age = u2f(S.r[HNB_REG_AGE]);
-                                mac_age_tick(age, u2f(S.r[HNB_REG_LIFETIME]), vm_rdf<false>(S, U, a), (aux & 1u) != 0u, S.alive);
-                                nage = age; wage = true;
-                            } break;
-                            case HNB_OP_M_EULER: npos = pos; mac_euler(npos, vel, vm_rdf<false>(S, U, a)); wpos = true; break;
-                            case HNB_OP_M_VEL_SCALE: nvel = vel; mac_vel_scale(nvel, vm_rdf<false>(S, U, a)); wvel = true; break;
-                            case HNB_OP_M_VEL_ADD: nvel = vel; mac_vel_add(nvel, vm_rd3<false>(S, U, a)); wvel = true; break;
-                            case HNB_OP_M_PIN_SET:  // dst is a pinned register: route through the pinned write-back
-                                if (d == HNB_REG_POSITION) { npos = vm_rd3<false>(S, U, a); wpos = true; }
-                                else if (d == HNB_REG_VELOCITY) { nvel = vm_rd3<false>(S, U, a); wvel = true; }
-                                else if (d == HNB_REG_AGE) { nage = vm_rdf<false>(S, U, a); wage = true; }
-                                else { nout = 1; o.v0 = vm_rd<false>(S, U, a); }  // LIFETIME: d == 7 via the common store
-                                break;
-                            case HNB_OP_M_RADIAL_ACCEL:
-                                nvel = vel; mac_radial_accel(pos, nvel, vm_rd3<false>(S, U, a), vm_rdf<false>(S, U, b)); wvel = true;
-                                break;
-                            case HNB_OP_M_TANGENT_ACCEL:
-                                nvel = vel;
-                                mac_tangent_accel(pos, nvel, vm_rd3<false>(S, U, a), vm_rd3<false>(S, U, b), vm_rdf<false>(S, U, c));
-                                wvel = true;
-                                break;
-                            case HNB_OP_M_CONFORM_SPHERE: {
-                                ConformParams q;
-                                q.c = vm_rd3<false>(S, U, a);
-                                q.radius = vm_rdf<false>(S, U, a + 3); q.influence_dist = vm_rdf<false>(S, U, a + 4);
-                                q.shell_half_thickness = vm_rdf<false>(S, U, a + 5); q.max_attraction_speed = vm_rdf<false>(S, U, a + 6);
-                                q.attraction_accel = vm_rdf<false>(S, U, a + 7); q.sticky_factor = vm_rdf<false>(S, U, a + 8);
-                                nvel = vel; mac_conform_sphere(pos, nvel, q, vm_rdf<false>(S, U, b)); wvel = true;
-                            } break;
-                            case HNB_OP_M_KILL_SPHERE:
-                                mac_kill_sphere(pos, vm_rd3<false>(S, U, a), vm_rdf<false>(S, U, b), (aux & 1u) != 0u, S.alive);
-                                break;
-                            case HNB_OP_M_KILL_AABB:
-                                mac_kill_aabb(pos, vm_rd3<false>(S, U, a), vm_rd3<false>(S, U, b), (aux & 1u) != 0u, S.alive);
-                                break;
-                            case HNB_OP_M_VEL_SPHERE:
-                                nvel = mac_vel_sphere(pos, vm_rd3<false>(S, U, a), vm_rdf<false>(S, U, b)); wvel = true;
-                                break;
-                            case HNB_OP_M_ADD_XLATE:
-                                npos = V3{pos.x + U.xf[3], pos.y + U.xf[7], pos.z + U.xf[11]}; wpos = true;
-                                break;
-                            default: break;
-                        }
-                    }
-                    if constexpr (HEAVY && !USTREAM) {
-                        const V3 pos = vm_pin3(S, HNB_REG_POSITION);
-                        switch (op) {
-                            case HNB_OP_FRAND: {
-                                nout = w;
-                                const Rand4 v = vm_frand_n(S.seed, w);
-                                o = Out4{f2u(v.v0), f2u(v.v1), f2u(v.v2), f2u(v.v3)};
-                            } break;
-                            case HNB_OP_RANDU: {  // a + frandN() * (b - a)
-                                nout = w;
-                                const Rand4 v = vm_frand_n(S.seed, w);
-                                uint32_t t[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                                for (uint32_t k = 0; k < 4; ++k)
-                                    if (k < w) {
-                                        const float lo = vm_rdf<false>(S, U, a + k * sa), hi = vm_rdf<false>(S, U, b + k * sb);
-                                        t[k] = f2u(lo + rand4_get(v, k) * (hi - lo));
-                                    }
-                                o = Out4{t[0], t[1], t[2], t[3]};
-                            } break;
-                            case HNB_OP_RANDN: {  // mean + std_dev * r * cos(tau * v), r = sqrt(-2 log u)
-                                nout = w;
-                                const float u = vm_frand(S.seed);
-                                const Rand4 v = vm_frand_n(S.seed, w);
-                                const float rr = f_sqrt(-2.0f * f_log(u));
-                                uint32_t t[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                                for (uint32_t k = 0; k < 4; ++k)
-                                    if (k < w) {
-                                        const float mean = vm_rdf<false>(S, U, a + k * sa), sd = vm_rdf<false>(S, U, b + k * sb);
-                                        t[k] = f2u(mean + sd * rr * f_cos(HNB_TAU * rand4_get(v, k)));
-                                    }
-                                o = Out4{t[0], t[1], t[2], t[3]};
-                            } break;
-                            case HNB_OP_M_POS_CIRCLE:
-                                npos = mac_pos_circle(S.seed, vm_rd3<false>(S, U, a), vm_rd3<false>(S, U, a + 3), vm_rdf<false>(S, U, a + 6),
-                                                      (aux & 1u) != 0u);
-                                wpos = true;
-                                break;
-                            case HNB_OP_M_POS_SPHERE:
-                                npos = mac_pos_sphere(S.seed, vm_rd3<false>(S, U, a), vm_rdf<false>(S, U, a + 3), (aux & 1u) != 0u);
-                                wpos = true;
-                                break;
-                            case HNB_OP_M_POS_CONE3D:
-                                npos = mac_pos_cone3d(S.seed, vm_rdf<false>(S, U, a), vm_rdf<false>(S, U, a + 1), vm_rdf<false>(S, U, a + 2), U.xf);
-                                wpos = true;
-                                break;
-                            case HNB_OP_M_VEL_CIRCLE:
-                                nvel = mac_vel_circle(pos, vm_rd3<false>(S, U, a), vm_rd3<false>(S, U, a + 3), vm_rdf<false>(S, U, a + 6), U.xf);
-                                wvel = true;
-                                break;
-                            case HNB_OP_M_VEL_TANGENT:
-                                nvel = mac_vel_tangent(pos, vm_rd3<false>(S, U, a), vm_rd3<false>(S, U, a + 3), vm_rdf<false>(S, U, a + 6), U.xf);
-                                wvel = true;
-                                break;
-                            default: break;
-                        }
-                    }
-                    if constexpr (HEAVY) {
-                        switch (op) {
-                            case HNB_OP_PACK4UNORM:
-                                nout = 1;
-                                o.v0 = pack_unorm8(vm_rdf<USTREAM>(S, U, a)) | (pack_unorm8(vm_rdf<USTREAM>(S, U, a + 1)) << 8) |
-                                       (pack_unorm8(vm_rdf<USTREAM>(S, U, a + 2)) << 16) | (pack_unorm8(vm_rdf<USTREAM>(S, U, a + 3)) << 24);
-                                break;
-                            case HNB_OP_PACK4SNORM:
-                                nout = 1;
-                                o.v0 = pack_snorm8(vm_rdf<USTREAM>(S, U, a)) | (pack_snorm8(vm_rdf<USTREAM>(S, U, a + 1)) << 8) |
-                                       (pack_snorm8(vm_rdf<USTREAM>(S, U, a + 2)) << 16) | (pack_snorm8(vm_rdf<USTREAM>(S, U, a + 3)) << 24);
-                                break;
-                            case HNB_OP_UNPACK4UNORM: {
-                                nout = 4;
-                                const uint32_t v = vm_rd<USTREAM>(S, U, a);
-                                o = Out4{f2u(unpack_unorm8(v)), f2u(unpack_unorm8(v >> 8)), f2u(unpack_unorm8(v >> 16)), f2u(unpack_unorm8(v >> 24))};
-                            } break;
-                            case HNB_OP_UNPACK4SNORM: {
-                                nout = 4;
-                                const uint32_t v = vm_rd<USTREAM>(S, U, a);
-                                o = Out4{f2u(unpack_snorm8(v)), f2u(unpack_snorm8(v >> 8)), f2u(unpack_snorm8(v >> 16)), f2u(unpack_snorm8(v >> 24))};
-                            } break;
-                            default: break;
-                        }
-                    }
-                    break;
-            }
-        }
-
-        // pinned write-back: compile-time register numbers
-        if constexpr (!USTREAM) {
-            if (wpos) { S.r[HNB_REG_POSITION] = f2u(npos.x); S.r[HNB_REG_POSITION + 1] = f2u(npos.y); S.r[HNB_REG_POSITION + 2] = f2u(npos.z); }
-            if (wvel) { S.r[HNB_REG_VELOCITY] = f2u(nvel.x); S.r[HNB_REG_VELOCITY + 1] = f2u(nvel.y); S.r[HNB_REG_VELOCITY + 2] = f2u(nvel.z); }
-            if (wage) S.r[HNB_REG_AGE] = f2u(nage);
-        }
-        // The one dynamically indexed store site.
-        for (uint32_t k = 0; k < nout; ++k) {
-            uint32_t out;
-            if (elementwise)
-                out = vm_elementwise<HEAVY>(op, vm_rd<USTREAM>(S, U, a + k * sa), vm_rd<USTREAM>(S, U, b + k * sb),
-                                            vm_rd<USTREAM>(S, U, c + k * sc));
-            else out = out4_get(o, k);
-            S.r[d + k] = out;
-        }
-    }
+    for (uint32_t pc = 0; pc < n_ins; ++pc) vm_exec<HEAVY, USTREAM>(code[pc], S, U, props, sim, io);
 }
 
 // Host: evaluate the uniform stream of one instance into its parameter block.
@@ -767,6 +775,17 @@ HNB_HD void apply_static(const Ins ins, Pinned<P>& X, const VmUniforms& U) {
         const V3 v = uf3(U, a);
 #pragma unroll
         for (int p = 0; p < P; ++p) mac_vel_add(X.vel[p], v);
+    } else if constexpr (OP == HNB_OP_M_PIN_SET) {
+        const uint32_t d = (ins.x >> 8) & 0xffu;  // wave-uniform: the destination register is an instruction field
+        if (d == HNB_REG_POSITION || d == HNB_REG_VELOCITY) {
+            const V3 v = uf3(U, a);
+#pragma unroll
+            for (int p = 0; p < P; ++p) { if (d == HNB_REG_POSITION) X.pos[p] = v; else X.vel[p] = v; }
+        } else {
+            const float s = uf(U, a);
+#pragma unroll
+            for (int p = 0; p < P; ++p) { if (d == HNB_REG_AGE) X.age[p] = s; else X.lifetime[p] = s; }
+        }
     } else if constexpr (OP == HNB_OP_M_RADIAL_ACCEL) {
         const V3 origin = uf3(U, a);
         const float s = uf(U, b);
@@ -796,6 +815,8 @@ HNB_HD void apply_static(const Ins ins, Pinned<P>& X, const VmUniforms& U) {
         const bool inside = (aux & 1u) != 0u;
 #pragma unroll
         for (int p = 0; p < P; ++p) mac_kill_aabb(X.pos[p], center, half, inside, X.alive[p]);
+    } else {
+        static_assert(OP == HNB_OP_M_AGE_TICK, "apply_static: opcode is not a streamable macro op");
     }
 }
 
@@ -805,6 +826,12 @@ struct ProgInterp {
     template <int P> HNB_HD_MEMBER static void run(const Ins* __restrict__ code, uint32_t n_ins, Pinned<P>& X, const VmUniforms& U) {
         fast_run<P, true>(code, n_ins, X, U);
     }
+};
+// Empty update stream (no AGE, no velocity, no update modifier): only the lists are maintained.
+struct ProgNone {
+    static constexpr uint32_t kLen = 0;
+    template <int P> HNB_HD_MEMBER static void run(const Ins* __restrict__, uint32_t, Pinned<P>&, const VmUniforms&) {}
+    static bool matches(const Ins*, uint32_t n_ins) { return n_ins == 0; }
 };
 // Fixed opcode sequence.
 template <uint32_t... OPS>

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "hnb_effect_set_parent", "hnb_frame_begin", "hnb_effect_set_frame", "hnb_effect_set_property", "hnb_simulate",
     "hnb_effect_metadata", "hnb_effect_alive_count", "hnb_effect_read_attr", "hnb_effect_read_alive_list",
     "hnb_effect_read_dead_list", "hnb_effect_write_attr", "hnb_effect_sort_ribbons", "hnb_ctx_enable_kernel_timing",
-    "hnb_ctx_kernel_timing",
+    "hnb_ctx_kernel_timing", "hnb_program_kernel_info", "hnb_jit_precompile",
 ]
 
 
@@ -83,6 +83,8 @@ def load_library():
         lib.hnb_effect_sort_ribbons.argtypes = [C.c_void_p]
         lib.hnb_ctx_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         lib.hnb_ctx_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        lib.hnb_program_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        lib.hnb_jit_precompile.argtypes = [C.c_char_p, C.c_size_t]
         _lib = lib
     return _lib
 
@@ -95,6 +97,11 @@ def _check(rc):
 def validate_program(blob: bytes):
     """Structural validation of a program blob; works without a GPU."""
     _check(load_library().hnb_program_validate(blob, len(blob)))
+
+
+def jit_precompile(blob: bytes):
+    """Compile and cache the kernels specialised for this program (hiprtc; needs no GPU)."""
+    _check(load_library().hnb_jit_precompile(blob, len(blob)))
 
 
 class Context:
@@ -159,6 +166,12 @@ class Program:
 
     def create_effect(self, slot_base=0):
         return Effect(self, slot_base)
+
+    def kernel_info(self):
+        """Which kernels run this program: 'init=jit|interp|none update=aot-stream:<name>|jit-stream|jit-generic|interp-*'."""
+        buf = C.create_string_buffer(4096)
+        _check(self._lib.hnb_program_kernel_info(self._h, buf, len(buf)))
+        return buf.value.decode()
 
     def destroy(self):
         if self._h:

@@ -19,8 +19,10 @@
 #ifndef HANABI_AMD_H
 #define HANABI_AMD_H
 
+#ifndef __HIPCC_RTC__  /* runtime-compiled device code gets these types from hiprtc */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -299,6 +301,16 @@ int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t 
 /* Ribbon post-update sort by (RIBBON_ID, AGE bits) ascending (src/render/mod.rs:7372-7612,
  * vfx_sort*.wgsl); rewrites the alive list column the renderer reads. */
 int hnb_effect_sort_ribbons(HnbEffect* fx);
+
+/* Which kernels run this program, as text: "init=jit|interp|none update=aot-stream:<name>|jit-stream|
+ * jit-generic|interp-stream|interp-generic", followed by the specialisation log if it failed.
+ * At creation the library specialises the kernels a program would otherwise interpret (the
+ * counterpart of the reference compiling generated WGSL per effect, src/lib.rs:805-1336) with
+ * hiprtc; HNB_JIT=0 in the environment keeps the interpreter kernels, HNB_JIT_CACHE=<dir> moves the
+ * on-disk cache of compiled code objects (default: jit_cache/ next to the library). */
+int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size);
+/* Compile and cache the specialised kernels of a program blob. Needs no device (build boxes). */
+int hnb_jit_precompile(const void* blob, size_t blob_size);
 
 /* Timing helper: average device time in ms of the update kernel, of the compaction kernel that
  * follows it (event after update -> event after compact, i.e. including the launch gap) and of the

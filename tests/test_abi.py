@@ -106,3 +106,22 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 assert not re.search(r"^\s*(import oracle|from oracle)|#include[^\n]*oracle|libhanabi_oracle|dlopen", src, flags=re.M), os.path.join(dp, f)
+
+
+def test_jit_precompile_without_a_device(tmp_path, monkeypatch):
+    """Kernel specialisation (hiprtc for gfx950) works on a box without a GPU and fills the cache."""
+    import bevy_hanabi_amd as bh
+    from test_lowering_cpu import ZOO
+    monkeypatch.setenv("HNB_JIT_CACHE", str(tmp_path))
+    bh.jit_precompile(bh.lower(effects.firework_trails(2048)))          # init only (update has a pre-built kernel)
+    n1 = len(list(tmp_path.glob("*.hsaco")))
+    assert n1 == 1
+    name = sorted(ZOO)[0]
+    bh.jit_precompile(bh.lower(ZOO[name]()))                            # a zoo program: init + update
+    assert len(list(tmp_path.glob("*.hsaco"))) == 2
+    names = [open(p).read().split() for p in tmp_path.glob("*.names")]
+    assert all(n and all(s.startswith("_ZN3hnb") for s in n) for n in names)
+    bh.jit_precompile(bh.lower(effects.firework_trails(1 << 20)))       # capacity does not enter the key
+    assert len(list(tmp_path.glob("*.hsaco"))) == 2
+    with pytest.raises(bh.HanabiError):
+        bh.jit_precompile(b"garbage")

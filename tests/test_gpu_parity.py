@@ -93,15 +93,42 @@ def test_c5_ribbon_churn(ctx):
     assert st["counters"]["dead_count"] > 0
 
 
+@pytest.fixture(params=["jit", "interp"])
+def kernels(request, monkeypatch):
+    """Both ways the generic kernels can run a program: specialised at creation (hiprtc) or interpreted."""
+    monkeypatch.setenv("HNB_JIT", "1" if request.param == "jit" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("name", sorted(ZOO))
-def test_zoo(ctx, name):
+def test_zoo(ctx, name, kernels):
     asset = ZOO[name]()
     cap = asset.capacity
     xf = np.array([0.0, -1.0, 0.0, 4.0, 1.0, 0.0, 0.0, -2.0, 0.0, 0.0, 1.0, 0.5], dtype=np.float32)
     frames = [Frame(1 / 60, cap // 2, frame_seed(0), xf)]
     for f in range(1, 60):
         frames.append(Frame(1 / 60 if f % 7 else 1 / 30, (cap // 9) if f % 11 == 0 else 0, frame_seed(f), xf, time=f / 60.0))
-    run_script(GpuRunner(asset, ctx=ctx), frames, OracleRunner(asset), every=10)
+    g = GpuRunner(asset, ctx=ctx)
+    info = g.prog.kernel_info()
+    if kernels == "jit":
+        assert "interp" not in info.split("\n")[0], info  # nothing left to the interpreter
+    else:
+        assert "jit" not in info, info
+    run_script(g, frames, OracleRunner(asset), every=10)
+    g.fx.destroy()
+    g.prog.destroy()
+
+
+def test_kernel_selection_for_the_baseline_configs(ctx):
+    """C1-C5: init specialised at creation, update on a pre-built streaming kernel (or specialised)."""
+    want = {"single_particle": "update=aot-stream:ProgNone", "firework_trails": "update=aot-stream:ProgDragAccel", "force_field": "update=aot-stream:ProgForceField",
+            "instancing": "update=aot-stream:ProgAgeEuler", "ribbon": "update=aot-stream:ProgAge"}
+    for name, upd in want.items():
+        prog = ctx.create_program(bh.lower(getattr(effects, name)(4096)))
+        info = prog.kernel_info()
+        assert info.startswith("init=jit"), info
+        assert upd in info, info
+        prog.destroy()
 
 
 def test_reference_contract_vectors_through_the_abi(ctx):

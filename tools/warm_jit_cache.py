@@ -1,0 +1,30 @@
+"""Fill bevy_hanabi_amd/jit_cache/ with the specialised kernels of the programs the tests, the bench
+and smoke() create. hiprtc needs no GPU, and the cache directory travels with the library, so a box
+that runs these programs never has to compile them. Safe to skip: a missing entry is compiled on demand."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import bevy_hanabi_amd as bh
+    from bevy_hanabi_amd import effects
+
+    assets = [effects.single_particle(16), effects.firework_trails(4096), effects.force_field(4096), effects.instancing(4096), effects.ribbon(4096)]
+    try:
+        from test_lowering_cpu import ZOO
+        assets += [ZOO[k]() for k in sorted(ZOO)]
+    except Exception as e:  # tests not present: product programs only
+        print("warm_jit_cache: zoo skipped:", e)
+    t0 = time.time()
+    for a in assets:
+        bh.jit_precompile(bh.lower(a))
+    print(f"warm_jit_cache: {len(assets)} programs in {time.time() - t0:.1f} s")
+
+
+if __name__ == "__main__":
+    main()
