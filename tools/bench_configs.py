@@ -82,4 +82,26 @@ if "c4" in which:
     tot = cap * n_inst
     print(f"   -> {tot * 68 / (tm['update_ms_avg'] * 1e-3) / 1e9:.1f} GB/s @68B, {tot / ((tm['update_ms_avg'] + tm['compact_ms_avg']) * 1e-3):.3e} updates/s (kernels)")
     prog.destroy()
+if "generic" in which:
+    # a non-streamable update stack (expression-driven SetAttribute in update): k_update_generic
+    cap = 1 << 24
+    h = bh
+    A = bh.Attribute
+    w = h.ExprWriter()
+    init = [h.SetAttributeModifier(A.POSITION, w.lit((0.0, 0.0, 0.0)).expr()),
+            h.SetAttributeModifier(A.VELOCITY, ((w.rand(h.VectorType.VEC3F) * w.lit(2.0) - w.lit(1.0)).normalized() * w.lit(40.0).uniform(w.lit(60.0))).expr()),
+            h.SetAttributeModifier(A.AGE, w.lit(0.0).expr()), h.SetAttributeModifier(A.LIFETIME, w.lit(0.8).uniform(w.lit(1.2)).expr())]
+    ratio = w.attr(A.AGE) / w.attr(A.LIFETIME)
+    upd = [h.LinearDragModifier(w.lit(4.0).expr()), h.AccelModifier(w.lit((0.0, -16.0, 0.0)).expr()),
+           h.SetAttributeModifier(A.SIZE, (w.lit(1.0) - ratio * ratio).expr())]
+    asset = h.EffectAsset(cap, h.SpawnerSettings.once(float(cap)), w.finish())
+    for m in init: asset.init(m)
+    for m in upd: asset.update(m)
+    for jit in ("1", "0"):
+        os.environ["HNB_JIT"] = jit
+        prog = ctx.create_program(bh.lower(asset)); fx = prog.create_effect()
+        print(prog.kernel_info().split("\n")[0])
+        tm = run(f"generic update 16M (HNB_JIT={jit})", prog, [fx], 20, lambda f, i: cap if f == 0 else 0, 76, warm=3)
+        print(f"   -> {cap * 76 / (tm['update_ms_avg'] * 1e-3) / 1e9:.1f} GB/s @76B (68 + size write 4 + ... )")
+        prog.destroy()
 ctx.close()
