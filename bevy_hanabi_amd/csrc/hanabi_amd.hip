@@ -99,6 +99,7 @@ struct HnbContext {
     uint32_t num_cus = 256;
     std::vector<HnbProgram*> programs;
     HnbSimParams sim{};
+    uint32_t frame = 0;         // simulated frames: parity double-buffers the spawn-event counters
     uint32_t timing = 0;        // 0 = off, n = time every n-th simulated frame
     uint32_t timing_tick = 0;
     std::vector<TimingPair> t_update, t_init, t_compact;
@@ -125,6 +126,10 @@ struct HnbProgram {
     uint32_t table_cap = 0;
     uint64_t* d_inst_base = nullptr;
     DevMeta* d_meta[2] = {nullptr, nullptr};
+    uint32_t* d_plane_by_attr = nullptr;  // [HNB_ATTR_COUNT] plane offsets by attribute id (children read parent particles through it)
+    std::vector<uint32_t> parent_attrs;   // attribute ids the init stream reads from the parent particle
+    uint32_t* d_ev_totals = nullptr;      // [table_cap * chunks_per_inst][HNB_MAX_EVENT_CHANNELS] (emitting programs)
+    uint32_t level = 0;                   // dependency level: parents are simulated before their children
     uint32_t* d_counts = nullptr;  // per chunk: survivors this frame
     uint32_t* d_deaths = nullptr;  // [2][table_cap]: casualties per instance, frame-parity double-buffered
     void* h_frame[2] = {nullptr, nullptr};
@@ -135,10 +140,19 @@ struct HnbProgram {
     uint32_t parity = 0;
 };
 
+struct EventChannel {
+    DevEventBuffer* buf = nullptr;  // device
+    uint32_t capacity = 0;
+    HnbEffect* child = nullptr;
+};
+
 struct HnbEffect {
     HnbProgram* prog = nullptr;
     uint32_t index = 0;
     void* slab = nullptr;
+    HnbEffect* parent = nullptr;    // EffectParent: init consumes the parent's spawn events
+    uint32_t parent_channel = 0;
+    EventChannel channels[HNB_MAX_EVENT_CHANNELS];  // as a parent
     uint32_t slot_base = 0;
     uint32_t spawn_count = 0;
     uint32_t seed = 0;
@@ -178,7 +192,7 @@ int validate_stream(const uint8_t* blob_base, const uint8_t* code, uint32_t len,
         }
         if (ustream && !(vm_op_is_elementwise(op) || (op >= HNB_OP_ALL && op <= HNB_OP_UNPACK4SNORM)))
             BAD("per-particle opcode in the uniform stream");
-        if (op == HNB_OP_LDPARENT || op == HNB_OP_M_EMIT_EVENTS) BAD("GPU spawn events are not supported by this build");
+        const bool is_init = which == 1;
         if (!ustream && (d & HNB_OPERAND_U)) BAD("destination must be a V register");
         auto OK = [&](uint32_t operand, uint32_t span) { return operand_ok(operand, span, nregs, h.n_uregs, ustream); };
         if (vm_op_is_elementwise(op)) {
@@ -262,6 +276,16 @@ int validate_stream(const uint8_t* blob_base, const uint8_t* code, uint32_t len,
                 if (!OK(a, 3)) BAD("operand out of range");
                 break;
             case HNB_OP_M_ADD_XLATE: break;
+            case HNB_OP_LDPARENT:
+                if (!is_init) BAD("LDPARENT outside the init stream");
+                if (d + wd > file_regs) BAD("destination out of range");
+                if ((w[1] >> 16) >= HNB_ATTR_COUNT) BAD("parent attribute id out of range");
+                break;
+            case HNB_OP_M_EMIT_EVENTS:
+                if (is_init) BAD("M_EMIT_EVENTS outside the update stream");
+                if (!OK(a, 1)) BAD("operand out of range");
+                if (((w[1] >> 16) & 0xffu) >= h.n_event_channels) BAD("event channel out of range");
+                break;
             default: BAD("unhandled opcode");
         }
 #undef BAD
@@ -335,6 +359,7 @@ void free_tables(HnbProgram* p) {
     }
     hipFree(p->d_counts); p->d_counts = nullptr;
     hipFree(p->d_deaths); p->d_deaths = nullptr;
+    hipFree(p->d_ev_totals); p->d_ev_totals = nullptr;
     p->table_cap = 0;
 }
 
@@ -374,6 +399,12 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
     hipFree(p->d_meta[1]);
     hipFree(p->d_counts);
     hipFree(p->d_deaths);
+    if (p->dev.n_event_channels) {
+        hipFree(p->d_ev_totals);
+        p->d_ev_totals = nullptr;
+        HIP_TRY(hipMalloc(&p->d_ev_totals, n_counts * HNB_MAX_EVENT_CHANNELS * 4));
+        HIP_TRY(hipMemset(p->d_ev_totals, 0, n_counts * HNB_MAX_EVENT_CHANNELS * 4));
+    }
     p->d_inst_base = nb;
     p->d_meta[0] = nm[0];
     p->d_meta[1] = nm[1];
@@ -538,7 +569,23 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
         d.attrs[i].upd_flags = p->attrs[i].update_flags;
         off += align_up((size_t)h.capacity * p->attrs[i].ncomp * 4, 256);
     }
+    d.n_event_channels = h.n_event_channels;
+    if (h.n_event_channels) {  // per-row staging of spawn events (k_update_generic -> k_emit_events)
+        d.ev_slot_off = (uint32_t)off; off += list_bytes;
+        for (uint32_t c = 0; c < h.n_event_channels; ++c) { d.ev_cnt_off[c] = (uint32_t)off; off += list_bytes; }
+        if (off > 0xffffffffull) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB"); }
+    }
     p->slab_bytes = off;
+    p->parent_attrs.resize(h.parent_n_attrs);
+    if (h.parent_n_attrs) memcpy(p->parent_attrs.data(), b + h.parent_attrs_off, (size_t)h.parent_n_attrs * 4);
+    {
+        uint32_t planes[HNB_ATTR_COUNT];
+        for (uint32_t i = 0; i < HNB_ATTR_COUNT; ++i) planes[i] = kNoPlane;
+        for (uint32_t i = 0; i < h.n_attrs; ++i) planes[p->attrs[i].attr] = d.attrs[i].plane_off;
+        hipError_t pe = hipMalloc(&p->d_plane_by_attr, sizeof planes);
+        if (pe != hipSuccess) { delete p; return fail(HNB_ERR_OUT_OF_MEMORY, "hipMalloc failed: %s", hipGetErrorString(pe)); }
+        hipMemcpy(p->d_plane_by_attr, planes, sizeof planes, hipMemcpyHostToDevice);
+    }
     p->uniform_code.resize(h.uniform_len);
     if (h.uniform_len) memcpy(p->uniform_code.data(), b + h.uniform_off, (size_t)h.uniform_len * 8);
     p->update_streams = update_is_streamable(b, h, p->attrs.data());
@@ -591,6 +638,7 @@ int hnb_program_destroy(HnbProgram* p) {
         if (p->kernels_done[i]) hipEventDestroy(p->kernels_done[i]);
     }
     if (p->jit_module) hipModuleUnload(p->jit_module);
+    hipFree(p->d_plane_by_attr);
     hipFree(p->d_code);
     ctx->programs.erase(std::remove(ctx->programs.begin(), ctx->programs.end(), p), ctx->programs.end());
     delete p;
@@ -638,6 +686,16 @@ int hnb_effect_destroy(HnbEffect* fx) {
     HnbProgram* p = fx->prog;
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
+    // unlink spawn-event relations in both directions
+    if (fx->parent) {
+        EventChannel& ch = fx->parent->channels[fx->parent_channel];
+        if (ch.child == fx) { hipFree(ch.buf); ch = EventChannel(); }
+    }
+    for (EventChannel& ch : fx->channels) {
+        if (ch.child) { ch.child->parent = nullptr; }
+        hipFree(ch.buf);
+        ch = EventChannel();
+    }
     // swap-remove: move the last instance's table rows into the freed index
     const uint32_t last = (uint32_t)p->effects.size() - 1;
     if (fx->index != last) {
@@ -654,8 +712,47 @@ int hnb_effect_destroy(HnbEffect* fx) {
     return HNB_OK;
 }
 
-int hnb_effect_set_parent(HnbEffect*, HnbEffect*, uint32_t, uint32_t) {
-    return fail(HNB_ERR_INVALID_ARG, "GPU spawn events are not implemented yet (SURVEY.md §8f-1)");
+int hnb_effect_set_parent(HnbEffect* child, HnbEffect* parent, uint32_t channel, uint32_t event_capacity) {
+    if (!child || !parent) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    if (child == parent) return fail(HNB_ERR_INVALID_ARG, "an effect cannot be its own parent");
+    HnbProgram* cp = child->prog;
+    HnbProgram* pp = parent->prog;
+    if (cp->ctx != pp->ctx) return fail(HNB_ERR_INVALID_ARG, "parent and child must live in the same context (same GPU)");
+    if (channel >= pp->dev.n_event_channels)
+        return fail(HNB_ERR_INVALID_ARG, "the parent effect emits no spawn events on channel %u (EmitSpawnEventModifier::child_index)", channel);
+    if (event_capacity == 0) return fail(HNB_ERR_INVALID_ARG, "event_capacity must be positive");
+    for (HnbEffect* a = parent; a; a = a->parent)
+        if (a == child) return fail(HNB_ERR_INVALID_ARG, "parent/child cycle");
+    // every attribute the child's init stream reads from the parent particle must exist in the parent layout
+    for (uint32_t id : cp->parent_attrs)
+        if (find_attr(pp, id) < 0) return fail(HNB_ERR_NOT_FOUND, "the parent layout has no attribute %u read by the child's init modifiers", id);
+    HIP_TRY(hipSetDevice(cp->ctx->device));
+    HIP_TRY(hipStreamSynchronize(cp->ctx->stream));
+    if (child->parent) {  // re-parenting: release the old channel
+        EventChannel& old = child->parent->channels[child->parent_channel];
+        if (old.child == child) { hipFree(old.buf); old = EventChannel(); }
+    }
+    EventChannel& ch = parent->channels[channel];
+    if (ch.child && ch.child != child) ch.child->parent = nullptr;  // the N-th child reads channel N: one consumer
+    hipFree(ch.buf);
+    const size_t bytes = sizeof(DevEventBuffer) + (size_t)event_capacity * 4;
+    void* buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, bytes));
+    HIP_TRY(hipMemset(buf, 0, bytes));
+    HIP_TRY(hipMemcpy(static_cast<char*>(buf) + offsetof(DevEventBuffer, capacity), &event_capacity, 4, hipMemcpyHostToDevice));
+    ch.buf = static_cast<DevEventBuffer*>(buf);
+    ch.capacity = event_capacity;
+    ch.child = child;
+    child->parent = parent;
+    child->parent_channel = channel;
+    // parents before children: dependency level per program
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (HnbProgram* q : cp->ctx->programs)
+            for (HnbEffect* e : q->effects)
+                if (e->parent && q->level <= e->parent->prog->level) { q->level = e->parent->prog->level + 1; changed = true; }
+    }
+    return HNB_OK;
 }
 
 int hnb_frame_begin(HnbContext* ctx, const HnbSimParams* params) {
@@ -684,12 +781,22 @@ int hnb_effect_set_property(HnbEffect* fx, const char* name, const void* value, 
     return fail(HNB_ERR_NOT_FOUND, "unknown property '%s'", name);
 }
 
+// One simulated frame, in the reference's order (src/render/mod.rs:6975-7370): every effect's init
+// pass, parents before children, THEN every effect's update pass. Spawn events appended by a parent's
+// update in frame N are consumed by its children's init in frame N+1.
 int hnb_simulate(HnbContext* ctx) {
     if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
-    for (HnbProgram* p : ctx->programs) {
+    std::vector<HnbProgram*> order;
+    for (HnbProgram* p : ctx->programs)
+        if (!p->effects.empty()) order.push_back(p);
+    std::stable_sort(order.begin(), order.end(), [](const HnbProgram* x, const HnbProgram* y) { return x->level < y->level; });
+    const bool timed = ctx->timing && (ctx->timing_tick % ctx->timing) == 0;
+    const uint32_t ev_parity = ctx->frame & 1u;
+
+    // ---- phase A: per-frame parameters + init passes --------------------------------------------------
+    for (HnbProgram* p : order) {
         const uint32_t n = (uint32_t)p->effects.size();
-        if (n == 0) continue;
         const uint32_t par = p->parity;
         // the host staging buffer of this parity was last used two frames ago
         HIP_TRY(hipEventSynchronize(p->upload_done[par]));
@@ -702,12 +809,25 @@ int hnb_simulate(HnbContext* ctx) {
         uint32_t blocks = 0;
         for (uint32_t i = 0; i < n; ++i) {
             HnbEffect* fx = p->effects[i];
-            fi[i].spawn_count = fx->spawn_count;
+            if (!p->parent_attrs.empty() && !fx->parent)
+                return fail(HNB_ERR_INVALID_ARG, "effect #%u reads its parent particle (InheritAttributeModifier / parent_attr) but has no parent: call hnb_effect_set_parent", i);
+            memset(&fi[i], 0, sizeof fi[i]);
+            fi[i].spawn_count = fx->parent ? 0u : fx->spawn_count;  // the CPU spawner of a child effect is unused (firework.rs:161)
             fi[i].seed = fx->seed;
             fi[i].slot_base = fx->slot_base;
             fi[i].init_block_start = blocks;
+            fi[i].ev_parity = ev_parity;
+            uint32_t max_request = fx->spawn_count;
+            if (fx->parent) {
+                const EventChannel& ch = fx->parent->channels[fx->parent_channel];
+                fi[i].parent_base = reinterpret_cast<uint64_t>(fx->parent->slab);
+                fi[i].parent_planes = reinterpret_cast<uint64_t>(fx->parent->prog->d_plane_by_attr);
+                fi[i].ev_in = reinterpret_cast<uint64_t>(ch.buf);
+                max_request = ch.capacity;  // the event count lives on the device: launch for the worst case
+            }
+            for (uint32_t c = 0; c < HNB_MAX_EVENT_CHANNELS; ++c) fi[i].ev_out[c] = reinterpret_cast<uint64_t>(fx->channels[c].buf);
             // never launch more init workgroups than the capacity allows (max_spawn <= capacity)
-            const uint32_t cap_spawn = std::min(fx->spawn_count, p->dev.capacity);
+            const uint32_t cap_spawn = std::min(max_request, p->dev.capacity);
             blocks += (cap_spawn + kInitBlock - 1) / kInitBlock;
             memcpy(fi[i].xf, fx->xf, sizeof fx->xf);
             // Parameter block: the uniform stream (literals, properties, sim params and every
@@ -727,9 +847,8 @@ int hnb_simulate(HnbContext* ctx) {
         const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
         const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
         p->dev.n_inst = n;
-        TimingPair ti{}, tu{};
-        const bool timed = ctx->timing && (ctx->timing_tick % ctx->timing) == 0;
         if (blocks) {
+            TimingPair ti{};
             if (timed) { hipEventCreate(&ti.a); hipEventCreate(&ti.b); hipEventRecord(ti.a, ctx->stream); }
             if (p->jit_init) {
                 const DevMeta* mi = p->d_meta[par];
@@ -740,6 +859,15 @@ int hnb_simulate(HnbContext* ctx) {
             }
             if (timed) { hipEventRecord(ti.b, ctx->stream); ctx->t_init.push_back(ti); }
         }
+    }
+
+    // ---- phase B: update + kill + compaction (+ spawn-event ordering) ------------------------------------
+    for (HnbProgram* p : order) {
+        const uint32_t n = (uint32_t)p->effects.size();
+        const uint32_t par = p->parity;
+        const char* d = static_cast<const char*>(p->d_frame[par]);
+        const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
+        const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
         // one workgroup per 4096-row chunk of every instance's alive list
         const uint32_t total_chunks = n * p->dev.chunks_per_inst;
         CompactBufs cb;
@@ -747,7 +875,8 @@ int hnb_simulate(HnbContext* ctx) {
         cb.deaths = p->d_deaths;
         cb.table_cap = p->table_cap;
         cb.parity = par;
-        TimingPair tc{};
+        cb.ev_totals = p->d_ev_totals;
+        TimingPair tu{}, tc{};
         if (timed) { hipEventCreate(&tu.a); hipEventCreate(&tu.b); hipEventCreate(&tc.b); hipEventRecord(tu.a, ctx->stream); }
         if (p->update_streams) {
             StreamArgs sa{};
@@ -778,6 +907,8 @@ int hnb_simulate(HnbContext* ctx) {
             k_update_generic<InterpCode><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub, cb);
         }
         if (timed) { hipEventRecord(tu.b, ctx->stream); ctx->t_update.push_back(tu); }
+        if (p->dev.n_event_channels)  // order this frame's spawn events into the children's buffers
+            k_emit_events<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb);
         CompactArgs ca{};
         ca.capacity = p->dev.capacity; ca.chunks_per_inst = p->dev.chunks_per_inst;
         ca.alive_off[0] = p->dev.alive_off[0]; ca.alive_off[1] = p->dev.alive_off[1]; ca.dead_off = p->dev.dead_off;
@@ -787,6 +918,7 @@ int hnb_simulate(HnbContext* ctx) {
         HIP_TRY(hipEventRecord(p->kernels_done[par], ctx->stream));
         p->parity ^= 1u;
     }
+    ctx->frame += 1;
     if (ctx->timing) ctx->timing_tick += 1;
     return HNB_OK;
 }

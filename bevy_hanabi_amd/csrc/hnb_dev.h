@@ -31,6 +31,10 @@ struct DevProgram {
     uint32_t dead_off;         // byte offset of the dead list
     uint32_t init_len, update_len;
     uint32_t n_inst;
+    // GPU spawn events this program's update appends (EmitSpawnEventModifier): per-row staging planes in the slab
+    uint32_t n_event_channels;
+    uint32_t ev_slot_off;                            // u32[capacity]: slot of each alive-list row (as the update saw it)
+    uint32_t ev_cnt_off[HNB_MAX_EVENT_CHANNELS];     // u32[capacity] per channel: events appended by that row
     DevAttr attrs[kMaxAttrs];
     const Ins* init_code;
     const Ins* update_code;
@@ -43,8 +47,25 @@ struct DevFrameInst {
     uint32_t slot_base;         // particle index offset for PRNG / ID (capacity-slab sharding)
     uint32_t init_block_start;  // first init workgroup of this instance (CPU prefix sum, batch.rs:348-386)
     float xf[12];               // row-major 3x4 transform
+    // GPU spawn events (GpuSpawnerParams::parent_slab_offset, GpuChildInfo; src/render/event.rs:200-214)
+    uint64_t parent_base;       // child: slab of the parent instance, 0 = CPU-spawned effect
+    uint64_t parent_planes;     // child: u32[HNB_ATTR_COUNT] plane byte offsets of the parent layout (kNoPlane = absent)
+    uint64_t ev_in;             // child: DevEventBuffer the init pass consumes
+    uint64_t ev_out[HNB_MAX_EVENT_CHANNELS];  // parent: DevEventBuffer per child channel, 0 = nobody listens
+    uint32_t ev_parity;         // context frame parity: events are appended to count[ev_parity], consumed from count[ev_parity ^ 1]
+    uint32_t pad;
 };
-static_assert(sizeof(DevFrameInst) == 64, "DevFrameInst layout");
+static_assert(sizeof(DevFrameInst) == 128, "DevFrameInst layout");
+
+// Spawn events of one (parent instance, channel). `count` keeps growing past the capacity like the
+// reference's GpuChildInfo::event_count (src/lib.rs:976-993); it is double-buffered by frame parity so
+// that every kernel of frame N+1 sees the number of events frame N appended, whatever the launch order.
+struct DevEventBuffer {
+    uint32_t count[2];
+    uint32_t capacity;      // arrayLength(&event_buffer.spawn_events)
+    uint32_t pad;
+    uint32_t data[1];       // [capacity] spawn_events[i].particle_index (slot in the parent slab)
+};
 
 // Device-resident per-instance counters; frame f reads [f&1] and writes [(f+1)&1].
 struct DevMeta {

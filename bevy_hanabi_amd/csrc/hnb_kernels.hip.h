@@ -67,6 +67,16 @@ __device__ __forceinline__ Out4 vfile_load_attr(uint32_t ncomp, const char* plan
     return o;
 }
 
+// Particles the init pass of instance k wants to spawn this frame: the CPU spawner's count, or — for an
+// effect with a parent — the number of spawn events its parent appended during the PREVIOUS frame
+// (vfx_init.wgsl:123-129; events past the buffer capacity were never stored).
+__device__ __forceinline__ uint32_t requested_spawn(const DevFrameInst& f) {
+    if (f.ev_in == 0ull) return f.spawn_count;
+    const DevEventBuffer* ev = reinterpret_cast<const DevEventBuffer*>(f.ev_in);
+    const uint32_t n = ev->count[f.ev_parity ^ 1u];
+    return n < ev->capacity ? n : ev->capacity;
+}
+
 // ---- code policies -----------------------------------------------------------------------------
 // How the generic kernels run a program. InterpCode interprets the bytecode (always available, any
 // program). The kernels specialised at program creation (hnb_jit.h) supply a policy with the same
@@ -135,7 +145,7 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
 
     const uint32_t alive0 = meta_in[k].alive_count;
     const uint32_t max_spawn = prog.capacity - alive0;
-    const uint32_t spawn = fi[k].spawn_count;
+    const uint32_t spawn = requested_spawn(fi[k]);
     const uint32_t n_spawn = spawn < max_spawn ? spawn : max_spawn;
     if (i >= n_spawn) return;
 
@@ -157,6 +167,12 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
 
     VmAttrIO io;
     io.slab = base; io.attrs = prog.attrs; io.slot = slot;
+    if (fi[k].ev_in != 0ull) {  // GPU-spawned: fetch the parent particle that emitted event i (vfx_init.wgsl:166-171)
+        S.gpu_spawned = true;
+        io.parent_slab = reinterpret_cast<const char*>(fi[k].parent_base);
+        io.parent_planes = reinterpret_cast<const uint32_t*>(fi[k].parent_planes);
+        io.parent_slot = reinterpret_cast<const DevEventBuffer*>(fi[k].ev_in)->data[i];
+    }
     CODE::zero_unassigned(prog, io);
     CODE::run_init(prog, S, U, io);
     alive[alive0 + i] = slot;
@@ -252,6 +268,7 @@ struct CompactBufs {
     uint32_t* deaths;   // [2][table_cap] casualties per instance, frame-parity double-buffered
     uint32_t table_cap;
     uint32_t parity;
+    uint32_t* ev_totals;  // [n_inst * chunks_per_inst][HNB_MAX_EVENT_CHANNELS] spawn events per chunk (emitting programs)
 };
 
 // Decode a chunk id; false when the chunk has no rows.
@@ -262,7 +279,7 @@ __device__ __forceinline__ bool chunk_setup(ChunkCtx& c, uint32_t chunk, const A
     c.j = chunk - c.k * args.chunks_per_inst;
     // vfx_indirect.wgsl:57-85 folded in: max_update = alive_count after init.
     c.m = meta_in[c.k];
-    const uint32_t spawn = fi[c.k].spawn_count;
+    const uint32_t spawn = requested_spawn(fi[c.k]);
     const uint32_t max_spawn = args.capacity - c.m.alive_count;
     c.n_spawn = spawn < max_spawn ? spawn : max_spawn;
     c.n = c.m.alive_count + c.n_spawn;
@@ -370,6 +387,69 @@ k_compact(const CompactArgs args, const uint64_t* __restrict__ inst_base, const 
 }
 #endif
 
+// ---- k_emit_events: order the staged spawn events (src/lib.rs:976-993 under serial thread order) ----
+// Event e of the frame is the e-th (row, repeat) pair in alive-list order; it is stored iff e < capacity.
+// One workgroup per chunk and channel loop: cross-chunk exclusive prefix of the chunk totals, then a
+// workgroup scan over the chunk's rows (16 consecutive rows per thread).
+#ifndef HNB_JIT_TU
+__global__ void __launch_bounds__(kBlock)
+k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+              const DevFrameInst* __restrict__ fi, const CompactBufs cb) {
+    __shared__ uint32_t s_red[kBlock / 64];
+    __shared__ uint32_t s_scan[kBlock];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t chunk = blockIdx.x;
+    ChunkCtx c;
+    const bool has_rows = chunk_setup(c, chunk, prog, inst_base, meta_in, fi);
+    const bool last = c.n == 0 ? c.j == 0 : (c.start < c.n && c.start + kChunk >= c.n);
+    const uint32_t rows = has_rows ? ((c.n - c.start) < kChunk ? (c.n - c.start) : kChunk) : 0u;
+    constexpr uint32_t kPer = kChunk / kBlock;  // rows per thread
+    for (uint32_t ch = 0; ch < prog.n_event_channels; ++ch) {
+        DevEventBuffer* ev = reinterpret_cast<DevEventBuffer*>(fi[c.k].ev_out[ch]);
+        if (!ev) continue;  // nobody listens on this channel
+        const uint32_t* tot = cb.ev_totals + (size_t)c.k * prog.chunks_per_inst * HNB_MAX_EVENT_CHANNELS + ch;
+        uint32_t part = 0;
+        for (uint32_t i = tid; i < c.j; i += kBlock) part += tot[(size_t)i * HNB_MAX_EVENT_CHANNELS];
+#pragma unroll
+        for (uint32_t off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        __syncthreads();
+        if (lane == 0) s_red[wave] = part;
+        __syncthreads();
+        uint32_t excl = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kBlock / 64; ++w) excl += s_red[w];
+        const uint32_t mine = has_rows ? tot[(size_t)c.j * HNB_MAX_EVENT_CHANNELS] : 0u;
+        if (last && tid == 0) ev->count[fi[c.k].ev_parity] = excl + mine;  // GpuChildInfo::event_count of this frame
+        if (mine == 0u) continue;
+        const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c.base + prog.ev_cnt_off[ch]) + c.start;
+        const uint32_t* slots = reinterpret_cast<const uint32_t*>(c.base + prog.ev_slot_off) + c.start;
+        uint32_t local = 0;
+        for (uint32_t r = 0; r < kPer; ++r) { const uint32_t row = tid * kPer + r; if (row < rows) local += cnt[row]; }
+        // workgroup exclusive scan of the per-thread sums
+        uint32_t incl = local;
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
+        if (lane == 63) s_scan[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t w = 0; w < wave; ++w) wbase += s_scan[w];
+        uint32_t pos = excl + wbase + incl - local;
+        const uint32_t capacity = ev->capacity;
+        for (uint32_t r = 0; r < kPer && pos < capacity; ++r) {
+            const uint32_t row = tid * kPer + r;
+            if (row >= rows) break;
+            const uint32_t n_ev = cnt[row];
+            if (!n_ev) continue;
+            const uint32_t slot = slots[row];
+            const uint32_t end = pos + n_ev < capacity ? pos + n_ev : capacity;
+            for (uint32_t e = pos; e < end; ++e) ev->data[e] = slot;
+            pos += n_ev;
+        }
+        __syncthreads();
+    }
+}
+#endif
+
 // ---- generic update kernel: any update stream, V register file, one particle per lane ----------
 template <class CODE>
 __global__ void __launch_bounds__(kBlock)
@@ -388,6 +468,7 @@ k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, 
     U.u = ublocks + (size_t)c.k * prog.n_uregs;
     U.xf = fi[c.k].xf;
     uint32_t local_alive = 0, local_dead = 0;
+    uint32_t ev_sum[HNB_MAX_EVENT_CHANNELS] = {};  // this thread's spawn events per child channel
     for (uint32_t sub = 0; sub < kChunk / kBlock; ++sub) {
         const uint32_t li = c.start + sub * kBlock + tid;
         if (c.start + sub * kBlock >= c.n) break;
@@ -405,6 +486,15 @@ k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, 
         if (valid) {
             CODE::run_update(prog, S, U, io);
             CODE::store_update(prog, S, c.base, slot);
+            if (prog.n_event_channels) {  // stage the row's spawn events; k_emit_events orders them (src/lib.rs:976-993)
+                reinterpret_cast<uint32_t*>(c.base + prog.ev_slot_off)[li] = slot;
+#pragma unroll
+                for (uint32_t ch = 0; ch < HNB_MAX_EVENT_CHANNELS; ++ch)
+                    if (ch < prog.n_event_channels) {
+                        reinterpret_cast<uint32_t*>(c.base + prog.ev_cnt_off[ch])[li] = S.ev[ch];
+                        ev_sum[ch] += S.ev[ch];
+                    }
+            }
         }
         // chunk-local stable compaction in LDS
         const uint32_t x = (valid && S.alive ? 1u : 0u) | ((valid && !S.alive ? 1u : 0u) << 16);
@@ -435,6 +525,24 @@ k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, 
     if (tid == 0) s_cnt[0] = local_alive | (local_dead << 16);
     __syncthreads();
     chunk_record<1>(c, chunk, cb, list, s_list, kChunk, s_cnt);
+    if (prog.n_event_channels) {  // per-chunk event totals for the cross-chunk prefix of k_emit_events
+        __syncthreads();
+#pragma unroll
+        for (uint32_t ch = 0; ch < HNB_MAX_EVENT_CHANNELS; ++ch) {
+            if (ch >= prog.n_event_channels) break;
+            uint32_t v = ev_sum[ch];
+#pragma unroll
+            for (uint32_t off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) s_wave[wave] = v;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t t = 0;
+                for (uint32_t w2 = 0; w2 < kBlock / 64; ++w2) t += s_wave[w2];
+                cb.ev_totals[(size_t)chunk * HNB_MAX_EVENT_CHANNELS + ch] = t;
+            }
+            __syncthreads();
+        }
+    }
 }
 // ---- streaming update kernel ---------------------------------------------------------------------
 // Macro-op update streams with U operands, named registers, 4 particles per lane.

@@ -42,6 +42,7 @@ struct VmUniforms {
     const uint32_t* u;   // parameter block: U registers produced by the uniform stream
     const float* xf;     // [12] emitter transform, row-major 3x4 (GpuSpawnerParams::transform)
 };
+constexpr uint32_t kNoPlane = 0xffffffffu;
 
 // Attribute table entry as the kernels see it, and the per-particle window onto the SoA planes
 // used by HNB_OP_LDA / HNB_OP_STA (non-pinned attributes are memory operands).
@@ -56,6 +57,10 @@ struct VmAttrIO {
     char* slab;              // instance slab base
     const AttrDesc* attrs;   // attribute table (uniform memory)
     uint32_t slot;           // this particle's slot
+    // parent particle that triggered this spawn (init of an effect with a parent, vfx_init.wgsl:166-171)
+    const char* parent_slab = nullptr;          // parent instance slab base
+    const uint32_t* parent_planes = nullptr;    // [HNB_ATTR_COUNT] plane byte offsets of the parent layout (kNoPlane = absent)
+    uint32_t parent_slot = 0;
 };
 HNB_HD uint32_t* vm_attr_ptr(const VmAttrIO& io, uint32_t idx) {
     return reinterpret_cast<uint32_t*>(io.slab + io.attrs[idx].plane_off) + (size_t)io.slot * io.attrs[idx].ncomp;
@@ -68,6 +73,9 @@ struct VmState {
     uint32_t pindex;    // particle_index (+slot_base): Attribute::ID
     uint32_t pcounter;  // particle_counter
     bool alive;
+    bool was_alive = true;                       // AGE_CODE: age < lifetime before ageing (src/lib.rs:1226-1233)
+    bool gpu_spawned = false;                    // init driven by GPU spawn events: no emitter translation (vfx_init.wgsl:183-189)
+    uint32_t ev[HNB_MAX_EVENT_CHANNELS] = {};    // spawn events this particle appends per child channel
 };
 
 #define HNB_TAU 6.283185307179586476925286766559f
@@ -421,6 +429,26 @@ HNB_HD void vm_exec(const Ins ins, ST& S, const VmUniforms& U, const uint32_t* p
                     for (uint32_t k = 0; k < w; ++k) p[k] = vm_rd<false>(S, U, a + k * sa);
                 }
                 break;
+            case HNB_OP_LDPARENT:
+                if constexpr (!USTREAM) {
+                    nout = w;
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(io.parent_slab + io.parent_planes[aux]) + (size_t)io.parent_slot * w;
+                    o.v0 = p[0];
+                    o.v1 = w > 1 ? p[1] : 0u;
+                    o.v2 = w > 2 ? p[2] : 0u;
+                    o.v3 = w > 3 ? p[3] : 0u;
+                }
+                break;
+            case HNB_OP_M_EMIT_EVENTS:
+                if constexpr (!USTREAM) {
+                    const uint32_t cnt = vm_rd<false>(S, U, a);
+                    const bool fire = (aux & 0x100u) ? (S.was_alive && !S.alive) : S.alive;
+                    const uint32_t ch = aux & 0xffu;
+#pragma unroll
+                    for (uint32_t k = 0; k < HNB_MAX_EVENT_CHANNELS; ++k)
+                        if (fire && k == ch) S.ev[k] += cnt;
+                }
+                break;
             case HNB_OP_LDID: nout = 1; o.v0 = S.pindex; break;
             case HNB_OP_LDPC: nout = 1; o.v0 = S.pcounter; break;
             case HNB_OP_LDALIVE: nout = 1; o.v0 = S.alive ? 1u : 0u; break;
@@ -484,6 +512,7 @@ HNB_HD void vm_exec(const Ins ins, ST& S, const VmUniforms& U, const uint32_t* p
                     switch (op) {
                         case HNB_OP_M_AGE_TICK: {
                             float age = u2f(S.r[HNB_REG_AGE]);
+                            if (aux & 1u) S.was_alive = age < u2f(S.r[HNB_REG_LIFETIME]);
                             mac_age_tick(age, u2f(S.r[HNB_REG_LIFETIME]), vm_rdf<false>(S, U, a), (aux & 1u) != 0u, S.alive);
                             nage = age; wage = true;
                         } break;
@@ -521,8 +550,8 @@ HNB_HD void vm_exec(const Ins ins, ST& S, const VmUniforms& U, const uint32_t* p
                         case HNB_OP_M_VEL_SPHERE:
                             nvel = mac_vel_sphere(pos, vm_rd3<false>(S, U, a), vm_rdf<false>(S, U, b)); wvel = true;
                             break;
-                        case HNB_OP_M_ADD_XLATE:
-                            npos = V3{pos.x + U.xf[3], pos.y + U.xf[7], pos.z + U.xf[11]}; wpos = true;
+                        case HNB_OP_M_ADD_XLATE:  // only CPU-spawned particles get the emitter translation (vfx_init.wgsl:183-189)
+                            if (!S.gpu_spawned) { npos = V3{pos.x + U.xf[3], pos.y + U.xf[7], pos.z + U.xf[11]}; wpos = true; }
                             break;
                         default: break;
                     }

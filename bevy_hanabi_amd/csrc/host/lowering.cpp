@@ -118,6 +118,12 @@ class Lowerer {
     static uint32_t opnd(const Loc& l) { return l.uniform ? (HNB_OPERAND_U | l.reg) : l.reg; }
 
     // ---- emission --------------------------------------------------------------------------
+    std::vector<uint32_t> parent_attrs_;  // HnbAttr ids the init stream reads from the parent particle
+    uint32_t n_event_channels_ = 0;       // child event channels the update stream appends to
+    void note_parent_attr(Attribute a) {
+        for (uint32_t id : parent_attrs_) if (id == a.id) return;
+        parent_attrs_.push_back((uint32_t)a.id);
+    }
     void emit(StreamId s, uint32_t op, uint32_t d, uint32_t a, uint32_t b, uint32_t c, uint32_t width, bool ba, bool bb, bool bc,
               uint32_t aux = 0) {
         S(s).code.push_back(encode(op, d, a, b, c, width, ba, bb, bc, aux));
@@ -243,8 +249,20 @@ class Lowerer {
             }
             case Expr::Kind::BuiltIn: return eval_builtin(w, e, s);
             case Expr::Kind::Attribute: return eval_attribute(e, s);
-            case Expr::Kind::ParentAttribute:
-                throw ShaderGenerateError("parent attributes require GPU spawn events, which this build does not support yet");
+            case Expr::Kind::ParentAttribute: {
+                // expr.rs: `parent_particle.<name>`; the variable only exists in the init shader of an
+                // effect with a parent (READ_PARENT_PARTICLE, vfx_init.wgsl:166-171)
+                if (s != StreamId::Init)
+                    throw ExprError(ExprError::GraphEvalError, "parent attributes are only available in the init context (vfx_init.wgsl:166-171)");
+                if (e.attribute == Attribute::ID || e.attribute == Attribute::PARTICLE_COUNTER)
+                    throw ExprError(ExprError::GraphEvalError, "pseudo-attributes of the parent particle cannot be read");
+                Loc l;
+                l.type = e.attribute.value_type();
+                l.reg = (uint8_t)alloc_v(l.type.count);
+                emit(s, HNB_OP_LDPARENT, l.reg, 0, 0, 0, l.type.count, true, true, true, (uint32_t)e.attribute.id);
+                note_parent_attr(e.attribute);
+                return l;
+            }
             case Expr::Kind::TextureSample:
                 throw ExprError(ExprError::GraphEvalError, "texture sampling is only available in the render context");
             case Expr::Kind::Unary: return eval_unary(w, e, s);
@@ -641,8 +659,18 @@ class Lowerer {
                 else if (!(s == StreamId::Update && (m.attribute == Attribute::PREV || m.attribute == Attribute::NEXT)))  // never written back by update
                     emit(s, HNB_OP_STA, 0, opnd(v), opnd(v), opnd(v), sl.ncomp, sl.ncomp == 1, true, true, (uint32_t)attr_index_[m.attribute.id]);
             } break;
-            case Modifier::Kind::InheritAttribute:
-                throw ShaderGenerateError("InheritAttributeModifier requires GPU spawn events, which this build does not support yet");
+            case Modifier::Kind::InheritAttribute: {
+                // attr.rs:173-186: particle.A = parent_particle.A;
+                const AttrSlot& sl = slot(m.attribute);
+                touch(s, m.attribute, true);
+                Loc v;
+                v.type = m.attribute.value_type();
+                v.reg = (uint8_t)alloc_v(sl.ncomp);
+                emit(s, HNB_OP_LDPARENT, v.reg, 0, 0, 0, sl.ncomp, true, true, true, (uint32_t)m.attribute.id);
+                note_parent_attr(m.attribute);
+                if (sl.reg != HNB_REG_NONE) emit(s, HNB_OP_M_PIN_SET, sl.reg, opnd(v), opnd(v), opnd(v), sl.ncomp, false, true, true);
+                else emit(s, HNB_OP_STA, 0, opnd(v), opnd(v), opnd(v), sl.ncomp, sl.ncomp == 1, true, true, (uint32_t)attr_index_[m.attribute.id]);
+            } break;
             case Modifier::Kind::SetPositionCircle: {
                 need(s, Attribute::POSITION, "SetPositionCircleModifier");
                 Writer fn{s, {}};
@@ -801,8 +829,18 @@ class Lowerer {
                 touch(s, Attribute::POSITION, false);
                 emit(s, HNB_OP_M_KILL_AABB, 0, opnd(c), opnd(hs), opnd(c), 1, true, true, true, m.kill_inside ? 1u : 0u);
             } break;
-            case Modifier::Kind::EmitSpawnEvent:
-                throw ShaderGenerateError("EmitSpawnEventModifier requires GPU spawn events, which this build does not support yet");
+            case Modifier::Kind::EmitSpawnEvent: {
+                // modifier/mod.rs:669-695: `let count = <expr>;` is evaluated unconditionally, then
+                // `if (is_alive)` / `if (was_alive && !is_alive)` append_spawn_events_<channel>(…, particle_index, count)
+                const Loc cnt = eval(main, m.e[0]);
+                if (cnt.type != ValueType(ScalarType::Uint))
+                    type_error("EmitSpawnEventModifier::count must be an expression of type u32, got " + cnt.type.to_string());
+                if (m.child_index >= HNB_MAX_EVENT_CHANNELS)
+                    throw ShaderGenerateError("EmitSpawnEventModifier::child_index " + std::to_string(m.child_index) + " exceeds the supported event channels");
+                emit(s, HNB_OP_M_EMIT_EVENTS, 0, opnd(cnt), opnd(cnt), opnd(cnt), 1, true, true, true,
+                     m.child_index | (m.condition == EventEmitCondition::OnDie ? 0x100u : 0u));
+                n_event_channels_ = std::max<uint32_t>(n_event_channels_, m.child_index + 1u);
+            } break;
             case Modifier::Kind::Render: break;
         }
         // statement temporaries die here; hoisted rand values of the main writer stay alive
@@ -928,7 +966,10 @@ std::vector<uint8_t> Lowerer::run() {
     h.magic = HNB_PROGRAM_MAGIC;
     h.version = HNB_PROGRAM_VERSION;
     h.capacity = asset_.capacity();
-    h.flags = (asset_.simulation_space == SimulationSpace::Global ? HNB_PROG_GLOBAL_SPACE : 0u) | (has_ribbon ? HNB_PROG_HAS_RIBBONS : 0u);
+    h.flags = (asset_.simulation_space == SimulationSpace::Global ? HNB_PROG_GLOBAL_SPACE : 0u) | (has_ribbon ? HNB_PROG_HAS_RIBBONS : 0u) |
+              (parent_attrs_.empty() ? 0u : HNB_PROG_READS_PARENT) | (n_event_channels_ ? HNB_PROG_EMITS_EVENTS : 0u);
+    h.n_event_channels = n_event_channels_;
+    h.parent_n_attrs = (uint32_t)parent_attrs_.size();
     h.n_attrs = (uint32_t)attrs_.size();
     h.n_props = (uint32_t)mod_.properties().size();
     h.prop_words = prop_words_;
@@ -941,6 +982,7 @@ std::vector<uint8_t> Lowerer::run() {
     uint32_t off = sizeof(HnbProgramHeader);
     h.attrs_off = off; off += h.n_attrs * (uint32_t)sizeof(HnbAttrEntry);
     h.props_off = off; off += h.n_props * (uint32_t)sizeof(HnbPropEntry);
+    h.parent_attrs_off = off; off += h.parent_n_attrs * 4u;
     off = (off + 7u) & ~7u;
     h.uniform_off = off; off += h.uniform_len * 8u;
     h.init_off = off; off += h.init_len * 8u;
@@ -970,6 +1012,7 @@ std::vector<uint8_t> Lowerer::run() {
         for (int c = 0; c < 4; ++c) e.default_bits[c] = p.default_value.bits[c];
         std::memcpy(blob.data() + h.props_off + i * sizeof e, &e, sizeof e);
     }
+    if (h.parent_n_attrs) std::memcpy(blob.data() + h.parent_attrs_off, parent_attrs_.data(), (size_t)h.parent_n_attrs * 4);
     if (h.uniform_len) std::memcpy(blob.data() + h.uniform_off, uni_.code.data(), (size_t)h.uniform_len * 8);
     if (h.init_len) std::memcpy(blob.data() + h.init_off, init_.code.data(), (size_t)h.init_len * 8);
     if (h.update_len) std::memcpy(blob.data() + h.update_off, upd_.code.data(), (size_t)h.update_len * 8);

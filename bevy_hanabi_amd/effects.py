@@ -123,3 +123,64 @@ def ribbon(capacity=1 << 22, rate=None):
     for m in mods:
         asset = asset.init(m)
     return asset.render(h.SizeOverLifetimeModifier()).render(h.ColorOverLifetimeModifier())
+
+
+# ---- the real examples/firework.rs: three linked effects (GPU spawn events) ------------------------------
+
+def firework_rocket(capacity=32, trail_count=5, explosion_count=1000):
+    """create_rocket_effect (examples/firework.rs:36-131): rate(1..3)/s rockets; every alive rocket emits
+    `trail_count` sparkle events per frame on channel 0 and `explosion_count` events on channel 1 when it dies."""
+    w = h.ExprWriter()
+    init_pos = h.SetPositionCircleModifier(w.lit((0.0, 0.0, 0.0)).expr(), w.lit((0.0, 1.0, 0.0)).expr(), w.lit(30.0).expr(), h.ShapeDimension.Volume)
+    zero = w.lit(0.0)
+    y = w.lit(140.0).uniform(w.lit(160.0))
+    init_vel = h.SetAttributeModifier(A.VELOCITY, zero.vec3(y, zero).expr())
+    init_age = h.SetAttributeModifier(A.AGE, w.lit(0.0).expr())
+    rgb = w.rand(h.VectorType.VEC3F) * w.lit(0.9) + w.lit(0.1)
+    init_trails_color = h.SetAttributeModifier(A.U32_0, rgb.vec4_xyz_w(w.lit(1.0)).pack4x8unorm().expr())
+    init_lifetime = h.SetAttributeModifier(A.LIFETIME, w.lit(0.8).uniform(w.lit(1.2)).expr())
+    update_accel = h.AccelModifier(w.lit((-0.0, -16.0, -0.0)).expr())
+    update_drag = h.LinearDragModifier(w.lit(4.0).expr())
+    spawn_trail = h.EmitSpawnEventModifier(h.EventEmitCondition.Always, w.lit(h.Value.u32(trail_count)).expr(), 0)
+    spawn_on_die = h.EmitSpawnEventModifier(h.EventEmitCondition.OnDie, w.lit(h.Value.u32(explosion_count)).expr(), 1)
+    spawner = h.SpawnerSettings.rate(h.CpuValue.Uniform(1.0, 3.0))
+    return (h.EffectAsset(capacity, spawner, w.finish()).with_name("rocket")
+            .init(init_pos).init(init_vel).init(init_age).init(init_lifetime).init(init_trails_color)
+            .update(update_drag).update(update_accel).update(spawn_trail).update(spawn_on_die)
+            .render(h.ColorOverLifetimeModifier()).render(h.SizeOverLifetimeModifier()))
+
+
+def firework_sparkle_trail(capacity=1000):
+    """create_sparkle_trail_effect (examples/firework.rs:135-183): child of the rocket on channel 0."""
+    w = h.ExprWriter()
+    init_pos = h.InheritAttributeModifier(A.POSITION)
+    vel = (w.rand(h.VectorType.VEC3F) * w.lit(2.0) - w.lit(1.0)).normalized() * w.lit(1.0)
+    init_vel = h.SetAttributeModifier(A.VELOCITY, vel.expr())
+    init_age = h.SetAttributeModifier(A.AGE, w.lit(0.0).expr())
+    init_lifetime = h.SetAttributeModifier(A.LIFETIME, w.lit(0.2).expr())
+    update_accel = h.AccelModifier(w.lit((-0.0, -16.0, -0.0)).expr())
+    update_drag = h.LinearDragModifier(w.lit(4.0).expr())
+    return (h.EffectAsset(capacity, h.SpawnerSettings(), w.finish()).with_name("sparkle_trail")
+            .init(init_pos).init(init_vel).init(init_age).init(init_lifetime)
+            .update(update_drag).update(update_accel)
+            .render(h.ColorOverLifetimeModifier()).render(h.SizeOverLifetimeModifier()))
+
+
+def firework_trails_child(capacity=10000):
+    """create_trails_effect (examples/firework.rs:187-251) verbatim: child of the rocket on channel 1,
+    position inherited from the exploding rocket, colour from the rocket's U32_0."""
+    w = h.ExprWriter()
+    init_pos = h.InheritAttributeModifier(A.POSITION)
+    init_color = h.SetAttributeModifier(A.COLOR, w.parent_attr(A.U32_0).expr())
+    center = w.attr(A.POSITION)
+    speed = w.lit(40.0).uniform(w.lit(60.0))
+    direction = w.rand(h.VectorType.VEC3F).mul(w.lit(2.0)).sub(w.lit(1.0)).normalized()
+    init_vel = h.SetAttributeModifier(A.VELOCITY, (center + direction * speed).expr())
+    init_age = h.SetAttributeModifier(A.AGE, w.lit(0.0).expr())
+    init_lifetime = h.SetAttributeModifier(A.LIFETIME, w.lit(0.8).uniform(w.lit(1.2)).expr())
+    update_accel = h.AccelModifier(w.lit((-0.0, -16.0, -0.0)).expr())
+    update_drag = h.LinearDragModifier(w.lit(4.0).expr())
+    return (h.EffectAsset(capacity, h.SpawnerSettings(), w.finish()).with_name("trail")
+            .init(init_pos).init(init_vel).init(init_age).init(init_lifetime).init(init_color)
+            .update(update_drag).update(update_accel)
+            .render(h.ColorOverLifetimeModifier()).render(h.SizeOverLifetimeModifier()).render(h.OrientModifier(h.OrientMode.AlongVelocity)))

@@ -197,6 +197,12 @@ class Effect:
             self._h = None
             self._prog._effects.remove(self)
 
+    def set_parent(self, parent, channel, event_capacity=256):
+        """EffectParent: this effect's init consumes the spawn events `parent` appends on `channel`
+        (EmitSpawnEventModifier.child_index). 256 events per frame is the reference's hard-coded capacity."""
+        _check(self._lib.hnb_effect_set_parent(self._h, parent._h, int(channel), int(event_capacity)))
+        self._parent = parent
+
     def set_frame(self, spawn_count, seed, transform=None):
         xf = None
         if transform is not None:

@@ -85,6 +85,7 @@ typedef enum HnbScalarType { HNB_BOOL = 0, HNB_F32 = 1, HNB_I32 = 2, HNB_U32 = 3
  * registers; an operand with its bcast bit set is a scalar broadcast.                  */
 #define HNB_VM_MAX_REGS 32u    /* V registers per particle */
 #define HNB_VM_MAX_UREGS 128u  /* U registers per instance */
+#define HNB_MAX_EVENT_CHANNELS 4u /* child event channels per parent effect (EmitSpawnEventModifier::child_index < 4) */
 #define HNB_OPERAND_U 0x80u
 
 typedef enum HnbOp {
@@ -97,7 +98,7 @@ typedef enum HnbOp {
     HNB_OP_LDID,     /* dst = particle_index (slot + slot_base) — Attribute::ID, expr.rs:1353-1360 */
     HNB_OP_LDPC,     /* dst = particle_counter — Attribute::PARTICLE_COUNTER, expr.rs:1361-1363 */
     HNB_OP_LDALIVE,  /* dst = is_alive (bool) — BuiltInOperator::IsAlive */
-    HNB_OP_LDPARENT, /* dst[..w] = parent particle attribute (plane index in aux) */
+    HNB_OP_LDPARENT, /* dst[..w] = parent_particle.<HnbAttr aux>: init stream of an effect with a parent (vfx_init.wgsl:166-171) */
     HNB_OP_LDA,      /* dst[..w] = particle.<attribute table entry aux> (non-pinned attributes live in memory) */
     HNB_OP_STA,      /* particle.<attribute table entry aux> = r[a..a+w] */
     HNB_OP_MOV,
@@ -153,7 +154,8 @@ typedef enum HnbOp {
     HNB_OP_M_VEL_CIRCLE,     /* a: center[3] axis[3] speed[1]                              (modifier/velocity.rs:45-80) */
     HNB_OP_M_VEL_TANGENT,    /* a: origin[3] axis[3] speed[1]                              (modifier/velocity.rs:188-223) */
     HNB_OP_M_ADD_XLATE,      /* position += transform[3].xyz (SimulationSpace::Global, src/lib.rs:518-531) */
-    HNB_OP_M_EMIT_EVENTS,    /* append r[a] spawn events to child channel aux (src/lib.rs:976-993) */
+    HNB_OP_M_EMIT_EVENTS,    /* EmitSpawnEventModifier (modifier/mod.rs:653-717): if (aux&0x100 ? was_alive && !is_alive : is_alive)
+                              * append r[a] (u32) spawn events to child channel aux&0xff (append_spawn_events_N, src/lib.rs:976-993) */
     HNB_OP_COUNT
 } HnbOp;
 
@@ -169,7 +171,7 @@ typedef enum HnbOp {
 /* Program flags */
 #define HNB_PROG_GLOBAL_SPACE 0x1u      /* informational: init stream ends with M_ADD_XLATE */
 #define HNB_PROG_HAS_RIBBONS 0x2u       /* layout contains RIBBON_ID (post-update sort stage) */
-#define HNB_PROG_CONSUMES_EVENTS 0x4u   /* init is driven by GPU spawn events, not the CPU spawner */
+#define HNB_PROG_READS_PARENT 0x4u      /* init stream uses HNB_OP_LDPARENT: instances need hnb_effect_set_parent() */
 #define HNB_PROG_EMITS_EVENTS 0x8u
 
 /* Per-attribute update flags */
@@ -207,7 +209,7 @@ typedef struct HnbProgramHeader {
     uint32_t init_regs, update_regs;             /* highest V register used + 1 */
     uint32_t attrs_off, props_off, uniform_off, init_off, update_off; /* byte offsets from blob start */
     uint32_t n_event_channels;  /* number of child event channels this program appends to */
-    uint32_t parent_n_attrs;    /* for HNB_PROG_CONSUMES_EVENTS: parent attribute table follows props */
+    uint32_t parent_n_attrs;    /* HNB_PROG_READS_PARENT: u32 HnbAttr ids read from the parent particle, at parent_attrs_off */
     uint32_t parent_attrs_off;
     uint32_t reserved[2];
 } HnbProgramHeader;
@@ -269,7 +271,11 @@ int hnb_program_validate(const void* blob, size_t blob_size);
  * capacity slab of a larger logical effect reproduces the single-GPU result. */
 int hnb_effect_create(HnbProgram* prog, uint32_t slot_base, HnbEffect** out_fx);
 int hnb_effect_destroy(HnbEffect* fx);
-/* Parent -> child link for GPU spawn events (EffectParent, src/render/event.rs). */
+/* EffectParent (src/render/event.rs, vfx_init.wgsl:123-129,166-171): `child`'s init pass consumes the spawn
+ * events `parent`'s update appends on `channel` (EmitSpawnEventModifier::child_index; the N-th child reads
+ * channel N), one frame later, and may read the emitting parent particle (InheritAttributeModifier,
+ * parent_attr). `event_capacity` = arrayLength(&event_buffer.spawn_events): events past it in a frame are
+ * dropped; the reference hard-codes 256 (src/render/event.rs:267). Both effects must share a context. */
 int hnb_effect_set_parent(HnbEffect* child, HnbEffect* parent, uint32_t channel, uint32_t event_capacity);
 
 /* Per-frame inputs (ExtractSchedule data, src/render/mod.rs:2670-2691,4437-4445):

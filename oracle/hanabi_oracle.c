@@ -83,7 +83,8 @@ typedef struct {
     uint8_t* side_effect; /* per expression */
 } Asset;
 
-typedef struct {
+#define MAX_CHANNELS 4
+typedef struct Effect_ {
     Asset* asset;
     uint32_t slot_base;
     void* plane[N_ATTRS];        /* packed SoA planes, capacity * count * 4 bytes */
@@ -93,6 +94,12 @@ typedef struct {
     uint32_t props[256];
     char error[256];
     int failed;
+    /* GPU spawn events (src/render/event.rs, src/lib.rs:976-993, vfx_init.wgsl:123-129,166-171) */
+    struct Effect_* parent;                 /* EffectParent: this effect's init consumes the parent's events */
+    uint32_t parent_channel;                /* the N-th child of a parent reads channel N */
+    uint32_t ev_capacity[MAX_CHANNELS];     /* arrayLength(&event_buffer_N.spawn_events); 256 in the reference (event.rs:267) */
+    uint32_t* ev_data[MAX_CHANNELS];        /* spawn_events[i].particle_index */
+    uint32_t ev_count[MAX_CHANNELS];        /* GpuChildInfo::event_count (keeps growing past the capacity) */
 } Effect;
 
 static char g_err[512];
@@ -161,6 +168,7 @@ void hor_effect_free(Effect* fx) {
     if (!fx) return;
     for (int i = 0; i < N_ATTRS; ++i) free(fx->plane[i]);
     free(fx->list[0]); free(fx->list[1]); free(fx->dead);
+    for (int i = 0; i < MAX_CHANNELS; ++i) free(fx->ev_data[i]);
     free(fx);
 }
 /* Slab initial state: dead_index[i] = i, alive_count = 0, max_spawn = capacity, write index 0
@@ -210,6 +218,9 @@ typedef struct {
     uint32_t particle_counter;
     int is_init;
     int is_alive;
+    int was_alive;            /* AGE_CODE (src/lib.rs:1226-1233) */
+    const Particle* parent;   /* parent_particle (READ_PARENT_PARTICLE), init of a child effect only */
+    uint32_t ev[MAX_CHANNELS];/* events appended by this thread, per channel (all carry particle_index) */
     const float* sim;         /* [6] */
     const float* xf;          /* [12] row-major 3x4 */
     int failed;
@@ -375,6 +386,11 @@ static Val eval_node(Ctx* c, Memo* memo, const ExprRec* e) {
                 Val v = mk(T_U32, 1); v.b[0] = c->particle_counter; return v;
             }
             return c->p->v[e->attr];
+        }
+        case EK_PARENT_ATTRIBUTE: { /* `parent_particle.<name>` */
+            if (!c->is_init || !c->parent) { fail(c, "parent_particle is only defined in the init shader of an effect with a parent"); return mkf(0); }
+            if (e->attr == A_ID || e->attr == A_PARTICLE_COUNTER) { fail(c, "pseudo-attribute of the parent particle"); return mkf(0); }
+            return c->parent->v[e->attr];
         }
         case EK_UNARY: {
             Val x = eval(c, memo, e->a);
@@ -759,8 +775,19 @@ static void apply_modifier(Ctx* c, Memo* main, const ModRec* m) {
             }
             if ((m->flags & 4u) ? all_in : any_out) c->is_alive = 0;
         } break;
+        case MK_INHERIT_ATTRIBUTE: /* attr.rs:173-186: particle.A = parent_particle.A; */
+            if (!c->is_init || !c->parent) { fail(c, "InheritAttributeModifier needs a parent effect"); break; }
+            p->v[m->attr] = c->parent->v[m->attr];
+            break;
+        case MK_EMIT_SPAWN_EVENT: { /* modifier/mod.rs:669-695 */
+            Val cnt = eval(c, main, m->e[0]);          /* `let count = <expr>;` evaluated unconditionally */
+            if (cnt.elem != T_U32 || cnt.count != 1) { fail(c, "EmitSpawnEventModifier count must be u32"); break; }
+            if (m->child_index >= MAX_CHANNELS) { fail(c, "event channel out of range"); break; }
+            const int fire = m->condition == 1 ? (c->was_alive && !c->is_alive) : c->is_alive;  /* OnDie : Always */
+            if (fire) c->ev[m->child_index] += cnt.b[0];
+        } break;
         case MK_RENDER: break;
-        default: fail(c, "modifier requires GPU spawn events (not supported)"); break;
+        default: fail(c, "unknown modifier"); break;
     }
 }
 
@@ -778,17 +805,54 @@ static void store_particle(Effect* fx, uint32_t slot, const Particle* p, int ski
     }
 }
 
-/* One frame: init -> indirect -> update, threads executed serially in increasing id. */
-int hor_effect_step(Effect* fx, const float* sim, uint32_t spawn_count, uint32_t seed, const float* xf) {
-    static const float identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    Asset* a = fx->asset;
-    if (!xf) xf = identity;
-    if (!a->in_layout[A_POSITION]) { snprintf(fx->error, sizeof fx->error, "missing POSITION attribute"); return -1; }
-    const int has_age = a->in_layout[A_AGE], has_life = a->in_layout[A_LIFETIME];
-    if (has_age && !has_life) { snprintf(fx->error, sizeof fx->error, "AGE without LIFETIME: reference update shader does not compile"); return -1; }
-    int failed = 0;
+static const float k_identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
 
-    /* ---- vfx_init.wgsl:101-196 ---- */
+static int check_layout(Effect* fx) {
+    Asset* a = fx->asset;
+    if (!a->in_layout[A_POSITION]) { snprintf(fx->error, sizeof fx->error, "missing POSITION attribute"); return -1; }
+    if (a->in_layout[A_AGE] && !a->in_layout[A_LIFETIME]) {
+        snprintf(fx->error, sizeof fx->error, "AGE without LIFETIME: reference update shader does not compile");
+        return -1;
+    }
+    return 0;
+}
+
+/* EffectParent: `child`'s init pass consumes the spawn events `parent` appends to `channel`
+ * (the N-th child of a parent reads channel N). event_capacity = arrayLength(&event_buffer.spawn_events);
+ * the reference hard-codes 256 (src/render/event.rs:267). */
+int hor_effect_set_parent(Effect* child, Effect* parent, uint32_t channel, uint32_t event_capacity) {
+    if (!child || !parent || channel >= MAX_CHANNELS || event_capacity == 0) return -1;
+    child->parent = parent;
+    child->parent_channel = channel;
+    free(parent->ev_data[channel]);
+    parent->ev_data[channel] = (uint32_t*)calloc(event_capacity, 4);
+    parent->ev_capacity[channel] = event_capacity;
+    parent->ev_count[channel] = 0;
+    return 0;
+}
+uint32_t hor_effect_event_count(const Effect* fx, uint32_t channel) { return channel < MAX_CHANNELS ? fx->ev_count[channel] : 0; }
+void hor_effect_read_events(const Effect* fx, uint32_t channel, uint32_t* dst) {
+    if (channel >= MAX_CHANNELS || !fx->ev_data[channel]) return;
+    const uint32_t n = fx->ev_count[channel] < fx->ev_capacity[channel] ? fx->ev_count[channel] : fx->ev_capacity[channel];
+    memcpy(dst, fx->ev_data[channel], (size_t)n * 4);
+}
+
+/* ---- init pass (vfx_init.wgsl:101-196), threads executed serially in increasing id ----
+ * CPU-spawned: `spawn_count` threads survive the caps. With a parent (CONSUME_GPU_SPAWN_EVENTS): one thread per
+ * spawn event the parent appended during ITS previous update; `spawn_count` is ignored. Reading an event past the
+ * buffer capacity is out of bounds in the reference (event_count keeps growing past it): clamped here. */
+int hor_effect_init_pass(Effect* fx, const float* sim, uint32_t spawn_count, uint32_t seed, const float* xf) {
+    Asset* a = fx->asset;
+    if (!xf) xf = k_identity;
+    if (check_layout(fx)) return -1;
+    int failed = 0;
+    const Effect* par = fx->parent;
+    const uint32_t* events = NULL;
+    if (par) {
+        const uint32_t ch = fx->parent_channel;
+        spawn_count = par->ev_count[ch] < par->ev_capacity[ch] ? par->ev_count[ch] : par->ev_capacity[ch];
+        events = par->ev_data[ch];
+    }
     const uint32_t alive0 = fx->alive_count;
     const uint32_t max_spawn = fx->max_spawn;                 /* constant during the pass */
     const uint32_t wi = fx->write_index;
@@ -800,13 +864,21 @@ int hor_effect_step(Effect* fx, const float* sim, uint32_t spawn_count, uint32_t
         Particle p;
         for (int k = 0; k < N_ATTRS; ++k) p.v[k] = mk(k_attr[k].elem, k_attr[k].count); /* var particle = Particle(); */
         char err[256];
-        Ctx c = {fx, &p, 0, slot + fx->slot_base, fx->particle_counter + i, 1, 1, sim, xf, 0, err};
+        Ctx c;
+        memset(&c, 0, sizeof c);
+        c.fx = fx; c.p = &p; c.particle_index = slot + fx->slot_base; c.particle_counter = fx->particle_counter + i;
+        c.is_init = 1; c.is_alive = 1; c.was_alive = 1; c.sim = sim; c.xf = xf; c.err = err;
         c.seed = pcg_hash(c.particle_index ^ seed);
+        Particle parent_particle;
+        if (par) {                                            /* vfx_init.wgsl:166-171 */
+            load_particle(par, events[i], &parent_particle);
+            c.parent = &parent_particle;
+        }
         MEMO_ON_STACK(main, a->n_exprs);
         for (uint32_t k = 0; k < a->n_init; ++k) apply_modifier(&c, main, &a->init[k]);
         if (fx->plane[A_PREV]) p.v[A_PREV].b[0] = 0xffffffffu;
         if (fx->plane[A_NEXT]) p.v[A_NEXT].b[0] = 0xffffffffu;
-        if (a->sim_space == 0) /* Global: particle.position += transform[3].xyz; */
+        if (a->sim_space == 0 && !par) /* Global, CPU-spawned only: particle.position += transform[3].xyz; (vfx_init.wgsl:183-189) */
             for (int k = 0; k < 3; ++k) sf(&p.v[A_POSITION], k, vf(&p.v[A_POSITION], k) + xf[4 * k + 3]);
         fx->list[wi][alive_index] = slot;
         store_particle(fx, slot, &p, 0);
@@ -819,17 +891,30 @@ int hor_effect_step(Effect* fx, const float* sim, uint32_t spawn_count, uint32_t
     fx->alive_count = alive0 + n_spawn;
     fx->particle_counter += n_spawn;
     fx->spawned = n_spawn;
+    fx->failed |= failed;
+    return failed ? -1 : 0;
+}
 
-    /* ---- vfx_indirect.wgsl:57-85 ---- */
+/* ---- indirect (vfx_indirect.wgsl:38-85) + update (vfx_update.wgsl:105-167) ---- */
+int hor_effect_update_pass(Effect* fx, const float* sim, uint32_t seed, const float* xf) {
+    Asset* a = fx->asset;
+    if (!xf) xf = k_identity;
+    if (check_layout(fx)) return -1;
+    const int has_age = a->in_layout[A_AGE];
+    int failed = 0;
+
+    /* vfx_indirect.wgsl:38-46: the events of the previous frame have been consumed by the children's init */
+    for (int ch = 0; ch < MAX_CHANNELS; ++ch) fx->ev_count[ch] = 0;
+    /* vfx_indirect.wgsl:57-85 */
     fx->instance_count = 0;
     fx->max_update = fx->alive_count;
     fx->max_spawn = a->capacity - fx->alive_count;
     fx->write_index = 1u - fx->write_index;
 
-    /* ---- vfx_update.wgsl:105-167 ---- */
     const uint32_t n = fx->max_update;
     const uint32_t write_index = fx->write_index, read_index = 1u - write_index;
     uint8_t* alive_flag = (uint8_t*)malloc(n ? n : 1);
+    uint32_t* ev = (uint32_t*)calloc((size_t)(n ? n : 1) * MAX_CHANNELS, 4);
     const int euler = a->motion_integration != 0 && a->in_layout[A_POSITION] && a->in_layout[A_VELOCITY];
 #pragma omp parallel for schedule(static) reduction(| : failed)
     for (uint32_t i = 0; i < n; ++i) {
@@ -837,10 +922,13 @@ int hor_effect_step(Effect* fx, const float* sim, uint32_t spawn_count, uint32_t
         Particle p;
         load_particle(fx, slot, &p);
         char err[256];
-        Ctx c = {fx, &p, 0, slot + fx->slot_base, 0, 0, 1, sim, xf, 0, err};
+        Ctx c;
+        memset(&c, 0, sizeof c);
+        c.fx = fx; c.p = &p; c.particle_index = slot + fx->slot_base; c.is_alive = 1; c.was_alive = 1; c.sim = sim; c.xf = xf; c.err = err;
         c.seed = pcg_hash(c.particle_index ^ seed);
         /* AGE_CODE / REAP_CODE (lib.rs:1223-1258) */
         if (has_age) {
+            c.was_alive = vf(&p.v[A_AGE], 0) < vf(&p.v[A_LIFETIME], 0);
             sf(&p.v[A_AGE], 0, vf(&p.v[A_AGE], 0) + sim[1]);
             c.is_alive = vf(&p.v[A_AGE], 0) < vf(&p.v[A_LIFETIME], 0);
             c.is_alive = c.is_alive && (vf(&p.v[A_AGE], 0) < vf(&p.v[A_LIFETIME], 0));
@@ -853,15 +941,26 @@ int hor_effect_step(Effect* fx, const float* sim, uint32_t spawn_count, uint32_t
             for (int k = 0; k < 3; ++k) sf(&p.v[A_POSITION], k, vf(&p.v[A_POSITION], k) + vf(&p.v[A_VELOCITY], k) * sim[1]);
         store_particle(fx, slot, &p, 1);
         alive_flag[i] = (uint8_t)c.is_alive;
+        for (int ch = 0; ch < MAX_CHANNELS; ++ch) ev[(size_t)i * MAX_CHANNELS + ch] = c.ev[ch];
         if (c.failed) {
             failed |= 1;
 #pragma omp critical
             snprintf(fx->error, sizeof fx->error, "%s", err);
         }
     }
-    /* list rebuild, serial thread order (vfx_update.wgsl:148-166) */
+    /* list rebuild and event append, serial thread order (vfx_update.wgsl:148-166, src/lib.rs:976-993) */
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t slot = fx->list[read_index][i];
+        for (int ch = 0; ch < MAX_CHANNELS; ++ch) {
+            const uint32_t count = ev[(size_t)i * MAX_CHANNELS + ch];
+            if (count == 0u) continue;
+            const uint32_t capacity = fx->ev_capacity[ch];                  /* no consumer bound: capacity 0, nothing stored */
+            const uint32_t prev = fx->ev_count[ch];                         /* atomicAdd(event_count, count) */
+            fx->ev_count[ch] = prev + count;
+            const uint32_t base = prev < capacity ? prev : capacity;
+            const uint32_t capped = count < capacity - base ? count : capacity - base;
+            for (uint32_t k = 0; k < capped; ++k) fx->ev_data[ch][base + k] = slot;   /* particle_index (slab-relative) */
+        }
         if (!alive_flag[i]) {
             const uint32_t alive_index = --fx->alive_count;   /* atomicSub(alive_count, 1) - 1 */
             fx->dead[alive_index] = slot;
@@ -871,9 +970,17 @@ int hor_effect_step(Effect* fx, const float* sim, uint32_t spawn_count, uint32_t
         }
     }
     free(alive_flag);
+    free(ev);
     fx->dead_count = n - fx->alive_count;
     fx->failed |= failed;
     return failed ? -1 : 0;
+}
+
+/* One frame of a stand-alone effect: init -> indirect -> update. Systems with parent/child links run
+ * every effect's init pass (parents first), then every effect's update pass (src/render/mod.rs:6975-7370). */
+int hor_effect_step(Effect* fx, const float* sim, uint32_t spawn_count, uint32_t seed, const float* xf) {
+    if (hor_effect_init_pass(fx, sim, spawn_count, seed, xf)) return -1;
+    return hor_effect_update_pass(fx, sim, seed, xf);
 }
 
 /* ---- readback ---------------------------------------------------------------------------------- */
@@ -1010,7 +1117,9 @@ float hor_to_float01(uint32_t u) { return to_float01(u); }
 void hor_frand_kat(uint32_t seed_in, uint32_t* state_out, float* out4, int which) {
     Effect fake; memset(&fake, 0, sizeof fake);
     char err[256];
-    Ctx c = {&fake, NULL, seed_in, 0, 0, 1, 1, NULL, NULL, 0, err};
+    Ctx c;
+    memset(&c, 0, sizeof c);
+    c.fx = &fake; c.seed = seed_in; c.is_init = 1; c.is_alive = 1; c.err = err;
     if (which == 1) { out4[0] = frand(&c); }
     else { Val v = frand_n(&c, which); for (int i = 0; i < which; ++i) out4[i] = vf(&v, i); }
     *state_out = c.seed;

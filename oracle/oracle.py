@@ -39,6 +39,12 @@ def _lib(omp=False):
         lib.hor_effect_free.argtypes = [C.c_void_p]
         lib.hor_effect_set_property.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32]
         lib.hor_effect_step.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.hor_effect_init_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.hor_effect_update_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.hor_effect_set_parent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.hor_effect_event_count.restype = C.c_uint32
+        lib.hor_effect_event_count.argtypes = [C.c_void_p, C.c_uint32]
+        lib.hor_effect_read_events.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         lib.hor_effect_alive_count.restype = C.c_uint32
         lib.hor_effect_alive_count.argtypes = [C.c_void_p]
         lib.hor_effect_counters.argtypes = [C.c_void_p, C.c_void_p]
@@ -105,6 +111,35 @@ class OracleEffect:
                                        None if xf is None else xf.ctypes.data)
         if rc != 0:
             raise OracleError(self._lib.hor_effect_error(self._fx).decode())
+
+    def _args(self, dt, time, transform, sim):
+        s = np.array(sim if sim is not None else [time, dt, time, dt, time, dt], dtype=np.float32)
+        xf = None if transform is None else np.ascontiguousarray(np.asarray(transform, dtype=np.float32).reshape(12))
+        return s, xf
+
+    def init_pass(self, dt, spawn_count, seed, time=0.0, transform=None, sim=None):
+        """vfx_init only. Systems with parent/child links run every init pass (parents first), then every update pass."""
+        s, xf = self._args(dt, time, transform, sim)
+        if self._lib.hor_effect_init_pass(self._fx, s.ctypes.data, int(spawn_count), int(seed) & 0xFFFFFFFF, None if xf is None else xf.ctypes.data):
+            raise OracleError(self._lib.hor_effect_error(self._fx).decode())
+
+    def update_pass(self, dt, seed, time=0.0, transform=None, sim=None):
+        s, xf = self._args(dt, time, transform, sim)
+        if self._lib.hor_effect_update_pass(self._fx, s.ctypes.data, int(seed) & 0xFFFFFFFF, None if xf is None else xf.ctypes.data):
+            raise OracleError(self._lib.hor_effect_error(self._fx).decode())
+
+    def set_parent(self, parent, channel, event_capacity=256):
+        """EffectParent: this effect's init consumes the spawn events `parent` appends to `channel`."""
+        if self._lib.hor_effect_set_parent(self._fx, parent._fx, int(channel), int(event_capacity)):
+            raise OracleError("set_parent failed")
+        self._parent = parent  # keep alive
+
+    def events(self, channel):
+        """(event_count, stored particle indices) of one of this effect's child channels."""
+        n = int(self._lib.hor_effect_event_count(self._fx, int(channel)))
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        self._lib.hor_effect_read_events(self._fx, int(channel), out.ctypes.data)
+        return n, out
 
     def alive_count(self):
         return int(self._lib.hor_effect_alive_count(self._fx))

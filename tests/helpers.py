@@ -174,3 +174,77 @@ def run_script(runner, frames, check_against=None, every=1):
             if (i + 1) % every == 0 or i == len(frames) - 1:
                 assert_same_state(check_against.state(), runner.state(), f"frame {i}")
     return runner.state()
+
+
+# ---- systems of linked effects (GPU spawn events) ---------------------------------------------------------
+class EffectSpec:
+    """One effect of a system: asset, optional parent (index into the system), event channel and capacity."""
+
+    def __init__(self, asset, parent=None, channel=0, event_capacity=256):
+        self.asset, self.parent, self.channel, self.event_capacity = asset, parent, channel, event_capacity
+
+
+class OracleSystem:
+    name = "oracle"
+
+    def __init__(self, specs, omp=False):
+        self.specs = specs
+        self.fx = [oracle.OracleEffect(bh.serialize_asset(s.asset), omp=omp) for s in specs]
+        for s, fx in zip(specs, self.fx):
+            if s.parent is not None:
+                fx.set_parent(self.fx[s.parent], s.channel, s.event_capacity)
+
+    def step(self, frames):
+        """frames: one Frame per effect. Every init pass (parents first: list order), then every update pass."""
+        for fx, fr in zip(self.fx, frames):
+            for k, v in fr.props.items():
+                fx.set_property(k, v)
+            fx.init_pass(fr.dt, fr.spawn, fr.seed, time=fr.time, transform=fr.transform)
+        for fx, fr in zip(self.fx, frames):
+            fx.update_pass(fr.dt, fr.seed, time=fr.time, transform=fr.transform)
+
+    def state(self):
+        out = []
+        for s, fx in zip(self.specs, self.fx):
+            out.append({"counters": fx.counters(), "alive": fx.alive_list(), "dead": fx.dead_list(),
+                        "attrs": {a.name: fx.read_attr(a.id).view(np.uint32) for a in stored_attrs(s.asset)}})
+        return out
+
+
+class GpuSystem:
+    name = "gpu"
+
+    def __init__(self, specs, ctx):
+        self.specs, self.ctx = specs, ctx
+        self.progs = [ctx.create_program(bh.lower(s.asset)) for s in specs]
+        self.fx = [p.create_effect() for p in self.progs]
+        for s, fx in zip(specs, self.fx):
+            if s.parent is not None:
+                fx.set_parent(self.fx[s.parent], s.channel, s.event_capacity)
+
+    def step(self, frames):
+        self.ctx.frame_begin(frames[0].dt, frames[0].time)
+        for fx, fr in zip(self.fx, frames):
+            for k, v in fr.props.items():
+                fx.set_property(k, v)
+            fx.set_frame(fr.spawn, fr.seed, fr.transform)
+        self.ctx.simulate()
+
+    def state(self):
+        keys = ["capacity", "alive_count", "max_update", "max_spawn", "indirect_write_index", "particle_counter", "instance_count", "dead_count"]
+        out = []
+        for s, fx in zip(self.specs, self.fx):
+            m = fx.metadata()
+            out.append({"counters": {k: m[k] for k in keys}, "alive": fx.alive_list(), "dead": fx.dead_list(),
+                        "attrs": {a.name: fx.read_attr(a.id).view(np.uint32) for a in stored_attrs(s.asset)}})
+        return out
+
+    def destroy(self):
+        for p in self.progs:
+            p.destroy()
+
+
+def assert_same_system_state(ref, got, what=""):
+    assert len(ref) == len(got)
+    for i, (r, g) in enumerate(zip(ref, got)):
+        assert_same_state(r, g, f"{what} effect #{i}")
