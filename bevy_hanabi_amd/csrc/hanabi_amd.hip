@@ -18,6 +18,7 @@
 
 #include "hnb_kernels.hip.h"
 #include "hnb_jit.h"
+#include "hnb_sort.hip.h"
 
 using namespace hnb;
 
@@ -126,6 +127,8 @@ struct HnbProgram {
     uint32_t table_cap = 0;
     uint64_t* d_inst_base = nullptr;
     DevMeta* d_meta[2] = {nullptr, nullptr};
+    bool has_ribbons = false;             // layout has RIBBON_ID: the alive list is sorted after every update (hnb_sort.hip.h)
+    SortArgs sort{};                      // slab offsets of the sort scratch
     uint32_t* d_plane_by_attr = nullptr;  // [HNB_ATTR_COUNT] plane offsets by attribute id (children read parent particles through it)
     std::vector<uint32_t> parent_attrs;   // attribute ids the init stream reads from the parent particle
     uint32_t* d_ev_totals = nullptr;      // [table_cap * chunks_per_inst][HNB_MAX_EVENT_CHANNELS] (emitting programs)
@@ -575,6 +578,22 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
         for (uint32_t c = 0; c < h.n_event_channels; ++c) { d.ev_cnt_off[c] = (uint32_t)off; off += list_bytes; }
         if (off > 0xffffffffull) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB"); }
     }
+    p->has_ribbons = (h.flags & HNB_PROG_HAS_RIBBONS) != 0;
+    if (p->has_ribbons) {  // radix-sort scratch: 64-bit keys and values ping-pong, per-chunk digit histograms, key OR/AND
+        SortArgs& so = p->sort;
+        so.capacity = h.capacity; so.chunks_per_inst = d.chunks_per_inst;
+        so.alive_off[0] = d.alive_off[0]; so.alive_off[1] = d.alive_off[1];
+        for (int i = 0; i < 2; ++i) { so.key_off[i] = (uint32_t)off; off += align_up((size_t)h.capacity * 8, 256); }
+        for (int i = 0; i < 2; ++i) { so.val_off[i] = (uint32_t)off; off += list_bytes; }
+        so.hist_off = (uint32_t)off; off += align_up((size_t)256 * d.chunks_per_inst * 4, 256);
+        so.bits_off = (uint32_t)off; off += 256;
+        so.rid_plane = so.age_plane = kNoPlane;
+        for (uint32_t i = 0; i < h.n_attrs; ++i) {
+            if (p->attrs[i].attr == HNB_ATTR_RIBBON_ID) so.rid_plane = d.attrs[i].plane_off;
+            if (p->attrs[i].attr == HNB_ATTR_AGE) so.age_plane = d.attrs[i].plane_off;
+        }
+        if (off > 0xffffffffull) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB"); }
+    }
     p->slab_bytes = off;
     p->parent_attrs.resize(h.parent_n_attrs);
     if (h.parent_n_attrs) memcpy(p->parent_attrs.data(), b + h.parent_attrs_off, (size_t)h.parent_n_attrs * 4);
@@ -666,6 +685,10 @@ int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
                                                               reinterpret_cast<uint32_t*>(base + p->dev.alive_off[1]), cap);
     // Attribute planes start zeroed (the reference pre-fills with 0xFF only in debug builds).
     HIP_TRY(hipMemsetAsync(base + p->dev.attrs[0].plane_off, 0, p->slab_bytes - p->dev.attrs[0].plane_off, ctx->stream));
+    if (p->has_ribbons) {  // {OR, AND} accumulators of the sort keys, both frame parities
+        const uint64_t bits[4] = {0ull, ~0ull, 0ull, ~0ull};
+        HIP_TRY(hipMemcpyAsync(base + p->sort.bits_off, bits, sizeof bits, hipMemcpyHostToDevice, ctx->stream));
+    }
     // alive_count = 0, max_spawn = capacity, indirect_write_index = 0 (src/render/mod.rs:6048-6070)
     DevMeta m{};
     uint64_t slab_addr = reinterpret_cast<uint64_t>(fx->slab);
@@ -914,6 +937,18 @@ int hnb_simulate(HnbContext* ctx) {
         ca.alive_off[0] = p->dev.alive_off[0]; ca.alive_off[1] = p->dev.alive_off[1]; ca.dead_off = p->dev.dead_off;
         k_compact<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
         if (timed) { tc.a = tu.b; hipEventRecord(tc.b, ctx->stream); ctx->t_compact.push_back(tc); }
+        if (p->has_ribbons) {  // ribbon sort of the compacted list by (RIBBON_ID, AGE) (src/render/mod.rs:7372-7612)
+            SortArgs so = p->sort;
+            so.parity = ctx->frame & 1u;
+            const DevMeta* mo = p->d_meta[par ^ 1];
+            k_sort_fill<<<total_chunks, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+            for (uint32_t pass = 0; pass < 8; ++pass) {
+                k_sort_hist<<<total_chunks, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
+                k_sort_scan<<<n, 256 * kScanGroups, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
+                k_sort_scatter<<<total_chunks, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
+            }
+            k_sort_copy<<<total_chunks, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(p->kernels_done[par], ctx->stream));
         p->parity ^= 1u;
@@ -1002,8 +1037,12 @@ int hnb_effect_read_dead_list(HnbEffect* fx, uint32_t* dst, size_t dst_count) {
     return HNB_OK;
 }
 
-int hnb_effect_sort_ribbons(HnbEffect*) {
-    return fail(HNB_ERR_INVALID_ARG, "ribbon sort is not implemented yet (SURVEY.md §8f-2)");
+int hnb_effect_sort_ribbons(HnbEffect* fx) {
+    if (!fx) return fail(HNB_ERR_INVALID_ARG, "fx is NULL");
+    if (!fx->prog->has_ribbons) return fail(HNB_ERR_INVALID_ARG, "the particle layout has no RIBBON_ID attribute: nothing to sort");
+    // hnb_simulate sorts ribbon effects after every update, as the reference does (src/render/mod.rs:7372-7612):
+    // the list read by hnb_effect_read_alive_list is already in (RIBBON_ID, AGE) order.
+    return HNB_OK;
 }
 
 int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {

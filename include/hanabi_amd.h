@@ -304,8 +304,9 @@ int hnb_effect_read_dead_list(HnbEffect* fx, uint32_t* dst, size_t dst_count);
 /* Overwrite an attribute plane / force counters (tests and state restore). */
 int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t src_size);
 
-/* Ribbon post-update sort by (RIBBON_ID, AGE bits) ascending (src/render/mod.rs:7372-7612,
- * vfx_sort*.wgsl); rewrites the alive list column the renderer reads. */
+/* Ribbon sort by (RIBBON_ID, AGE bits) ascending, stable (vfx_sort*.wgsl, src/render/mod.rs:7372-7612).
+ * hnb_simulate runs it after the update of every effect whose layout has RIBBON_ID, like the reference;
+ * this entry point only reports whether the effect is such an effect (OK) or not (INVALID_ARG). */
 int hnb_effect_sort_ribbons(HnbEffect* fx);
 
 /* Which kernels run this program, as text: "init=jit|interp|none update=aot-stream:<name>|jit-stream|

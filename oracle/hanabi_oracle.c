@@ -895,6 +895,38 @@ int hor_effect_init_pass(Effect* fx, const float* sim, uint32_t spawn_count, uin
     return failed ? -1 : 0;
 }
 
+/* ---- ribbon sort (vfx_sort_fill.wgsl, vfx_sort.wgsl, vfx_sort_copy.wgsl; scheduled after the update pass for
+ * effects whose layout has RIBBON_ID, src/render/mod.rs:4599-4618,7372-7612) ----
+ * fill: pairs[i] = {key = RIBBON_ID, key2 = AGE bits, value = particle_index} in alive-list order of the column the
+ * update just wrote (atomicAdd order == thread order under serial execution); sort: insertion sort that moves an
+ * element only past STRICTLY greater ones, i.e. a stable ascending sort by (key, key2); copy: values back into the
+ * same column. Restated as a stable merge sort (same result, O(n log n)). Without AGE the reference reads key2 out
+ * of bounds (sort_key2_offset = u32::MAX, mod.rs:6042-6046): taken as 0 here. */
+typedef struct { uint32_t key, key2, value; } SortPair;
+static int pair_greater(const SortPair* x, const SortPair* y) { return x->key > y->key || (x->key == y->key && x->key2 > y->key2); }
+static void sort_ribbons(Effect* fx) {
+    const uint32_t n = fx->alive_count;
+    if (n < 2) return;
+    uint32_t* col = fx->list[fx->write_index];
+    SortPair* a = (SortPair*)malloc((size_t)n * sizeof(SortPair));
+    SortPair* b = (SortPair*)malloc((size_t)n * sizeof(SortPair));
+    const uint32_t* rid = (const uint32_t*)fx->plane[A_RIBBON_ID];
+    const uint32_t* age = (const uint32_t*)fx->plane[A_AGE];
+    for (uint32_t i = 0; i < n; ++i) { a[i].value = col[i]; a[i].key = rid[col[i]]; a[i].key2 = age ? age[col[i]] : 0u; }
+    for (uint32_t w = 1; w < n; w *= 2) {
+        for (uint32_t lo = 0; lo < n; lo += 2 * w) {
+            const uint32_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            uint32_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) b[k++] = pair_greater(&a[i], &a[j]) ? a[j++] : a[i++];  /* ties keep the left element first */
+            while (i < mid) b[k++] = a[i++];
+            while (j < hi) b[k++] = a[j++];
+        }
+        SortPair* t = a; a = b; b = t;
+    }
+    for (uint32_t i = 0; i < n; ++i) col[i] = a[i].value;
+    free(a); free(b);
+}
+
 /* ---- indirect (vfx_indirect.wgsl:38-85) + update (vfx_update.wgsl:105-167) ---- */
 int hor_effect_update_pass(Effect* fx, const float* sim, uint32_t seed, const float* xf) {
     Asset* a = fx->asset;
@@ -973,6 +1005,7 @@ int hor_effect_update_pass(Effect* fx, const float* sim, uint32_t seed, const fl
     free(ev);
     fx->dead_count = n - fx->alive_count;
     fx->failed |= failed;
+    if (a->in_layout[A_RIBBON_ID] && !failed) sort_ribbons(fx);
     return failed ? -1 : 0;
 }
 

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../../bevy_hanabi_amd/csrc/hnb_vm.h"
@@ -167,6 +168,17 @@ void cvm_step(CpuVm* v, const float* sim, uint32_t spawn_count, uint32_t seed, c
         else { v->dead[n - 1u - casualties] = slot; ++casualties; }
     }
     v->alive = survivors;
+    if (v->h.flags & HNB_PROG_HAS_RIBBONS) {  // ribbon sort: stable by (RIBBON_ID, AGE bits) (vfx_sort*.wgsl)
+        const uint32_t *rid = nullptr, *age = nullptr;
+        for (size_t a = 0; a < v->attrs.size(); ++a) {
+            if (v->attrs[a].attr == HNB_ATTR_RIBBON_ID) rid = reinterpret_cast<const uint32_t*>(v->slab.data() + v->adesc[a].plane_off);
+            if (v->attrs[a].attr == HNB_ATTR_AGE) age = reinterpret_cast<const uint32_t*>(v->slab.data() + v->adesc[a].plane_off);
+        }
+        std::stable_sort(wr.begin(), wr.begin() + survivors, [&](uint32_t x, uint32_t y) {
+            const uint64_t kx = ((uint64_t)rid[x] << 32) | (age ? age[x] : 0u), ky = ((uint64_t)rid[y] << 32) | (age ? age[y] : 0u);
+            return kx < ky;
+        });
+    }
     v->counter += n_spawn;
     v->write_index = wi ^ 1u;
     v->max_update = n;

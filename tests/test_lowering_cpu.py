@@ -295,7 +295,25 @@ def asset_update_streamable_all_macros():
     return asset
 
 
+def asset_ribbons_multi():
+    """Five interleaved ribbons with random lifetimes: particles die in the middle of a ribbon, so the
+    post-update sort by (RIBBON_ID, AGE) (vfx_sort*.wgsl) really reorders the alive list."""
+    w = h.ExprWriter()
+    U = h.ValueType(h.ScalarType.Uint)
+    init = [
+        h.SetPositionSphereModifier(w.lit((0.0, 0.0, 0.0)).expr(), w.lit(1.0).expr(), h.ShapeDimension.Surface),
+        h.SetAttributeModifier(A.AGE, (w.rand(F) * w.lit(0.05)).expr()),
+        h.SetAttributeModifier(A.LIFETIME, w.lit(0.1).uniform(w.lit(0.6)).expr()),
+        h.SetAttributeModifier(A.RIBBON_ID, (w.rand(F) * w.lit(4.999)).cast(U).expr()),
+        h.SetAttributeModifier(A.SIZE, w.lit(0.5).expr()),
+    ]
+    asset = _mk(6000, w, init, [])
+    asset.motion_integration = h.MotionIntegration.None_
+    return asset
+
+
 ZOO = {
+    "ribbons_multi": asset_ribbons_multi,
     "unary_a": asset_unary_a,
     "unary_b": asset_unary_b,
     "unary_c": asset_unary_c,
