@@ -79,23 +79,30 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--capacity", type=int, default=CAPACITY)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
+    ap.add_argument("--force-device", type=int, default=None, help="dry runs: every rank uses this GPU instead of LOCAL_RANK")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    device_index = local_rank if args.force_device is None else args.force_device
+    reduce_device = "cuda" if args.backend == "nccl" else "cpu"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     n_gpus = world if distributed else 1
     if args.gpus != n_gpus and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1", file=sys.stderr)
 
     cap = args.capacity
     asset = effects.firework_trails(cap)
-    ctx = bh.Context(local_rank)
+    ctx = bh.Context(device_index)
     prog = ctx.create_program(bh.lower(asset))
     slot_base, _ = sharding.slab_plan(cap * n_gpus, n_gpus)[rank]  # rank g owns global slots [g*cap, (g+1)*cap)
     fx = prog.create_effect(slot_base=slot_base)
@@ -132,11 +139,11 @@ def main():
 
     alive = fx.alive_count()
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the only collective of the design: alive-particle counters, for reporting
-        alive_total = sharding.allreduce_alive([alive], device="cuda")[0]
+        alive_total = sharding.allreduce_alive([alive], device=reduce_device)[0]
     else:
         alive_total = alive
     assert alive_total == cap * n_gpus, f"expected every particle alive during the timed frames, got {alive_total}"
@@ -150,7 +157,7 @@ def main():
             "metric": "particle-updates/sec", "value": value, "unit": "particle-updates/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "firework.rs trails EffectAsset, capacity=16_777_216 per GPU, burst spawner, all particles alive",
+            "config": {"workload": f"firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst spawner, all particles alive",
                        "capacity_per_gpu": cap, "dt": dt, "sharding": f"capacity slab x{n_gpus}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": PMC_TRAFFIC_BYTES.get(cap), "traffic_unit": "B/launch", "traffic_source": PMC_TRAFFIC_SOURCE, "kernel": "k_update_stream<ProgDragAccel>", "kernel_ms_avg": k_ms, "compact_ms_avg": timing["compact_ms_avg"],
