@@ -153,6 +153,7 @@ struct HnbEffect {
     HnbProgram* prog = nullptr;
     uint32_t index = 0;
     void* slab = nullptr;
+    bool simulated = true;          // false: frozen (SimulationCondition::WhenVisible while invisible, src/render/mod.rs:4347-4356)
     HnbEffect* parent = nullptr;    // EffectParent: init consumes the parent's spawn events
     uint32_t parent_channel = 0;
     EventChannel channels[HNB_MAX_EVENT_CHANNELS];  // as a parent
@@ -792,6 +793,12 @@ int hnb_effect_set_frame(HnbEffect* fx, uint32_t spawn_count, uint32_t seed, con
     return HNB_OK;
 }
 
+int hnb_effect_set_simulated(HnbEffect* fx, int simulated) {
+    if (!fx) return fail(HNB_ERR_INVALID_ARG, "fx is NULL");
+    fx->simulated = simulated != 0;
+    return HNB_OK;
+}
+
 int hnb_effect_set_property(HnbEffect* fx, const char* name, const void* value, uint32_t n_words) {
     if (!fx || !name || !value) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
     for (const HnbPropEntry& pe : fx->prog->props) {
@@ -840,8 +847,9 @@ int hnb_simulate(HnbContext* ctx) {
             fi[i].slot_base = fx->slot_base;
             fi[i].init_block_start = blocks;
             fi[i].ev_parity = ev_parity;
-            uint32_t max_request = fx->spawn_count;
-            if (fx->parent) {
+            fi[i].skip = fx->simulated ? 0u : 1u;
+            uint32_t max_request = fx->simulated ? fx->spawn_count : 0u;
+            if (fx->parent && fx->simulated) {
                 const EventChannel& ch = fx->parent->channels[fx->parent_channel];
                 fi[i].parent_base = reinterpret_cast<uint64_t>(fx->parent->slab);
                 fi[i].parent_planes = reinterpret_cast<uint64_t>(fx->parent->prog->d_plane_by_attr);

@@ -53,7 +53,7 @@ struct DevFrameInst {
     uint64_t ev_in;             // child: DevEventBuffer the init pass consumes
     uint64_t ev_out[HNB_MAX_EVENT_CHANNELS];  // parent: DevEventBuffer per child channel, 0 = nobody listens
     uint32_t ev_parity;         // context frame parity: events are appended to count[ev_parity], consumed from count[ev_parity ^ 1]
-    uint32_t pad;
+    uint32_t skip;              // 1: the instance is not simulated this frame (SimulationCondition::WhenVisible and not visible): state frozen
 };
 static_assert(sizeof(DevFrameInst) == 128, "DevFrameInst layout");
 

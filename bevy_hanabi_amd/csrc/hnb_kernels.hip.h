@@ -71,6 +71,7 @@ __device__ __forceinline__ Out4 vfile_load_attr(uint32_t ncomp, const char* plan
 // effect with a parent — the number of spawn events its parent appended during the PREVIOUS frame
 // (vfx_init.wgsl:123-129; events past the buffer capacity were never stored).
 __device__ __forceinline__ uint32_t requested_spawn(const DevFrameInst& f) {
+    if (f.skip) return 0u;
     if (f.ev_in == 0ull) return f.spawn_count;
     const DevEventBuffer* ev = reinterpret_cast<const DevEventBuffer*>(f.ev_in);
     const uint32_t n = ev->count[f.ev_parity ^ 1u];
@@ -282,7 +283,7 @@ __device__ __forceinline__ bool chunk_setup(ChunkCtx& c, uint32_t chunk, const A
     const uint32_t spawn = requested_spawn(fi[c.k]);
     const uint32_t max_spawn = args.capacity - c.m.alive_count;
     c.n_spawn = spawn < max_spawn ? spawn : max_spawn;
-    c.n = c.m.alive_count + c.n_spawn;
+    c.n = fi[c.k].skip ? 0u : c.m.alive_count + c.n_spawn;  // a frozen instance has nothing to update
     c.start = c.j * kChunk;
     c.base = reinterpret_cast<char*>(inst_base[c.k]);
     return c.start < c.n;
@@ -323,6 +324,10 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     const uint32_t chunk = blockIdx.x;
     ChunkCtx c;
     const bool has_rows = chunk_setup(c, chunk, args, inst_base, meta_in, fi);
+    if (fi[c.k].skip) {  // not simulated this frame: counters carry over unchanged
+        if (c.j == 0 && tid == 0) { meta_out[c.k] = c.m; cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + c.k] = 0u; }
+        return;
+    }
     uint32_t* deaths_cur = cb.deaths + (size_t)cb.parity * cb.table_cap;
     const uint32_t total_dead = deaths_cur[c.k];
     if (c.j == 0 && tid == 0) cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + c.k] = 0u;  // next frame's counter

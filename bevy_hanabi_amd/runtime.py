@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "hnb_effect_set_parent", "hnb_frame_begin", "hnb_effect_set_frame", "hnb_effect_set_property", "hnb_simulate",
     "hnb_effect_metadata", "hnb_effect_alive_count", "hnb_effect_read_attr", "hnb_effect_read_alive_list",
     "hnb_effect_read_dead_list", "hnb_effect_write_attr", "hnb_effect_sort_ribbons", "hnb_ctx_enable_kernel_timing",
-    "hnb_ctx_kernel_timing", "hnb_program_kernel_info", "hnb_jit_precompile",
+    "hnb_ctx_kernel_timing", "hnb_program_kernel_info", "hnb_jit_precompile", "hnb_effect_set_simulated",
 ]
 
 
@@ -83,6 +83,7 @@ def load_library():
         lib.hnb_effect_sort_ribbons.argtypes = [C.c_void_p]
         lib.hnb_ctx_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         lib.hnb_ctx_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        lib.hnb_effect_set_simulated.argtypes = [C.c_void_p, C.c_int]
         lib.hnb_program_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         lib.hnb_jit_precompile.argtypes = [C.c_char_p, C.c_size_t]
         _lib = lib
@@ -196,6 +197,10 @@ class Effect:
             _check(self._lib.hnb_effect_destroy(self._h))
             self._h = None
             self._prog._effects.remove(self)
+
+    def set_simulated(self, simulated=True):
+        """False freezes the instance (SimulationCondition::WhenVisible while not visible)."""
+        _check(self._lib.hnb_effect_set_simulated(self._h, int(bool(simulated))))
 
     def set_parent(self, parent, channel, event_capacity=256):
         """EffectParent: this effect's init consumes the spawn events `parent` appends on `channel`

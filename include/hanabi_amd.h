@@ -284,6 +284,11 @@ int hnb_frame_begin(HnbContext* ctx, const HnbSimParams* params);
 /* ... and per effect: CPU spawn count (EffectSpawner::tick), PRNG seed, row-major 3x4
  * emitter transform (NULL = identity). */
 int hnb_effect_set_frame(HnbEffect* fx, uint32_t spawn_count, uint32_t seed, const float* transform3x4);
+/* SimulationCondition (src/asset.rs, src/spawn.rs:983-991, src/render/mod.rs:4347-4356): an effect whose asset
+ * says WhenVisible is neither ticked nor simulated while it is not visible. The host decides visibility and
+ * passes 0 here: the instance is skipped by the following hnb_simulate calls (its state is frozen, its
+ * pending spawn request is dropped) until 1 is passed again. Default: simulated. */
+int hnb_effect_set_simulated(HnbEffect* fx, int simulated);
 /* Properties (EffectProperties::set, src/properties.rs:216-395). `n_words` 32-bit words. */
 int hnb_effect_set_property(HnbEffect* fx, const char* name, const void* value, uint32_t n_words);
 

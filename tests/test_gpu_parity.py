@@ -262,3 +262,51 @@ def test_full_size_die_off_invariants(ctx):
     assert len(dead) == cap and np.array_equal(np.sort(dead), np.arange(cap, dtype=np.uint32))
     r.fx.destroy()
     r.prog.destroy()
+
+
+def test_simulation_condition_freezes_an_instance(ctx):
+    """SimulationCondition::WhenVisible (spawn.rs:983-991, mod.rs:4347-4356): an invisible instance is neither
+    ticked nor simulated; the other instances of the same batch go on. Oracle: simply not stepped."""
+    cap = 9000
+    asset = effects.instancing(cap, rate=cap / 0.25)
+    prog = ctx.create_program(bh.lower(asset))
+    fxs = [prog.create_effect() for _ in range(3)]
+    orcs = [OracleRunner(asset) for _ in range(3)]
+    sps = [bh.EffectSpawner(asset.spawner) for _ in range(3)]
+    rng = bh.Pcg32()
+    for f in range(50):
+        ctx.frame_begin(1 / 60, f / 60)
+        for i, (fx, orc, sp) in enumerate(zip(fxs, orcs, sps)):
+            visible = not (i == 1 and 10 <= f < 30) and not (i == 2 and f % 4 == 0)
+            fx.set_simulated(visible)
+            if not visible:
+                fx.set_frame(12345, 1)  # a request made while frozen is dropped
+                continue
+            n, seed = sp.tick(1 / 60, rng), frame_seed(f * 8 + i)
+            fx.set_frame(n, seed)
+            orc.step(Frame(1 / 60, n, seed, time=f / 60))
+        ctx.simulate()
+        if f in (9, 10, 29, 30, 49):
+            for fx, orc in zip(fxs, orcs):
+                ref = orc.state()
+                np.testing.assert_array_equal(ref["alive"], fx.alive_list())
+                np.testing.assert_array_equal(ref["dead"], fx.dead_list())
+                for a in (A.POSITION, A.VELOCITY, A.AGE):
+                    np.testing.assert_array_equal(ref["attrs"][a.name], fx.read_attr(a.id).view(np.uint32))
+    prog.destroy()
+
+
+def test_ribbon_sort_is_stable_on_equal_keys(ctx):
+    """Equal (RIBBON_ID, AGE) keys keep their list order (vfx_sort.wgsl only moves past strictly greater keys)."""
+    cap = 10000
+    asset = effects.ribbon(cap)
+    g = GpuRunner(asset, ctx=ctx)
+    g.step(Frame(1 / 60, cap, 5))                       # list = identity, every key equal
+    np.testing.assert_array_equal(g.fx.alive_list(), np.arange(cap, dtype=np.uint32))
+    rid = (np.arange(cap, dtype=np.uint32) * 7919 % 3).reshape(cap, 1)   # three ribbons, every age still equal
+    g.fx.write_attr(A.RIBBON_ID.id, rid)
+    g.step(Frame(1 / 60, 0, 6))
+    want = np.concatenate([np.nonzero(rid[:, 0] == r)[0] for r in range(3)]).astype(np.uint32)   # stable partition
+    np.testing.assert_array_equal(g.fx.alive_list(), want)
+    g.fx.destroy()
+    g.prog.destroy()

@@ -49,6 +49,33 @@ __global__ void __launch_bounds__(256) k_ideal(const uint32_t* __restrict__ list
     reinterpret_cast<uint4*>(list_out)[q] = o;
 }
 
+// the same update on component-planar storage (x[], y[], z[] per vec3 attribute): every access is one
+// aligned 16-byte load per lane, 1 KiB contiguous per wave instruction
+__global__ void __launch_bounds__(256) k_ideal_planar(const uint32_t* __restrict__ list, float* pos, float* vel, float* age, const float* __restrict__ life,
+                                                      uint32_t* __restrict__ list_out, uint32_t n, float dt, float drag, float ay) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q * 4 >= n) return;
+    const uint4 idx = reinterpret_cast<const uint4*>(list)[q];
+    const size_t plane = (size_t)n / 4;  // float4s per component plane
+    float4* pp = reinterpret_cast<float4*>(pos);
+    float4* vp = reinterpret_cast<float4*>(vel);
+    float4 px = pp[q], py = pp[plane + q], pz = pp[2 * plane + q];
+    float4 vx = vp[q], vy = vp[plane + q], vz = vp[2 * plane + q];
+    float4 a = reinterpret_cast<float4*>(age)[q];
+    const float4 l = reinterpret_cast<const float4*>(life)[q];
+#define UPD(P, V, ADD) V.x = V.x * drag + ADD; V.y = V.y * drag + ADD; V.z = V.z * drag + ADD; V.w = V.w * drag + ADD; \
+    P.x += V.x * dt; P.y += V.y * dt; P.z += V.z * dt; P.w += V.w * dt;
+    UPD(px, vx, 0.0f) UPD(py, vy, ay) UPD(pz, vz, 0.0f)
+#undef UPD
+    a.x += dt; a.y += dt; a.z += dt; a.w += dt;
+    pp[q] = px; pp[plane + q] = py; pp[2 * plane + q] = pz;
+    vp[q] = vx; vp[plane + q] = vy; vp[2 * plane + q] = vz;
+    reinterpret_cast<float4*>(age)[q] = a;
+    uint4 o = idx;
+    if (!(a.x < l.x)) o.x = 0xffffffffu;
+    reinterpret_cast<uint4*>(list_out)[q] = o;
+}
+
 template <class F> float time_ms(int iters, F f) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -134,6 +161,8 @@ int main(int argc, char** argv) {
     {
         float ms = time_ms(iters, [&] { k_ideal<<<cap / 4 / 256, 256>>>((uint32_t*)(slab + sa.alive_off[0]), (float*)(slab + sa.plane_off[0]), (float*)(slab + sa.plane_off[1]), (float*)(slab + sa.plane_off[2]), (float*)(slab + sa.plane_off[3]), (uint32_t*)(slab + sa.alive_off[1]), cap, 1.f / 60, 0.93f, -0.26f); });
         printf("%-44s %8.3f ms  %7.1f GB/s\n", "hand-written ideal (no compaction)", ms, bytes / ms / 1e6);
+        ms = time_ms(iters, [&] { k_ideal_planar<<<cap / 4 / 256, 256>>>((uint32_t*)(slab + sa.alive_off[0]), (float*)(slab + sa.plane_off[0]), (float*)(slab + sa.plane_off[1]), (float*)(slab + sa.plane_off[2]), (float*)(slab + sa.plane_off[3]), (uint32_t*)(slab + sa.alive_off[1]), cap, 1.f / 60, 0.93f, -0.26f); });
+        printf("%-44s %8.3f ms  %7.1f GB/s\n", "ideal, component-planar vec3 storage", ms, bytes / ms / 1e6);
     }
     {
         const size_t n16 = (size_t)cap * 32 / 16;  // 32 B/particle read + 32 B/particle written ~ 64 B/particle
