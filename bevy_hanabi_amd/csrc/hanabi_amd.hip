@@ -582,11 +582,12 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     p->has_ribbons = (h.flags & HNB_PROG_HAS_RIBBONS) != 0;
     if (p->has_ribbons) {  // radix-sort scratch: 64-bit keys and values ping-pong, per-chunk digit histograms, key OR/AND
         SortArgs& so = p->sort;
-        so.capacity = h.capacity; so.chunks_per_inst = d.chunks_per_inst;
+        so.capacity = h.capacity; so.chunks_per_inst = (h.capacity + kSortTile - 1) / kSortTile;
         so.alive_off[0] = d.alive_off[0]; so.alive_off[1] = d.alive_off[1];
         for (int i = 0; i < 2; ++i) { so.key_off[i] = (uint32_t)off; off += align_up((size_t)h.capacity * 8, 256); }
         for (int i = 0; i < 2; ++i) { so.val_off[i] = (uint32_t)off; off += list_bytes; }
-        so.hist_off = (uint32_t)off; off += align_up((size_t)256 * d.chunks_per_inst * 4, 256);
+        so.hist_off = (uint32_t)off; off += align_up((size_t)256 * so.chunks_per_inst * 4, 256);
+        so.gsum_off = (uint32_t)off; off += align_up((size_t)8 * ((so.chunks_per_inst + kSortGroup - 1) / kSortGroup) * 256 * 4, 256);
         so.bits_off = (uint32_t)off; off += 256;
         so.rid_plane = so.age_plane = kNoPlane;
         for (uint32_t i = 0; i < h.n_attrs; ++i) {
@@ -949,13 +950,13 @@ int hnb_simulate(HnbContext* ctx) {
             SortArgs so = p->sort;
             so.parity = ctx->frame & 1u;
             const DevMeta* mo = p->d_meta[par ^ 1];
-            k_sort_fill<<<total_chunks, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+            const uint32_t tiles = n * so.chunks_per_inst;
+            k_sort_fill<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
             for (uint32_t pass = 0; pass < 8; ++pass) {
-                k_sort_hist<<<total_chunks, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
-                k_sort_scan<<<n, 256 * kScanGroups, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
-                k_sort_scatter<<<total_chunks, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
+                k_sort_hist<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
+                k_sort_scatter<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
             }
-            k_sort_copy<<<total_chunks, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+            k_sort_copy<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(p->kernels_done[par], ctx->stream));
