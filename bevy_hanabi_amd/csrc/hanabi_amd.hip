@@ -860,7 +860,10 @@ int hnb_simulate(HnbContext* ctx) {
             for (uint32_t c = 0; c < HNB_MAX_EVENT_CHANNELS; ++c) fi[i].ev_out[c] = reinterpret_cast<uint64_t>(fx->channels[c].buf);
             // never launch more init workgroups than the capacity allows (max_spawn <= capacity)
             const uint32_t cap_spawn = std::min(max_request, p->dev.capacity);
-            blocks += (cap_spawn + kInitBlock - 1) / kInitBlock;
+            uint32_t inst_blocks = (cap_spawn + kInitBlock - 1) / kInitBlock;
+            // event-driven spawns: the count lives on the device, so launch a bounded grid that strides (k_init)
+            if (fx->parent) inst_blocks = std::min<uint32_t>(inst_blocks, ctx->num_cus * 8u);
+            blocks += inst_blocks;
             memcpy(fi[i].xf, fx->xf, sizeof fx->xf);
             // Parameter block: the uniform stream (literals, properties, sim params and every
             // expression built only from them) evaluated here, once per instance per frame.

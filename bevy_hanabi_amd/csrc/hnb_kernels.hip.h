@@ -142,42 +142,45 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
         if (blk >= fi[mid].init_block_start) lo = mid + 1; else hi = mid;
     }
     const uint32_t k = lo - 1;
-    const uint32_t i = (blk - fi[k].init_block_start) * kInitBlock + threadIdx.x;
+    // The instance's workgroups stride over its spawns: exactly one round for CPU spawners; for effects with a
+    // parent the event count is only known on the device, so the grid is capped and loops (no indirect dispatch in HIP).
+    const uint32_t first_block = fi[k].init_block_start;
+    const uint32_t n_blocks = (k + 1u < prog.n_inst ? fi[k + 1u].init_block_start : gridDim.x) - first_block;
 
     const uint32_t alive0 = meta_in[k].alive_count;
     const uint32_t max_spawn = prog.capacity - alive0;
     const uint32_t spawn = requested_spawn(fi[k]);
     const uint32_t n_spawn = spawn < max_spawn ? spawn : max_spawn;
-    if (i >= n_spawn) return;
 
     char* base = reinterpret_cast<char*>(inst_base[k]);
     const uint32_t* dead = reinterpret_cast<const uint32_t*>(base + prog.dead_off);
     uint32_t* alive = reinterpret_cast<uint32_t*>(base + prog.alive_off[meta_in[k].write_index]);  // the column holding the list
-
-    const uint32_t slot = dead[alive0 + i];
-
     VmUniforms U;
     U.u = ublocks + (size_t)k * prog.n_uregs;
     U.xf = fi[k].xf;
-    VmState<vreg_file_t> S;
-    S.r = vreg_file_t{};  // var particle = Particle();  (vfx_init.wgsl:174)
-    S.pindex = slot + fi[k].slot_base;
-    S.seed = pcg_hash(S.pindex ^ fi[k].seed);
-    S.pcounter = meta_in[k].particle_counter + i;
-    S.alive = true;
 
-    VmAttrIO io;
-    io.slab = base; io.attrs = prog.attrs; io.slot = slot;
-    if (fi[k].ev_in != 0ull) {  // GPU-spawned: fetch the parent particle that emitted event i (vfx_init.wgsl:166-171)
-        S.gpu_spawned = true;
-        io.parent_slab = reinterpret_cast<const char*>(fi[k].parent_base);
-        io.parent_planes = reinterpret_cast<const uint32_t*>(fi[k].parent_planes);
-        io.parent_slot = reinterpret_cast<const DevEventBuffer*>(fi[k].ev_in)->data[i];
+    for (uint32_t i = (blk - first_block) * kInitBlock + threadIdx.x; i < n_spawn; i += n_blocks * kInitBlock) {
+        const uint32_t slot = dead[alive0 + i];
+        VmState<vreg_file_t> S;
+        S.r = vreg_file_t{};  // var particle = Particle();  (vfx_init.wgsl:174)
+        S.pindex = slot + fi[k].slot_base;
+        S.seed = pcg_hash(S.pindex ^ fi[k].seed);
+        S.pcounter = meta_in[k].particle_counter + i;
+        S.alive = true;
+
+        VmAttrIO io;
+        io.slab = base; io.attrs = prog.attrs; io.slot = slot;
+        if (fi[k].ev_in != 0ull) {  // GPU-spawned: fetch the parent particle that emitted event i (vfx_init.wgsl:166-171)
+            S.gpu_spawned = true;
+            io.parent_slab = reinterpret_cast<const char*>(fi[k].parent_base);
+            io.parent_planes = reinterpret_cast<const uint32_t*>(fi[k].parent_planes);
+            io.parent_slot = reinterpret_cast<const DevEventBuffer*>(fi[k].ev_in)->data[i];
+        }
+        CODE::zero_unassigned(prog, io);
+        CODE::run_init(prog, S, U, io);
+        alive[alive0 + i] = slot;
+        CODE::store_init(prog, S, base, slot);
     }
-    CODE::zero_unassigned(prog, io);
-    CODE::run_init(prog, S, U, io);
-    alive[alive0 + i] = slot;
-    CODE::store_init(prog, S, base, slot);
 }
 // ---- streaming-kernel pinned attribute access (P = 4) -------------------------------------------
 template <int P>

@@ -82,6 +82,37 @@ if "c4" in which:
     tot = cap * n_inst
     print(f"   -> {tot * 68 / (tm['update_ms_avg'] * 1e-3) / 1e9:.1f} GB/s @68B, {tot / ((tm['update_ms_avg'] + tm['compact_ms_avg']) * 1e-3):.3e} updates/s (kernels)")
     prog.destroy()
+if "events" in which:
+    # 1M-particle parent, every dying particle spawns 16 children (OnDie) into a 16M-particle child effect
+    A = bh.Attribute
+    w = bh.ExprWriter()
+    pinit = [bh.SetPositionSphereModifier(w.lit((0.0, 0.0, 0.0)).expr(), w.lit(5.0).expr(), bh.ShapeDimension.Volume),
+             bh.SetVelocitySphereModifier(w.lit((0.0, 0.0, 0.0)).expr(), w.lit(3.0).expr()),
+             bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()), bh.SetAttributeModifier(A.LIFETIME, w.lit(0.2).uniform(w.lit(0.6)).expr())]
+    pupd = [bh.AccelModifier(w.lit((0.0, -9.0, 0.0)).expr()), bh.EmitSpawnEventModifier(bh.EventEmitCondition.OnDie, w.lit(bh.Value.u32(16)).expr(), 0)]
+    pcap, ccap = 1 << 20, 1 << 24
+    parent = bh.EffectAsset(pcap, bh.SpawnerSettings.once(float(pcap)), w.finish())
+    for m in pinit: parent.init(m)
+    for m in pupd: parent.update(m)
+    w = bh.ExprWriter()
+    cinit = [bh.InheritAttributeModifier(A.POSITION), bh.SetAttributeModifier(A.VELOCITY, ((w.rand(bh.VectorType.VEC3F) * w.lit(2.0) - w.lit(1.0)).normalized() * w.lit(4.0)).expr()),
+             bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()), bh.SetAttributeModifier(A.LIFETIME, w.lit(0.5).expr())]
+    child = bh.EffectAsset(ccap, bh.SpawnerSettings(), w.finish())
+    for m in cinit: child.init(m)
+    child.update(bh.LinearDragModifier(w.lit(1.0).expr())) if False else None
+    pp, cp = ctx.create_program(bh.lower(parent)), ctx.create_program(bh.lower(child))
+    pf, cf = pp.create_effect(), cp.create_effect()
+    cf.set_parent(pf, 0, 1 << 24)
+    print(pp.kernel_info().split("\n")[0], "|", cp.kernel_info().split("\n")[0])
+    for f in range(45):
+        ctx.enable_kernel_timing(1)
+        ctx.frame_begin(DT, f * DT); pf.set_frame(pcap if f == 0 else 0, frame_seed(f)); cf.set_frame(0, frame_seed(1000 + f)); ctx.simulate()
+        tm = ctx.kernel_timing()
+        if f % 4 == 1 or f < 3:
+            print(f"  frame {f:2d}: parent alive {pf.alive_count():8d} child alive {cf.alive_count():9d} | per-program avg: update {tm['update_ms_avg']*1e3:7.1f} us, emit+compact {tm['compact_ms_avg']*1e3:7.1f} us, init {tm['init_ms_avg']*1e3:7.1f} us")
+    ctx.enable_kernel_timing(0)
+    pp.destroy(); cp.destroy()
+
 if "generic" in which:
     # a non-streamable update stack (expression-driven SetAttribute in update): k_update_generic
     cap = 1 << 24
