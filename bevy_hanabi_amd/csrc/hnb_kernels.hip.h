@@ -29,7 +29,7 @@ struct u2_t { uint32_t x, y; };
 struct u3_t { uint32_t x, y, z; };
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 // Streaming accesses use the default cache policy: `nontemporal` hints measured 13 % SLOWER on
-// MI355X for this kernel (profiles/r01_variants.md).
+// MI355X for this kernel (profiles/r01b_summary.md).
 #ifdef HNB_NONTEMPORAL
 #define HNB_NT_LOAD(p) __builtin_nontemporal_load(p)
 #define HNB_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
