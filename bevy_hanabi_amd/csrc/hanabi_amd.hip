@@ -511,6 +511,7 @@ int hnb_ctx_destroy(HnbContext* ctx) {
     while (!ctx->programs.empty()) hnb_program_destroy(ctx->programs.back());
     for (auto& t : ctx->t_update) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (auto& t : ctx->t_init) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    for (auto& t : ctx->t_compact) hipEventDestroy(t.b);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     if (ctx->upload_stream) hipStreamDestroy(ctx->upload_stream);
     delete ctx;
@@ -637,7 +638,12 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     }
     const size_t code_bytes = ((size_t)h.init_len + h.update_len) * 8;
     hipError_t e = hipMalloc(&p->d_code, std::max<size_t>(code_bytes, 8));
-    if (e != hipSuccess) { delete p; return fail(HNB_ERR_OUT_OF_MEMORY, "hipMalloc(code) failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) {
+        if (p->jit_module) hipModuleUnload(p->jit_module);
+        hipFree(p->d_plane_by_attr);
+        delete p;
+        return fail(HNB_ERR_OUT_OF_MEMORY, "hipMalloc(code) failed: %s", hipGetErrorString(e));
+    }
     if (h.init_len) hipMemcpy(p->d_code, b + h.init_off, (size_t)h.init_len * 8, hipMemcpyHostToDevice);
     if (h.update_len) hipMemcpy(p->d_code + h.init_len, b + h.update_off, (size_t)h.update_len * 8, hipMemcpyHostToDevice);
     d.init_code = p->d_code;
