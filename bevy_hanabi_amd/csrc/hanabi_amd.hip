@@ -101,6 +101,7 @@ struct HnbContext {
     std::vector<HnbProgram*> programs;
     HnbSimParams sim{};
     uint32_t frame = 0;         // simulated frames: parity double-buffers the spawn-event counters
+    uint32_t list_order = HNB_LIST_ORDER_SPAWN;  // applied to programs created afterwards
     uint32_t timing = 0;        // 0 = off, n = time every n-th simulated frame
     uint32_t timing_tick = 0;
     std::vector<TimingPair> t_update, t_init, t_compact;
@@ -127,6 +128,13 @@ struct HnbProgram {
     uint32_t table_cap = 0;
     uint64_t* d_inst_base = nullptr;
     DevMeta* d_meta[2] = {nullptr, nullptr};
+    // Effect slabs are carved out of large blocks (one hipMalloc per ~1 GiB instead of one per instance):
+    // thousands of instances stay within a few large mappings, and creating an instance does not hit the driver.
+    struct SlabBlock { char* base = nullptr; uint32_t n_slots = 0; };
+    std::vector<SlabBlock> slab_blocks;
+    std::vector<void*> free_slabs;
+    size_t slab_stride = 0;
+    bool slot_order = false;              // HNB_LIST_ORDER_SLOT: lists rebuilt in slot order every frame
     bool has_ribbons = false;             // layout has RIBBON_ID: the alive list is sorted after every update (hnb_sort.hip.h)
     SortArgs sort{};                      // slab offsets of the sort scratch
     uint32_t* d_plane_by_attr = nullptr;  // [HNB_ATTR_COUNT] plane offsets by attribute id (children read parent particles through it)
@@ -529,6 +537,17 @@ int hnb_ctx_set_stream(HnbContext* ctx, void* hip_stream) {
     return HNB_OK;
 }
 
+int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
+    if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
+    switch (option) {
+        case HNB_OPT_LIST_ORDER:
+            if (value != HNB_LIST_ORDER_SPAWN && value != HNB_LIST_ORDER_SLOT) return fail(HNB_ERR_INVALID_ARG, "unknown list order %u", value);
+            ctx->list_order = value;
+            return HNB_OK;
+        default: return fail(HNB_ERR_INVALID_ARG, "unknown option %u", option);
+    }
+}
+
 int hnb_ctx_synchronize(HnbContext* ctx) {
     if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -574,6 +593,9 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
         d.attrs[i].upd_flags = p->attrs[i].update_flags;
         off += align_up((size_t)h.capacity * p->attrs[i].ncomp * 4, 256);
     }
+    d.alive_flag_off = kNoPlane;
+    p->slot_order = ctx->list_order == HNB_LIST_ORDER_SLOT && !(h.flags & HNB_PROG_HAS_RIBBONS);  // ribbons are re-sorted anyway
+    if (p->slot_order) { d.alive_flag_off = (uint32_t)off; off += align_up((size_t)h.capacity, 256); }  // zeroed with the attribute planes
     d.n_event_channels = h.n_event_channels;
     if (h.n_event_channels) {  // per-row staging of spawn events (k_update_generic -> k_emit_events)
         d.ev_slot_off = (uint32_t)off; off += list_bytes;
@@ -665,6 +687,7 @@ int hnb_program_destroy(HnbProgram* p) {
         if (p->kernels_done[i]) hipEventDestroy(p->kernels_done[i]);
     }
     if (p->jit_module) hipModuleUnload(p->jit_module);
+    for (auto& blk : p->slab_blocks) hipFree(blk.base);
     hipFree(p->d_plane_by_attr);
     hipFree(p->d_code);
     ctx->programs.erase(std::remove(ctx->programs.begin(), ctx->programs.end(), p), ctx->programs.end());
@@ -684,7 +707,21 @@ int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
     fx->prog = p;
     fx->index = index;
     fx->slot_base = slot_base;
-    hipError_t e = hipMalloc(&fx->slab, p->slab_bytes);
+    hipError_t e = hipSuccess;
+    if (p->free_slabs.empty()) {
+        p->slab_stride = align_up(p->slab_bytes, 64 * 1024);
+        const size_t want = std::max<size_t>(1, ((size_t)1 << 30) / p->slab_stride);
+        // grow geometrically with the instance count, capped at ~1 GiB blocks
+        const uint32_t n_slots = (uint32_t)std::min<size_t>(want, std::max<size_t>(1, p->effects.size()));
+        HnbProgram::SlabBlock blk;
+        blk.n_slots = n_slots;
+        e = hipMalloc(reinterpret_cast<void**>(&blk.base), p->slab_stride * n_slots);
+        if (e == hipSuccess) {
+            p->slab_blocks.push_back(blk);
+            for (uint32_t i = n_slots; i-- > 0;) p->free_slabs.push_back(blk.base + (size_t)i * p->slab_stride);
+        }
+    }
+    if (e == hipSuccess) { fx->slab = p->free_slabs.back(); p->free_slabs.pop_back(); }
     if (e != hipSuccess) { delete fx; return fail(HNB_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes) for effect slab failed: %s", p->slab_bytes, hipGetErrorString(e)); }
     char* base = static_cast<char*>(fx->slab);
     const uint32_t cap = p->dev.capacity;
@@ -738,7 +775,7 @@ int hnb_effect_destroy(HnbEffect* fx) {
     }
     p->effects.pop_back();
     p->dev.n_inst = (uint32_t)p->effects.size();
-    hipFree(fx->slab);
+    p->free_slabs.push_back(fx->slab);  // the block itself is released with the program
     delete fx;
     return HNB_OK;
 }
@@ -953,7 +990,12 @@ int hnb_simulate(HnbContext* ctx) {
         CompactArgs ca{};
         ca.capacity = p->dev.capacity; ca.chunks_per_inst = p->dev.chunks_per_inst;
         ca.alive_off[0] = p->dev.alive_off[0]; ca.alive_off[1] = p->dev.alive_off[1]; ca.dead_off = p->dev.dead_off;
+        ca.alive_flag_off = p->dev.alive_flag_off;
         k_compact<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
+        if (p->slot_order) {  // rebuild the list in increasing slot order (instances without a casualty or spawn return at once)
+            k_order_count<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
+            k_order_write<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
+        }
         if (timed) { tc.a = tu.b; hipEventRecord(tc.b, ctx->stream); ctx->t_compact.push_back(tc); }
         if (p->has_ribbons) {  // ribbon sort of the compacted list by (RIBBON_ID, AGE) (src/render/mod.rs:7372-7612)
             SortArgs so = p->sort;

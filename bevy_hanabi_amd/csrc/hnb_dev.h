@@ -32,6 +32,7 @@ struct DevProgram {
     uint32_t init_len, update_len;
     uint32_t n_inst;
     // GPU spawn events this program's update appends (EmitSpawnEventModifier): per-row staging planes in the slab
+    uint32_t alive_flag_off;   // HNB_LIST_ORDER_SLOT: u8[capacity] alive flag per slot (kNoPlane = spawn-order lists)
     uint32_t n_event_channels;
     uint32_t ev_slot_off;                            // u32[capacity]: slot of each alive-list row (as the update saw it)
     uint32_t ev_cnt_off[HNB_MAX_EVENT_CHANNELS];     // u32[capacity] per channel: events appended by that row

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "hnb_effect_set_parent", "hnb_frame_begin", "hnb_effect_set_frame", "hnb_effect_set_property", "hnb_simulate",
     "hnb_effect_metadata", "hnb_effect_alive_count", "hnb_effect_read_attr", "hnb_effect_read_alive_list",
     "hnb_effect_read_dead_list", "hnb_effect_write_attr", "hnb_effect_sort_ribbons", "hnb_ctx_enable_kernel_timing",
-    "hnb_ctx_kernel_timing", "hnb_program_kernel_info", "hnb_jit_precompile", "hnb_effect_set_simulated",
+    "hnb_ctx_kernel_timing", "hnb_program_kernel_info", "hnb_jit_precompile", "hnb_effect_set_simulated", "hnb_ctx_set_option",
 ]
 
 
@@ -84,6 +84,7 @@ def load_library():
         lib.hnb_ctx_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         lib.hnb_ctx_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         lib.hnb_effect_set_simulated.argtypes = [C.c_void_p, C.c_int]
+        lib.hnb_ctx_set_option.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         lib.hnb_program_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         lib.hnb_jit_precompile.argtypes = [C.c_char_p, C.c_size_t]
         _lib = lib
@@ -134,6 +135,10 @@ class Context:
 
     def synchronize(self):
         _check(self._lib.hnb_ctx_synchronize(self._h))
+
+    def set_list_order(self, order):
+        """'spawn' (default: the serial-thread order) or 'slot' (lists kept in increasing slot order; programs created afterwards)."""
+        _check(self._lib.hnb_ctx_set_option(self._h, 1, {"spawn": 0, "slot": 1}[order]))
 
     def create_program(self, blob: bytes):
         return Program(self, blob)

@@ -258,6 +258,16 @@ int hnb_ctx_destroy(HnbContext* ctx);
 /* Stream used by hnb_simulate (a hipStream_t; NULL selects the context's own stream). */
 int hnb_ctx_set_stream(HnbContext* ctx, void* hip_stream);
 int hnb_ctx_synchronize(HnbContext* ctx);
+/* Context options, applied to the programs created afterwards.
+ * HNB_OPT_LIST_ORDER: order of an effect's alive list after each frame. The reference's order is whatever its
+ * atomics produce (vfx_update.wgsl:161-165); both values are deterministic, legal outcomes:
+ *   HNB_LIST_ORDER_SPAWN (default)  serial-thread order: survivors keep their relative order, spawns are appended;
+ *   HNB_LIST_ORDER_SLOT             survivors in increasing slot order: under steady spawn/kill churn the update
+ *                                   keeps streaming through memory instead of gathering 12 bytes at random. */
+#define HNB_OPT_LIST_ORDER 1u
+#define HNB_LIST_ORDER_SPAWN 0u
+#define HNB_LIST_ORDER_SLOT 1u
+int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value);
 
 /* Replaces EffectShaderSources::generate + pipeline specialisation (src/lib.rs:805-1336). */
 int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbProgram** out_prog);

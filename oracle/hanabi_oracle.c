@@ -95,6 +95,7 @@ typedef struct Effect_ {
     char error[256];
     int failed;
     /* GPU spawn events (src/render/event.rs, src/lib.rs:976-993, vfx_init.wgsl:123-129,166-171) */
+    int order_by_slot;                      /* alternative canonical schedule: see hor_effect_set_list_order */
     struct Effect_* parent;                 /* EffectParent: this effect's init consumes the parent's events */
     uint32_t parent_channel;                /* the N-th child of a parent reads channel N */
     uint32_t ev_capacity[MAX_CHANNELS];     /* arrayLength(&event_buffer_N.spawn_events); 256 in the reference (event.rs:267) */
@@ -927,6 +928,15 @@ static void sort_ribbons(Effect* fx) {
     free(a); free(b);
 }
 
+/* The reference's alive-list order is whatever its atomics produce (vfx_update.wgsl:161-165): any permutation of
+ * the survivors is a legal outcome. The default canonical schedule here is "threads in increasing global id" (stable
+ * compaction). order_by_slot selects a second deterministic schedule in which the update pass
+ * leaves the survivors in increasing SLOT order: equally legal, and the one the product offers for steady-state
+ * effects because it keeps memory accesses coalesced (HNB_LIST_ORDER_SLOT). Everything else is unchanged: threads of
+ * a pass still run in list-row order, so the k-th casualty in row order lands on dead row n-1-k. */
+void hor_effect_set_list_order(Effect* fx, int by_slot) { fx->order_by_slot = by_slot; }
+static int cmp_u32(const void* x, const void* y) { const uint32_t a = *(const uint32_t*)x, b = *(const uint32_t*)y; return a < b ? -1 : a > b; }
+
 /* ---- indirect (vfx_indirect.wgsl:38-85) + update (vfx_update.wgsl:105-167) ---- */
 int hor_effect_update_pass(Effect* fx, const float* sim, uint32_t seed, const float* xf) {
     Asset* a = fx->asset;
@@ -1005,6 +1015,10 @@ int hor_effect_update_pass(Effect* fx, const float* sim, uint32_t seed, const fl
     free(ev);
     fx->dead_count = n - fx->alive_count;
     fx->failed |= failed;
+    if (fx->order_by_slot && !a->in_layout[A_RIBBON_ID] && !failed) {   /* see hor_effect_set_list_order; ribbon effects are re-sorted below anyway */
+        uint32_t* col = fx->list[fx->write_index];
+        qsort(col, fx->alive_count, 4, cmp_u32);
+    }
     if (a->in_layout[A_RIBBON_ID] && !failed) sort_ribbons(fx);
     return failed ? -1 : 0;
 }

@@ -45,6 +45,7 @@ def _lib(omp=False):
         lib.hor_effect_event_count.restype = C.c_uint32
         lib.hor_effect_event_count.argtypes = [C.c_void_p, C.c_uint32]
         lib.hor_effect_read_events.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.hor_effect_set_list_order.argtypes = [C.c_void_p, C.c_int]
         lib.hor_effect_alive_count.restype = C.c_uint32
         lib.hor_effect_alive_count.argtypes = [C.c_void_p]
         lib.hor_effect_counters.argtypes = [C.c_void_p, C.c_void_p]
@@ -127,6 +128,10 @@ class OracleEffect:
         s, xf = self._args(dt, time, transform, sim)
         if self._lib.hor_effect_update_pass(self._fx, s.ctypes.data, int(seed) & 0xFFFFFFFF, None if xf is None else xf.ctypes.data):
             raise OracleError(self._lib.hor_effect_error(self._fx).decode())
+
+    def set_list_order(self, by_slot):
+        """Second canonical schedule: survivors of an update are left in increasing slot order."""
+        self._lib.hor_effect_set_list_order(self._fx, int(bool(by_slot)))
 
     def set_parent(self, parent, channel, event_capacity=256):
         """EffectParent: this effect's init consumes the spawn events `parent` appends to `channel`."""

@@ -310,3 +310,70 @@ def test_ribbon_sort_is_stable_on_equal_keys(ctx):
     np.testing.assert_array_equal(g.fx.alive_list(), want)
     g.fx.destroy()
     g.prog.destroy()
+
+
+# ---- HNB_LIST_ORDER_SLOT: the second canonical schedule (lists kept in increasing slot order) -----------------
+
+@pytest.fixture(scope="module")
+def slot_ctx():
+    c = bh.Context(0)
+    c.set_list_order("slot")
+    yield c
+    c.close()
+
+
+def _slot_oracle(asset, **kw):
+    o = OracleRunner(asset, **kw)
+    o.fx.set_list_order(True)
+    return o
+
+
+def test_slot_order_firework_life_cycle(slot_ctx):
+    cap = 20000
+    asset = effects.firework_trails(cap)
+    frames = burst_then_run(cap, 80) + [Frame(1 / 60, 7777, frame_seed(100))] + [Frame(1 / 60, 0, frame_seed(101 + f)) for f in range(30)]
+    g = GpuRunner(asset, ctx=slot_ctx)
+    st = run_script(g, frames, _slot_oracle(asset), every=6)
+    alive = st["alive"].astype(np.int64)
+    assert len(alive) > 1 and (np.diff(alive) > 0).all()   # the list really is in slot order
+    g.prog.destroy()
+
+
+def test_slot_order_churn_batch(slot_ctx):
+    """Steady spawn/kill churn over a batch of instances: slots are recycled last-killed-first, the list stays sorted."""
+    cap, n_inst = 9000, 4
+    asset = effects.instancing(cap, rate=cap / 0.25)
+    w = bh.ExprWriter()
+    prog = slot_ctx.create_program(bh.lower(asset))
+    fxs = [prog.create_effect() for _ in range(n_inst)]
+    orcs = [_slot_oracle(asset) for _ in range(n_inst)]
+    # shorten lifetimes through AGE writes? not needed: rate = cap / 0.25 s fills the capacity, then spawns are capped
+    sps = [bh.EffectSpawner(asset.spawner) for _ in range(n_inst)]
+    rng = bh.Pcg32()
+    for f in range(60):
+        slot_ctx.frame_begin(1 / 60, f / 60)
+        for i, (fx, orc, sp) in enumerate(zip(fxs, orcs, sps)):
+            n, seed = (sp.tick(1 / 60, rng) if (f + i) % 3 else 0), frame_seed(f * 16 + i)
+            fx.set_frame(n, seed)
+            orc.step(Frame(1 / 60, n, seed, time=f / 60))
+        slot_ctx.simulate()
+        if f % 10 == 9:
+            for fx, orc in zip(fxs, orcs):
+                ref = orc.state()
+                np.testing.assert_array_equal(ref["alive"], fx.alive_list())
+                np.testing.assert_array_equal(ref["dead"], fx.dead_list())
+                for a in (A.POSITION, A.VELOCITY, A.AGE, A.LIFETIME):
+                    np.testing.assert_array_equal(ref["attrs"][a.name], fx.read_attr(a.id).view(np.uint32))
+    prog.destroy()
+
+
+@pytest.mark.parametrize("name", ["update_generic", "update_all_macros", "shapes_volume_local"])
+def test_slot_order_zoo(slot_ctx, name):
+    asset = ZOO[name]()
+    cap = asset.capacity
+    frames = [Frame(1 / 60, cap // 2, frame_seed(0))]
+    for f in range(1, 60):
+        frames.append(Frame(1 / 60, (cap // 9) if f % 5 == 0 else 0, frame_seed(f), time=f / 60.0))
+    g = GpuRunner(asset, ctx=slot_ctx)
+    run_script(g, frames, _slot_oracle(asset), every=10)
+    g.prog.destroy()

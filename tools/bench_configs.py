@@ -82,6 +82,30 @@ if "c4" in which:
     tot = cap * n_inst
     print(f"   -> {tot * 68 / (tm['update_ms_avg'] * 1e-3) / 1e9:.1f} GB/s @68B, {tot / ((tm['update_ms_avg'] + tm['compact_ms_avg']) * 1e-3):.3e} updates/s (kernels)")
     prog.destroy()
+if "churn" in which:
+    # steady spawn/kill churn over many instances: every instance spawns and loses ~3 % of its particles per frame
+    A = bh.Attribute
+    cap, n_inst = int(os.environ.get("CHURN_CAP", "65536")), int(os.environ.get("C4_INST", "1024"))
+    w = bh.ExprWriter()
+    mods = [bh.SetPositionSphereModifier(w.lit((0.0, 0.0, 0.0)).expr(), w.lit(1.0).expr(), bh.ShapeDimension.Volume),
+            bh.SetVelocitySphereModifier(w.lit((0.0, 0.0, 0.0)).expr(), w.lit(2.0).expr()),
+            bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()), bh.SetAttributeModifier(A.LIFETIME, w.lit(0.3).uniform(w.lit(0.6)).expr())]
+    asset = bh.EffectAsset(cap, bh.SpawnerSettings.rate(cap * 2.0), w.finish())
+    for m in mods: asset.init(m)
+    asset.update(bh.AccelModifier(w.lit((0.0, -3.0, 0.0)).expr())) if False else None
+    per_frame = int(cap * 2.0 / 60)
+    for order in ("spawn", "slot"):
+        ctx.set_list_order(order)
+        prog = ctx.create_program(bh.lower(asset))
+        fxs = [prog.create_effect() for _ in range(n_inst)]
+        tm = run(f"churn {n_inst}x{cap}, {per_frame} spawns/instance/frame, list order = {order}", prog, fxs, 30, lambda f, i: per_frame, 56, warm=45)
+        alive = sum(fx.alive_count() for fx in fxs[:8]) / 8
+        tot = alive * n_inst
+        k = tm['update_ms_avg'] + tm['compact_ms_avg'] + tm['init_ms_avg']
+        print(f"   -> steady alive/instance {alive:.0f} ({alive / cap:.2f} full); init+update+compact(+reorder) {k * 1e3:.0f} us per frame = {tot / (k * 1e-3):.3e} updates/s; update alone {tot * 56 / (tm['update_ms_avg'] * 1e-3) / 1e9:.0f} GB/s @56B")
+        prog.destroy()
+    ctx.set_list_order("spawn")
+
 if "events" in which:
     # 1M-particle parent, every dying particle spawns 16 children (OnDie) into a 16M-particle child effect
     A = bh.Attribute
