@@ -932,8 +932,9 @@ static void sort_ribbons(Effect* fx) {
  * the survivors is a legal outcome. The default canonical schedule here is "threads in increasing global id" (stable
  * compaction). order_by_slot selects a second deterministic schedule in which the update pass
  * leaves the survivors in increasing SLOT order: equally legal, and the one the product offers for steady-state
- * effects because it keeps memory accesses coalesced (HNB_LIST_ORDER_SLOT). Everything else is unchanged: threads of
- * a pass still run in list-row order, so the k-th casualty in row order lands on dead row n-1-k. */
+ * effects because it keeps memory accesses coalesced (HNB_LIST_ORDER_SLOT). The dead-slot stack is left in increasing
+ * slot order as well (any order of the casualties is a legal outcome of the reference's atomics), so that spawns fill the
+ * lowest free slots. Threads of a pass still run in list-row order. */
 void hor_effect_set_list_order(Effect* fx, int by_slot) { fx->order_by_slot = by_slot; }
 static int cmp_u32(const void* x, const void* y) { const uint32_t a = *(const uint32_t*)x, b = *(const uint32_t*)y; return a < b ? -1 : a > b; }
 
@@ -1018,6 +1019,9 @@ int hor_effect_update_pass(Effect* fx, const float* sim, uint32_t seed, const fl
     if (fx->order_by_slot && !a->in_layout[A_RIBBON_ID] && !failed) {   /* see hor_effect_set_list_order; ribbon effects are re-sorted below anyway */
         uint32_t* col = fx->list[fx->write_index];
         qsort(col, fx->alive_count, 4, cmp_u32);
+        /* ... and the free slots in increasing order on the dead rows [alive_count, capacity): spawn i of the next
+         * init pass pops dead[alive_count + i], i.e. the lowest free slots first */
+        if (fx->spawned || fx->dead_count) qsort(fx->dead + fx->alive_count, a->capacity - fx->alive_count, 4, cmp_u32);
     }
     if (a->in_layout[A_RIBBON_ID] && !failed) sort_ribbons(fx);
     return failed ? -1 : 0;
