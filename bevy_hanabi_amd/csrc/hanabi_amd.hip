@@ -954,6 +954,7 @@ int hnb_simulate(HnbContext* ctx) {
         cb.table_cap = p->table_cap;
         cb.parity = par;
         cb.ev_totals = p->d_ev_totals;
+        cb.xcd_remap = n > 1 ? 1u : 0u;
         TimingPair tu{}, tc{};
         if (timed) { hipEventCreate(&tu.a); hipEventCreate(&tu.b); hipEventCreate(&tc.b); hipEventRecord(tu.a, ctx->stream); }
         if (p->update_streams) {

@@ -124,7 +124,7 @@ int main(int argc, char** argv) {
     CompactBufs cb;
     CK(hipMalloc(&cb.counts, (size_t)sa.chunks_per_inst * 4)); CK(hipMemset(cb.counts, 0, (size_t)sa.chunks_per_inst * 4));
     CK(hipMalloc(&cb.deaths, 2 * 4 * 4)); CK(hipMemset(cb.deaths, 0, 2 * 4 * 4));
-    cb.table_cap = 4; cb.parity = 0;
+    cb.table_cap = 4; cb.parity = 0; cb.ev_totals = nullptr; cb.xcd_remap = 0;
     uint32_t* ticket = cb.deaths;
     CompactArgs ca{};
     ca.capacity = cap; ca.chunks_per_inst = sa.chunks_per_inst; ca.alive_off[0] = sa.alive_off[0]; ca.alive_off[1] = sa.alive_off[1]; ca.dead_off = sa.dead_off;
