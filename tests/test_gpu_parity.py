@@ -377,3 +377,33 @@ def test_slot_order_zoo(slot_ctx, name):
     g = GpuRunner(asset, ctx=slot_ctx)
     run_script(g, frames, _slot_oracle(asset), every=10)
     g.prog.destroy()
+
+
+@pytest.mark.parametrize("cap", [1, 3, 63, 64, 255, 256, 257, 1023, 1025, 4095, 4096, 4097, 8191, 12289])
+@pytest.mark.parametrize("order", ["spawn", "slot"])
+def test_ragged_capacities_and_random_spawn_requests(ctx, slot_ctx, cap, order):
+    """Capacities around the wave / step / chunk boundaries, spawn requests from 0 to beyond the free capacity,
+    short lifetimes so that slots are recycled many times: both list orders against the oracle."""
+    c = ctx if order == "spawn" else slot_ctx
+    w = bh.ExprWriter()
+    mods = [bh.SetPositionSphereModifier(w.lit((0.0, 0.0, 0.0)).expr(), w.lit(1.0).expr(), bh.ShapeDimension.Volume),
+            bh.SetVelocitySphereModifier(w.lit((0.0, 0.0, 0.0)).expr(), w.lit(2.0).expr()),
+            bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()), bh.SetAttributeModifier(A.LIFETIME, w.lit(0.02).uniform(w.lit(0.2)).expr())]
+    upd = [bh.LinearDragModifier(w.lit(2.0).expr()), bh.AccelModifier(w.lit((0.0, -5.0, 0.0)).expr())]
+    asset = bh.EffectAsset(cap, bh.SpawnerSettings.once(1.0), w.finish())
+    for m in mods:
+        asset.init(m)
+    for m in upd:
+        asset.update(m)
+    g = GpuRunner(asset, ctx=c)
+    o = OracleRunner(asset)
+    o.fx.set_list_order(order == "slot")
+    rng = np.random.default_rng(cap)
+    frames = []
+    for f in range(48):
+        r = rng.random()
+        spawn = 0 if r < 0.25 else (cap * 3 if r > 0.9 else int(rng.integers(0, max(2, cap // 2 + 2))))
+        frames.append(Frame(1 / 60, spawn, frame_seed(f + cap), time=f / 60))
+    run_script(g, frames, o, every=8)
+    g.fx.destroy()
+    g.prog.destroy()
