@@ -187,9 +187,11 @@ class EffectSpec:
 class OracleSystem:
     name = "oracle"
 
-    def __init__(self, specs, omp=False):
+    def __init__(self, specs, omp=False, slot_order=False):
         self.specs = specs
         self.fx = [oracle.OracleEffect(bh.serialize_asset(s.asset), omp=omp) for s in specs]
+        for fx in self.fx:
+            fx.set_list_order(slot_order)
         for s, fx in zip(specs, self.fx):
             if s.parent is not None:
                 fx.set_parent(self.fx[s.parent], s.channel, s.event_capacity)

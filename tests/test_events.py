@@ -226,3 +226,21 @@ def tiny_parent_without_u32():
     pos = w.lit((0.0, 0.0, 0.0)).expr()
     emit = bh.EmitSpawnEventModifier(bh.EventEmitCondition.Always, w.lit(bh.Value.u32(1)).expr(), 0)
     return bh.EffectAsset(8, bh.SpawnerSettings.once(1.0), w.finish()).init(bh.SetAttributeModifier(A.POSITION, pos)).update(emit)
+
+
+@pytest.mark.gpu
+def test_gpu_real_firework_slot_order():
+    """The three-effect firework with the lists kept in slot order (HNB_LIST_ORDER_SLOT): events are appended in
+    list-row order, which now is the slot order, in the product and in the oracle alike."""
+    c = bh.Context(0)
+    c.set_list_order("slot")
+    specs = firework_system((4096, 65536), caps=(32, 4000, 30000))
+    g, o = GpuSystem(specs, c), OracleSystem(specs, slot_order=True)
+    frames = firework_frames(200, specs[0].asset)
+    for f, fr in enumerate(frames):
+        g.step(fr)
+        o.step(fr)
+        if f % 25 == 24 or f == len(frames) - 1:
+            assert_same_system_state(o.state(), g.state(), f"frame {f}")
+    assert g.state()[2]["counters"]["particle_counter"] > 1000
+    c.close()
