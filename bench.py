@@ -160,7 +160,7 @@ def main():
             "config": {"workload": f"firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst spawner, all particles alive",
                        "capacity_per_gpu": cap, "dt": dt, "sharding": f"capacity slab x{n_gpus}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": PMC_TRAFFIC_BYTES.get(cap), "traffic_unit": "B/launch", "traffic_source": PMC_TRAFFIC_SOURCE, "kernel": "k_update_stream<ProgDragAccel>", "kernel_ms_avg": k_ms, "compact_ms_avg": timing["compact_ms_avg"],
+                         "traffic": PMC_TRAFFIC_BYTES.get(cap), "traffic_unit": "B/launch", "traffic_source": PMC_TRAFFIC_SOURCE, "kernel": "k_update_slots_stream<ProgDragAccel>", "kernel_ms_avg": k_ms, "compact_ms_avg": timing["compact_ms_avg"],
                          "kernel_samples": timing["frames"], "timing": f"HIP events on the simulation stream, every {TIMING_PERIOD}th timed frame", "bytes_per_update": BYTES_PER_UPDATE,
                          "hbm_gbs_whole_step": updates / n_gpus * BYTES_PER_UPDATE / elapsed / 1e9},
         }

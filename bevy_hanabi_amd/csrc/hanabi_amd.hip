@@ -53,12 +53,12 @@ struct TimingPair { hipEvent_t a, b; };
 // ---- streaming kernel instantiations ------------------------------------------------------------------
 // Statically specialised op sequences for the common modifier stacks (the reference's example
 // effects), plus the interpreter for every other streamable sequence.
-typedef void (*StreamLaunchFn)(uint32_t grid, hipStream_t stream, const StreamArgs& sa, const uint64_t* inst_base, const DevMeta* meta_in,
-                               const DevFrameInst* fi, const uint32_t* ublocks, const CompactBufs& cb);
+typedef void (*StreamLaunchFn)(uint32_t grid, hipStream_t stream, const SlotArgs& sa, const uint64_t* inst_base, const DevFrameInst* fi,
+                               const uint32_t* ublocks, const CompactBufs& cb);
 template <class PROG, int WAVES>
-void launch_stream(uint32_t grid, hipStream_t stream, const StreamArgs& sa, const uint64_t* inst_base, const DevMeta* meta_in,
-                   const DevFrameInst* fi, const uint32_t* ublocks, const CompactBufs& cb) {
-    k_update_stream<PROG, WAVES><<<grid, kBlock, 0, stream>>>(sa, inst_base, meta_in, fi, ublocks, cb);
+void launch_stream(uint32_t grid, hipStream_t stream, const SlotArgs& sa, const uint64_t* inst_base, const DevFrameInst* fi,
+                   const uint32_t* ublocks, const CompactBufs& cb) {
+    k_update_slots_stream<PROG, WAVES><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
 }
 #define OP_(x) (uint32_t)HNB_OP_M_##x
 typedef ProgStatic<OP_(AGE_TICK)> ProgAge;                                                        // ribbon.rs
@@ -578,7 +578,7 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     d.chunks_per_inst = (h.capacity + kChunk - 1) / kChunk;
     d.init_len = h.init_len;
     d.update_len = h.update_len;
-    // Slab layout: [alive list column 0][column 1][dead list][attribute planes...], 256-byte aligned.
+    // Slab layout: [alive list column 0][column 1][dead list][attribute planes...][alive byte per slot]..., 256-byte aligned.
     // The alive list moves to the other column only in frames where particles died (k_compact).
     size_t off = 0;
     const size_t list_bytes = align_up((size_t)h.capacity * 4, 256);
@@ -593,12 +593,10 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
         d.attrs[i].upd_flags = p->attrs[i].update_flags;
         off += align_up((size_t)h.capacity * p->attrs[i].ncomp * 4, 256);
     }
-    d.alive_flag_off = kNoPlane;
     p->slot_order = ctx->list_order == HNB_LIST_ORDER_SLOT && !(h.flags & HNB_PROG_HAS_RIBBONS);  // ribbons are re-sorted anyway
-    if (p->slot_order) { d.alive_flag_off = (uint32_t)off; off += align_up((size_t)h.capacity, 256); }  // zeroed with the attribute planes
+    d.alive_flag_off = (uint32_t)off; off += align_up((size_t)h.capacity, 256);  // alive byte per slot, zeroed with the attribute planes
     d.n_event_channels = h.n_event_channels;
-    if (h.n_event_channels) {  // per-row staging of spawn events (k_update_generic -> k_emit_events)
-        d.ev_slot_off = (uint32_t)off; off += list_bytes;
+    if (h.n_event_channels) {  // per-slot staging of spawn events (k_update_slots_generic -> k_emit_count / k_emit_events)
         for (uint32_t c = 0; c < h.n_event_channels; ++c) { d.ev_cnt_off[c] = (uint32_t)off; off += list_bytes; }
         if (off > 0xffffffffull) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB"); }
     }
@@ -957,12 +955,14 @@ int hnb_simulate(HnbContext* ctx) {
         cb.xcd_remap = n > 1 ? 1u : 0u;
         TimingPair tu{}, tc{};
         if (timed) { hipEventCreate(&tu.a); hipEventCreate(&tu.b); hipEventCreate(&tc.b); hipEventRecord(tu.a, ctx->stream); }
+        const uint32_t died_mark = p->slot_order ? 0u : 2u;
         if (p->update_streams) {
-            StreamArgs sa{};
+            SlotArgs sa{};
             sa.capacity = p->dev.capacity; sa.n_uregs = p->dev.n_uregs; sa.chunks_per_inst = p->dev.chunks_per_inst; sa.n_inst = n;
-            sa.alive_off[0] = p->dev.alive_off[0]; sa.alive_off[1] = p->dev.alive_off[1]; sa.dead_off = p->dev.dead_off;
+            sa.alive_flag_off = p->dev.alive_flag_off;
             sa.update_len = p->dev.update_len;
             sa.update_code = p->dev.update_code;
+            sa.died_mark = died_mark;
             for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
                 const DevAttr& at = p->dev.attrs[a];
                 const int pi = at.reg == HNB_REG_POSITION ? 0 : at.reg == HNB_REG_VELOCITY ? 1 : at.reg == HNB_REG_AGE ? 2 : at.reg == HNB_REG_LIFETIME ? 3 : -1;
@@ -972,28 +972,32 @@ int hnb_simulate(HnbContext* ctx) {
                 if (at.upd_flags & HNB_ATTR_UPD_STORE) sa.flags |= 16u << pi;
             }
             if (p->jit_update) {
-                const DevMeta* mi = p->d_meta[par];
-                void* ka[] = {&sa, &p->d_inst_base, &mi, &dfi, &dub, &cb};
+                void* ka[] = {&sa, &p->d_inst_base, &dfi, &dub, &cb};
                 HIP_TRY(hipModuleLaunchKernel(p->jit_update, total_chunks, 1, 1, kBlock, 1, 1, 0, ctx->stream, ka, nullptr));
             } else {
-                p->stream_launch(total_chunks, ctx->stream, sa, p->d_inst_base, p->d_meta[par], dfi, dub, cb);
+                p->stream_launch(total_chunks, ctx->stream, sa, p->d_inst_base, dfi, dub, cb);
             }
         } else if (p->jit_update) {
-            const DevMeta* mi = p->d_meta[par];
-            void* ka[] = {&p->dev, &p->d_inst_base, &mi, &dfi, &dub, &cb};
+            uint32_t dm = died_mark;
+            void* ka[] = {&p->dev, &p->d_inst_base, &dfi, &dub, &cb, &dm};
             HIP_TRY(hipModuleLaunchKernel(p->jit_update, total_chunks, 1, 1, kBlock, 1, 1, 0, ctx->stream, ka, nullptr));
         } else {
-            k_update_generic<InterpCode><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub, cb);
+            k_update_slots_generic<InterpCode><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, dfi, dub, cb, died_mark);
         }
         if (timed) { hipEventRecord(tu.b, ctx->stream); ctx->t_update.push_back(tu); }
-        if (p->dev.n_event_channels)  // order this frame's spawn events into the children's buffers
-            k_emit_events<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb);
         CompactArgs ca{};
         ca.capacity = p->dev.capacity; ca.chunks_per_inst = p->dev.chunks_per_inst;
         ca.alive_off[0] = p->dev.alive_off[0]; ca.alive_off[1] = p->dev.alive_off[1]; ca.dead_off = p->dev.dead_off;
         ca.alive_flag_off = p->dev.alive_flag_off;
+        ca.slot_order = p->slot_order ? 1u : 0u;
+        if (p->dev.n_event_channels) {  // order this frame's spawn events (by list row) into the children's buffers
+            k_emit_count<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb);
+            k_emit_events<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb);
+        }
+        // lists: only the instances that lost particles have anything to do
+        if (!p->slot_order) k_list_rows<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
         k_compact<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
-        if (p->slot_order) {  // rebuild the list in increasing slot order (instances without a casualty or spawn return at once)
+        if (p->slot_order) {  // rebuild the lists in increasing slot order (instances without a casualty or spawn return at once)
             k_order_count<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
             k_order_write<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
         }

@@ -32,10 +32,9 @@ struct DevProgram {
     uint32_t init_len, update_len;
     uint32_t n_inst;
     // GPU spawn events this program's update appends (EmitSpawnEventModifier): per-row staging planes in the slab
-    uint32_t alive_flag_off;   // HNB_LIST_ORDER_SLOT: u8[capacity] alive flag per slot (kNoPlane = spawn-order lists)
+    uint32_t alive_flag_off;   // u8[capacity]: 0 free, 1 alive, 2 died in this frame's update (drives the slot-major update)
     uint32_t n_event_channels;
-    uint32_t ev_slot_off;                            // u32[capacity]: slot of each alive-list row (as the update saw it)
-    uint32_t ev_cnt_off[HNB_MAX_EVENT_CHANNELS];     // u32[capacity] per channel: events appended by that row
+    uint32_t ev_cnt_off[HNB_MAX_EVENT_CHANNELS];     // u32[capacity] per channel: events appended by the particle in that slot
     DevAttr attrs[kMaxAttrs];
     const Ins* init_code;
     const Ins* update_code;

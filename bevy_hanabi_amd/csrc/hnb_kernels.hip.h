@@ -179,7 +179,7 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
         CODE::zero_unassigned(prog, io);
         CODE::run_init(prog, S, U, io);
         alive[alive0 + i] = slot;
-        if (prog.alive_flag_off != kNoPlane) reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = 1u;
+        reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = 1u;  // the update walks the slots through these bytes
         CODE::store_init(prog, S, base, slot);
     }
 }
@@ -247,18 +247,16 @@ __device__ __forceinline__ void pin_store1(const float (&src)[P], char* plane, c
 }
 
 // ---- update + kill + compaction ----------------------------------------------------------------
-// Two launches per frame, no inter-workgroup communication (measured alternatives: a single-pass
-// decoupled look-back with ticketed persistent workgroups was 10-13 % slower on this short kernel
+// Launches per program per frame, none of which waits for another workgroup (measured alternative: a
+// single-pass decoupled look-back with ticketed persistent workgroups was 10-13 % slower on this short kernel
 // because of its scheduling tail and spin-waits):
-//   k_update_*  one workgroup per 4096-row chunk of the alive list: runs the UPDATE program, ranks
-//               survivors / casualties inside each wave with ballots, and — only if something in
-//               the chunk died — rewrites the chunk's own rows as [survivors | casualties]. It
-//               records the chunk's survivor count and adds its casualties to the instance total.
-//   k_compact   per chunk: if the instance had no casualty this frame the alive list is already
-//               final and the workgroup exits; otherwise it sums the survivor counts of the earlier
-//               chunks (exclusive prefix), moves its survivors to the other list column and pushes
-//               its casualties on the dead list in serial order. It also rotates the counters
-//               (vfx_indirect.wgsl:57-85).
+//   k_update_slots_*  the UPDATE program over the SLOTS (see "Slot-major update" below);
+//   k_list_rows       only for instances that lost particles: every 4096-row chunk of the alive list becomes
+//                     [survivors | casualties] in row order, survivor count recorded;
+//   k_compact         per chunk: if the instance had no casualty the list is final and the workgroup only
+//                     rotates the counters (vfx_indirect.wgsl:57-85); otherwise exclusive prefix of the earlier
+//                     chunks' survivor counts, survivors move to the other list column, casualties are pushed on
+//                     the dead list in serial order.
 struct ChunkCtx {
     uint32_t k, j;          // instance, chunk within instance
     uint32_t n;             // max_update of the instance
@@ -362,6 +360,18 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
         }
         return;
     }
+    if (args.slot_order) {  // the lists are rebuilt from the alive bytes: only the counters move
+        if (c.j == 0 && tid == 0) {
+            const uint32_t survivors = c.n - total_dead;
+            DevMeta o = c.m;
+            o.alive_count = survivors;
+            o.particle_counter = c.m.particle_counter + c.n_spawn;
+            o.ref_write_index = c.m.ref_write_index ^ 1u;
+            o.max_update = c.n; o.dead_count = total_dead; o.spawned = c.n_spawn; o.instance_count = survivors;
+            meta_out[c.k] = o;
+        }
+        return;
+    }
     if (!has_rows) return;
     // exclusive prefix of the survivor counts of the earlier chunks of this instance
     const uint32_t* cnt = cb.counts + (size_t)c.k * args.chunks_per_inst;
@@ -380,23 +390,21 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     uint32_t* dst = reinterpret_cast<uint32_t*>(c.base + args.alive_off[c.m.write_index ^ 1u]) + excl;
     uint32_t* dead = reinterpret_cast<uint32_t*>(c.base + args.dead_off);
     const uint32_t dead_before = c.start - excl;
-    const bool slot_order = args.alive_flag_off != kNoPlane;
-    if (slot_order) {
-        // the list and the free-slot stack are rebuilt from the alive bytes by k_order_write: only clear the casualties' bytes
-        uint8_t* flags = reinterpret_cast<uint8_t*>(c.base + args.alive_flag_off);
-        for (uint32_t i = tid; i < rows - a; i += kBlock) flags[src[a + i]] = 0u;
-    } else {
-        // survivors keep their (stable, serial) order (vfx_update.wgsl:161-165)
-        for (uint32_t i = tid; i < a; i += kBlock) dst[i] = src[i];
-        // the d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151)
-        for (uint32_t i = tid; i < rows - a; i += kBlock) dead[c.n - 1u - (dead_before + i)] = src[a + i];
+    // survivors keep their (stable, serial) order (vfx_update.wgsl:161-165)
+    for (uint32_t i = tid; i < a; i += kBlock) dst[i] = src[i];
+    // the d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151); its slot is free again
+    uint8_t* flags = reinterpret_cast<uint8_t*>(c.base + args.alive_flag_off);
+    for (uint32_t i = tid; i < rows - a; i += kBlock) {
+        const uint32_t slot = src[a + i];
+        dead[c.n - 1u - (dead_before + i)] = slot;
+        flags[slot] = 0u;
     }
     if (last && tid == 0) {
         const uint32_t survivors = excl + a;
         DevMeta o = c.m;
         o.alive_count = survivors;
         o.particle_counter = c.m.particle_counter + c.n_spawn;
-        o.write_index = slot_order ? c.m.write_index : c.m.write_index ^ 1u;  // spawn order: the list now lives in the other column
+        o.write_index = c.m.write_index ^ 1u;  // the list now lives in the other column
         o.ref_write_index = c.m.ref_write_index ^ 1u;
         o.max_update = c.n;
         o.dead_count = c.n - survivors;
@@ -409,7 +417,8 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
 struct CompactArgs {
     uint32_t capacity, chunks_per_inst;
     uint32_t alive_off[2], dead_off;
-    uint32_t alive_flag_off;   // kNoPlane unless the lists are kept in slot order
+    uint32_t alive_flag_off;   // u8[capacity]: 0 free, 1 alive, 2 died in this frame's update
+    uint32_t slot_order;       // HNB_LIST_ORDER_SLOT: k_order_write rebuilds the lists from the alive bytes
 };
 #ifndef HNB_JIT_TU
 __global__ void __launch_bounds__(kBlock)
@@ -539,10 +548,10 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
         const uint32_t mine = has_rows ? tot[(size_t)c.j * HNB_MAX_EVENT_CHANNELS] : 0u;
         if (last && tid == 0) ev->count[fi[c.k].ev_parity] = excl + mine;  // GpuChildInfo::event_count of this frame
         if (mine == 0u) continue;
-        const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c.base + prog.ev_cnt_off[ch]) + c.start;
-        const uint32_t* slots = reinterpret_cast<const uint32_t*>(c.base + prog.ev_slot_off) + c.start;
+        const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c.base + prog.ev_cnt_off[ch]);                 // per slot
+        const uint32_t* slots = reinterpret_cast<const uint32_t*>(c.base + prog.alive_off[c.m.write_index]) + c.start;  // rows as the update saw them
         uint32_t local = 0;
-        for (uint32_t r = 0; r < kPer; ++r) { const uint32_t row = tid * kPer + r; if (row < rows) local += cnt[row]; }
+        for (uint32_t r = 0; r < kPer; ++r) { const uint32_t row = tid * kPer + r; if (row < rows) local += cnt[slots[row]]; }
         // workgroup exclusive scan of the per-thread sums
         uint32_t incl = local;
 #pragma unroll
@@ -556,9 +565,9 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
         for (uint32_t r = 0; r < kPer && pos < capacity; ++r) {
             const uint32_t row = tid * kPer + r;
             if (row >= rows) break;
-            const uint32_t n_ev = cnt[row];
-            if (!n_ev) continue;
             const uint32_t slot = slots[row];
+            const uint32_t n_ev = cnt[slot];
+            if (!n_ev) continue;
             const uint32_t end = pos + n_ev < capacity ? pos + n_ev : capacity;
             for (uint32_t e = pos; e < end; ++e) ev->data[e] = slot;
             pos += n_ev;
@@ -568,263 +577,248 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
 }
 #endif
 
-// ---- generic update kernel: any update stream, V register file, one particle per lane ----------
-template <class CODE>
-__global__ void __launch_bounds__(kBlock)
-k_update_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
-                 const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
-    __shared__ uint32_t s_list[kChunk];
-    __shared__ uint32_t s_cnt[1];
-    __shared__ uint32_t s_wave[kBlock / 64];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
-    ChunkCtx c;
-    if (!chunk_setup(c, chunk, prog, inst_base, meta_in, fi)) return;
-    uint32_t* list = reinterpret_cast<uint32_t*>(c.base + prog.alive_off[c.m.write_index]);
-    const uint32_t seed_k = fi[c.k].seed, slot_base = fi[c.k].slot_base;
-    VmUniforms U;
-    U.u = ublocks + (size_t)c.k * prog.n_uregs;
-    U.xf = fi[c.k].xf;
-    uint32_t local_alive = 0, local_dead = 0;
-    uint32_t ev_sum[HNB_MAX_EVENT_CHANNELS] = {};  // this thread's spawn events per child channel
-    for (uint32_t sub = 0; sub < kChunk / kBlock; ++sub) {
-        const uint32_t li = c.start + sub * kBlock + tid;
-        if (c.start + sub * kBlock >= c.n) break;
-        const bool valid = li < c.n;
-        const uint32_t slot = valid ? list[li] : 0u;
-        VmState<vreg_file_t> S;
-        S.r = vreg_file_t{};
-        CODE::load_update(prog, S, c.base, slot, valid);
-        S.pindex = slot + slot_base;
-        S.seed = pcg_hash(S.pindex ^ seed_k);  // vfx_update.wgsl:138
-        S.pcounter = 0u;
-        S.alive = true;
-        VmAttrIO io;
-        io.slab = c.base; io.attrs = prog.attrs; io.slot = slot;
-        if (valid) {
-            CODE::run_update(prog, S, U, io);
-            CODE::store_update(prog, S, c.base, slot);
-            if (prog.n_event_channels) {  // stage the row's spawn events; k_emit_events orders them (src/lib.rs:976-993)
-                reinterpret_cast<uint32_t*>(c.base + prog.ev_slot_off)[li] = slot;
-#pragma unroll
-                for (uint32_t ch = 0; ch < HNB_MAX_EVENT_CHANNELS; ++ch)
-                    if (ch < prog.n_event_channels) {
-                        reinterpret_cast<uint32_t*>(c.base + prog.ev_cnt_off[ch])[li] = S.ev[ch];
-                        ev_sum[ch] += S.ev[ch];
-                    }
-            }
-        }
-        // chunk-local stable compaction in LDS
-        const uint32_t x = (valid && S.alive ? 1u : 0u) | ((valid && !S.alive ? 1u : 0u) << 16);
-        uint32_t incl = x;
-#pragma unroll
-        for (uint32_t off = 1; off < 64; off <<= 1) {
-            const uint32_t y = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += y;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t wbase = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < kBlock / 64; ++w) {
-            const uint32_t t = s_wave[w];
-            if (w < wave) wbase += t;
-            total += t;
-        }
-        const uint32_t excl = wbase + incl - x;
-        if (valid) {
-            if (S.alive) s_list[local_alive + (excl & 0xffffu)] = slot;
-            else s_list[kChunk - 1u - (local_dead + (excl >> 16))] = slot;
-        }
-        local_alive += total & 0xffffu;
-        local_dead += total >> 16;
-        __syncthreads();
-    }
-    if (tid == 0) s_cnt[0] = local_alive | (local_dead << 16);
-    __syncthreads();
-    chunk_record<1>(c, chunk, cb, list, s_list, kChunk, s_cnt);
-    if (prog.n_event_channels) {  // per-chunk event totals for the cross-chunk prefix of k_emit_events
-        __syncthreads();
-#pragma unroll
-        for (uint32_t ch = 0; ch < HNB_MAX_EVENT_CHANNELS; ++ch) {
-            if (ch >= prog.n_event_channels) break;
-            uint32_t v = ev_sum[ch];
-#pragma unroll
-            for (uint32_t off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0) s_wave[wave] = v;
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t t = 0;
-                for (uint32_t w2 = 0; w2 < kBlock / 64; ++w2) t += s_wave[w2];
-                cb.ev_totals[(size_t)chunk * HNB_MAX_EVENT_CHANNELS + ch] = t;
-            }
-            __syncthreads();
-        }
-    }
-}
-// ---- streaming update kernel ---------------------------------------------------------------------
-// Macro-op update streams with U operands, named registers, 4 particles per lane.
-//  * a workgroup owns a 4096-row chunk of the alive list; each of its 4 WAVES owns a private,
-//    contiguous 1024-row quarter and walks it in 4 steps of 256 rows (64 lanes x 4 rows, so the
-//    dense path moves 16 B per lane per access); the quarter's list rows are fetched up front;
-//  * survivors / casualties are ranked inside the wave with ballots (no shuffles) and staged in
-//    the wave's own LDS segment: the loop contains no workgroup barrier.
-struct StreamArgs {
-    uint32_t capacity, n_uregs, chunks_per_inst, n_inst;
-    uint32_t alive_off[2], dead_off, update_len;
-    uint32_t plane_off[4];   // position, velocity, age, lifetime
-    uint32_t flags;          // bit i: load pinned attr i; bit 4+i: store pinned attr i
-    const Ins* update_code;
-};
-
+// ---- register budgets of the streaming kernels ------------------------------------------------------
 #ifndef HNB_STREAM_WAVES
-// Waves per SIMD the lean streaming kernels are register-budgeted for. Measured on MI355X (16M
-// firework): 8 (<= 64 VGPRs) 0.266 ms, 6 (<= 80 VGPRs, what the kernel wants) 0.230 ms: the tighter
-// budget serialises the 8 loads per lane that should all be in flight.
+// Waves per SIMD the lean streaming kernels are register-budgeted for. Measured on MI355X (16M firework, the
+// row-major predecessor of k_update_slots_stream): 8 (<= 64 VGPRs) 0.266 ms, 6 (<= 80 VGPRs) 0.230 ms: a tight
+// budget serialises the loads of a 48-byte-per-lane plane that should all be in flight, and lines are fetched twice.
 #define HNB_STREAM_WAVES 6
 #endif
 #ifndef HNB_STREAM_WAVES_FULL
 #define HNB_STREAM_WAVES_FULL 5
 #endif
-constexpr uint32_t kWaveRows = kChunk / (kBlock / 64);  // 1024 rows per wave
-constexpr uint32_t kStepRows = 64 * 4;                  // 256 rows per wave step
+constexpr uint32_t kWaveRows = kChunk / (kBlock / 64);  // 1024 slots (or list rows) per wave
+constexpr uint32_t kStepRows = 64 * 4;                  // 256 per wave step: 4 per lane
 
-// PROBE (tools/stream_probe.hip only; 0 in the product): ablation bits: 2 = skip the chunk record,
-// 4 = skip stores, 8 = skip the program, 16 = skip the alive-list read (assume identity).
+// =====================================================================================================
+// Slot-major update
+// =====================================================================================================
+// What a particle becomes in a frame does not depend on where it sits in the alive list (the PRNG is seeded
+// by the slot, vfx_update.wgsl:138); only the LISTS depend on the row order. So the update walks the SLOTS,
+// driven by one alive byte per slot (0 free, 1 alive, 2 died in this frame), and never touches the alive
+// list: every access is a 16-byte load / store of 4 consecutive slots whatever the list looks like after hours
+// of spawn / kill churn. The row order only matters to a second, much lighter pass over the rows of the
+// instances that lost particles (k_list_rows: 4 bytes of list + one byte gather per row), which feeds the same
+// chunk-local / cross-chunk compaction as before, and to k_emit_events.
+struct SlotArgs {
+    uint32_t capacity, n_uregs, chunks_per_inst, n_inst;
+    uint32_t alive_flag_off, update_len;
+    uint32_t plane_off[4];   // position, velocity, age, lifetime
+    uint32_t flags;          // bit i: load pinned attr i; bit 4+i: store pinned attr i
+    uint32_t died_mark;      // byte written for a particle that dies: 2 (k_list_rows pushes it on the dead list) or 0 (slot-ordered lists)
+    const Ins* update_code;
+};
+
+// PROBE (tools/stream_probe.hip only; 0 in the product): 4 = skip stores, 8 = skip the program.
 template <class PROG, int WAVES, int PROBE = 0>
 __global__ void __launch_bounds__(kBlock, WAVES)
-k_update_stream(const StreamArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
-                const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
-    __shared__ uint32_t s_list[kChunk];
-    __shared__ uint32_t s_wave[kBlock / 64];
+k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
+                      const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
+    __shared__ uint32_t s_died[kBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
-    ChunkCtx c;
-    if (!chunk_setup(c, chunk, args, inst_base, meta_in, fi)) return;
-    const uint32_t n = c.n;
+    const uint32_t k = chunk / args.chunks_per_inst, j = chunk - k * args.chunks_per_inst;
+    if (fi[k].skip) return;  // frozen instance
+    char* base = reinterpret_cast<char*>(inst_base[k]);
     VmUniforms U;
-    U.u = ublocks + (size_t)c.k * args.n_uregs;
-    U.xf = fi[c.k].xf;
-    char* p_pos = c.base + args.plane_off[0];
-    char* p_vel = c.base + args.plane_off[1];
-    char* p_age = c.base + args.plane_off[2];
-    char* p_life = c.base + args.plane_off[3];
+    U.u = ublocks + (size_t)k * args.n_uregs;
+    U.xf = fi[k].xf;
+    char* p_pos = base + args.plane_off[0];
+    char* p_vel = base + args.plane_off[1];
+    char* p_age = base + args.plane_off[2];
+    char* p_life = base + args.plane_off[3];
+    uint32_t* flags4 = reinterpret_cast<uint32_t*>(base + args.alive_flag_off);  // 4 alive bytes per word
     const uint32_t fl = args.flags;
-    uint32_t* list = reinterpret_cast<uint32_t*>(c.base + args.alive_off[c.m.write_index]);
-    const uint32_t* alive_rd = list;
-
-    // ---- the wave's private quarter ------------------------------------------------------------------
-    const uint32_t wstart = c.start + wave * kWaveRows;
-    uint32_t* seg = s_list + wave * kWaveRows;
-    uint32_t wa = 0, wd = 0;  // wave-uniform survivor / casualty counts of this quarter
-    const uint64_t below = (1ull << lane) - 1ull;
-    // Alive-list rows of the whole quarter, fetched up front (one round trip instead of one per
-    // step) in ROW-major order: rowsT[step][p] = row step*256 + p*64 + lane, so every load
-    // instruction reads 64 consecutive rows.
-    uint32_t rowsT[kWaveRows / kStepRows][4];
+    uint32_t died_total = 0;  // wave-uniform
 #pragma unroll
     for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
+        const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;  // first of this lane's 4 slots
+        const uint32_t f4 = s0 < args.capacity ? flags4[s0 >> 2] : 0u;  // the plane is padded: slots past the capacity read 0
+        bool was[4];
 #pragma unroll
-        for (uint32_t p = 0; p < 4; ++p) {
-            const uint32_t li = wstart + step * kStepRows + p * 64u + lane;
-            rowsT[step][p] = 0u;
-            if constexpr (!(PROBE & 16)) {
-                if (li < n) rowsT[step][p] = alive_rd[li];
-            } else {
-                rowsT[step][p] = li;
-            }
-        }
-    }
-#pragma unroll
-    for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
-        const uint32_t sbase = wstart + step * kStepRows;
-        if (sbase >= n) break;
-        // Two row->lane mappings, chosen per step (wave-uniform):
-        //  dense  the 256 rows hold 256 consecutive slots starting at a multiple of 4 (a burst that
-        //         has not lost anyone yet): lane l owns rows 4l..4l+3 = 4 consecutive slots, and
-        //         every plane access is a 16-byte load / store;
-        //  sparse lane l owns rows l, 64+l, 128+l, 192+l, so each per-particle access instruction
-        //         touches 64 consecutive list rows (neighbouring slots while the list is sorted).
-        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowsT[step][0]);
-        bool run_ok = sbase + kStepRows <= n && (s0 & 3u) == 0u;
-#pragma unroll
-        for (uint32_t p = 0; p < 4; ++p) run_ok = run_ok && rowsT[step][p] == s0 + p * 64u + lane;
-        const bool dense = __all(run_ok);
+        for (int p = 0; p < 4; ++p) was[p] = ((f4 >> (8 * p)) & 0xffu) == 1u;
+        const bool any = was[0] || was[1] || was[2] || was[3];
+        if (!__any(any)) continue;
+        const bool full = was[0] && was[1] && was[2] && was[3];
         uint32_t slot[4];
-        bool valid[4];
 #pragma unroll
-        for (uint32_t p = 0; p < 4; ++p) {
-            slot[p] = dense ? s0 + lane * 4u + p : rowsT[step][p];
-            valid[p] = dense || (sbase + p * 64u + lane < n);
-        }
-
+        for (int p = 0; p < 4; ++p) slot[p] = s0 + p;
+        bool lanes_on[4] = {any, any, any, any};  // loads: the whole quad whenever one of its slots is alive
         Pinned<4> X;
 #pragma unroll
         for (int p = 0; p < 4; ++p) { X.pos[p] = V3{0, 0, 0}; X.vel[p] = V3{0, 0, 0}; X.age[p] = 0.0f; X.lifetime[p] = 0.0f; X.alive[p] = true; }
-        if (fl & 1u) pin_load3<4>(X.pos, p_pos, slot, valid, dense);
-        if (fl & 2u) pin_load3<4>(X.vel, p_vel, slot, valid, dense);
-        if (fl & 4u) pin_load1<4>(X.age, p_age, slot, valid, dense);
-        if (fl & 8u) pin_load1<4>(X.lifetime, p_life, slot, valid, dense);
-
+        if (any) {
+            if (fl & 1u) pin_load3<4>(X.pos, p_pos, slot, lanes_on, true);
+            if (fl & 2u) pin_load3<4>(X.vel, p_vel, slot, lanes_on, true);
+            if (fl & 4u) pin_load1<4>(X.age, p_age, slot, lanes_on, true);
+            if (fl & 8u) pin_load1<4>(X.lifetime, p_life, slot, lanes_on, true);
+        }
         if constexpr (!(PROBE & 8)) PROG::template run<4>(args.update_code, args.update_len, X, U);
-
         if constexpr (!(PROBE & 4)) {
-            if (fl & 16u) pin_store3<4>(X.pos, p_pos, slot, valid, dense);
-            if (fl & 32u) pin_store3<4>(X.vel, p_vel, slot, valid, dense);
-            if (fl & 64u) pin_store1<4>(X.age, p_age, slot, valid, dense);
-            if (fl & 128u) pin_store1<4>(X.lifetime, p_life, slot, valid, dense);
+            if (any) {  // a full quad is stored with 16-byte stores; otherwise only the alive slots are written
+                if (fl & 16u) pin_store3<4>(X.pos, p_pos, slot, was, full);
+                if (fl & 32u) pin_store3<4>(X.vel, p_vel, slot, was, full);
+                if (fl & 64u) pin_store1<4>(X.age, p_age, slot, was, full);
+                if (fl & 128u) pin_store1<4>(X.lifetime, p_life, slot, was, full);
+            }
         } else {
             float acc = 0.0f;  // keep the loads alive
 #pragma unroll
             for (int p = 0; p < 4; ++p) acc += X.pos[p].x + X.pos[p].y + X.pos[p].z + X.vel[p].x + X.vel[p].y + X.vel[p].z + X.age[p] + X.lifetime[p];
             if (acc == 123.456f) X.alive[0] = false;
         }
-
-        // wave-local stable ranks from ballots (no shuffles), in the row order of the mapping
-        uint32_t tot_a = 0, tot_v = 0;
-        bool al[4];
-        uint64_t ma[4], mv[4];
+        uint32_t nf = f4;
+        uint32_t died_here = 0;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            al[p] = valid[p] && X.alive[p];
+            const bool died = was[p] && !X.alive[p];
+            if (died) nf = (nf & ~(0xffu << (8 * p))) | (args.died_mark << (8 * p));
+            died_here += (uint32_t)__popcll(__ballot(died));
+        }
+        if (nf != f4) flags4[s0 >> 2] = nf;
+        died_total += died_here;
+    }
+    if (lane == 0) s_died[wave] = died_total;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t d = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kBlock / 64; ++w) d += s_died[w];
+        if (d) atomicAdd(&cb.deaths[(size_t)cb.parity * cb.table_cap + k], d);
+    }
+}
+
+// Any update program on the V register file: one slot per lane, same protocol.
+template <class CODE>
+__global__ void __launch_bounds__(kBlock)
+k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
+                       const uint32_t* __restrict__ ublocks, const CompactBufs cb, const uint32_t died_mark) {
+    __shared__ uint32_t s_died[kBlock / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
+    const uint32_t k = chunk / prog.chunks_per_inst, j = chunk - k * prog.chunks_per_inst;
+    if (fi[k].skip) return;
+    char* base = reinterpret_cast<char*>(inst_base[k]);
+    uint8_t* flags = reinterpret_cast<uint8_t*>(base + prog.alive_flag_off);
+    const uint32_t seed_k = fi[k].seed, slot_base = fi[k].slot_base;
+    VmUniforms U;
+    U.u = ublocks + (size_t)k * prog.n_uregs;
+    U.xf = fi[k].xf;
+    uint32_t died_total = 0;
+    for (uint32_t sub = 0; sub < kChunk / kBlock; ++sub) {
+        const uint32_t slot = j * kChunk + sub * kBlock + tid;
+        const bool valid = slot < prog.capacity && flags[slot] == 1u;
+        if (!__any(valid)) continue;
+        VmState<vreg_file_t> S;
+        S.r = vreg_file_t{};
+        CODE::load_update(prog, S, base, slot, valid);
+        S.pindex = slot + slot_base;
+        S.seed = pcg_hash(S.pindex ^ seed_k);  // vfx_update.wgsl:138
+        S.pcounter = 0u;
+        S.alive = true;
+        VmAttrIO io;
+        io.slab = base; io.attrs = prog.attrs; io.slot = slot;
+        if (valid) {
+            CODE::run_update(prog, S, U, io);
+            CODE::store_update(prog, S, base, slot);
+            if (prog.n_event_channels) {  // this slot's spawn events; k_emit_count / k_emit_events order them by list row
+#pragma unroll
+                for (uint32_t ch = 0; ch < HNB_MAX_EVENT_CHANNELS; ++ch)
+                    if (ch < prog.n_event_channels) reinterpret_cast<uint32_t*>(base + prog.ev_cnt_off[ch])[slot] = S.ev[ch];
+            }
+            if (!S.alive) flags[slot] = (uint8_t)died_mark;
+        }
+        died_total += (uint32_t)__popcll(__ballot(valid && !S.alive));
+    }
+    if (lane == 0) s_died[wave] = died_total;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t d = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kBlock / 64; ++w) d += s_died[w];
+        if (d) atomicAdd(&cb.deaths[(size_t)cb.parity * cb.table_cap + k], d);
+    }
+}
+
+#ifndef HNB_JIT_TU
+// Row-major list maintenance for the instances that lost particles this frame: every 4096-row chunk of the
+// alive list is rewritten as [survivors | casualties] (stable, in row order) from the alive bytes, and its
+// survivor count recorded; k_compact then takes the cross-chunk prefix exactly as before.
+__global__ void __launch_bounds__(kBlock)
+k_list_rows(const CompactArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+            const DevFrameInst* __restrict__ fi, const CompactBufs cb) {
+    __shared__ uint32_t s_list[kChunk];
+    __shared__ uint32_t s_wave[kBlock / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
+    ChunkCtx c;
+    if (!chunk_setup(c, chunk, args, inst_base, meta_in, fi)) return;
+    if (cb.deaths[(size_t)cb.parity * cb.table_cap + c.k] == 0u) return;  // nothing died in this instance: the list stands
+    uint32_t* list = reinterpret_cast<uint32_t*>(c.base + args.alive_off[c.m.write_index]);
+    const uint8_t* flags = reinterpret_cast<const uint8_t*>(c.base + args.alive_flag_off);
+    const uint32_t n = c.n;
+    const uint32_t wstart = c.start + wave * kWaveRows;
+    uint32_t* seg = s_list + wave * kWaveRows;
+    uint32_t wa = 0, wd = 0;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
+        const uint32_t sbase = wstart + step * kStepRows;
+        if (sbase >= n) break;
+        uint32_t slot[4];
+        bool valid[4], al[4];
+        uint64_t ma[4], mv[4];
+#pragma unroll
+        for (uint32_t p = 0; p < 4; ++p) {  // lane l owns rows l, 64+l, 128+l, 192+l of the step
+            const uint32_t row = sbase + p * 64u + lane;
+            valid[p] = row < n;
+            slot[p] = valid[p] ? list[row] : 0u;
+            al[p] = valid[p] && flags[slot[p]] == 1u;  // 2 = died in this frame's update
             ma[p] = __ballot(al[p]);
             mv[p] = __ballot(valid[p]);
-            tot_a += (uint32_t)__popcll(ma[p]);
-            tot_v += (uint32_t)__popcll(mv[p]);
         }
-        if (dense) {  // lane-major rows: everything the lower lanes own comes first
-            uint32_t before_a = 0, before_v = 0;
+        uint32_t base_a = wa, base_d = wd;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) { before_a += (uint32_t)__popcll(ma[p] & below); before_v += (uint32_t)__popcll(mv[p] & below); }
-            uint32_t ra = wa + before_a;                 // survivors of this quarter before my first row
-            uint32_t rd = wd + (before_v - before_a);    // casualties before my first row
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (al[p]) seg[ra++] = slot[p];
-                else seg[kWaveRows - 1u - (rd++)] = slot[p];
+        for (uint32_t p = 0; p < 4; ++p) {
+            const uint32_t ba = (uint32_t)__popcll(ma[p] & below), bv = (uint32_t)__popcll(mv[p] & below);
+            if (valid[p]) {
+                if (al[p]) seg[base_a + ba] = slot[p];
+                else seg[kWaveRows - 1u - (base_d + (bv - ba))] = slot[p];
             }
-        } else {      // row-major rows: group p comes after all of groups < p
-            uint32_t base_a = wa, base_d = wd;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const uint32_t ba = (uint32_t)__popcll(ma[p] & below), bv = (uint32_t)__popcll(mv[p] & below);
-                if (valid[p]) {
-                    if (al[p]) seg[base_a + ba] = slot[p];
-                    else seg[kWaveRows - 1u - (base_d + (bv - ba))] = slot[p];
-                }
-                base_a += (uint32_t)__popcll(ma[p]);
-                base_d += (uint32_t)__popcll(mv[p]) - (uint32_t)__popcll(ma[p]);
-            }
+            base_a += (uint32_t)__popcll(ma[p]);
+            base_d += (uint32_t)__popcll(mv[p]) - (uint32_t)__popcll(ma[p]);
         }
-        wa += tot_a;
-        wd += tot_v - tot_a;
+        wa = base_a;
+        wd = base_d;
     }
     if (lane == 0) s_wave[wave] = wa | (wd << 16);
     __syncthreads();
-    if constexpr (PROBE & 2) {
-        if (s_wave[0] == 0xffffffffu) cb.counts[chunk] = 1;
-        return;
-    }
     chunk_record<kBlock / 64>(c, chunk, cb, list, s_list, kWaveRows, s_wave);
 }
+
+// Per 4096-row chunk of the alive list (as the update saw it): spawn events per channel, for the cross-chunk
+// prefix of k_emit_events. Event counts are staged per SLOT by k_update_slots_generic.
+__global__ void __launch_bounds__(kBlock)
+k_emit_count(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+             const DevFrameInst* __restrict__ fi, const CompactBufs cb) {
+    __shared__ uint32_t s_red[kBlock / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
+    ChunkCtx c;
+    if (!chunk_setup(c, chunk, prog, inst_base, meta_in, fi)) return;
+    const uint32_t* list = reinterpret_cast<const uint32_t*>(c.base + prog.alive_off[c.m.write_index]);
+    const uint32_t rows = (c.n - c.start) < kChunk ? (c.n - c.start) : kChunk;
+    for (uint32_t ch = 0; ch < prog.n_event_channels; ++ch) {
+        const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c.base + prog.ev_cnt_off[ch]);
+        uint32_t v = 0;
+        for (uint32_t r = tid; r < rows; r += kBlock) v += cnt[list[c.start + r]];
+#pragma unroll
+        for (uint32_t off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        __syncthreads();
+        if (lane == 0) s_red[wave] = v;
+        __syncthreads();
+        if (tid == 0) cb.ev_totals[(size_t)chunk * HNB_MAX_EVENT_CHANNELS + ch] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    }
+}
+#endif
+
 }  // namespace hnb

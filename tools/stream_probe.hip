@@ -1,6 +1,6 @@
 // Ablation probe for the streaming update kernel (development tool, not part of the product).
 // Builds the same data layout as the runtime for one 16M-particle effect (all alive, identity
-// alive list), then times k_update_stream<ProgDragAccel> with parts switched off, next to plain
+// alive list), then times k_update_slots_stream<ProgDragAccel> with parts switched off, next to plain
 // copy kernels moving the same number of bytes. Usage: ./stream_probe [capacity] [iters]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -91,22 +91,25 @@ int main(int argc, char** argv) {
     const int iters = argc > 2 ? atoi(argv[2]) : 20;
     const int blocks_per_cu = argc > 3 ? atoi(argv[3]) : 8;
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-    StreamArgs sa{};
-    sa.capacity = cap; sa.n_uregs = 8; sa.chunks_per_inst = (cap + kChunk - 1) / kChunk; sa.n_inst = 1;
+    SlotArgs sa{};
+    sa.capacity = cap; sa.n_uregs = 8; sa.chunks_per_inst = (cap + kChunk - 1) / kChunk; sa.n_inst = 1; sa.died_mark = 2;
     size_t off = 0;
-    sa.alive_off[0] = off; off += al((size_t)cap * 4);
-    sa.alive_off[1] = off; off += al((size_t)cap * 4);
-    sa.dead_off = off; off += al((size_t)cap * 4);
+    uint32_t alive_off[2], dead_off;
+    alive_off[0] = off; off += al((size_t)cap * 4);
+    alive_off[1] = off; off += al((size_t)cap * 4);
+    dead_off = off; off += al((size_t)cap * 4);
     sa.plane_off[0] = off; off += al((size_t)cap * 12);
     sa.plane_off[1] = off; off += al((size_t)cap * 12);
     sa.plane_off[2] = off; off += al((size_t)cap * 4);
     sa.plane_off[3] = off; off += al((size_t)cap * 4);
+    sa.alive_flag_off = off; off += al((size_t)cap);
     sa.flags = 0xf | (0x7 << 4);
     char* slab; CK(hipMalloc(&slab, off));
     std::vector<uint32_t> ident(cap); for (uint32_t i = 0; i < cap; ++i) ident[i] = i;
-    CK(hipMemcpy(slab + sa.alive_off[0], ident.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(slab + sa.alive_off[1], ident.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(slab + alive_off[0], ident.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(slab + alive_off[1], ident.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
     CK(hipMemset(slab + sa.plane_off[0], 0, (size_t)cap * 32));
+    CK(hipMemset(slab + sa.alive_flag_off, 1, (size_t)cap));
     std::vector<float> life(cap, 1e30f);
     CK(hipMemcpy(slab + sa.plane_off[3], life.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
     // program: AGE_TICK u0 ; VEL_SCALE u1 ; VEL_ADD u2..4 ; EULER u0
@@ -127,46 +130,39 @@ int main(int argc, char** argv) {
     cb.table_cap = 4; cb.parity = 0; cb.ev_totals = nullptr; cb.xcd_remap = 0;
     uint32_t* ticket = cb.deaths;
     CompactArgs ca{};
-    ca.capacity = cap; ca.chunks_per_inst = sa.chunks_per_inst; ca.alive_off[0] = sa.alive_off[0]; ca.alive_off[1] = sa.alive_off[1]; ca.dead_off = sa.dead_off;
+    ca.capacity = cap; ca.chunks_per_inst = sa.chunks_per_inst; ca.alive_off[0] = alive_off[0]; ca.alive_off[1] = alive_off[1]; ca.dead_off = dead_off;
+    ca.alive_flag_off = sa.alive_flag_off; ca.slot_order = 0;
     const double bytes = (double)cap * 68.0;
     const uint32_t grid = sa.chunks_per_inst;
     (void)blocks_per_cu;
 #define RUN(NAME, PROBE, WAVES, COMPACT)                                                                                         \
     {                                                                                                                            \
         float ms = time_ms(iters, [&] {                                                                                          \
-            k_update_stream<ProgDragAccel, WAVES, PROBE><<<grid, kBlock>>>(sa, dbase, dmeta, dfi, dub, cb);                       \
-            if (COMPACT) k_compact<<<grid, kBlock>>>(ca, dbase, dmeta, dmeta + 1, dfi, cb);                                       \
+            k_update_slots_stream<ProgDragAccel, WAVES, PROBE><<<grid, kBlock>>>(sa, dbase, dfi, dub, cb);                       \
+            if (COMPACT) { k_list_rows<<<grid, kBlock>>>(ca, dbase, dmeta, dfi, cb); k_compact<<<grid, kBlock>>>(ca, dbase, dmeta, dmeta + 1, dfi, cb); }                                       \
         });                                                                                                                      \
         printf("%-44s %8.3f ms  %7.1f GB/s (68 B/particle)\n", NAME, ms, bytes / ms / 1e6);                                       \
     }
-    RUN("k_update (waves 8)", 0, 8, 0)
-    RUN("k_update + k_compact (waves 8)", 0, 8, 1)
-    RUN("k_update (waves 7)", 0, 7, 0)
-    RUN("k_update (waves 6)", 0, 6, 0)
-    RUN("k_update + k_compact (waves 6)", 0, 6, 1)
-    RUN("k_update (waves 5)", 0, 5, 0)
-    RUN("k_update (waves 4)", 0, 4, 0)
-    RUN("k_update (waves 3)", 0, 3, 0)
-    RUN("k_update (waves 2)", 0, 2, 0)
-    RUN("no chunk record (waves 6)", 2, 6, 0)
-    RUN("no chunk record", 2, 8, 0)
-    RUN("no record, no stores", 6, 8, 0)
-    RUN("no record, no program", 10, 8, 0)
-    RUN("no record, identity list", 18, 8, 0)
-    RUN("no record, no stores, identity", 22, 8, 0)
+    RUN("k_update_slots (budget 8)", 0, 8, 0)
+    RUN("k_update_slots (budget 6)", 0, 6, 0)
+    RUN("k_update_slots + k_list_rows + k_compact (6)", 0, 6, 1)
+    RUN("k_update_slots (budget 5)", 0, 5, 0)
+    RUN("k_update_slots (budget 4)", 0, 4, 0)
+    RUN("no stores", 4, 6, 0)
+    RUN("no program", 8, 6, 0)
     {
         float ms = time_ms(iters, [&] { k_compact<<<grid, kBlock>>>(ca, dbase, dmeta, dmeta + 1, dfi, cb); });
         printf("%-44s %8.3f ms\n", "k_compact alone (no deaths)", ms);
     }
     {
-        float ms = time_ms(iters, [&] { k_ideal<<<cap / 4 / 256, 256>>>((uint32_t*)(slab + sa.alive_off[0]), (float*)(slab + sa.plane_off[0]), (float*)(slab + sa.plane_off[1]), (float*)(slab + sa.plane_off[2]), (float*)(slab + sa.plane_off[3]), (uint32_t*)(slab + sa.alive_off[1]), cap, 1.f / 60, 0.93f, -0.26f); });
+        float ms = time_ms(iters, [&] { k_ideal<<<cap / 4 / 256, 256>>>((uint32_t*)(slab + alive_off[0]), (float*)(slab + sa.plane_off[0]), (float*)(slab + sa.plane_off[1]), (float*)(slab + sa.plane_off[2]), (float*)(slab + sa.plane_off[3]), (uint32_t*)(slab + alive_off[1]), cap, 1.f / 60, 0.93f, -0.26f); });
         printf("%-44s %8.3f ms  %7.1f GB/s\n", "hand-written ideal (no compaction)", ms, bytes / ms / 1e6);
-        ms = time_ms(iters, [&] { k_ideal_planar<<<cap / 4 / 256, 256>>>((uint32_t*)(slab + sa.alive_off[0]), (float*)(slab + sa.plane_off[0]), (float*)(slab + sa.plane_off[1]), (float*)(slab + sa.plane_off[2]), (float*)(slab + sa.plane_off[3]), (uint32_t*)(slab + sa.alive_off[1]), cap, 1.f / 60, 0.93f, -0.26f); });
+        ms = time_ms(iters, [&] { k_ideal_planar<<<cap / 4 / 256, 256>>>((uint32_t*)(slab + alive_off[0]), (float*)(slab + sa.plane_off[0]), (float*)(slab + sa.plane_off[1]), (float*)(slab + sa.plane_off[2]), (float*)(slab + sa.plane_off[3]), (uint32_t*)(slab + alive_off[1]), cap, 1.f / 60, 0.93f, -0.26f); });
         printf("%-44s %8.3f ms  %7.1f GB/s\n", "ideal, component-planar vec3 storage", ms, bytes / ms / 1e6);
     }
     {
         const size_t n16 = (size_t)cap * 32 / 16;  // 32 B/particle read + 32 B/particle written ~ 64 B/particle
-        float ms = time_ms(iters, [&] { k_copy16<<<2048, 256>>>((const uint4*)(slab + sa.plane_off[0]), (uint4*)(slab + sa.alive_off[0]), n16 / 2); });
+        float ms = time_ms(iters, [&] { k_copy16<<<2048, 256>>>((const uint4*)(slab + sa.plane_off[0]), (uint4*)(slab + alive_off[0]), n16 / 2); });
         printf("%-44s %8.3f ms  %7.1f GB/s (r+w)\n", "float4 copy 268 MB -> 268 MB, 2048 blocks", ms, (double)(n16 / 2) * 32 / ms / 1e6);
         ms = time_ms(iters, [&] { k_read16<<<2048, 256>>>((const uint4*)(slab + sa.plane_off[0]), ticket, n16); });
         printf("%-44s %8.3f ms  %7.1f GB/s (r)\n", "float4 read 537 MB", ms, (double)n16 * 16 / ms / 1e6);
