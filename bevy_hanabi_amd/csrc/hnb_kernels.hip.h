@@ -465,6 +465,7 @@ __global__ void __launch_bounds__(kBlock)
 k_order_write(const CompactArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in, const DevMeta* __restrict__ meta_out,
               const DevFrameInst* __restrict__ fi, const CompactBufs cb) {
     __shared__ uint32_t s_red[kBlock / 64];
+    __shared__ uint32_t s_alive[kChunk], s_free[kChunk];  // the chunk's alive / free slots, ascending: written out coalesced
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     ChunkCtx c;
     chunk_setup(c, chunk_of_workgroup(cb.xcd_remap), args, inst_base, meta_in, fi);
@@ -476,15 +477,16 @@ k_order_write(const CompactArgs args, const uint64_t* __restrict__ inst_base, co
     for (uint32_t off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
     if (lane == 0) s_red[wave] = part;
     __syncthreads();
-    const uint32_t excl = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const uint32_t excl = s_red[0] + s_red[1] + s_red[2] + s_red[3];  // alive slots in the earlier chunks of this instance
     __syncthreads();
     // 16 consecutive slots per thread
     constexpr uint32_t kPer = kChunk / kBlock;
-    const uint32_t first = c.j * kChunk + tid * kPer;
+    const uint32_t chunk_first = c.j * kChunk;
+    const uint32_t first = chunk_first + tid * kPer;
     const uint8_t* flags = reinterpret_cast<const uint8_t*>(c.base + args.alive_flag_off);
     uint32_t mask = 0;
     if (first < args.capacity) {
-        const uint4 f = *reinterpret_cast<const uint4*>(flags + first);  // 16 flag bytes (planes are padded to 256 B)
+        const uint4 f = *reinterpret_cast<const uint4*>(flags + first);  // 16 alive bytes (planes are padded to 256 B)
         const uint32_t words[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
         for (uint32_t q = 0; q < 4; ++q)
@@ -498,19 +500,25 @@ k_order_write(const CompactArgs args, const uint64_t* __restrict__ inst_base, co
     for (uint32_t off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
     if (lane == 63) s_red[wave] = incl;
     __syncthreads();
-    uint32_t pos = excl + incl - local;
+    uint32_t pos = incl - local;  // alive slots of this chunk before this thread's
     for (uint32_t w = 0; w < wave; ++w) pos += s_red[w];
-    uint32_t* list = reinterpret_cast<uint32_t*>(c.base + args.alive_off[meta_out[c.k].write_index & 1u]);
-    uint32_t* dead = reinterpret_cast<uint32_t*>(c.base + args.dead_off);
-    const uint32_t alive_total = meta_out[c.k].alive_count;
-    // alive slots go to the list, free slots to the dead rows [alive_total, capacity), both ascending: the next
-    // init pass pops dead[alive_total + i], so spawns fill the lowest free slots and write coalesced too
+    const uint32_t chunk_alive = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const uint32_t chunk_slots = chunk_first < args.capacity ? ((args.capacity - chunk_first) < kChunk ? (args.capacity - chunk_first) : kChunk) : 0u;
+    uint32_t fpos = tid * kPer - pos;  // free slots of this chunk before this thread's
     for (uint32_t b = 0; b < kPer; ++b) {
         const uint32_t slot = first + b;
         if (slot >= args.capacity) break;
-        if (mask & (1u << b)) list[pos++] = slot;
-        else dead[alive_total + slot - pos] = slot;  // slot - pos = free slots before this one
+        if (mask & (1u << b)) s_alive[pos++] = slot;
+        else s_free[fpos++] = slot;
     }
+    __syncthreads();
+    // alive slots go to the list, free slots to the dead rows [alive_total, capacity), both ascending: the next
+    // init pass pops dead[alive_total + i], so spawns fill the lowest free slots
+    uint32_t* list = reinterpret_cast<uint32_t*>(c.base + args.alive_off[meta_out[c.k].write_index & 1u]) + excl;
+    for (uint32_t i = tid; i < chunk_alive; i += kBlock) list[i] = s_alive[i];
+    const uint32_t alive_total = meta_out[c.k].alive_count;
+    uint32_t* dead = reinterpret_cast<uint32_t*>(c.base + args.dead_off) + alive_total + (chunk_first - excl);  // chunk_first - excl = free slots before this chunk
+    for (uint32_t i = tid; i < chunk_slots - chunk_alive; i += kBlock) dead[i] = s_free[i];
 }
 #endif
 
