@@ -21,6 +21,12 @@ def main():
         assets += [ZOO[k]() for k in sorted(ZOO)]
     except Exception as e:  # tests not present: product programs only
         print("warm_jit_cache: zoo skipped:", e)
+    # entries are keyed by the generated source and the kernel headers: drop what older builds left behind
+    cache = os.path.join(ROOT, "bevy_hanabi_amd", "jit_cache")
+    if os.path.isdir(cache) and not os.environ.get("HNB_JIT_CACHE"):
+        for f in os.listdir(cache):
+            if f.endswith((".hsaco", ".names")):
+                os.remove(os.path.join(cache, f))
     t0 = time.time()
     for a in assets:
         bh.jit_precompile(bh.lower(a))
