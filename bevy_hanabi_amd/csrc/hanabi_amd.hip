@@ -835,6 +835,25 @@ int hnb_effect_set_frame(HnbEffect* fx, uint32_t spawn_count, uint32_t seed, con
     return HNB_OK;
 }
 
+int hnb_program_set_frames(HnbProgram* prog, uint32_t first, uint32_t count, const uint32_t* spawn_counts, const uint32_t* seeds,
+                           const float* transforms3x4) {
+    if (!prog || !spawn_counts || !seeds) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    if ((size_t)first + count > prog->effects.size()) return fail(HNB_ERR_INVALID_ARG, "instance range [%u, %u) exceeds the %zu instances of the program", first, first + count, prog->effects.size());
+    for (uint32_t i = 0; i < count; ++i) {
+        HnbEffect* fx = prog->effects[first + i];
+        fx->spawn_count = spawn_counts[i];
+        fx->seed = seeds[i];
+        if (transforms3x4) memcpy(fx->xf, transforms3x4 + (size_t)i * 12, sizeof fx->xf);
+    }
+    return HNB_OK;
+}
+
+int hnb_effect_index(HnbEffect* fx, uint32_t* out_index) {
+    if (!fx || !out_index) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    *out_index = fx->index;
+    return HNB_OK;
+}
+
 int hnb_effect_set_simulated(HnbEffect* fx, int simulated) {
     if (!fx) return fail(HNB_ERR_INVALID_ARG, "fx is NULL");
     fx->simulated = simulated != 0;
@@ -908,8 +927,11 @@ int hnb_simulate(HnbContext* ctx) {
             memcpy(fi[i].xf, fx->xf, sizeof fx->xf);
             // Parameter block: the uniform stream (literals, properties, sim params and every
             // expression built only from them) evaluated here, once per instance per frame.
-            if (nu) uniform_run(p->uniform_code.data(), (uint32_t)p->uniform_code.size(), fx->props.data(), sim,
-                                ublocks + (size_t)i * nu, nu);
+            // (instances with the same property values share the result: thousands of instances of one effect cost one evaluation)
+            if (nu) {
+                if (i > 0 && fx->props == p->effects[i - 1]->props) memcpy(ublocks + (size_t)i * nu, ublocks + (size_t)(i - 1) * nu, (size_t)nu * 4);
+                else uniform_run(p->uniform_code.data(), (uint32_t)p->uniform_code.size(), fx->props.data(), sim, ublocks + (size_t)i * nu, nu);
+            }
             fx->spawn_count = 0;  // a spawn request is consumed by exactly one frame
         }
         const size_t bytes = (size_t)n * sizeof(DevFrameInst) + (size_t)n * nu * 4;

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "hnb_effect_set_parent", "hnb_frame_begin", "hnb_effect_set_frame", "hnb_effect_set_property", "hnb_simulate",
     "hnb_effect_metadata", "hnb_effect_alive_count", "hnb_effect_read_attr", "hnb_effect_read_alive_list",
     "hnb_effect_read_dead_list", "hnb_effect_write_attr", "hnb_effect_sort_ribbons", "hnb_ctx_enable_kernel_timing",
-    "hnb_ctx_kernel_timing", "hnb_program_kernel_info", "hnb_jit_precompile", "hnb_effect_set_simulated", "hnb_ctx_set_option",
+    "hnb_ctx_kernel_timing", "hnb_program_kernel_info", "hnb_jit_precompile", "hnb_effect_set_simulated", "hnb_ctx_set_option", "hnb_program_set_frames", "hnb_effect_index",
 ]
 
 
@@ -85,6 +85,8 @@ def load_library():
         lib.hnb_ctx_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         lib.hnb_effect_set_simulated.argtypes = [C.c_void_p, C.c_int]
         lib.hnb_ctx_set_option.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.hnb_program_set_frames.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.hnb_effect_index.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         lib.hnb_program_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         lib.hnb_jit_precompile.argtypes = [C.c_char_p, C.c_size_t]
         _lib = lib
@@ -172,6 +174,14 @@ class Program:
 
     def create_effect(self, slot_base=0):
         return Effect(self, slot_base)
+
+    def set_frames(self, spawn_counts, seeds, transforms=None, first=0):
+        """Per-frame inputs of instances [first, first + n) in one call (creation order)."""
+        sc = np.ascontiguousarray(spawn_counts, dtype=np.uint32)
+        sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+        assert sc.shape == sd.shape
+        xf = None if transforms is None else np.ascontiguousarray(transforms, dtype=np.float32).reshape(len(sc), 12)
+        _check(self._lib.hnb_program_set_frames(self._h, int(first), len(sc), sc.ctypes.data, sd.ctypes.data, None if xf is None else xf.ctypes.data))
 
     def kernel_info(self):
         """Which kernels run this program: 'init=jit|interp|none update=aot-stream:<name>|jit-stream|jit-generic|interp-*'."""

@@ -294,6 +294,12 @@ int hnb_frame_begin(HnbContext* ctx, const HnbSimParams* params);
 /* ... and per effect: CPU spawn count (EffectSpawner::tick), PRNG seed, row-major 3x4
  * emitter transform (NULL = identity). */
 int hnb_effect_set_frame(HnbEffect* fx, uint32_t spawn_count, uint32_t seed, const float* transform3x4);
+/* The same for a range of instances of one program in one call (instances are numbered in creation order, see
+ * hnb_effect_index; destroying an instance moves the last one into its place): the reference re-uploads one
+ * GpuSpawnerParams row per instance per frame (src/render/mod.rs:4316,4679-4687). transforms3x4 may be NULL. */
+int hnb_program_set_frames(HnbProgram* prog, uint32_t first, uint32_t count, const uint32_t* spawn_counts, const uint32_t* seeds,
+                           const float* transforms3x4);
+int hnb_effect_index(HnbEffect* fx, uint32_t* out_index);
 /* SimulationCondition (src/asset.rs, src/spawn.rs:983-991, src/render/mod.rs:4347-4356): an effect whose asset
  * says WhenVisible is neither ticked nor simulated while it is not visible. The host decides visibility and
  * passes 0 here: the instance is skipped by the following hnb_simulate calls (its state is frozen, its

@@ -125,3 +125,7 @@ def test_jit_precompile_without_a_device(tmp_path, monkeypatch):
     assert len(list(tmp_path.glob("*.hsaco"))) == 2
     with pytest.raises(bh.HanabiError):
         bh.jit_precompile(b"garbage")
+
+
+def test_batched_frame_inputs_are_declared():
+    assert "hnb_program_set_frames" in declared_symbols() and "hnb_effect_index" in declared_symbols()

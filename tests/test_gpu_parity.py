@@ -407,3 +407,28 @@ def test_ragged_capacities_and_random_spawn_requests(ctx, slot_ctx, cap, order):
     run_script(g, frames, o, every=8)
     g.fx.destroy()
     g.prog.destroy()
+
+
+def test_batched_frame_inputs_match_per_instance_calls(ctx):
+    """hnb_program_set_frames == one hnb_effect_set_frame per instance."""
+    cap, n_inst = 5000, 6
+    asset = effects.firework_trails(cap)
+    pa, pb = ctx.create_program(bh.lower(asset)), ctx.create_program(bh.lower(asset))
+    fa, fb = [pa.create_effect() for _ in range(n_inst)], [pb.create_effect() for _ in range(n_inst)]
+    rng = np.random.default_rng(7)
+    for f in range(70):
+        spawns = [int(rng.integers(0, 900)) if f % 5 == 0 else 0 for _ in range(n_inst)]
+        seeds = [frame_seed(f * 16 + i) for i in range(n_inst)]
+        xf = np.stack([translation(i, -i, 0.5 * f) for i in range(n_inst)])
+        ctx.frame_begin(1 / 60, f / 60)
+        for i, fx in enumerate(fa):
+            fx.set_frame(spawns[i], seeds[i], xf[i])
+        pb.set_frames(spawns, seeds, xf)
+        ctx.simulate()
+    for x, y in zip(fa, fb):
+        np.testing.assert_array_equal(x.alive_list(), y.alive_list())
+        np.testing.assert_array_equal(x.dead_list(), y.dead_list())
+        for a in (A.POSITION, A.VELOCITY, A.AGE, A.LIFETIME, A.COLOR):
+            np.testing.assert_array_equal(x.read_attr(a.id).view(np.uint32), y.read_attr(a.id).view(np.uint32))
+    pa.destroy()
+    pb.destroy()

@@ -15,8 +15,11 @@ def run(label, prog, fxs, frames, spawn_fn, bytes_per_update, warm=3):
     def step(timed):
         nonlocal f
         ctx.frame_begin(DT, f * DT)
-        for i, fx in enumerate(fxs):
-            fx.set_frame(spawn_fn(f, i), frame_seed(f * 4099 + i))
+        if len(fxs) > 16:   # batches: one call for all instances
+            prog.set_frames([spawn_fn(f, i) for i in range(len(fxs))], [(f * 4099 + i) * 2654435761 & 0xffffffff for i in range(len(fxs))])
+        else:
+            for i, fx in enumerate(fxs):
+                fx.set_frame(spawn_fn(f, i), frame_seed(f * 4099 + i))
         ctx.simulate(); f += 1
     for _ in range(warm): step(False)
     ctx.synchronize()
