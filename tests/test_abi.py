@@ -129,3 +129,10 @@ def test_jit_precompile_without_a_device(tmp_path, monkeypatch):
 
 def test_batched_frame_inputs_are_declared():
     assert "hnb_program_set_frames" in declared_symbols() and "hnb_effect_index" in declared_symbols()
+
+
+def test_integration_binding_lists_every_entry_point():
+    """INTEGRATION.md's Rust `extern "C"` block mirrors the header one to one."""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    bound = set(re.findall(r"pub fn (hnb_[a-z0-9_]+)\(", txt))
+    assert bound == set(declared_symbols())
