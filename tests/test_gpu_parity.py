@@ -432,3 +432,66 @@ def test_batched_frame_inputs_match_per_instance_calls(ctx):
             np.testing.assert_array_equal(x.read_attr(a.id).view(np.uint32), y.read_attr(a.id).view(np.uint32))
     pa.destroy()
     pb.destroy()
+
+
+def test_lifecycle_create_destroy_reparent(ctx):
+    """Instances come and go (slab slots are recycled, the last instance moves into a destroyed one's place),
+    children are re-parented and parents destroyed first: the survivors keep simulating correctly."""
+    cap = 3000
+    asset = effects.firework_trails(cap)
+    prog = ctx.create_program(bh.lower(asset))
+    fxs = [prog.create_effect() for _ in range(5)]
+    orcs = [OracleRunner(asset) for _ in range(5)]
+
+    def step(f):
+        ctx.frame_begin(1 / 60, f / 60)
+        for i, (fx, orc) in enumerate(zip(fxs, orcs)):
+            n, seed = (cap if f % 37 == 0 else 0), frame_seed(f * 8 + i)
+            fx.set_frame(n, seed)
+            orc.step(Frame(1 / 60, n, seed, time=f / 60))
+        ctx.simulate()
+
+    def check():
+        for fx, orc in zip(fxs, orcs):
+            ref = orc.state()
+            np.testing.assert_array_equal(ref["alive"], fx.alive_list())
+            np.testing.assert_array_equal(ref["dead"], fx.dead_list())
+            np.testing.assert_array_equal(ref["attrs"]["position"], fx.read_attr(A.POSITION.id).view(np.uint32))
+
+    for f in range(20):
+        step(f)
+    check()
+    fxs.pop(1).destroy(); orcs.pop(1)      # the last instance takes index 1
+    for f in range(20, 50):
+        step(f)
+    check()
+    fxs.append(prog.create_effect()); orcs.append(OracleRunner(asset))   # reuses the freed slab
+    fxs.pop(0).destroy(); orcs.pop(0)
+    for f in range(50, 90):
+        step(f)
+    check()
+    prog.destroy()
+
+    # event links: re-parent a child, destroy a parent before its child
+    rocket_a = ctx.create_program(bh.lower(effects.firework_rocket())).create_effect()
+    rocket_b = ctx.create_program(bh.lower(effects.firework_rocket())).create_effect()
+    child_prog = ctx.create_program(bh.lower(effects.firework_trails_child(4000)))
+    child = child_prog.create_effect()
+    child.set_parent(rocket_a, 1, 512)
+    for f in range(5):
+        ctx.frame_begin(1 / 60, f / 60)
+        rocket_a.set_frame(2, frame_seed(f)); rocket_b.set_frame(2, frame_seed(100 + f)); child.set_frame(0, frame_seed(200 + f))
+        ctx.simulate()
+    child.set_parent(rocket_b, 1, 512)     # re-parent
+    rocket_a.destroy()                      # old parent goes away
+    for f in range(5, 90):
+        ctx.frame_begin(1 / 60, f / 60)
+        rocket_b.set_frame(1 if f % 10 == 0 else 0, frame_seed(100 + f)); child.set_frame(0, frame_seed(200 + f))
+        ctx.simulate()
+    assert child.metadata()["particle_counter"] > 0   # rocket_b's explosions reached the child
+    rocket_b.destroy()                      # parent destroyed before the child
+    ctx.frame_begin(1 / 60, 2.0)
+    child.set_frame(0, 1)
+    with pytest.raises(bh.HanabiError):     # the child reads its parent particle and has none any more
+        ctx.simulate()
+    child_prog.destroy()
