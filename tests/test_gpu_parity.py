@@ -495,3 +495,34 @@ def test_lifecycle_create_destroy_reparent(ctx):
     with pytest.raises(bh.HanabiError):     # the child reads its parent particle and has none any more
         ctx.simulate()
     child_prog.destroy()
+
+
+def test_instances_with_different_property_values_share_one_launch(ctx):
+    """The reference cannot merge instances whose property values differ (batch.rs:153-173, property_key);
+    here every instance carries its own parameter block and the whole program still runs in one launch."""
+    cap, n_inst = 6000, 4
+    asset = effects.force_field(cap)
+    prog = ctx.create_program(bh.lower(asset))
+    fxs = [prog.create_effect() for _ in range(n_inst)]
+    orcs = [OracleRunner(asset) for _ in range(n_inst)]
+    for i, (fx, orc) in enumerate(zip(fxs, orcs)):
+        props = {"repulsor_position": (0.1 * i, 0.5 - 0.1 * i, 0.05 * i), "repulsor_accel": -15.0 - 3.0 * i, "attraction_accel": 20.0 + i}
+        for k, v in props.items():
+            fx.set_property(k, v)
+            orc.fx.set_property(k, v)
+    for f in range(60):
+        ctx.frame_begin(1 / 60, f / 60)
+        for i, (fx, orc) in enumerate(zip(fxs, orcs)):
+            if f == 30 and i == 2:   # a property changes mid-run on one instance only
+                fx.set_property("sticky_factor", 3.5)
+                orc.fx.set_property("sticky_factor", 3.5)
+            n, seed = (cap if f == 0 else 0), frame_seed(f * 8 + i)
+            fx.set_frame(n, seed)
+            orc.step(Frame(1 / 60, n, seed, time=f / 60))
+        ctx.simulate()
+    for fx, orc in zip(fxs, orcs):
+        ref = orc.state()
+        np.testing.assert_array_equal(ref["alive"], fx.alive_list())
+        for a in (A.POSITION, A.VELOCITY, A.AGE):
+            np.testing.assert_array_equal(ref["attrs"][a.name], fx.read_attr(a.id).view(np.uint32))
+    prog.destroy()
