@@ -526,3 +526,32 @@ def test_instances_with_different_property_values_share_one_launch(ctx):
         for a in (A.POSITION, A.VELOCITY, A.AGE):
             np.testing.assert_array_equal(ref["attrs"][a.name], fx.read_attr(a.id).view(np.uint32))
     prog.destroy()
+
+
+def test_denormals_and_special_values_match(ctx, kernels):
+    """f32 denormals are preserved (no flush to zero), and inf / NaN propagate identically (normalize of a zero vector,
+    0 * inf, division by zero) in the oracle and on the GPU, for the streaming kernel's macro ops and for the VM."""
+    w = bh.ExprWriter()
+    F = bh.ValueType(bh.ScalarType.Float)
+    init = [bh.SetAttributeModifier(A.POSITION, w.lit((0.0, 0.0, 0.0)).expr()),
+            bh.SetAttributeModifier(A.VELOCITY, (w.rand(bh.VectorType.VEC3F) * w.lit(1e-30)).expr()),     # tiny: Euler products underflow to denormals
+            bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()), bh.SetAttributeModifier(A.LIFETIME, w.lit(10.0).expr()),
+            bh.SetAttributeModifier(A.F32_0, (w.rand(F) * w.lit(1e-20)).expr()),
+            bh.SetAttributeModifier(A.F32X3_0, (w.attr(A.POSITION) - w.attr(A.POSITION)).normalized().expr()),  # normalize(0) -> NaN
+            bh.SetAttributeModifier(A.F32_1, (w.lit(1.0) / (w.rand(F) - w.rand(F)) * w.lit(0.0)).expr())]
+    upd = [bh.LinearDragModifier(w.lit(30.0).expr()),      # velocity *= 0.5 per frame: walks through the denormal range to zero
+           bh.SetAttributeModifier(A.F32_0, (w.attr(A.F32_0) * w.lit(1e-6)).expr()),
+           bh.SetAttributeModifier(A.F32_1, (w.attr(A.F32_1) + w.attr(A.F32_0)).expr())]
+    asset = bh.EffectAsset(3000, bh.SpawnerSettings.once(3000.0), w.finish())
+    for m in init:
+        asset.init(m)
+    for m in upd:
+        asset.update(m)
+    frames = [Frame(1 / 60, 3000, 11)] + [Frame(1 / 60, 0, 12 + f, time=f / 60) for f in range(1, 80)]
+    g = GpuRunner(asset, ctx=ctx)
+    st = run_script(g, frames, OracleRunner(asset), every=10)
+    f0 = st["attrs"]["f32_0"].view(np.float32)
+    assert (f0 == 0.0).all()   # ... and went through denormals on the way (checked bit-exact at every 10th frame)
+    assert np.isnan(st["attrs"]["f32x3_0"].view(np.float32)).all()
+    g.fx.destroy()
+    g.prog.destroy()
