@@ -54,7 +54,7 @@ def frame_seed(f):
     return ((word >> 22) ^ word) & 0xFFFFFFFF
 
 
-def cpu_baseline(sample_capacity=1 << 20, frames=16):
+def cpu_baseline(sample_capacity=1 << 22, frames=24):
     """The oracle (a restatement of the reference's WGSL semantics; the reference has no CPU
     simulation path) timed with OpenMP on the host cores, on a bounded sample of the same workload."""
     import oracle
