@@ -729,8 +729,9 @@ int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
     // Attribute planes start zeroed (the reference pre-fills with 0xFF only in debug builds).
     HIP_TRY(hipMemsetAsync(base + p->dev.attrs[0].plane_off, 0, p->slab_bytes - p->dev.attrs[0].plane_off, ctx->stream));
     if (p->has_ribbons) {  // {OR, AND} accumulators of the sort keys, both frame parities
-        const uint64_t bits[4] = {0ull, ~0ull, 0ull, ~0ull};
-        HIP_TRY(hipMemcpyAsync(base + p->sort.bits_off, bits, sizeof bits, hipMemcpyHostToDevice, ctx->stream));
+        SortState st[2];
+        for (SortState& z : st) { z.or_all = 0ull; z.and_all = ~0ull; z.or_tail = 0ull; z.and_tail = ~0ull; z.head_unsorted = 0u; z.pad[0] = z.pad[1] = z.pad[2] = 0u; }
+        HIP_TRY(hipMemcpyAsync(base + p->sort.bits_off, st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
     }
     // alive_count = 0, max_spawn = capacity, indirect_write_index = 0 (src/render/mod.rs:6048-6070)
     DevMeta m{};
@@ -1035,11 +1036,12 @@ int hnb_simulate(HnbContext* ctx) {
             const DevMeta* mo = p->d_meta[par ^ 1];
             const uint32_t tiles = n * so.chunks_per_inst;
             k_sort_fill<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+            k_sort_check<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
             for (uint32_t pass = 0; pass < 8; ++pass) {
                 k_sort_hist<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
                 k_sort_scatter<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
             }
-            k_sort_copy<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+            k_sort_merge<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(p->kernels_done[p->ring % kFrameRing], ctx->stream));

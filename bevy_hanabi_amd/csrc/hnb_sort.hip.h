@@ -6,17 +6,24 @@
 // elements = stable), vfx_sort_copy.wgsl (values back into the same list column); scheduled after the
 // update pass (src/render/mod.rs:4599-4618, 7372-7612).
 //
-// Here: a least-significant-digit radix sort on the 64-bit key (RIBBON_ID << 32 | AGE bits), 8 bits per
-// pass, every instance of a program in the same launches:
-//   k_sort_fill      keys / values from the compacted list + OR / AND of all keys of the instance;
-//   per pass p       k_sort_hist (LDS histogram per 4096-item tile, plus per-group sums by atomics) ->
-//                    k_sort_scatter (each tile derives its digit offsets itself from the group sums and the
-//                    histograms of the earlier tiles of its group: no serial spine scan; stable ranks by
-//                    wave match with ballots, per-round digit bases in LDS);
-//   k_sort_copy      values of the final buffer back into the list column.
-// A pass whose digit is identical in every key of the instance (known from OR ^ AND on the device,
-// e.g. the whole RIBBON_ID half when there is one ribbon) returns immediately in all three kernels, and
-// the ping-pong index is derived from the number of passes that did run, so nothing is read back.
+// Here, per instance and frame, every instance of a program in the same launches:
+//   k_sort_fill    64-bit keys (RIBBON_ID << 32 | AGE bits) and values in list order; OR / AND of the keys,
+//                  over all rows and over the TAIL = the last `spawned` rows (this frame's spawns sit at the
+//                  end of the compacted list);
+//   k_sort_check   is the HEAD (everything before the tail) still in order? It is the list the previous
+//                  frame's sort produced, minus the casualties, with every age advanced by the same dt, so
+//                  normally yes; an update program that rewrites AGE / RIBBON_ID can break it, and then the
+//                  whole list is the sort range instead of the tail;
+//   8 radix passes least-significant-digit radix sort of the RANGE (tail, or everything), 8 bits per pass:
+//                  k_sort_hist (LDS histogram per 4096-key tile + per-group sums) and k_sort_scatter (each
+//                  tile derives its digit offsets itself from the group sums and the histograms of the earlier
+//                  tiles of its group: no serial spine scan; stable ranks by wave match with ballots). A pass
+//                  whose digit is identical in every key of the range (known on the device from OR ^ AND)
+//                  returns immediately, and the ping-pong index follows from the passes that did run;
+//   k_sort_merge   stable merge of the sorted head and the sorted tail straight into the list column (head
+//                  elements first on equal keys, as in the list), by binary search into the other run; with
+//                  the whole list as range it is a plain copy.
+// Nothing is read back: every decision above is taken on the device from the same few words.
 #pragma once
 #include "hnb_kernels.hip.h"
 
@@ -34,16 +41,38 @@ struct SortArgs {
     uint32_t val_off[2];   // u32[capacity] ping-pong
     uint32_t hist_off;     // u32[chunks_per_inst][256]: per-tile digit counts of the current pass
     uint32_t gsum_off;     // u32[8 passes][groups][256]: digit counts per group of kSortGroup tiles (zeroed by k_sort_fill)
-    uint32_t bits_off;     // u64[2][2]: per frame parity {OR, AND} of the keys
+    uint32_t bits_off;     // SortState[2]: per frame parity
     uint32_t rid_plane, age_plane;  // plane offsets (kNoPlane: key half is 0)
-    uint32_t parity;       // frame parity of the bits double buffer
+    uint32_t parity;       // frame parity of the state double buffer
 };
+
+struct SortState {
+    uint64_t or_all, and_all;    // over every key of the instance
+    uint64_t or_tail, and_tail;  // over the tail rows
+    uint32_t head_unsorted;      // set by k_sort_check
+    uint32_t pad[3];
+};
+static_assert(sizeof(SortState) == 48, "SortState layout");
+
+struct SortRange {
+    uint32_t n;        // rows of the list
+    uint32_t lo;       // first row of the sort range: rows [lo, n) are radix-sorted, rows [0, lo) are already in order
+    uint64_t varying;  // key bits that differ inside the range
+};
+// n after this frame's update + compaction, and the range to sort
+__device__ __forceinline__ SortRange sort_range(const char* base, const SortArgs& a, const DevMeta& m) {
+    const SortState* st = reinterpret_cast<const SortState*>(base + a.bits_off) + a.parity;
+    SortRange r;
+    r.n = m.alive_count;
+    const uint32_t tail = m.spawned < r.n ? m.spawned : r.n;
+    if (st->head_unsorted) { r.lo = 0u; r.varying = st->or_all ^ st->and_all; }
+    else { r.lo = r.n - tail; r.varying = tail ? (st->or_tail ^ st->and_tail) : 0ull; }
+    return r;
+}
 
 struct SortPass { bool active; uint32_t src; };
 // Which ping-pong buffer pass p (0..7) reads, and whether it runs at all; p = 8 gives the buffer holding the result.
-__device__ __forceinline__ SortPass sort_pass_info(const char* base, const SortArgs& a, uint32_t pass) {
-    const uint64_t* bits = reinterpret_cast<const uint64_t*>(base + a.bits_off) + a.parity * 2u;
-    const uint64_t varying = bits[0] ^ bits[1];
+__device__ __forceinline__ SortPass sort_pass_info(uint64_t varying, uint32_t pass) {
     uint32_t ran = 0;
     for (uint32_t q = 0; q < pass; ++q) ran += ((varying >> (8u * q)) & 0xffull) ? 1u : 0u;
     SortPass r;
@@ -52,36 +81,50 @@ __device__ __forceinline__ SortPass sort_pass_info(const char* base, const SortA
     return r;
 }
 
-// n and list column after this frame's update + compaction
-__device__ __forceinline__ void sort_setup(uint32_t chunk, const SortArgs& a, const uint64_t* inst_base, const DevMeta* meta, uint32_t& k, uint32_t& j,
-                                           uint32_t& n, char*& base, uint32_t& column) {
+__device__ __forceinline__ void sort_setup(uint32_t chunk, const SortArgs& a, const uint64_t* inst_base, uint32_t& k, uint32_t& j, char*& base) {
     k = chunk / a.chunks_per_inst;
     j = chunk - k * a.chunks_per_inst;
-    n = meta[k].alive_count;
-    column = meta[k].write_index & 1u;
     base = reinterpret_cast<char*>(inst_base[k]);
+}
+
+__device__ __forceinline__ uint64_t wave_or(uint64_t v) {
+#pragma unroll
+    for (uint32_t off = 32; off > 0; off >>= 1) v |= (uint64_t)__shfl_xor((unsigned long long)v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_and(uint64_t v) {
+#pragma unroll
+    for (uint32_t off = 32; off > 0; off >>= 1) v &= (uint64_t)__shfl_xor((unsigned long long)v, off, 64);
+    return v;
 }
 
 __global__ void __launch_bounds__(kBlock)
 k_sort_fill(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta) {
-    __shared__ uint64_t s_or[kBlock / 64], s_and[kBlock / 64];
-    uint32_t k, j, n, column; char* base;
-    sort_setup(blockIdx.x, a, inst_base, meta, k, j, n, base, column);
+    __shared__ uint64_t s_acc[4][kBlock / 64];
+    uint32_t k, j; char* base;
+    sort_setup(blockIdx.x, a, inst_base, k, j, base);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint64_t* bits = reinterpret_cast<uint64_t*>(base + a.bits_off);
-    if (j == 0 && tid == 0) { bits[(a.parity ^ 1u) * 2u] = 0ull; bits[(a.parity ^ 1u) * 2u + 1u] = ~0ull; }  // re-arm next frame's pair
+    const uint32_t n = meta[k].alive_count;
+    const uint32_t tail = meta[k].spawned < n ? meta[k].spawned : n;
+    const uint32_t tail_lo = n - tail;
+    SortState* st = reinterpret_cast<SortState*>(base + a.bits_off);
+    if (j == 0 && tid == 0) {  // re-arm next frame's state
+        SortState z;
+        z.or_all = 0ull; z.and_all = ~0ull; z.or_tail = 0ull; z.and_tail = ~0ull; z.head_unsorted = 0u; z.pad[0] = z.pad[1] = z.pad[2] = 0u;
+        st[a.parity ^ 1u] = z;
+    }
     {   // clear the per-group digit sums of all 8 passes (each tile clears a slice)
         const uint32_t groups = (a.chunks_per_inst + kSortGroup - 1u) / kSortGroup;
         const uint32_t total = 8u * groups * 256u;
         uint32_t* gs = reinterpret_cast<uint32_t*>(base + a.gsum_off);
         for (uint32_t i = j * kBlock + tid; i < total; i += a.chunks_per_inst * kBlock) gs[i] = 0u;
     }
-    const uint32_t* list = reinterpret_cast<const uint32_t*>(base + a.alive_off[column]);
+    const uint32_t* list = reinterpret_cast<const uint32_t*>(base + a.alive_off[meta[k].write_index & 1u]);
     uint64_t* keys = reinterpret_cast<uint64_t*>(base + a.key_off[0]);
     uint32_t* vals = reinterpret_cast<uint32_t*>(base + a.val_off[0]);
     const uint32_t* rid = a.rid_plane == kNoPlane ? nullptr : reinterpret_cast<const uint32_t*>(base + a.rid_plane);
     const uint32_t* age = a.age_plane == kNoPlane ? nullptr : reinterpret_cast<const uint32_t*>(base + a.age_plane);
-    uint64_t vor = 0ull, vand = ~0ull;
+    uint64_t or_all = 0ull, and_all = ~0ull, or_tail = 0ull, and_tail = ~0ull;
     for (uint32_t r = 0; r < kSortTile / kBlock; ++r) {
         const uint32_t i = j * kSortTile + r * kBlock + tid;
         if (i >= n) break;
@@ -89,37 +132,57 @@ k_sort_fill(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevM
         const uint64_t key = ((uint64_t)(rid ? rid[slot] : 0u) << 32) | (uint64_t)(age ? age[slot] : 0u);
         keys[i] = key;
         vals[i] = slot;
-        vor |= key;
-        vand &= key;
+        or_all |= key; and_all &= key;
+        if (i >= tail_lo) { or_tail |= key; and_tail &= key; }
     }
-#pragma unroll
-    for (uint32_t off = 32; off > 0; off >>= 1) {
-        vor |= (uint64_t)__shfl_xor((unsigned long long)vor, off, 64);
-        vand &= (uint64_t)__shfl_xor((unsigned long long)vand, off, 64);
-    }
-    if (lane == 0) { s_or[wave] = vor; s_and[wave] = vand; }
+    or_all = wave_or(or_all); and_all = wave_and(and_all); or_tail = wave_or(or_tail); and_tail = wave_and(and_tail);
+    if (lane == 0) { s_acc[0][wave] = or_all; s_acc[1][wave] = and_all; s_acc[2][wave] = or_tail; s_acc[3][wave] = and_tail; }
     __syncthreads();
     if (tid == 0 && j * kSortTile < n) {
-        for (uint32_t w = 1; w < kBlock / 64; ++w) { vor |= s_or[w]; vand &= s_and[w]; }
-        atomicOr(reinterpret_cast<unsigned long long*>(bits + a.parity * 2u), (unsigned long long)vor);
-        atomicAnd(reinterpret_cast<unsigned long long*>(bits + a.parity * 2u + 1u), (unsigned long long)vand);
+        for (uint32_t w = 1; w < kBlock / 64; ++w) { or_all |= s_acc[0][w]; and_all &= s_acc[1][w]; or_tail |= s_acc[2][w]; and_tail &= s_acc[3][w]; }
+        SortState* cur = st + a.parity;
+        atomicOr(reinterpret_cast<unsigned long long*>(&cur->or_all), (unsigned long long)or_all);
+        atomicAnd(reinterpret_cast<unsigned long long*>(&cur->and_all), (unsigned long long)and_all);
+        if (j * kSortTile + kSortTile > tail_lo) {  // the tile reaches into the tail
+            atomicOr(reinterpret_cast<unsigned long long*>(&cur->or_tail), (unsigned long long)or_tail);
+            atomicAnd(reinterpret_cast<unsigned long long*>(&cur->and_tail), (unsigned long long)and_tail);
+        }
     }
+}
+
+// Is the head (rows before this frame's spawns) in non-decreasing key order?
+__global__ void __launch_bounds__(kBlock)
+k_sort_check(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta) {
+    uint32_t k, j; char* base;
+    sort_setup(blockIdx.x, a, inst_base, k, j, base);
+    const uint32_t n = meta[k].alive_count;
+    const uint32_t tail = meta[k].spawned < n ? meta[k].spawned : n;
+    const uint32_t head = n - tail;
+    if (j * kSortTile + 1u >= head) return;
+    const uint64_t* keys = reinterpret_cast<const uint64_t*>(base + a.key_off[0]);
+    bool bad = false;
+    for (uint32_t r = 0; r < kSortTile / kBlock; ++r) {
+        const uint32_t i = j * kSortTile + r * kBlock + threadIdx.x;
+        if (i + 1u < head) bad = bad || keys[i] > keys[i + 1u];
+    }
+    if (__any(bad) && (threadIdx.x & 63u) == 0u) (reinterpret_cast<SortState*>(base + a.bits_off) + a.parity)->head_unsorted = 1u;
 }
 
 __global__ void __launch_bounds__(kBlock)
 k_sort_hist(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta, uint32_t pass) {
     __shared__ uint32_t s_hist[256];
-    uint32_t k, j, n, column; char* base;
-    sort_setup(blockIdx.x, a, inst_base, meta, k, j, n, base, column);
-    const SortPass sp = sort_pass_info(base, a, pass);
+    uint32_t k, j; char* base;
+    sort_setup(blockIdx.x, a, inst_base, k, j, base);
+    const SortRange rg = sort_range(base, a, meta[k]);
+    const SortPass sp = sort_pass_info(rg.varying, pass);
     if (!sp.active) return;
     const uint32_t tid = threadIdx.x;
     s_hist[tid] = 0u;
     __syncthreads();
     const uint64_t* keys = reinterpret_cast<const uint64_t*>(base + a.key_off[sp.src]);
     for (uint32_t r = 0; r < kSortTile / kBlock; ++r) {
-        const uint32_t i = j * kSortTile + r * kBlock + tid;
-        if (i >= n) break;
+        const uint32_t i = rg.lo + j * kSortTile + r * kBlock + tid;
+        if (i >= rg.n) break;
         atomicAdd(&s_hist[(uint32_t)(keys[i] >> (8u * pass)) & 0xffu], 1u);
     }
     __syncthreads();
@@ -134,16 +197,18 @@ __global__ void __launch_bounds__(kBlock)
 k_sort_scatter(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta, uint32_t pass) {
     __shared__ uint32_t s_base[256];
     __shared__ uint32_t s_cnt[kBlock / 64][256];
-    uint32_t k, j, n, column; char* base;
-    sort_setup(blockIdx.x, a, inst_base, meta, k, j, n, base, column);
-    const SortPass sp = sort_pass_info(base, a, pass);
+    uint32_t k, j; char* base;
+    sort_setup(blockIdx.x, a, inst_base, k, j, base);
+    const SortRange rg = sort_range(base, a, meta[k]);
+    const SortPass sp = sort_pass_info(rg.varying, pass);
+    const uint32_t n = rg.n - rg.lo;  // keys in the range; rows below are relative to its start
     if (!sp.active || j * kSortTile >= n) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t below = (1ull << lane) - 1ull;
-    const uint64_t* skey = reinterpret_cast<const uint64_t*>(base + a.key_off[sp.src]);
-    const uint32_t* sval = reinterpret_cast<const uint32_t*>(base + a.val_off[sp.src]);
-    uint64_t* dkey = reinterpret_cast<uint64_t*>(base + a.key_off[sp.src ^ 1u]);
-    uint32_t* dval = reinterpret_cast<uint32_t*>(base + a.val_off[sp.src ^ 1u]);
+    const uint64_t* skey = reinterpret_cast<const uint64_t*>(base + a.key_off[sp.src]) + rg.lo;
+    const uint32_t* sval = reinterpret_cast<const uint32_t*>(base + a.val_off[sp.src]) + rg.lo;
+    uint64_t* dkey = reinterpret_cast<uint64_t*>(base + a.key_off[sp.src ^ 1u]) + rg.lo;
+    uint32_t* dval = reinterpret_cast<uint32_t*>(base + a.val_off[sp.src ^ 1u]) + rg.lo;
     {   // offset(d, j) = sum_{d' < d} total(d') + sum_{groups before mine} gsum(g, d) + sum_{earlier tiles of my group} hist(j', d)
         const uint32_t groups = (a.chunks_per_inst + kSortGroup - 1u) / kSortGroup;
         const uint32_t used_groups = ((n + kSortTile - 1u) / kSortTile + kSortGroup - 1u) / kSortGroup;  // groups holding keys
@@ -202,20 +267,42 @@ k_sort_scatter(const SortArgs a, const uint64_t* __restrict__ inst_base, const D
     }
 }
 
+// number of keys < x (strict) or <= x in the sorted run keys[0..count)
+__device__ __forceinline__ uint32_t sorted_rank(const uint64_t* keys, uint32_t count, uint64_t x, bool strict) {
+    if (count == 0u) return 0u;
+    // the usual ribbon frame: every new particle is younger than every old one, so one of the two ends decides
+    const uint64_t first = keys[0], last = keys[count - 1u];
+    if (strict ? last < x : last <= x) return count;
+    if (strict ? !(first < x) : !(first <= x)) return 0u;
+    uint32_t lo = 0, hi = count;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint64_t v = keys[mid];
+        if (strict ? v < x : v <= x) lo = mid + 1u; else hi = mid;
+    }
+    return lo;
+}
+
 __global__ void __launch_bounds__(kBlock)
-k_sort_copy(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta) {
-    uint32_t k, j, n, column; char* base;
-    sort_setup(blockIdx.x, a, inst_base, meta, k, j, n, base, column);
-    if (j * kSortTile >= n) return;
-    const SortPass sp = sort_pass_info(base, a, 8u);  // where the result lives
-    const uint64_t* bits = reinterpret_cast<const uint64_t*>(base + a.bits_off) + a.parity * 2u;
-    if (bits[0] == bits[1]) return;  // every key equal: no pass ran, the list is already in order
-    const uint32_t* vals = reinterpret_cast<const uint32_t*>(base + a.val_off[sp.src]);
-    uint32_t* list = reinterpret_cast<uint32_t*>(base + a.alive_off[column]);
+k_sort_merge(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta) {
+    uint32_t k, j; char* base;
+    sort_setup(blockIdx.x, a, inst_base, k, j, base);
+    const SortRange rg = sort_range(base, a, meta[k]);
+    if (j * kSortTile >= rg.n) return;
+    const uint32_t m = rg.n - rg.lo;
+    if (m == 0u) return;                              // no spawn, head in order: the list stands
+    if (rg.lo == 0u && rg.varying == 0ull) return;    // whole list in range but every key equal: the list stands
+    const uint32_t res = sort_pass_info(rg.varying, 8u).src;  // buffer holding the sorted range
+    const uint64_t* hkey = reinterpret_cast<const uint64_t*>(base + a.key_off[0]);            // head: untouched fill output
+    const uint32_t* hval = reinterpret_cast<const uint32_t*>(base + a.val_off[0]);
+    const uint64_t* tkey = reinterpret_cast<const uint64_t*>(base + a.key_off[res]) + rg.lo;  // sorted tail
+    const uint32_t* tval = reinterpret_cast<const uint32_t*>(base + a.val_off[res]) + rg.lo;
+    uint32_t* list = reinterpret_cast<uint32_t*>(base + a.alive_off[meta[k].write_index & 1u]);
     for (uint32_t r = 0; r < kSortTile / kBlock; ++r) {
         const uint32_t i = j * kSortTile + r * kBlock + threadIdx.x;
-        if (i >= n) break;
-        list[i] = vals[i];
+        if (i >= rg.n) break;
+        if (i < rg.lo) list[i + sorted_rank(tkey, m, hkey[i], true)] = hval[i];                       // head element: strictly smaller tail keys go first
+        else list[(i - rg.lo) + sorted_rank(hkey, rg.lo, tkey[i - rg.lo], false)] = tval[i - rg.lo];  // tail element: head keys <= go first
     }
 }
 
