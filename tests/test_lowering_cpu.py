@@ -312,8 +312,29 @@ def asset_ribbons_multi():
     return asset
 
 
+def asset_ribbons_rewritten_keys():
+    """The update program rewrites AGE and RIBBON_ID at random: last frame's order is worthless, the
+    ribbon sort has to order the whole list every frame (the head check of hnb_sort.hip.h fails)."""
+    w = h.ExprWriter()
+    U = h.ValueType(h.ScalarType.Uint)
+    init = [
+        h.SetPositionSphereModifier(w.lit((0.0, 0.0, 0.0)).expr(), w.lit(1.0).expr(), h.ShapeDimension.Surface),
+        h.SetAttributeModifier(A.AGE, w.lit(0.0).expr()),
+        h.SetAttributeModifier(A.LIFETIME, w.lit(5.0).expr()),
+        h.SetAttributeModifier(A.RIBBON_ID, w.lit(h.Value.u32(0)).expr()),
+    ]
+    update = [
+        h.SetAttributeModifier(A.AGE, (w.rand(F) * w.lit(3.0)).expr()),
+        h.SetAttributeModifier(A.RIBBON_ID, (w.rand(F) * w.lit(2.999)).cast(U).expr()),
+    ]
+    asset = _mk(9000, w, init, update)
+    asset.motion_integration = h.MotionIntegration.None_
+    return asset
+
+
 ZOO = {
     "ribbons_multi": asset_ribbons_multi,
+    "ribbons_rewritten_keys": asset_ribbons_rewritten_keys,
     "unary_a": asset_unary_a,
     "unary_b": asset_unary_b,
     "unary_c": asset_unary_c,
