@@ -379,7 +379,7 @@ void free_tables(HnbProgram* p) {
 }
 
 size_t frame_bytes_for(const HnbProgram* p, uint32_t n) {
-    return (size_t)n * sizeof(DevFrameInst) + (size_t)n * p->dev.n_uregs * 4 + 16;
+    return (size_t)n * sizeof(DevFrameInst) + (size_t)n * p->dev.n_uregs * 4 + (size_t)n * 4 + 16;  // + packed init_block_start[]
 }
 
 // Grow the per-program device tables to hold `need` instances, preserving state.
@@ -936,7 +936,9 @@ int hnb_simulate(HnbContext* ctx) {
             }
             fx->spawn_count = 0;  // a spawn request is consumed by exactly one frame
         }
-        const size_t bytes = (size_t)n * sizeof(DevFrameInst) + (size_t)n * nu * 4;
+        uint32_t* init_start = ublocks + (size_t)n * nu;  // packed copy of init_block_start for k_init's search
+        for (uint32_t i = 0; i < n; ++i) init_start[i] = fi[i].init_block_start;
+        const size_t bytes = (size_t)n * sizeof(DevFrameInst) + (size_t)n * nu * 4 + (size_t)n * 4;
         HIP_TRY(hipMemcpyAsync(p->d_frame[slot], h, bytes, hipMemcpyHostToDevice, ctx->upload_stream));
         p->init_blocks = blocks;
         p->dev.n_inst = n;

@@ -133,13 +133,16 @@ template <class CODE>
 __global__ void __launch_bounds__(kInitBlock)
 k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
        const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks) {
-    // Find the instance owning this workgroup: binary search over the CPU prefix sum of
-    // init workgroups (find_location_from_particle, vfx_init.wgsl:51-72, at workgroup granularity).
+    // Find the instance owning this workgroup: binary search over the CPU prefix sum of init workgroups
+    // (find_location_from_particle, vfx_init.wgsl:51-72, at workgroup granularity). The prefix sums sit in a
+    // packed array behind the parameter blocks, so the first steps of the search hit the same cached words in
+    // every workgroup (searching the 128-byte DevFrameInst rows cost ~10 dependent cache misses per workgroup).
     const uint32_t blk = blockIdx.x;
+    const uint32_t* init_start = ublocks + (size_t)prog.n_inst * prog.n_uregs;
     uint32_t lo = 0, hi = prog.n_inst;
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (blk >= fi[mid].init_block_start) lo = mid + 1; else hi = mid;
+        if (blk >= init_start[mid]) lo = mid + 1; else hi = mid;
     }
     const uint32_t k = lo - 1;
     // The instance's workgroups stride over its spawns: exactly one round for CPU spawners; for effects with a
