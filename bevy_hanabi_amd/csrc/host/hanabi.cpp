@@ -390,6 +390,63 @@ std::vector<Attribute> EffectAsset::particle_layout() const {
     return out;
 }
 
+ParticleLayout EffectAsset::reference_particle_layout() const {
+    ParticleLayout::Builder b = ParticleLayout::make();
+    for (Attribute a : particle_layout())
+        if (!a.is_pseudo()) b.append(a);
+    return b.build();
+}
+
+// ---- ParticleLayout (attributes.rs:1516-1670) --------------------------------------------------------------
+ParticleLayout ParticleLayout::Builder::build() const {
+    // remove duplicates, sort by size (ties by name: the reference sorts by name first, then by size)
+    std::vector<Attribute> v = attrs_;
+    std::sort(v.begin(), v.end(), [](Attribute x, Attribute y) { return std::string(x.name()) < std::string(y.name()); });
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    std::stable_sort(v.begin(), v.end(), [](Attribute x, Attribute y) { return x.size() < y.size(); });
+    ParticleLayout out;
+    out.unpadded_len_ = (uint32_t)v.size();
+    std::vector<Attribute> s1, s2, s3, s4;
+    for (Attribute a : v) (a.size() >= 16 ? s4 : a.size() >= 12 ? s3 : a.size() >= 8 ? s2 : s1).push_back(a);
+    uint32_t offset = 0, align = 4;
+    auto push = [&](Attribute a, uint32_t bytes) { out.layout_.push_back(AttributeLayout{a, offset, false}); offset += bytes; };
+    auto pad = [&](uint32_t at) { AttributeLayout p; p.attribute = Attribute::F32_0; p.offset = at; p.padding = true; out.layout_.push_back(p); };
+    for (Attribute a : s4) push(a, 16);
+    if (!s4.empty()) align = 16;
+    if (!s3.empty()) align = 16; else if (!s2.empty()) align = std::max<uint32_t>(align, 8);
+    const size_t pairs = std::min(s1.size(), s3.size());
+    for (size_t i = 0; i < pairs; ++i) { push(s3[i], 12); push(s1[i], 4); }        // { vec3 + scalar }
+    for (size_t i = 0; i + 1 < s2.size(); i += 2) { push(s2[i], 8); push(s2[i + 1], 8); }  // { vec2 + vec2 }
+    for (size_t i = pairs; i < s3.size(); ++i) { push(s3[i], 12); pad(offset); offset += 4; }  // vec3 + padding field
+    if (s2.size() % 2) push(s2.back(), 8);
+    for (size_t i = pairs; i < s1.size(); ++i) push(s1[i], 4);
+    for (uint32_t rem = (offset + align - 1) / align * align - offset; rem > 0; rem -= 4) { pad(offset); offset += 4; }
+    out.align_ = align;
+    return out;
+}
+ParticleLayout ParticleLayout::default_layout() {
+    return make().append(Attribute::POSITION).append(Attribute::AGE).append(Attribute::VELOCITY).append(Attribute::LIFETIME).build();
+}
+uint32_t ParticleLayout::size() const {
+    if (layout_.empty()) return 0;
+    const AttributeLayout& last = layout_.back();
+    return last.offset + (last.padding ? 4u : last.attribute.size());
+}
+bool ParticleLayout::contains(Attribute a) const {
+    for (const AttributeLayout& e : layout_) if (!e.padding && e.attribute == a) return true;
+    return false;
+}
+bool ParticleLayout::byte_offset(Attribute a, uint32_t* out) const {
+    for (const AttributeLayout& e : layout_) if (!e.padding && e.attribute == a) { *out = e.offset; return true; }
+    return false;
+}
+ParticleLayout ParticleLayout::merged_with(const std::vector<Attribute>& more) const {
+    Builder b = make();
+    for (const AttributeLayout& e : layout_) if (!e.padding) b.append(e.attribute);
+    for (Attribute a : more) b.append(a);
+    return b.build();
+}
+
 // `ToWgslString for f32` (src/lib.rs:264-269): format!("{:.6}") then parsed back by the WGSL
 // front end as an abstract float converted to f32.
 float round_literal_f32(float x) {

@@ -108,6 +108,44 @@ struct Attribute {
         F32X3_0, F32X3_1, F32X3_2, F32X3_3, F32X4_0, F32X4_1, F32X4_2, F32X4_3, U32_0, U32_1, U32_2, U32_3, RIBBON_ID;
 };
 
+// ---- ParticleLayout: the reference's interleaved (AoS) particle struct (src/attributes.rs:1479-1890) --------
+// This engine stores one packed plane per attribute instead, so the layout below drives nothing on the GPU; it is
+// mirrored because it is part of the authoring API (EffectAsset::particle_layout) and because its sizes are the
+// "bytes per particle" of the reference that DESIGN.md compares against.
+struct AttributeLayout {
+    Attribute attribute;
+    uint32_t offset = 0;
+    bool padding = false;  // one of the reference's PAD0..PAD4 filler fields
+};
+class ParticleLayout {
+   public:
+    class Builder {
+       public:
+        Builder& append(Attribute a) { attrs_.push_back(a); return *this; }
+        // WGSL struct packing as ParticleLayoutBuilder::build (attributes.rs:1516-1670): duplicates dropped, vec4 first,
+        // then {vec3 + scalar} pairs, {vec2 + vec2} pairs, padded vec3, the odd vec2, scalars; struct padded to its alignment.
+        ParticleLayout build() const;
+       private:
+        std::vector<Attribute> attrs_;
+    };
+    static Builder make() { return Builder(); }                 // ParticleLayout::new()
+    static ParticleLayout empty() { return ParticleLayout(); }
+    static ParticleLayout default_layout();                     // { position, age, velocity, lifetime }
+    bool is_empty() const { return unpadded_len_ == 0; }
+    uint32_t len() const { return unpadded_len_; }              // attributes, padding fields not counted
+    uint32_t size() const;                                      // bytes, incl. padding
+    uint32_t align() const { return align_; }
+    uint32_t min_binding_size() const { return (size() + 15u) / 16u * 16u; }  // the reference's particle stride
+    bool contains(Attribute a) const;
+    bool byte_offset(Attribute a, uint32_t* out) const;
+    const std::vector<AttributeLayout>& entries() const { return layout_; }
+    ParticleLayout merged_with(const std::vector<Attribute>& more) const;
+
+   private:
+    std::vector<AttributeLayout> layout_;
+    uint32_t align_ = 4, unpadded_len_ = 0;
+};
+
 // ---- expressions -----------------------------------------------------------------------------------
 struct ExprHandle {
     uint32_t id = 0;  // 1-based, serialised "#<id>" in the reference (expr.rs:132-213)
@@ -453,6 +491,8 @@ class EffectAsset {
     // Union of the modifiers' attributes and of every Expr::Attribute in the module
     // (asset.rs:605-624), in ascending attribute-id order.
     std::vector<Attribute> particle_layout() const;
+    // The same set as the reference's interleaved struct (sizes / offsets the reference's buffers would have).
+    ParticleLayout reference_particle_layout() const;
 
    private:
     uint32_t capacity_ = 0;

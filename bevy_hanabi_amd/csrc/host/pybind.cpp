@@ -278,6 +278,26 @@ PYBIND11_MODULE(_hanabi_host, m) {
         .def("reset", &EffectSpawner::reset)
         .def("tick", &EffectSpawner::tick);
 
+    py::class_<ParticleLayout>(m, "ParticleLayout")
+        .def_static("new", []() { return ParticleLayout::make(); })
+        .def_static("empty", &ParticleLayout::empty)
+        .def_static("default", &ParticleLayout::default_layout)
+        .def("is_empty", &ParticleLayout::is_empty)
+        .def("len", &ParticleLayout::len)
+        .def("size", &ParticleLayout::size)
+        .def("align", &ParticleLayout::align)
+        .def("min_binding_size", &ParticleLayout::min_binding_size)
+        .def("contains", &ParticleLayout::contains)
+        .def("merged_with", &ParticleLayout::merged_with)
+        .def("byte_offset", [](const ParticleLayout& l, Attribute a) -> py::object { uint32_t o; if (l.byte_offset(a, &o)) return py::int_(o); return py::none(); })
+        .def("entries", [](const ParticleLayout& l) {
+            py::list out;
+            for (const AttributeLayout& e : l.entries()) out.append(py::make_tuple(e.padding ? std::string("pad") : std::string(e.attribute.name()), e.offset));
+            return out;
+        });
+    py::class_<ParticleLayout::Builder>(m, "ParticleLayoutBuilder")
+        .def("append", [](ParticleLayout::Builder& b, Attribute a) { b.append(a); return b; })
+        .def("build", &ParticleLayout::Builder::build);
     py::class_<EffectAsset>(m, "EffectAsset")
         .def(py::init<uint32_t, const SpawnerSettings&, const Module&>(), py::arg("capacity"), py::arg("spawner"), py::arg("module"))
         .def_readwrite("name", &EffectAsset::name)
@@ -298,6 +318,7 @@ PYBIND11_MODULE(_hanabi_host, m) {
         .def("render", [](EffectAsset& a, const Modifier& md) { return a.render(md); })
         .def("add_modifier", [](EffectAsset& a, uint32_t ctx, const Modifier& md) { return a.add_modifier(ctx, md); })
         .def("particle_layout", &EffectAsset::particle_layout)
+        .def("reference_particle_layout", &EffectAsset::reference_particle_layout)
         .def_property_readonly("init_modifiers", &EffectAsset::init_modifiers)
         .def_property_readonly("update_modifiers", &EffectAsset::update_modifiers)
         .def_property_readonly("render_modifiers", &EffectAsset::render_modifiers);

@@ -136,3 +136,31 @@ def test_pcg32_is_deterministic_per_seed():
     va = [bh.CpuValue.Uniform(1.0, 3.0).sample(a) for _ in range(8)]
     vb = [bh.CpuValue.Uniform(1.0, 3.0).sample(b) for _ in range(8)]
     assert va == vb and all(1.0 <= v <= 3.0 for v in va) and len(set(va)) > 1
+
+
+def test_particle_layout_mirror():
+    """The reference's interleaved particle struct (attributes.rs:1479-1890): doc examples and the per-particle sizes
+    of the BASELINE configs. This engine stores packed planes; the layout is API only."""
+    PL = bh.ParticleLayout
+    l = PL.new().append(A.POSITION).build()                       # attributes.rs:1802-1805
+    assert l.size() == 16 and l.align() == 16 and l.len() == 1
+    l = PL.new().append(A.POSITION).append(A.SIZE).build()       # attributes.rs:1878-1883
+    assert l.byte_offset(A.SIZE) == 12 and l.size() == 16 and l.contains(A.SIZE) and not l.contains(A.AGE)
+    assert l.byte_offset(A.AGE) is None
+    d = PL.default()                                              # { position, age, velocity, lifetime }
+    assert d.size() == 32 and [n for n, _ in d.entries()] == ["position", "age", "velocity", "lifetime"]
+    assert PL.empty().is_empty() and PL.empty().size() == 0
+    l = PL.new().append(A.AGE).append(A.AGE).append(A.LIFETIME).build()   # duplicates are dropped
+    assert l.len() == 2 and l.size() == 8 and l.align() == 4
+    l = PL.new().append(A.SIZE2).build()
+    assert l.size() == 8 and l.align() == 8
+    l = PL.new().append(A.HDR_COLOR).append(A.POSITION).append(A.VELOCITY).append(A.AGE).append(A.SIZE2).build()
+    names = [n for n, _ in l.entries()]
+    assert names[0] == "hdr_color" and l.align() == 16 and l.size() % 16 == 0        # vec4 first, struct padded to its alignment
+    assert l.byte_offset(A.AGE) == l.byte_offset(A.POSITION) + 12                      # { vec3 + scalar } pairing
+    assert d.merged_with([A.COLOR]).size() == 48
+    # sizes the reference's particle buffers would have at the BASELINE configs
+    from bevy_hanabi_amd import effects
+    want = {"firework_trails": 48, "force_field": 32, "instancing": 32, "ribbon": 32}
+    for name, size in want.items():
+        assert getattr(effects, name)(64).reference_particle_layout().min_binding_size() == size, name
