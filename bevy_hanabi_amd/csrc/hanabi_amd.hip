@@ -116,6 +116,7 @@ struct HnbProgram {
     DevProgram dev{};
     Ins* d_code = nullptr;
     size_t slab_bytes = 0;
+    bool wide_file = false;       // init_regs / update_regs above HNB_VM_MAX_REGS: generic kernels use the wide V file
     bool update_streams = false;  // update stream runs on the streaming kernel (macro ops, U operands)
     StreamLaunchFn stream_launch = nullptr;  // specialised (or interpreted) streaming kernel for this update stream
     const char* stream_kernel_name = "";
@@ -324,9 +325,9 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
         !in_range(h.update_off, (uint64_t)h.update_len * 8))
         return fail(HNB_ERR_BAD_PROGRAM, "program section out of bounds");
     if ((h.uniform_off & 7) || (h.init_off & 7) || (h.update_off & 7)) return fail(HNB_ERR_BAD_PROGRAM, "code sections must be 8-byte aligned");
-    if (h.init_regs > HNB_VM_MAX_REGS || h.update_regs > HNB_VM_MAX_REGS)
+    if (h.init_regs > HNB_VM_MAX_REGS_WIDE || h.update_regs > HNB_VM_MAX_REGS_WIDE)
         return fail(HNB_ERR_BAD_PROGRAM, "program needs %u V registers, the VM has %u", std::max(h.init_regs, h.update_regs),
-                    HNB_VM_MAX_REGS);
+                    HNB_VM_MAX_REGS_WIDE);
     if (h.init_regs < HNB_REG_FIRST_FREE || h.update_regs < HNB_REG_FIRST_FREE)
         return fail(HNB_ERR_BAD_PROGRAM, "register counts must cover the pinned registers");
     if (h.n_uregs > HNB_VM_MAX_UREGS) return fail(HNB_ERR_BAD_PROGRAM, "program needs %u U registers, limit %u", h.n_uregs, HNB_VM_MAX_UREGS);
@@ -479,6 +480,7 @@ jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const
     rq.init = reinterpret_cast<const Ins*>(b + h.init_off); rq.init_len = h.init_len;
     rq.update = reinterpret_cast<const Ins*>(b + h.update_off); rq.update_len = h.update_len;
     rq.want_init = h.init_len > 0;
+    rq.wide_file = std::max(h.init_regs, h.update_regs) > HNB_VM_MAX_REGS;
     rq.want_update_stream = streams && !aot_static && h.update_len > 0;
     rq.want_update_generic = !streams && h.update_len > 0;
     bool lean = true;
@@ -633,9 +635,10 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     p->uniform_code.resize(h.uniform_len);
     if (h.uniform_len) memcpy(p->uniform_code.data(), b + h.uniform_off, (size_t)h.uniform_len * 8);
     p->update_streams = update_is_streamable(b, h, p->attrs.data());
+    p->wide_file = std::max(h.init_regs, h.update_regs) > HNB_VM_MAX_REGS;
     if (p->update_streams) select_stream_kernel(reinterpret_cast<const Ins*>(b + h.update_off), h.update_len, &p->stream_launch, &p->stream_kernel_name);
     const bool aot_static = p->update_streams && strcmp(p->stream_kernel_name, "ProgInterp") != 0;
-    p->kernel_info = std::string("init=") + (h.init_len ? "interp" : "none") + " update=" +
+    p->kernel_info = std::string(p->wide_file ? "wide-file " : "") + "init=" + (h.init_len ? "interp" : "none") + " update=" +
                      (p->update_streams ? (aot_static ? std::string("aot-stream:") + p->stream_kernel_name : std::string("interp-stream")) : std::string("interp-generic"));
     if (jit::enabled()) {
         const jit::Request rq = make_jit_request(b, h, p->attrs.data(), p->update_streams, aot_static);
@@ -648,7 +651,7 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
                 p->jit_log = std::string("loading the specialised code object failed: ") + hipGetErrorString(je);
                 p->jit_init = p->jit_update = nullptr;
             } else {
-                p->kernel_info = std::string("init=") + (p->jit_init ? "jit" : (h.init_len ? "interp" : "none")) + " update=" +
+                p->kernel_info = std::string(p->wide_file ? "wide-file " : "") + "init=" + (p->jit_init ? "jit" : (h.init_len ? "interp" : "none")) + " update=" +
                                  (p->jit_update ? (p->update_streams ? "jit-stream" : "jit-generic")
                                                 : (p->update_streams ? (aot_static ? std::string("aot-stream:") + p->stream_kernel_name : std::string("interp-stream"))
                                                                      : std::string("interp-generic")));
@@ -961,7 +964,8 @@ int hnb_simulate(HnbContext* ctx) {
                 void* ka[] = {&p->dev, &p->d_inst_base, &mi, &dfi, &dub};
                 HIP_TRY(hipModuleLaunchKernel(p->jit_init, blocks, 1, 1, kInitBlock, 1, 1, 0, ctx->stream, ka, nullptr));
             } else {
-                k_init<InterpCode><<<blocks, kInitBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub);
+                if (p->wide_file) k_init<InterpCodeWide><<<blocks, kInitBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub);
+                else k_init<InterpCode><<<blocks, kInitBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub);
             }
             if (timed) { hipEventRecord(ti.b, ctx->stream); ctx->t_init.push_back(ti); }
         }
@@ -1012,7 +1016,8 @@ int hnb_simulate(HnbContext* ctx) {
             void* ka[] = {&p->dev, &p->d_inst_base, &dfi, &dub, &cb, &dm};
             HIP_TRY(hipModuleLaunchKernel(p->jit_update, total_chunks, 1, 1, kBlock, 1, 1, 0, ctx->stream, ka, nullptr));
         } else {
-            k_update_slots_generic<InterpCode><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, dfi, dub, cb, died_mark);
+            if (p->wide_file) k_update_slots_generic<InterpCodeWide><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, dfi, dub, cb, died_mark);
+            else k_update_slots_generic<InterpCode><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, dfi, dub, cb, died_mark);
         }
         if (timed) { hipEventRecord(tu.b, ctx->stream); ctx->t_update.push_back(tu); }
         CompactArgs ca{};

@@ -47,7 +47,8 @@ __global__ void k_reset_lists(uint32_t* __restrict__ dead, uint32_t* __restrict_
 #endif
 
 // ---- V-file attribute access (generic kernels, one particle per lane) -----------------------
-__device__ __forceinline__ void vfile_store_attr(const vreg_file_t& r, uint32_t ncomp, uint32_t reg, char* plane, uint32_t slot) {
+template <class FILE_T>
+__device__ __forceinline__ void vfile_store_attr(const FILE_T& r, uint32_t ncomp, uint32_t reg, char* plane, uint32_t slot) {
     switch (ncomp) {
         case 1: reinterpret_cast<uint32_t*>(plane)[slot] = r[reg]; break;
         case 2: reinterpret_cast<u2_t*>(plane)[slot] = u2_t{r[reg], r[reg + 1]}; break;
@@ -84,6 +85,7 @@ __device__ __forceinline__ uint32_t requested_spawn(const DevFrameInst& f) {
 // interface whose bodies are straight-line code generated from the same bytecode: every decode,
 // switch and register index folds at compile time.
 struct InterpCode {
+    using file_t = vreg_file_t;
     template <class ST>
     static __device__ __forceinline__ void run_init(const DevProgram& p, ST& S, const VmUniforms& U, const VmAttrIO& io) {
         vm_run<true, false>(p.init_code, p.init_len, S, U, nullptr, nullptr, io);
@@ -122,6 +124,12 @@ struct InterpCode {
             if ((at.upd_flags & HNB_ATTR_UPD_STORE) && at.reg != HNB_REG_NONE) vfile_store_attr(S.r, at.ncomp, at.reg, base + at.plane_off, slot);
         }
     }
+};
+// The same interpreter over the wide V file (programs above HNB_VM_MAX_REGS registers). 128 dynamically
+// indexed registers do not stay in VGPRs: this is the slow-but-correct path for HNB_JIT=0; the specialised
+// kernels of such programs index the file with constants and pay nothing.
+struct InterpCodeWide : InterpCode {
+    using file_t = vreg_file_wide_t;
 };
 
 // ---- init -----------------------------------------------------------------------------------
@@ -164,8 +172,8 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
 
     for (uint32_t i = (blk - first_block) * kInitBlock + threadIdx.x; i < n_spawn; i += n_blocks * kInitBlock) {
         const uint32_t slot = dead[alive0 + i];
-        VmState<vreg_file_t> S;
-        S.r = vreg_file_t{};  // var particle = Particle();  (vfx_init.wgsl:174)
+        VmState<typename CODE::file_t> S;
+        S.r = typename CODE::file_t{};  // var particle = Particle();  (vfx_init.wgsl:174)
         S.pindex = slot + fi[k].slot_base;
         S.seed = pcg_hash(S.pindex ^ fi[k].seed);
         S.pcounter = meta_in[k].particle_counter + i;
@@ -720,8 +728,8 @@ k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_
         const uint32_t slot = j * kChunk + sub * kBlock + tid;
         const bool valid = slot < prog.capacity && flags[slot] == 1u;
         if (!__any(valid)) continue;
-        VmState<vreg_file_t> S;
-        S.r = vreg_file_t{};
+        VmState<typename CODE::file_t> S;
+        S.r = typename CODE::file_t{};
         CODE::load_update(prog, S, base, slot, valid);
         S.pindex = slot + slot_base;
         S.seed = pcg_hash(S.pindex ^ seed_k);  // vfx_update.wgsl:138

@@ -29,6 +29,14 @@ struct __attribute__((aligned(8))) Ins { uint32_t x, y; };
 // V register file of one particle: a single LLVM vector so that dynamic (wave-uniform)
 // register numbers lower to VGPR-indexed moves instead of scratch memory.
 typedef uint32_t vreg_file_t __attribute__((vector_size(HNB_VM_MAX_REGS * 4)));
+// Wide file for programs with init_regs / update_regs > HNB_VM_MAX_REGS (hanabi_amd.h).
+// An array, not a vector type: constant indices (specialised kernels) scalarise it just the same, and the
+// interpreter's dynamic indices address ONE scratch object instead of a vector temporary per site.
+struct vreg_file_wide_t {
+    uint32_t v[HNB_VM_MAX_REGS_WIDE];
+    HNB_HD_MEMBER uint32_t& operator[](uint32_t i) { return v[i]; }
+    HNB_HD_MEMBER const uint32_t& operator[](uint32_t i) const { return v[i]; }
+};
 // U register file on the host.
 struct UFile {
     uint32_t v[HNB_VM_MAX_UREGS];

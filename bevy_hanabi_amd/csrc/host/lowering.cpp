@@ -63,9 +63,14 @@ struct Writer {
     std::map<uint32_t, Loc> memo;  // side-effect expressions already hoisted (expr cache)
 };
 
+// Internal: the stream does not fit the V file it was lowered for.
+struct RegisterPressure : ShaderGenerateError { using ShaderGenerateError::ShaderGenerateError; };
+
 class Lowerer {
    public:
-    explicit Lowerer(const EffectAsset& a) : asset_(a), mod_(a.module()) {}
+    // `vlimit`: size of the V file the program may use (HNB_VM_MAX_REGS, or HNB_VM_MAX_REGS_WIDE for the retry
+    // of a program that does not fit the fast file).
+    explicit Lowerer(const EffectAsset& a, uint32_t vlimit = HNB_VM_MAX_REGS) : asset_(a), mod_(a.module()), vlimit_(vlimit) {}
     std::vector<uint8_t> run();
 
    private:
@@ -81,7 +86,11 @@ class Lowerer {
     std::map<std::array<uint32_t, 6>, uint32_t> ulit_;                  // literal dedupe
     std::map<uint32_t, int> uniform_cache_;                             // is_uniform() memo
     // V allocation (per stream while lowering it)
+    uint32_t vlimit_ = HNB_VM_MAX_REGS;
     uint32_t vtop_ = 0, ptop_ = HNB_VM_MAX_REGS, vmax_ = 0;
+    [[noreturn]] void out_of_registers() const {
+        throw RegisterPressure("expression too complex: more than " + std::to_string(vlimit_) + " per-particle registers needed");
+    }
     std::vector<uint32_t> prop_offset_;
     uint32_t prop_words_ = 0;
 
@@ -103,16 +112,16 @@ class Lowerer {
         return r;
     }
     uint32_t alloc_v(uint32_t n) {
-        if (vtop_ + n > ptop_) throw ShaderGenerateError("expression too complex: more than 32 per-particle registers needed");
+        if (vtop_ + n > ptop_) out_of_registers();
         const uint32_t r = vtop_;
         vtop_ += n;
         vmax_ = std::max(vmax_, vtop_);
         return r;
     }
     uint32_t alloc_persistent(uint32_t n) {
-        if (ptop_ < vtop_ + n) throw ShaderGenerateError("expression too complex: more than 32 per-particle registers needed");
+        if (ptop_ < vtop_ + n) out_of_registers();
         ptop_ -= n;
-        vmax_ = HNB_VM_MAX_REGS;
+        vmax_ = vlimit_;
         return ptop_;
     }
     static uint32_t opnd(const Loc& l) { return l.uniform ? (HNB_OPERAND_U | l.reg) : l.reg; }
@@ -861,7 +870,7 @@ class Lowerer {
 
     void lower_stream(StreamId s) {
         vtop_ = attr_end_;
-        ptop_ = HNB_VM_MAX_REGS;
+        ptop_ = vlimit_;
         vmax_ = attr_end_;
         Writer main{s, {}};
         if (s == StreamId::Init) {
@@ -1039,7 +1048,15 @@ const char* op_name(uint32_t op) {
 
 }  // namespace
 
-std::vector<uint8_t> lower(const EffectAsset& asset) { return Lowerer(asset).run(); }
+std::vector<uint8_t> lower(const EffectAsset& asset) {
+    // Programs that fit the 32-register file keep it (the interpreter kernels hold it in VGPRs); deeper
+    // expression trees are lowered again for the wide file.
+    try {
+        return Lowerer(asset).run();
+    } catch (const RegisterPressure&) {
+        return Lowerer(asset, HNB_VM_MAX_REGS_WIDE).run();
+    }
+}
 
 std::string disassemble(const std::vector<uint8_t>& blob) {
     std::ostringstream os;

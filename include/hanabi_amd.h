@@ -80,10 +80,13 @@ typedef enum HnbScalarType { HNB_BOOL = 0, HNB_F32 = 1, HNB_I32 = 2, HNB_U32 = 3
  *   (HNB_OP_LOADK: w1 is the 32-bit immediate; HNB_OP_LDP: w1 = property word offset,
  *    width-1 in a[1:0]).
  * Operand bytes: bit 7 set = U register (parameter block, index in bits 6:0), clear = V
- * register (per-particle, 32 x 32-bit). In the uniform stream every operand is a U
+ * register (per-particle, up to 128 x 32-bit). In the uniform stream every operand is a U
  * register and bit 7 is not set. A vector operand occupies `width` consecutive
  * registers; an operand with its bcast bit set is a scalar broadcast.                  */
-#define HNB_VM_MAX_REGS 32u    /* V registers per particle */
+#define HNB_VM_MAX_REGS 32u    /* V registers per particle: the file every kernel holds in VGPRs */
+#define HNB_VM_MAX_REGS_WIDE 128u /* largest V file a program may ask for (init_regs / update_regs). Programs above
+                                    HNB_VM_MAX_REGS run on the wide file: specialised kernels scalarise it, the
+                                    interpreter kernels index it in scratch memory (correct, slower). */
 #define HNB_VM_MAX_UREGS 128u  /* U registers per instance */
 #define HNB_MAX_EVENT_CHANNELS 4u /* child event channels per parent effect (EmitSpawnEventModifier::child_index < 4) */
 #define HNB_OPERAND_U 0x80u

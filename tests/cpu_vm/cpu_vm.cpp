@@ -25,6 +25,115 @@ struct CpuVm {
     bool streamable = true;
 };
 
+// force_generic: run the update stream through vm_run even when it is streamable
+template <class FILE_T>
+static void step_impl(CpuVm* v, const float* sim, uint32_t spawn_count, uint32_t seed, const float* xf_in, int force_generic) {
+    static const float identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    const float* xf = xf_in ? xf_in : identity;
+    const HnbProgramHeader& h = v->h;
+    uniform_run(v->ucode.data(), (uint32_t)v->ucode.size(), v->prop_words.data(), sim, v->ublock.data(), h.n_uregs);
+    VmUniforms U;
+    U.u = v->ublock.data();
+    U.xf = xf;
+    // init
+    const uint32_t alive0 = v->alive, max_spawn = h.capacity - alive0;
+    const uint32_t n_spawn = spawn_count < max_spawn ? spawn_count : max_spawn;
+    const uint32_t wi = v->write_index;
+    for (uint32_t i = 0; i < n_spawn; ++i) {
+        const uint32_t slot = v->dead[alive0 + i];
+        VmState<FILE_T> S;
+        S.r = FILE_T{};
+        S.pindex = slot + v->slot_base;
+        S.seed = pcg_hash(S.pindex ^ seed);
+        S.pcounter = v->counter + i;
+        S.alive = true;
+        VmAttrIO io;
+        io.slab = reinterpret_cast<char*>(v->slab.data()); io.attrs = v->adesc.data(); io.slot = slot;
+        for (size_t a = 0; a < v->attrs.size(); ++a)
+            if (v->attrs[a].reg == HNB_REG_NONE)
+                for (uint32_t c = 0; c < v->attrs[a].ncomp; ++c) vm_attr_ptr(io, (uint32_t)a)[c] = 0u;
+        vm_run<true, false>(v->icode.data(), (uint32_t)v->icode.size(), S, U, nullptr, nullptr, io);
+        v->list[wi][alive0 + i] = slot;
+        for (size_t a = 0; a < v->attrs.size(); ++a)
+            if (v->attrs[a].reg != HNB_REG_NONE)
+                for (uint32_t c = 0; c < v->attrs[a].ncomp; ++c) vm_attr_ptr(io, (uint32_t)a)[c] = S.r[v->attrs[a].reg + c];
+    }
+    const uint32_t n = alive0 + n_spawn;
+    // update + stable compaction
+    uint32_t survivors = 0, casualties = 0;
+    std::vector<uint32_t>& rd = v->list[wi];
+    std::vector<uint32_t>& wr = v->list[wi ^ 1u];
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t slot = rd[i];
+        bool alive = true;
+        VmAttrIO io;
+        io.slab = reinterpret_cast<char*>(v->slab.data()); io.attrs = v->adesc.data(); io.slot = slot;
+        if (v->streamable && !force_generic) {
+            Pinned<1> X;
+            X.pos[0] = V3{0, 0, 0}; X.vel[0] = V3{0, 0, 0}; X.age[0] = 0; X.lifetime[0] = 0; X.alive[0] = true;
+            for (size_t a = 0; a < v->attrs.size(); ++a) {
+                const HnbAttrEntry& at = v->attrs[a];
+                if (!(at.update_flags & HNB_ATTR_UPD_LOAD)) continue;
+                const uint32_t* p = vm_attr_ptr(io, (uint32_t)a);
+                if (at.reg == HNB_REG_POSITION) X.pos[0] = V3{u2f(p[0]), u2f(p[1]), u2f(p[2])};
+                else if (at.reg == HNB_REG_VELOCITY) X.vel[0] = V3{u2f(p[0]), u2f(p[1]), u2f(p[2])};
+                else if (at.reg == HNB_REG_AGE) X.age[0] = u2f(p[0]);
+                else if (at.reg == HNB_REG_LIFETIME) X.lifetime[0] = u2f(p[0]);
+            }
+            fast_run<1, true>(v->ucode_update.data(), (uint32_t)v->ucode_update.size(), X, U);
+            for (size_t a = 0; a < v->attrs.size(); ++a) {
+                const HnbAttrEntry& at = v->attrs[a];
+                if (!(at.update_flags & HNB_ATTR_UPD_STORE)) continue;
+                uint32_t* p = vm_attr_ptr(io, (uint32_t)a);
+                if (at.reg == HNB_REG_POSITION) { p[0] = f2u(X.pos[0].x); p[1] = f2u(X.pos[0].y); p[2] = f2u(X.pos[0].z); }
+                else if (at.reg == HNB_REG_VELOCITY) { p[0] = f2u(X.vel[0].x); p[1] = f2u(X.vel[0].y); p[2] = f2u(X.vel[0].z); }
+                else if (at.reg == HNB_REG_AGE) p[0] = f2u(X.age[0]);
+                else if (at.reg == HNB_REG_LIFETIME) p[0] = f2u(X.lifetime[0]);
+            }
+            alive = X.alive[0];
+        } else {
+            VmState<FILE_T> S;
+            S.r = FILE_T{};
+            for (size_t a = 0; a < v->attrs.size(); ++a) {
+                const HnbAttrEntry& at = v->attrs[a];
+                if (!(at.update_flags & HNB_ATTR_UPD_LOAD) || at.reg == HNB_REG_NONE) continue;
+                for (uint32_t c = 0; c < at.ncomp; ++c) S.r[at.reg + c] = vm_attr_ptr(io, (uint32_t)a)[c];
+            }
+            S.pindex = slot + v->slot_base;
+            S.seed = pcg_hash(S.pindex ^ seed);
+            S.pcounter = 0;
+            S.alive = true;
+            vm_run<true, false>(v->ucode_update.data(), (uint32_t)v->ucode_update.size(), S, U, nullptr, nullptr, io);
+            for (size_t a = 0; a < v->attrs.size(); ++a) {
+                const HnbAttrEntry& at = v->attrs[a];
+                if (!(at.update_flags & HNB_ATTR_UPD_STORE) || at.reg == HNB_REG_NONE) continue;
+                for (uint32_t c = 0; c < at.ncomp; ++c) vm_attr_ptr(io, (uint32_t)a)[c] = S.r[at.reg + c];
+            }
+            alive = S.alive;
+        }
+        if (alive) wr[survivors++] = slot;
+        else { v->dead[n - 1u - casualties] = slot; ++casualties; }
+    }
+    v->alive = survivors;
+    if (v->h.flags & HNB_PROG_HAS_RIBBONS) {  // ribbon sort: stable by (RIBBON_ID, AGE bits) (vfx_sort*.wgsl)
+        const uint32_t *rid = nullptr, *age = nullptr;
+        for (size_t a = 0; a < v->attrs.size(); ++a) {
+            if (v->attrs[a].attr == HNB_ATTR_RIBBON_ID) rid = reinterpret_cast<const uint32_t*>(v->slab.data() + v->adesc[a].plane_off);
+            if (v->attrs[a].attr == HNB_ATTR_AGE) age = reinterpret_cast<const uint32_t*>(v->slab.data() + v->adesc[a].plane_off);
+        }
+        std::stable_sort(wr.begin(), wr.begin() + survivors, [&](uint32_t x, uint32_t y) {
+            const uint64_t kx = ((uint64_t)rid[x] << 32) | (age ? age[x] : 0u), ky = ((uint64_t)rid[y] << 32) | (age ? age[y] : 0u);
+            return kx < ky;
+        });
+    }
+    v->counter += n_spawn;
+    v->write_index = wi ^ 1u;
+    v->max_update = n;
+    v->dead_count = casualties;
+    v->spawned = n_spawn;
+}
+
+
 extern "C" {
 
 CpuVm* cvm_create(const uint8_t* blob, size_t size, uint32_t slot_base) {
@@ -79,111 +188,10 @@ int cvm_set_property(CpuVm* v, const char* name, const uint32_t* words, uint32_t
     return -2;
 }
 
-// force_generic: run the update stream through vm_run even when it is streamable
 void cvm_step(CpuVm* v, const float* sim, uint32_t spawn_count, uint32_t seed, const float* xf_in, int force_generic) {
-    static const float identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    const float* xf = xf_in ? xf_in : identity;
-    const HnbProgramHeader& h = v->h;
-    uniform_run(v->ucode.data(), (uint32_t)v->ucode.size(), v->prop_words.data(), sim, v->ublock.data(), h.n_uregs);
-    VmUniforms U;
-    U.u = v->ublock.data();
-    U.xf = xf;
-    // init
-    const uint32_t alive0 = v->alive, max_spawn = h.capacity - alive0;
-    const uint32_t n_spawn = spawn_count < max_spawn ? spawn_count : max_spawn;
-    const uint32_t wi = v->write_index;
-    for (uint32_t i = 0; i < n_spawn; ++i) {
-        const uint32_t slot = v->dead[alive0 + i];
-        VmState<vreg_file_t> S;
-        S.r = vreg_file_t{};
-        S.pindex = slot + v->slot_base;
-        S.seed = pcg_hash(S.pindex ^ seed);
-        S.pcounter = v->counter + i;
-        S.alive = true;
-        VmAttrIO io;
-        io.slab = reinterpret_cast<char*>(v->slab.data()); io.attrs = v->adesc.data(); io.slot = slot;
-        for (size_t a = 0; a < v->attrs.size(); ++a)
-            if (v->attrs[a].reg == HNB_REG_NONE)
-                for (uint32_t c = 0; c < v->attrs[a].ncomp; ++c) vm_attr_ptr(io, (uint32_t)a)[c] = 0u;
-        vm_run<true, false>(v->icode.data(), (uint32_t)v->icode.size(), S, U, nullptr, nullptr, io);
-        v->list[wi][alive0 + i] = slot;
-        for (size_t a = 0; a < v->attrs.size(); ++a)
-            if (v->attrs[a].reg != HNB_REG_NONE)
-                for (uint32_t c = 0; c < v->attrs[a].ncomp; ++c) vm_attr_ptr(io, (uint32_t)a)[c] = S.r[v->attrs[a].reg + c];
-    }
-    const uint32_t n = alive0 + n_spawn;
-    // update + stable compaction
-    uint32_t survivors = 0, casualties = 0;
-    std::vector<uint32_t>& rd = v->list[wi];
-    std::vector<uint32_t>& wr = v->list[wi ^ 1u];
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t slot = rd[i];
-        bool alive = true;
-        VmAttrIO io;
-        io.slab = reinterpret_cast<char*>(v->slab.data()); io.attrs = v->adesc.data(); io.slot = slot;
-        if (v->streamable && !force_generic) {
-            Pinned<1> X;
-            X.pos[0] = V3{0, 0, 0}; X.vel[0] = V3{0, 0, 0}; X.age[0] = 0; X.lifetime[0] = 0; X.alive[0] = true;
-            for (size_t a = 0; a < v->attrs.size(); ++a) {
-                const HnbAttrEntry& at = v->attrs[a];
-                if (!(at.update_flags & HNB_ATTR_UPD_LOAD)) continue;
-                const uint32_t* p = vm_attr_ptr(io, (uint32_t)a);
-                if (at.reg == HNB_REG_POSITION) X.pos[0] = V3{u2f(p[0]), u2f(p[1]), u2f(p[2])};
-                else if (at.reg == HNB_REG_VELOCITY) X.vel[0] = V3{u2f(p[0]), u2f(p[1]), u2f(p[2])};
-                else if (at.reg == HNB_REG_AGE) X.age[0] = u2f(p[0]);
-                else if (at.reg == HNB_REG_LIFETIME) X.lifetime[0] = u2f(p[0]);
-            }
-            fast_run<1, true>(v->ucode_update.data(), (uint32_t)v->ucode_update.size(), X, U);
-            for (size_t a = 0; a < v->attrs.size(); ++a) {
-                const HnbAttrEntry& at = v->attrs[a];
-                if (!(at.update_flags & HNB_ATTR_UPD_STORE)) continue;
-                uint32_t* p = vm_attr_ptr(io, (uint32_t)a);
-                if (at.reg == HNB_REG_POSITION) { p[0] = f2u(X.pos[0].x); p[1] = f2u(X.pos[0].y); p[2] = f2u(X.pos[0].z); }
-                else if (at.reg == HNB_REG_VELOCITY) { p[0] = f2u(X.vel[0].x); p[1] = f2u(X.vel[0].y); p[2] = f2u(X.vel[0].z); }
-                else if (at.reg == HNB_REG_AGE) p[0] = f2u(X.age[0]);
-                else if (at.reg == HNB_REG_LIFETIME) p[0] = f2u(X.lifetime[0]);
-            }
-            alive = X.alive[0];
-        } else {
-            VmState<vreg_file_t> S;
-            S.r = vreg_file_t{};
-            for (size_t a = 0; a < v->attrs.size(); ++a) {
-                const HnbAttrEntry& at = v->attrs[a];
-                if (!(at.update_flags & HNB_ATTR_UPD_LOAD) || at.reg == HNB_REG_NONE) continue;
-                for (uint32_t c = 0; c < at.ncomp; ++c) S.r[at.reg + c] = vm_attr_ptr(io, (uint32_t)a)[c];
-            }
-            S.pindex = slot + v->slot_base;
-            S.seed = pcg_hash(S.pindex ^ seed);
-            S.pcounter = 0;
-            S.alive = true;
-            vm_run<true, false>(v->ucode_update.data(), (uint32_t)v->ucode_update.size(), S, U, nullptr, nullptr, io);
-            for (size_t a = 0; a < v->attrs.size(); ++a) {
-                const HnbAttrEntry& at = v->attrs[a];
-                if (!(at.update_flags & HNB_ATTR_UPD_STORE) || at.reg == HNB_REG_NONE) continue;
-                for (uint32_t c = 0; c < at.ncomp; ++c) vm_attr_ptr(io, (uint32_t)a)[c] = S.r[at.reg + c];
-            }
-            alive = S.alive;
-        }
-        if (alive) wr[survivors++] = slot;
-        else { v->dead[n - 1u - casualties] = slot; ++casualties; }
-    }
-    v->alive = survivors;
-    if (v->h.flags & HNB_PROG_HAS_RIBBONS) {  // ribbon sort: stable by (RIBBON_ID, AGE bits) (vfx_sort*.wgsl)
-        const uint32_t *rid = nullptr, *age = nullptr;
-        for (size_t a = 0; a < v->attrs.size(); ++a) {
-            if (v->attrs[a].attr == HNB_ATTR_RIBBON_ID) rid = reinterpret_cast<const uint32_t*>(v->slab.data() + v->adesc[a].plane_off);
-            if (v->attrs[a].attr == HNB_ATTR_AGE) age = reinterpret_cast<const uint32_t*>(v->slab.data() + v->adesc[a].plane_off);
-        }
-        std::stable_sort(wr.begin(), wr.begin() + survivors, [&](uint32_t x, uint32_t y) {
-            const uint64_t kx = ((uint64_t)rid[x] << 32) | (age ? age[x] : 0u), ky = ((uint64_t)rid[y] << 32) | (age ? age[y] : 0u);
-            return kx < ky;
-        });
-    }
-    v->counter += n_spawn;
-    v->write_index = wi ^ 1u;
-    v->max_update = n;
-    v->dead_count = casualties;
-    v->spawned = n_spawn;
+    // same file selection as hnb_program_create
+    if (v->h.init_regs > HNB_VM_MAX_REGS || v->h.update_regs > HNB_VM_MAX_REGS) step_impl<vreg_file_wide_t>(v, sim, spawn_count, seed, xf_in, force_generic);
+    else step_impl<vreg_file_t>(v, sim, spawn_count, seed, xf_in, force_generic);
 }
 
 void cvm_counters(CpuVm* v, uint32_t* out8) {

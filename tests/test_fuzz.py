@@ -50,3 +50,63 @@ def test_fuzz_gpu(ctx, seed, jit, monkeypatch):
     finally:
         if "g" in holder:
             holder["g"].prog.destroy()
+
+
+# ---- programs above the 32-register fast file ---------------------------------------------------------
+def wide_asset(n_rands, capacity=300):
+    """One statement keeping `n_rands` hoisted vec4 draws alive at once (4 registers each)."""
+    w = bh.ExprWriter()
+    A = bh.Attribute
+    acc = w.rand(bh.VectorType.VEC4F)
+    for k in range(1, n_rands):
+        acc = acc + w.rand(bh.VectorType.VEC4F) * w.lit(1.0 + 0.25 * k)
+    upd = w.rand(bh.VectorType.VEC4F)
+    for k in range(1, n_rands):
+        upd = upd.max(w.rand(bh.VectorType.VEC4F) - w.attr(A.F32X4_0) * w.lit(0.125 * k))
+    init = [bh.SetAttributeModifier(A.POSITION, w.rand(bh.VectorType.VEC3F).expr()),
+            bh.SetAttributeModifier(A.VELOCITY, w.lit((0.0, 1.0, 0.0)).expr()),
+            bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()),
+            bh.SetAttributeModifier(A.LIFETIME, w.lit(0.2).uniform(w.lit(0.7)).expr()),
+            bh.SetAttributeModifier(A.F32X4_0, acc.expr())]
+    update = [bh.SetAttributeModifier(A.F32X4_1, upd.expr())]
+    asset = bh.EffectAsset(capacity, bh.SpawnerSettings.once(float(capacity)), w.finish())
+    for m in init:
+        asset.init(m)
+    for m in update:
+        asset.update(m)
+    return asset
+
+
+def _header_regs(blob):
+    import struct
+    words = struct.unpack_from("<14I", blob)   # HnbProgramHeader: init_regs, update_regs are words 12, 13
+    return words[12], words[13]
+
+
+@pytest.mark.parametrize("n_rands", [7, 12, 26])
+def test_wide_register_file_cpu(n_rands):
+    asset = wide_asset(n_rands)
+    blob = bh.lower(asset)
+    bh.validate_program(blob)
+    init_regs, update_regs = _header_regs(blob)
+    assert (max(init_regs, update_regs) > 32) == (n_rands > 5)
+    run_script(CpuVmRunner(asset), random_frames(n_rands, asset.capacity, n=18), OracleRunner(asset), every=3)
+
+
+def test_register_limit_is_a_lowering_error():
+    with pytest.raises(bh.ShaderGenerateError, match="more than 128 per-particle registers"):
+        bh.lower(wide_asset(40))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rands", [12, 26])
+@pytest.mark.parametrize("jit", ["1", "0"])
+def test_wide_register_file_gpu(ctx, n_rands, jit, monkeypatch):
+    monkeypatch.setenv("HNB_JIT", jit)
+    asset = wide_asset(n_rands)
+    g = GpuRunner(asset, ctx=ctx)
+    try:
+        assert "wide-file" in g.prog.kernel_info()
+        run_script(g, random_frames(n_rands, asset.capacity, n=18), OracleRunner(asset), every=3)
+    finally:
+        g.prog.destroy()
