@@ -182,7 +182,7 @@ namespace {
 // parameter block.
 bool operand_ok(uint32_t operand, uint32_t span, uint32_t nregs, uint32_t n_uregs, bool ustream) {
     if (ustream) return operand + span <= n_uregs;
-    if (operand & HNB_OPERAND_U) return (operand & 0x7fu) + span <= n_uregs;
+    if (operand & HNB_OPERAND_DECODED_U) return (operand & 0xffu) + span <= n_uregs;
     return operand + span <= nregs;
 }
 
@@ -193,8 +193,11 @@ int validate_stream(const uint8_t* blob_base, const uint8_t* code, uint32_t len,
     for (uint32_t i = 0; i < len; ++i) {
         uint32_t w[2];
         memcpy(w, code + (size_t)i * 8, 8);
-        const uint32_t op = w[0] & 0xff, d = (w[0] >> 8) & 0xff, a = (w[0] >> 16) & 0xff, b = w[0] >> 24;
-        const uint32_t c = w[1] & 0xff, wd = ((w[1] >> 8) & 3u) + 1u;
+        const uint32_t op = w[0] & 0xff, d = (w[0] >> 8) & 0xff, wd = ((w[1] >> 8) & 3u) + 1u;
+        // same decode as vm_exec
+        const uint32_t a = ustream ? (w[0] >> 16) & 0xff : HNB_OPERAND_DECODE((w[0] >> 16) & 0xff, w[1] >> 13);
+        const uint32_t b = ustream ? w[0] >> 24 : HNB_OPERAND_DECODE(w[0] >> 24, w[1] >> 14);
+        const uint32_t c = ustream ? w[1] & 0xff : HNB_OPERAND_DECODE(w[1] & 0xff, w[1] >> 15);
         const bool ba = (w[1] >> 10) & 1u, bb = (w[1] >> 11) & 1u, bc = (w[1] >> 12) & 1u;
 #define BAD(msg) return fail(HNB_ERR_BAD_PROGRAM, "%s stream, instruction %u (op %u): %s", sname, i, op, msg)
         if (op >= HNB_OP_COUNT || op == HNB_OP_NOP) BAD("invalid opcode");

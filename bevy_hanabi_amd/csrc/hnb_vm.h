@@ -377,7 +377,7 @@ HNB_HD uint32_t out4_get(const Out4& o, uint32_t k) { return k == 0 ? o.v0 : (k 
 template <bool USTREAM, class ST>
 HNB_HD uint32_t vm_rd(const ST& S, const VmUniforms& U, uint32_t operand) {
     if constexpr (USTREAM) return S.r[operand];
-    else return (operand & HNB_OPERAND_U) ? U.u[operand & 0x7fu] : S.r[operand];
+    else return (operand & HNB_OPERAND_DECODED_U) ? U.u[operand & 0xffu] : S.r[operand];
 }
 template <bool USTREAM, class ST> HNB_HD float vm_rdf(const ST& S, const VmUniforms& U, uint32_t operand) {
     return u2f(vm_rd<USTREAM>(S, U, operand));
@@ -391,8 +391,11 @@ template <class ST> HNB_HD V3 vm_pin3(const ST& S, uint32_t reg) { return V3{u2f
 // creation, hnb_jit.h) every decode, switch and register index below folds away.
 template <bool HEAVY, bool USTREAM, class ST>
 HNB_HD void vm_exec(const Ins ins, ST& S, const VmUniforms& U, const uint32_t* props, const float* sim, const VmAttrIO& io) {
-    const uint32_t op = ins.x & 0xffu, d = (ins.x >> 8) & 0xffu, a = (ins.x >> 16) & 0xffu, b = ins.x >> 24;
-    const uint32_t c = ins.y & 0xffu, w = ((ins.y >> 8) & 3u) + 1u;
+    const uint32_t op = ins.x & 0xffu, d = (ins.x >> 8) & 0xffu, w = ((ins.y >> 8) & 3u) + 1u;
+    // varying streams: operand bytes -> decoded operands (bit 8 = U register); uniform stream: plain U indices
+    const uint32_t a = USTREAM ? (ins.x >> 16) & 0xffu : HNB_OPERAND_DECODE((ins.x >> 16) & 0xffu, ins.y >> 13);
+    const uint32_t b = USTREAM ? ins.x >> 24 : HNB_OPERAND_DECODE(ins.x >> 24, ins.y >> 14);
+    const uint32_t c = USTREAM ? ins.y & 0xffu : HNB_OPERAND_DECODE(ins.y & 0xffu, ins.y >> 15);
     const uint32_t sa = (ins.y >> 10) & 1u ? 0u : 1u, sb = (ins.y >> 11) & 1u ? 0u : 1u, sc = (ins.y >> 12) & 1u ? 0u : 1u;
     const uint32_t aux = ins.y >> 16;
     const bool elementwise = vm_op_is_elementwise(op);
@@ -695,7 +698,7 @@ struct Pinned {
     float age[P], lifetime[P];
     bool alive[P];
 };
-HNB_HD float uf(const VmUniforms& U, uint32_t operand) { return u2f(U.u[operand & 0x7fu]); }
+HNB_HD float uf(const VmUniforms& U, uint32_t operand) { return u2f(U.u[operand & 0xffu]); }
 HNB_HD V3 uf3(const VmUniforms& U, uint32_t operand) { return V3{uf(U, operand), uf(U, operand + 1), uf(U, operand + 2)}; }
 
 // Ops of the "lean" streaming variant; the rest (normalize / cross / smoothstep heavy) only exist
@@ -709,8 +712,9 @@ template <int P, bool FULL>
 HNB_HD void fast_run(const Ins* __restrict__ code, uint32_t n_ins, Pinned<P>& X, const VmUniforms& U) {
     for (uint32_t pc = 0; pc < n_ins; ++pc) {
         const Ins ins = code[pc];
-        const uint32_t op = ins.x & 0xffu, d = (ins.x >> 8) & 0xffu, a = (ins.x >> 16) & 0xffu, b = ins.x >> 24;
-        const uint32_t c = ins.y & 0xffu, aux = ins.y >> 16;
+        const uint32_t op = ins.x & 0xffu, d = (ins.x >> 8) & 0xffu, aux = ins.y >> 16;
+        const uint32_t a = HNB_OPERAND_DECODE((ins.x >> 16) & 0xffu, ins.y >> 13), b = HNB_OPERAND_DECODE(ins.x >> 24, ins.y >> 14);
+        const uint32_t c = HNB_OPERAND_DECODE(ins.y & 0xffu, ins.y >> 15);
         switch (op) {
             case HNB_OP_M_AGE_TICK: {
                 const float dt = uf(U, a);
@@ -794,7 +798,8 @@ HNB_HD void fast_run(const Ins* __restrict__ code, uint32_t n_ins, Pinned<P>& X,
 // serves every effect whose update stream has the same opcode sequence.
 template <uint32_t OP, int P>
 HNB_HD void apply_static(const Ins ins, Pinned<P>& X, const VmUniforms& U) {
-    const uint32_t a = (ins.x >> 16) & 0xffu, b = ins.x >> 24, c = ins.y & 0xffu, aux = ins.y >> 16;
+    const uint32_t a = HNB_OPERAND_DECODE((ins.x >> 16) & 0xffu, ins.y >> 13), b = HNB_OPERAND_DECODE(ins.x >> 24, ins.y >> 14);
+    const uint32_t c = HNB_OPERAND_DECODE(ins.y & 0xffu, ins.y >> 15), aux = ins.y >> 16;
     if constexpr (OP == HNB_OP_M_AGE_TICK) {
         const float dt = uf(U, a);
         const bool has_lifetime = (aux & 1u) != 0u;

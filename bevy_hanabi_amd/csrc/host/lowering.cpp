@@ -48,10 +48,14 @@ struct Stream {
     std::vector<uint64_t> code;
 };
 
+// a, b, c: a plain register index (V register, or U register of the uniform stream), or
+// HNB_OPERAND_DECODED_U | index for a U register read by a varying stream (-> operand byte + bank bit).
 uint64_t encode(uint32_t op, uint32_t d, uint32_t a, uint32_t b, uint32_t c, uint32_t width, bool ba, bool bb, bool bc, uint32_t aux) {
-    const uint32_t w0 = (op & 0xffu) | ((d & 0xffu) << 8) | ((a & 0xffu) << 16) | ((b & 0xffu) << 24);
-    const uint32_t w1 = (c & 0xffu) | (((width - 1u) & 3u) << 8) | (ba ? 1u << 10 : 0u) | (bb ? 1u << 11 : 0u) | (bc ? 1u << 12 : 0u) |
-                        ((aux & 0xffffu) << 16);
+    auto byte = [](uint32_t v) { return (v & HNB_OPERAND_DECODED_U) ? (HNB_OPERAND_U | (v & 0x7fu)) : (v & 0xffu); };
+    auto bank = [](uint32_t v) { return (v & HNB_OPERAND_DECODED_U) ? ((v >> 7) & 1u) : 0u; };
+    const uint32_t w0 = (op & 0xffu) | ((d & 0xffu) << 8) | (byte(a) << 16) | (byte(b) << 24);
+    const uint32_t w1 = byte(c) | (((width - 1u) & 3u) << 8) | (ba ? 1u << 10 : 0u) | (bb ? 1u << 11 : 0u) | (bc ? 1u << 12 : 0u) |
+                        (bank(a) << 13) | (bank(b) << 14) | (bank(c) << 15) | ((aux & 0xffffu) << 16);
     return (uint64_t)w0 | ((uint64_t)w1 << 32);
 }
 
@@ -124,7 +128,7 @@ class Lowerer {
         vmax_ = vlimit_;
         return ptop_;
     }
-    static uint32_t opnd(const Loc& l) { return l.uniform ? (HNB_OPERAND_U | l.reg) : l.reg; }
+    static uint32_t opnd(const Loc& l) { return l.uniform ? (HNB_OPERAND_DECODED_U | l.reg) : l.reg; }
 
     // ---- emission --------------------------------------------------------------------------
     std::vector<uint32_t> parent_attrs_;  // HnbAttr ids the init stream reads from the parent particle
@@ -1071,7 +1075,7 @@ std::string disassemble(const std::vector<uint8_t>& blob) {
     }
     auto reg = [](uint32_t o, bool ustream) {
         char b[16];
-        if (ustream || (o & HNB_OPERAND_U)) std::snprintf(b, sizeof b, "u%u", o & 0x7fu);
+        if (ustream || (o & HNB_OPERAND_DECODED_U)) std::snprintf(b, sizeof b, "u%u", o & 0xffu);
         else std::snprintf(b, sizeof b, "r%u", o);
         return std::string(b);
     };
@@ -1082,7 +1086,9 @@ std::string disassemble(const std::vector<uint8_t>& blob) {
         for (uint32_t i = 0; i < lens[s]; ++i) {
             uint32_t w[2];
             std::memcpy(w, blob.data() + offs[s] + (size_t)i * 8, 8);
-            const uint32_t op = w[0] & 0xff, d = (w[0] >> 8) & 0xff, a = (w[0] >> 16) & 0xff, b = w[0] >> 24, c = w[1] & 0xff;
+            const uint32_t op = w[0] & 0xff, d = (w[0] >> 8) & 0xff;
+            uint32_t a = (w[0] >> 16) & 0xff, b = w[0] >> 24, c = w[1] & 0xff;
+            if (s != 0) { a = HNB_OPERAND_DECODE(a, w[1] >> 13); b = HNB_OPERAND_DECODE(b, w[1] >> 14); c = HNB_OPERAND_DECODE(c, w[1] >> 15); }
             os << "  " << op_name(op) << " ";
             if (op == HNB_OP_LOADK) { float f; std::memcpy(&f, &w[1], 4); os << reg(d, true) << " = 0x" << std::hex << w[1] << std::dec << " (" << f << ")"; }
             else if (op == HNB_OP_LDB) os << reg(d, true) << " = sim[" << a << "]";

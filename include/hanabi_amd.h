@@ -76,20 +76,23 @@ typedef enum HnbScalarType { HNB_BOOL = 0, HNB_F32 = 1, HNB_I32 = 2, HNB_U32 = 3
 /* ---------------------------------------------------------------------------------- */
 /* Instruction = two little-endian u32 words:
  *   w0: op[7:0] dst[15:8] a[23:16] b[31:24]
- *   w1: c[7:0] width-1[9:8] bcast_a[10] bcast_b[11] bcast_c[12] aux[31:16]
+ *   w1: c[7:0] width-1[9:8] bcast_a[10] bcast_b[11] bcast_c[12] ubank_a[13] ubank_b[14] ubank_c[15] aux[31:16]
  *   (HNB_OP_LOADK: w1 is the 32-bit immediate; HNB_OP_LDP: w1 = property word offset,
  *    width-1 in a[1:0]).
- * Operand bytes: bit 7 set = U register (parameter block, index in bits 6:0), clear = V
+ * Operand bytes: bit 7 set = U register (parameter block, index = bits 6:0 | ubank << 7), clear = V
  * register (per-particle, up to 128 x 32-bit). In the uniform stream every operand is a U
- * register and bit 7 is not set. A vector operand occupies `width` consecutive
+ * register and the byte is its index (0..255). A vector operand occupies `width` consecutive
  * registers; an operand with its bcast bit set is a scalar broadcast.                  */
 #define HNB_VM_MAX_REGS 32u    /* V registers per particle: the file every kernel holds in VGPRs */
 #define HNB_VM_MAX_REGS_WIDE 128u /* largest V file a program may ask for (init_regs / update_regs). Programs above
                                     HNB_VM_MAX_REGS run on the wide file: specialised kernels scalarise it, the
                                     interpreter kernels index it in scratch memory (correct, slower). */
-#define HNB_VM_MAX_UREGS 128u  /* U registers per instance */
+#define HNB_VM_MAX_UREGS 256u  /* U registers per instance */
 #define HNB_MAX_EVENT_CHANNELS 4u /* child event channels per parent effect (EmitSpawnEventModifier::child_index < 4) */
 #define HNB_OPERAND_U 0x80u
+/* Decoded operand of a varying stream (what the VM works with): bit 8 = U register, bits 7:0 = index. */
+#define HNB_OPERAND_DECODED_U 0x100u
+#define HNB_OPERAND_DECODE(byte, bank) (((byte) & HNB_OPERAND_U) ? (HNB_OPERAND_DECODED_U | ((byte) & 0x7fu) | (((bank) & 1u) << 7)) : (byte))
 
 typedef enum HnbOp {
     HNB_OP_NOP = 0,

@@ -110,3 +110,57 @@ def test_wide_register_file_gpu(ctx, n_rands, jit, monkeypatch):
         run_script(g, random_frames(n_rands, asset.capacity, n=18), OracleRunner(asset), every=3)
     finally:
         g.prog.destroy()
+
+
+# ---- programs above 128 uniform parameter words (U bank bits of the instruction encoding) ----------------
+def uniform_heavy_asset(n_lits, streamable_update, capacity=300):
+    w = bh.ExprWriter()
+    A = bh.Attribute
+    rng = __import__("numpy").random.default_rng(n_lits)
+    acc = w.rand(bh.VectorType.VEC4F)
+    for k in range(n_lits):   # distinct vec4 literals: 4 parameter words each
+        acc = acc * w.lit(tuple(float(x) for x in rng.uniform(0.5, 1.5, 4).round(4))) + w.lit(tuple(float(x) for x in rng.uniform(-1, 1, 4).round(4)))
+    init = [bh.SetPositionSphereModifier(w.lit((0.0, 0.5, 0.0)).expr(), w.lit(1.5).expr(), bh.ShapeDimension.Volume),
+            bh.SetAttributeModifier(A.VELOCITY, (w.rand(bh.VectorType.VEC3F) - w.lit(0.5)).expr()),
+            bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()),
+            bh.SetAttributeModifier(A.LIFETIME, w.lit(0.2).uniform(w.lit(0.9)).expr()),
+            bh.SetAttributeModifier(A.F32X4_0, acc.expr())]
+    # the update stream's operands are allocated after the init stream's: their U indices are above 128
+    update = [bh.AccelModifier(w.lit((0.25, -9.0, 0.5)).expr()), bh.LinearDragModifier(w.lit(0.75).expr()),
+              bh.KillSphereModifier(w.lit((0.0, 0.0, 0.0)).expr(), w.lit(2.5).expr(), False)]
+    if not streamable_update:
+        update.append(bh.SetAttributeModifier(A.F32X4_1, (w.attr(A.F32X4_0) * w.lit((0.9, 0.8, 0.7, 0.6)) + w.rand(bh.VectorType.VEC4F)).expr()))
+    asset = bh.EffectAsset(capacity, bh.SpawnerSettings.once(float(capacity)), w.finish())
+    for m in init:
+        asset.init(m)
+    for m in update:
+        asset.update(m)
+    return asset
+
+
+@pytest.mark.parametrize("streamable", [True, False])
+def test_many_uniform_words_cpu(streamable):
+    import struct
+    asset = uniform_heavy_asset(20, streamable)
+    blob = bh.lower(asset)
+    bh.validate_program(blob)
+    assert struct.unpack_from("<12I", blob)[11] > 128   # HnbProgramHeader::n_uregs
+    run_script(CpuVmRunner(asset), random_frames(5, asset.capacity, n=18), OracleRunner(asset), every=3)
+
+
+def test_uniform_word_limit_is_a_lowering_error():
+    with pytest.raises(bh.ShaderGenerateError, match="more than 256 uniform parameter words"):
+        bh.lower(uniform_heavy_asset(40, True))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("streamable", [True, False])
+@pytest.mark.parametrize("jit", ["1", "0"])
+def test_many_uniform_words_gpu(ctx, streamable, jit, monkeypatch):
+    monkeypatch.setenv("HNB_JIT", jit)
+    asset = uniform_heavy_asset(20, streamable)
+    g = GpuRunner(asset, ctx=ctx)
+    try:
+        run_script(g, random_frames(5, asset.capacity, n=18), OracleRunner(asset), every=3)
+    finally:
+        g.prog.destroy()
