@@ -9,6 +9,25 @@
 
 namespace hanabi {
 
+ExprHandle ExprHandle::parse(const std::string& s) {
+    if (s.size() < 2 || s[0] != '#') throw std::invalid_argument("Invalid ID format (expected '#N')");
+    // Rust's str::parse::<u32>: an optional '+', then decimal digits only, no overflow
+    size_t i = 1;
+    if (s[i] == '+') ++i;
+    if (i == s.size()) throw std::invalid_argument("Failed to parse ID value");
+    uint64_t v = 0;
+    for (; i < s.size(); ++i) {
+        if (s[i] < '0' || s[i] > '9') throw std::invalid_argument("Failed to parse ID value");
+        v = v * 10 + (uint64_t)(s[i] - '0');
+        if (v > 0xffffffffull) throw std::invalid_argument("Failed to parse ID value");
+    }
+    if (v == 0) throw std::invalid_argument("Invalid ID value");
+    ExprHandle h;
+    h.id = (uint32_t)v;
+    return h;
+}
+
+
 std::string ValueType::to_string() const {
     static const char* names[] = {"bool", "f32", "i32", "u32"};
     const char* e = names[(int)elem];

@@ -152,6 +152,10 @@ struct ExprHandle {
     uint32_t index() const { return id - 1; }
     bool valid() const { return id != 0; }
     bool operator==(const ExprHandle& o) const { return id == o.id; }
+    // The serialised form of the reference, "#<id>" (expr.rs:159-166), and its inverse with the same rejections
+    // (expr.rs:182-200): not "#N", N not a u32, N == 0. Throws std::invalid_argument.
+    std::string to_string() const { return "#" + std::to_string(id); }
+    static ExprHandle parse(const std::string& s);
 };
 struct PropertyHandle {
     uint32_t id = 0;

@@ -121,7 +121,9 @@ PYBIND11_MODULE(_hanabi_host, m) {
     py::class_<ExprHandle>(m, "ExprHandle")
         .def_readonly("id", &ExprHandle::id)
         .def("__eq__", [](const ExprHandle& a, const ExprHandle& b) { return a == b; })
-        .def("__repr__", [](const ExprHandle& h) { return "#" + std::to_string(h.id); });
+        .def("to_string", &ExprHandle::to_string)
+        .def_static("parse", &ExprHandle::parse)
+        .def("__repr__", [](const ExprHandle& h) { return h.to_string(); });
     py::class_<PropertyHandle>(m, "PropertyHandle").def_readonly("id", &PropertyHandle::id);
 
     py::enum_<BuiltInOperator>(m, "BuiltInOperator")

@@ -164,3 +164,17 @@ def test_particle_layout_mirror():
     want = {"firework_trails": 48, "force_field": 32, "instancing": 32, "ribbon": 32}
     for name, size in want.items():
         assert getattr(effects, name)(64).reference_particle_layout().min_binding_size() == size, name
+
+
+def test_expr_handle_serialised_form():
+    """ExprHandle <-> "#<id>" with the reference's accept / reject cases (expr.rs:4825-4890, expr_handle_serde)."""
+    w = bh.ExprWriter()
+    h42 = None
+    for _ in range(42):
+        h42 = w.lit(1.0).expr()
+    assert h42.id == 42 and h42.to_string() == "#42"
+    assert bh.ExprHandle.parse(h42.to_string()) == h42
+    assert bh.ExprHandle.parse("#4294967295").id == 0xFFFFFFFF
+    for bad in ["invalid", "33", "#0", "#-5", "#4294967296", "#", "", "#1x", "# 1"]:
+        with pytest.raises(ValueError):
+            bh.ExprHandle.parse(bad)
