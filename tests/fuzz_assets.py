@@ -166,3 +166,163 @@ def random_frames(seed, capacity, n=36):
         spawn = capacity // 2 if f == 0 else (int(rng.integers(0, capacity // 3)) if rng.random() < 0.25 else 0)
         out.append(Frame(1 / 60 if rng.random() < 0.8 else 1 / 30, spawn, frame_seed(seed * 131 + f), xf, time=f / 60))
     return out
+
+
+# ---- typed generator: float / int / uint / bool, every operator (NaN, inf and division by zero included) -----
+I = h.ValueType(h.ScalarType.Int)
+U = h.ValueType(h.ScalarType.Uint)
+KIND_TYPE = {"f": h.ScalarType.Float, "i": h.ScalarType.Int, "u": h.ScalarType.Uint, "b": h.ScalarType.Bool}
+F_UNARY_ALL = UNARY_SAFE + ["acos", "asin", "exp", "log", "log2", "sqrt", "inverse_sqrt", "tan"]
+SINKS = {("f", 1): ATTR_BY_WIDTH[1], ("f", 2): ATTR_BY_WIDTH[2], ("f", 3): ATTR_BY_WIDTH[3], ("f", 4): ATTR_BY_WIDTH[4],
+         ("i", 1): [A.SPRITE_INDEX], ("u", 1): [A.U32_0, A.U32_1, A.U32_2, A.COLOR]}
+
+
+def vtype(kind, width):
+    return h.ValueType(KIND_TYPE[kind], width)
+
+
+class TypedGen(Gen):
+    """Expressions of a requested (kind, width); kinds mix through casts, comparisons and pack / unpack."""
+
+    def tlit(self, kind, width):
+        rng = self.rng
+        if kind == "f":
+            return self.lit(width)
+        if kind == "i":
+            v = [int(x) for x in rng.integers(-9, 10, width)]
+            return self.w.lit(h.Value.i32(v[0]) if width == 1 else h.Value.vec_i(v))
+        if kind == "u":
+            v = [int(x) for x in rng.integers(0, 12, width)]
+            return self.w.lit(h.Value.u32(v[0]) if width == 1 else h.Value.vec_u(v))
+        v = [bool(x) for x in rng.integers(0, 2, width)]
+        return self.w.lit(h.Value.bool(v[0]) if width == 1 else h.Value.vec_b(v))
+
+    def tleaf(self, kind, width, ctx):
+        r = self.rng.random()
+        if kind == "f":
+            if r < 0.12 and width == 1 and self.props:
+                return self.w.prop(self.props[int(self.rng.integers(len(self.props)))])
+            return self.leaf(width, ctx)
+        if kind == "u" and width == 1 and r < 0.35:
+            return self.w.attr(A.ID if r < 0.2 or ctx != "init" else A.PARTICLE_COUNTER)   # the counter only exists in init
+        if kind in ("i", "u") and r < 0.6:   # a draw scaled into the integers
+            return (self.w.rand(VEC[width]) * self.w.lit(40.0) - self.w.lit(0.0 if kind == "u" else 20.0)).cast(vtype(kind, width))
+        if (kind, width) in self.treadable and r < 0.8:
+            pool = self.treadable[(kind, width)]
+            return self.w.attr(pool[int(self.rng.integers(len(pool)))])
+        return self.tlit(kind, width)
+
+    def texpr(self, kind, width, depth, ctx):
+        rng = self.rng
+        if depth == 0 or rng.random() < 0.15:
+            return self.tleaf(kind, width, ctx)
+        r = rng.random()
+        sub = lambda k=kind, wd=width: self.texpr(k, wd, depth - 1, ctx)
+        if kind == "b":
+            if width > 1 or r < 0.8:   # comparison of two numeric operands of this width
+                k = "fiu"[int(rng.integers(3))]
+                a, b = sub(k), sub(k)
+                return getattr(a, ["lt", "le", "gt", "ge"][int(rng.integers(4))])(b)
+            v = self.texpr("b", int(rng.integers(2, 5)), depth - 1, ctx)
+            return v.all() if rng.random() < 0.5 else v.any()
+        if kind == "f":
+            if r < 0.22:
+                return getattr(sub(), F_UNARY_ALL[int(rng.integers(len(F_UNARY_ALL)))])()
+            if r < 0.50:
+                op = ["add", "sub", "mul", "div", "rem", "min", "max", "step", "atan2"][int(rng.integers(9))]
+                a, b = sub(), sub()
+                return {"add": lambda: a + b, "sub": lambda: a - b, "mul": lambda: a * b, "div": lambda: a / b, "rem": lambda: a % b}.get(op, lambda: getattr(a, op)(b))()
+            if r < 0.58:
+                t = rng.random()
+                if t < 0.4:
+                    return sub().mix(sub(), sub())
+                if t < 0.7:
+                    return sub().smoothstep(sub(), sub())
+                return sub().clamp(sub(), sub())
+            if r < 0.72:   # from another kind
+                k = "iub"[int(rng.integers(3))]
+                return sub(k).cast(vtype("f", width))
+            if r < 0.80 and width == 1:
+                wd = int(rng.integers(2, 5))
+                t = rng.random()
+                if t < 0.3:
+                    return sub("f", wd).length()
+                if t < 0.55:
+                    return sub("f", wd).dot(sub("f", wd))
+                if t < 0.8:
+                    return sub("f", wd).distance(sub("f", wd))
+                return getattr(sub("f", wd), "xyzw"[int(rng.integers(wd))])()
+            if r < 0.86 and width == 4:
+                return sub("u", 1).unpack4x8unorm() if rng.random() < 0.5 else sub("u", 1).unpack4x8snorm()
+            if r < 0.90 and width == 3:
+                return sub().cross(sub()) if rng.random() < 0.5 else sub().normalized()
+            if r < 0.95 and width == 1:   # draws with statically typed bounds
+                return self.lit(1).uniform(self.lit(1)) if rng.random() < 0.6 else self.lit(1).normal(self.w.lit(float(rng.uniform(0.1, 2.0))))
+            return self.expr(width, depth - 1, ctx)
+        # int / uint
+        if r < 0.45:
+            op = ["add", "sub", "mul", "div", "rem", "min", "max"][int(rng.integers(7))]
+            a, b = sub(), sub()
+            return {"add": lambda: a + b, "sub": lambda: a - b, "mul": lambda: a * b, "div": lambda: a / b, "rem": lambda: a % b}.get(op, lambda: getattr(a, op)(b))()
+        if r < 0.55:
+            return sub().clamp(sub(), sub())
+        if r < 0.65 and kind == "i":
+            return sub().abs() if rng.random() < 0.5 else sub().sign()
+        if r < 0.85:   # float (any magnitude, NaN included) or the other integer kind, converted
+            k = "f" if rng.random() < 0.6 else ("u" if kind == "i" else "i")
+            return sub(k).cast(vtype(kind, width))
+        if r < 0.93 and kind == "u" and width == 1:
+            return sub("f", 4).pack4x8unorm() if rng.random() < 0.5 else sub("f", 4).pack4x8snorm()
+        return self.tleaf(kind, width, ctx)
+
+    def asset(self, capacity):
+        rng, w = self.rng, self.w
+        self.treadable = {}
+        self.props = []
+        for k in range(int(rng.integers(0, 3))):
+            self.props.append(w.add_property(f"p{k}", float(rng.uniform(-2, 2))))
+        init, update = [], []
+        init.append(h.SetAttributeModifier(A.POSITION, self.texpr("f", 3, 2, "init").expr()))
+        init.append(h.SetAttributeModifier(A.VELOCITY, self.texpr("f", 3, 2, "init").expr()))
+        self.has_age = rng.random() < 0.85
+        if self.has_age:
+            init.append(h.SetAttributeModifier(A.AGE, w.lit(0.0).expr()))
+            init.append(h.SetAttributeModifier(A.LIFETIME, w.lit(0.15).uniform(w.lit(float(rng.uniform(0.3, 1.2)))).expr()))
+        sinks = list(SINKS)
+
+        def assign(ctx, depth):
+            kind, width = sinks[int(rng.integers(len(sinks)))]
+            pool = SINKS[(kind, width)]
+            attr = pool[int(rng.integers(len(pool)))]
+            m = h.SetAttributeModifier(attr, self.texpr(kind, width, depth, ctx).expr())
+            if kind == "f":
+                self.readable.setdefault(width, [])
+                if attr not in self.readable[width]:
+                    self.readable[width].append(attr)
+            else:
+                self.treadable.setdefault((kind, width), [])
+                if attr not in self.treadable[(kind, width)]:
+                    self.treadable[(kind, width)].append(attr)
+            return m
+
+        for _ in range(int(rng.integers(2, 5))):
+            init.append(assign("init", 3))
+        for _ in range(int(rng.integers(1, 5))):
+            if rng.random() < 0.3:
+                update.append(h.KillSphereModifier(self.texpr("f", 3, 1, "update").expr(), w.lit(float(rng.uniform(4.0, 60.0))).expr(), False))
+            elif rng.random() < 0.3:
+                update.append(h.AccelModifier(self.texpr("f", 3, 2, "update").expr()))
+            else:
+                update.append(assign("update", 3))
+        asset = h.EffectAsset(capacity, h.SpawnerSettings.once(float(capacity)), w.finish())
+        for m in init:
+            asset.init(m)
+        for m in update:
+            asset.update(m)
+        asset.motion_integration = [h.MotionIntegration.PostUpdate, h.MotionIntegration.PreUpdate, h.MotionIntegration.None_][int(rng.integers(3))]
+        asset.simulation_space = h.SimulationSpace.Global if rng.random() < 0.5 else h.SimulationSpace.Local
+        return asset
+
+
+def random_typed_asset(seed, capacity=300):
+    return TypedGen(seed).asset(capacity)

@@ -164,3 +164,38 @@ def test_many_uniform_words_gpu(ctx, streamable, jit, monkeypatch):
         run_script(g, random_frames(5, asset.capacity, n=18), OracleRunner(asset), every=3)
     finally:
         g.prog.destroy()
+
+
+# ---- typed generator (float / int / uint / bool, NaN / inf / division by zero reachable) -------------------------
+TYPED_CPU_SEEDS = list(range(2000, 2060))
+TYPED_GPU_SEEDS = list(range(2100, 2116))
+
+
+def _run_typed(seed, make_runner):
+    from fuzz_assets import random_typed_asset
+    asset = random_typed_asset(seed)
+    bh.validate_program(bh.lower(asset))
+    run_script(make_runner(asset), random_frames(seed, asset.capacity, n=24), OracleRunner(asset), every=4)
+
+
+@pytest.mark.parametrize("seed", TYPED_CPU_SEEDS)
+def test_fuzz_typed_cpu(seed):
+    _run_typed(seed, lambda a: CpuVmRunner(a))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", TYPED_GPU_SEEDS)
+@pytest.mark.parametrize("jit", ["1", "0"])
+def test_fuzz_typed_gpu(ctx, seed, jit, monkeypatch):
+    monkeypatch.setenv("HNB_JIT", jit)
+    holder = {}
+
+    def mk(a):
+        holder["g"] = GpuRunner(a, ctx=ctx)
+        return holder["g"]
+
+    try:
+        _run_typed(seed, mk)
+    finally:
+        if "g" in holder:
+            holder["g"].prog.destroy()
