@@ -199,3 +199,84 @@ def test_fuzz_typed_gpu(ctx, seed, jit, monkeypatch):
     finally:
         if "g" in holder:
             holder["g"].prog.destroy()
+
+
+# ---- random worlds: several programs and instances in one context, random schedule -----------------------------
+def _world(seed, order):
+    """2-3 random programs x 1-5 instances (created and destroyed along the way), random spawn requests (none, some,
+    more than fits), frozen instances, property changes, per-instance transforms; one simulate() per frame for everything.
+    Every instance has its own oracle, stepped only when the instance is simulated."""
+    import numpy as np
+    from fuzz_assets import random_typed_asset
+    from helpers import Frame, assert_same_state, frame_seed, stored_attrs
+
+    rng = np.random.default_rng(seed)
+    ctx = bh.Context(0)
+    if order == "slot":
+        ctx.set_list_order("slot")
+    programs = []
+    try:
+        for p in range(int(rng.integers(2, 4))):
+            cap = int([1, 63, 300, 4097, 9000][int(rng.integers(5))])
+            s = int(rng.integers(1 << 20))
+            asset = random_typed_asset(s, cap) if rng.random() < 0.6 else random_asset(s, cap)
+            programs.append({"asset": asset, "prog": ctx.create_program(bh.lower(asset)), "inst": [], "props": list(asset.module().property_names)})
+
+        def add_instance(pr):
+            orc = OracleRunner(pr["asset"])
+            orc.fx.set_list_order(order == "slot")
+            pr["inst"].append({"fx": pr["prog"].create_effect(), "orc": orc, "xf": None})
+
+        def state_of(pr, it):
+            m = it["fx"].metadata()
+            keys = ["capacity", "alive_count", "max_update", "max_spawn", "indirect_write_index", "particle_counter", "instance_count", "dead_count"]
+            return {"counters": {k: m[k] for k in keys}, "alive": it["fx"].alive_list(), "dead": it["fx"].dead_list(),
+                    "attrs": {a.name: it["fx"].read_attr(a.id).view(np.uint32) for a in stored_attrs(pr["asset"])}}
+
+        for pr in programs:
+            for _ in range(int(rng.integers(1, 4))):
+                add_instance(pr)
+        for f in range(40):
+            dt = 1 / 60 if rng.random() < 0.8 else 1 / 24
+            ctx.frame_begin(dt, f / 60)
+            for pr in programs:
+                r = rng.random()
+                if r < 0.08 and len(pr["inst"]) < 5:
+                    add_instance(pr)
+                elif r < 0.14 and len(pr["inst"]) > 1:
+                    it = pr["inst"].pop(int(rng.integers(len(pr["inst"]))))
+                    it["fx"].destroy()
+                cap = pr["asset"].capacity
+                for it in pr["inst"]:
+                    visible = rng.random() > 0.15
+                    it["fx"].set_simulated(visible)
+                    if not visible:
+                        continue
+                    props = {}
+                    if pr["props"] and rng.random() < 0.3:
+                        props[pr["props"][int(rng.integers(len(pr["props"])))]] = [float(np.float32(rng.uniform(-2, 2)))]
+                    if rng.random() < 0.2:
+                        it["xf"] = np.array([1, 0, 0, rng.uniform(-3, 3), 0, 1, 0, rng.uniform(-3, 3), 0, 0, 1, rng.uniform(-3, 3)], dtype=np.float32)
+                    r = rng.random()
+                    spawn = 0 if r < 0.35 else (cap * 2 + 1 if r > 0.92 else int(rng.integers(0, cap // 2 + 2)))
+                    sd = frame_seed(seed * 977 + f * 31 + int(rng.integers(1 << 16)))
+                    for k, v in props.items():
+                        it["fx"].set_property(k, v)
+                    it["fx"].set_frame(spawn, sd, it["xf"])
+                    it["orc"].step(Frame(dt, spawn, sd, it["xf"], time=f / 60, props=props))
+            ctx.simulate()
+            if f % 8 == 7 or f == 39:
+                for pi, pr in enumerate(programs):
+                    for ii, it in enumerate(pr["inst"]):
+                        assert_same_state(it["orc"].state(), state_of(pr, it), f"seed {seed} frame {f} program {pi} instance {ii}")
+    finally:
+        for pr in programs:
+            pr["prog"].destroy()
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["spawn", "slot"])
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_fuzz_world_gpu(seed, order):
+    _world(seed, order)
