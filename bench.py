@@ -167,7 +167,7 @@ def main():
         # the burst frame's init kernel (not part of the metric): 44 B per spawned particle
         out["init"] = {"kernel": "k_init", "kernel_ms": init_ms, "spawned": cap, "bytes_per_spawn": 44,
                        "achieved_gbs": cap * 44 / (init_ms * 1e-3) / 1e9 if init_ms > 0 else 0.0, "kernels": prog.kernel_info().split("\n")[0]}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and n_gpus == 1:   # rank 0 at N=1 only: the host cores are shared by the ranks otherwise
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     ctx.close()
