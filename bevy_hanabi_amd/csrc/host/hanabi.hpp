@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -463,6 +464,33 @@ class EffectSpawner {
 
 // ---- asset (src/asset.rs) -------------------------------------------------------------------------------------
 enum class SimulationSpace : uint8_t { Global, Local };
+// ---- WGSL text of the reference (wgsl.cpp) ---------------------------------------------------------------------
+// `ToWgslString` (src/lib.rs:259-430, src/graph/mod.rs:287-296,1003-1024)
+std::string to_wgsl_string(float x);
+std::string to_wgsl_string(const Value& v);
+
+// The evaluation context of the reference (`ShaderWriter`, src/modifier/mod.rs:204-367), restricted to what
+// `Expr::eval` needs: the WGSL text of an expression, memoised per handle, with side-effect expressions hoisted
+// into `let varN = ...;` statements appended to `main_code`. Inspection / test output only: the simulation runs
+// the program produced by lower(), not this text.
+class ShaderWriter {
+   public:
+    explicit ShaderWriter(uint32_t modifier_context, bool attribute_pointer = false) : context_(modifier_context), attribute_pointer_(attribute_pointer) {}
+    ShaderWriter with_attribute_pointer() const { ShaderWriter w = *this; w.attribute_pointer_ = true; return w; }
+    uint32_t modifier_context() const { return context_; }
+    bool is_attribute_pointer() const { return attribute_pointer_; }
+    std::string eval(const Module& module, ExprHandle handle);
+    std::string make_local_var();
+    std::string main_code;
+
+   private:
+    std::string hoist_if_side_effect(const std::string& code, bool side_effect);
+    uint32_t context_;
+    bool attribute_pointer_;
+    uint32_t var_counter_ = 0;
+    std::map<uint32_t, std::string> expr_cache_;
+};
+
 enum class SimulationCondition : uint8_t { WhenVisible, Always };
 enum class MotionIntegration : uint8_t { None, PreUpdate, PostUpdate };
 

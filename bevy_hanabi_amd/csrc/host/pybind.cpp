@@ -193,6 +193,15 @@ PYBIND11_MODULE(_hanabi_host, m) {
         .def("alpha_cutoff", &ExprWriter::alpha_cutoff)
         .def("finish", &ExprWriter::finish);
 
+    m.def("to_wgsl_string", [](py::object v) { return to_wgsl_string(value_from_py(v)); });
+    py::class_<ShaderWriter>(m, "ShaderWriter")
+        .def(py::init<uint32_t, bool>(), py::arg("modifier_context"), py::arg("attribute_pointer") = false)
+        .def("with_attribute_pointer", &ShaderWriter::with_attribute_pointer)
+        .def("eval", &ShaderWriter::eval)
+        .def("make_local_var", &ShaderWriter::make_local_var)
+        .def_property_readonly("is_attribute_pointer", &ShaderWriter::is_attribute_pointer)
+        .def_readonly("main_code", &ShaderWriter::main_code);
+
     py::class_<Modifier>(m, "Modifier")
         .def_property_readonly("context", &Modifier::context)
         .def_property_readonly("attributes", &Modifier::attributes)
