@@ -178,6 +178,24 @@ struct HnbEffect {
 
 namespace {
 
+// Components of every HnbAttr (src/attributes.rs:549-675): the streaming kernels and the sort address the planes of
+// POSITION / VELOCITY / AGE / LIFETIME / RIBBON_ID by these sizes, so the attribute table must agree with them.
+constexpr uint8_t kAttrComponents[HNB_ATTR_COUNT] = {
+    1, 1,              // ID, PARTICLE_COUNTER (pseudo, never stored)
+    3, 3, 1, 1,        // POSITION, VELOCITY, AGE, LIFETIME
+    1, 4, 1,           // COLOR, HDR_COLOR, ALPHA
+    1, 2, 3,           // SIZE, SIZE2, SIZE3
+    1, 1,              // PREV, NEXT
+    3, 3, 3,           // AXIS_X, AXIS_Y, AXIS_Z
+    1,                 // SPRITE_INDEX
+    1, 1, 1, 1,        // F32_0..3
+    2, 2, 2, 2,        // F32X2_0..3
+    3, 3, 3, 3,        // F32X3_0..3
+    4, 4, 4, 4,        // F32X4_0..3
+    1, 1, 1, 1,        // U32_0..3
+    1,                 // RIBBON_ID
+};
+
 // Operand span check: V operands must stay inside the V file, U operands inside the
 // parameter block.
 bool operand_ok(uint32_t operand, uint32_t span, uint32_t nregs, uint32_t n_uregs, bool ustream) {
@@ -206,7 +224,7 @@ int validate_stream(const uint8_t* blob_base, const uint8_t* code, uint32_t len,
             const uint32_t span = op == HNB_OP_LDP ? (a & 3u) + 1u : 1u;
             if (d + span > file_regs) BAD("destination out of range");
             if (op == HNB_OP_LDB && a > 5) BAD("bad sim-params field");
-            if (op == HNB_OP_LDP && w[1] + span > h.prop_words) BAD("property offset out of range");
+            if (op == HNB_OP_LDP && (uint64_t)w[1] + span > h.prop_words) BAD("property offset out of range");
             continue;
         }
         if (ustream && !(vm_op_is_elementwise(op) || (op >= HNB_OP_ALL && op <= HNB_OP_UNPACK4SNORM)))
@@ -298,7 +316,18 @@ int validate_stream(const uint8_t* blob_base, const uint8_t* code, uint32_t len,
             case HNB_OP_LDPARENT:
                 if (!is_init) BAD("LDPARENT outside the init stream");
                 if (d + wd > file_regs) BAD("destination out of range");
-                if ((w[1] >> 16) >= HNB_ATTR_COUNT) BAD("parent attribute id out of range");
+                {
+                    const uint32_t id = w[1] >> 16;
+                    if (id >= HNB_ATTR_COUNT || id < HNB_ATTR_POSITION) BAD("parent attribute id out of range");
+                    if (wd != kAttrComponents[id]) BAD("LDPARENT must read a whole attribute");
+                    bool listed = false;  // hnb_effect_set_parent checks the parent's layout against this list
+                    for (uint32_t k = 0; k < h.parent_n_attrs && !listed; ++k) {
+                        uint32_t pid;
+                        memcpy(&pid, blob_base + h.parent_attrs_off + k * 4, 4);
+                        listed = pid == id;
+                    }
+                    if (!listed) BAD("LDPARENT of an attribute that is not in the program's parent attribute list");
+                }
                 break;
             case HNB_OP_M_EMIT_EVENTS:
                 if (is_init) BAD("M_EMIT_EVENTS outside the update stream");
@@ -325,8 +354,12 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
     if (!in_range(h.attrs_off, (uint64_t)h.n_attrs * sizeof(HnbAttrEntry)) ||
         !in_range(h.props_off, (uint64_t)h.n_props * sizeof(HnbPropEntry)) ||
         !in_range(h.uniform_off, (uint64_t)h.uniform_len * 8) || !in_range(h.init_off, (uint64_t)h.init_len * 8) ||
-        !in_range(h.update_off, (uint64_t)h.update_len * 8))
+        !in_range(h.update_off, (uint64_t)h.update_len * 8) || !in_range(h.parent_attrs_off, (uint64_t)h.parent_n_attrs * 4))
         return fail(HNB_ERR_BAD_PROGRAM, "program section out of bounds");
+    if (h.prop_words > 4ull * h.n_props) return fail(HNB_ERR_BAD_PROGRAM, "%u property words for %u properties", h.prop_words, h.n_props);
+    if (h.n_event_channels > HNB_MAX_EVENT_CHANNELS)
+        return fail(HNB_ERR_BAD_PROGRAM, "program appends to %u event channels, limit %u", h.n_event_channels, HNB_MAX_EVENT_CHANNELS);
+    if (h.parent_n_attrs > HNB_ATTR_COUNT) return fail(HNB_ERR_BAD_PROGRAM, "invalid parent attribute count %u", h.parent_n_attrs);
     if ((h.uniform_off & 7) || (h.init_off & 7) || (h.update_off & 7)) return fail(HNB_ERR_BAD_PROGRAM, "code sections must be 8-byte aligned");
     if (h.init_regs > HNB_VM_MAX_REGS_WIDE || h.update_regs > HNB_VM_MAX_REGS_WIDE)
         return fail(HNB_ERR_BAD_PROGRAM, "program needs %u V registers, the VM has %u", std::max(h.init_regs, h.update_regs),
@@ -335,13 +368,18 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
         return fail(HNB_ERR_BAD_PROGRAM, "register counts must cover the pinned registers");
     if (h.n_uregs > HNB_VM_MAX_UREGS) return fail(HNB_ERR_BAD_PROGRAM, "program needs %u U registers, limit %u", h.n_uregs, HNB_VM_MAX_UREGS);
     const uint8_t* p = static_cast<const uint8_t*>(blob);
-    bool has_position = false;
+    bool has_position = false, has_age = false, has_ribbon_id = false;
+    uint64_t seen = 0;
     for (uint32_t i = 0; i < h.n_attrs; ++i) {
         HnbAttrEntry a;
         memcpy(&a, p + h.attrs_off + i * sizeof a, sizeof a);
         if (a.attr >= HNB_ATTR_COUNT || a.attr < HNB_ATTR_POSITION) return fail(HNB_ERR_BAD_PROGRAM, "attribute %u is not storable", a.attr);
-        if (a.ncomp < 1 || a.ncomp > 4) return fail(HNB_ERR_BAD_PROGRAM, "bad attribute entry %u", i);
+        if (a.ncomp != kAttrComponents[a.attr]) return fail(HNB_ERR_BAD_PROGRAM, "attribute %u has %u components, not %u", a.attr, a.ncomp, kAttrComponents[a.attr]);
+        if (seen >> a.attr & 1u) return fail(HNB_ERR_BAD_PROGRAM, "attribute %u appears twice in the layout", a.attr);
+        seen |= 1ull << a.attr;
         if (a.attr == HNB_ATTR_POSITION) has_position = true;
+        if (a.attr == HNB_ATTR_AGE) has_age = true;
+        if (a.attr == HNB_ATTR_RIBBON_ID) has_ribbon_id = true;
         const bool pinned = a.attr == HNB_ATTR_POSITION || a.attr == HNB_ATTR_VELOCITY || a.attr == HNB_ATTR_AGE ||
                             a.attr == HNB_ATTR_LIFETIME;
         const uint32_t want = a.attr == HNB_ATTR_POSITION ? HNB_REG_POSITION
@@ -352,10 +390,23 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
     }
     // The POSITION attribute is mandatory (src/lib.rs:838-845).
     if (!has_position) return fail(HNB_ERR_BAD_PROGRAM, "the particle layout is missing the POSITION attribute");
+    // Ribbons: the flag and the RIBBON_ID attribute go together, and AGE is mandatory (src/lib.rs:846-856).
+    if (((h.flags & HNB_PROG_HAS_RIBBONS) != 0) != has_ribbon_id)
+        return fail(HNB_ERR_BAD_PROGRAM, "HNB_PROG_HAS_RIBBONS must be set exactly when the layout has RIBBON_ID");
+    if (has_ribbon_id && !has_age) return fail(HNB_ERR_BAD_PROGRAM, "a layout with RIBBON_ID needs the AGE attribute");
+    if (((h.flags & HNB_PROG_READS_PARENT) != 0) != (h.parent_n_attrs != 0))
+        return fail(HNB_ERR_BAD_PROGRAM, "HNB_PROG_READS_PARENT must be set exactly when parent attributes are listed");
+    if (((h.flags & HNB_PROG_EMITS_EVENTS) != 0) != (h.n_event_channels != 0))
+        return fail(HNB_ERR_BAD_PROGRAM, "HNB_PROG_EMITS_EVENTS must be set exactly when the program has event channels");
+    for (uint32_t i = 0; i < h.parent_n_attrs; ++i) {
+        uint32_t id;
+        memcpy(&id, p + h.parent_attrs_off + i * 4, 4);
+        if (id >= HNB_ATTR_COUNT || id < HNB_ATTR_POSITION) return fail(HNB_ERR_BAD_PROGRAM, "parent attribute %u is not storable", id);
+    }
     for (uint32_t i = 0; i < h.n_props; ++i) {
         HnbPropEntry pe;
         memcpy(&pe, p + h.props_off + i * sizeof pe, sizeof pe);
-        if (pe.ncomp < 1 || pe.ncomp > 4 || pe.word_offset + pe.ncomp > h.prop_words) return fail(HNB_ERR_BAD_PROGRAM, "bad property entry %u", i);
+        if (pe.ncomp < 1 || pe.ncomp > 4 || (uint64_t)pe.word_offset + pe.ncomp > h.prop_words) return fail(HNB_ERR_BAD_PROGRAM, "bad property entry %u", i);
         if (!memchr(pe.name, 0, sizeof pe.name)) return fail(HNB_ERR_BAD_PROGRAM, "unterminated property name %u", i);
     }
     int rc = validate_stream(p, p + h.uniform_off, h.uniform_len, 0, h, 0);

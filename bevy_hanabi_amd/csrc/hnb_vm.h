@@ -26,6 +26,20 @@ namespace hnb {
 // One instruction (two 32-bit words, see include/hanabi_amd.h).
 struct __attribute__((aligned(8))) Ins { uint32_t x, y; };
 
+#ifdef HNB_VM_BOUNDS_CHECK
+// Host test builds only (tests/validator_fuzz): every register access is checked, so that a program the
+// validator accepted but that addresses outside a file is reported instead of being undefined behaviour.
+extern "C" void hnb_vm_oob(uint32_t index, uint32_t size);
+template <uint32_t N>
+struct checked_file_t {
+    uint32_t v[N];
+    uint32_t& operator[](uint32_t i) { if (i >= N) hnb_vm_oob(i, N); return v[i < N ? i : 0]; }
+    const uint32_t& operator[](uint32_t i) const { if (i >= N) hnb_vm_oob(i, N); return v[i < N ? i : 0]; }
+};
+typedef checked_file_t<HNB_VM_MAX_REGS> vreg_file_t;
+typedef checked_file_t<HNB_VM_MAX_REGS_WIDE> vreg_file_wide_t;
+typedef checked_file_t<HNB_VM_MAX_UREGS> UFile;
+#else
 // V register file of one particle: a single LLVM vector so that dynamic (wave-uniform)
 // register numbers lower to VGPR-indexed moves instead of scratch memory.
 typedef uint32_t vreg_file_t __attribute__((vector_size(HNB_VM_MAX_REGS * 4)));
@@ -43,6 +57,7 @@ struct UFile {
     HNB_HD_MEMBER uint32_t& operator[](uint32_t i) { return v[i]; }
     HNB_HD_MEMBER const uint32_t& operator[](uint32_t i) const { return v[i]; }
 };
+#endif
 
 // Wave-uniform inputs of one effect instance for one frame (pointers into uniform memory:
 // on the device every access through them is a scalar load).
