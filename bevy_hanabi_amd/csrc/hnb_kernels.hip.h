@@ -228,6 +228,21 @@ __device__ __forceinline__ void pin_store3(const V3 (&src)[P], char* plane, cons
             return;
         }
     }
+    if constexpr (P == 4) {
+        // A quad with free slots: its 48 bytes are read again (they were loaded a moment ago: an L2 / MALL hit), the
+        // alive slots' words replaced, and the whole quad stored with 16-byte stores. Partial 12-byte stores leave
+        // sectors half-written, which the memory side completes with a read-modify-write (measured in the firework
+        // die-off: a frame with free slots took 1.24x a frame with none before, 1.19x now). Nothing else writes a
+        // free slot during the update.
+        u4v* dst = reinterpret_cast<u4v*>(plane) + (size_t)(slot[0] >> 2) * 3;
+        u4v q0 = dst[0], q1 = dst[1], q2 = dst[2];
+        if (valid[0]) { q0.x = f2u(src[0].x); q0.y = f2u(src[0].y); q0.z = f2u(src[0].z); }
+        if (valid[1]) { q0.w = f2u(src[1].x); q1.x = f2u(src[1].y); q1.y = f2u(src[1].z); }
+        if (valid[2]) { q1.z = f2u(src[2].x); q1.w = f2u(src[2].y); q2.x = f2u(src[2].z); }
+        if (valid[3]) { q2.y = f2u(src[3].x); q2.z = f2u(src[3].y); q2.w = f2u(src[3].z); }
+        dst[0] = q0; dst[1] = q1; dst[2] = q2;
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < P; ++p)
         if (valid[p]) reinterpret_cast<u3_t*>(plane)[slot[p]] = u3_t{f2u(src[p].x), f2u(src[p].y), f2u(src[p].z)};
@@ -251,6 +266,16 @@ __device__ __forceinline__ void pin_store1(const float (&src)[P], char* plane, c
             HNB_NT_STORE((u4v{f2u(src[0]), f2u(src[1]), f2u(src[2]), f2u(src[3])}), reinterpret_cast<u4v*>(plane) + (slot[0] >> 2));
             return;
         }
+    }
+    if constexpr (P == 4) {  // as in pin_store3: read the quad again, blend, store 16 bytes
+        u4v* dst = reinterpret_cast<u4v*>(plane) + (slot[0] >> 2);
+        u4v q = *dst;
+        if (valid[0]) q.x = f2u(src[0]);
+        if (valid[1]) q.y = f2u(src[1]);
+        if (valid[2]) q.z = f2u(src[2]);
+        if (valid[3]) q.w = f2u(src[3]);
+        *dst = q;
+        return;
     }
 #pragma unroll
     for (int p = 0; p < P; ++p)
@@ -327,10 +352,7 @@ __device__ __forceinline__ void chunk_record(const ChunkCtx& c, uint32_t chunk, 
     uint32_t local_alive = 0, local_dead = 0;
 #pragma unroll
     for (int w = 0; w < NSEG; ++w) { a[w] = s_cnt[w] & 0xffffu; d[w] = s_cnt[w] >> 16; local_alive += a[w]; local_dead += d[w]; }
-    if (tid == 0) {
-        cb.counts[chunk] = local_alive;
-        if (local_dead) atomicAdd(&cb.deaths[(size_t)cb.parity * cb.table_cap + c.k], local_dead);
-    }
+    if (tid == 0) cb.counts[chunk] = local_alive;  // (the casualties were counted per instance by the update kernel)
     if (!local_dead) return;  // rows are already [survivors]: nothing to rewrite
     uint32_t abase = c.start, dbase = c.start + local_alive;
 #pragma unroll
@@ -402,13 +424,21 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     uint32_t* dead = reinterpret_cast<uint32_t*>(c.base + args.dead_off);
     const uint32_t dead_before = c.start - excl;
     // survivors keep their (stable, serial) order (vfx_update.wgsl:161-165)
-    for (uint32_t i = tid; i < a; i += kBlock) dst[i] = src[i];
+    // (the chunk's rows are all requested before the first store: one dependent access per row otherwise)
+    constexpr uint32_t kPer = kChunk / kBlock;
+    uint32_t v[kPer];
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) { const uint32_t i = tid + q * kBlock; v[q] = i < rows ? src[i] : 0u; }
     // the d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151); its slot is free again
     uint8_t* flags = reinterpret_cast<uint8_t*>(c.base + args.alive_flag_off);
-    for (uint32_t i = tid; i < rows - a; i += kBlock) {
-        const uint32_t slot = src[a + i];
-        dead[c.n - 1u - (dead_before + i)] = slot;
-        flags[slot] = 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) {
+        const uint32_t i = tid + q * kBlock;
+        if (i < a) dst[i] = v[q];
+        else if (i < rows) {
+            dead[c.n - 1u - (dead_before + (i - a))] = v[q];
+            flags[v[q]] = 0u;
+        }
     }
     if (last && tid == 0) {
         const uint32_t survivors = excl + a;
@@ -780,28 +810,39 @@ k_list_rows(const CompactArgs args, const uint64_t* __restrict__ inst_base, cons
     uint32_t* seg = s_list + wave * kWaveRows;
     uint32_t wa = 0, wd = 0;
     const uint64_t below = (1ull << lane) - 1ull;
-    for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
-        const uint32_t sbase = wstart + step * kStepRows;
-        if (sbase >= n) break;
-        uint32_t slot[4];
-        bool valid[4], al[4];
+    // All 16 rows of a lane are requested before anything is used, then all 16 alive bytes: the kernel is a chain of
+    // two dependent memory accesses per row, so its speed is the number of them in flight. Lane l owns rows
+    // l, 64+l, 128+l, 192+l of each of the wave's 4 steps.
+    constexpr uint32_t kSteps = kWaveRows / kStepRows;
+    uint32_t slot[kSteps][4];
+    bool valid[kSteps][4], al[kSteps][4];
+#pragma unroll
+    for (uint32_t step = 0; step < kSteps; ++step)
+#pragma unroll
+        for (uint32_t p = 0; p < 4; ++p) {
+            const uint32_t row = wstart + step * kStepRows + p * 64u + lane;
+            valid[step][p] = row < n;
+            slot[step][p] = valid[step][p] ? list[row] : 0u;
+        }
+#pragma unroll
+    for (uint32_t step = 0; step < kSteps; ++step)
+#pragma unroll
+        for (uint32_t p = 0; p < 4; ++p) al[step][p] = valid[step][p] && flags[slot[step][p]] == 1u;  // 2 = died in this frame's update
+#pragma unroll
+    for (uint32_t step = 0; step < kSteps; ++step) {
         uint64_t ma[4], mv[4];
 #pragma unroll
-        for (uint32_t p = 0; p < 4; ++p) {  // lane l owns rows l, 64+l, 128+l, 192+l of the step
-            const uint32_t row = sbase + p * 64u + lane;
-            valid[p] = row < n;
-            slot[p] = valid[p] ? list[row] : 0u;
-            al[p] = valid[p] && flags[slot[p]] == 1u;  // 2 = died in this frame's update
-            ma[p] = __ballot(al[p]);
-            mv[p] = __ballot(valid[p]);
+        for (uint32_t p = 0; p < 4; ++p) {
+            ma[p] = __ballot(al[step][p]);
+            mv[p] = __ballot(valid[step][p]);
         }
         uint32_t base_a = wa, base_d = wd;
 #pragma unroll
         for (uint32_t p = 0; p < 4; ++p) {
             const uint32_t ba = (uint32_t)__popcll(ma[p] & below), bv = (uint32_t)__popcll(mv[p] & below);
-            if (valid[p]) {
-                if (al[p]) seg[base_a + ba] = slot[p];
-                else seg[kWaveRows - 1u - (base_d + (bv - ba))] = slot[p];
+            if (valid[step][p]) {
+                if (al[step][p]) seg[base_a + ba] = slot[step][p];
+                else seg[kWaveRows - 1u - (base_d + (bv - ba))] = slot[step][p];
             }
             base_a += (uint32_t)__popcll(ma[p]);
             base_d += (uint32_t)__popcll(mv[p]) - (uint32_t)__popcll(ma[p]);
