@@ -750,6 +750,72 @@ int hnb_program_destroy(HnbProgram* p) {
     return HNB_OK;
 }
 
+// Where a large block lands in physical memory decides how evenly its planes spread over the HBM stacks, and the
+// driver's choice varies from one allocation to the next: on MI355X the same update kernel over the same 822 MB
+// slab at the same virtual address measured 0.201, 0.223 or 0.231 ms depending on the allocation (stable for the
+// life of the allocation; tools/bimodal_probe.py), and a plain pass that streams the planes the way the update does
+// tells the placements apart (0.231 vs 0.241 ms). For blocks of kPlacementMinBytes or more, up to
+// HNB_SLAB_CANDIDATES (default 24) allocations are tried, each timed with that pass; the search stops as soon as one
+// candidate is clearly faster than another (two classes seen, the fast one in hand), the fastest is kept and the
+// others are released. About one placement in eight is a fast one. Candidates cost ~3 ms each and transient
+// memory (bounded by kPlacementMaxTransient), once per block; a failed candidate allocation just ends the search.
+constexpr size_t kPlacementMinBytes = (size_t)256 << 20;
+constexpr size_t kPlacementMaxTransient = (size_t)32 << 30;
+hipError_t alloc_slab_block(HnbProgram* p, size_t bytes, char** out) {
+    int want = 24;
+    if (const char* e = getenv("HNB_SLAB_CANDIDATES")) want = std::max(1, std::min(32, atoi(e)));
+    want = (int)std::min<size_t>((size_t)want, std::max<size_t>(1, kPlacementMaxTransient / std::max<size_t>(bytes, 1)));
+    // Blocks shared by many small instances showed a single class (24 candidates of 1 GiB within 1 %): not searched.
+    if (bytes < kPlacementMinBytes || bytes != p->slab_stride) want = 1;
+    const bool debug = getenv("HNB_DEBUG_ALLOC") != nullptr;
+    if (want == 1) return hipMalloc(reinterpret_cast<void**>(out), bytes);
+    ProbeArgs pa{};
+    pa.n_quads = (p->dev.capacity + 3u) / 4u;
+    for (uint32_t a = 0; a < p->dev.n_attrs && pa.n_planes < 8; ++a) {  // the pinned attribute planes, as a streaming update touches them
+        const DevAttr& at = p->dev.attrs[a];
+        if (at.reg == HNB_REG_NONE) continue;
+        pa.off[pa.n_planes] = at.plane_off;
+        pa.stride16[pa.n_planes] = at.ncomp;   // ncomp * 4 B * 4 slots = ncomp 16-byte words per quad
+        if (at.reg != HNB_REG_LIFETIME) pa.write_mask |= 1u << pa.n_planes;
+        pa.n_planes += 1;
+    }
+    hipStream_t st = p->ctx->stream;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) return hipMalloc(reinterpret_cast<void**>(out), bytes);
+    char* best = nullptr;
+    float best_ms = 0.0f, worst_ms = 0.0f;
+    std::vector<char*> rejected;
+    hipError_t first_error = hipSuccess;
+    for (int c = 0; c < want; ++c) {
+        char* cand = nullptr;
+        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&cand), bytes);
+        if (e != hipSuccess) { if (!best) first_error = e; (void)hipGetLastError(); break; }
+        hipMemsetAsync(cand, 0, bytes, st);  // touch every page before timing
+        float ms = 1e30f;
+        const uint32_t grid = (uint32_t)((pa.n_quads + 255u) / 256u);
+        for (int rep = 0; rep < 4; ++rep) {
+            hipEventRecord(ev0, st);
+            k_probe_placement<<<grid, 256, 0, st>>>(cand, pa);
+            hipEventRecord(ev1, st);
+            hipEventSynchronize(ev1);
+            float t = 0.0f;
+            hipEventElapsedTime(&t, ev0, ev1);
+            if (rep > 0 && t < ms) ms = t;  // the first pass warms the TLBs
+        }
+        if (debug) fprintf(stderr, "hanabi_amd: slab candidate %d at %p: %.4f ms\n", c, (void*)cand, ms);
+        if (!best || ms < best_ms) { if (best) rejected.push_back(best); best = cand; best_ms = ms; }
+        else rejected.push_back(cand);
+        worst_ms = std::max(worst_ms, ms);
+        if (best_ms < 0.975f * worst_ms) break;  // two classes of placement seen and the fast one is in hand
+    }
+    for (char* r : rejected) hipFree(r);
+    hipEventDestroy(ev0);
+    hipEventDestroy(ev1);
+    if (!best) return first_error;
+    *out = best;
+    return hipSuccess;
+}
+
 int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
     if (!p || !out_fx) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
     HnbContext* ctx = p->ctx;
@@ -770,13 +836,14 @@ int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
         const uint32_t n_slots = (uint32_t)std::min<size_t>(want, std::max<size_t>(1, p->effects.size()));
         HnbProgram::SlabBlock blk;
         blk.n_slots = n_slots;
-        e = hipMalloc(reinterpret_cast<void**>(&blk.base), p->slab_stride * n_slots);
+        e = alloc_slab_block(p, p->slab_stride * n_slots, &blk.base);
         if (e == hipSuccess) {
             p->slab_blocks.push_back(blk);
             for (uint32_t i = n_slots; i-- > 0;) p->free_slabs.push_back(blk.base + (size_t)i * p->slab_stride);
         }
     }
     if (e == hipSuccess) { fx->slab = p->free_slabs.back(); p->free_slabs.pop_back(); }
+    if (e == hipSuccess && getenv("HNB_DEBUG_ALLOC")) fprintf(stderr, "hanabi_amd: effect slab %p (%zu bytes)\n", fx->slab, p->slab_bytes);
     if (e != hipSuccess) { delete fx; return fail(HNB_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes) for effect slab failed: %s", p->slab_bytes, hipGetErrorString(e)); }
     char* base = static_cast<char*>(fx->slab);
     const uint32_t cap = p->dev.capacity;
