@@ -10,8 +10,12 @@ from . import build  # noqa: F401
 
 try:
     from ._hanabi_host import *  # noqa: F401,F403
-    from . import _hanabi_host as host  # noqa: F401
-except ImportError as _e:  # pragma: no cover
-    raise ImportError("bevy_hanabi_amd._hanabi_host is not built: run `python -m bevy_hanabi_amd.build`") from _e
+except ImportError:  # a fresh checkout: the host library (g++, no GPU toolchain needed) is built in-tree on first import
+    try:
+        build.build_host(verbose=True)
+        from ._hanabi_host import *  # noqa: F401,F403
+    except Exception as _e:  # pragma: no cover
+        raise ImportError("bevy_hanabi_amd._hanabi_host could not be built: run `python -m bevy_hanabi_amd.build`") from _e
+from . import _hanabi_host as host  # noqa: F401,E402
 
 from .runtime import Context, Effect, EffectMetadata, HanabiError, Program, SimParams, jit_precompile, validate_program  # noqa: F401,E402
