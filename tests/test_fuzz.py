@@ -280,3 +280,91 @@ def _world(seed, order):
 @pytest.mark.parametrize("seed", list(range(8)))
 def test_fuzz_world_gpu(seed, order):
     _world(seed, order)
+
+
+# ---- random systems of linked effects (GPU spawn events, parent reads) -------------------------------------------
+def _random_system(seed):
+    """A root effect with 1-3 event channels, children on them (some with a grand-child), random event counts (typed
+    expressions), capacities around the chunk size, event buffers from 'always overflows' to 'never'."""
+    import numpy as np
+    from fuzz_assets import TypedGen
+    from helpers import EffectSpec
+
+    rng = np.random.default_rng(seed)
+    A = bh.Attribute
+    U = bh.ValueType(bh.ScalarType.Uint)
+
+    def make(cap, n_channels, child_of_float_attrs):
+        g = TypedGen(int(rng.integers(1 << 30)))
+        g.treadable, g.props, g.has_age = {}, [], True
+        w = g.w
+        init = []
+        if child_of_float_attrs is None:
+            init.append(bh.SetAttributeModifier(A.POSITION, g.texpr("f", 3, 2, "init").expr()))
+        else:   # a child: position from the parent, one attribute computed from the parent's
+            init.append(bh.InheritAttributeModifier(A.POSITION))
+            src = child_of_float_attrs[int(rng.integers(len(child_of_float_attrs)))]
+            init.append(bh.SetAttributeModifier(A.F32_3, (w.parent_attr(src) * w.lit(0.5) + w.rand(bh.ValueType(bh.ScalarType.Float))).expr()))
+        init.append(bh.SetAttributeModifier(A.VELOCITY, g.texpr("f", 3, 2, "init").expr()))
+        init.append(bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()))
+        init.append(bh.SetAttributeModifier(A.LIFETIME, w.lit(0.05).uniform(w.lit(float(rng.uniform(0.1, 0.5)))).expr()))
+        init.append(bh.SetAttributeModifier(A.F32_0, g.texpr("f", 1, 2, "init").expr()))
+        update = []
+        if rng.random() < 0.5:
+            update.append(bh.AccelModifier(w.lit((0.0, -3.0, 0.0)).expr()))
+        for ch in range(n_channels):
+            cond = bh.EventEmitCondition.OnDie if rng.random() < 0.5 else bh.EventEmitCondition.Always
+            k = rng.random()
+            if k < 0.4:
+                count = w.lit(bh.Value.u32(int(rng.integers(0, 4))))
+            else:
+                count = (w.rand(bh.ValueType(bh.ScalarType.Float)) * w.lit(float(rng.uniform(0.5, 3.9)))).cast(U)
+            update.append(bh.EmitSpawnEventModifier(cond, count.expr(), ch))
+        asset = bh.EffectAsset(cap, bh.SpawnerSettings.once(float(cap)), w.finish())
+        for m in init:
+            asset.init(m)
+        for m in update:
+            asset.update(m)
+        return asset
+
+    caps = [37, 300, 4096, 4200, 9000]
+    n_ch = int(rng.integers(1, 4))
+    specs = [EffectSpec(make(int(rng.choice(caps)), n_ch, None))]
+    for ch in range(n_ch):
+        grand = rng.random() < 0.4
+        specs.append(EffectSpec(make(int(rng.choice(caps)) * 2, 1 if grand else 0, [A.F32_0]), parent=0, channel=ch,
+                                event_capacity=int(rng.choice([16, 256, 5000, 1 << 16]))))
+        if grand:
+            specs.append(EffectSpec(make(int(rng.choice(caps)), 0, [A.F32_0, A.F32_3]), parent=len(specs) - 1, channel=0,
+                                    event_capacity=int(rng.choice([64, 4096]))))
+    return specs
+
+
+def _run_system(seed, ctx, slot_order=False):
+    import numpy as np
+    from helpers import Frame, GpuSystem, OracleSystem, assert_same_system_state, frame_seed
+
+    specs = _random_system(seed)
+    g = GpuSystem(specs, ctx)
+    o = OracleSystem(specs, slot_order=slot_order)
+    rng = np.random.default_rng(seed + 5)
+    try:
+        root_cap = specs[0].asset.capacity
+        for f in range(36):
+            dt = 1 / 60 if rng.random() < 0.8 else 1 / 30
+            spawn = root_cap if f == 0 else (int(rng.integers(0, root_cap // 2 + 2)) if rng.random() < 0.4 else 0)
+            frames = [Frame(dt, spawn if i == 0 else 0, frame_seed(seed * 101 + f * 7 + i), time=f / 60) for i in range(len(specs))]
+            g.step(frames)
+            o.step(frames)
+            if f % 6 == 5:
+                assert_same_system_state(o.state(), g.state(), f"seed {seed} frame {f}")
+    finally:
+        g.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jit", ["1", "0"])
+@pytest.mark.parametrize("seed", list(range(300, 310)))
+def test_fuzz_systems_gpu(ctx, seed, jit, monkeypatch):
+    monkeypatch.setenv("HNB_JIT", jit)
+    _run_system(seed, ctx)

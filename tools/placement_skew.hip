@@ -27,8 +27,8 @@ int main(int argc, char** argv) {
     const bool use_vmm = argc > 2 && atoi(argv[2]) == 1;
     const uint64_t cap = 1ull << 24;
     const uint64_t MiB = 1ull << 20;
-    const size_t bytes = 960 * MiB;
-    const uint64_t skews[] = {0, 65536};
+    const size_t bytes = (argc > 3 ? (size_t)atoi(argv[3]) : 960) * MiB;
+    const uint64_t skews[] = {0};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<char*> bufs;
     printf("candidate:   "); for (uint64_t s : skews) printf(" skew=%-8llu", (unsigned long long)s); printf("\n");
