@@ -781,7 +781,11 @@ hipError_t alloc_slab_block(HnbProgram* p, size_t bytes, char** out) {
     }
     hipStream_t st = p->ctx->stream;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) return hipMalloc(reinterpret_cast<void**>(out), bytes);
+    if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) {
+        if (ev0) hipEventDestroy(ev0);
+        (void)hipGetLastError();
+        return hipMalloc(reinterpret_cast<void**>(out), bytes);
+    }
     char* best = nullptr;
     float best_ms = 0.0f, worst_ms = 0.0f;
     std::vector<char*> rejected;
