@@ -31,10 +31,11 @@ CAPACITY = 1 << 24
 BYTES_PER_UPDATE = 68  # reads pos12+vel12+age4+lifetime4, writes pos12+vel12+age4, + 8 B alive-list entry
 HBM_PEAK_GBS = 8000.0  # MI355X spec (guides/MI355X_MICROARCH.md)
 # HBM bytes per k_update_slots_stream launch at capacity 16,777,216 from the PMC passes committed under
-# profiles/ (r01e_summary.md: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate rocprofv3 runs).
+# profiles/ (r01i_summary.md: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate rocprofv3 runs; with lifetime
+# culling the LIFETIME plane is not read in the timed frames: 57.1 B per particle).
 # Counters cannot be collected from inside this script; the figure is per launch of this workload.
-PMC_TRAFFIC_BYTES = {1 << 24: 1.0352e9}
-PMC_TRAFFIC_SOURCE = "profiles/r01e_summary.md"
+PMC_TRAFFIC_BYTES = {1 << 24: 9.587e8}
+PMC_TRAFFIC_SOURCE = "profiles/r01i_summary.md"
 DT = 1.0 / 60.0
 MIN_LIFETIME = 0.8  # firework.rs: lifetime = uniform(0.8, 1.2)
 TIMING_PERIOD = 5   # HIP events bracket the kernels of every 5th timed frame (each costs ~20 us of stream bubbles)

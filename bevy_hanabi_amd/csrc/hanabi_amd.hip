@@ -117,6 +117,7 @@ struct HnbProgram {
     Ins* d_code = nullptr;
     size_t slab_bytes = 0;
     bool wide_file = false;       // init_regs / update_regs above HNB_VM_MAX_REGS: generic kernels use the wide V file
+    uint32_t cull_dt_operand = 0; // lifetime culling: decoded operand a of the update stream's AGE_TICK (dev.cull_lifetime)
     bool update_streams = false;  // update stream runs on the streaming kernel (macro ops, U operands)
     StreamLaunchFn stream_launch = nullptr;  // specialised (or interpreted) streaming kernel for this update stream
     const char* stream_kernel_name = "";
@@ -653,6 +654,7 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     }
     p->slot_order = ctx->list_order == HNB_LIST_ORDER_SLOT && !(h.flags & HNB_PROG_HAS_RIBBONS);  // ribbons are re-sorted anyway
     d.alive_flag_off = (uint32_t)off; off += align_up((size_t)h.capacity, 256);  // alive byte per slot, zeroed with the attribute planes
+    d.lmin_off = (uint32_t)off; off += align_up((size_t)d.chunks_per_inst * 4, 256);  // lifetime bound per chunk (0 = unknown), zeroed too
     d.n_event_channels = h.n_event_channels;
     if (h.n_event_channels) {  // per-slot staging of spawn events (k_update_slots_generic -> k_emit_count / k_emit_events)
         for (uint32_t c = 0; c < h.n_event_channels; ++c) { d.ev_cnt_off[c] = (uint32_t)off; off += list_bytes; }
@@ -690,6 +692,26 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     if (h.uniform_len) memcpy(p->uniform_code.data(), b + h.uniform_off, (size_t)h.uniform_len * 8);
     p->update_streams = update_is_streamable(b, h, p->attrs.data());
     p->wide_file = std::max(h.init_regs, h.update_regs) > HNB_VM_MAX_REGS;
+    // Lifetime culling (hnb_kernels.hip.h): the streaming update reads LIFETIME only for the AGE_TICK's `age < lifetime`.
+    // Eligible: the stream starts with the only AGE_TICK, which tests the lifetime; nothing else writes AGE or LIFETIME.
+    if (p->update_streams && h.update_len > 0 && !(getenv("HNB_CULL_LIFETIME") && getenv("HNB_CULL_LIFETIME")[0] == '0')) {
+        const Ins* uc = reinterpret_cast<const Ins*>(b + h.update_off);
+        bool ok = (uc[0].x & 0xffu) == HNB_OP_M_AGE_TICK && ((uc[0].y >> 16) & 1u);
+        for (uint32_t i = 1; i < h.update_len && ok; ++i) {
+            const uint32_t op = uc[i].x & 0xffu, dst = (uc[i].x >> 8) & 0xffu;
+            if (op == HNB_OP_M_AGE_TICK) ok = false;
+            if (op == HNB_OP_M_PIN_SET && (dst == HNB_REG_AGE || dst == HNB_REG_LIFETIME)) ok = false;
+        }
+        bool loads_life = false, stores_life = false, has_age = false;
+        for (uint32_t a = 0; a < h.n_attrs; ++a) {
+            if (p->attrs[a].reg == HNB_REG_LIFETIME) { loads_life = (p->attrs[a].update_flags & HNB_ATTR_UPD_LOAD) != 0; stores_life = (p->attrs[a].update_flags & HNB_ATTR_UPD_STORE) != 0; }
+            if (p->attrs[a].reg == HNB_REG_AGE) has_age = (p->attrs[a].update_flags & HNB_ATTR_UPD_LOAD) != 0;
+        }
+        if (ok && loads_life && !stores_life && has_age) {
+            d.cull_lifetime = 1u;
+            p->cull_dt_operand = HNB_OPERAND_DECODE((uc[0].x >> 16) & 0xffu, uc[0].y >> 13);
+        }
+    }
     if (p->update_streams) select_stream_kernel(reinterpret_cast<const Ins*>(b + h.update_off), h.update_len, &p->stream_launch, &p->stream_kernel_name);
     const bool aot_static = p->update_streams && strcmp(p->stream_kernel_name, "ProgInterp") != 0;
     p->kernel_info = std::string(p->wide_file ? "wide-file " : "") + "init=" + (h.init_len ? "interp" : "none") + " update=" +
@@ -1122,6 +1144,7 @@ int hnb_simulate(HnbContext* ctx) {
             sa.update_len = p->dev.update_len;
             sa.update_code = p->dev.update_code;
             sa.died_mark = died_mark;
+            sa.cull_lifetime = p->dev.cull_lifetime; sa.lmin_off = p->dev.lmin_off; sa.dt_operand = p->cull_dt_operand;
             for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
                 const DevAttr& at = p->dev.attrs[a];
                 const int pi = at.reg == HNB_REG_POSITION ? 0 : at.reg == HNB_REG_VELOCITY ? 1 : at.reg == HNB_REG_AGE ? 2 : at.reg == HNB_REG_LIFETIME ? 3 : -1;
@@ -1236,6 +1259,8 @@ int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t 
     if (src_size != bytes) return fail(HNB_ERR_INVALID_ARG, "source size %zu != plane size %zu", src_size, bytes);
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     HIP_TRY(hipMemcpy(static_cast<char*>(fx->slab) + p->dev.attrs[ai].plane_off, src, bytes, hipMemcpyHostToDevice));
+    // the chunks' lifetime bounds (lifetime culling) no longer describe the planes
+    HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.lmin_off, 0, (size_t)p->dev.chunks_per_inst * 4));
     return HNB_OK;
 }
 

@@ -35,6 +35,10 @@ struct DevProgram {
     uint32_t alive_flag_off;   // u8[capacity]: 0 free, 1 alive, 2 died in this frame's update (drives the slot-major update)
     uint32_t n_event_channels;
     uint32_t ev_cnt_off[HNB_MAX_EVENT_CHANNELS];     // u32[capacity] per channel: events appended by the particle in that slot
+    // Lifetime culling (k_update_slots_stream): f32[chunks_per_inst], a lower bound of the LIFETIME of every alive particle
+    // of the 4096-slot chunk, 0 = unknown. k_init zeroes the entry of a chunk it spawns into.
+    uint32_t lmin_off;
+    uint32_t cull_lifetime;    // 1: the streaming update keeps the bounds up to date and uses them
     DevAttr attrs[kMaxAttrs];
     const Ins* init_code;
     const Ins* update_code;

@@ -215,6 +215,7 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
         CODE::run_init(prog, S, U, io);
         alive[alive0 + i] = slot;
         reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = 1u;  // the update walks the slots through these bytes
+        if (prog.cull_lifetime) reinterpret_cast<float*>(base + prog.lmin_off)[slot / kChunk] = 0.0f;  // the chunk's lifetime bound is unknown again
         CODE::store_init(prog, S, base, slot);
     }
 }
@@ -683,8 +684,20 @@ struct SlotArgs {
     uint32_t plane_off[4];   // position, velocity, age, lifetime
     uint32_t flags;          // bit i: load pinned attr i; bit 4+i: store pinned attr i
     uint32_t died_mark;      // byte written for a particle that dies: 2 (k_list_rows pushes it on the dead list) or 0 (slot-ordered lists)
+    uint32_t cull_lifetime;  // 1: lifetime culling (below); lmin_off = f32[chunks_per_inst] in the slab, dt_operand = operand a of the AGE_TICK
+    uint32_t lmin_off, dt_operand;
     const Ins* update_code;
 };
+
+// Lifetime culling. In a streamable update the LIFETIME plane is read for one thing: `is_alive = age < lifetime` right
+// after `age += dt` (src/lib.rs:1223-1258). Per 4096-slot chunk the slab keeps Lm, a lower bound of the lifetime of
+// every alive particle of the chunk (the exact minimum when it was last recomputed; deaths can only raise the true
+// minimum, a spawn resets the bound to "unknown"). A wave step whose alive particles all satisfy age + dt < Lm cannot
+// lose a particle - age + dt < Lm <= lifetime, the very comparison the program makes, no rounding involved - so it
+// does not load the lifetimes at all: 4 of the 61.7 bytes per particle of the firework update. Steps that cannot
+// prove it load the plane and test exactly as before; when every step of a chunk loaded it, the chunk's bound is
+// recomputed. A burst effect runs culled for most of its particles' lives; an effect that spawns into every chunk every
+// frame recomputes every frame and costs what it did before.
 
 // PROBE (tools/stream_probe.hip only; 0 in the product): 4 = skip stores, 8 = skip the program.
 template <class PROG, int WAVES, int PROBE = 0>
@@ -692,6 +705,7 @@ __global__ void __launch_bounds__(kBlock, WAVES)
 k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
                       const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
     __shared__ uint32_t s_died[kBlock / 64];
+    __shared__ float s_lmin[kBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
     const uint32_t k = chunk / args.chunks_per_inst, j = chunk - k * args.chunks_per_inst;
@@ -707,6 +721,12 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     uint32_t* flags4 = reinterpret_cast<uint32_t*>(base + args.alive_flag_off);  // 4 alive bytes per word
     const uint32_t fl = args.flags;
     uint32_t died_total = 0;  // wave-uniform
+    const bool cull = args.cull_lifetime != 0u;
+    float* lmin = reinterpret_cast<float*>(base + args.lmin_off);
+    const float Lm = cull ? lmin[j] : 0.0f;           // 0 (or anything not > 0): unknown, every step loads the lifetimes
+    const float dt_tick = cull ? uf(U, args.dt_operand) : 0.0f;
+    float wave_min = __builtin_inff();                // minimum lifetime of the particles that stay alive (steps that loaded them)
+    bool loaded_all = true;                           // wave-uniform: every step with alive slots loaded the lifetimes
 #pragma unroll
     for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
         const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;  // first of this lane's 4 slots
@@ -724,12 +744,26 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
         Pinned<4> X;
 #pragma unroll
         for (int p = 0; p < 4; ++p) { X.pos[p] = V3{0, 0, 0}; X.vel[p] = V3{0, 0, 0}; X.age[p] = 0.0f; X.lifetime[p] = 0.0f; X.alive[p] = true; }
+        bool need_life = true;  // wave-uniform
         if (any) {
             if (fl & 1u) pin_load3<4>(X.pos, p_pos, slot, lanes_on, true);
             if (fl & 2u) pin_load3<4>(X.vel, p_vel, slot, lanes_on, true);
             if (fl & 4u) pin_load1<4>(X.age, p_age, slot, lanes_on, true);
-            if (fl & 8u) pin_load1<4>(X.lifetime, p_life, slot, lanes_on, true);
         }
+        if (cull && Lm > 0.0f) {  // can this step lose a particle? `age + dt` is the AGE_TICK's own arithmetic
+            bool may_die = false;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) may_die = may_die || (was[p] && !(X.age[p] + dt_tick < Lm));
+            need_life = __any(may_die);
+        }
+        if (any && (fl & 8u)) {
+            if (need_life) pin_load1<4>(X.lifetime, p_life, slot, lanes_on, true);
+            else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) X.lifetime[p] = Lm;  // age + dt < Lm holds for every alive slot of the step
+            }
+        }
+        if (!need_life) loaded_all = false;
         if constexpr (!(PROBE & 8)) PROG::template run<4>(args.update_code, args.update_len, X, U);
         if constexpr (!(PROBE & 4)) {
             if (any) {  // a full quad is stored with 16-byte stores; otherwise only the alive slots are written
@@ -744,6 +778,11 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
             for (int p = 0; p < 4; ++p) acc += X.pos[p].x + X.pos[p].y + X.pos[p].z + X.vel[p].x + X.vel[p].y + X.vel[p].z + X.age[p] + X.lifetime[p];
             if (acc == 123.456f) X.alive[0] = false;
         }
+        if (cull && need_life) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (was[p] && X.alive[p]) wave_min = fminf(wave_min, X.lifetime[p]);
+        }
         uint32_t nf = f4;
         uint32_t died_here = 0;
 #pragma unroll
@@ -755,13 +794,26 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
         if (nf != f4) flags4[s0 >> 2] = nf;
         died_total += died_here;
     }
-    if (lane == 0) s_died[wave] = died_total;
+    if (cull) {
+#pragma unroll
+        for (uint32_t off = 32; off > 0; off >>= 1) wave_min = fminf(wave_min, __shfl_xor(wave_min, off, 64));
+    }
+    // (a negative value marks a wave that skipped a load; a real negative minimum reads the same: the bound then simply
+    // stays unknown, which is always correct)
+    if (lane == 0) { s_died[wave] = died_total; s_lmin[wave] = loaded_all ? wave_min : -1.0f; }
     __syncthreads();
     if (tid == 0) {
         uint32_t d = 0;
 #pragma unroll
         for (uint32_t w = 0; w < kBlock / 64; ++w) d += s_died[w];
         if (d) atomicAdd(&cb.deaths[(size_t)cb.parity * cb.table_cap + k], d);
+        if (cull) {  // every step of the chunk loaded the lifetimes: the exact minimum over the particles still alive
+            float m = __builtin_inff();
+            bool all = true;
+#pragma unroll
+            for (uint32_t w = 0; w < kBlock / 64; ++w) { all = all && !(s_lmin[w] < 0.0f); m = fminf(m, s_lmin[w]); }
+            if (all) lmin[j] = m < 3.0e38f ? m : 3.0e38f;  // an empty chunk: any finite bound; a spawn resets it
+        }
     }
 }
 
