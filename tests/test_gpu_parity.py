@@ -555,3 +555,56 @@ def test_denormals_and_special_values_match(ctx, kernels):
     assert np.isnan(st["attrs"]["f32x3_0"].view(np.float32)).all()
     g.fx.destroy()
     g.prog.destroy()
+
+
+def test_lifetime_culling_respects_host_writes_and_partial_respawns(ctx):
+    """Lifetime culling (k_update_slots_stream): after frames in which no chunk read the LIFETIME plane, (1) a host write
+    that shortens some lifetimes must kill exactly those particles in the next frame, (2) a partial respawn into culled
+    chunks must be aged and killed by its own lifetimes. Both against the oracle's rule age + dt < lifetime."""
+    cap = 3 * 4096 + 500
+    w = bh.ExprWriter()
+    init = [bh.SetAttributeModifier(A.POSITION, w.rand(bh.VectorType.VEC3F).expr()), bh.SetAttributeModifier(A.VELOCITY, w.lit((0.0, 1.0, 0.0)).expr()),
+            bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()), bh.SetAttributeModifier(A.LIFETIME, w.lit(5.0).uniform(w.lit(6.0)).expr())]
+    accel = bh.AccelModifier(w.lit((0.0, -1.0, 0.0)).expr())
+    asset = bh.EffectAsset(cap, bh.SpawnerSettings.once(float(cap)), w.finish())
+    for m in init:
+        asset.init(m)
+    asset.update(accel)
+    g = GpuRunner(asset, ctx=ctx)
+    assert "stream" in g.prog.kernel_info()
+    dt = 1 / 60
+    g.step(Frame(dt, cap, frame_seed(0)))
+    for f in range(1, 8):   # culled frames: every lifetime is at least 5 s
+        g.step(Frame(dt, 0, frame_seed(f)))
+    assert g.fx.alive_count() == cap
+    life = g.fx.read_attr(A.LIFETIME.id).reshape(-1).copy()
+    age = g.fx.read_attr(A.AGE.id).reshape(-1)
+    doomed = np.zeros(cap, dtype=bool)
+    doomed[::7] = True
+    doomed[4096:4096 + 64] = True
+    life[doomed] = age[doomed]            # age + dt < lifetime fails in the next frame
+    g.fx.write_attr(A.LIFETIME.id, life)
+    g.step(Frame(dt, 0, frame_seed(8)))
+    assert g.fx.alive_count() == cap - int(doomed.sum())
+    dead_now = set(int(s) for s in g.fx.dead_list())
+    assert dead_now == set(np.nonzero(doomed)[0].tolist())
+    for f in range(9, 14):  # culled again on the new bounds
+        g.step(Frame(dt, 0, frame_seed(f)))
+    assert g.fx.alive_count() == cap - int(doomed.sum())
+    # respawn half of the free slots: their lifetimes are fresh draws, the survivors' are not touched
+    n_new = int(doomed.sum()) // 2
+    g.step(Frame(dt, n_new, frame_seed(14)))
+    assert g.fx.alive_count() == cap - int(doomed.sum()) + n_new
+    life2 = g.fx.read_attr(A.LIFETIME.id).reshape(-1)
+    keep = ~doomed
+    np.testing.assert_array_equal(life2[keep].view(np.uint32), life[keep].view(np.uint32))
+    # shorten ONE respawned particle's lifetime by a host write and check that only it dies
+    alive = g.fx.alive_list()
+    victim = int(alive[-1])
+    life3 = life2.copy()
+    life3[victim] = 0.0
+    g.fx.write_attr(A.LIFETIME.id, life3)
+    g.step(Frame(dt, 0, frame_seed(15)))
+    assert g.fx.alive_count() == cap - int(doomed.sum()) + n_new - 1
+    assert victim not in set(int(s) for s in g.fx.alive_list())
+    g.prog.destroy()
