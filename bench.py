@@ -32,9 +32,10 @@ BYTES_PER_UPDATE = 68  # reads pos12+vel12+age4+lifetime4, wri
 HBM_PEAK_GBS = 8000.0  # MI355X spec (guides/MI355X_MICROARCH.md)
 # HBM bytes per k_update_slots_stream launch at capacity 16,777,216 from the PMC passes committed under
 # profiles/ (r01i_summary.md: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate rocprofv3 runs; with lifetime
-# culling the LIFETIME plane is not read in the timed frames: 57.1 B per particle).
+# culling the LIFETIME plane is not read in the timed frames, and completely alive chunks skip the alive bytes:
+# 56.06 B per particle = pos + vel + age read, pos + vel + age written).
 # Counters cannot be collected from inside this script; the figure is per launch of this workload.
-PMC_TRAFFIC_BYTES = {1 << 24: 9.587e8}
+PMC_TRAFFIC_BYTES = {1 << 24: 9.406e8}
 PMC_TRAFFIC_SOURCE = "profiles/r01i_summary.md"
 DT = 1.0 / 60.0
 MIN_LIFETIME = 0.8  # firework.rs: lifetime = uniform(0.8, 1.2)

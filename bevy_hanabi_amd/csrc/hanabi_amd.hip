@@ -654,7 +654,7 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     }
     p->slot_order = ctx->list_order == HNB_LIST_ORDER_SLOT && !(h.flags & HNB_PROG_HAS_RIBBONS);  // ribbons are re-sorted anyway
     d.alive_flag_off = (uint32_t)off; off += align_up((size_t)h.capacity, 256);  // alive byte per slot, zeroed with the attribute planes
-    d.lmin_off = (uint32_t)off; off += align_up((size_t)d.chunks_per_inst * 4, 256);  // lifetime bound per chunk (0 = unknown), zeroed too
+    d.lmin_off = (uint32_t)off; off += align_up((size_t)d.chunks_per_inst * 8, 256);  // per chunk: lifetime bound (0 = unknown), then "completely alive" flag; zeroed too
     d.n_event_channels = h.n_event_channels;
     if (h.n_event_channels) {  // per-slot staging of spawn events (k_update_slots_generic -> k_emit_count / k_emit_events)
         for (uint32_t c = 0; c < h.n_event_channels; ++c) { d.ev_cnt_off[c] = (uint32_t)off; off += list_bytes; }
@@ -1260,7 +1260,7 @@ int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t 
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     HIP_TRY(hipMemcpy(static_cast<char*>(fx->slab) + p->dev.attrs[ai].plane_off, src, bytes, hipMemcpyHostToDevice));
     // the chunks' lifetime bounds (lifetime culling) no longer describe the planes
-    HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.lmin_off, 0, (size_t)p->dev.chunks_per_inst * 4));
+    HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.lmin_off, 0, (size_t)p->dev.chunks_per_inst * 4));  // (the "completely alive" flags that follow stay valid)
     return HNB_OK;
 }
 

@@ -706,6 +706,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
                       const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
     __shared__ uint32_t s_died[kBlock / 64];
     __shared__ float s_lmin[kBlock / 64];
+    __shared__ uint32_t s_alive[kBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
     const uint32_t k = chunk / args.chunks_per_inst, j = chunk - k * args.chunks_per_inst;
@@ -721,6 +722,13 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     uint32_t* flags4 = reinterpret_cast<uint32_t*>(base + args.alive_flag_off);  // 4 alive bytes per word
     const uint32_t fl = args.flags;
     uint32_t died_total = 0;  // wave-uniform
+    // Chunks known to be completely alive skip the alive bytes as well (u32[chunks_per_inst] after the lifetime bounds:
+    // 1 = every slot of the chunk holds a live particle). Only this kernel maintains the flag: it sets it after counting
+    // 4096 alive slots and no casualty, and clears it when a particle of the chunk dies; spawns only ever go to chunks
+    // with free slots, whose flag is already clear.
+    uint32_t* cfull = reinterpret_cast<uint32_t*>(base + args.lmin_off) + args.chunks_per_inst;
+    const bool chunk_full = cfull[j] == 1u;
+    uint32_t lane_alive = 0;
     const bool cull = args.cull_lifetime != 0u;
     float* lmin = reinterpret_cast<float*>(base + args.lmin_off);
     const float Lm = cull ? lmin[j] : 0.0f;           // 0 (or anything not > 0): unknown, every step loads the lifetimes
@@ -730,10 +738,10 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
 #pragma unroll
     for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
         const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;  // first of this lane's 4 slots
-        const uint32_t f4 = s0 < args.capacity ? flags4[s0 >> 2] : 0u;  // the plane is padded: slots past the capacity read 0
+        const uint32_t f4 = chunk_full ? 0x01010101u : (s0 < args.capacity ? flags4[s0 >> 2] : 0u);  // the plane is padded: slots past the capacity read 0
         bool was[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) was[p] = ((f4 >> (8 * p)) & 0xffu) == 1u;
+        for (int p = 0; p < 4; ++p) { was[p] = ((f4 >> (8 * p)) & 0xffu) == 1u; lane_alive += was[p] ? 1u : 0u; }
         const bool any = was[0] || was[1] || was[2] || was[3];
         if (!__any(any)) continue;
         const bool full = was[0] && was[1] && was[2] && was[3];
@@ -798,6 +806,11 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
 #pragma unroll
         for (uint32_t off = 32; off > 0; off >>= 1) wave_min = fminf(wave_min, __shfl_xor(wave_min, off, 64));
     }
+    if (!chunk_full) {
+#pragma unroll
+        for (uint32_t off = 32; off > 0; off >>= 1) lane_alive += __shfl_xor(lane_alive, off, 64);
+    }
+    if (lane == 0) s_alive[wave] = lane_alive;
     // (a negative value marks a wave that skipped a load; a real negative minimum reads the same: the bound then simply
     // stays unknown, which is always correct)
     if (lane == 0) { s_died[wave] = died_total; s_lmin[wave] = loaded_all ? wave_min : -1.0f; }
@@ -807,6 +820,8 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
 #pragma unroll
         for (uint32_t w = 0; w < kBlock / 64; ++w) d += s_died[w];
         if (d) atomicAdd(&cb.deaths[(size_t)cb.parity * cb.table_cap + k], d);
+        if (chunk_full) { if (d) cfull[j] = 0u; }
+        else if (d == 0u && s_alive[0] + s_alive[1] + s_alive[2] + s_alive[3] == kChunk) cfull[j] = 1u;
         if (cull) {  // every step of the chunk loaded the lifetimes: the exact minimum over the particles still alive
             float m = __builtin_inff();
             bool all = true;
