@@ -837,7 +837,7 @@ template <class CODE>
 __global__ void __launch_bounds__(kBlock)
 k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
                        const uint32_t* __restrict__ ublocks, const CompactBufs cb, const uint32_t died_mark) {
-    __shared__ uint32_t s_died[kBlock / 64];
+    __shared__ uint32_t s_died[kBlock / 64], s_alive[kBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
     const uint32_t k = chunk / prog.chunks_per_inst, j = chunk - k * prog.chunks_per_inst;
@@ -848,10 +848,14 @@ k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_
     VmUniforms U;
     U.u = ublocks + (size_t)k * prog.n_uregs;
     U.xf = fi[k].xf;
-    uint32_t died_total = 0;
+    uint32_t died_total = 0, alive_total = 0;  // wave-uniform
+    // completely alive chunks skip the alive bytes (same flag and rules as in k_update_slots_stream)
+    uint32_t* cfull = reinterpret_cast<uint32_t*>(base + prog.lmin_off) + prog.chunks_per_inst;
+    const bool chunk_full = cfull[j] == 1u;
     for (uint32_t sub = 0; sub < kChunk / kBlock; ++sub) {
         const uint32_t slot = j * kChunk + sub * kBlock + tid;
-        const bool valid = slot < prog.capacity && flags[slot] == 1u;
+        const bool valid = chunk_full || (slot < prog.capacity && flags[slot] == 1u);
+        alive_total += (uint32_t)__popcll(__ballot(valid));
         if (!__any(valid)) continue;
         VmState<typename CODE::file_t> S;
         S.r = typename CODE::file_t{};
@@ -874,13 +878,15 @@ k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_
         }
         died_total += (uint32_t)__popcll(__ballot(valid && !S.alive));
     }
-    if (lane == 0) s_died[wave] = died_total;
+    if (lane == 0) { s_died[wave] = died_total; s_alive[wave] = alive_total; }
     __syncthreads();
     if (tid == 0) {
-        uint32_t d = 0;
+        uint32_t d = 0, a = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < kBlock / 64; ++w) d += s_died[w];
+        for (uint32_t w = 0; w < kBlock / 64; ++w) { d += s_died[w]; a += s_alive[w]; }
         if (d) atomicAdd(&cb.deaths[(size_t)cb.parity * cb.table_cap + k], d);
+        if (chunk_full) { if (d) cfull[j] = 0u; }
+        else if (d == 0u && a == kChunk) cfull[j] = 1u;
     }
 }
 
