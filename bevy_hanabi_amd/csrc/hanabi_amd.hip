@@ -778,7 +778,7 @@ int hnb_program_destroy(HnbProgram* p) {
 // life of the allocation; tools/bimodal_probe.py), and a plain pass that streams the planes the way the update does
 // tells the placements apart (0.231 vs 0.241 ms). For blocks of kPlacementMinBytes or more, up to
 // HNB_SLAB_CANDIDATES (default 24) allocations are tried, each timed with that pass; the search stops as soon as one
-// candidate is clearly faster than another (two classes seen, the fast one in hand), the fastest is kept and the
+// candidate is 3 % faster than the median of those tried (two classes seen, the fast one in hand), the fastest is kept and the
 // others are released. About one placement in eight is a fast one. Candidates cost ~3 ms each and transient
 // memory (bounded by kPlacementMaxTransient), once per block; a failed candidate allocation just ends the search.
 constexpr size_t kPlacementMinBytes = (size_t)256 << 20;
@@ -809,7 +809,8 @@ hipError_t alloc_slab_block(HnbProgram* p, size_t bytes, char** out) {
         return hipMalloc(reinterpret_cast<void**>(out), bytes);
     }
     char* best = nullptr;
-    float best_ms = 0.0f, worst_ms = 0.0f;
+    float best_ms = 0.0f;
+    std::vector<float> times;
     std::vector<char*> rejected;
     hipError_t first_error = hipSuccess;
     for (int c = 0; c < want; ++c) {
@@ -831,8 +832,12 @@ hipError_t alloc_slab_block(HnbProgram* p, size_t bytes, char** out) {
         if (debug) fprintf(stderr, "hanabi_amd: slab candidate %d at %p: %.4f ms\n", c, (void*)cand, ms);
         if (!best || ms < best_ms) { if (best) rejected.push_back(best); best = cand; best_ms = ms; }
         else rejected.push_back(cand);
-        worst_ms = std::max(worst_ms, ms);
-        if (best_ms < 0.975f * worst_ms) break;  // two classes of placement seen and the fast one is in hand
+        times.push_back(ms);
+        if (times.size() >= 3) {  // two classes of placement seen and the fast one is in hand: 4 % apart, the noise within a class is ~1 %
+            std::vector<float> sorted = times;
+            std::sort(sorted.begin(), sorted.end());
+            if (best_ms < 0.97f * sorted[sorted.size() / 2]) break;
+        }
     }
     for (char* r : rejected) hipFree(r);
     hipEventDestroy(ev0);
