@@ -103,8 +103,10 @@ int main(int argc, char** argv) {
     sa.plane_off[2] = off; off += al((size_t)cap * 4);
     sa.plane_off[3] = off; off += al((size_t)cap * 4);
     sa.alive_flag_off = off; off += al((size_t)cap);
+    sa.lmin_off = off; off += al((size_t)sa.chunks_per_inst * 8);  // lifetime bounds + "completely alive" flags (left at 0: the probe measures the plain path)
     sa.flags = 0xf | (0x7 << 4);
     char* slab; CK(hipMalloc(&slab, off));
+    CK(hipMemset(slab + sa.lmin_off, 0, (size_t)sa.chunks_per_inst * 8));
     std::vector<uint32_t> ident(cap); for (uint32_t i = 0; i < cap; ++i) ident[i] = i;
     CK(hipMemcpy(slab + alive_off[0], ident.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(slab + alive_off[1], ident.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
