@@ -893,6 +893,8 @@ int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
     uint64_t slab_addr = reinterpret_cast<uint64_t>(fx->slab);
     HIP_TRY(hipMemcpyAsync(p->d_inst_base + index, &slab_addr, 8, hipMemcpyHostToDevice, ctx->stream));
     for (int i = 0; i < 2; ++i) HIP_TRY(hipMemcpyAsync(p->d_meta[i] + index, &m, sizeof m, hipMemcpyHostToDevice, ctx->stream));
+    // an index that a destroyed instance used before still holds its last casualty count in one of the two rows
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipMemsetAsync(p->d_deaths + (size_t)i * p->table_cap + index, 0, 4, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     fx->props.assign(p->hdr.prop_words, 0u);
     for (const HnbPropEntry& pe : p->props)
@@ -924,6 +926,8 @@ int hnb_effect_destroy(HnbEffect* fx) {
         HnbEffect* moved = p->effects[last];
         hipMemcpy(p->d_inst_base + fx->index, p->d_inst_base + last, 8, hipMemcpyDeviceToDevice);
         for (int i = 0; i < 2; ++i) hipMemcpy(p->d_meta[i] + fx->index, p->d_meta[i] + last, sizeof(DevMeta), hipMemcpyDeviceToDevice);
+        // casualty counters travel with the instance (the row of the coming frame is armed = 0, the other one is stale)
+        for (int i = 0; i < 2; ++i) hipMemcpy(p->d_deaths + (size_t)i * p->table_cap + fx->index, p->d_deaths + (size_t)i * p->table_cap + last, 4, hipMemcpyDeviceToDevice);
         moved->index = fx->index;
         p->effects[fx->index] = moved;
     }

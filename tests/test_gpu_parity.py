@@ -608,3 +608,54 @@ def test_lifetime_culling_respects_host_writes_and_partial_respawns(ctx):
     assert g.fx.alive_count() == cap - int(doomed.sum()) + n_new - 1
     assert victim not in set(int(s) for s in g.fx.alive_list())
     g.prog.destroy()
+
+
+@pytest.mark.parametrize("order", ["spawn", "slot"])
+@pytest.mark.parametrize("gap", [1, 2])
+def test_instance_index_reuse_after_destroy(ctx, slot_ctx, order, gap):
+    """An instance created at a table index that a destroyed instance used before must not inherit that instance's last
+    casualty count (either frame parity): it once left the new instance's counters unrotated and, with slot-ordered lists,
+    produced an alive count of billions."""
+    c = ctx if order == "spawn" else slot_ctx
+    cap = 5000
+    w = bh.ExprWriter()
+    mods = [bh.SetAttributeModifier(A.POSITION, w.rand(bh.VectorType.VEC3F).expr()), bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()),
+            bh.SetAttributeModifier(A.LIFETIME, w.lit(0.02).uniform(w.lit(0.08)).expr())]
+    asset = bh.EffectAsset(cap, bh.SpawnerSettings.once(float(cap)), w.finish())
+    for m in mods:
+        asset.init(m)
+    prog = c.create_program(bh.lower(asset))
+    a, b = prog.create_effect(), prog.create_effect()
+    f = 0
+
+    def frame(pairs):
+        nonlocal f
+        c.frame_begin(1 / 60, f / 60)
+        for fx, orc, spawn in pairs:
+            seed = frame_seed(1000 + f * 3 + (0 if fx is a else 1))
+            fx.set_frame(spawn, seed)
+            if orc is not None:
+                orc.step(Frame(1 / 60, spawn, seed, time=f / 60))
+        c.simulate()
+        f += 1
+
+    frame([(a, None, 100), (b, None, cap)])
+    for _ in range(3):          # particles of b (index 1) die in these frames: its casualty rows are non-zero
+        frame([(a, None, 0), (b, None, 0)])
+    assert b.alive_count() < cap
+    b.destroy()                 # index 1 is free again
+    for _ in range(gap):        # 1 or 2 frames: the new instance's first frame lands on either parity
+        frame([(a, None, 0)])
+    n = prog.create_effect()    # reuses index 1
+    orc = OracleRunner(asset)
+    orc.fx.set_list_order(order == "slot")
+    frame([(a, None, 0), (n, orc, 0)])          # nothing to update: only the counters rotate
+    frame([(a, None, 0), (n, orc, 700)])
+    for _ in range(6):
+        frame([(a, None, 0), (n, orc, 0)])
+    ref = orc.state()
+    m = n.metadata()
+    assert {k: m[k] for k in ref["counters"]} == ref["counters"]
+    np.testing.assert_array_equal(ref["alive"], n.alive_list())
+    np.testing.assert_array_equal(ref["dead"], n.dead_list())
+    prog.destroy()

@@ -1,0 +1,22 @@
+import sys, time
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import bevy_hanabi_amd as bh
+import test_fuzz as t
+bad = 0
+t0 = time.time()
+for seed in range(100, 160):
+    for order in ("spawn", "slot"):
+        print('world', seed, order, flush=True)
+        try:
+            t._world(seed, order)
+        except AssertionError as e:
+            bad += 1; print("WORLD MISMATCH", seed, order, str(e)[:200])
+ctx = bh.Context(0)
+for seed in range(400, 460):
+    print('system', seed, flush=True)
+    try:
+        t._run_system(seed, ctx)
+    except AssertionError as e:
+        bad += 1; print("SYSTEM MISMATCH", seed, str(e)[:200])
+ctx.close()
+print("soak: %d mismatches in %.0f s" % (bad, time.time() - t0))
