@@ -212,6 +212,8 @@ def _world(seed, order):
 
     import os
     trace = os.environ.get("HNB_FUZZ_TRACE") == "1"   # print the schedule and compare after every frame
+    max_inst = int(os.environ.get("HNB_FUZZ_MAX_INST", "5"))   # soak runs raise it to grow the instance tables
+    p_create, p_destroy = (0.08, 0.14) if max_inst <= 5 else (0.30, 0.50)
     rng = np.random.default_rng(seed)
     ctx = bh.Context(0)
     if order == "slot":
@@ -243,11 +245,11 @@ def _world(seed, order):
             ctx.frame_begin(dt, f / 60)
             for pr in programs:
                 r = rng.random()
-                if r < 0.08 and len(pr["inst"]) < 5:
+                if r < p_create and len(pr["inst"]) < max_inst:
                     add_instance(pr)
                     if trace:
                         print(f"frame {f}: program {programs.index(pr)} + instance (now {len(pr['inst'])})", flush=True)
-                elif r < 0.14 and len(pr["inst"]) > 1:
+                elif r < p_destroy and len(pr["inst"]) > 1:
                     victim = int(rng.integers(len(pr["inst"])))
                     it = pr["inst"].pop(victim)
                     it["fx"].destroy()

@@ -4,7 +4,9 @@ import bevy_hanabi_amd as bh
 import test_fuzz as t
 bad = 0
 t0 = time.time()
-for seed in range(100, 160):
+import os
+lo = int(os.environ.get('SOAK_LO', '100')); hi = int(os.environ.get('SOAK_HI', '160'))
+for seed in range(lo, hi):
     for order in ("spawn", "slot"):
         print('world', seed, order, flush=True)
         try:
@@ -12,7 +14,7 @@ for seed in range(100, 160):
         except AssertionError as e:
             bad += 1; print("WORLD MISMATCH", seed, order, str(e)[:200])
 ctx = bh.Context(0)
-for seed in range(400, 460):
+for seed in range(400 + lo - 100, 400 + hi - 100):
     print('system', seed, flush=True)
     try:
         t._run_system(seed, ctx)
