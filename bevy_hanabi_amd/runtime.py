@@ -213,6 +213,13 @@ class Effect:
             self._h = None
             self._prog._effects.remove(self)
 
+    def index(self):
+        """Current position of this instance in its program's tables (hnb_effect_index): destroying an instance moves the
+        last one into its place."""
+        out = C.c_uint32()
+        _check(self._lib.hnb_effect_index(self._h, C.byref(out)))
+        return out.value
+
     def set_simulated(self, simulated=True):
         """False freezes the instance (SimulationCondition::WhenVisible while not visible)."""
         _check(self._lib.hnb_effect_set_simulated(self._h, int(bool(simulated))))

@@ -215,6 +215,7 @@ def _world(seed, order):
     max_inst = int(os.environ.get("HNB_FUZZ_MAX_INST", "5"))   # soak runs raise it to grow the instance tables
     p_create, p_destroy = (0.08, 0.14) if max_inst <= 5 else (0.30, 0.50)
     rng = np.random.default_rng(seed)
+    brng = np.random.default_rng(seed + 999)
     ctx = bh.Context(0)
     if order == "slot":
         ctx.set_list_order("slot")
@@ -256,6 +257,8 @@ def _world(seed, order):
                     if trace:
                         print(f"frame {f}: program {programs.index(pr)} - instance {victim} (now {len(pr['inst'])})", flush=True)
                 cap = pr["asset"].capacity
+                batched = brng.random() < 0.4   # (its own generator: the schedules of the recorded seeds stay what they were)
+                batch = {}
                 for it in pr["inst"]:
                     visible = rng.random() > 0.15
                     it["fx"].set_simulated(visible)
@@ -273,8 +276,15 @@ def _world(seed, order):
                     sd = frame_seed(seed * 977 + f * 31 + int(rng.integers(1 << 16)))
                     for k, v in props.items():
                         it["fx"].set_property(k, v)
-                    it["fx"].set_frame(spawn, sd, it["xf"])
+                    if batched:
+                        batch[it["fx"].index()] = (spawn, sd, it["xf"])
+                    else:
+                        it["fx"].set_frame(spawn, sd, it["xf"])
                     it["orc"].step(Frame(dt, spawn, sd, it["xf"], time=f / 60, props=props))
+                if batched:   # one hnb_program_set_frames call, rows in table order (frozen instances: ignored values)
+                    ident = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float32)
+                    rows = [batch.get(i, (12345, 1, None)) for i in range(len(pr["inst"]))]
+                    pr["prog"].set_frames([r[0] for r in rows], [r[1] for r in rows], [ident if r[2] is None else r[2] for r in rows])
             ctx.simulate()
             if trace or f % 8 == 7 or f == 39:
                 for pi, pr in enumerate(programs):
