@@ -466,6 +466,79 @@ ParticleLayout ParticleLayout::merged_with(const std::vector<Attribute>& more) c
     return b.build();
 }
 
+// ---- PropertyLayout (src/properties.rs:521-842) -------------------------------------------------------------------------
+namespace {
+uint32_t prop_size(const Property& p) { return 4u * p.default_value.type.count; }                       // f32 4, vec2 8, vec3 12, vec4 16
+uint32_t prop_align(const Property& p) { return p.default_value.type.count == 1 ? 4u : p.default_value.type.count == 2 ? 8u : 16u; }  // WGSL
+}  // namespace
+
+PropertyLayout::PropertyLayout(const std::vector<Property>& properties) {
+    // properties.rs:563-680. The reference sorts by size with an unstable sort, which keeps the input order of equal
+    // sizes for the short lists it is used on (its tests pin that order); a stable sort states it.
+    std::vector<const Property*> sorted;
+    for (const Property& p : properties) sorted.push_back(&p);
+    std::stable_sort(sorted.begin(), sorted.end(), [](const Property* a, const Property* b) { return prop_size(*a) < prop_size(*b); });
+    auto first_at_least = [&](uint32_t size) {
+        size_t i = 0;
+        while (i < sorted.size() && prop_size(*sorted[i]) < size) ++i;
+        return i;
+    };
+    uint32_t offset = 0;
+    auto put = [&](const Property* p, uint32_t advance) { layout_.push_back(Entry{*p, offset}); offset += advance; };
+    const size_t index4 = first_at_least(16), index3 = first_at_least(12), index2 = first_at_least(8);
+    for (size_t i = index4; i < sorted.size(); ++i) put(sorted[i], 16);                 // vec4: already aligned
+    size_t num1 = index2, num2 = index3 - index2, num3 = index4 - index3;
+    const size_t pairs = std::min(num1, num3);
+    for (size_t i = 0; i < pairs; ++i) { put(sorted[index3 + i], 12); put(sorted[i], 4); }  // {vec3 + scalar}
+    const size_t i1 = pairs, i3 = index3 + pairs;
+    num1 -= pairs; num3 -= pairs;
+    for (size_t i = 0; i < num2 / 2; ++i)                                                  // {vec2 + vec2}
+        for (size_t j = 0; j < 2; ++j) put(sorted[index2 + i * 2 + j], 8);
+    const size_t i2 = index2 + (num2 / 2) * 2;
+    num2 %= 2;
+    if (num3 > num1) {  // scalars are used up: the remaining vec3 take 16 bytes each (WGSL alignment), then the odd vec2
+        for (size_t i = 0; i < num3; ++i) put(sorted[i3 + i], 16);
+        if (num2) put(sorted[i2], 0);
+    } else {            // vec3 are used up: the odd vec2, then the remaining scalars
+        if (num2) put(sorted[i2], 8);
+        for (size_t i = 0; i < num1; ++i) put(sorted[i1 + i], 4);
+    }
+}
+uint32_t PropertyLayout::cpu_size() const { return layout_.empty() ? 0u : layout_.back().offset + prop_size(layout_.back().property); }
+uint32_t PropertyLayout::align() const {
+    uint32_t a = 0;
+    for (const Entry& e : layout_) a = std::max(a, prop_align(e.property));
+    return a;
+}
+uint32_t PropertyLayout::min_binding_size() const {
+    if (layout_.empty()) throw PanicError("Cannot compute min binding size for empty property layout.");
+    const uint32_t a = align();
+    return (cpu_size() + a - 1) / a * a;
+}
+bool PropertyLayout::contains(const std::string& name) const {
+    for (const Entry& e : layout_) if (e.property.name == name) return true;
+    return false;
+}
+bool PropertyLayout::offset(const std::string& name, uint32_t* out) const {
+    for (const Entry& e : layout_) if (e.property.name == name) { *out = e.offset; return true; }
+    return false;
+}
+std::string PropertyLayout::generate_property_struct_code() const {
+    if (layout_.empty()) return "";
+    std::string s = "struct Properties {\n";
+    for (const Entry& e : layout_) s += "    " + e.property.name + ": " + e.property.default_value.type.to_string() + ",\n";
+    return s + "}\n";
+}
+std::vector<uint8_t> PropertyLayout::serialize(const std::vector<Property>& values) const {
+    std::vector<uint8_t> data(cpu_size(), 0);
+    for (const Property& p : values) {
+        uint32_t off;
+        if (!offset(p.name, &off)) continue;
+        std::memcpy(data.data() + off, p.default_value.bits, prop_size(p));
+    }
+    return data;
+}
+
 // `ToWgslString for f32` (src/lib.rs:264-269): format!("{:.6}") then parsed back by the WGSL
 // front end as an abstract float converted to f32.
 float round_literal_f32(float x) {

@@ -200,6 +200,30 @@ struct Property {
     Value default_value;
 };
 
+// The byte layout of an effect's property block in the reference (`PropertyLayout`, src/properties.rs:521-842): WGSL
+// struct packing - vec4 first, {vec3 + scalar} pairs, {vec2 + vec2} pairs, then padded vec3 and the odd vec2, or the
+// odd vec2 and the remaining scalars. A host that uploads property bytes the reference's way (EffectProperties::serialize,
+// properties.rs:437-453) needs these offsets; this library itself sets properties by name (hnb_effect_set_property).
+class PropertyLayout {
+   public:
+    struct Entry { Property property; uint32_t offset; };
+    PropertyLayout() = default;                                  // PropertyLayout::empty()
+    explicit PropertyLayout(const std::vector<Property>& properties);
+    bool is_empty() const { return layout_.empty(); }
+    uint32_t cpu_size() const;                                   // offset + size of the last entry, no tail padding
+    uint32_t align() const;                                      // largest WGSL alignment of a member, 0 when empty
+    uint32_t min_binding_size() const;                           // cpu_size rounded up to align; PanicError when empty
+    bool contains(const std::string& name) const;
+    bool offset(const std::string& name, uint32_t* out) const;
+    const std::vector<Entry>& properties() const { return layout_; }
+    std::string generate_property_struct_code() const;           // "" when empty (the reference returns None)
+    // EffectProperties::serialize (properties.rs:437-453): the values, at their offsets, in cpu_size() bytes
+    std::vector<uint8_t> serialize(const std::vector<Property>& values) const;
+
+   private:
+    std::vector<Entry> layout_;
+};
+
 class Module {
    public:
     ExprHandle add_expr(const Expr& e) { expressions_.push_back(e); return ExprHandle{(uint32_t)expressions_.size()}; }
@@ -525,6 +549,7 @@ class EffectAsset {
     std::vector<Attribute> particle_layout() const;
     // The same set as the reference's interleaved struct (sizes / offsets the reference's buffers would have).
     ParticleLayout reference_particle_layout() const;
+    PropertyLayout property_layout() const { return PropertyLayout(module_.properties()); }  // asset.rs: EffectAsset::property_layout()
 
    private:
     uint32_t capacity_ = 0;

@@ -289,6 +289,29 @@ PYBIND11_MODULE(_hanabi_host, m) {
         .def("reset", &EffectSpawner::reset)
         .def("tick", &EffectSpawner::tick);
 
+    py::class_<PropertyLayout>(m, "PropertyLayout")
+        .def(py::init<>())
+        .def(py::init([](const std::vector<std::pair<std::string, py::object>>& props) {
+            std::vector<Property> v;
+            for (const auto& kv : props) v.push_back(Property{kv.first, value_from_py(kv.second)});
+            return PropertyLayout(v);
+        }))
+        .def_static("empty", []() { return PropertyLayout(); })
+        .def("is_empty", &PropertyLayout::is_empty)
+        .def("cpu_size", &PropertyLayout::cpu_size)
+        .def("align", &PropertyLayout::align)
+        .def("min_binding_size", &PropertyLayout::min_binding_size)
+        .def("contains", &PropertyLayout::contains)
+        .def("offset", [](const PropertyLayout& l, const std::string& n) -> py::object { uint32_t o; if (l.offset(n, &o)) return py::int_(o); return py::none(); })
+        .def("properties", [](const PropertyLayout& l) { std::vector<std::pair<uint32_t, std::string>> r; for (const auto& e : l.properties()) r.emplace_back(e.offset, e.property.name); return r; })
+        .def("generate_property_struct_code", [](const PropertyLayout& l) -> py::object { if (l.is_empty()) return py::none(); return py::str(l.generate_property_struct_code()); })
+        .def("serialize", [](const PropertyLayout& l, const std::vector<std::pair<std::string, py::object>>& props) {
+            std::vector<Property> v;
+            for (const auto& kv : props) v.push_back(Property{kv.first, value_from_py(kv.second)});
+            const std::vector<uint8_t> d = l.serialize(v);
+            return py::bytes(reinterpret_cast<const char*>(d.data()), d.size());
+        });
+
     py::class_<ParticleLayout>(m, "ParticleLayout")
         .def_static("new", []() { return ParticleLayout::make(); })
         .def_static("empty", &ParticleLayout::empty)
@@ -330,6 +353,7 @@ PYBIND11_MODULE(_hanabi_host, m) {
         .def("add_modifier", [](EffectAsset& a, uint32_t ctx, const Modifier& md) { return a.add_modifier(ctx, md); })
         .def("particle_layout", &EffectAsset::particle_layout)
         .def("reference_particle_layout", &EffectAsset::reference_particle_layout)
+        .def("property_layout", &EffectAsset::property_layout)
         .def_property_readonly("init_modifiers", &EffectAsset::init_modifiers)
         .def_property_readonly("update_modifiers", &EffectAsset::update_modifiers)
         .def_property_readonly("render_modifiers", &EffectAsset::render_modifiers);

@@ -178,3 +178,53 @@ def test_expr_handle_serialised_form():
     for bad in ["invalid", "33", "#0", "#-5", "#4294967296", "#", "", "#1x", "# 1"]:
         with pytest.raises(ValueError):
             bh.ExprHandle.parse(bad)
+
+
+def _pl(*props):
+    return bh.PropertyLayout(list(props))
+
+
+def test_property_layout_mirror():
+    """PropertyLayout against the reference's own tests (src/properties.rs:990-1165): layout_empty, layout_valid,
+    layout_padding_vec3 (regression #478), layout_tail_332, layout_tail_32, layout_tail_21."""
+    e = bh.PropertyLayout.empty()
+    assert e.is_empty() and e.cpu_size() == 0 and e.align() == 0 and e.properties() == [] and e.generate_property_struct_code() is None
+    with pytest.raises(bh.PanicError):
+        e.min_binding_size()
+
+    v = _pl(("f32", 3.4), ("vec3", (0.0, 0.0, 0.0)), ("vec2", (0.0, -1.0)), ("vec4", (0.0, 1.0, 0.0, 0.0)))
+    assert (v.cpu_size(), v.align(), v.min_binding_size()) == (40, 16, 48)
+    assert v.properties() == [(0, "vec4"), (16, "vec3"), (28, "f32"), (32, "vec2")]
+    assert v.generate_property_struct_code() == "struct Properties {\n    vec4: vec4<f32>,\n    vec3: vec3<f32>,\n    f32: f32,\n    vec2: vec2<f32>,\n}\n"
+    assert v.contains("vec3") and not v.contains("nope") and v.offset("f32") == 28 and v.offset("nope") is None
+
+    p = _pl(("vec4a", (0.0, 1.0, 0.0, 0.0)), ("vec3b", (0.0, 0.0, 0.0)), ("vec3c", (1.0, 1.0, 1.0)))
+    assert (p.cpu_size(), p.align(), p.min_binding_size()) == (44, 16, 48)
+    assert p.properties() == [(0, "vec4a"), (16, "vec3b"), (32, "vec3c")]
+    assert p.generate_property_struct_code() == "struct Properties {\n    vec4a: vec4<f32>,\n    vec3b: vec3<f32>,\n    vec3c: vec3<f32>,\n}\n"
+
+    t332 = _pl(("vec2", (0.0, -1.0)), ("vec3a", (0.0, 0.0, 0.0)), ("vec3b", (-1.0, 0.0, 0.0)))
+    assert (t332.cpu_size(), t332.align(), t332.min_binding_size()) == (40, 16, 48)
+    assert t332.properties() == [(0, "vec3a"), (16, "vec3b"), (32, "vec2")]
+
+    t32 = _pl(("vec2", (0.0, -1.0)), ("vec3", (0.0, 0.0, 0.0)))
+    assert (t32.cpu_size(), t32.align(), t32.min_binding_size()) == (24, 16, 32)
+    assert t32.properties() == [(0, "vec3"), (16, "vec2")]
+
+    t21 = _pl(("f32", 3.4), ("vec2", (0.0, -1.0)))
+    assert (t21.cpu_size(), t21.align(), t21.min_binding_size()) == (12, 8, 16)
+    assert t21.properties() == [(0, "vec2"), (8, "f32")]
+    assert t21.generate_property_struct_code() == "struct Properties {\n    vec2: vec2<f32>,\n    f32: f32,\n}\n"
+
+
+def test_property_layout_of_an_asset_and_serialised_bytes():
+    """EffectAsset::property_layout() and EffectProperties::serialize (properties.rs:437-453): values at their offsets."""
+    import struct
+    w = bh.ExprWriter()
+    w.add_property("speed", 2.5)
+    w.add_property("origin", (1.0, 2.0, 3.0))
+    asset = bh.EffectAsset(16, bh.SpawnerSettings.once(1.0), w.finish())
+    layout = asset.property_layout()
+    assert layout.properties() == [(0, "origin"), (12, "speed")] and layout.cpu_size() == 16
+    data = layout.serialize([("speed", 7.0), ("origin", (4.0, 5.0, 6.0))])
+    assert struct.unpack("<4f", data) == (4.0, 5.0, 6.0, 7.0)
