@@ -228,3 +228,23 @@ def test_property_layout_of_an_asset_and_serialised_bytes():
     assert layout.properties() == [(0, "origin"), (12, "speed")] and layout.cpu_size() == 16
     data = layout.serialize([("speed", 7.0), ("origin", (4.0, 5.0, 6.0))])
     assert struct.unpack("<4f", data) == (4.0, 5.0, 6.0, 7.0)
+
+
+def test_transitive_attribute_and_add_modifier():
+    """asset.rs `transitive_attr` (an attribute only READ by an expression is part of the layout) and `add_modifiers`
+    (add_modifier(context, modifier) files the modifier under that context)."""
+    m = bh.Module()
+    age = m.attr(A.F32_0)
+    asset = bh.EffectAsset(32, bh.SpawnerSettings.once(3.0), m).init(bh.SetAttributeModifier(A.AGE, age))
+    names = [a.name for a in asset.particle_layout()]
+    assert "age" in names and "f32_0" in names
+    ref = asset.reference_particle_layout()
+    assert ref.contains(A.AGE) and ref.contains(A.F32_0)
+
+    m = bh.Module()
+    expr = m.lit(3.0)
+    for context, getter in [(1, "init_modifiers"), (2, "update_modifiers")]:   # ModifierContext::Init / Update
+        effect = bh.EffectAsset(1, bh.SpawnerSettings.once(1.0), m).add_modifier(context, bh.SetAttributeModifier(A.POSITION, expr))
+        mods = getattr(effect, getter)
+        assert len(mods) == 1 and mods[0].context & context
+        assert len(effect.init_modifiers) + len(effect.update_modifiers) + len(effect.render_modifiers) == 1
