@@ -87,6 +87,8 @@ struct Value {
     void set_f(int i, float f) { std::memcpy(&bits[i], &f, 4); }
     float get_f(int i) const { float f; std::memcpy(&f, &bits[i], 4); return f; }
     ValueType value_type() const { return type; }
+    // Value::as_bytes (src/graph/mod.rs): the components, little-endian, no padding
+    std::vector<uint8_t> as_bytes() const { std::vector<uint8_t> b(4u * type.count); std::memcpy(b.data(), bits, b.size()); return b; }
 };
 
 // ---- attributes ----------------------------------------------------------------------------------

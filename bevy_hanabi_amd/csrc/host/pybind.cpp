@@ -97,6 +97,7 @@ PYBIND11_MODULE(_hanabi_host, m) {
         .def_static("vec_i", [](std::vector<int32_t> v) { Value r; r.type = ValueType(ScalarType::Int, (uint8_t)v.size()); for (size_t i = 0; i < v.size() && i < 4; ++i) r.bits[i] = (uint32_t)v[i]; return r; })
         .def_static("vec_u", [](std::vector<uint32_t> v) { Value r; r.type = ValueType(ScalarType::Uint, (uint8_t)v.size()); for (size_t i = 0; i < v.size() && i < 4; ++i) r.bits[i] = v[i]; return r; })
         .def_static("vec_b", [](std::vector<bool> v) { Value r; r.type = ValueType(ScalarType::Bool, (uint8_t)v.size()); for (size_t i = 0; i < v.size() && i < 4; ++i) r.bits[i] = v[i] ? 1u : 0u; return r; })
+        .def("as_bytes", [](const Value& v) { const std::vector<uint8_t> b = v.as_bytes(); return py::bytes(reinterpret_cast<const char*>(b.data()), b.size()); })
         .def_property_readonly("value_type", &Value::value_type)
         .def_property_readonly("bits", [](const Value& v) { return std::vector<uint32_t>(v.bits, v.bits + v.type.count); })
         .def("to_py", &value_to_py);

@@ -248,3 +248,13 @@ def test_transitive_attribute_and_add_modifier():
         mods = getattr(effect, getter)
         assert len(mods) == 1 and mods[0].context & context
         assert len(effect.init_modifiers) + len(effect.update_modifiers) + len(effect.render_modifiers) == 1
+
+
+def test_value_as_bytes():   # src/graph/mod.rs `as_bytes`
+    V = bh.Value
+    assert V(3.0).as_bytes() == bytes([0, 0, 0x40, 0x40])
+    assert V.u32(0x12FF89AC).as_bytes() == bytes([0xAC, 0x89, 0xFF, 0x12])
+    assert V.i32(0x12FF89AC).as_bytes() == bytes([0xAC, 0x89, 0xFF, 0x12])
+    assert V((-2.0, 3.0)).as_bytes() == bytes([0, 0, 0, 0xC0, 0, 0, 0x40, 0x40])
+    assert V((-2.0, 3.0, 4.0)).as_bytes() == bytes([0, 0, 0, 0xC0, 0, 0, 0x40, 0x40, 0, 0, 0x80, 0x40])
+    assert V((-2.0, 3.0, 4.0, -5.0)).as_bytes() == bytes([0, 0, 0, 0xC0, 0, 0, 0x40, 0x40, 0, 0, 0x80, 0x40, 0, 0, 0xA0, 0xC0])
