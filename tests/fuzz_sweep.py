@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--typed", action="store_true")
     ap.add_argument("--seeds", default="0:100")
     ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--capacity", type=int, default=None, help="particles per effect (default: the generators' 300-400); >= 4096 covers completely alive chunks")
     args = ap.parse_args()
     os.environ["HNB_JIT"] = args.jit
     import bevy_hanabi_amd as bh
@@ -32,7 +33,7 @@ def main():
     bad = skipped = 0
     t0 = time.time()
     for seed in range(lo, hi):
-        asset = (random_typed_asset if args.typed else random_asset)(seed)
+        asset = (random_typed_asset if args.typed else random_asset)(seed) if args.capacity is None else (random_typed_asset if args.typed else random_asset)(seed, args.capacity)
         try:
             bh.lower(asset)
         except (bh.ExprError, bh.ShaderGenerateError) as e:
