@@ -539,6 +539,70 @@ std::vector<uint8_t> PropertyLayout::serialize(const std::vector<Property>& valu
     return data;
 }
 
+// ---- EffectProperties (src/properties.rs:200-453) -------------------------------------------------------------------------
+namespace {
+bool same_value(const Value& a, const Value& b) {
+    if (a.type != b.type) return false;
+    for (int i = 0; i < a.type.count; ++i) if (a.bits[i] != b.bits[i]) return false;
+    return true;
+}
+}  // namespace
+EffectProperties& EffectProperties::with_properties(const std::vector<std::pair<std::string, Value>>& properties) {
+    for (const auto& kv : properties) {
+        bool found = false;
+        for (Instance& pi : properties_) {
+            if (pi.def.name != kv.first) continue;
+            if (pi.value.type != kv.second.type)
+                throw PanicError("Trying to overwrite existing property '" + kv.first + "' with value of type " + kv.second.type.to_string() +
+                                 ", but property has type " + pi.value.type.to_string());
+            pi.value = kv.second;  // the definition keeps its original default (properties.rs:224-233)
+            found = true;
+            break;
+        }
+        if (!found) properties_.push_back(Instance{Property{kv.first, kv.second}, kv.second});
+    }
+    return *this;
+}
+bool EffectProperties::get_stored(const std::string& name, Value* out) const {
+    for (const Instance& pi : properties_) if (pi.def.name == name) { *out = pi.value; return true; }
+    return false;
+}
+void EffectProperties::set(const std::string& name, const Value& value) { (void)set_if_changed(name, value); }
+bool EffectProperties::set_if_changed(const std::string& name, const Value& value) {
+    for (Instance& pi : properties_) {
+        if (pi.def.name != name) continue;
+        if (pi.def.default_value.type != value.type)
+            throw PanicError("Cannot assign value of type " + value.type.to_string() + " to property '" + name + "' of type " + pi.def.default_value.type.to_string());
+        if (same_value(pi.value, value)) return false;
+        pi.value = value;
+        return true;
+    }
+    properties_.push_back(Instance{Property{name, value}, value});
+    return true;
+}
+void EffectProperties::update(const std::vector<Property>& asset_properties) {
+    // properties.rs:395-430: instances the asset does not declare are dropped, declared properties without an instance
+    // are appended with their default value, the others keep their current value and position
+    std::vector<Instance> kept, added;
+    for (const Property& prop : asset_properties) {
+        bool known = false;
+        for (const Instance& pi : properties_) known = known || pi.def.name == prop.name;
+        if (!known) added.push_back(Instance{prop, prop.default_value});
+    }
+    for (const Instance& pi : properties_) {
+        bool declared = false;
+        for (const Property& prop : asset_properties) declared = declared || prop.name == pi.def.name;
+        if (declared) kept.push_back(pi);
+    }
+    properties_ = kept;
+    properties_.insert(properties_.end(), added.begin(), added.end());
+}
+std::vector<uint8_t> EffectProperties::serialize(const PropertyLayout& layout) const {
+    std::vector<Property> values;
+    for (const Instance& pi : properties_) values.push_back(Property{pi.def.name, pi.value});
+    return layout.serialize(values);
+}
+
 // `ToWgslString for f32` (src/lib.rs:264-269): format!("{:.6}") then parsed back by the WGSL
 // front end as an abstract float converted to f32.
 float round_literal_f32(float x) {

@@ -226,6 +226,26 @@ class PropertyLayout {
     std::vector<Entry> layout_;
 };
 
+// Per-instance property values (`EffectProperties`, src/properties.rs:200-453): an ordered list of (definition, value);
+// a value may be set before the asset's properties are known, a definition's type never changes (PanicError, like the
+// reference's assert), `update` reconciles the list with an asset's properties the way the component does when the
+// asset (re)loads. The values reach the GPU through hnb_effect_set_property (by name) or, laid out the reference's
+// way, through serialize().
+class EffectProperties {
+   public:
+    struct Instance { Property def; Value value; };
+    EffectProperties& with_properties(const std::vector<std::pair<std::string, Value>>& properties);
+    const std::vector<Instance>& properties() const { return properties_; }
+    bool get_stored(const std::string& name, Value* out) const;
+    void set(const std::string& name, const Value& value);
+    bool set_if_changed(const std::string& name, const Value& value);   // true when the list was modified
+    void update(const std::vector<Property>& asset_properties);
+    std::vector<uint8_t> serialize(const PropertyLayout& layout) const;
+
+   private:
+    std::vector<Instance> properties_;
+};
+
 class Module {
    public:
     ExprHandle add_expr(const Expr& e) { expressions_.push_back(e); return ExprHandle{(uint32_t)expressions_.size()}; }

@@ -313,6 +313,33 @@ PYBIND11_MODULE(_hanabi_host, m) {
             return py::bytes(reinterpret_cast<const char*>(d.data()), d.size());
         });
 
+    py::class_<EffectProperties>(m, "EffectProperties")
+        .def(py::init<>())
+        .def("with_properties", [](EffectProperties& ep, const std::vector<std::pair<std::string, py::object>>& props) {
+            std::vector<std::pair<std::string, Value>> v;
+            for (const auto& kv : props) v.emplace_back(kv.first, value_from_py(kv.second));
+            ep.with_properties(v);
+            return ep;
+        })
+        .def("properties", [](const EffectProperties& ep) {
+            py::list out;
+            for (const auto& pi : ep.properties()) out.append(py::make_tuple(pi.def.name, value_to_py(pi.def.default_value), value_to_py(pi.value)));
+            return out;
+        })
+        .def("get_stored", [](const EffectProperties& ep, const std::string& n) -> py::object { Value v; if (ep.get_stored(n, &v)) return value_to_py(v); return py::none(); })
+        .def("set", [](EffectProperties& ep, const std::string& n, py::object v) { ep.set(n, value_from_py(v)); })
+        .def("set_if_changed", [](EffectProperties& ep, const std::string& n, py::object v) { return ep.set_if_changed(n, value_from_py(v)); })
+        .def("update", [](EffectProperties& ep, const std::vector<std::pair<std::string, py::object>>& asset_props) {
+            std::vector<Property> v;
+            for (const auto& kv : asset_props) v.push_back(Property{kv.first, value_from_py(kv.second)});
+            ep.update(v);
+        })
+        .def("serialize", [](const EffectProperties& ep, const PropertyLayout& layout) {
+            const std::vector<uint8_t> d = ep.serialize(layout);
+            return py::bytes(reinterpret_cast<const char*>(d.data()), d.size());
+        })
+        .def("layout", [](const EffectProperties& ep) { std::vector<Property> defs; for (const auto& pi : ep.properties()) defs.push_back(pi.def); return PropertyLayout(defs); });
+
     py::class_<ParticleLayout>(m, "ParticleLayout")
         .def_static("new", []() { return ParticleLayout::make(); })
         .def_static("empty", &ParticleLayout::empty)

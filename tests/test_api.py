@@ -258,3 +258,45 @@ def test_value_as_bytes():   # src/graph/mod.rs `as_bytes`
     assert V((-2.0, 3.0)).as_bytes() == bytes([0, 0, 0, 0xC0, 0, 0, 0x40, 0x40])
     assert V((-2.0, 3.0, 4.0)).as_bytes() == bytes([0, 0, 0, 0xC0, 0, 0, 0x40, 0x40, 0, 0, 0x80, 0x40])
     assert V((-2.0, 3.0, 4.0, -5.0)).as_bytes() == bytes([0, 0, 0, 0xC0, 0, 0, 0x40, 0x40, 0, 0, 0x80, 0x40, 0, 0, 0xA0, 0xC0])
+
+
+def test_effect_properties_mirror():
+    """EffectProperties against the reference's tests (src/properties.rs:1167-1440): with_properties keeps the first default
+    and overwrites the value, type mismatches panic, get_stored / set, update() reconciles with an asset's properties
+    (missing ones appended with their default, unknown ones dropped, existing values kept), serialize() in a layout."""
+    import struct
+    ep = bh.EffectProperties().with_properties([("a", 3.0), ("b", (0.0, 0.0, 0.0))]).with_properties([("a", 7.0), ("c", (1.0, 1.0))])
+    props = ep.properties()
+    assert [p[0] for p in props] == ["a", "b", "c"]
+    assert props[0][1] == 3.0 and props[0][2] == 7.0                     # default kept, value overwritten
+    assert tuple(props[1][1]) == (0.0, 0.0, 0.0) and tuple(props[2][2]) == (1.0, 1.0)
+    assert ep.get_stored("a") == 7.0 and ep.get_stored("b") is not None and ep.get_stored("c") is not None and ep.get_stored("x") is None
+    with pytest.raises(bh.PanicError):
+        bh.EffectProperties().with_properties([("a", 3.0)]).with_properties([("a", (1.0, 1.0))])
+
+    ep = bh.EffectProperties().with_properties([("a", 3.0), ("b", (0.0, 0.0, 0.0))])
+    ep.set("a", 7.0)
+    ep.set("x", 3.0)
+    assert ep.get_stored("a") == 7.0 and ep.get_stored("x") == 3.0
+    assert ep.set_if_changed("a", 7.0) is False and ep.set_if_changed("a", 8.0) is True
+    with pytest.raises(bh.PanicError):
+        bh.EffectProperties().with_properties([("a", 3.0)]).set("a", (0.0, 0.0, 0.0))
+
+    # update (effect_properties_update_empty / _added / _removed / _override / _mixed)
+    ep = bh.EffectProperties(); ep.update([]); assert ep.properties() == []
+    ep = bh.EffectProperties(); ep.update([("prop1", 32.0)])
+    assert [(p[0], p[2]) for p in ep.properties()] == [("prop1", 32.0)]
+    ep = bh.EffectProperties().with_properties([("prop1", 5.0)]); ep.update([])
+    assert ep.properties() == []
+    ep = bh.EffectProperties().with_properties([("prop1", 5.0)]); ep.update([("prop1", 32.0)])
+    assert [(p[0], p[2]) for p in ep.properties()] == [("prop1", 5.0)]
+    ep = bh.EffectProperties().with_properties([("prop1", 5.0), ("prop3", 1.0)]); ep.update([("prop1", 32.0), ("prop2", False)])
+    assert [(p[0], p[2]) for p in ep.properties()] == [("prop1", 5.0), ("prop2", False)]
+
+    # serialize (effect_properties_serialize)
+    ep = bh.EffectProperties().with_properties([("a", 3.0), ("b", (1.0, 1.0, 1.0))])
+    layout = ep.layout()
+    blob = ep.serialize(layout)
+    assert len(blob) == layout.cpu_size()
+    assert blob[layout.offset("a"):layout.offset("a") + 4] == struct.pack("<f", 3.0)
+    assert blob[layout.offset("b"):layout.offset("b") + 12] == struct.pack("<3f", 1.0, 1.0, 1.0)
