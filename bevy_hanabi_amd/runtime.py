@@ -12,6 +12,7 @@ from . import build as _build
 
 HNB_OK = 0
 HNB_ERR_NO_DEVICE = -4
+HNB_ERR_NOT_FOUND = -6
 
 ATTR_COMPONENTS = [1, 1, 3, 3, 1, 1, 1, 4, 1, 1, 2, 3, 1, 1, 3, 3, 3, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 1, 1, 1, 1, 1]
 ATTR_IS_FLOAT = [0, 0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0] + [1] * 16 + [0] * 5
@@ -241,6 +242,16 @@ class Effect:
         words = v.astype(np.float32).view(np.uint32) if v.dtype.kind == "f" else v.astype(np.uint32)
         words = np.ascontiguousarray(words)
         _check(self._lib.hnb_effect_set_property(self._h, name.encode(), words.ctypes.data, len(words)))
+
+    def apply_properties(self, effect_properties):
+        """Push every value of an `EffectProperties` the program declares (the reference uploads the component's values
+        every frame they changed, src/render/mod.rs property upload)."""
+        for name, _default, value in effect_properties.properties():
+            try:
+                self.set_property(name, value)
+            except HanabiError as e:
+                if e.code != HNB_ERR_NOT_FOUND:   # a value for a property this effect's asset does not declare is not an error
+                    raise
 
     def metadata(self):
         m = EffectMetadata()

@@ -659,3 +659,20 @@ def test_instance_index_reuse_after_destroy(ctx, slot_ctx, order, gap):
     np.testing.assert_array_equal(ref["alive"], n.alive_list())
     np.testing.assert_array_equal(ref["dead"], n.dead_list())
     prog.destroy()
+
+
+def test_effect_properties_reach_the_gpu(ctx):
+    """EffectProperties (the reference's per-instance property component) applied through the binding: the declared values
+    are set by name, a value for an undeclared property is ignored, results equal the oracle's with the same values."""
+    asset = effects.force_field(6000)
+    g, o = GpuRunner(asset, ctx=ctx), OracleRunner(asset)
+    ep = bh.EffectProperties().with_properties([("repulsor_accel", -25.0), ("repulsor_position", (0.1, 0.4, 0.0)), ("not_declared", 1.0)])
+    g.fx.apply_properties(ep)
+    props = {"repulsor_accel": [-25.0], "repulsor_position": [0.1, 0.4, 0.0]}
+    frames = [Frame(1 / 60, 6000 if f == 0 else 0, frame_seed(f), time=f / 60, props=props if f == 0 else None) for f in range(40)]
+    for fr in frames:
+        fr_gpu = Frame(fr.dt, fr.spawn, fr.seed, time=fr.time)   # the GPU side got its values from apply_properties
+        g.step(fr_gpu)
+        o.step(fr)
+    assert_same_state(o.state(), g.state(), "force field with EffectProperties")
+    g.prog.destroy()
