@@ -95,8 +95,8 @@ void select_stream_kernel(const Ins* code, uint32_t n, StreamLaunchFn* fn, const
 
 struct HnbContext {
     int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
+    hipStream_t stream = nullptr;       // the stream hnb_simulate enqueues on: own_stream or the caller's (hnb_ctx_set_stream)
+    hipStream_t own_stream = nullptr;   // created with the context, lives as long as it does
     hipStream_t upload_stream = nullptr;  // per-frame parameter uploads, overlapped with the previous frame's kernels
     uint32_t num_cus = 256;
     std::vector<HnbProgram*> programs;
@@ -106,6 +106,7 @@ struct HnbContext {
     uint32_t timing = 0;        // 0 = off, n = time every n-th simulated frame
     uint32_t timing_tick = 0;
     std::vector<TimingPair> t_update, t_init, t_compact;
+    std::vector<hipEvent_t> event_pool;  // timing events are recycled, never created on the frame path once the pool is warm
 };
 
 struct HnbProgram {
@@ -178,6 +179,21 @@ struct HnbEffect {
 };
 
 namespace {
+
+hipEvent_t take_event(HnbContext* ctx) {
+    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+void recycle_timing_events(HnbContext* ctx) {
+    for (auto& t : ctx->t_update) { ctx->event_pool.push_back(t.a); ctx->event_pool.push_back(t.b); }
+    for (auto& t : ctx->t_init) { ctx->event_pool.push_back(t.a); ctx->event_pool.push_back(t.b); }
+    for (auto& t : ctx->t_compact) ctx->event_pool.push_back(t.b);  // (t.a is the update's end event)
+    ctx->t_compact.clear();
+    ctx->t_update.clear();
+    ctx->t_init.clear();
+}
 
 // Components of every HnbAttr (src/attributes.rs:549-675): the streaming kernels and the sort address the planes of
 // POSITION / VELOCITY / AGE / LIFETIME / RIBBON_ID by these sizes, so the attribute table must agree with them.
@@ -342,6 +358,65 @@ int validate_stream(const uint8_t* blob_base, const uint8_t* code, uint32_t len,
     return HNB_OK;
 }
 
+// Slab layout of one effect instance: [alive list column 0][column 1][dead list][attribute planes...][alive byte per slot]
+// [per-chunk lifetime bounds + "completely alive" flags][spawn-event staging][ribbon-sort scratch], 256-byte aligned sections.
+// The alive list moves to the other column only in frames where particles died (k_compact). Every section offset is a
+// u32 in the device structs: the layout is computed in 64 bits and rejected as a whole when it does not fit (offsets grow
+// monotonically, so the total bounds every one of them).
+bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgram& d, SortArgs& so, size_t* out_bytes) {
+    d.capacity = h.capacity;
+    d.n_attrs = h.n_attrs;
+    d.n_uregs = h.n_uregs;
+    d.chunks_per_inst = (h.capacity + kChunk - 1) / kChunk;
+    d.init_len = h.init_len;
+    d.update_len = h.update_len;
+    uint64_t off = 0;
+    const uint64_t list_bytes = align_up((size_t)h.capacity * 4, 256);
+    auto place = [&](uint64_t bytes) { const uint64_t at = off; off += bytes; return at; };
+    const uint64_t a0 = place(list_bytes), a1 = place(list_bytes), dd = place(list_bytes);
+    uint64_t plane[kMaxAttrs];
+    for (uint32_t i = 0; i < h.n_attrs; ++i) plane[i] = place(align_up((size_t)h.capacity * attrs[i].ncomp * 4, 256));
+    const uint64_t flag_off = place(align_up((size_t)h.capacity, 256));             // alive byte per slot, zeroed with the attribute planes
+    const uint64_t lmin_off = place(align_up((size_t)d.chunks_per_inst * 8, 256));  // per chunk: lifetime bound (0 = unknown), then "completely alive" flag; zeroed too
+    uint64_t ev_off[HNB_MAX_EVENT_CHANNELS] = {};
+    for (uint32_t c = 0; c < h.n_event_channels; ++c) ev_off[c] = place(list_bytes);  // per-slot staging of spawn events (k_update_slots_generic -> k_emit_count / k_emit_events)
+    uint64_t key_off[2] = {}, val_off[2] = {}, hist_off = 0, gsum_off = 0, bits_off = 0;
+    const bool ribbons = (h.flags & HNB_PROG_HAS_RIBBONS) != 0;
+    const uint32_t sort_chunks = (h.capacity + kSortTile - 1) / kSortTile;
+    if (ribbons) {  // radix-sort scratch: 64-bit keys and values ping-pong, per-chunk digit histograms, key OR/AND
+        for (int i = 0; i < 2; ++i) key_off[i] = place(align_up((size_t)h.capacity * 8, 256));
+        for (int i = 0; i < 2; ++i) val_off[i] = place(list_bytes);
+        hist_off = place(align_up((size_t)256 * sort_chunks * 4, 256));
+        gsum_off = place(align_up((size_t)8 * ((sort_chunks + kSortGroup - 1) / kSortGroup) * 256 * 4, 256));
+        bits_off = place(256);
+    }
+    if (off > 0xffffffffull) return false;
+    d.alive_off[0] = (uint32_t)a0; d.alive_off[1] = (uint32_t)a1; d.dead_off = (uint32_t)dd;
+    for (uint32_t i = 0; i < h.n_attrs; ++i) {
+        d.attrs[i].plane_off = (uint32_t)plane[i];
+        d.attrs[i].ncomp = attrs[i].ncomp;
+        d.attrs[i].reg = attrs[i].reg;
+        d.attrs[i].upd_flags = attrs[i].update_flags;
+    }
+    d.alive_flag_off = (uint32_t)flag_off;
+    d.lmin_off = (uint32_t)lmin_off;
+    d.n_event_channels = h.n_event_channels;
+    for (uint32_t c = 0; c < h.n_event_channels; ++c) d.ev_cnt_off[c] = (uint32_t)ev_off[c];
+    if (ribbons) {
+        so.capacity = h.capacity; so.chunks_per_inst = sort_chunks;
+        so.alive_off[0] = d.alive_off[0]; so.alive_off[1] = d.alive_off[1];
+        for (int i = 0; i < 2; ++i) { so.key_off[i] = (uint32_t)key_off[i]; so.val_off[i] = (uint32_t)val_off[i]; }
+        so.hist_off = (uint32_t)hist_off; so.gsum_off = (uint32_t)gsum_off; so.bits_off = (uint32_t)bits_off;
+        so.rid_plane = so.age_plane = kNoPlane;
+        for (uint32_t i = 0; i < h.n_attrs; ++i) {
+            if (attrs[i].attr == HNB_ATTR_RIBBON_ID) so.rid_plane = d.attrs[i].plane_off;
+            if (attrs[i].attr == HNB_ATTR_AGE) so.age_plane = d.attrs[i].plane_off;
+        }
+    }
+    *out_bytes = (size_t)off;
+    return true;
+}
+
 int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
     if (!blob || size < sizeof(HnbProgramHeader)) return fail(HNB_ERR_BAD_PROGRAM, "program blob too small");
     HnbProgramHeader h;
@@ -416,6 +491,14 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
     if (rc != HNB_OK) return rc;
     rc = validate_stream(p, p + h.update_off, h.update_len, h.update_regs, h, 2);
     if (rc != HNB_OK) return rc;
+    {   // the instance slab is addressed with 32-bit section offsets
+        std::vector<HnbAttrEntry> at(h.n_attrs);
+        memcpy(at.data(), p + h.attrs_off, (size_t)h.n_attrs * sizeof(HnbAttrEntry));
+        DevProgram d{};
+        SortArgs so{};
+        size_t bytes = 0;
+        if (!layout_slab(h, at.data(), d, so, &bytes)) return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB (capacity %u)", h.capacity);
+    }
     if (out_hdr) *out_hdr = h;
     return HNB_OK;
 }
@@ -562,7 +645,7 @@ int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
     ctx->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(HNB_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
-    ctx->own_stream = true;
+    ctx->own_stream = ctx->stream;
     e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return fail(HNB_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     hipDeviceProp_t prop;
@@ -576,10 +659,9 @@ int hnb_ctx_destroy(HnbContext* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     while (!ctx->programs.empty()) hnb_program_destroy(ctx->programs.back());
-    for (auto& t : ctx->t_update) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
-    for (auto& t : ctx->t_init) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
-    for (auto& t : ctx->t_compact) hipEventDestroy(t.b);
-    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    recycle_timing_events(ctx);
+    for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     if (ctx->upload_stream) hipStreamDestroy(ctx->upload_stream);
     delete ctx;
     return HNB_OK;
@@ -587,12 +669,8 @@ int hnb_ctx_destroy(HnbContext* ctx) {
 
 int hnb_ctx_set_stream(HnbContext* ctx, void* hip_stream) {
     if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (hip_stream) {
-        if (ctx->own_stream) hipStreamDestroy(ctx->stream);
-        ctx->stream = static_cast<hipStream_t>(hip_stream);
-        ctx->own_stream = false;
-    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // everything enqueued so far completes on the stream it was enqueued on
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     return HNB_OK;
 }
 
@@ -631,53 +709,11 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     if (h.n_props) memcpy(p->props.data(), b + h.props_off, h.n_props * sizeof(HnbPropEntry));
 
     DevProgram& d = p->dev;
-    d.capacity = h.capacity;
-    d.n_attrs = h.n_attrs;
-    d.n_uregs = h.n_uregs;
-    d.chunks_per_inst = (h.capacity + kChunk - 1) / kChunk;
-    d.init_len = h.init_len;
-    d.update_len = h.update_len;
-    // Slab layout: [alive list column 0][column 1][dead list][attribute planes...][alive byte per slot]..., 256-byte aligned.
-    // The alive list moves to the other column only in frames where particles died (k_compact).
-    size_t off = 0;
-    const size_t list_bytes = align_up((size_t)h.capacity * 4, 256);
-    d.alive_off[0] = (uint32_t)off; off += list_bytes;
-    d.alive_off[1] = (uint32_t)off; off += list_bytes;
-    d.dead_off = (uint32_t)off; off += list_bytes;
-    for (uint32_t i = 0; i < h.n_attrs; ++i) {
-        if (off > 0xffffffffull) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB"); }
-        d.attrs[i].plane_off = (uint32_t)off;
-        d.attrs[i].ncomp = p->attrs[i].ncomp;
-        d.attrs[i].reg = p->attrs[i].reg;
-        d.attrs[i].upd_flags = p->attrs[i].update_flags;
-        off += align_up((size_t)h.capacity * p->attrs[i].ncomp * 4, 256);
-    }
+    size_t slab_bytes = 0;
+    if (!layout_slab(h, p->attrs.data(), d, p->sort, &slab_bytes)) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB (capacity %u)", h.capacity); }
     p->slot_order = ctx->list_order == HNB_LIST_ORDER_SLOT && !(h.flags & HNB_PROG_HAS_RIBBONS);  // ribbons are re-sorted anyway
-    d.alive_flag_off = (uint32_t)off; off += align_up((size_t)h.capacity, 256);  // alive byte per slot, zeroed with the attribute planes
-    d.lmin_off = (uint32_t)off; off += align_up((size_t)d.chunks_per_inst * 8, 256);  // per chunk: lifetime bound (0 = unknown), then "completely alive" flag; zeroed too
-    d.n_event_channels = h.n_event_channels;
-    if (h.n_event_channels) {  // per-slot staging of spawn events (k_update_slots_generic -> k_emit_count / k_emit_events)
-        for (uint32_t c = 0; c < h.n_event_channels; ++c) { d.ev_cnt_off[c] = (uint32_t)off; off += list_bytes; }
-        if (off > 0xffffffffull) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB"); }
-    }
     p->has_ribbons = (h.flags & HNB_PROG_HAS_RIBBONS) != 0;
-    if (p->has_ribbons) {  // radix-sort scratch: 64-bit keys and values ping-pong, per-chunk digit histograms, key OR/AND
-        SortArgs& so = p->sort;
-        so.capacity = h.capacity; so.chunks_per_inst = (h.capacity + kSortTile - 1) / kSortTile;
-        so.alive_off[0] = d.alive_off[0]; so.alive_off[1] = d.alive_off[1];
-        for (int i = 0; i < 2; ++i) { so.key_off[i] = (uint32_t)off; off += align_up((size_t)h.capacity * 8, 256); }
-        for (int i = 0; i < 2; ++i) { so.val_off[i] = (uint32_t)off; off += list_bytes; }
-        so.hist_off = (uint32_t)off; off += align_up((size_t)256 * so.chunks_per_inst * 4, 256);
-        so.gsum_off = (uint32_t)off; off += align_up((size_t)8 * ((so.chunks_per_inst + kSortGroup - 1) / kSortGroup) * 256 * 4, 256);
-        so.bits_off = (uint32_t)off; off += 256;
-        so.rid_plane = so.age_plane = kNoPlane;
-        for (uint32_t i = 0; i < h.n_attrs; ++i) {
-            if (p->attrs[i].attr == HNB_ATTR_RIBBON_ID) so.rid_plane = d.attrs[i].plane_off;
-            if (p->attrs[i].attr == HNB_ATTR_AGE) so.age_plane = d.attrs[i].plane_off;
-        }
-        if (off > 0xffffffffull) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB"); }
-    }
-    p->slab_bytes = off;
+    p->slab_bytes = slab_bytes;
     p->parent_attrs.resize(h.parent_n_attrs);
     if (h.parent_n_attrs) memcpy(p->parent_attrs.data(), b + h.parent_attrs_off, (size_t)h.parent_n_attrs * 4);
     {
@@ -949,6 +985,22 @@ int hnb_effect_set_parent(HnbEffect* child, HnbEffect* parent, uint32_t channel,
     if (event_capacity == 0) return fail(HNB_ERR_INVALID_ARG, "event_capacity must be positive");
     for (HnbEffect* a = parent; a; a = a->parent)
         if (a == child) return fail(HNB_ERR_INVALID_ARG, "parent/child cycle");
+    // A program's init pass is ONE launch for all its instances and parents must run before children, so the dependency
+    // graph is checked at PROGRAM granularity: child->prog must not be reachable from parent->prog's ancestors (which
+    // includes parent and child being instances of the same program).
+    if (cp == pp) return fail(HNB_ERR_INVALID_ARG, "parent and child are instances of the same program: their init passes are one launch and cannot be ordered");
+    {
+        std::vector<HnbProgram*> stack{pp}, seen;
+        while (!stack.empty()) {
+            HnbProgram* q = stack.back();
+            stack.pop_back();
+            if (q == cp) return fail(HNB_ERR_INVALID_ARG, "parent/child cycle between programs: the parent's program already depends on the child's program");
+            if (std::find(seen.begin(), seen.end(), q) != seen.end()) continue;
+            seen.push_back(q);
+            for (HnbEffect* e : q->effects)
+                if (e->parent && e != child) stack.push_back(e->parent->prog);   // (child's current link is about to be replaced)
+        }
+    }
     // every attribute the child's init stream reads from the parent particle must exist in the parent layout
     for (uint32_t id : cp->parent_attrs)
         if (find_attr(pp, id) < 0) return fail(HNB_ERR_NOT_FOUND, "the parent layout has no attribute %u read by the child's init modifiers", id);
@@ -971,12 +1023,16 @@ int hnb_effect_set_parent(HnbEffect* child, HnbEffect* parent, uint32_t channel,
     ch.child = child;
     child->parent = parent;
     child->parent_channel = channel;
-    // parents before children: dependency level per program
-    for (bool changed = true; changed;) {
-        changed = false;
+    // parents before children: dependency level per program. The program graph is acyclic (checked above), so the levels
+    // settle within one pass per program; the bound is a backstop, never a hang.
+    const size_t n_prog = cp->ctx->programs.size();
+    for (HnbProgram* q : cp->ctx->programs) q->level = 0;
+    for (size_t pass = 0; pass <= n_prog; ++pass) {
+        bool changed = false;
         for (HnbProgram* q : cp->ctx->programs)
             for (HnbEffect* e : q->effects)
                 if (e->parent && q->level <= e->parent->prog->level) { q->level = e->parent->prog->level + 1; changed = true; }
+        if (!changed) break;
     }
     return HNB_OK;
 }
@@ -1044,6 +1100,12 @@ int hnb_simulate(HnbContext* ctx) {
     std::stable_sort(order.begin(), order.end(), [](const HnbProgram* x, const HnbProgram* y) { return x->level < y->level; });
     const bool timed = ctx->timing && (ctx->timing_tick % ctx->timing) == 0;
     const uint32_t ev_parity = ctx->frame & 1u;
+    // validate every instance before any per-frame state is touched: a failed call must leave the frame's inputs intact
+    for (HnbProgram* p : order)
+        if (!p->parent_attrs.empty())
+            for (size_t i = 0; i < p->effects.size(); ++i)
+                if (!p->effects[i]->parent)
+                    return fail(HNB_ERR_INVALID_ARG, "effect #%zu reads its parent particle (InheritAttributeModifier / parent_attr) but has no parent: call hnb_effect_set_parent", i);
 
     // ---- per-frame parameters: filled into the program's next ring slot and uploaded on the upload stream. The host
     // waits for the (tiny) copies itself, so the simulation stream carries no cross-stream wait: such a wait costs an
@@ -1061,8 +1123,6 @@ int hnb_simulate(HnbContext* ctx) {
         uint32_t blocks = 0;
         for (uint32_t i = 0; i < n; ++i) {
             HnbEffect* fx = p->effects[i];
-            if (!p->parent_attrs.empty() && !fx->parent)
-                return fail(HNB_ERR_INVALID_ARG, "effect #%u reads its parent particle (InheritAttributeModifier / parent_attr) but has no parent: call hnb_effect_set_parent", i);
             memset(&fi[i], 0, sizeof fi[i]);
             fi[i].spawn_count = fx->parent ? 0u : fx->spawn_count;  // the CPU spawner of a child effect is unused (firework.rs:161)
             fi[i].seed = fx->seed;
@@ -1093,7 +1153,6 @@ int hnb_simulate(HnbContext* ctx) {
                 if (i > 0 && fx->props == p->effects[i - 1]->props) memcpy(ublocks + (size_t)i * nu, ublocks + (size_t)(i - 1) * nu, (size_t)nu * 4);
                 else uniform_run(p->uniform_code.data(), (uint32_t)p->uniform_code.size(), fx->props.data(), sim, ublocks + (size_t)i * nu, nu);
             }
-            fx->spawn_count = 0;  // a spawn request is consumed by exactly one frame
         }
         uint32_t* init_start = ublocks + (size_t)n * nu;  // packed copy of init_block_start for k_init's search
         for (uint32_t i = 0; i < n; ++i) init_start[i] = fi[i].init_block_start;
@@ -1114,7 +1173,7 @@ int hnb_simulate(HnbContext* ctx) {
         const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
         if (blocks) {
             TimingPair ti{};
-            if (timed) { hipEventCreate(&ti.a); hipEventCreate(&ti.b); hipEventRecord(ti.a, ctx->stream); }
+            if (timed) { ti.a = take_event(ctx); ti.b = take_event(ctx); hipEventRecord(ti.a, ctx->stream); }
             if (p->jit_init) {
                 const DevMeta* mi = p->d_meta[par];
                 void* ka[] = {&p->dev, &p->d_inst_base, &mi, &dfi, &dub};
@@ -1144,7 +1203,7 @@ int hnb_simulate(HnbContext* ctx) {
         cb.ev_totals = p->d_ev_totals;
         cb.xcd_remap = n > 1 ? 1u : 0u;
         TimingPair tu{}, tc{};
-        if (timed) { hipEventCreate(&tu.a); hipEventCreate(&tu.b); hipEventCreate(&tc.b); hipEventRecord(tu.a, ctx->stream); }
+        if (timed) { tu.a = take_event(ctx); tu.b = take_event(ctx); tc.b = take_event(ctx); hipEventRecord(tu.a, ctx->stream); }
         const uint32_t died_mark = p->slot_order ? 0u : 2u;
         if (p->update_streams) {
             SlotArgs sa{};
@@ -1212,6 +1271,8 @@ int hnb_simulate(HnbContext* ctx) {
         p->ring += 1;
         p->parity ^= 1u;
     }
+    for (HnbProgram* p : order)
+        for (HnbEffect* fx : p->effects) fx->spawn_count = 0;  // a spawn request is consumed by exactly one (enqueued) frame
     ctx->frame += 1;
     if (ctx->timing) ctx->timing_tick += 1;
     return HNB_OK;
@@ -1339,12 +1400,7 @@ int hnb_jit_precompile(const void* blob, size_t blob_size) {
 int hnb_ctx_enable_kernel_timing(HnbContext* ctx, int enable) {
     if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (auto& t : ctx->t_update) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
-    for (auto& t : ctx->t_init) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
-    for (auto& t : ctx->t_compact) hipEventDestroy(t.b);
-    ctx->t_compact.clear();
-    ctx->t_update.clear();
-    ctx->t_init.clear();
+    recycle_timing_events(ctx);
     ctx->timing = enable > 0 ? (uint32_t)enable : 0u;
     ctx->timing_tick = 0;
     return HNB_OK;

@@ -1,22 +1,26 @@
 // HIP kernels of the particle hot path for gfx950 (MI355X, CDNA4).
 //
-//   k_init    replaces vfx_init.wgsl:101-196      (spawn: pop dead slot, run INIT program, append to alive list)
-//   k_update  replaces vfx_indirect.wgsl:30-90 + vfx_prefix_sum.wgsl:13-43 + vfx_update.wgsl:105-167
-//             (age/reap/modifiers/Euler, kill, and alive/dead list rebuild)
+//   k_init                  replaces vfx_init.wgsl:101-196   (spawn: pop dead slot, run INIT program, append to alive list)
+//   k_update_slots_stream   replaces vfx_update.wgsl:105-167 for update programs made of macro ops on POSITION / VELOCITY /
+//   k_update_slots_generic  AGE / LIFETIME (stream) or any program (generic): age / reap / modifiers / Euler / kill test
+//   k_list_rows, k_compact  the alive / dead list rebuild of vfx_update.wgsl:148-166 and the counter rotation of
+//                           vfx_indirect.wgsl:30-90 + vfx_prefix_sum.wgsl:13-43, only where particles died
+//   k_emit_count/_events    append_spawn_events_N (src/lib.rs:976-993) in serial order
 //
 // Design notes (MI355X-first):
-//  * SoA: one packed plane per attribute. In the streaming kernel a lane owns 4 consecutive
-//    alive-list entries, so on the dense path every access is a 16-byte dwordx4.
-//  * Uniform sub-expressions never reach the GPU as code: the host evaluates them into a
-//    per-instance parameter block that the kernels read with scalar loads.
-//  * The reference rebuilds the alive list with 1-3 global atomics per particle
-//    (vfx_update.wgsl:148-166). Here each 4096-particle chunk compacts survivors and
-//    casualties in LDS (wave prefix scan via cross-lane shuffles + 4-wave LDS combine), then a
-//    single-pass decoupled look-back across chunks gives the global offsets; the lists
-//    are written coalesced and in serial (stable) order. No per-particle atomics.
-//  * HIP has no indirect dispatch: chunks are handed out by a ticket counter (forward
-//    progress under any dispatch order) and sized from device-resident counters, so no
-//    readback and no vfx_indirect / vfx_prefix_sum launches are needed.
+//  * SoA: one packed plane per attribute. The update walks the SLOTS, driven by one alive byte per slot (0 free, 1 alive,
+//    2 died in this frame): a lane owns 4 consecutive slots, so every attribute access is a 16-byte dwordx4 whatever the
+//    alive list looks like after hours of spawn / kill churn; the update never touches the lists.
+//  * Uniform sub-expressions never reach the GPU as code: the host evaluates them into a per-instance parameter block
+//    that the kernels read with scalar loads.
+//  * The reference rebuilds the alive list with 1-3 global atomics per particle (vfx_update.wgsl:148-166). Here the lists
+//    change only in frames with casualties, and then in two light passes over the ROWS: k_list_rows partitions every
+//    4096-row chunk into [survivors | casualties] with wave ballots + popcounts staged in LDS and records the survivor
+//    count; k_compact takes the exclusive prefix of the earlier chunks' counts and moves survivors / casualties to
+//    their final rows in serial (stable) order. One non-returning atomic per workgroup with casualties, none per particle.
+//  * No workgroup ever waits for another (no tickets, no look-back spin): nothing here can hang the GPU. HIP has no
+//    indirect dispatch: grids are sized on the host for the worst case the host knows (capacity, event-buffer size) and
+//    surplus workgroups exit after reading the device-resident counters, so there is no readback on the frame path.
 #pragma once
 #ifndef __HIPCC_RTC__  // hiprtc (hnb_jit) provides the runtime declarations itself
 #include <hip/hip_runtime.h>

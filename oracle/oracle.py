@@ -18,13 +18,17 @@ ATTR_IS_FLOAT = [0, 0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0] + [1] * 1
 
 def build(force=False):
     """Compile the oracle (building the checker is not using it)."""
-    targets = ["libhanabi_oracle.so", "libhanabi_oracle_omp.so"]
-    if force or not all(os.path.exists(os.path.join(_DIR, t)) for t in targets):
+    targets = ["libhanabi_oracle.so", "libhanabi_oracle_omp.so", "libhanabi_oracle_libm.so"]
+    srcs = [os.path.join(_DIR, f) for f in ("hanabi_oracle.c", "oracle_math.h")]
+    stale = lambda t: not os.path.exists(t) or any(os.path.getmtime(s) > os.path.getmtime(t) for s in srcs)
+    if force or any(stale(os.path.join(_DIR, t)) for t in targets):
         subprocess.check_call(["make", "-C", _DIR, "-s"] + (["-B"] if force else []))
 
 
-def _lib(omp=False):
-    name = "libhanabi_oracle_omp.so" if omp else "libhanabi_oracle.so"
+def _lib(omp=False, libm=False):
+    """omp: OpenMP over particles (same arithmetic). libm: the independent flavour whose transcendental builtins go through
+    the host libm (oracle_math.h, ORACLE_LIBM) — tolerance checks only, it is not bit-compatible with the product."""
+    name = "libhanabi_oracle_libm.so" if libm else "libhanabi_oracle_omp.so" if omp else "libhanabi_oracle.so"
     if name not in _LIBS:
         path = os.path.join(_DIR, name)
         if not os.path.exists(path):
@@ -77,8 +81,8 @@ class OracleError(RuntimeError):
 class OracleEffect:
     """One effect instance simulated by the serial-order CPU restatement."""
 
-    def __init__(self, asset_blob: bytes, slot_base=0, omp=False):
-        self._lib = _lib(omp)
+    def __init__(self, asset_blob: bytes, slot_base=0, omp=False, libm=False):
+        self._lib = _lib(omp, libm)
         self._asset = self._lib.hor_asset_parse(asset_blob, len(asset_blob))
         if not self._asset:
             raise OracleError(self._lib.hor_last_error().decode())
@@ -266,3 +270,73 @@ def find_location(prefix, offset, count, index):
 
 def omp_threads():
     return int(_lib(True).hor_omp_threads())
+
+
+# ---- tuned CPU port of the lowered streaming update (cpu_soa.c): bench.py's cpu_baseline -------------------
+HCS_AGE_TICK, HCS_VEL_SCALE, HCS_VEL_ADD, HCS_EULER = 1, 2, 3, 4
+_SOA = {}
+
+
+class _HcsOp(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("v", C.c_float * 3)]
+
+
+def _host_tag():
+    """cpu_soa.c is compiled with -march=native: one library per host CPU model (the in-tree .so files travel to the GPU box)."""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        model = "unknown"
+    return hashlib.sha1(model.encode()).hexdigest()[:10]
+
+
+def build_cpu_soa():
+    path = os.path.join(_DIR, f"libhanabi_cpu_soa_{_host_tag()}.so")
+    src = os.path.join(_DIR, "cpu_soa.c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-std=gnu11", "-O3", "-march=native", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+                               "-Wall", "-shared", src, "-o", path])
+    return path
+
+
+def _soa():
+    if "lib" not in _SOA:
+        lib = C.CDLL(build_cpu_soa())
+        lib.hcs_threads.restype = C.c_int
+        lib.hcs_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+        lib.hcs_update.restype = C.c_uint64
+        lib.hcs_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
+        _SOA["lib"] = lib
+    return _SOA["lib"]
+
+
+class CpuSoaEffect:
+    """Packed SoA planes (position, velocity, age, lifetime + one alive byte per slot) updated by cpu_soa.c."""
+
+    def __init__(self, position, velocity, age, lifetime, alive):
+        self._lib = _soa()
+        n = len(age)
+        self.n = n
+        # parallel first-touch copies: pages land on the NUMA node of the thread that updates them
+        self.pos, self.vel = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+        self.age, self.life, self.alive = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.uint8)
+        for dst, src, bpp in ((self.pos, position, 12), (self.vel, velocity, 12), (self.age, age, 4), (self.life, lifetime, 4), (self.alive, alive, 1)):
+            s = np.ascontiguousarray(src, dtype=dst.dtype).reshape(dst.shape)
+            self._lib.hcs_copy(dst.ctypes.data, s.ctypes.data, n, bpp)
+
+    @staticmethod
+    def threads():
+        return int(_soa().hcs_threads())
+
+    def update(self, ops):
+        """ops: [(HCS_*, (v0, v1, v2))]; returns the number of particles that died."""
+        arr = (_HcsOp * len(ops))()
+        for i, (op, v) in enumerate(ops):
+            arr[i].op = op
+            vv = list(np.asarray(v, dtype=np.float32).reshape(-1)) + [0.0, 0.0, 0.0]
+            for c in range(3):
+                arr[i].v[c] = float(vv[c])
+        return int(self._lib.hcs_update(self.pos.ctypes.data, self.vel.ctypes.data, self.age.ctypes.data, self.life.ctypes.data,
+                                        self.alive.ctypes.data, self.n, C.byref(arr), len(ops)))

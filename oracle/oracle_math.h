@@ -213,7 +213,26 @@ HNB_HD double d_atan2(double y, double x) {
     return y;
 }
 
-// ---- binary32 entry points (what WGSL `sin(x)` etc. mean in this framework) ----------
+// ---- binary32 entry points -----------------------------------------------------------
+#ifdef ORACLE_LIBM
+/* Independent flavour of the oracle (libhanabi_oracle_libm.so): the transcendental WGSL builtins are evaluated by the host's
+ * libm in binary64 and rounded once to binary32 — no code shared with the product's hnb_math.h. The GPU parity tests compare
+ * the product with this flavour within north_star's 1e-5 relative tolerance; the polynomial flavour below stays the
+ * bit-exact checker for lists and counters. */
+#include <math.h>
+HNB_HD float f_sin(float x) { return (float)sin((double)x); }
+HNB_HD float f_cos(float x) { return (float)cos((double)x); }
+HNB_HD float f_tan(float x) { return (float)tan((double)x); }
+HNB_HD float f_atan(float x) { return (float)atan((double)x); }
+HNB_HD float f_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+HNB_HD float f_asin(float x) { return (float)asin((double)x); }
+HNB_HD float f_acos(float x) { return (float)acos((double)x); }
+HNB_HD float f_exp(float x) { return (float)exp((double)x); }
+HNB_HD float f_exp2(float x) { return (float)exp2((double)x); }
+HNB_HD float f_log(float x) { return (float)log((double)x); }
+HNB_HD float f_log2(float x) { return (float)log2((double)x); }
+HNB_HD float f_pow(float x, float y) { return (float)pow((double)x, (double)y); }
+#else
 HNB_HD bool trig_in_range(float x) { return f_abs(x) <= 1099511627776.0f; }  // 2^40
 
 HNB_HD float f_sin(float x) {
@@ -286,6 +305,8 @@ HNB_HD float f_pow(float x, float y) {
     if (t < -120.0) t = -120.0;
     return (float)d_exp(t);
 }
+
+#endif  /* ORACLE_LIBM */
 
 // ---- conversions (WGSL value constructors: truncate + saturate, NaN -> 0) -------------
 HNB_HD int32_t f_to_i32(float x) {

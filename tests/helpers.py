@@ -40,9 +40,9 @@ def stored_attrs(asset):
 class OracleRunner:
     name = "oracle"
 
-    def __init__(self, asset, slot_base=0, omp=False):
+    def __init__(self, asset, slot_base=0, omp=False, libm=False):
         self.asset = asset
-        self.fx = oracle.OracleEffect(bh.serialize_asset(asset), slot_base, omp=omp)
+        self.fx = oracle.OracleEffect(bh.serialize_asset(asset), slot_base, omp=omp, libm=libm)
 
     def step(self, fr: Frame):
         for k, v in fr.props.items():
@@ -269,3 +269,27 @@ def assert_same_system_state(ref, got, what=""):
     assert len(ref) == len(got)
     for i, (r, g) in enumerate(zip(ref, got)):
         assert_same_state(r, g, f"{what} effect #{i}")
+
+
+# ---- GPU evaluation of the hanabi-math builtins (tests/test_gpu_scale.py, tools/warm_jit_cache.py) -------------
+def math_probe_asset(capacity):
+    """One effect whose UPDATE evaluates every transcendental builtin of the expression API on per-particle inputs:
+         F32X4_0 = (sin, cos, tan, atan)(F32_0)      F32X4_1 = (asin, acos)(F32_1), (exp, exp2)(F32_2)
+         F32X4_2 = (log, log2, sqrt, inverseSqrt)(F32_3)      F32X2_1 = (atan2(F32X2_0.x, F32X2_0.y), 0)
+    The test writes the input planes through the ABI, runs one frame and reads the outputs back."""
+    w = bh.ExprWriter()
+    a, b, c, d = (w.attr(x) for x in (A.F32_0, A.F32_1, A.F32_2, A.F32_3))
+    p = w.attr(A.F32X2_0)
+    out0 = a.sin().vec3(a.cos(), a.tan()).vec4_xyz_w(a.atan())
+    out1 = b.asin().vec3(b.acos(), c.exp()).vec4_xyz_w(c.exp2())
+    out2 = d.log().vec3(d.log2(), d.sqrt()).vec4_xyz_w(d.inverse_sqrt())
+    out3 = p.x().atan2(p.y()).vec2(w.lit(0.0))
+    mods_init = [bh.SetAttributeModifier(A.POSITION, w.lit((0.0, 0.0, 0.0)).expr())]
+    mods_update = [bh.SetAttributeModifier(A.F32X4_0, out0.expr()), bh.SetAttributeModifier(A.F32X4_1, out1.expr()),
+                   bh.SetAttributeModifier(A.F32X4_2, out2.expr()), bh.SetAttributeModifier(A.F32X2_1, out3.expr())]
+    asset = bh.EffectAsset(capacity, bh.SpawnerSettings.once(float(capacity)), w.finish())
+    for m in mods_init:
+        asset.init(m)
+    for m in mods_update:
+        asset.update(m)
+    return asset

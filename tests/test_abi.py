@@ -109,22 +109,50 @@ def test_product_package_never_imports_the_oracle():
 
 
 def test_jit_precompile_without_a_device(tmp_path, monkeypatch):
-    """Kernel specialisation (hiprtc for gfx950) works on a box without a GPU and fills the cache."""
+    """Kernel specialisation (hiprtc for gfx950) works on a box without a GPU and fills the cache; cache entries are
+    self-describing and verified on load: a truncated, a corrupted and a foreign entry are all recompiled and replaced."""
     import bevy_hanabi_amd as bh
     from test_lowering_cpu import ZOO
-    monkeypatch.setenv("HNB_JIT_CACHE", str(tmp_path))
+    monkeypatch.setenv("HNB_JIT_CACHE", str(tmp_path / "cache"))
+    cache = tmp_path / "cache"
     bh.jit_precompile(bh.lower(effects.firework_trails(2048)))          # init only (update has a pre-built kernel)
-    n1 = len(list(tmp_path.glob("*.hsaco")))
-    assert n1 == 1
+    entries = list(cache.glob("*.hnbjit"))
+    assert len(entries) == 1
+    assert (os.stat(cache).st_mode & 0o777) == 0o700                    # private directory
     name = sorted(ZOO)[0]
     bh.jit_precompile(bh.lower(ZOO[name]()))                            # a zoo program: init + update
-    assert len(list(tmp_path.glob("*.hsaco"))) == 2
-    names = [open(p).read().split() for p in tmp_path.glob("*.names")]
-    assert all(n and all(s.startswith("_ZN3hnb") for s in n) for n in names)
+    assert len(list(cache.glob("*.hnbjit"))) == 2
     bh.jit_precompile(bh.lower(effects.firework_trails(1 << 20)))       # capacity does not enter the key
-    assert len(list(tmp_path.glob("*.hsaco"))) == 2
+    assert len(list(cache.glob("*.hnbjit"))) == 2
+    good = entries[0].read_bytes()
+    assert good[:7] == b"HNBJIT2" and b"_ZN3hnb" in good                # header + lowered kernel names + code object
+    mtime = lambda: os.stat(entries[0]).st_mtime_ns
+    t0 = mtime()
+    bh.jit_precompile(bh.lower(effects.firework_trails(2048)))          # a valid entry is a hit: not rewritten
+    assert mtime() == t0
+    for bad in (good[: len(good) // 2],                                 # truncated
+                good[:-16] + bytes(16),                                 # code object damaged
+                good[:24] + bytes([good[24] ^ 1]) + good[25:]):         # built from something else (key hash differs)
+        entries[0].write_bytes(bad)
+        bh.jit_precompile(bh.lower(effects.firework_trails(2048)))
+        assert entries[0].read_bytes() == good
+    assert not list(cache.glob("*.tmp*"))
     with pytest.raises(bh.HanabiError):
         bh.jit_precompile(b"garbage")
+
+
+def test_slab_layout_must_fit_32_bit_offsets():
+    """The instance slab is addressed with u32 section offsets: a capacity whose LAST sections (alive bytes, lifetime bounds)
+    would pass 4 GiB is rejected as a whole (49 B per slot for the firework layout: the limit is ~87.6M slots), not just
+    the ones whose attribute planes do."""
+    bh.validate_program(bh.lower(effects.firework_trails(80_000_000)))
+    for cap in (89_500_000, 92_000_000, 97_600_000, 200_000_000):
+        with pytest.raises(bh.HanabiError) as ei:
+            bh.validate_program(bh.lower(effects.firework_trails(cap)))
+        assert "4 GiB" in str(ei.value)
+    bh.validate_program(bh.lower(effects.ribbon(60_000_000)))
+    with pytest.raises(bh.HanabiError):
+        bh.validate_program(bh.lower(effects.ribbon(75_000_000)))     # ribbon: 28 B attributes + 12 lists + 1 + 24 sort scratch per slot
 
 
 def test_batched_frame_inputs_are_declared():

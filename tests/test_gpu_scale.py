@@ -1,0 +1,311 @@
+"""GPU tests that close the gaps of round 1's parity story:
+
+  * the PRODUCT's capacity-slab sharding: two product effects with slot_base 0 and C on one GPU, their union compared
+    bit for bit with one product effect of capacity 2C and with the oracle;
+  * an INDEPENDENT float check: the product against the oracle flavour whose transcendental builtins go through the
+    host libm (oracle/oracle_math.h, ORACLE_LIBM) within north_star's 1e-5 relative tolerance on position / velocity,
+    exact on counts and lists; and every hanabi-math builtin evaluated ON THE GPU over >= 1e6 inputs against numpy's
+    binary64 libm, <= 1 ulp;
+  * parity at BASELINE.json's sizes: C3 8,388,608 (full state against the OpenMP oracle), C4 512 x 65,536 (one GPU's
+    share; sampled instances in full, every instance's counters), C5 4,194,304 (full state incl. the ribbon sort) — a
+    handful of frames each, with spawns, deaths and slot reuse forced by a large dt.
+"""
+import numpy as np
+import pytest
+
+import bevy_hanabi_amd as bh
+from bevy_hanabi_amd import effects, sharding
+from helpers import A, Frame, GpuRunner, OracleRunner, assert_same_state, frame_seed, math_probe_asset, translation
+from test_lowering_cpu import burst_then_run
+from test_math import ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5  # BASELINE.json north_star: "within 1e-5 relative fp32 on position/velocity and bit-exact on alive counts"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = bh.Context(0)
+    yield c
+    c.close()
+
+
+# ---- capacity-slab sharding of the product ---------------------------------------------------------------------
+def test_two_slabs_with_slot_base_equal_one_effect(ctx):
+    """Rank g of a slab-sharded effect owns global slots [g*C, (g+1)*C) and passes slot_base = g*C. Both slabs live on one
+    GPU here: their union must equal one effect of capacity 2C bit for bit, through the burst, the flight and the die-off."""
+    C = 37000  # not a multiple of the 4096-slot chunk: the slabs' last chunks are ragged
+    plan = sharding.slab_plan(2 * C, 2)
+    assert plan == [(0, C), (C, C)]
+    prog2 = ctx.create_program(bh.lower(effects.firework_trails(2 * C)))
+    one = prog2.create_effect()
+    prog = ctx.create_program(bh.lower(effects.firework_trails(C)))
+    slabs = [prog.create_effect(slot_base=base) for base, _ in plan]
+    orc = OracleRunner(effects.firework_trails(2 * C))
+    checked_deaths = False
+    for f in range(75):
+        seed = frame_seed(f)
+        spawn = 2 * C if f == 0 else 0
+        split = sharding.split_spawn(spawn, [fx.capacity - fx.alive_count() for fx in slabs]) if spawn else [0, 0]
+        ctx.frame_begin(1 / 60, f / 60)
+        one.set_frame(spawn, seed)
+        for fx, n in zip(slabs, split):
+            fx.set_frame(n, seed)
+        ctx.simulate()
+        orc.step(Frame(1 / 60, spawn, seed, time=f / 60))
+        if f in (0, 30, 52, 60, 74):
+            ref = orc.state()
+            assert one.alive_count() == ref["counters"]["alive_count"] == sum(fx.alive_count() for fx in slabs)
+            if 0 < ref["counters"]["alive_count"] < 2 * C:
+                checked_deaths = True
+            for a in (A.POSITION, A.VELOCITY, A.AGE, A.LIFETIME, A.COLOR):
+                union = np.concatenate([fx.read_attr(a.id).view(np.uint32) for fx in slabs])
+                np.testing.assert_array_equal(union, one.read_attr(a.id).view(np.uint32), err_msg=f"frame {f}: {a.name}: slabs vs one effect")
+                np.testing.assert_array_equal(union, ref["attrs"][a.name], err_msg=f"frame {f}: {a.name}: slabs vs oracle")
+            # each slab's alive list holds LOCAL slots; shifted by its base the union is the one effect's alive SET
+            glob = np.concatenate([fx.alive_list() + base for fx, (base, _) in zip(slabs, plan)])
+            np.testing.assert_array_equal(np.sort(glob), np.sort(one.alive_list()))
+    assert checked_deaths
+    prog.destroy()
+    prog2.destroy()
+
+
+# ---- independent float check: product vs the libm flavour of the oracle ---------------------------------------------
+def _assert_close_state(ref, got, what):
+    assert ref["counters"] == got["counters"], f"{what}: counters differ\n ref {ref['counters']}\n got {got['counters']}"
+    np.testing.assert_array_equal(ref["alive"], got["alive"], err_msg=f"{what}: alive list")
+    np.testing.assert_array_equal(ref["dead"], got["dead"], err_msg=f"{what}: dead list")
+    worst = 0.0
+    for k in ("position", "velocity", "age", "lifetime"):
+        if k not in ref["attrs"]:
+            continue
+        a = ref["attrs"][k].view(np.float32).astype(np.float64)
+        b = got["attrs"][k].view(np.float32).astype(np.float64)
+        both_nan = np.isnan(a) & np.isnan(b)
+        err = np.abs(a - b)
+        bound = REL_TOL * np.maximum(np.abs(a), np.abs(b))
+        bad = (err > bound) & ~both_nan
+        assert not bad.any(), f"{what}: {k}: {bad.sum()} components beyond {REL_TOL} relative; worst {err[bad].max()} at {np.argwhere(bad)[0]}"
+        with np.errstate(invalid="ignore", divide="ignore"):
+            rel = np.where(bound > 0, err / np.maximum(np.abs(a), np.abs(b)), 0.0)
+        worst = max(worst, float(np.nanmax(rel)) if rel.size else 0.0)
+    return worst
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4"])
+def test_product_against_libm_oracle(ctx, name):
+    if name == "c2":
+        cap = 20000
+        asset, frames = effects.firework_trails(cap), burst_then_run(cap, 80)
+    elif name == "c3":
+        cap = 30000
+        asset, frames = effects.force_field(cap), burst_then_run(cap, 100)
+        frames[40].props = {"repulsor_position": (0.1, 0.2, 0.0), "repulsor_accel": -25.0}
+    else:
+        cap = 9000
+        asset, frames = effects.instancing(cap), burst_then_run(cap, 60, xf=translation(3.0, -2.0, 7.0))
+    gpu, orc = GpuRunner(asset, ctx=ctx), OracleRunner(asset, libm=True)
+    worst = 0.0
+    for i, fr in enumerate(frames):
+        gpu.step(fr)
+        orc.step(fr)
+        if i % 10 == 9 or i == len(frames) - 1:
+            worst = max(worst, _assert_close_state(orc.state(), gpu.state(), f"{name} frame {i}"))
+    print(f"{name}: worst relative difference to the libm oracle over the run: {worst:.3g}")
+    gpu.fx.destroy(); gpu.prog.destroy()
+
+
+def test_math_builtins_on_the_gpu_against_libm(ctx):
+    """Every transcendental builtin of hnb_math.h evaluated by the GPU build over 2^20 (> 1e6) inputs each, through the
+    C ABI (write the input planes, one update frame, read the output planes), against numpy's binary64 libm rounded to
+    binary32: at most 1 ulp apart, same finiteness. The oracle is not involved."""
+    n = 1 << 20
+    rng = np.random.default_rng(20260924)
+    r = GpuRunner(math_probe_asset(n), ctx=ctx)
+    assert "jit" in r.prog.kernel_info() or "interp" in r.prog.kernel_info()
+    r.step(Frame(1 / 60, n, 1))
+    trig = rng.uniform(-50, 50, n).astype(np.float32)
+    trig[:64] = np.array([1e4, 12345.678, 1e6, 3.4e7, -7.7e6, 0.0, -0.0, 1e-30] * 8, np.float32)
+    unit = rng.uniform(-1, 1, n).astype(np.float32)
+    unit[:4] = (1.0, -1.0, 0.0, 0.5)
+    expo = rng.uniform(-80, 80, n).astype(np.float32)
+    posi = np.exp(rng.uniform(-80, 80, n)).astype(np.float32)
+    xy = rng.uniform(-100, 100, (n, 2)).astype(np.float32)
+    for attr, plane in ((A.F32_0, trig), (A.F32_1, unit), (A.F32_2, expo), (A.F32_3, posi), (A.F32X2_0, xy)):
+        r.fx.write_attr(attr.id, plane)
+    r.step(Frame(1 / 60, 0, 2))
+    o0, o1, o2 = (r.fx.read_attr(a.id) for a in (A.F32X4_0, A.F32X4_1, A.F32X4_2))
+    o3 = r.fx.read_attr(A.F32X2_1.id)
+    d = np.float64
+    cases = [("sin", o0[:, 0], np.sin(trig.astype(d)), trig), ("cos", o0[:, 1], np.cos(trig.astype(d)), trig),
+             ("tan", o0[:, 2], np.tan(trig.astype(d)), trig), ("atan", o0[:, 3], np.arctan(trig.astype(d)), trig),
+             ("asin", o1[:, 0], np.arcsin(unit.astype(d)), unit), ("acos", o1[:, 1], np.arccos(unit.astype(d)), unit),
+             ("exp", o1[:, 2], np.exp(expo.astype(d)), expo), ("exp2", o1[:, 3], np.exp2(expo.astype(d)), expo),
+             ("log", o2[:, 0], np.log(posi.astype(d)), posi), ("log2", o2[:, 1], np.log2(posi.astype(d)), posi),
+             ("sqrt", o2[:, 2], np.sqrt(posi.astype(d)), posi), ("inverseSqrt", o2[:, 3], 1.0 / np.sqrt(posi.astype(d)), posi),
+             ("atan2", o3[:, 0], np.arctan2(xy[:, 0].astype(d), xy[:, 1].astype(d)), xy[:, 0])]
+    report = []
+    for fn, got, want64, x in cases:
+        with np.errstate(over="ignore", under="ignore"):
+            want = want64.astype(np.float32)
+        finite = np.isfinite(want)
+        assert (np.isfinite(got) == finite).all(), f"{fn}: finiteness differs"
+        if fn == "inverseSqrt":   # defined as 1 / sqrt(x) in binary32 (two roundings): <= 1 ulp of that definition, <= 2 of libm
+            want = (np.float32(1.0) / np.sqrt(x.astype(np.float32))).astype(np.float32)
+        ud = ulp_diff(got[finite], want[finite])
+        assert ud.max() <= 1, f"{fn}: {ud.max()} ulp at x = {x[finite][ud.argmax()]!r}"
+        report.append(f"{fn} {int(ud.max())} ulp ({int((ud > 0).sum())} of {int(finite.sum())} differ)")
+    print("GPU hanabi-math vs libm over 2^20 inputs each: " + "; ".join(report))
+    r.fx.destroy(); r.prog.destroy()
+
+
+# ---- parity at BASELINE.json's sizes -------------------------------------------------------------------------------
+def test_c3_force_field_at_baseline_size(ctx):
+    """force_field.rs at 8,388,608 particles (BASELINE config 3), full state against the OpenMP oracle: burst, then
+    frames of dt = 0.5 s — at that step the force field throws a fifth of the particles out of the KillAabb box within two
+    frames and more in the following ones (deaths in several frames, lists compacted at full size)."""
+    cap = 1 << 23
+    asset = effects.force_field(cap)
+    gpu, orc = GpuRunner(asset, ctx=ctx), OracleRunner(asset, omp=True)
+    alive = []
+    for f in range(5):
+        fr = Frame(1 / 60 if f == 0 else 0.5, cap if f == 0 else 0, frame_seed(f), time=f * 0.5)
+        gpu.step(fr)
+        orc.step(fr)
+        if f in (0, 2, 4):
+            assert_same_state(orc.state(), gpu.state(), f"C3 8M frame {f}")
+        alive.append(gpu.fx.alive_count())
+    assert alive[0] == cap and 0 < alive[-1] < cap, alive
+    print("C3 8,388,608: alive per frame", alive)
+    gpu.fx.destroy(); gpu.prog.destroy()
+
+
+def test_c4_instancing_one_gpu_share_at_baseline_size(ctx):
+    """instancing.rs, 512 instances x 65,536 (one GPU's share of BASELINE config 4: 4096 instances over 8 GPUs, instance i
+    on rank i mod 8 — rank 0 owns 0, 8, 16, ...). dt = 3 s with the rate spawner: a quarter of the capacity spawns per frame
+    and dies four frames later, so the six frames cover spawn, death and slot reuse. Four sampled instances are compared
+    in full with the oracle; EVERY instance's counters are compared with the oracle's (identical by construction)."""
+    cap, n_local, world = 65536, 512, 8
+    gids = sharding.instance_plan(n_local * world, world)[0]
+    assert gids[:3] == [0, 8, 16] and len(gids) == n_local
+    asset = effects.instancing(cap)
+    prog = ctx.create_program(bh.lower(asset))
+    fxs = [prog.create_effect() for _ in gids]
+    sampled = [0, 1, 255, 511]
+    oracles = {k: OracleRunner(asset, omp=True) for k in sampled}
+    sp = bh.EffectSpawner(asset.spawner)
+    rng = bh.Pcg32()
+    xfs = np.array([translation(10.0 * (g % 64), 0.0, 10.0 * (g // 64)) for g in gids], np.float32)
+    dt = 3.0
+    for f in range(6):
+        n = sp.tick(dt, rng)
+        seeds = [(frame_seed(f) ^ (g * 2654435761)) & 0xFFFFFFFF for g in gids]
+        ctx.frame_begin(dt, f * dt)
+        prog.set_frames([n] * n_local, seeds, xfs)
+        ctx.simulate()
+        for k, o in oracles.items():
+            o.step(Frame(dt, n, seeds[k], xfs[k], time=f * dt))
+    ref = {k: o.state() for k, o in oracles.items()}
+    counters = ref[0]["counters"]
+    assert 0 < counters["alive_count"] < cap and counters["dead_count"] > 0
+    keys = ["capacity", "alive_count", "max_update", "max_spawn", "indirect_write_index", "particle_counter", "instance_count", "dead_count"]
+    for i, fx in enumerate(fxs):
+        m = fx.metadata()
+        assert {k: m[k] for k in keys} == counters, f"instance {i}"
+    for k in sampled:
+        fx = fxs[k]
+        got = {"counters": {q: fx.metadata()[q] for q in keys}, "alive": fx.alive_list(), "dead": fx.dead_list(),
+               "attrs": {a.name: fx.read_attr(a.id).view(np.uint32) for a in (A.POSITION, A.VELOCITY, A.AGE, A.LIFETIME)}}
+        assert_same_state(ref[k], got, f"C4 instance {k} (global {gids[k]})")
+    prog.destroy()
+
+
+def test_c5_ribbon_at_baseline_size(ctx):
+    """ribbon.rs at 4,194,304 particles (BASELINE config 5), full state incl. the (RIBBON_ID, AGE) sort of the alive list
+    against the OpenMP oracle. dt = 0.5 s with the rate spawner (capacity / 1.5 per second): a third of the capacity
+    spawns per frame and dies three frames later; from frame 3 on every frame spawns into recycled slots."""
+    cap = 1 << 22
+    asset = effects.ribbon(cap)
+    gpu, orc = GpuRunner(asset, ctx=ctx), OracleRunner(asset, omp=True)
+    sp = bh.EffectSpawner(asset.spawner)
+    rng = bh.Pcg32()
+    dt = 0.5
+    for f in range(6):
+        t = f * dt
+        fr = Frame(dt, sp.tick(dt, rng), frame_seed(f), translation(25.0 * np.cos(3.0 * t), 25.0 * np.sin(2.0 * t), 0.0), time=t)
+        gpu.step(fr)
+        orc.step(fr)
+        if f in (1, 3, 5):
+            assert_same_state(orc.state(), gpu.state(), f"C5 4M frame {f}")
+    m = gpu.fx.metadata()
+    assert m["dead_count"] > 0 and m["spawned"] > 0 and 0 < m["alive_count"] <= cap
+    gpu.fx.destroy(); gpu.prog.destroy()
+
+
+# ---- C-ABI behaviour fixed in round 2 --------------------------------------------------------------------
+def test_set_parent_rejects_program_level_cycles_instead_of_hanging(ctx):
+    """A program's init pass is one launch for all its instances, so parent/child links are ordered per PROGRAM: two
+    instances of one program, or two programs that are each other's parent through different instances, cannot be
+    scheduled. hnb_effect_set_parent must refuse them (it used to spin forever raising dependency levels)."""
+    px = ctx.create_program(bh.lower(effects.firework_rocket()))
+    py = ctx.create_program(bh.lower(effects.firework_rocket()))
+    x1, x2, y1 = px.create_effect(), px.create_effect(), py.create_effect()
+    with pytest.raises(bh.HanabiError) as ei:
+        x2.set_parent(x1, 0)              # same program
+    assert ei.value.code == -1
+    y1.set_parent(x1, 0)                  # Y depends on X
+    with pytest.raises(bh.HanabiError) as ei:
+        x2.set_parent(y1, 1)              # ... so X cannot depend on Y
+    assert ei.value.code == -1 and "cycle" in str(ei.value)
+    # the accepted link still works: a frame runs, parents first
+    ctx.frame_begin(1 / 60, 0.0)
+    for fx in (x1, x2, y1):
+        fx.set_frame(4, 7)
+    ctx.simulate()
+    assert x1.alive_count() == 4 and y1.alive_count() == 0
+    px.destroy(); py.destroy()
+
+
+def test_failed_simulate_keeps_the_frame_inputs(ctx):
+    """hnb_simulate validates every instance before it touches per-frame state: when it fails (a child effect without its
+    parent) no spawn request is consumed, and the next successful frame spawns what was asked."""
+    parent_prog = ctx.create_program(bh.lower(effects.firework_rocket()))
+    child_prog = ctx.create_program(bh.lower(effects.firework_trails_child(2000)))
+    plain = GpuRunner(effects.firework_trails(3000), ctx=ctx)
+    rocket, child = parent_prog.create_effect(), child_prog.create_effect()
+    ctx.frame_begin(1 / 60, 0.0)
+    plain.fx.set_frame(1234, frame_seed(0))
+    rocket.set_frame(3, frame_seed(1))
+    with pytest.raises(bh.HanabiError):
+        ctx.simulate()                    # `child` reads its parent particle but has no parent yet
+    assert plain.fx.alive_count() == 0 and rocket.alive_count() == 0
+    child.set_parent(rocket, 1, 256)
+    ctx.simulate()                        # same frame inputs, now valid
+    assert plain.fx.alive_count() == 1234 and rocket.alive_count() == 3
+    orc = OracleRunner(effects.firework_trails(3000))
+    orc.step(Frame(1 / 60, 1234, frame_seed(0)))
+    np.testing.assert_array_equal(orc.state()["attrs"]["velocity"], plain.fx.read_attr(A.VELOCITY.id).view(np.uint32))
+    parent_prog.destroy(); child_prog.destroy(); plain.prog.destroy()
+
+
+def test_set_stream_null_returns_to_the_context_stream():
+    """hnb_ctx_set_stream(ctx, NULL) selects the context's own stream again (the header's contract): the caller's stream
+    may be destroyed afterwards."""
+    import torch
+    c = bh.Context(0)
+    r = GpuRunner(effects.firework_trails(5000), ctx=c)
+    orc = OracleRunner(effects.firework_trails(5000))
+    ext = torch.cuda.Stream()
+    c.set_stream(ext.cuda_stream)
+    for f in range(3):
+        fr = Frame(1 / 60, 5000 if f == 0 else 0, frame_seed(f), time=f / 60)
+        r.step(fr); orc.step(fr)
+    c.set_stream(None)
+    del ext
+    torch.cuda.synchronize()
+    for f in range(3, 6):
+        fr = Frame(1 / 60, 0, frame_seed(f), time=f / 60)
+        r.step(fr); orc.step(fr)
+    assert_same_state(orc.state(), r.state(), "after returning to the context's stream")
+    c.close()

@@ -19,13 +19,15 @@ def main():
     try:
         from test_lowering_cpu import ZOO
         assets += [ZOO[k]() for k in sorted(ZOO)]
+        from helpers import math_probe_asset
+        assets.append(math_probe_asset(4096))
     except Exception as e:  # tests not present: product programs only
         print("warm_jit_cache: zoo skipped:", e)
     # entries are keyed by the generated source and the kernel headers: drop what older builds left behind
     cache = os.path.join(ROOT, "bevy_hanabi_amd", "jit_cache")
     if os.path.isdir(cache) and not os.environ.get("HNB_JIT_CACHE"):
         for f in os.listdir(cache):
-            if f.endswith((".hsaco", ".names")):
+            if f.endswith((".hsaco", ".names", ".hnbjit")):
                 os.remove(os.path.join(cache, f))
     t0 = time.time()
     for a in assets:
