@@ -103,6 +103,7 @@ struct HnbContext {
     HnbSimParams sim{};
     uint32_t frame = 0;         // simulated frames: parity double-buffers the spawn-event counters
     uint32_t list_order = HNB_LIST_ORDER_SPAWN;  // applied to programs created afterwards
+    bool alternate = true;      // walk the chunks in alternating directions from frame to frame (HNB_ALTERNATE=0 turns it off)
     uint32_t timing = 0;        // 0 = off, n = time every n-th simulated frame
     uint32_t timing_tick = 0;
     std::vector<TimingPair> t_update, t_init, t_compact;
@@ -155,6 +156,7 @@ struct HnbProgram {
     uint32_t init_blocks = 0;   // k_init grid of the frame being enqueued
     size_t frame_bytes = 0;
     uint32_t parity = 0;
+    uint32_t frames_run = 0;    // frames this program was simulated in: the chunk walk alternates its direction with it
 };
 
 struct EventChannel {
@@ -650,6 +652,7 @@ int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
     if (e != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return fail(HNB_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
+    if (const char* e = getenv("HNB_ALTERNATE")) ctx->alternate = e[0] != '0';
     *out_ctx = ctx;
     return HNB_OK;
 }
@@ -1201,7 +1204,7 @@ int hnb_simulate(HnbContext* ctx) {
         cb.table_cap = p->table_cap;
         cb.parity = par;
         cb.ev_totals = p->d_ev_totals;
-        cb.xcd_remap = n > 1 ? 1u : 0u;
+        cb.xcd_remap = (n > 1 ? 1u : 0u) | (ctx->alternate && (p->frames_run & 1u) ? 2u : 0u);  // see chunk_of_workgroup
         TimingPair tu{}, tc{};
         if (timed) { tu.a = take_event(ctx); tu.b = take_event(ctx); tc.b = take_event(ctx); hipEventRecord(tu.a, ctx->stream); }
         const uint32_t died_mark = p->slot_order ? 0u : 2u;
@@ -1270,6 +1273,7 @@ int hnb_simulate(HnbContext* ctx) {
         HIP_TRY(hipEventRecord(p->kernels_done[p->ring % kFrameRing], ctx->stream));
         p->ring += 1;
         p->parity ^= 1u;
+        p->frames_run += 1;
     }
     for (HnbProgram* p : order)
         for (HnbEffect* fx : p->effects) fx->spawn_count = 0;  // a spawn request is consumed by exactly one (enqueued) frame

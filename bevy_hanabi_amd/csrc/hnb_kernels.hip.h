@@ -337,21 +337,31 @@ struct CompactBufs {
     uint32_t table_cap;
     uint32_t parity;
     uint32_t* ev_totals;  // [n_inst * chunks_per_inst][HNB_MAX_EVENT_CHANNELS] spawn events per chunk (emitting programs)
-    uint32_t xcd_remap;   // batches of instances: XCD-aware workgroup -> chunk mapping (chunk_of_workgroup)
+    uint32_t xcd_remap;   // workgroup -> chunk mapping (chunk_of_workgroup): bit 0 XCD-aware (batches of instances), bit 1 descending order (every other frame)
 };
 
 // Workgroup -> chunk. The hardware deals workgroups to the 8 XCDs round-robin (workgroup b runs on XCD b mod 8,
 // each XCD with its own L2). In a batch of instances, mapping b straight to chunk b pins chunk j of EVERY instance
 // to XCD j mod 8 whenever an instance has a multiple of 8 chunks (measured, churn: 1024 x 65,536 slots 1.84 ms vs
-// 1024 x 65,792 slots 0.93 ms); with `xcd_remap` every XCD walks its own contiguous eighth of the chunks instead
-// (0.99 ms). A single large instance keeps the straight mapping, which measured 2 % faster there.
-__device__ __forceinline__ uint32_t chunk_of_workgroup(uint32_t xcd_remap) {
+// 1024 x 65,792 slots 0.93 ms); with bit 0 of `mode` (CompactBufs::xcd_remap) every XCD walks its own contiguous
+// eighth of the chunks instead (0.99 ms). A single large instance keeps the straight mapping, which measured 2 %
+// faster there.
+// Bit 1 of `mode`: walk the chunks in DESCENDING order. hnb_simulate sets it in every other frame, because the 256 MiB
+// Infinity Cache sits on the memory side and keeps what was written last: a frame that starts where the previous
+// one ended finds the most recently written quarter of a 16.7M-particle effect's planes still on the die instead of in
+// HBM (workgroups are dispatched in increasing blockIdx order). Measured with the firework update over
+// 16,777,216 particles (tools/layout_probe.hip, profiles/r02d_layout_probe.log): 0.204 ms ascending every frame, 0.204 ms
+// descending every frame, 0.171 ms alternating. Any bijection is correct: a workgroup handles the chunk it computes here.
+__device__ __forceinline__ uint32_t chunk_of_workgroup(uint32_t mode) {
     const uint32_t b = blockIdx.x;
-    if (!xcd_remap) return b;
     const uint32_t total = gridDim.x;
-    const uint32_t xcd = b & 7u, local = b >> 3;
-    const uint32_t q = total >> 3, r = total & 7u;
-    return xcd * q + (xcd < r ? xcd : r) + local;
+    uint32_t c = b;
+    if (mode & 1u) {
+        const uint32_t xcd = b & 7u, local = b >> 3;
+        const uint32_t q = total >> 3, r = total & 7u;
+        c = xcd * q + (xcd < r ? xcd : r) + local;
+    }
+    return (mode & 2u) ? total - 1u - c : c;
 }
 
 // Decode a chunk id; false when the chunk has no rows.

@@ -35,6 +35,14 @@ int hcs_threads(void) {
 #endif
 }
 
+void hcs_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* Parallel copy with the schedule of hcs_update: first touch places every block's pages on the NUMA node of the thread
  * that will update it. */
 void hcs_copy(void* dst, const void* src, uint64_t n_particles, uint32_t bytes_per_particle) {

@@ -305,6 +305,7 @@ def _soa():
     if "lib" not in _SOA:
         lib = C.CDLL(build_cpu_soa())
         lib.hcs_threads.restype = C.c_int
+        lib.hcs_set_threads.argtypes = [C.c_int]
         lib.hcs_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
         lib.hcs_update.restype = C.c_uint64
         lib.hcs_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
@@ -329,6 +330,10 @@ class CpuSoaEffect:
     @staticmethod
     def threads():
         return int(_soa().hcs_threads())
+
+    @staticmethod
+    def set_threads(n):
+        _soa().hcs_set_threads(int(n))
 
     def update(self, ops):
         """ops: [(HCS_*, (v0, v1, v2))]; returns the number of particles that died."""

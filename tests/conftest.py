@@ -19,6 +19,7 @@ def pytest_configure(config):
     if os.path.exists(hipcc) or shutil.which("hipcc"):
         hb.build_runtime()
     hb.build_host()
+    hb.build_host_lib()
     import oracle
 
     oracle.build()

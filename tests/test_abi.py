@@ -163,4 +163,7 @@ def test_integration_binding_lists_every_entry_point():
     """INTEGRATION.md's Rust `extern "C"` block mirrors the header one to one."""
     txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     bound = set(re.findall(r"pub fn (hnb_[a-z0-9_]+)\(", txt))
-    assert bound == set(declared_symbols())
+    host = open(os.path.join(ROOT, "include", "hanabi_amd_host.h")).read()
+    host = re.sub(r"/\*.*?\*/", "", host, flags=re.S)
+    host_syms = set(re.findall(r"\b(hnb_[a-z0-9_]+)\s*\(", host))
+    assert bound == set(declared_symbols()) | host_syms   # device ABI (section 1) + host ABI (section 3)
