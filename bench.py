@@ -33,6 +33,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# CPU baseline: OpenMP threads are bound to cores. libgomp reads these when it is first loaded (which `import torch` may already
+# trigger), so they are set before any import that could; unbound threads measured 6-15x slower on the 2-socket host.
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402,F401  (before the HIP library of this package: torch bundles its own libamdhip64, and whichever copy is loaded
@@ -107,9 +111,7 @@ def cpu_baseline(capacity, frames=60, check_frames=2):
     simulation path, so this is a port, not bevy_hanabi code. Before it is timed the port is checked
     bit-for-bit against the oracle (hanabi_oracle.c, the restatement of the WGSL semantics) on the same particles.
     Threads are bound (OMP_PROC_BIND=spread over OMP_PLACES=cores unless the environment says otherwise: unbound threads
-    measured 6-15x slower on the 2-socket host) and the thread count is the best of {cores/2, cores, hardware threads}."""
-    os.environ.setdefault("OMP_PROC_BIND", "spread")   # read by libgomp when the oracle libraries load it (below)
-    os.environ.setdefault("OMP_PLACES", "cores")
+    measured 6-15x slower on the 2-socket host) and the thread count is the best of {1/8, 1/4, 1/2} of the hardware threads."""
     import bevy_hanabi_amd as bh
     import oracle
     from bevy_hanabi_amd import effects
@@ -142,7 +144,7 @@ def cpu_baseline(capacity, frames=60, check_frames=2):
     # the timed frames use a small dt so that no particle reaches its lifetime however many frames are timed (the arithmetic
     # per frame is the same); every thread count gets a fresh first-touch copy of the state
     ops = ops_for(1e-4)
-    for threads in sorted({max(1, hw // 4), max(1, hw // 2), hw}):
+    for threads in sorted({max(1, hw // 8), max(1, hw // 4), max(1, hw // 2)}):
         oracle.CpuSoaEffect.set_threads(threads)
         soa = oracle.CpuSoaEffect(*state)
         for _ in range(3):

@@ -103,6 +103,7 @@ struct HnbContext {
     HnbSimParams sim{};
     uint32_t frame = 0;         // simulated frames: parity double-buffers the spawn-event counters
     uint32_t list_order = HNB_LIST_ORDER_SPAWN;  // applied to programs created afterwards
+    bool skip_lists = true;     // skip the list kernels of frames the device's no-death bound covers (HNB_SKIP_LISTS=0 turns it off)
     bool alternate = true;      // walk the chunks in alternating directions from frame to frame (HNB_ALTERNATE=0 turns it off)
     uint32_t timing = 0;        // 0 = off, n = time every n-th simulated frame
     uint32_t timing_tick = 0;
@@ -157,6 +158,17 @@ struct HnbProgram {
     size_t frame_bytes = 0;
     uint32_t parity = 0;
     uint32_t frames_run = 0;    // frames this program was simulated in: the chunk walk alternates its direction with it
+    // "no particle can die before ..." (hnb_kernels.hip.h, SlotArgs): the update publishes a lower bound of the remaining life of
+    // every alive particle; while the ticks accumulated since stay below it, a frame without spawn needs no list kernels.
+    bool skip_eligible = false;             // streamable, lifetime-culled, no kill modifier: particles only die of old age
+    uint32_t* d_safe = nullptr;             // u32[2][table_cap * chunks_per_inst] device words (allocated with the tables)
+    unsigned long long* h_safe = nullptr;   // host-mapped {tag, bound bits}
+    uint32_t* d_fault = nullptr;            // set by the kernel if a particle died in a frame whose lists were skipped
+    double cum_tick[128] = {};              // sum of the AGE_TICK operands of frames 0..F, ring indexed by F & 127
+    uint32_t last_dirty = 0;                // a bound must come from this frame or later (spawn, host write, (un)freeze, unknown tick)
+    bool dirty = true;                      // something outside the frame inputs changed the particles since the last frame
+    uint32_t skipped_frames = 0;            // statistics: frames whose list kernels were skipped
+    bool skip_now = false;                  // decision for the frame being enqueued
 };
 
 struct EventChannel {
@@ -516,6 +528,7 @@ void free_tables(HnbProgram* p) {
     hipFree(p->d_counts); p->d_counts = nullptr;
     hipFree(p->d_deaths); p->d_deaths = nullptr;
     hipFree(p->d_ev_totals); p->d_ev_totals = nullptr;
+    hipFree(p->d_safe); p->d_safe = nullptr;
     p->table_cap = 0;
 }
 
@@ -566,6 +579,14 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
     p->d_meta[1] = nm[1];
     p->d_counts = ns;
     p->d_deaths = nd;
+    {   // no-death bounds per chunk and frame parity: start at +inf; growing the tables restarts them (effect creation marks the program dirty)
+        hipFree(p->d_safe);
+        p->d_safe = nullptr;
+        HIP_TRY(hipMalloc(&p->d_safe, 2 * n_counts * 4));
+        std::vector<uint32_t> inf(2 * n_counts, 0x7f800000u);
+        HIP_TRY(hipMemcpy(p->d_safe, inf.data(), inf.size() * 4, hipMemcpyHostToDevice));
+        p->dirty = true;
+    }
     const size_t fb = frame_bytes_for(p, cap);
     for (uint32_t i = 0; i < kFrameRing; ++i) {
         hipFree(p->d_frame[i]);
@@ -653,6 +674,7 @@ int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     if (const char* e = getenv("HNB_ALTERNATE")) ctx->alternate = e[0] != '0';
+    if (const char* e = getenv("HNB_SKIP_LISTS")) ctx->skip_lists = e[0] != '0';
     *out_ctx = ctx;
     return HNB_OK;
 }
@@ -684,6 +706,8 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
             if (value != HNB_LIST_ORDER_SPAWN && value != HNB_LIST_ORDER_SLOT) return fail(HNB_ERR_INVALID_ARG, "unknown list order %u", value);
             ctx->list_order = value;
             return HNB_OK;
+        case HNB_OPT_ALTERNATE: ctx->alternate = value != 0u; return HNB_OK;
+        case HNB_OPT_SKIP_LISTS: ctx->skip_lists = value != 0u; return HNB_OK;
         default: return fail(HNB_ERR_INVALID_ARG, "unknown option %u", option);
     }
 }
@@ -776,11 +800,29 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
             p->jit_log = res.log;
         }
     }
+    {
+        bool kills = false;
+        const Ins* uc = reinterpret_cast<const Ins*>(b + h.update_off);
+        for (uint32_t i = 0; i < h.update_len; ++i) {
+            const uint32_t op = uc[i].x & 0xffu;
+            kills = kills || op == HNB_OP_M_KILL_SPHERE || op == HNB_OP_M_KILL_AABB;
+        }
+        p->skip_eligible = p->update_streams && d.cull_lifetime && !kills && h.n_event_channels == 0 && !(h.flags & HNB_PROG_READS_PARENT);
+        if (hipMalloc(&p->d_fault, 4) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&p->h_safe), 8, hipHostMallocDefault) != hipSuccess) {
+            if (p->jit_module) hipModuleUnload(p->jit_module);
+            hipFree(p->d_fault); hipFree(p->d_plane_by_attr);
+            delete p;
+            return fail(HNB_ERR_OUT_OF_MEMORY, "allocating the program's bookkeeping words failed");
+        }
+        hipMemset(p->d_fault, 0, 4);
+        *p->h_safe = 0xffffffffull;  // tag = none
+    }
     const size_t code_bytes = ((size_t)h.init_len + h.update_len) * 8;
     hipError_t e = hipMalloc(&p->d_code, std::max<size_t>(code_bytes, 8));
     if (e != hipSuccess) {
         if (p->jit_module) hipModuleUnload(p->jit_module);
-        hipFree(p->d_plane_by_attr);
+        hipFree(p->d_plane_by_attr); hipFree(p->d_fault); hipHostFree(p->h_safe);
         delete p;
         return fail(HNB_ERR_OUT_OF_MEMORY, "hipMalloc(code) failed: %s", hipGetErrorString(e));
     }
@@ -806,6 +848,8 @@ int hnb_program_destroy(HnbProgram* p) {
     for (auto& blk : p->slab_blocks) hipFree(blk.base);
     hipFree(p->d_plane_by_attr);
     hipFree(p->d_code);
+    hipFree(p->d_fault);
+    if (p->h_safe) hipHostFree(p->h_safe);
     ctx->programs.erase(std::remove(ctx->programs.begin(), ctx->programs.end(), p), ctx->programs.end());
     delete p;
     return HNB_OK;
@@ -940,6 +984,7 @@ int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
         for (uint32_t c = 0; c < pe.ncomp; ++c) fx->props[pe.word_offset + c] = pe.default_bits[c];
     p->effects.push_back(fx);
     p->dev.n_inst = (uint32_t)p->effects.size();
+    p->dirty = true;
     *out_fx = fx;
     return HNB_OK;
 }
@@ -972,6 +1017,7 @@ int hnb_effect_destroy(HnbEffect* fx) {
     }
     p->effects.pop_back();
     p->dev.n_inst = (uint32_t)p->effects.size();
+    p->dirty = true;
     p->free_slabs.push_back(fx->slab);  // the block itself is released with the program
     delete fx;
     return HNB_OK;
@@ -1026,6 +1072,7 @@ int hnb_effect_set_parent(HnbEffect* child, HnbEffect* parent, uint32_t channel,
     ch.child = child;
     child->parent = parent;
     child->parent_channel = channel;
+    cp->dirty = true;
     // parents before children: dependency level per program. The program graph is acyclic (checked above), so the levels
     // settle within one pass per program; the bound is a backstop, never a hang.
     const size_t n_prog = cp->ctx->programs.size();
@@ -1075,6 +1122,7 @@ int hnb_effect_index(HnbEffect* fx, uint32_t* out_index) {
 
 int hnb_effect_set_simulated(HnbEffect* fx, int simulated) {
     if (!fx) return fail(HNB_ERR_INVALID_ARG, "fx is NULL");
+    if (fx->simulated != (simulated != 0)) fx->prog->dirty = true;  // a thawed instance ages again: older no-death bounds do not cover it
     fx->simulated = simulated != 0;
     return HNB_OK;
 }
@@ -1157,6 +1205,37 @@ int hnb_simulate(HnbContext* ctx) {
                 else uniform_run(p->uniform_code.data(), (uint32_t)p->uniform_code.size(), fx->props.data(), sim, ublocks + (size_t)i * nu, nu);
             }
         }
+        {   // can this frame lose or gain a particle? (see SlotArgs in hnb_kernels.hip.h)
+            const uint32_t F = p->frames_run;
+            bool any_spawn = false, any_parent = false, tick_known = p->skip_eligible;
+            float tick = 0.0f;
+            bool have_tick = false;
+            for (uint32_t i = 0; i < n && p->skip_eligible; ++i) {
+                const HnbEffect* fx = p->effects[i];
+                any_parent = any_parent || fx->parent != nullptr;
+                if (!fx->simulated) continue;
+                any_spawn = any_spawn || fx->spawn_count != 0u;
+                float t;
+                memcpy(&t, ublocks + (size_t)i * nu + (p->cull_dt_operand & 0xffu), 4);
+                if (!have_tick) { tick = t; have_tick = true; }
+                else if (memcmp(&t, &tick, 4) != 0) tick_known = false;
+            }
+            if (!(tick >= 0.0f)) tick_known = false;  // negative or NaN ticks: no statement about the future
+            if (any_spawn || any_parent || p->dirty || !tick_known) p->last_dirty = F;  // only a bound computed in this frame or later covers it
+            p->dirty = false;
+            p->cum_tick[F & 127u] = (F ? p->cum_tick[(F - 1u) & 127u] : 0.0) + (tick_known ? (double)tick : 0.0);
+            p->skip_now = false;
+            if (p->skip_eligible && ctx->skip_lists && !any_spawn && !any_parent && tick_known) {
+                const unsigned long long pub = *reinterpret_cast<volatile unsigned long long*>(p->h_safe);
+                const uint32_t tag = (uint32_t)pub, bits = (uint32_t)(pub >> 32);
+                float bound;
+                memcpy(&bound, &bits, 4);
+                if (tag != 0xffffffffu && tag < F && tag >= p->last_dirty && F - tag <= 64u && bits <= 0x7f800000u) {
+                    const double ticks = p->cum_tick[F & 127u] - p->cum_tick[tag & 127u];   // frames tag+1 .. F
+                    p->skip_now = ticks * (1.0 + 1e-6) < (double)bound;
+                }
+            }
+        }
         uint32_t* init_start = ublocks + (size_t)n * nu;  // packed copy of init_block_start for k_init's search
         for (uint32_t i = 0; i < n; ++i) init_start[i] = fi[i].init_block_start;
         const size_t bytes = (size_t)n * sizeof(DevFrameInst) + (size_t)n * nu * 4 + (size_t)n * 4;
@@ -1204,7 +1283,7 @@ int hnb_simulate(HnbContext* ctx) {
         cb.table_cap = p->table_cap;
         cb.parity = par;
         cb.ev_totals = p->d_ev_totals;
-        cb.xcd_remap = (n > 1 ? 1u : 0u) | (ctx->alternate && (p->frames_run & 1u) ? 2u : 0u);  // see chunk_of_workgroup
+        cb.xcd_remap = (n > 1 ? 1u : 0u) | (ctx->alternate && !(p->frames_run & 1u) ? 2u : 0u);  // see chunk_of_workgroup; the first frame walks DOWN: a burst's init wrote the planes upwards
         TimingPair tu{}, tc{};
         if (timed) { tu.a = take_event(ctx); tu.b = take_event(ctx); tc.b = take_event(ctx); hipEventRecord(tu.a, ctx->stream); }
         const uint32_t died_mark = p->slot_order ? 0u : 2u;
@@ -1216,6 +1295,10 @@ int hnb_simulate(HnbContext* ctx) {
             sa.update_code = p->dev.update_code;
             sa.died_mark = died_mark;
             sa.cull_lifetime = p->dev.cull_lifetime; sa.lmin_off = p->dev.lmin_off; sa.dt_operand = p->cull_dt_operand;
+            if (p->skip_eligible) { sa.safe_words = p->d_safe; sa.safe_host = p->h_safe; sa.safe_parity = p->frames_run & 1u; sa.publish_tag = p->frames_run - 1u; sa.safe_stride = p->table_cap * p->dev.chunks_per_inst; }
+            sa.skip_lists = p->skip_now ? 1u : 0u;
+            sa.meta_in = p->d_meta[par]; sa.meta_out = p->d_meta[par ^ 1];
+            sa.fault = p->d_fault;
             for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
                 const DevAttr& at = p->dev.attrs[a];
                 const int pi = at.reg == HNB_REG_POSITION ? 0 : at.reg == HNB_REG_VELOCITY ? 1 : at.reg == HNB_REG_AGE ? 2 : at.reg == HNB_REG_LIFETIME ? 3 : -1;
@@ -1244,14 +1327,16 @@ int hnb_simulate(HnbContext* ctx) {
         ca.alive_off[0] = p->dev.alive_off[0]; ca.alive_off[1] = p->dev.alive_off[1]; ca.dead_off = p->dev.dead_off;
         ca.alive_flag_off = p->dev.alive_flag_off;
         ca.slot_order = p->slot_order ? 1u : 0u;
-        if (p->dev.n_event_channels) {  // order this frame's spawn events (by list row) into the children's buffers
+        const bool lists = !(p->update_streams && p->skip_now);  // false: proven no spawn, no casualty; the update rotated the counters
+        if (!lists) p->skipped_frames += 1;
+        if (lists && p->dev.n_event_channels) {  // order this frame's spawn events (by list row) into the children's buffers
             k_emit_count<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb);
             k_emit_events<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb);
         }
         // lists: only the instances that lost particles have anything to do
-        if (!p->slot_order) k_list_rows<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
-        k_compact<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
-        if (p->slot_order) {  // rebuild the lists in increasing slot order (instances without a casualty or spawn return at once)
+        if (lists && !p->slot_order) k_list_rows<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
+        if (lists) k_compact<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
+        if (lists && p->slot_order) {  // rebuild the lists in increasing slot order (instances without a casualty or spawn return at once)
             k_order_count<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
             k_order_write<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
         }
@@ -1299,6 +1384,7 @@ int hnb_effect_metadata(HnbEffect* fx, HnbEffectMetadata* out) {
     out->dead_count = m.dead_count;
     out->spawned = m.spawned;
     out->fault = 0;
+    if (fx->prog->d_fault) HIP_TRY(hipMemcpy(&out->fault, fx->prog->d_fault, 4, hipMemcpyDeviceToHost));
     out->reserved = 0;
     return HNB_OK;
 }
@@ -1333,6 +1419,7 @@ int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t 
     if (src_size != bytes) return fail(HNB_ERR_INVALID_ARG, "source size %zu != plane size %zu", src_size, bytes);
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     HIP_TRY(hipMemcpy(static_cast<char*>(fx->slab) + p->dev.attrs[ai].plane_off, src, bytes, hipMemcpyHostToDevice));
+    p->dirty = true;  // ... nor does the published no-death bound
     // the chunks' lifetime bounds (lifetime culling) no longer describe the planes
     HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.lmin_off, 0, (size_t)p->dev.chunks_per_inst * 4));  // (the "completely alive" flags that follow stay valid)
     return HNB_OK;
@@ -1375,6 +1462,7 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
     if (!prog || !buf || !buf_size) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
     std::string s = prog->kernel_info;
     if (!prog->jit_log.empty()) s += "\njit log: " + prog->jit_log;
+    s += "\nlists skipped: " + std::to_string(prog->skipped_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->skip_eligible ? "" : " (not eligible)");
     snprintf(buf, buf_size, "%s", s.c_str());
     return HNB_OK;
 }

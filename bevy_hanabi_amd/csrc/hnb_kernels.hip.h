@@ -701,7 +701,29 @@ struct SlotArgs {
     uint32_t cull_lifetime;  // 1: lifetime culling (below); lmin_off = f32[chunks_per_inst] in the slab, dt_operand = operand a of the AGE_TICK
     uint32_t lmin_off, dt_operand;
     const Ins* update_code;
+    // "No particle can die before ..." (below): safe_words = u32[2][safe_stride] float bits, the frame's minimum remaining life
+    // per chunk, double-buffered by safe_parity; safe_host = host-mapped {frame tag, bound bits} the host reads without any
+    // synchronisation; publish_tag = index of the previous frame of this program. Null pointers: the program is not eligible.
+    uint32_t* safe_words;
+    unsigned long long* safe_host;
+    uint32_t safe_parity, publish_tag, safe_stride;
+    // skip_lists: the host PROVED that this frame has no spawn and no casualty (see hnb_simulate), so k_list_rows / k_compact
+    // are not launched and this kernel rotates the counters itself (vfx_indirect.wgsl:57-85), one thread per instance.
+    uint32_t skip_lists;
+    const DevMeta* meta_in;
+    DevMeta* meta_out;
+    uint32_t* fault;         // set to 1 if a particle dies in a frame whose lists were skipped (never, unless the proof is wrong)
 };
+
+// The deaths of a frame are known on the device only after its update ran, and HIP has no indirect dispatch: the list
+// kernels of a frame are launched by a host that runs several frames ahead. For the effects whose particles can only die
+// of old age (the streamable stacks without kill modifiers: every burst effect between its burst and its die-off) the
+// device tells the host how long that cannot happen: every update computes R = min over the alive particles of
+// (lifetime - age) - 1e-5 * lifetime (with the chunk's lifetime bound Lm where the lifetimes were not loaded: a lower
+// bound of the same expression), the NEXT frame's kernel publishes {frame, R} to host-mapped memory, and the host skips the
+// list kernels of a frame F as long as the ticks accumulated since the published frame stay below R (at most 64 frames
+// ahead, no spawn or host write in between). age accumulates one rounding error of 2^-24 relative per frame: 64 frames
+// stay inside the 1e-5 * lifetime margin. In such a frame this kernel is the ONLY launch of the program.
 
 // Lifetime culling. In a streamable update the LIFETIME plane is read for one thing: `is_alive = age < lifetime` right
 // after `age += dt` (src/lib.rs:1223-1258). Per 4096-slot chunk the slab keeps Lm, a lower bound of the lifetime of
@@ -721,14 +743,39 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     __shared__ uint32_t s_died[kBlock / 64];
     __shared__ float s_lmin[kBlock / 64];
     __shared__ uint32_t s_alive[kBlock / 64];
+    __shared__ float s_rem[kBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
     const uint32_t k = chunk / args.chunks_per_inst, j = chunk - k * args.chunks_per_inst;
+    if (args.safe_words && chunk == 0u) {  // publish the previous frame's bound: its kernel has completed, every chunk's word is final
+        const uint32_t* prev = args.safe_words + (size_t)(args.safe_parity ^ 1u) * args.safe_stride;
+        uint32_t m = 0x7f800000u;
+        for (uint32_t i = tid; i < gridDim.x; i += kBlock) { const uint32_t v = prev[i]; m = v < m ? v : m; }
+#pragma unroll
+        for (uint32_t off = 32; off > 0; off >>= 1) { const uint32_t y = __shfl_xor(m, off, 64); m = y < m ? y : m; }
+        if (lane == 0) s_alive[wave] = m;
+        __syncthreads();
+        if (tid == 0u) {
+            for (uint32_t w = 1; w < kBlock / 64; ++w) m = s_alive[w] < m ? s_alive[w] : m;
+            *reinterpret_cast<volatile unsigned long long*>(args.safe_host) = ((unsigned long long)m << 32) | (unsigned long long)args.publish_tag;
+        }
+        __syncthreads();
+    }
+    if (args.skip_lists && j == 0u && tid == 0u) {  // counter rotation of a frame without spawn and casualty (k_compact's zero-casualty path)
+        DevMeta o = args.meta_in[k];
+        if (!fi[k].skip) {
+            o.ref_write_index ^= 1u;
+            o.max_update = o.alive_count; o.dead_count = 0u; o.spawned = 0u; o.instance_count = o.alive_count;
+        }
+        args.meta_out[k] = o;
+        cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + k] = 0u;
+    }
     if (fi[k].skip) return;  // frozen instance
     char* base = reinterpret_cast<char*>(inst_base[k]);
     VmUniforms U;
     U.u = ublocks + (size_t)k * args.n_uregs;
     U.xf = fi[k].xf;
+    float rem_min = __builtin_inff();  // min over this lane's particles that stay alive of (lifetime - age) - 1e-5 * lifetime
     char* p_pos = base + args.plane_off[0];
     char* p_vel = base + args.plane_off[1];
     char* p_age = base + args.plane_off[2];
@@ -805,6 +852,11 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
             for (int p = 0; p < 4; ++p)
                 if (was[p] && X.alive[p]) wave_min = fminf(wave_min, X.lifetime[p]);
         }
+        if (args.safe_words) {  // X.lifetime holds the lifetimes, or Lm where they were not loaded (a lower bound of each of them)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (was[p] && X.alive[p]) rem_min = fminf(rem_min, (X.lifetime[p] - X.age[p]) - 1.0e-5f * X.lifetime[p]);
+        }
         uint32_t nf = f4;
         uint32_t died_here = 0;
 #pragma unroll
@@ -827,6 +879,11 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     if (lane == 0) s_alive[wave] = lane_alive;
     // (a negative value marks a wave that skipped a load; a real negative minimum reads the same: the bound then simply
     // stays unknown, which is always correct)
+    if (args.safe_words) {
+#pragma unroll
+        for (uint32_t off = 32; off > 0; off >>= 1) rem_min = fminf(rem_min, __shfl_xor(rem_min, off, 64));
+        if (lane == 0) s_rem[wave] = rem_min;
+    }
     if (lane == 0) { s_died[wave] = died_total; s_lmin[wave] = loaded_all ? wave_min : -1.0f; }
     __syncthreads();
     if (tid == 0) {
@@ -834,6 +891,12 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
 #pragma unroll
         for (uint32_t w = 0; w < kBlock / 64; ++w) d += s_died[w];
         if (d) atomicAdd(&cb.deaths[(size_t)cb.parity * cb.table_cap + k], d);
+        if (d && args.skip_lists) *args.fault = 1u;  // the host's proof was wrong: report it (HnbEffectMetadata::fault)
+        if (args.safe_words) {  // one word per chunk and frame parity, plain store (same-address atomics from 8 XCDs cost ~0.1 us EACH)
+            float r = fminf(fminf(s_rem[0], s_rem[1]), fminf(s_rem[2], s_rem[3]));
+            r = r > 0.0f ? r : 0.0f;  // non-negative floats order like their bit patterns; +inf: no live particle in the chunk
+            args.safe_words[(size_t)args.safe_parity * args.safe_stride + chunk] = f2u(r);
+        }
         if (chunk_full) { if (d) cfull[j] = 0u; }
         else if (d == 0u && s_alive[0] + s_alive[1] + s_alive[2] + s_alive[3] == kChunk) cfull[j] = 1u;
         if (cull) {  // every step of the chunk loaded the lifetimes: the exact minimum over the particles still alive

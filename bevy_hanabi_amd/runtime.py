@@ -143,6 +143,10 @@ class Context:
         """'spawn' (default: the serial-thread order) or 'slot' (lists kept in increasing slot order; programs created afterwards)."""
         _check(self._lib.hnb_ctx_set_option(self._h, 1, {"spawn": 0, "slot": 1}[order]))
 
+    def set_option(self, option, value):
+        """hnb_ctx_set_option: 2 = HNB_OPT_ALTERNATE, 3 = HNB_OPT_SKIP_LISTS (scheduling choices; results do not change)."""
+        _check(self._lib.hnb_ctx_set_option(self._h, int(option), int(value)))
+
     def create_program(self, blob: bytes):
         return Program(self, blob)
 

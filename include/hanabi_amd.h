@@ -243,7 +243,7 @@ typedef struct HnbEffectMetadata {
     uint32_t dispatch_x;           /* ceil(alive_count / 64): indirect args of the next update */
     uint32_t dead_count;           /* particles killed by the last update */
     uint32_t spawned;              /* particles spawned by the last init */
-    uint32_t fault;                /* reserved (0): the kernels have no device-side waits */
+    uint32_t fault;                /* 0; 1 = a particle died in a frame whose list kernels the host had proven unnecessary and skipped (a bug) */
     uint32_t reserved;
 } HnbEffectMetadata;
 
@@ -273,6 +273,13 @@ int hnb_ctx_synchronize(HnbContext* ctx);
 #define HNB_OPT_LIST_ORDER 1u
 #define HNB_LIST_ORDER_SPAWN 0u
 #define HNB_LIST_ORDER_SLOT 1u
+/* HNB_OPT_ALTERNATE (default 1; environment HNB_ALTERNATE): the update walks an effect's chunks in alternating directions from
+ *   frame to frame, so that each frame starts on what the previous one wrote last and finds it in the 256 MiB Infinity Cache.
+ * HNB_OPT_SKIP_LISTS (default 1; environment HNB_SKIP_LISTS): frames in which provably no particle can die or spawn (the update
+ *   kernel publishes a lower bound of every particle's remaining life) do not launch the list kernels.
+ * Both are pure scheduling choices: results are identical with either value. They apply from the next hnb_simulate on. */
+#define HNB_OPT_ALTERNATE 2u
+#define HNB_OPT_SKIP_LISTS 3u
 int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value);
 
 /* Replaces EffectShaderSources::generate + pipeline specialisation (src/lib.rs:805-1336). */

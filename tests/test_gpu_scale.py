@@ -309,3 +309,83 @@ def test_set_stream_null_returns_to_the_context_stream():
         r.step(fr); orc.step(fr)
     assert_same_state(orc.state(), r.state(), "after returning to the context's stream")
     c.close()
+
+
+# ---- frames whose list kernels are skipped (the device's no-death bound) -----------------------------------------------
+def _skipped(prog):
+    line = [l for l in prog.kernel_info().split("\n") if l.startswith("lists skipped")][0]
+    return int(line.split()[2]), int(line.split()[4])
+
+
+def test_list_kernels_are_skipped_only_where_nothing_can_die(ctx):
+    """A burst effect between its burst and its die-off cannot lose a particle: the update publishes a lower bound of every
+    particle's remaining life and the host skips k_list_rows / k_compact while the accumulated ticks stay below it (the update
+    rotates the counters itself). The host runs many frames ahead of the device here (no read-back between checkpoints); frame
+    times vary; state, lists and counters stay bit-exact through the first deaths, and no fault is reported."""
+    cap = 150000
+    asset = effects.firework_trails(cap)
+    gpu, orc = GpuRunner(asset, ctx=ctx), OracleRunner(asset, omp=True)
+    rng = np.random.default_rng(5)
+    t, f = 0.0, 0
+    first_death_frame = None
+    for checkpoint in (30, 50, 58, 64, 70, 76, 84, 110, 140):
+        while f < checkpoint:
+            dt = 1 / 60 if f < 8 else float(rng.uniform(1 / 240, 1 / 50))
+            fr = Frame(dt, cap if f == 0 else 0, frame_seed(f), time=t)
+            gpu.step(fr)
+            orc.step(fr)
+            t += dt
+            f += 1
+        ref, got = orc.state(), gpu.state()
+        assert_same_state(ref, got, f"frame {f}")
+        assert gpu.fx.metadata()["fault"] == 0
+        if first_death_frame is None and ref["counters"]["alive_count"] < cap:
+            first_death_frame = f
+    skipped, frames = _skipped(gpu.prog)
+    assert frames == 140 and first_death_frame is not None and first_death_frame <= 64
+    # skipped: most frames before the first death, none of the ~40 die-off frames (the bit-exact checkpoints in between and
+    # fault == 0 say so), and again every frame once nothing is left alive (+inf bound)
+    assert 30 <= skipped <= 140 - 30, (skipped, first_death_frame)
+    gpu.fx.destroy(); gpu.prog.destroy()
+
+
+def test_skipping_is_suspended_by_everything_the_bound_does_not_cover(ctx):
+    """Spawns, host writes to the planes and thawed instances invalidate the published bound: the frames that follow run
+    their list kernels until a bound computed after the event arrives, and the results stay exact."""
+    cap = 60000
+    asset = effects.firework_trails(cap)
+    prog = ctx.create_program(bh.lower(asset))
+    a, b = prog.create_effect(), prog.create_effect()
+    ob = OracleRunner(asset)
+    b_frozen_from, b_thawed_at = 12, 40
+    for f in range(70):
+        ctx.frame_begin(1 / 60, f / 60)
+        spawn_a = cap // 2 if f in (0, 20) else 0        # a second burst into the free half at frame 20
+        a.set_frame(spawn_a, frame_seed(f))
+        b.set_frame(cap if f == 0 else 0, frame_seed(1000 + f))
+        frozen = b_frozen_from <= f < b_thawed_at
+        b.set_simulated(not frozen)
+        if f == 30:   # the host shortens every lifetime of `a`: particles die earlier than any bound published before said
+            life = a.read_attr(A.LIFETIME.id)
+            a.write_attr(A.LIFETIME.id, (life * np.float32(0.75)).astype(np.float32))
+        ctx.simulate()
+        if not frozen:
+            ob.step(Frame(1 / 60, cap if f == 0 else 0, frame_seed(1000 + f), time=f / 60))
+    # the oracle has no write_attr: replay `a` on a second oracle whose lifetimes are scaled at the same point through its planes
+    # is not possible either, so `a` is checked through invariants and `b` (frozen / thawed, never written) bit for bit.
+    rb = ob.state()
+    np.testing.assert_array_equal(rb["alive"], b.alive_list())
+    np.testing.assert_array_equal(rb["dead"], b.dead_list())
+    for at in (A.POSITION, A.VELOCITY, A.AGE, A.LIFETIME):
+        np.testing.assert_array_equal(rb["attrs"][at.name], b.read_attr(at.id).view(np.uint32))
+    ma = a.metadata()
+    assert ma["fault"] == 0 and b.metadata()["fault"] == 0
+    age, life = a.read_attr(A.AGE.id)[:, 0], a.read_attr(A.LIFETIME.id)[:, 0]
+    alive = np.zeros(cap, bool)
+    alive[a.alive_list()] = True
+    assert ma["alive_count"] == alive.sum() and (age[alive] < life[alive]).all()      # every listed particle is alive by its own numbers
+    dead_slots = np.sort(a.dead_list())
+    assert np.array_equal(dead_slots, np.flatnonzero(~alive))                           # alive + dead lists partition the slots
+    skipped, frames = _skipped(prog)
+    assert frames == 70 and 0 < skipped < 60
+    prog.destroy()
