@@ -169,6 +169,17 @@ struct HnbProgram {
     bool dirty = true;                      // something outside the frame inputs changed the particles since the last frame
     uint32_t skipped_frames = 0;            // statistics: frames whose list kernels were skipped
     bool skip_now = false;                  // decision for the frame being enqueued
+    // Ribbon sort: can the host prove that the head of the list (everything but this frame's spawns) is still sorted? Then the
+    // radix range is at most the frame's spawns, which the host can bound. Static part (program creation): the update only
+    // advances AGE through its AGE_TICK and never stores RIBBON_ID, the init sets AGE from a uniform value or not at all.
+    bool sort_provable = false;
+    uint32_t sort_age_init_operand = 0;     // decoded U operand of the init stream's AGE assignment (valid if sort_age_init_set)
+    bool sort_age_init_set = false;
+    uint32_t sort_tick_operand = 0;         // decoded U operand of the update's AGE_TICK
+    bool sort_dirty = true;                 // a host write (or nothing yet) since the last sort: the whole list is the range
+    uint32_t sort_parity = 0;               // frames in which the sort ran (its state double buffer)
+    uint32_t frame_max_spawn = 0;           // largest spawn request of an instance in the frame being enqueued
+    bool frame_sort_values_ok = false;      // this frame's init age and tick are >= +0 for every instance
 };
 
 struct EventChannel {
@@ -800,6 +811,32 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
             p->jit_log = res.log;
         }
     }
+    if (p->has_ribbons && p->update_streams) {  // ribbon sort: static part of "the head stays sorted" (see HnbProgram::sort_provable)
+        bool ok = true;
+        uint32_t ticks = 0;
+        const Ins* uc = reinterpret_cast<const Ins*>(b + h.update_off);
+        for (uint32_t i = 0; i < h.update_len && ok; ++i) {
+            const uint32_t op = uc[i].x & 0xffu, dst = (uc[i].x >> 8) & 0xffu;
+            if (op == HNB_OP_M_AGE_TICK) { ticks += 1; p->sort_tick_operand = HNB_OPERAND_DECODE((uc[i].x >> 16) & 0xffu, uc[i].y >> 13); ok = (p->sort_tick_operand & HNB_OPERAND_DECODED_U) != 0; }
+            if (op == HNB_OP_M_PIN_SET && dst == HNB_REG_AGE) ok = false;
+        }
+        ok = ok && ticks == 1;
+        for (uint32_t a = 0; a < h.n_attrs; ++a)   // (a streamable update touches no non-pinned attribute, RIBBON_ID included)
+            if (p->attrs[a].attr == HNB_ATTR_RIBBON_ID && (p->attrs[a].update_flags & HNB_ATTR_UPD_STORE)) ok = false;
+        const Ins* ic = reinterpret_cast<const Ins*>(b + h.init_off);
+        for (uint32_t i = 0; i < h.init_len && ok; ++i) {
+            const uint32_t op = ic[i].x & 0xffu, dst = (ic[i].x >> 8) & 0xffu, wd = ((ic[i].y >> 8) & 3u) + 1u;
+            if (op == HNB_OP_M_PIN_SET && dst == HNB_REG_AGE) {
+                p->sort_age_init_operand = HNB_OPERAND_DECODE((ic[i].x >> 16) & 0xffu, ic[i].y >> 13);
+                p->sort_age_init_set = true;
+                ok = (p->sort_age_init_operand & HNB_OPERAND_DECODED_U) != 0;   // a per-particle age could be negative: key order != age order
+            } else if (op != HNB_OP_STA && op != HNB_OP_ALIVE_SET && op != HNB_OP_ALIVE_AND && op != HNB_OP_KILL_IF && !(op >= HNB_OP_M_AGE_TICK) &&
+                       dst <= HNB_REG_AGE && dst + wd > HNB_REG_AGE) {
+                ok = false;  // some other instruction writes the AGE register
+            }
+        }
+        p->sort_provable = ok;
+    }
     {
         bool kills = false;
         const Ins* uc = reinterpret_cast<const Ins*>(b + h.update_off);
@@ -1224,6 +1261,22 @@ int hnb_simulate(HnbContext* ctx) {
             if (any_spawn || any_parent || p->dirty || !tick_known) p->last_dirty = F;  // only a bound computed in this frame or later covers it
             p->dirty = false;
             p->cum_tick[F & 127u] = (F ? p->cum_tick[(F - 1u) & 127u] : 0.0) + (tick_known ? (double)tick : 0.0);
+            if (p->has_ribbons) {
+                p->frame_max_spawn = 0;
+                bool ok = p->sort_provable;
+                for (uint32_t i = 0; i < n; ++i) {
+                    const HnbEffect* fx = p->effects[i];
+                    if (!fx->simulated) continue;
+                    const uint32_t req = fx->parent ? fx->parent->channels[fx->parent_channel].capacity : fx->spawn_count;
+                    p->frame_max_spawn = std::max(p->frame_max_spawn, std::min(req, p->dev.capacity));
+                    if (!ok) continue;
+                    const uint32_t* ub = ublocks + (size_t)i * nu;
+                    const uint32_t tick_bits = ub[p->sort_tick_operand & 0xffu];
+                    const uint32_t age_bits = p->sort_age_init_set ? ub[p->sort_age_init_operand & 0xffu] : 0u;
+                    ok = tick_bits <= 0x7f800000u && age_bits <= 0x7f800000u;   // >= +0 and not NaN: ages stay non-negative, key order == age order
+                }
+                p->frame_sort_values_ok = ok;
+            }
             p->skip_now = false;
             if (p->skip_eligible && ctx->skip_lists && !any_spawn && !any_parent && tick_known) {
                 const unsigned long long pub = *reinterpret_cast<volatile unsigned long long*>(p->h_safe);
@@ -1342,17 +1395,31 @@ int hnb_simulate(HnbContext* ctx) {
         }
         if (timed) { tc.a = tu.b; hipEventRecord(tc.b, ctx->stream); ctx->t_compact.push_back(tc); }
         if (p->has_ribbons) {  // ribbon sort of the compacted list by (RIBBON_ID, AGE) (src/render/mod.rs:7372-7612)
-            SortArgs so = p->sort;
-            so.parity = ctx->frame & 1u;
-            const DevMeta* mo = p->d_meta[par ^ 1];
-            const uint32_t tiles = n * so.chunks_per_inst;
-            k_sort_fill<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
-            k_sort_check<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
-            for (uint32_t pass = 0; pass < 8; ++pass) {
-                k_sort_hist<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
-                k_sort_scatter<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
+            // The list is last frame's sorted list minus the casualties (stable compaction), every age advanced by the same
+            // non-negative tick (monotone under rounding; non-negative floats order like their bits), plus this frame's spawns
+            // at the end. Where the host can prove the premises (HnbProgram::sort_provable + this frame's values + no host write)
+            // the radix range is at most the largest spawn request: nothing to do without spawns, one single-workgroup launch
+            // for a small range. Otherwise the device decides (k_sort_check) and all launches are issued.
+            const bool proven = p->sort_provable && p->frame_sort_values_ok && !p->sort_dirty && ctx->skip_lists;
+            if (!(proven && p->frame_max_spawn == 0u)) {
+                SortArgs so = p->sort;
+                so.parity = p->sort_parity & 1u;
+                p->sort_parity += 1;
+                const DevMeta* mo = p->d_meta[par ^ 1];
+                const uint32_t tiles = n * so.chunks_per_inst;
+                k_sort_fill<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+                k_sort_check<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+                if (proven && p->frame_max_spawn <= kSortSmallMax) {
+                    k_sort_small<<<n, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+                } else {
+                    for (uint32_t pass = 0; pass < 8; ++pass) {
+                        k_sort_hist<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
+                        k_sort_scatter<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
+                    }
+                }
+                k_sort_merge<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+                p->sort_dirty = false;
             }
-            k_sort_merge<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(p->kernels_done[p->ring % kFrameRing], ctx->stream));
@@ -1420,6 +1487,7 @@ int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t 
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     HIP_TRY(hipMemcpy(static_cast<char*>(fx->slab) + p->dev.attrs[ai].plane_off, src, bytes, hipMemcpyHostToDevice));
     p->dirty = true;  // ... nor does the published no-death bound
+    p->sort_dirty = true;  // ... and a ribbon list may no longer be in key order
     // the chunks' lifetime bounds (lifetime culling) no longer describe the planes
     HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.lmin_off, 0, (size_t)p->dev.chunks_per_inst * 4));  // (the "completely alive" flags that follow stay valid)
     return HNB_OK;

@@ -29,6 +29,16 @@
 
 namespace hnb {
 
+// A pointer that was loaded from a table (slab bases, event buffers) is a generic ("flat") pointer to the compiler: every
+// access through it becomes a flat_load / flat_store, which the hardware resolves against the LDS and scratch apertures
+// first. The slabs are global memory: saying so through the address space turns them into global_load / global_store
+// with an SGPR base and a 32-bit VGPR offset.
+template <class T>
+__device__ __forceinline__ T* global_ptr(uint64_t addr) {
+    typedef __attribute__((address_space(1))) T global_t;
+    return (T*)(global_t*)addr;
+}
+
 struct u2_t { uint32_t x, y; };
 struct u3_t { uint32_t x, y, z; };
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
@@ -102,7 +112,7 @@ __device__ __forceinline__ Out4 vfile_load_attr(uint32_t ncomp, const char* plan
 __device__ __forceinline__ uint32_t requested_spawn(const DevFrameInst& f) {
     if (f.skip) return 0u;
     if (f.ev_in == 0ull) return f.spawn_count;
-    const DevEventBuffer* ev = reinterpret_cast<const DevEventBuffer*>(f.ev_in);
+    const DevEventBuffer* ev = global_ptr<const DevEventBuffer>(f.ev_in);
     const uint32_t n = ev->count[f.ev_parity ^ 1u];
     return n < ev->capacity ? n : ev->capacity;
 }
@@ -191,7 +201,7 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
     const uint32_t spawn = requested_spawn(fi[k]);
     const uint32_t n_spawn = spawn < max_spawn ? spawn : max_spawn;
 
-    char* base = reinterpret_cast<char*>(inst_base[k]);
+    char* base = global_ptr<char>(inst_base[k]);
     const uint32_t* dead = reinterpret_cast<const uint32_t*>(base + prog.dead_off);
     uint32_t* alive = reinterpret_cast<uint32_t*>(base + prog.alive_off[meta_in[k].write_index]);  // the column holding the list
     VmUniforms U;
@@ -211,9 +221,9 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
         io.slab = base; io.attrs = prog.attrs; io.slot = slot;
         if (fi[k].ev_in != 0ull) {  // GPU-spawned: fetch the parent particle that emitted event i (vfx_init.wgsl:166-171)
             S.gpu_spawned = true;
-            io.parent_slab = reinterpret_cast<const char*>(fi[k].parent_base);
-            io.parent_planes = reinterpret_cast<const uint32_t*>(fi[k].parent_planes);
-            io.parent_slot = reinterpret_cast<const DevEventBuffer*>(fi[k].ev_in)->data[i];
+            io.parent_slab = global_ptr<const char>(fi[k].parent_base);
+            io.parent_planes = global_ptr<const uint32_t>(fi[k].parent_planes);
+            io.parent_slot = global_ptr<const DevEventBuffer>(fi[k].ev_in)->data[i];
         }
         CODE::zero_unassigned(prog, io);
         CODE::run_init(prog, S, U, io);
@@ -377,7 +387,7 @@ __device__ __forceinline__ bool chunk_setup(ChunkCtx& c, uint32_t chunk, const A
     c.n_spawn = spawn < max_spawn ? spawn : max_spawn;
     c.n = fi[c.k].skip ? 0u : c.m.alive_count + c.n_spawn;  // a frozen instance has nothing to update
     c.start = c.j * kChunk;
-    c.base = reinterpret_cast<char*>(inst_base[c.k]);
+    c.base = global_ptr<char>(inst_base[c.k]);
     return c.start < c.n;
 }
 
@@ -624,7 +634,7 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
     const uint32_t rows = has_rows ? ((c.n - c.start) < kChunk ? (c.n - c.start) : kChunk) : 0u;
     constexpr uint32_t kPer = kChunk / kBlock;  // rows per thread
     for (uint32_t ch = 0; ch < prog.n_event_channels; ++ch) {
-        DevEventBuffer* ev = reinterpret_cast<DevEventBuffer*>(fi[c.k].ev_out[ch]);
+        DevEventBuffer* ev = global_ptr<DevEventBuffer>(fi[c.k].ev_out[ch]);
         if (!ev) continue;  // nobody listens on this channel
         const uint32_t* tot = cb.ev_totals + (size_t)c.k * prog.chunks_per_inst * HNB_MAX_EVENT_CHANNELS + ch;
         uint32_t part = 0;
@@ -771,7 +781,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
         cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + k] = 0u;
     }
     if (fi[k].skip) return;  // frozen instance
-    char* base = reinterpret_cast<char*>(inst_base[k]);
+    char* base = global_ptr<char>(inst_base[k]);
     VmUniforms U;
     U.u = ublocks + (size_t)k * args.n_uregs;
     U.xf = fi[k].xf;
@@ -919,7 +929,7 @@ k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
     const uint32_t k = chunk / prog.chunks_per_inst, j = chunk - k * prog.chunks_per_inst;
     if (fi[k].skip) return;
-    char* base = reinterpret_cast<char*>(inst_base[k]);
+    char* base = global_ptr<char>(inst_base[k]);
     uint8_t* flags = reinterpret_cast<uint8_t*>(base + prog.alive_flag_off);
     const uint32_t seed_k = fi[k].seed, slot_base = fi[k].slot_base;
     VmUniforms U;

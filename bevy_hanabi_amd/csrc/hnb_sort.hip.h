@@ -84,7 +84,7 @@ __device__ __forceinline__ SortPass sort_pass_info(uint64_t varying, uint32_t pa
 __device__ __forceinline__ void sort_setup(uint32_t chunk, const SortArgs& a, const uint64_t* inst_base, uint32_t& k, uint32_t& j, char*& base) {
     k = chunk / a.chunks_per_inst;
     j = chunk - k * a.chunks_per_inst;
-    base = reinterpret_cast<char*>(inst_base[k]);
+    base = global_ptr<char>(inst_base[k]);
 }
 
 __device__ __forceinline__ uint64_t wave_or(uint64_t v) {
@@ -264,6 +264,83 @@ k_sort_scatter(const SortArgs a, const uint64_t* __restrict__ inst_base, const D
             s_base[tid] += add;
         }
         __syncthreads();
+    }
+}
+
+// The whole radix sort of one instance's range by ONE workgroup: every pass whose digit varies, histogram -> digit bases ->
+// stable scatter over the range's keys in order, the passes separated by workgroup barriers only. The usual ribbon frame
+// sorts this frame's spawns (tens of thousands of keys, most often all equal: zero passes) - sixteen launches that each
+// find nothing to do cost 4 us apiece; this is one. hnb_simulate uses it when it can bound the range on the host (see there);
+// it is correct for any range, just slow for a large one.
+constexpr uint32_t kSortSmallMax = 65536;
+__global__ void __launch_bounds__(kBlock)
+k_sort_small(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta) {
+    __shared__ uint32_t s_base[256];
+    __shared__ uint32_t s_cnt[kBlock / 64][256];
+    const uint32_t k = blockIdx.x;
+    char* base = global_ptr<char>(inst_base[k]);
+    const SortRange rg = sort_range(base, a, meta[k]);
+    const uint32_t n = rg.n - rg.lo;
+    if (n == 0u || rg.varying == 0ull) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t src = 0;
+    for (uint32_t pass = 0; pass < 8; ++pass) {
+        if (((rg.varying >> (8u * pass)) & 0xffull) == 0ull) continue;
+        const uint64_t* skey = reinterpret_cast<const uint64_t*>(base + a.key_off[src]) + rg.lo;
+        const uint32_t* sval = reinterpret_cast<const uint32_t*>(base + a.val_off[src]) + rg.lo;
+        uint64_t* dkey = reinterpret_cast<uint64_t*>(base + a.key_off[src ^ 1u]) + rg.lo;
+        uint32_t* dval = reinterpret_cast<uint32_t*>(base + a.val_off[src ^ 1u]) + rg.lo;
+        s_base[tid] = 0u;
+#pragma unroll
+        for (uint32_t w = 0; w < kBlock / 64; ++w) s_cnt[w][tid] = 0u;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += kBlock) atomicAdd(&s_base[(uint32_t)(skey[i] >> (8u * pass)) & 0xffu], 1u);
+        __syncthreads();
+        {   // exclusive scan of the 256 digit counts (thread d owns digit d)
+            const uint32_t total = s_base[tid];
+            uint32_t incl = total;
+#pragma unroll
+            for (uint32_t off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
+            __syncthreads();
+            if (lane == 63) s_base[wave] = incl;  // scratch: the wave totals
+            __syncthreads();
+            uint32_t digit_base = incl - total;
+            for (uint32_t w = 0; w < wave; ++w) digit_base += s_base[w];
+            __syncthreads();
+            s_base[tid] = digit_base;
+        }
+        __syncthreads();
+        for (uint32_t rbase = 0; rbase < n; rbase += kBlock) {   // rounds of 256 keys in order: stable ranks by wave match (as k_sort_scatter)
+            const uint32_t i = rbase + tid;
+            const bool valid = i < n;
+            const uint64_t key = valid ? skey[i] : 0ull;
+            const uint32_t val = valid ? sval[i] : 0u;
+            const uint32_t digit = (uint32_t)(key >> (8u * pass)) & 0xffu;
+            uint64_t same = __ballot(valid);
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b) {
+                const bool bit = (digit >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                same &= bit ? bal : ~bal;
+            }
+            const uint32_t rank = (uint32_t)__popcll(same & below);
+            if (valid && rank == 0u) s_cnt[wave][digit] = (uint32_t)__popcll(same);
+            __syncthreads();
+            if (valid) {
+                uint32_t off = s_base[digit];
+                for (uint32_t w = 0; w < wave; ++w) off += s_cnt[w][digit];
+                dkey[off + rank] = key;
+                dval[off + rank] = val;
+            }
+            __syncthreads();
+            uint32_t add = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kBlock / 64; ++w) { add += s_cnt[w][tid]; s_cnt[w][tid] = 0u; }
+            s_base[tid] += add;
+            __syncthreads();
+        }
+        src ^= 1u;   // (== sort_pass_info(varying, pass + 1).src: k_sort_merge finds the result where the multi-launch path leaves it)
     }
 }
 
