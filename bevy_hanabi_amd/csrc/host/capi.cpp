@@ -32,6 +32,8 @@ int guarded(F f) {
         return fail(HNB_ERR_EXPR, e.what());
     } catch (const ShaderGenerateError& e) {
         return fail(HNB_ERR_BAD_PROGRAM, e.what());
+    } catch (const RonError& e) {
+        return fail(HNB_ERR_BAD_PROGRAM, e.what());
     } catch (const PanicError& e) {
         return fail(HNB_ERR_INVALID_ARG, e.what());
     } catch (const SpawnerSettingsError& e) {
@@ -206,6 +208,12 @@ int hnb_spawner_set_active(HnbSpawner* spawner, int active) {
     return HNB_OK;
 }
 
+int hnb_next_prng_seed(uint32_t prng_seed, uint32_t* out_next) {
+    REQUIRE(out_next, "out_next is NULL");
+    *out_next = next_prng_seed(prng_seed);
+    return HNB_OK;
+}
+
 // ---- EffectAsset ------------------------------------------------------------------------------------------------------
 int hnb_asset_create(uint32_t capacity, const HnbSpawnerSettings* spawner, const HnbModule* module, HnbAsset** out_asset) {
     REQUIRE(spawner && module && out_asset, "NULL argument");
@@ -304,6 +312,24 @@ int hnb_asset_particle_layout(const HnbAsset* asset, uint32_t* out_attrs, uint32
 int hnb_lower(const HnbAsset* asset, void** out_blob, size_t* out_size) {
     REQUIRE(asset && out_blob && out_size, "NULL argument");
     return guarded([&] { return copy_out(lower(asset->a), out_blob, out_size); });
+}
+
+int hnb_asset_to_ron(const HnbAsset* asset, char** out_text, size_t* out_size) {
+    REQUIRE(asset && out_text && out_size, "NULL argument");
+    return guarded([&] {
+        const std::string t = to_ron(asset->a);
+        char* p = static_cast<char*>(std::malloc(t.size() + 1));
+        if (!p) return fail(HNB_ERR_OUT_OF_MEMORY, "out of memory");
+        std::memcpy(p, t.c_str(), t.size() + 1);
+        *out_text = p;
+        *out_size = t.size();
+        return (int)HNB_OK;
+    });
+}
+
+int hnb_asset_from_ron(const char* text, size_t size, HnbAsset** out_asset) {
+    REQUIRE(text && out_asset, "NULL argument");
+    return guarded([&] { *out_asset = new HnbAsset{from_ron(std::string(text, size))}; return HNB_OK; });
 }
 
 int hnb_asset_serialize(const HnbAsset* asset, void** out_blob, size_t* out_size) {

@@ -273,6 +273,44 @@ uint32_t Pcg32::next_u32() {
     return (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
 }
 
+// ---- per-frame seed evolution (src/lib.rs:1813-1820; rand's StdRng, see hanabi.hpp) -----------------------------------
+void chacha_block(const uint32_t key[8], uint64_t counter, uint64_t stream, int rounds, uint32_t out[16]) {
+    uint32_t init[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,   // "expand 32-byte k"
+                         key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                         (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    uint32_t s[16];
+    std::memcpy(s, init, sizeof s);
+    auto rotl = [](uint32_t x, int n) { return (x << n) | (x >> (32 - n)); };
+    auto qr = [&](int a, int b, int c, int d) {
+        s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 16);
+        s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 12);
+        s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 8);
+        s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 7);
+    };
+    for (int r = 0; r < rounds / 2; ++r) {
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);   // column round
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);   // diagonal round
+    }
+    for (int i = 0; i < 16; ++i) out[i] = s[i] + init[i];
+}
+void seed_from_u64(uint64_t state, uint8_t out_seed[32]) {
+    for (int chunk = 0; chunk < 8; ++chunk) {   // PCG32 (XSH-RR), state advanced BEFORE each output
+        state = state * 6364136223846793005ull + 11634580027462260723ull;
+        const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+        const uint32_t rot = (uint32_t)(state >> 59);
+        const uint32_t x = (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
+        for (int b = 0; b < 4; ++b) out_seed[chunk * 4 + b] = (uint8_t)(x >> (8 * b));   // to_le_bytes
+    }
+}
+uint32_t next_prng_seed(uint32_t prng_seed) {
+    uint8_t seed[32];
+    seed_from_u64((uint64_t)prng_seed, seed);
+    uint32_t key[8], out[16];
+    for (int i = 0; i < 8; ++i) key[i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) | ((uint32_t)seed[4 * i + 2] << 16) | ((uint32_t)seed[4 * i + 3] << 24);
+    chacha_block(key, 0, 0, 12, out);
+    return out[0];
+}
+
 // CpuValue::sample (spawn.rs:105-110). `Uniform::new_inclusive(a, b).sample(rng)` is the
 // `rand` crate's UniformFloat: value in [0,1) from the top 23 bits, times a scale adjusted
 // so the maximum never exceeds `b`. Third-party algorithm, restated; parity unpinned.

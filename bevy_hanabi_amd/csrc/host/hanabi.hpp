@@ -35,6 +35,7 @@ struct ExprError : std::runtime_error {
     ExprError(Kind k, const std::string& msg) : std::runtime_error(msg), kind(k) {}
 };
 struct ShaderGenerateError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct RonError : std::runtime_error { using std::runtime_error::runtime_error; };   // ron::Error of EffectAsset::deserialize
 struct SpawnerSettingsError : std::runtime_error {
     enum Kind { InvalidPeriod, InfinitePeriod };
     Kind kind;
@@ -437,6 +438,17 @@ struct Pcg32 {
     uint32_t next_u32();
 };
 
+// Per-frame PRNG seed evolution of the reference (`compile_effects`, src/lib.rs:1813-1820): every frame an effect was not
+// recompiled, `prng_seed = StdRng::seed_from_u64(prng_seed as u64).random::<u32>()`. Third-party code (rand 0.10, absent from
+// /root/reference): restated from the published algorithms of the rand family - `SeedableRng::seed_from_u64` expands the u64
+// with PCG32 (XSH-RR, multiplier 6364136223846793005, increment 11634580027462260723) into the 32-byte seed, `StdRng` is
+// ChaCha with 12 rounds, key = seed, 64-bit block counter 0, stream 0, and `random::<u32>()` is the first output word.
+// Pinned on the ChaCha vectors of RFC 7539 and eSTREAM and on rand's own `StdRng` value-stability test (tests/test_seed.py);
+// whether rand 0.10 changed `StdRng` cannot be checked here, so the reference-exact sequence is "parity unpinned".
+void chacha_block(const uint32_t key[8], uint64_t counter, uint64_t stream, int rounds, uint32_t out[16]);
+void seed_from_u64(uint64_t state, uint8_t out_seed[32]);
+uint32_t next_prng_seed(uint32_t prng_seed);
+
 struct CpuValue {
     bool is_uniform = false;
     float a = 0.0f, b = 0.0f;
@@ -586,6 +598,9 @@ float round_literal_f32(float x);
 std::vector<uint8_t> lower(const EffectAsset& asset);
 // Human-readable listing of a program blob (debugging / tests).
 std::string disassemble(const std::vector<uint8_t>& blob);
+// The reference's on-disk format (RON; EffectAsset::serialize / deserialize, src/asset.rs:674-716); see ron.cpp.
+std::string to_ron(const EffectAsset& asset);
+EffectAsset from_ron(const std::string& text);
 // Flat authoring-level description of the asset (expressions, modifiers, settings): the
 // input format of the CPU oracle under oracle/ and a first step towards an on-disk format.
 std::vector<uint8_t> serialize_asset(const EffectAsset& asset);

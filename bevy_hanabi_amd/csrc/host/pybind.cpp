@@ -389,5 +389,17 @@ PYBIND11_MODULE(_hanabi_host, m) {
     m.def("round_literal_f32", &round_literal_f32);
     m.def("lower", [](const EffectAsset& a) { auto b = lower(a); return py::bytes(reinterpret_cast<const char*>(b.data()), b.size()); });
     m.def("disassemble", [](py::bytes b) { std::string s = b; return disassemble(std::vector<uint8_t>(s.begin(), s.end())); });
+    m.def("next_prng_seed", &next_prng_seed, "StdRng::seed_from_u64(seed).random::<u32>() (src/lib.rs:1813-1820)");
+    m.def("seed_from_u64", [](uint64_t state) { uint8_t seed[32]; seed_from_u64(state, seed); return py::bytes(reinterpret_cast<const char*>(seed), 32); });
+    m.def("chacha_block", [](py::bytes key, uint64_t counter, uint64_t stream, int rounds) {
+        const std::string k = key;
+        if (k.size() != 32) throw std::invalid_argument("key must be 32 bytes");
+        uint32_t kw[8], out[16];
+        std::memcpy(kw, k.data(), 32);
+        chacha_block(kw, counter, stream, rounds, out);
+        return py::bytes(reinterpret_cast<const char*>(out), 64);
+    });
+    m.def("to_ron", &to_ron, "EffectAsset::serialize (src/asset.rs:674-681): the reference's RON text format");
+    m.def("from_ron", &from_ron, "EffectAsset::deserialize (src/asset.rs:707-716)");
     m.def("serialize_asset", [](const EffectAsset& a) { auto b = serialize_asset(a); return py::bytes(reinterpret_cast<const char*>(b.data()), b.size()); });
 }

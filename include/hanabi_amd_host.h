@@ -102,6 +102,11 @@ int hnb_spawner_tick(HnbSpawner* spawner, float dt, uint32_t* out_spawn_count);
 int hnb_spawner_reset(HnbSpawner* spawner);
 int hnb_spawner_set_active(HnbSpawner* spawner, int active);
 
+/* Per-frame seed evolution of `compile_effects` (src/lib.rs:1813-1820): the seed handed to hnb_effect_set_frame in frame N+1 is
+ * StdRng::seed_from_u64(seed_N as u64).random::<u32>() unless the effect was recompiled. rand's published algorithms (PCG32 seed
+ * expansion, ChaCha12), restated and pinned on their known-answer vectors; see hanabi.hpp. */
+int hnb_next_prng_seed(uint32_t prng_seed, uint32_t* out_next);
+
 /* ---- EffectAsset (src/asset.rs:272-646) -------------------------------------------------------------------------- */
 typedef enum HnbSimulationSpace { HNB_SPACE_GLOBAL = 0, HNB_SPACE_LOCAL = 1 } HnbSimulationSpace;
 typedef enum HnbSimulationCondition { HNB_SIM_WHEN_VISIBLE = 0, HNB_SIM_ALWAYS = 1 } HnbSimulationCondition;
@@ -164,6 +169,12 @@ int hnb_asset_add_modifier(HnbAsset* asset, uint32_t context, const HnbModifierD
 int hnb_asset_particle_layout(const HnbAsset* asset, uint32_t* out_attrs, uint32_t cap, uint32_t* out_count);
 /* EffectShaderSources::generate counterpart: the HnbProgram blob for hnb_program_create() / hnb_program_validate(). */
 int hnb_lower(const HnbAsset* asset, void** out_blob, size_t* out_size);
+/* The reference's on-disk asset format: RON text as EffectAsset::serialize writes and ::deserialize reads it
+ * (src/asset.rs:674-716; `.effect` files, loader extension asset.rs:1128-1130). hnb_asset_to_ron returns a NUL-terminated
+ * buffer (hnb_host_free); hnb_asset_from_ron fails with HNB_ERR_BAD_PROGRAM and the parser's message (line / column or the
+ * offending field) on malformed text, unknown attributes, unknown modifier type paths, out-of-range expression handles. */
+int hnb_asset_to_ron(const HnbAsset* asset, char** out_text, size_t* out_size);
+int hnb_asset_from_ron(const char* text, size_t size, HnbAsset** out_asset);
 /* Flat authoring-level description (expressions, properties, modifiers, settings): the CPU oracle's input format. */
 int hnb_asset_serialize(const HnbAsset* asset, void** out_blob, size_t* out_size);
 
