@@ -146,6 +146,7 @@ struct HnbProgram {
     uint32_t* d_plane_by_attr = nullptr;  // [HNB_ATTR_COUNT] plane offsets by attribute id (children read parent particles through it)
     std::vector<uint32_t> parent_attrs;   // attribute ids the init stream reads from the parent particle
     uint32_t* d_ev_totals = nullptr;      // [table_cap * chunks_per_inst][HNB_MAX_EVENT_CHANNELS] (emitting programs)
+    unsigned long long* h_ev_counts = nullptr;  // host-mapped [table_cap][HNB_MAX_EVENT_CHANNELS] {frame, event count} written by k_emit_events (emitting programs)
     uint32_t level = 0;                   // dependency level: parents are simulated before their children
     uint32_t* d_counts = nullptr;  // per chunk: survivors this frame
     uint32_t* d_deaths = nullptr;  // [2][table_cap]: casualties per instance, frame-parity double-buffered
@@ -539,6 +540,8 @@ void free_tables(HnbProgram* p) {
     hipFree(p->d_counts); p->d_counts = nullptr;
     hipFree(p->d_deaths); p->d_deaths = nullptr;
     hipFree(p->d_ev_totals); p->d_ev_totals = nullptr;
+    if (p->h_ev_counts) hipHostFree(p->h_ev_counts);
+    p->h_ev_counts = nullptr;
     hipFree(p->d_safe); p->d_safe = nullptr;
     p->table_cap = 0;
 }
@@ -584,6 +587,10 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
         p->d_ev_totals = nullptr;
         HIP_TRY(hipMalloc(&p->d_ev_totals, n_counts * HNB_MAX_EVENT_CHANNELS * 4));
         HIP_TRY(hipMemset(p->d_ev_totals, 0, n_counts * HNB_MAX_EVENT_CHANNELS * 4));
+        if (p->h_ev_counts) hipHostFree(p->h_ev_counts);
+        p->h_ev_counts = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_ev_counts), (size_t)cap * HNB_MAX_EVENT_CHANNELS * 8, hipHostMallocDefault));
+        for (size_t i = 0; i < (size_t)cap * HNB_MAX_EVENT_CHANNELS; ++i) p->h_ev_counts[i] = 0xffffffffull;  // frame tag: none
     }
     p->d_inst_base = nb;
     p->d_meta[0] = nm[0];
@@ -1043,6 +1050,8 @@ int hnb_effect_destroy(HnbEffect* fx) {
     }
     // swap-remove: move the last instance's table rows into the freed index
     const uint32_t last = (uint32_t)p->effects.size() - 1;
+    if (p->h_ev_counts)   // the host copies of the event counts are indexed by instance: forget those of the two rows that change
+        for (uint32_t c = 0; c < HNB_MAX_EVENT_CHANNELS; ++c) p->h_ev_counts[(size_t)fx->index * HNB_MAX_EVENT_CHANNELS + c] = p->h_ev_counts[(size_t)last * HNB_MAX_EVENT_CHANNELS + c] = 0xffffffffull;
     if (fx->index != last) {
         HnbEffect* moved = p->effects[last];
         hipMemcpy(p->d_inst_base + fx->index, p->d_inst_base + last, 8, hipMemcpyDeviceToDevice);
@@ -1106,6 +1115,7 @@ int hnb_effect_set_parent(HnbEffect* child, HnbEffect* parent, uint32_t channel,
     HIP_TRY(hipMemcpy(static_cast<char*>(buf) + offsetof(DevEventBuffer, capacity), &event_capacity, 4, hipMemcpyHostToDevice));
     ch.buf = static_cast<DevEventBuffer*>(buf);
     ch.capacity = event_capacity;
+    if (pp->h_ev_counts) pp->h_ev_counts[(size_t)parent->index * HNB_MAX_EVENT_CHANNELS + channel] = 0xffffffffull;  // a fresh (empty) buffer
     ch.child = child;
     child->parent = parent;
     child->parent_channel = channel;
@@ -1224,7 +1234,15 @@ int hnb_simulate(HnbContext* ctx) {
                 fi[i].parent_base = reinterpret_cast<uint64_t>(fx->parent->slab);
                 fi[i].parent_planes = reinterpret_cast<uint64_t>(fx->parent->prog->d_plane_by_attr);
                 fi[i].ev_in = reinterpret_cast<uint64_t>(ch.buf);
-                max_request = ch.capacity;  // the event count lives on the device: launch for the worst case
+                max_request = ch.capacity;  // the event count lives on the device: launch for the worst case ...
+                // ... unless last frame's count has already arrived in host memory (k_emit_events): then the grid is sized for it. The kernel
+                // reads the true count itself and strides, so this only ever changes how many workgroups are launched - except for
+                // zero, which is exact (the tag says the copy is last frame's).
+                const HnbProgram* pp = fx->parent->prog;
+                if (pp->h_ev_counts && ctx->frame > 0u) {
+                    const unsigned long long v = *reinterpret_cast<volatile unsigned long long*>(pp->h_ev_counts + (size_t)fx->parent->index * HNB_MAX_EVENT_CHANNELS + fx->parent_channel);
+                    if ((uint32_t)v == ctx->frame - 1u) max_request = std::min<uint32_t>((uint32_t)(v >> 32), ch.capacity);
+                }
             }
             for (uint32_t c = 0; c < HNB_MAX_EVENT_CHANNELS; ++c) fi[i].ev_out[c] = reinterpret_cast<uint64_t>(fx->channels[c].buf);
             // never launch more init workgroups than the capacity allows (max_spawn <= capacity)
@@ -1384,7 +1402,7 @@ int hnb_simulate(HnbContext* ctx) {
         if (!lists) p->skipped_frames += 1;
         if (lists && p->dev.n_event_channels) {  // order this frame's spawn events (by list row) into the children's buffers
             k_emit_count<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb);
-            k_emit_events<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb);
+            k_emit_events<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb, p->h_ev_counts, ctx->frame);
         }
         // lists: only the instances that lost particles have anything to do
         if (lists && !p->slot_order) k_list_rows<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
@@ -1399,7 +1417,7 @@ int hnb_simulate(HnbContext* ctx) {
             // non-negative tick (monotone under rounding; non-negative floats order like their bits), plus this frame's spawns
             // at the end. Where the host can prove the premises (HnbProgram::sort_provable + this frame's values + no host write)
             // the radix range is at most the largest spawn request: nothing to do without spawns, one single-workgroup launch
-            // for a small range. Otherwise the device decides (k_sort_check) and all launches are issued.
+            // for a small range. Otherwise the device decides (k_sort_fill's order check) and all launches are issued.
             const bool proven = p->sort_provable && p->frame_sort_values_ok && !p->sort_dirty && ctx->skip_lists;
             if (!(proven && p->frame_max_spawn == 0u)) {
                 SortArgs so = p->sort;
@@ -1408,7 +1426,6 @@ int hnb_simulate(HnbContext* ctx) {
                 const DevMeta* mo = p->d_meta[par ^ 1];
                 const uint32_t tiles = n * so.chunks_per_inst;
                 k_sort_fill<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
-                k_sort_check<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
                 if (proven && p->frame_max_spawn <= kSortSmallMax) {
                     k_sort_small<<<n, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
                 } else {

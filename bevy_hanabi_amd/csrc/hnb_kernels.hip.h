@@ -623,7 +623,7 @@ k_order_write(const CompactArgs args, const uint64_t* __restrict__ inst_base, co
 #ifndef HNB_JIT_TU
 __global__ void __launch_bounds__(kBlock)
 k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
-              const DevFrameInst* __restrict__ fi, const CompactBufs cb) {
+              const DevFrameInst* __restrict__ fi, const CompactBufs cb, unsigned long long* __restrict__ ev_host, const uint32_t frame_tag) {
     __shared__ uint32_t s_red[kBlock / 64];
     __shared__ uint32_t s_scan[kBlock];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -648,7 +648,12 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
 #pragma unroll
         for (uint32_t w = 0; w < kBlock / 64; ++w) excl += s_red[w];
         const uint32_t mine = has_rows ? tot[(size_t)c.j * HNB_MAX_EVENT_CHANNELS] : 0u;
-        if (last && tid == 0) ev->count[fi[c.k].ev_parity] = excl + mine;  // GpuChildInfo::event_count of this frame
+        if (last && tid == 0) {
+            ev->count[fi[c.k].ev_parity] = excl + mine;  // GpuChildInfo::event_count of this frame
+            // ... and a copy for the host ({frame, count} in host-mapped memory, no read-back): when it has arrived by the time the next
+            // frame is enqueued, the child's init grid is sized for the events that exist instead of for the buffer's capacity
+            if (ev_host) *reinterpret_cast<volatile unsigned long long*>(ev_host + (size_t)c.k * HNB_MAX_EVENT_CHANNELS + ch) = ((unsigned long long)(excl + mine) << 32) | frame_tag;
+        }
         if (mine == 0u) continue;
         const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c.base + prog.ev_cnt_off[ch]);                 // per slot
         const uint32_t* slots = reinterpret_cast<const uint32_t*>(c.base + prog.alive_off[c.m.write_index]) + c.start;  // rows as the update saw them

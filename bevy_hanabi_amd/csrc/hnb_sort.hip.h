@@ -10,10 +10,10 @@
 //   k_sort_fill    64-bit keys (RIBBON_ID << 32 | AGE bits) and values in list order; OR / AND of the keys,
 //                  over all rows and over the TAIL = the last `spawned` rows (this frame's spawns sit at the
 //                  end of the compacted list);
-//   k_sort_check   is the HEAD (everything before the tail) still in order? It is the list the previous
-//                  frame's sort produced, minus the casualties, with every age advanced by the same dt, so
-//                  normally yes; an update program that rewrites AGE / RIBBON_ID can break it, and then the
-//                  whole list is the sort range instead of the tail;
+//                  and, in the same pass, whether the HEAD (everything before the tail) is still in order: it is the
+//                  list the previous frame's sort produced, minus the casualties, with every age advanced by the
+//                  same dt, so normally yes; an update program that rewrites AGE / RIBBON_ID can break it, and
+//                  then the whole list is the sort range instead of the tail;
 //   8 radix passes least-significant-digit radix sort of the RANGE (tail, or everything), 8 bits per pass:
 //                  k_sort_hist (LDS histogram per 4096-key tile + per-group sums) and k_sort_scatter (each
 //                  tile derives its digit offsets itself from the group sums and the histograms of the earlier
@@ -49,7 +49,7 @@ struct SortArgs {
 struct SortState {
     uint64_t or_all, and_all;    // over every key of the instance
     uint64_t or_tail, and_tail;  // over the tail rows
-    uint32_t head_unsorted;      // set by k_sort_check
+    uint32_t head_unsorted;      // set by k_sort_fill
     uint32_t pad[3];
 };
 static_assert(sizeof(SortState) == 48, "SortState layout");
@@ -125,19 +125,29 @@ k_sort_fill(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevM
     const uint32_t* rid = a.rid_plane == kNoPlane ? nullptr : reinterpret_cast<const uint32_t*>(base + a.rid_plane);
     const uint32_t* age = a.age_plane == kNoPlane ? nullptr : reinterpret_cast<const uint32_t*>(base + a.age_plane);
     uint64_t or_all = 0ull, and_all = ~0ull, or_tail = 0ull, and_tail = ~0ull;
+    auto key_of = [&](uint32_t slot) { return ((uint64_t)(rid ? rid[slot] : 0u) << 32) | (uint64_t)(age ? age[slot] : 0u); };
+    bool bad = false;  // is the HEAD (rows before this frame's spawns) still in non-decreasing key order? (was k_sort_check, a launch of its own)
     for (uint32_t r = 0; r < kSortTile / kBlock; ++r) {
         const uint32_t i = j * kSortTile + r * kBlock + tid;
-        if (i >= n) break;
-        const uint32_t slot = list[i];
-        const uint64_t key = ((uint64_t)(rid ? rid[slot] : 0u) << 32) | (uint64_t)(age ? age[slot] : 0u);
-        keys[i] = key;
-        vals[i] = slot;
-        or_all |= key; and_all &= key;
-        if (i >= tail_lo) { or_tail |= key; and_tail &= key; }
+        const bool valid = i < n;
+        const uint32_t slot = valid ? list[i] : 0u;
+        const uint64_t key = valid ? key_of(slot) : 0ull;
+        if (valid) {
+            keys[i] = key;
+            vals[i] = slot;
+            or_all |= key; and_all &= key;
+            if (i >= tail_lo) { or_tail |= key; and_tail &= key; }
+        }
+        // the next row's key: the neighbouring lane's, or - for the last lane of a wave - fetched like our own
+        uint64_t next = (uint64_t)__shfl_down((unsigned long long)key, 1, 64);
+        if (lane == 63u && i + 1u < tail_lo) next = key_of(list[i + 1u]);
+        if (i + 1u < tail_lo) bad = bad || key > next;
+        if (j * kSortTile + (r + 1u) * kBlock >= n) break;  // (uniform: no further rows in this tile)
     }
     or_all = wave_or(or_all); and_all = wave_and(and_all); or_tail = wave_or(or_tail); and_tail = wave_and(and_tail);
     if (lane == 0) { s_acc[0][wave] = or_all; s_acc[1][wave] = and_all; s_acc[2][wave] = or_tail; s_acc[3][wave] = and_tail; }
     __syncthreads();
+    if (__any(bad) && lane == 0u) (st + a.parity)->head_unsorted = 1u;
     if (tid == 0 && j * kSortTile < n) {
         for (uint32_t w = 1; w < kBlock / 64; ++w) { or_all |= s_acc[0][w]; and_all &= s_acc[1][w]; or_tail |= s_acc[2][w]; and_tail &= s_acc[3][w]; }
         SortState* cur = st + a.parity;
@@ -148,24 +158,6 @@ k_sort_fill(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevM
             atomicAnd(reinterpret_cast<unsigned long long*>(&cur->and_tail), (unsigned long long)and_tail);
         }
     }
-}
-
-// Is the head (rows before this frame's spawns) in non-decreasing key order?
-__global__ void __launch_bounds__(kBlock)
-k_sort_check(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta) {
-    uint32_t k, j; char* base;
-    sort_setup(blockIdx.x, a, inst_base, k, j, base);
-    const uint32_t n = meta[k].alive_count;
-    const uint32_t tail = meta[k].spawned < n ? meta[k].spawned : n;
-    const uint32_t head = n - tail;
-    if (j * kSortTile + 1u >= head) return;
-    const uint64_t* keys = reinterpret_cast<const uint64_t*>(base + a.key_off[0]);
-    bool bad = false;
-    for (uint32_t r = 0; r < kSortTile / kBlock; ++r) {
-        const uint32_t i = j * kSortTile + r * kBlock + threadIdx.x;
-        if (i + 1u < head) bad = bad || keys[i] > keys[i + 1u];
-    }
-    if (__any(bad) && (threadIdx.x & 63u) == 0u) (reinterpret_cast<SortState*>(base + a.bits_off) + a.parity)->head_unsorted = 1u;
 }
 
 __global__ void __launch_bounds__(kBlock)

@@ -107,3 +107,56 @@ def test_two_rank_slabs_equal_single_device_run():
     assert len(totals) == 1
     assert totals.pop() == sum(t[6] for t in results)
     assert [t[1] for t in results] == [0, TOTAL // 2]
+
+
+# ---- BASELINE config 4: sharding BY INSTANCE (bench.py --config c4) ---------------------------------------------------
+N_INST, INST_CAP, INST_FRAMES = 12, 300, 6
+
+
+def _instance_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from helpers import Frame, OracleRunner
+    mine = sharding.instance_plan(N_INST, world)[rank]          # instance i lives on rank i mod world, as in bench.py
+    runners = {g: OracleRunner(effects.instancing(INST_CAP)) for g in mine}
+    for f in range(INST_FRAMES):
+        for g, r in runners.items():   # per-instance seed and transform depend on the GLOBAL instance index only
+            r.step(Frame(1 / 60, INST_CAP if f == 0 else 0, bench.instance_seed(f, g), np.array(bench.instance_transform(g), np.float32), time=f / 60))
+    alive_local = [runners[g].fx.alive_count() if g in runners else 0 for g in range(N_INST)]
+    alive_total = sharding.allreduce_alive(alive_local)          # the only collective: per-effect alive counters
+    q.put((rank, mine, alive_total, {g: r.state()["attrs"]["position"] for g, r in runners.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_instance_sharding_equals_single_process():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from helpers import Frame, OracleRunner
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_instance_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0][1] == list(range(0, N_INST, 2)) and results[1][1] == list(range(1, N_INST, 2))
+    assert results[0][2] == results[1][2] == [INST_CAP] * N_INST   # every rank sees every instance's counter after the all-reduce
+    got = {}
+    for _, _, _, planes in results:
+        got.update(planes)
+    for g in range(N_INST):   # one process simulating all instances gives the same particles
+        r = OracleRunner(effects.instancing(INST_CAP))
+        for f in range(INST_FRAMES):
+            r.step(Frame(1 / 60, INST_CAP if f == 0 else 0, bench.instance_seed(f, g), np.array(bench.instance_transform(g), np.float32), time=f / 60))
+        np.testing.assert_array_equal(r.state()["attrs"]["position"], got[g], err_msg=f"instance {g}")
