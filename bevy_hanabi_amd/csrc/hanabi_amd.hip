@@ -403,7 +403,7 @@ bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgra
     uint64_t plane[kMaxAttrs];
     for (uint32_t i = 0; i < h.n_attrs; ++i) plane[i] = place(align_up((size_t)h.capacity * attrs[i].ncomp * 4, 256));
     const uint64_t flag_off = place(align_up((size_t)h.capacity, 256));             // alive byte per slot, zeroed with the attribute planes
-    const uint64_t lmin_off = place(align_up((size_t)d.chunks_per_inst * 8, 256));  // per chunk: lifetime bound (0 = unknown), then "completely alive" flag; zeroed too
+    const uint64_t lmin_off = place(align_up((size_t)d.chunks_per_inst * 16, 256));  // four u32 / f32 arrays per chunk: lifetime bound (0 = unknown), "completely alive" flag, age-cohort state, age-cohort value; zeroed too
     uint64_t ev_off[HNB_MAX_EVENT_CHANNELS] = {};
     for (uint32_t c = 0; c < h.n_event_channels; ++c) ev_off[c] = place(list_bytes);  // per-slot staging of spawn events (k_update_slots_generic -> k_emit_count / k_emit_events)
     uint64_t key_off[2] = {}, val_off[2] = {}, hist_off = 0, gsum_off = 0, bits_off = 0;
@@ -790,6 +790,8 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
         }
         if (ok && loads_life && !stores_life && has_age) {
             d.cull_lifetime = 1u;
+            // age cohorts: the same structural conditions (one AGE_TICK up front, nothing else writes AGE), and nobody else reads the plane on the device
+            if (!(h.flags & HNB_PROG_HAS_RIBBONS) && !(getenv("HNB_AGE_COHORT") && getenv("HNB_AGE_COHORT")[0] == '0')) d.age_cohort = 1u;
             p->cull_dt_operand = HNB_OPERAND_DECODE((uc[0].x >> 16) & 0xffu, uc[0].y >> 13);
         }
     }
@@ -1366,6 +1368,7 @@ int hnb_simulate(HnbContext* ctx) {
             sa.update_code = p->dev.update_code;
             sa.died_mark = died_mark;
             sa.cull_lifetime = p->dev.cull_lifetime; sa.lmin_off = p->dev.lmin_off; sa.dt_operand = p->cull_dt_operand;
+            sa.age_cohort = p->dev.age_cohort;
             if (p->skip_eligible) { sa.safe_words = p->d_safe; sa.safe_host = p->h_safe; sa.safe_parity = p->frames_run & 1u; sa.publish_tag = p->frames_run - 1u; sa.safe_stride = p->table_cap * p->dev.chunks_per_inst; }
             sa.skip_lists = p->skip_now ? 1u : 0u;
             sa.meta_in = p->d_meta[par]; sa.meta_out = p->d_meta[par ^ 1];
@@ -1489,6 +1492,9 @@ int hnb_effect_read_attr(HnbEffect* fx, uint32_t attr, void* dst, size_t dst_siz
     if (ai < 0) return fail(HNB_ERR_NOT_FOUND, "attribute %u is not part of the particle layout", attr);
     const size_t bytes = (size_t)p->dev.capacity * p->attrs[ai].ncomp * 4;
     if (dst_size < bytes) return fail(HNB_ERR_INVALID_ARG, "destination too small (%zu < %zu)", dst_size, bytes);
+    if (p->dev.age_cohort && attr == HNB_ATTR_AGE)   // chunks whose particles share one age keep it in a word: write it out first
+        k_materialise_age<<<p->dev.chunks_per_inst, kBlock, 0, p->ctx->stream>>>(static_cast<char*>(fx->slab), p->dev.capacity, p->dev.chunks_per_inst, p->dev.lmin_off,
+                                                                                  p->dev.attrs[ai].plane_off, p->dev.alive_flag_off);
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     HIP_TRY(hipMemcpy(dst, static_cast<char*>(fx->slab) + p->dev.attrs[ai].plane_off, bytes, hipMemcpyDeviceToHost));
     return HNB_OK;
@@ -1507,6 +1513,8 @@ int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t 
     p->sort_dirty = true;  // ... and a ribbon list may no longer be in key order
     // the chunks' lifetime bounds (lifetime culling) no longer describe the planes
     HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.lmin_off, 0, (size_t)p->dev.chunks_per_inst * 4));  // (the "completely alive" flags that follow stay valid)
+    if (p->dev.age_cohort && attr == HNB_ATTR_AGE)   // the plane is the truth again: forget the cohort states (and values)
+        HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.lmin_off + (size_t)p->dev.chunks_per_inst * 8, 0, (size_t)p->dev.chunks_per_inst * 8));
     return HNB_OK;
 }
 
@@ -1547,6 +1555,16 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
     if (!prog || !buf || !buf_size) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
     std::string s = prog->kernel_info;
     if (!prog->jit_log.empty()) s += "\njit log: " + prog->jit_log;
+    if (prog->dev.age_cohort) {   // (debug statistics: synchronises and reads the per-chunk state words of every instance)
+        hipStreamSynchronize(prog->ctx->stream);
+        std::vector<uint32_t> st(prog->dev.chunks_per_inst);
+        size_t in_cohort = 0;
+        for (const HnbEffect* fx : prog->effects) {
+            if (hipMemcpy(st.data(), static_cast<const char*>(fx->slab) + prog->dev.lmin_off + (size_t)prog->dev.chunks_per_inst * 8, st.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+            for (uint32_t v : st) in_cohort += v == 1u ? 1u : 0u;
+        }
+        s += "\nage cohorts: " + std::to_string(in_cohort) + " of " + std::to_string(prog->effects.size() * (size_t)prog->dev.chunks_per_inst) + " chunks";
+    }
     s += "\nlists skipped: " + std::to_string(prog->skipped_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->skip_eligible ? "" : " (not eligible)");
     snprintf(buf, buf_size, "%s", s.c_str());
     return HNB_OK;

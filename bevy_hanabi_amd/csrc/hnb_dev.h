@@ -39,6 +39,7 @@ struct DevProgram {
     // of the 4096-slot chunk, 0 = unknown. k_init zeroes the entry of a chunk it spawns into.
     uint32_t lmin_off;
     uint32_t cull_lifetime;    // 1: the streaming update keeps the bounds up to date and uses them
+    uint32_t age_cohort;       // 1: chunks whose alive particles share one AGE keep it in a word (hnb_kernels.hip.h "Age cohorts")
     DevAttr attrs[kMaxAttrs];
     const Ins* init_code;
     const Ins* update_code;

@@ -228,7 +228,13 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
         CODE::zero_unassigned(prog, io);
         CODE::run_init(prog, S, U, io);
         alive[alive0 + i] = slot;
-        reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = 1u;  // the update walks the slots through these bytes
+        uint8_t alive_byte = 1u;  // the update walks the slots through these bytes
+        if (prog.age_cohort) {  // a chunk that keeps its particles' common age in one word: this slot's age is in the plane (state 2, byte 3)
+            uint32_t* astate = reinterpret_cast<uint32_t*>(base + prog.lmin_off) + 2u * prog.chunks_per_inst;
+            const uint32_t st = astate[slot / kChunk];
+            if (st != 0u) { if (st != 2u) astate[slot / kChunk] = 2u; alive_byte = 3u; }
+        }
+        reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = alive_byte;
         if (prog.cull_lifetime) reinterpret_cast<float*>(base + prog.lmin_off)[slot / kChunk] = 0.0f;  // the chunk's lifetime bound is unknown again
         CODE::store_init(prog, S, base, slot);
     }
@@ -715,6 +721,7 @@ struct SlotArgs {
     uint32_t died_mark;      // byte written for a particle that dies: 2 (k_list_rows pushes it on the dead list) or 0 (slot-ordered lists)
     uint32_t cull_lifetime;  // 1: lifetime culling (below); lmin_off = f32[chunks_per_inst] in the slab, dt_operand = operand a of the AGE_TICK
     uint32_t lmin_off, dt_operand;
+    uint32_t age_cohort;     // 1: chunks whose alive particles all have the same AGE keep it in one word (below)
     const Ins* update_code;
     // "No particle can die before ..." (below): safe_words = u32[2][safe_stride] float bits, the frame's minimum remaining life
     // per chunk, double-buffered by safe_parity; safe_host = host-mapped {frame tag, bound bits} the host reads without any
@@ -750,6 +757,20 @@ struct SlotArgs {
 // recomputed. A burst effect runs culled for most of its particles' lives; an effect that spawns into every chunk every
 // frame recomputes every frame and costs what it did before.
 
+// Age cohorts. A burst spawns its particles in one frame with one initial AGE, and AGE_TICK adds the same dt to all of them:
+// the alive particles of a chunk then share ONE age, bit for bit, for the rest of their lives, and reading and writing 4 + 4
+// bytes of it per particle per frame (8 of the 56 the firework update moves) carries no information. Per chunk the slab keeps
+// a state word and a value word (behind the lifetime bounds and the "completely alive" flags):
+//   state 0  the AGE plane holds every age (the default);
+//   state 1  every alive particle of the chunk has age == value; the plane is stale for the alive slots (dead slots keep the age
+//            they died with: the kernel stores the age of a particle in the frame it dies, as the reference's write-back does);
+//   state 2  state 1 + this frame's spawns, whose ages ARE in the plane and whose alive byte is 3 (k_init sets both; within a frame only).
+// The update reads the state, takes the value instead of the plane where it may (2: per slot, by the alive byte), and after the
+// program checks whether the survivors' new ages are all equal (min == max of their bit patterns): then it writes the value
+// and skips the plane, else it stores the ages (which materialises them) and returns to state 0. Host reads of the AGE plane
+// materialise first (k_materialise_age), host writes reset the states. Eligible programs: the lifetime-culling ones (the
+// stream starts with its only AGE_TICK, nothing else writes AGE) without ribbons (the sort reads the plane); HNB_AGE_COHORT=0 off.
+
 // PROBE (tools/stream_probe.hip only; 0 in the product): 4 = skip stores, 8 = skip the program.
 template <class PROG, int WAVES, int PROBE = 0>
 __global__ void __launch_bounds__(kBlock, WAVES)
@@ -759,6 +780,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     __shared__ float s_lmin[kBlock / 64];
     __shared__ uint32_t s_alive[kBlock / 64];
     __shared__ float s_rem[kBlock / 64];
+    __shared__ uint32_t s_amin[kBlock / 64], s_amax[kBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
     const uint32_t k = chunk / args.chunks_per_inst, j = chunk - k * args.chunks_per_inst;
@@ -804,6 +826,11 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     // with free slots, whose flag is already clear.
     uint32_t* cfull = reinterpret_cast<uint32_t*>(base + args.lmin_off) + args.chunks_per_inst;
     const bool chunk_full = cfull[j] == 1u;
+    uint32_t* astate = cfull + args.chunks_per_inst;      // age cohorts: state and value per chunk
+    uint32_t* aval = astate + args.chunks_per_inst;
+    const uint32_t ast = args.age_cohort ? astate[j] : 0u;
+    const float A = args.age_cohort ? u2f(aval[j]) : 0.0f;
+    uint32_t amin = 0xffffffffu, amax = 0u;               // bit patterns of the ages of the particles that stay alive
     uint32_t lane_alive = 0;
     const bool cull = args.cull_lifetime != 0u;
     float* lmin = reinterpret_cast<float*>(base + args.lmin_off);
@@ -815,9 +842,14 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
         const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;  // first of this lane's 4 slots
         const uint32_t f4 = chunk_full ? 0x01010101u : (s0 < args.capacity ? flags4[s0 >> 2] : 0u);  // the plane is padded: slots past the capacity read 0
-        bool was[4];
+        bool was[4], fresh[4];  // fresh: spawned this frame into a chunk that kept its ages in the value word (alive byte 3)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { was[p] = ((f4 >> (8 * p)) & 0xffu) == 1u; lane_alive += was[p] ? 1u : 0u; }
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t byte = (f4 >> (8 * p)) & 0xffu;
+            fresh[p] = byte == 3u;
+            was[p] = byte == 1u || fresh[p];
+            lane_alive += was[p] ? 1u : 0u;
+        }
         const bool any = was[0] || was[1] || was[2] || was[3];
         if (!__any(any)) continue;
         const bool full = was[0] && was[1] && was[2] && was[3];
@@ -832,7 +864,14 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
         if (any) {
             if (fl & 1u) pin_load3<4>(X.pos, p_pos, slot, lanes_on, true);
             if (fl & 2u) pin_load3<4>(X.vel, p_vel, slot, lanes_on, true);
-            if (fl & 4u) pin_load1<4>(X.age, p_age, slot, lanes_on, true);
+            if (fl & 4u) {
+                if (ast != 1u) pin_load1<4>(X.age, p_age, slot, lanes_on, true);
+                if (ast != 0u) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        if (ast == 1u || !fresh[p]) X.age[p] = A;
+                }
+            }
         }
         if (cull && Lm > 0.0f) {  // can this step lose a particle? `age + dt` is the AGE_TICK's own arithmetic
             bool may_die = false;
@@ -853,7 +892,14 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
             if (any) {  // a full quad is stored with 16-byte stores; otherwise only the alive slots are written
                 if (fl & 16u) pin_store3<4>(X.pos, p_pos, slot, was, full);
                 if (fl & 32u) pin_store3<4>(X.vel, p_vel, slot, was, full);
-                if (fl & 64u) pin_store1<4>(X.age, p_age, slot, was, full);
+                if (fl & 64u) {
+                    if (ast != 1u) pin_store1<4>(X.age, p_age, slot, was, full);
+                    else {  // the chunk's ages live in its value word; a particle that dies now leaves its last age in the plane
+#pragma unroll
+                        for (int p = 0; p < 4; ++p)
+                            if (was[p] && !X.alive[p]) reinterpret_cast<float*>(p_age)[slot[p]] = X.age[p];
+                    }
+                }
                 if (fl & 128u) pin_store1<4>(X.lifetime, p_life, slot, was, full);
             }
         } else {
@@ -872,12 +918,18 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
             for (int p = 0; p < 4; ++p)
                 if (was[p] && X.alive[p]) rem_min = fminf(rem_min, (X.lifetime[p] - X.age[p]) - 1.0e-5f * X.lifetime[p]);
         }
+        if (args.age_cohort) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (was[p] && X.alive[p]) { const uint32_t b = f2u(X.age[p]); amin = b < amin ? b : amin; amax = b > amax ? b : amax; }
+        }
         uint32_t nf = f4;
         uint32_t died_here = 0;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const bool died = was[p] && !X.alive[p];
             if (died) nf = (nf & ~(0xffu << (8 * p))) | (args.died_mark << (8 * p));
+            else if (fresh[p]) nf = (nf & ~(0xffu << (8 * p))) | (1u << (8 * p));   // an ordinary alive slot from now on
             died_here += (uint32_t)__popcll(__ballot(died));
         }
         if (nf != f4) flags4[s0 >> 2] = nf;
@@ -899,9 +951,27 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
         for (uint32_t off = 32; off > 0; off >>= 1) rem_min = fminf(rem_min, __shfl_xor(rem_min, off, 64));
         if (lane == 0) s_rem[wave] = rem_min;
     }
+    if (args.age_cohort) {
+#pragma unroll
+        for (uint32_t off = 32; off > 0; off >>= 1) {
+            const uint32_t lo = __shfl_xor(amin, off, 64), hi = __shfl_xor(amax, off, 64);
+            amin = lo < amin ? lo : amin; amax = hi > amax ? hi : amax;
+        }
+        if (lane == 0) { s_amin[wave] = amin; s_amax[wave] = amax; }
+    }
     if (lane == 0) { s_died[wave] = died_total; s_lmin[wave] = loaded_all ? wave_min : -1.0f; }
     __syncthreads();
     if (tid == 0) {
+        if (args.age_cohort) {   // do the survivors share one age? (amin > amax: there are none)
+            uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+            for (uint32_t w = 0; w < kBlock / 64; ++w) { lo = s_amin[w] < lo ? s_amin[w] : lo; hi = s_amax[w] > hi ? s_amax[w] : hi; }
+            const uint32_t now = (lo == hi) ? 1u : 0u;
+            // a chunk that was NOT in state 1 stored its ages in this launch; one that was, did not: it may only stay in state 1
+            // (same value for all survivors by construction) or empty out (lo > hi -> 0: nothing alive, the plane is right for the dead)
+            if (now) aval[j] = lo;
+            if (now != ast) astate[j] = now;
+        }
         uint32_t d = 0;
 #pragma unroll
         for (uint32_t w = 0; w < kBlock / 64; ++w) d += s_died[w];
@@ -983,6 +1053,22 @@ k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_
 }
 
 #ifndef HNB_JIT_TU
+// Writes the common age of every cohort chunk (state 1) into the AGE plane for its alive slots: before the host reads the plane.
+__global__ void __launch_bounds__(kBlock)
+k_materialise_age(char* __restrict__ base, uint32_t capacity, uint32_t chunks_per_inst, uint32_t lmin_off, uint32_t age_plane_off, uint32_t alive_flag_off) {
+    const uint32_t j = blockIdx.x;
+    const uint32_t* astate = reinterpret_cast<const uint32_t*>(base + lmin_off) + 2u * chunks_per_inst;
+    const uint32_t* aval = astate + chunks_per_inst;
+    if (astate[j] != 1u) return;
+    const uint32_t v = aval[j];
+    const uint8_t* flags = reinterpret_cast<const uint8_t*>(base + alive_flag_off);
+    uint32_t* age = reinterpret_cast<uint32_t*>(base + age_plane_off);
+    for (uint32_t i = threadIdx.x; i < kChunk; i += kBlock) {
+        const uint32_t slot = j * kChunk + i;
+        if (slot < capacity && flags[slot] == 1u) age[slot] = v;
+    }
+}
+
 // Row-major list maintenance for the instances that lost particles this frame: every 4096-row chunk of the
 // alive list is rewritten as [survivors | casualties] (stable, in row order) from the alive bytes, and its
 // survivor count recorded; k_compact then takes the cross-chunk prefix exactly as before.

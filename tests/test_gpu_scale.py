@@ -389,3 +389,50 @@ def test_skipping_is_suspended_by_everything_the_bound_does_not_cover(ctx):
     skipped, frames = _skipped(prog)
     assert frames == 70 and 0 < skipped < 60
     prog.destroy()
+
+
+# ---- age cohorts: chunks whose alive particles share one age keep it in a word ------------------------------------------
+def _cohort_chunks(prog):
+    line = [l for l in prog.kernel_info().split("\n") if l.startswith("age cohorts")][0]
+    return int(line.split()[2]), int(line.split()[4])
+
+
+def test_age_cohorts_engage_and_dissolve_without_a_trace(ctx):
+    """After a burst every chunk's particles share one age: the update stops reading and writing the AGE plane (state word 1).
+    Reading AGE through the ABI materialises it; respawning into recycled slots mixes ages and returns those chunks to the
+    plane; deaths leave the dead slot's last age in the plane; a host write of AGE resets everything. State, lists and counters
+    are compared with the oracle bit for bit throughout (the oracle knows nothing of this)."""
+    cap = 50000   # 13 chunks, the last one ragged
+    asset = effects.firework_trails(cap)
+    gpu, orc = GpuRunner(asset, ctx=ctx), OracleRunner(asset)
+    n_chunks = (cap + 4095) // 4096
+
+    def run(frames, first, spawn_at=None, spawn=0):
+        for f in range(first, first + frames):
+            fr = Frame(1 / 60, spawn if f == spawn_at else 0, frame_seed(f), time=f / 60)
+            gpu.step(fr); orc.step(fr)
+        return first + frames
+
+    f = run(1, 0, spawn_at=0, spawn=cap)
+    f = run(2, f)
+    assert _cohort_chunks(gpu.prog) == (n_chunks, n_chunks)                  # every chunk found its particles' ages equal
+    assert_same_state(orc.state(), gpu.state(), "in cohort state")           # (reads AGE: materialised on demand)
+    assert _cohort_chunks(gpu.prog) == (n_chunks, n_chunks)                  # ... and stays in cohort state afterwards
+    f = run(50, f)                                                           # into the die-off: deaths inside cohort chunks
+    st = orc.state()
+    assert 0 < st["counters"]["alive_count"] < cap
+    assert_same_state(st, gpu.state(), "deaths in cohort chunks")            # dead slots keep the age they died with
+    f = run(1, f, spawn_at=f, spawn=9000)                                    # respawn into recycled slots: two ages per chunk
+    assert_same_state(orc.state(), gpu.state(), "fresh spawns next to a cohort")
+    in_cohort, _ = _cohort_chunks(gpu.prog)
+    assert in_cohort < n_chunks
+    f = run(30, f)
+    assert_same_state(orc.state(), gpu.state(), "old particles died, new ones remain")
+    # a host write of AGE: the plane is the truth again. Write what is there (materialised) -> same run as before
+    age = gpu.fx.read_attr(A.AGE.id).copy()
+    gpu.fx.write_attr(A.AGE.id, age)
+    assert _cohort_chunks(gpu.prog)[0] == 0
+    f = run(3, f)
+    assert_same_state(orc.state(), gpu.state(), "after a host write of AGE")
+    assert gpu.fx.metadata()["fault"] == 0
+    gpu.fx.destroy(); gpu.prog.destroy()
