@@ -772,7 +772,8 @@ struct SlotArgs {
 // stream starts with its only AGE_TICK, nothing else writes AGE) without ribbons (the sort reads the plane); HNB_AGE_COHORT=0 off.
 
 // PROBE (tools/stream_probe.hip only; 0 in the product): 4 = skip stores, 8 = skip the program.
-template <class PROG, int WAVES, int PROBE = 0>
+// COHORT: compile the age-cohort paths in (programs that are eligible: SlotArgs::age_cohort); false leaves the kernel as it was.
+template <class PROG, int WAVES, int PROBE = 0, bool COHORT = false>
 __global__ void __launch_bounds__(kBlock, WAVES)
 k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
                       const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
@@ -828,8 +829,8 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     const bool chunk_full = cfull[j] == 1u;
     uint32_t* astate = cfull + args.chunks_per_inst;      // age cohorts: state and value per chunk
     uint32_t* aval = astate + args.chunks_per_inst;
-    const uint32_t ast = args.age_cohort ? astate[j] : 0u;
-    const float A = args.age_cohort ? u2f(aval[j]) : 0.0f;
+    const uint32_t ast = COHORT ? astate[j] : 0u;      // wave-uniform
+    const float A = COHORT ? u2f(aval[j]) : 0.0f;
     uint32_t amin = 0xffffffffu, amax = 0u;               // bit patterns of the ages of the particles that stay alive
     uint32_t lane_alive = 0;
     const bool cull = args.cull_lifetime != 0u;
@@ -842,11 +843,11 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
         const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;  // first of this lane's 4 slots
         const uint32_t f4 = chunk_full ? 0x01010101u : (s0 < args.capacity ? flags4[s0 >> 2] : 0u);  // the plane is padded: slots past the capacity read 0
-        bool was[4], fresh[4];  // fresh: spawned this frame into a chunk that kept its ages in the value word (alive byte 3)
+        bool was[4], fresh[4];  // fresh: spawned this frame into a chunk that kept its ages in the value word (alive byte 3, state 2 only)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const uint32_t byte = (f4 >> (8 * p)) & 0xffu;
-            fresh[p] = byte == 3u;
+            fresh[p] = COHORT && byte == 3u;
             was[p] = byte == 1u || fresh[p];
             lane_alive += was[p] ? 1u : 0u;
         }
@@ -865,11 +866,10 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
             if (fl & 1u) pin_load3<4>(X.pos, p_pos, slot, lanes_on, true);
             if (fl & 2u) pin_load3<4>(X.vel, p_vel, slot, lanes_on, true);
             if (fl & 4u) {
-                if (ast != 1u) pin_load1<4>(X.age, p_age, slot, lanes_on, true);
-                if (ast != 0u) {
+                if (!COHORT || ast != 1u) pin_load1<4>(X.age, p_age, slot, lanes_on, true);
+                if (COHORT && ast != 0u) {   // (selects, no divergence: ast is uniform, fresh[] only ever set in state 2)
 #pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        if (ast == 1u || !fresh[p]) X.age[p] = A;
+                    for (int p = 0; p < 4; ++p) X.age[p] = fresh[p] ? X.age[p] : A;
                 }
             }
         }
@@ -893,12 +893,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
                 if (fl & 16u) pin_store3<4>(X.pos, p_pos, slot, was, full);
                 if (fl & 32u) pin_store3<4>(X.vel, p_vel, slot, was, full);
                 if (fl & 64u) {
-                    if (ast != 1u) pin_store1<4>(X.age, p_age, slot, was, full);
-                    else {  // the chunk's ages live in its value word; a particle that dies now leaves its last age in the plane
-#pragma unroll
-                        for (int p = 0; p < 4; ++p)
-                            if (was[p] && !X.alive[p]) reinterpret_cast<float*>(p_age)[slot[p]] = X.age[p];
-                    }
+                    if (!COHORT || ast != 1u) pin_store1<4>(X.age, p_age, slot, was, full);
                 }
                 if (fl & 128u) pin_store1<4>(X.lifetime, p_life, slot, was, full);
             }
@@ -918,10 +913,24 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
             for (int p = 0; p < 4; ++p)
                 if (was[p] && X.alive[p]) rem_min = fminf(rem_min, (X.lifetime[p] - X.age[p]) - 1.0e-5f * X.lifetime[p]);
         }
-        if (args.age_cohort) {
+        if constexpr (COHORT) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-                if (was[p] && X.alive[p]) { const uint32_t b = f2u(X.age[p]); amin = b < amin ? b : amin; amax = b > amax ? b : amax; }
+            for (int p = 0; p < 4; ++p) {   // min / max of the survivors' age bits (selects)
+                const bool stays = was[p] && X.alive[p];
+                const uint32_t b = f2u(X.age[p]);
+                amin = (stays && b < amin) ? b : amin;
+                amax = (stays && b > amax) ? b : amax;
+            }
+            if constexpr (!(PROBE & 4)) {
+                // a chunk in state 1 keeps its ages in the value word; a particle that dies now leaves its last age in the plane
+                // (rare: one wave-uniform vote per step keeps the stores out of the way)
+                const bool dies = (was[0] && !X.alive[0]) || (was[1] && !X.alive[1]) || (was[2] && !X.alive[2]) || (was[3] && !X.alive[3]);
+                if (ast == 1u && (fl & 64u) && __any(dies)) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        if (was[p] && !X.alive[p]) reinterpret_cast<float*>(p_age)[slot[p]] = X.age[p];
+                }
+            }
         }
         uint32_t nf = f4;
         uint32_t died_here = 0;
@@ -929,7 +938,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
         for (int p = 0; p < 4; ++p) {
             const bool died = was[p] && !X.alive[p];
             if (died) nf = (nf & ~(0xffu << (8 * p))) | (args.died_mark << (8 * p));
-            else if (fresh[p]) nf = (nf & ~(0xffu << (8 * p))) | (1u << (8 * p));   // an ordinary alive slot from now on
+            else if (COHORT && fresh[p]) nf = (nf & ~(0xffu << (8 * p))) | (1u << (8 * p));   // an ordinary alive slot from now on
             died_here += (uint32_t)__popcll(__ballot(died));
         }
         if (nf != f4) flags4[s0 >> 2] = nf;
@@ -951,7 +960,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
         for (uint32_t off = 32; off > 0; off >>= 1) rem_min = fminf(rem_min, __shfl_xor(rem_min, off, 64));
         if (lane == 0) s_rem[wave] = rem_min;
     }
-    if (args.age_cohort) {
+    if constexpr (COHORT) {
 #pragma unroll
         for (uint32_t off = 32; off > 0; off >>= 1) {
             const uint32_t lo = __shfl_xor(amin, off, 64), hi = __shfl_xor(amax, off, 64);
@@ -962,7 +971,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     if (lane == 0) { s_died[wave] = died_total; s_lmin[wave] = loaded_all ? wave_min : -1.0f; }
     __syncthreads();
     if (tid == 0) {
-        if (args.age_cohort) {   // do the survivors share one age? (amin > amax: there are none)
+        if constexpr (COHORT) {   // do the survivors share one age? (amin > amax: there are none)
             uint32_t lo = 0xffffffffu, hi = 0u;
 #pragma unroll
             for (uint32_t w = 0; w < kBlock / 64; ++w) { lo = s_amin[w] < lo ? s_amin[w] : lo; hi = s_amax[w] > hi ? s_amax[w] : hi; }

@@ -126,7 +126,11 @@ k_sort_fill(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevM
     const uint32_t* age = a.age_plane == kNoPlane ? nullptr : reinterpret_cast<const uint32_t*>(base + a.age_plane);
     uint64_t or_all = 0ull, and_all = ~0ull, or_tail = 0ull, and_tail = ~0ull;
     auto key_of = [&](uint32_t slot) { return ((uint64_t)(rid ? rid[slot] : 0u) << 32) | (uint64_t)(age ? age[slot] : 0u); };
-    bool bad = false;  // is the HEAD (rows before this frame's spawns) still in non-decreasing key order? (was k_sort_check, a launch of its own)
+    // Is the HEAD (rows before this frame's spawns) still in non-decreasing key order? (It was a launch of its own, k_sort_check.) Every lane
+    // compares its key with its right neighbour's (a shuffle); the last lane of a wave has its neighbour in another wave or round: the first
+    // and last key of every (round, wave) go through LDS and are compared after the loop; only the tile's very last row looks at global memory.
+    __shared__ uint64_t s_first[kSortTile / kBlock][kBlock / 64], s_last[kSortTile / kBlock][kBlock / 64];
+    bool bad = false;
     for (uint32_t r = 0; r < kSortTile / kBlock; ++r) {
         const uint32_t i = j * kSortTile + r * kBlock + tid;
         const bool valid = i < n;
@@ -138,11 +142,22 @@ k_sort_fill(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevM
             or_all |= key; and_all &= key;
             if (i >= tail_lo) { or_tail |= key; and_tail &= key; }
         }
-        // the next row's key: the neighbouring lane's, or - for the last lane of a wave - fetched like our own
-        uint64_t next = (uint64_t)__shfl_down((unsigned long long)key, 1, 64);
-        if (lane == 63u && i + 1u < tail_lo) next = key_of(list[i + 1u]);
-        if (i + 1u < tail_lo) bad = bad || key > next;
-        if (j * kSortTile + (r + 1u) * kBlock >= n) break;  // (uniform: no further rows in this tile)
+        const uint64_t next = (uint64_t)__shfl_down((unsigned long long)key, 1, 64);
+        if (lane != 63u && i + 1u < tail_lo) bad = bad || key > next;
+        if (lane == 0u) s_first[r][wave] = key;
+        if (lane == 63u) s_last[r][wave] = key;
+    }
+    __syncthreads();
+    if (tid < (kSortTile / kBlock) * (kBlock / 64)) {   // one thread per (round, wave): its last row against the row that follows it
+        const uint32_t r = tid / (kBlock / 64), w = tid % (kBlock / 64);
+        const uint32_t i = j * kSortTile + r * kBlock + w * 64u + 63u;   // the row of that wave's last lane
+        if (i + 1u < tail_lo) {
+            uint64_t next;
+            if (w + 1u < kBlock / 64) next = s_first[r][w + 1u];
+            else if (r + 1u < kSortTile / kBlock) next = s_first[r + 1u][0];
+            else next = key_of(list[i + 1u]);                              // first row of the next tile
+            bad = bad || s_last[r][w] > next;
+        }
     }
     or_all = wave_or(or_all); and_all = wave_and(and_all); or_tail = wave_or(or_tail); and_tail = wave_and(and_tail);
     if (lane == 0) { s_acc[0][wave] = or_all; s_acc[1][wave] = and_all; s_acc[2][wave] = or_tail; s_acc[3][wave] = and_tail; }
