@@ -707,7 +707,7 @@ jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const
 extern "C" {
 
 const char* hnb_last_error(void) { return g_last_error.c_str(); }
-const char* hnb_version(void) { return "bevy_hanabi_amd 0.1.0 (gfx950)"; }
+const char* hnb_version(void) { return "bevy_hanabi_amd 0.2.0 (gfx950)"; }
 
 int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
     if (!out_ctx) return fail(HNB_ERR_INVALID_ARG, "out_ctx is NULL");

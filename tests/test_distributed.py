@@ -160,3 +160,24 @@ def test_two_rank_instance_sharding_equals_single_process():
         for f in range(INST_FRAMES):
             r.step(Frame(1 / 60, INST_CAP if f == 0 else 0, bench.instance_seed(f, g), np.array(bench.instance_transform(g), np.float32), time=f / 60))
         np.testing.assert_array_equal(r.state()["attrs"]["position"], got[g], err_msg=f"instance {g}")
+
+
+def test_bench_helpers_agree_with_the_oracle_and_the_profiles():
+    """bench.py restates the PCG hash for its seed lists and reads roofline.traffic from the committed PMC summary."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import oracle
+    for f in (0, 1, 7, 1000, 123456):
+        assert bench.frame_seed(f) == oracle.pcg_hash(0xC0FFEE + f)
+        assert bench.instance_seed(f, 0) == bench.frame_seed(f) and bench.instance_seed(f, 5) != bench.frame_seed(f)
+    assert set(bench.CONFIGS) == {"c2", "c3", "c4", "c5"} and bench.CONFIGS["c2"]["capacity"] == 16_777_216 and bench.CONFIGS["c2"]["bytes_per_update"] == 68
+    assert bench.CONFIGS["c3"]["capacity"] == 8_388_608 and bench.CONFIGS["c5"]["capacity"] == 4_194_304 and bench.CONFIGS["c4"]["instances"] * 8 == 4096
+    traffic, source = bench.load_traffic("c2", 1 << 24, 1)
+    table = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert traffic == table["c2:16777216x1"]["bytes_per_launch"] and 40 * (1 << 24) < traffic < 68 * (1 << 24)   # less than the algorithmic 68 B per update
+    assert os.path.exists(os.path.join(root, source.split(" + ")[0]))                                               # the CSV the number comes from is committed
+    assert bench.load_traffic("c2", 12345, 1) == (None, None)
+    assert bench.frame_dt(36) == bench.DT and bench.frame_dt(10_000) * 10_000 < bench.MIN_LIFETIME
