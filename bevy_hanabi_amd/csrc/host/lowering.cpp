@@ -21,7 +21,10 @@
 //  * age / reap / Euler placement (lib.rs:1106-1133, 1223-1258); PREV/NEXT = 0xffffffff at
 //    init and never written back by update (vfx_init.wgsl:176-181, lib.rs:1266-1281).
 #include <algorithm>
+#include <cmath>
+#include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <sstream>
 
@@ -34,6 +37,10 @@ struct Loc {
     bool uniform = false;  // U register (parameter block) vs V register (per particle)
     uint8_t reg = 0;
     ValueType type;
+    // WGSL abstract numeric (see "abstract numerics" below): no register yet, the value is a host-side constant
+    uint8_t abs = 0;  // 0: concrete, 1: AbstractInt (ai), 2: AbstractFloat (ad)
+    int64_t ai = 0;
+    double ad = 0.0;
 };
 
 [[noreturn]] void type_error(const std::string& msg) { throw ExprError(ExprError::TypeError, msg); }
@@ -179,9 +186,9 @@ class Lowerer {
     }
 
     // ---- literals -----------------------------------------------------------------------------------
-    Loc load_literal(const Value& v) {
+    Loc load_literal(const Value& v, bool as_written = true) {
         Value r = v;
-        if (v.type.elem == ScalarType::Float)
+        if (as_written && v.type.elem == ScalarType::Float)
             for (int i = 0; i < v.type.count; ++i) r.set_f(i, round_literal_f32(v.get_f(i)));
         std::array<uint32_t, 6> key = {(uint32_t)r.type.elem, r.type.count, 0, 0, 0, 0};
         for (int i = 0; i < r.type.count; ++i) key[2 + i] = r.bits[i];
@@ -196,6 +203,98 @@ class Lowerer {
         return l;
     }
     Loc lit_f32(float x) { return load_literal(Value(x)); }
+
+    // ---- abstract numerics ---------------------------------------------------------------------------
+    // `ToWgslString` writes a scalar f32 literal as `5.` / `0.1` and a scalar i32 literal as `-3` (src/lib.rs:264-269,
+    // 354-358): an AbstractFloat and an AbstractInt of WGSL. The front end evaluates expressions of abstract operands
+    // only in f64 / i64, converts an abstract operand to the type of the concrete operand it meets (AbstractInt -> i32,
+    // u32 or f32; AbstractFloat -> f32), and a `let` without a type concretises to i32 / f32. That is what makes
+    // examples/instancing.rs:274 (`RadialAccelModifier::new(origin, writer.lit(-3).expr())`) a valid effect. u32
+    // literals (`3u`), booleans and vector literals (`vec3<f32>(...)`) are concrete.
+    static Loc abstract_int(int64_t i) {
+        Loc l;
+        l.uniform = true;
+        l.type = ValueType(ScalarType::Int);
+        l.reg = 0xff;
+        l.abs = 1;
+        l.ai = i;
+        return l;
+    }
+    static Loc abstract_float(double d) {
+        if (!std::isfinite(d)) type_error("abstract float constant expression is not finite");
+        Loc l;
+        l.uniform = true;
+        l.type = ValueType(ScalarType::Float);
+        l.reg = 0xff;
+        l.abs = 2;
+        l.ad = d;
+        return l;
+    }
+    static double abs_d(const Loc& l) { return l.abs == 1 ? (double)l.ai : l.ad; }
+    // conversion of an abstract value to a concrete scalar type: materialised as a uniform constant
+    Loc conv(const Loc& l, ScalarType elem) {
+        if (!l.abs) return l;
+        if (l.abs == 2) {
+            if (elem != ScalarType::Float) type_error("an abstract float constant does not convert to " + ValueType(elem).to_string());
+            const float f = (float)l.ad;
+            if (!std::isfinite(f)) type_error("abstract float constant out of range for f32");
+            return load_literal(Value(f), false);
+        }
+        switch (elem) {
+            case ScalarType::Float: return load_literal(Value((float)l.ai), false);
+            case ScalarType::Int:
+                if (l.ai < INT32_MIN || l.ai > INT32_MAX) type_error("abstract int constant out of range for i32");
+                return load_literal(Value((int32_t)l.ai));
+            case ScalarType::Uint:
+                if (l.ai < 0 || l.ai > (int64_t)UINT32_MAX) type_error("abstract int constant out of range for u32");
+                return load_literal(Value((uint32_t)l.ai));
+            default: type_error("an abstract int constant does not convert to bool");
+        }
+    }
+    Loc conc(const Loc& l) { return l.abs ? conv(l, l.abs == 1 ? ScalarType::Int : ScalarType::Float) : l; }
+    // operands of one operator or constructor: abstract ones take the concrete one's element type; all abstract: f32 if
+    // any is a float, else i32
+    void unify(std::initializer_list<Loc*> v) {
+        bool have = false, any_float = false;
+        ScalarType elem = ScalarType::Int;
+        for (Loc* l : v) {
+            if (!l->abs) { if (!have) { elem = l->type.elem; have = true; } }
+            else if (l->abs == 2) any_float = true;
+        }
+        if (!have) elem = any_float ? ScalarType::Float : ScalarType::Int;
+        for (Loc* l : v) *l = conv(*l, elem);
+    }
+    // `l op r` with both operands abstract: i64 when both are ints, f64 otherwise
+    static Loc abstract_arith(BinaryOperator op, const Loc& l, const Loc& r) {
+        if (l.abs == 1 && r.abs == 1) {
+            const int64_t x = l.ai, y = r.ai;
+            int64_t z = 0;
+            bool bad = false;
+            switch (op) {
+                case BinaryOperator::Add: bad = __builtin_add_overflow(x, y, &z); break;
+                case BinaryOperator::Sub: bad = __builtin_sub_overflow(x, y, &z); break;
+                case BinaryOperator::Mul: bad = __builtin_mul_overflow(x, y, &z); break;
+                case BinaryOperator::Div: if (y == 0 || (x == INT64_MIN && y == -1)) bad = true; else z = x / y; break;
+                default: if (y == 0 || (x == INT64_MIN && y == -1)) bad = true; else z = x % y; break;
+            }
+            if (bad) type_error("abstract int constant expression overflows or divides by zero");
+            return abstract_int(z);
+        }
+        const double x = abs_d(l), y = abs_d(r);
+        switch (op) {
+            case BinaryOperator::Add: return abstract_float(x + y);
+            case BinaryOperator::Sub: return abstract_float(x - y);
+            case BinaryOperator::Mul: return abstract_float(x * y);
+            case BinaryOperator::Div: return abstract_float(x / y);
+            default: return abstract_float(std::fmod(x, y));
+        }
+    }
+    // a modifier parameter pasted into an expression of the template (`... * ({speed})`): an abstract value takes the
+    // type the expression asks for. Parameters the template binds with `let` first go through eval(), which concretises.
+    Loc eval_inline(Writer& w, ExprHandle h, ScalarType elem) {
+        const Loc l = eval_abs(w, h);
+        return l.abs ? conv(l, elem) : l;
+    }
     Loc delta_time_loc() {
         Expr e;
         e.kind = Expr::Kind::BuiltIn;
@@ -219,7 +318,8 @@ class Lowerer {
     }
 
     // ---- expression evaluation --------------------------------------------------------------------
-    Loc eval(Writer& w, ExprHandle h) {
+    Loc eval(Writer& w, ExprHandle h) { return conc(eval_abs(w, h)); }
+    Loc eval_abs(Writer& w, ExprHandle h) {
         const Expr& e = mod_.try_get(h);
         if (is_uniform(h)) {
             auto it = umemo_.find(h.id);
@@ -248,7 +348,14 @@ class Lowerer {
 
     Loc eval_node(Writer& w, ExprHandle h, const Expr& e, StreamId s) {
         switch (e.kind) {
-            case Expr::Kind::Literal: return load_literal(e.literal);
+            case Expr::Kind::Literal:
+                if (e.literal.type == ValueType(ScalarType::Int)) return abstract_int((int32_t)e.literal.bits[0]);
+                if (e.literal.type == ValueType(ScalarType::Float) && std::isfinite(e.literal.get_f(0))) {
+                    char buf[400];  // the f64 the front end reads back from the 6-decimal text
+                    std::snprintf(buf, sizeof buf, "%.6f", (double)e.literal.get_f(0));
+                    return abstract_float(std::strtod(buf, nullptr));
+                }
+                return load_literal(e.literal);
             case Expr::Kind::Property: {
                 const Property* p = mod_.get_property(e.property);
                 if (!p) throw ExprError(ExprError::PropertyError, "Unknown property handle in evaluation module.");
@@ -350,7 +457,17 @@ class Lowerer {
 
     Loc eval_unary(Writer& w, const Expr& e, StreamId s) {
         const int base = (int)vtop_;
-        const Loc x = eval(w, e.a);
+        Loc x = eval_abs(w, e.a);
+        if (x.abs) {
+            // abs() / sign() keep an integer an integer; the other builtins only exist for floats (AbstractInt ->
+            // AbstractFloat -> f32) or fail below on a scalar
+            switch (e.unary) {
+                case UnaryOperator::Abs: case UnaryOperator::Sign: case UnaryOperator::All: case UnaryOperator::Any:
+                case UnaryOperator::X: case UnaryOperator::Y: case UnaryOperator::Z: case UnaryOperator::W:
+                case UnaryOperator::Unpack4x8snorm: case UnaryOperator::Unpack4x8unorm: x = conc(x); break;
+                default: x = conv(x, ScalarType::Float); break;
+            }
+        }
         const ValueType t = x.type;
         auto float_only = [&](const char* name) { if (!t.is_float()) type_error(std::string(name) + "() requires a floating-point operand, got " + t.to_string()); };
         auto simple = [&](uint32_t op) { return emit_elementwise(s, op, t, &x, nullptr, nullptr, base); };
@@ -474,8 +591,44 @@ class Lowerer {
     Loc eval_binary(Writer& w, const Expr& e, StreamId s) {
         if (e.binary == BinaryOperator::UniformRand || e.binary == BinaryOperator::NormalRand) return eval_rand_binary(w, e, s);
         const int base = (int)vtop_;
-        const Loc l = eval(w, e.a);
-        const Loc r = eval(w, e.b);
+        Loc l = eval_abs(w, e.a);
+        Loc r = eval_abs(w, e.b);
+        if (l.abs || r.abs) {
+            const bool both = l.abs && r.abs;
+            switch (e.binary) {
+                case BinaryOperator::Add: case BinaryOperator::Sub: case BinaryOperator::Mul: case BinaryOperator::Div: case BinaryOperator::Remainder:
+                    if (both) return abstract_arith(e.binary, l, r);
+                    if (l.abs) l = conv(l, r.type.elem); else r = conv(r, l.type.elem);
+                    break;
+                case BinaryOperator::LessThan: case BinaryOperator::LessThanOrEqual: case BinaryOperator::GreaterThan: case BinaryOperator::GreaterThanOrEqual:
+                    if (both) {
+                        bool t;
+                        if (l.abs == 1 && r.abs == 1) {
+                            const int64_t x = l.ai, y = r.ai;
+                            t = e.binary == BinaryOperator::LessThan ? x < y : e.binary == BinaryOperator::LessThanOrEqual ? x <= y
+                                : e.binary == BinaryOperator::GreaterThan ? x > y : x >= y;
+                        } else {
+                            const double x = abs_d(l), y = abs_d(r);
+                            t = e.binary == BinaryOperator::LessThan ? x < y : e.binary == BinaryOperator::LessThanOrEqual ? x <= y
+                                : e.binary == BinaryOperator::GreaterThan ? x > y : x >= y;
+                        }
+                        return load_literal(Value(t));
+                    }
+                    unify({&l, &r});
+                    break;
+                case BinaryOperator::Max: case BinaryOperator::Min:
+                    if (both) {
+                        const bool mx = e.binary == BinaryOperator::Max;
+                        if (l.abs == 1 && r.abs == 1) return abstract_int(mx ? (l.ai < r.ai ? r.ai : l.ai) : (r.ai < l.ai ? r.ai : l.ai));
+                        const double x = abs_d(l), y = abs_d(r);
+                        return abstract_float(mx ? (x < y ? y : x) : (y < x ? y : x));
+                    }
+                    unify({&l, &r});
+                    break;
+                case BinaryOperator::Vec2: case BinaryOperator::Vec4XyzW: unify({&l, &r}); break;
+                default: l = conv(l, ScalarType::Float); r = conv(r, ScalarType::Float); break;  // step, atan2, cross, dot, distance: float only
+            }
+        }
         switch (e.binary) {
             case BinaryOperator::Add: { const ValueType t = arith_type(l, r, "+"); return emit_elementwise(s, pick(t.elem, HNB_OP_FADD, HNB_OP_IADD, HNB_OP_IADD, "+"), t, &l, &r, nullptr, base); }
             case BinaryOperator::Sub: { const ValueType t = arith_type(l, r, "-"); return emit_elementwise(s, pick(t.elem, HNB_OP_FSUB, HNB_OP_ISUB, HNB_OP_ISUB, "-"), t, &l, &r, nullptr, base); }
@@ -551,9 +704,16 @@ class Lowerer {
 
     Loc eval_ternary(Writer& w, const Expr& e, StreamId s) {
         const int base = (int)vtop_;
-        const Loc x = eval(w, e.a);
-        const Loc y = eval(w, e.b);
-        const Loc z = eval(w, e.c);
+        Loc x = eval_abs(w, e.a);
+        Loc y = eval_abs(w, e.b);
+        Loc z = eval_abs(w, e.c);
+        if (x.abs || y.abs || z.abs) {
+            if (e.ternary == TernaryOperator::Mix || e.ternary == TernaryOperator::SmoothStep) {
+                x = conv(x, ScalarType::Float); y = conv(y, ScalarType::Float); z = conv(z, ScalarType::Float);
+            } else {
+                unify({&x, &y, &z});  // clamp, vec3
+            }
+        }
         switch (e.ternary) {
             case TernaryOperator::Mix:
                 same_type(x, y, "mix()");
@@ -644,8 +804,8 @@ class Lowerer {
         pos.type = VectorType::VEC3F;
         pos.reg = HNB_REG_POSITION;
         const Expr& e = mod_.try_get(origin);
-        const Loc l = eval(w, e.a);
-        const Loc r = eval(w, e.b);
+        const Loc l = eval_inline(w, e.a, ScalarType::Float);
+        const Loc r = eval_inline(w, e.b, ScalarType::Float);
         const Loc t = emit_elementwise(s, HNB_OP_FSUB, arith_type(pos, l, "-"), &pos, &l, nullptr);
         return emit_elementwise(s, e.binary == BinaryOperator::Add ? HNB_OP_FADD : HNB_OP_FSUB, arith_type(t, r, "+"), &t, &r, nullptr);
     }
@@ -662,7 +822,8 @@ class Lowerer {
                     type_error(std::string("Mismatching expression type in SetAttributeModifer: attribute '") + upper(m.attribute.name()) +
                                "' requires an expression producing a value of type " + m.attribute.value_type().to_string() + ", but a value of type " +
                                known.to_string() + " was produced instead");
-                const Loc v = eval(main, m.e[0]);
+                Loc v = eval_abs(main, m.e[0]);  // `particle.A = <expr>;`: an abstract constant takes the attribute's type
+                if (v.abs) v = m.attribute.value_type().is_scalar() ? conv(v, m.attribute.value_type().elem) : conc(v);
                 if (v.type != m.attribute.value_type())
                     type_error(std::string("cannot assign a value of type ") + v.type.to_string() + " to attribute '" + upper(m.attribute.name()) + "' of type " +
                                m.attribute.value_type().to_string());
@@ -689,7 +850,9 @@ class Lowerer {
                 Writer fn{s, {}};
                 const Loc c = want(eval(fn, m.e[0]), VectorType::VEC3F, "circle center");
                 const Loc n = want(eval(fn, m.e[1]), VectorType::VEC3F, "circle axis");
-                const Loc r = want(eval(fn, m.e[2]), ValueType(ScalarType::Float), "circle radius");
+                // Surface: `let r = {radius};`, Volume: `let r = sqrt(frand()) * ({radius});` (position.rs:68-78)
+                const Loc r = want(m.dimension == ShapeDimension::Volume ? eval_inline(fn, m.e[2], ScalarType::Float) : eval(fn, m.e[2]),
+                                   ValueType(ScalarType::Float), "circle radius");
                 const Loc blk = make_block(s, {c, n, r});
                 touch(s, Attribute::POSITION, true);
                 emit(s, HNB_OP_M_POS_CIRCLE, 0, opnd(blk), opnd(blk), opnd(blk), 1, true, true, true, m.dimension == ShapeDimension::Volume ? 1u : 0u);
@@ -698,7 +861,8 @@ class Lowerer {
                 need(s, Attribute::POSITION, "SetPositionSphereModifier");
                 Writer fn{s, {}};
                 const Loc c = want(eval(fn, m.e[0]), VectorType::VEC3F, "sphere center");
-                const Loc r = want(eval(fn, m.e[1]), ValueType(ScalarType::Float), "sphere radius");
+                const Loc r = want(m.dimension == ShapeDimension::Volume ? eval_inline(fn, m.e[1], ScalarType::Float) : eval(fn, m.e[1]),
+                                   ValueType(ScalarType::Float), "sphere radius");  // position.rs:167-181
                 const Loc blk = make_block(s, {c, r});
                 touch(s, Attribute::POSITION, true);
                 emit(s, HNB_OP_M_POS_SPHERE, 0, opnd(blk), opnd(blk), opnd(blk), 1, true, true, true, m.dimension == ShapeDimension::Volume ? 1u : 0u);
@@ -722,7 +886,7 @@ class Lowerer {
                 Writer fn{s, {}};
                 const Loc c = want(eval(fn, m.e[0]), VectorType::VEC3F, "center/origin");
                 const Loc ax = want(eval(fn, m.e[1]), VectorType::VEC3F, "axis");
-                const Loc sp = want(eval(fn, m.e[2]), ValueType(ScalarType::Float), "speed");
+                const Loc sp = want(eval_inline(fn, m.e[2], ScalarType::Float), ValueType(ScalarType::Float), "speed");
                 const Loc blk = make_block(s, {c, ax, sp});
                 emit(s, m.kind == Modifier::Kind::SetVelocityCircle ? HNB_OP_M_VEL_CIRCLE : HNB_OP_M_VEL_TANGENT, 0, opnd(blk), opnd(blk), opnd(blk), 1,
                      true, true, true);
@@ -731,7 +895,7 @@ class Lowerer {
                 need(s, Attribute::POSITION, "SetVelocitySphereModifier");
                 need(s, Attribute::VELOCITY, "SetVelocitySphereModifier");
                 const Loc c = want(eval(main, m.e[0]), VectorType::VEC3F, "center");
-                const Loc sp = want(eval(main, m.e[1]), ValueType(ScalarType::Float), "speed");
+                const Loc sp = want(eval_inline(main, m.e[1], ScalarType::Float), ValueType(ScalarType::Float), "speed");
                 touch(s, Attribute::POSITION, false);
                 touch(s, Attribute::VELOCITY, true);
                 emit(s, HNB_OP_M_VEL_SPHERE, 0, opnd(c), opnd(sp), opnd(c), 1, true, true, true);
@@ -739,7 +903,7 @@ class Lowerer {
             case Modifier::Kind::Accel: {
                 // accel.rs:79-86: `velocity += (<accel>) * delta_time;`
                 need(s, Attribute::VELOCITY, "AccelModifier");
-                const Loc a = eval(main, m.e[0]);
+                const Loc a = eval_inline(main, m.e[0], ScalarType::Float);
                 Loc t = mul_dt(s, a);
                 if (t.type == ValueType(ScalarType::Float)) {  // vec3 += f32: scalar broadcast
                     Loc v = new_loc(t.uniform ? StreamId::Uniform : s, VectorType::VEC3F);
@@ -775,19 +939,19 @@ class Lowerer {
                         emit(s, HNB_OP_NORMALIZE, tn.reg, opnd(cr), opnd(cr), opnd(cr), 3, false, true, true);
                         dir = tn;
                     }
-                    const Loc acc = want(eval(wr, m.e[radial ? 1 : 2]), ValueType(ScalarType::Float), "acceleration");
+                    const Loc acc = want(eval_inline(wr, m.e[radial ? 1 : 2], ScalarType::Float), ValueType(ScalarType::Float), "acceleration");
                     const Loc sdt = mul_dt(s, acc);
                     const Loc dv = emit_elementwise(s, HNB_OP_FMUL, VectorType::VEC3F, &dir, &sdt, nullptr);
                     emit(s, HNB_OP_M_VEL_ADD, 0, opnd(dv), opnd(dv), opnd(dv), 1, true, true, true);
                 } else if (radial) {
                     const Loc o = want(eval(wr, m.e[0]), VectorType::VEC3F, "origin");
-                    const Loc acc = want(eval(wr, m.e[1]), ValueType(ScalarType::Float), "acceleration");
+                    const Loc acc = want(eval_inline(wr, m.e[1], ScalarType::Float), ValueType(ScalarType::Float), "acceleration");
                     const Loc sdt = mul_dt(s, acc);
                     emit(s, HNB_OP_M_RADIAL_ACCEL, 0, opnd(o), opnd(sdt), opnd(o), 1, true, true, true);
                 } else {
                     const Loc o = want(eval(wr, m.e[0]), VectorType::VEC3F, "origin");
                     const Loc ax = want(eval(wr, m.e[1]), VectorType::VEC3F, "axis");
-                    const Loc acc = want(eval(wr, m.e[2]), ValueType(ScalarType::Float), "acceleration");
+                    const Loc acc = want(eval_inline(wr, m.e[2], ScalarType::Float), ValueType(ScalarType::Float), "acceleration");
                     const Loc sdt = mul_dt(s, acc);
                     emit(s, HNB_OP_M_TANGENT_ACCEL, 0, opnd(o), opnd(ax), opnd(sdt), 1, true, true, true);
                 }
@@ -795,7 +959,7 @@ class Lowerer {
             case Modifier::Kind::LinearDrag: {
                 // force.rs:284-297: velocity *= max(0., (1.) - ((drag) * (delta_time)))
                 need(s, Attribute::VELOCITY, "LinearDragModifier");
-                const Loc drag = eval(main, m.e[0]);
+                const Loc drag = eval_inline(main, m.e[0], ScalarType::Float);
                 const Loc dt = delta_time_loc();
                 const StreamId ms = drag.uniform ? StreamId::Uniform : s;
                 const Loc drag_dt = emit_elementwise(ms, HNB_OP_FMUL, arith_type(drag, dt, "*"), &drag, &dt, nullptr);
@@ -819,7 +983,7 @@ class Lowerer {
                 const Loc shell = m.has_shell ? want(eval(fn, m.e[5]), F, "shell_half_thickness") : lit_f32(0.1f);
                 const Loc maxs = want(eval(fn, m.e[4]), F, "max_attraction_speed");
                 const Loc acc = want(eval(fn, m.e[3]), F, "attraction_accel");
-                const Loc sticky = m.has_sticky ? want(eval(fn, m.e[6]), F, "sticky_factor") : lit_f32(2.0f);
+                const Loc sticky = m.has_sticky ? want(eval_inline(fn, m.e[6], ScalarType::Float), F, "sticky_factor") : lit_f32(2.0f);
                 const Loc blk = make_block(s, {origin, radius, infl, shell, maxs, acc, sticky});
                 const Loc dt = delta_time_loc();
                 touch(s, Attribute::POSITION, false);
@@ -830,7 +994,7 @@ class Lowerer {
                 // kill.rs:76-96: dot(pos - center, pos - center) </> sqr_radius
                 need(s, Attribute::POSITION, "KillSphereModifier");
                 const Loc c = want(eval(main, m.e[0]), VectorType::VEC3F, "center");
-                const Loc r2 = want(eval(main, m.e[1]), ValueType(ScalarType::Float), "sqr_radius");
+                const Loc r2 = want(eval_inline(main, m.e[1], ScalarType::Float), ValueType(ScalarType::Float), "sqr_radius");
                 touch(s, Attribute::POSITION, false);
                 emit(s, HNB_OP_M_KILL_SPHERE, 0, opnd(c), opnd(r2), opnd(c), 1, true, true, true, m.kill_inside ? 1u : 0u);
             } break;

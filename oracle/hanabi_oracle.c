@@ -38,7 +38,10 @@
 enum { T_BOOL = 0, T_F32 = 1, T_I32 = 2, T_U32 = 3 };
 enum { A_ID = 0, A_PARTICLE_COUNTER = 1, A_POSITION = 2, A_VELOCITY = 3, A_AGE = 4, A_LIFETIME = 5, A_PREV = 12, A_NEXT = 13, A_RIBBON_ID = 38 };
 
-typedef struct { uint8_t elem, count; uint32_t b[4]; } Val;
+/* A value of the expression language. `abs` marks a WGSL abstract numeric (a scalar `5.` / `-3` literal of the emitted text, or a
+ * constant expression of such literals): b[0] then holds the default concretisation (f32 / i32) and b[1..2] the f64 / i64 payload. */
+enum { ABS_NONE = 0, ABS_INT = 1, ABS_FLOAT = 2 };
+typedef struct { uint8_t elem, count, abs; uint32_t b[4]; } Val;
 
 /* attribute table: name, elem type, component count (src/attributes.rs:549-675) */
 static const struct { const char* name; uint8_t elem, count; } k_attr[N_ATTRS] = {
@@ -245,6 +248,52 @@ static float round_literal(float x) {
     return (float)strtod(buf, NULL);
 }
 
+/* ---- WGSL abstract numerics ----------------------------------------------------------------------------
+ * `ToWgslString` writes a scalar f32 literal as `5.` / `0.1` and a scalar i32 literal as `-3` (src/lib.rs:264-269, 354-358): in WGSL
+ * these are an AbstractFloat and an AbstractInt. The front end (naga's constant evaluator) evaluates expressions whose operands are
+ * all abstract in f64 / i64, and converts an abstract operand to the type of the concrete one it meets (AbstractInt -> i32, u32, f32;
+ * AbstractFloat -> f32); a `let` without a type concretises to i32 / f32. u32 literals (`3u`), booleans and every vector literal
+ * (`vec3<f32>(...)`) are concrete. This is what lets examples/instancing.rs:274 pass `lit(-3)` as an acceleration. */
+static int64_t abs_i(const Val* v) { int64_t i; memcpy(&i, &v->b[1], 8); return i; }
+static double abs_d(const Val* v) { if (v->abs == ABS_INT) return (double)abs_i(v); double d; memcpy(&d, &v->b[1], 8); return d; }
+static Val abs_int(int64_t i) { Val v = mk(T_I32, 1); v.abs = ABS_INT; v.b[0] = (uint32_t)i; memcpy(&v.b[1], &i, 8); return v; }
+static Val abs_float(Ctx* c, double d) {
+    if (!(d - d == 0.0)) fail(c, "abstract float constant is not finite");
+    Val v = mk(T_F32, 1); v.abs = ABS_FLOAT; sf(&v, 0, (float)d); memcpy(&v.b[1], &d, 8); return v;
+}
+/* conversion of an abstract value to the concrete scalar type `elem` */
+static Val conv(Ctx* c, Val v, uint8_t elem) {
+    if (!v.abs) return v;
+    Val o = mk(elem, 1);
+    if (v.abs == ABS_FLOAT) {
+        if (elem != T_F32) { fail(c, "an abstract float does not convert to an integer or boolean type"); return o; }
+        const float f = (float)abs_d(&v);
+        if (!(f - f == 0.0f)) fail(c, "abstract float constant out of range for f32");
+        sf(&o, 0, f);
+        return o;
+    }
+    const int64_t i = abs_i(&v);
+    switch (elem) {
+        case T_F32: sf(&o, 0, (float)i); break;
+        case T_I32: if (i < INT32_MIN || i > INT32_MAX) fail(c, "abstract int constant out of range for i32"); o.b[0] = (uint32_t)(int32_t)i; break;
+        case T_U32: if (i < 0 || i > (int64_t)UINT32_MAX) fail(c, "abstract int constant out of range for u32"); o.b[0] = (uint32_t)i; break;
+        default: fail(c, "an abstract int does not convert to bool"); break;
+    }
+    return o;
+}
+/* default concretisation (`let x = 3;` is an i32, `let x = 3.;` an f32) */
+static Val conc(Ctx* c, Val v) { return v.abs ? conv(c, v, v.abs == ABS_INT ? T_I32 : T_F32) : v; }
+/* operands of one operator or constructor: abstract ones take the concrete one's element type; all abstract: f32 if any is a float, else i32 */
+static void unify(Ctx* c, Val** v, int n) {
+    int elem = -1, any_float = 0;
+    for (int i = 0; i < n; ++i) { if (!v[i]->abs) { if (elem < 0) elem = v[i]->elem; } else if (v[i]->abs == ABS_FLOAT) any_float = 1; }
+    if (elem < 0) elem = any_float ? T_F32 : T_I32;
+    for (int i = 0; i < n; ++i) *v[i] = conv(c, *v[i], (uint8_t)elem);
+}
+/* constant evaluation of `l op r` with both operands abstract: i64 when both are ints, f64 otherwise */
+static Val abs_arith(Ctx* c, uint32_t op, Val l, Val r);
+static int abs_compare(uint32_t op, const Val* l, const Val* r);
+
 /* PRNG (vfx_common.wgsl:278-343) */
 static float frand(Ctx* c) { c->seed = pcg_hash(c->seed); return to_float01(pcg_hash(c->seed)); }
 static Val frand_n(Ctx* c, int n) {
@@ -270,6 +319,8 @@ static int same_type(const Val* a, const Val* b) { return a->elem == b->elem && 
 
 /* component-wise binary arithmetic with WGSL scalar/vector broadcasting */
 static Val arith(Ctx* c, uint32_t op, Val l, Val r) {
+    if (l.abs && r.abs) return abs_arith(c, op, l, r);
+    if (l.abs) l = conv(c, l, r.elem); else if (r.abs) r = conv(c, r, l.elem);
     if (l.elem != r.elem || l.elem == T_BOOL || !(l.count == r.count || l.count == 1 || r.count == 1)) { fail(c, "type error in arithmetic"); return mkf(0); }
     const int n = l.count > r.count ? l.count : r.count;
     Val o = mk(l.elem, (uint8_t)n);
@@ -306,6 +357,35 @@ static Val arith(Ctx* c, uint32_t op, Val l, Val r) {
         }
     }
     return o;
+}
+static Val abs_arith(Ctx* c, uint32_t op, Val l, Val r) {
+    if (l.abs == ABS_INT && r.abs == ABS_INT) {
+        const int64_t x = abs_i(&l), y = abs_i(&r);
+        int64_t z = 0;
+        int bad = 0;
+        switch (op) {
+            case B_ADD: bad = __builtin_add_overflow(x, y, &z); break;
+            case B_SUB: bad = __builtin_sub_overflow(x, y, &z); break;
+            case B_MUL: bad = __builtin_mul_overflow(x, y, &z); break;
+            case B_DIV: if (y == 0 || (x == INT64_MIN && y == -1)) bad = 1; else z = x / y; break;
+            default: if (y == 0 || (x == INT64_MIN && y == -1)) bad = 1; else z = x % y; break;
+        }
+        if (bad) { fail(c, "abstract int constant expression overflows or divides by zero"); return abs_int(0); }
+        return abs_int(z);
+    }
+    const double x = abs_d(&l), y = abs_d(&r);
+    switch (op) {
+        case B_ADD: return abs_float(c, x + y);
+        case B_SUB: return abs_float(c, x - y);
+        case B_MUL: return abs_float(c, x * y);
+        case B_DIV: return abs_float(c, x / y);
+        default: return abs_float(c, fmod(x, y));
+    }
+}
+static int abs_compare(uint32_t op, const Val* l, const Val* r) {
+    if (l->abs == ABS_INT && r->abs == ABS_INT) { const int64_t x = abs_i(l), y = abs_i(r); return op == B_GT ? x > y : op == B_GE ? x >= y : op == B_LT ? x < y : x <= y; }
+    const double x = abs_d(l), y = abs_d(r);
+    return op == B_GT ? x > y : op == B_GE ? x >= y : op == B_LT ? x < y : x <= y;
 }
 static float dotf(const Val* a, const Val* b) {
     float s = vf(a, 0) * vf(b, 0);
@@ -352,6 +432,12 @@ static Val eval_node(Ctx* c, Memo* memo, const ExprRec* e) {
     const Asset* a = c->fx->asset;
     switch (e->kind) {
         case EK_LITERAL: {
+            if (e->vt_count == 1 && e->vt_elem == T_I32) return abs_int((int32_t)e->bits[0]);
+            if (e->vt_count == 1 && e->vt_elem == T_F32 && (u2f(e->bits[0]) - u2f(e->bits[0]) == 0.0f)) {
+                char buf[400]; /* the f64 the front end reads back from the 6-decimal text */
+                snprintf(buf, sizeof buf, "%.6f", (double)u2f(e->bits[0]));
+                return abs_float(c, strtod(buf, NULL));
+            }
             Val v = mk((uint8_t)e->vt_elem, (uint8_t)e->vt_count);
             for (int i = 0; i < v.count; ++i) v.b[i] = e->vt_elem == T_F32 ? f2u(round_literal(u2f(e->bits[i]))) : e->bits[i];
             return v;
@@ -395,6 +481,10 @@ static Val eval_node(Ctx* c, Memo* memo, const ExprRec* e) {
         }
         case EK_UNARY: {
             Val x = eval(c, memo, e->a);
+            /* abs() / sign() keep an integer an integer; every other builtin of the list only exists for floats
+             * (AbstractInt -> AbstractFloat -> f32), or fails below on a scalar */
+            if (x.abs) x = (e->op == U_ABS || e->op == U_SIGN || e->op == U_ALL || e->op == U_ANY || (e->op >= U_W && e->op <= U_Z) ||
+                            e->op == U_UNPACK4X8SNORM || e->op == U_UNPACK4X8UNORM) ? conc(c, x) : conv(c, x, T_F32);
             if (e->op >= U_W && e->op <= U_Z) {
                 const int idx = e->op == U_X ? 0 : e->op == U_Y ? 1 : e->op == U_Z ? 2 : 3;
                 if (x.count < 2 || idx >= x.count) { fail(c, "bad component access"); return mkf(0); }
@@ -459,8 +549,8 @@ static Val eval_node(Ctx* c, Memo* memo, const ExprRec* e) {
         case EK_BINARY: {
             if (e->op == B_UNIFORM_RAND || e->op == B_NORMAL_RAND) {
                 /* operands first (left, right), then the draw: rand_uniform_T(a, b) (expr.rs:1149-1190) */
-                Val l = eval(c, memo, e->a);
-                Val r = eval(c, memo, e->b);
+                Val l = conc(c, eval(c, memo, e->a));
+                Val r = conc(c, eval(c, memo, e->b));
                 uint8_t le, lc, re, rc;
                 if (!ref_value_type(a, e->a, &le, &lc) || !ref_value_type(a, e->b, &re, &rc)) { fail(c, "Can't determine the type of the operand"); return mkf(0); }
                 if (le != re || lc != rc) { fail(c, "Mismatched types"); return mkf(0); }
@@ -479,6 +569,26 @@ static Val eval_node(Ctx* c, Memo* memo, const ExprRec* e) {
             }
             Val l = eval(c, memo, e->a);
             Val r = eval(c, memo, e->b);
+            if (l.abs || r.abs) {
+                const int both = l.abs && r.abs;
+                switch (e->op) {
+                    case B_ADD: case B_SUB: case B_MUL: case B_DIV: case B_REM: break; /* arith() */
+                    case B_GT: case B_GE: case B_LT: case B_LE:
+                        if (both) { Val o = mk(T_BOOL, 1); o.b[0] = abs_compare(e->op, &l, &r) ? 1u : 0u; return o; }
+                        { Val* lr[2] = {&l, &r}; unify(c, lr, 2); }
+                        break;
+                    case B_MAX: case B_MIN:
+                        if (both) {
+                            if (l.abs == ABS_INT && r.abs == ABS_INT) { const int64_t x = abs_i(&l), y = abs_i(&r); return abs_int(e->op == B_MAX ? (x < y ? y : x) : (y < x ? y : x)); }
+                            const double x = abs_d(&l), y = abs_d(&r);
+                            return abs_float(c, e->op == B_MAX ? (x < y ? y : x) : (y < x ? y : x));
+                        }
+                        { Val* lr[2] = {&l, &r}; unify(c, lr, 2); }
+                        break;
+                    case B_VEC2: case B_VEC4_XYZ_W: { Val* lr[2] = {&l, &r}; unify(c, lr, 2); } break;
+                    default: l = conv(c, l, T_F32); r = conv(c, r, T_F32); break; /* step, atan2, cross, dot, distance: float only */
+                }
+            }
             switch (e->op) {
                 case B_ADD: case B_SUB: case B_MUL: case B_DIV: case B_REM: return arith(c, e->op, l, r);
                 case B_GT: case B_GE: case B_LT: case B_LE: {
@@ -537,6 +647,10 @@ static Val eval_node(Ctx* c, Memo* memo, const ExprRec* e) {
             Val x = eval(c, memo, e->a);
             Val y = eval(c, memo, e->b);
             Val z = eval(c, memo, e->c);
+            if (x.abs || y.abs || z.abs) {
+                if (e->op == TR_MIX || e->op == TR_SMOOTHSTEP) { x = conv(c, x, T_F32); y = conv(c, y, T_F32); z = conv(c, z, T_F32); }
+                else { Val* xyz[3] = {&x, &y, &z}; unify(c, xyz, 3); } /* clamp, vec3 */
+            }
             switch (e->op) {
                 case TR_MIX: {
                     if (!same_type(&x, &y) || x.elem != T_F32 || !(same_type(&x, &z) || (z.elem == T_F32 && z.count == 1))) { fail(c, "mix type error"); return mkf(0); }
@@ -567,7 +681,7 @@ static Val eval_node(Ctx* c, Memo* memo, const ExprRec* e) {
             }
         }
         case EK_CAST: {
-            Val x = eval(c, memo, e->a);
+            Val x = conc(c, eval(c, memo, e->a));
             const uint8_t te = (uint8_t)e->vt_elem, tc = (uint8_t)e->vt_count;
             if ((tc == 1 && x.count != 1) || (tc > 1 && x.count > 1 && x.count != tc)) { fail(c, "invalid cast"); return mkf(0); }
             Val o = mk(te, tc);
@@ -598,10 +712,16 @@ static Val eval(Ctx* c, Memo* memo, uint32_t handle) {
     return v;
 }
 
+/* A modifier parameter whose text is pasted into an expression of the template (`... * ({speed})`): an abstract value takes the type
+ * the expression asks for. want_let(): the template binds it first (`let r = {radius};`), which concretises it to i32 / f32. */
 static Val want(Ctx* c, Val v, uint8_t elem, uint8_t count, const char* what) {
+    if (v.abs && count == 1) v = conv(c, v, elem);
+    v = conc(c, v);
     if (v.elem != elem || v.count != count) { fail(c, what); return mk(elem, count); }
     return v;
 }
+
+static Val want_let(Ctx* c, Val v, uint8_t elem, uint8_t count, const char* what) { return want(c, conc(c, v), elem, count, what); }
 
 /* One modifier's emitted statement(s), executed for the current particle. */
 static void apply_modifier(Ctx* c, Memo* main, const ModRec* m) {
@@ -609,6 +729,8 @@ static void apply_modifier(Ctx* c, Memo* main, const ModRec* m) {
     const float dt = c->sim[1];
     switch (m->kind) {
         case MK_SET_ATTRIBUTE: { /* attr.rs:92-115: particle.A = <expr>; */
+            uint8_t ke, kc; /* the Rust-side check on expressions of known type comes first (attr.rs:97-107) */
+            if (ref_value_type(c->fx->asset, m->e[0], &ke, &kc) && (ke != k_attr[m->attr].elem || kc != k_attr[m->attr].count)) { fail(c, "SetAttributeModifier type mismatch"); break; }
             Val v = eval(c, main, m->e[0]);
             p->v[m->attr] = want(c, v, k_attr[m->attr].elem, k_attr[m->attr].count, "SetAttributeModifier type mismatch");
         } break;
@@ -616,7 +738,8 @@ static void apply_modifier(Ctx* c, Memo* main, const ModRec* m) {
             MEMO_ON_STACK(fn, c->fx->asset->n_exprs);
             Val ce = want(c, eval(c, fn, m->e[0]), T_F32, 3, "circle center");
             Val n = want(c, eval(c, fn, m->e[1]), T_F32, 3, "circle axis");
-            Val radius = want(c, eval(c, fn, m->e[2]), T_F32, 1, "circle radius");
+            /* Surface: `let r = {radius};`, Volume: `let r = sqrt(frand()) * ({radius});` (position.rs:68-78) */
+            Val radius = (m->dimension == 1 ? want : want_let)(c, eval(c, fn, m->e[2]), T_F32, 1, "circle radius");
             const float sign = f_step(0.0f, vf(&n, 2)) * 2.0f - 1.0f;
             const float a = -1.0f / (sign + vf(&n, 2));
             const float b = vf(&n, 0) * vf(&n, 1) * a;
@@ -630,7 +753,7 @@ static void apply_modifier(Ctx* c, Memo* main, const ModRec* m) {
         case MK_SET_POSITION_SPHERE: { /* position.rs:152-210 */
             MEMO_ON_STACK(fn, c->fx->asset->n_exprs);
             Val ce = want(c, eval(c, fn, m->e[0]), T_F32, 3, "sphere center");
-            Val radius = want(c, eval(c, fn, m->e[1]), T_F32, 1, "sphere radius");
+            Val radius = (m->dimension == 1 ? want : want_let)(c, eval(c, fn, m->e[1]), T_F32, 1, "sphere radius"); /* position.rs:167-181 */
             const float r = m->dimension == 1 ? f_pow(frand(c), (float)(1. / 3.)) * (vf(&radius, 0)) : vf(&radius, 0);
             const float theta = frand(c) * TAU;
             const float z = frand(c) * 2.f - 1.f;
@@ -644,9 +767,9 @@ static void apply_modifier(Ctx* c, Memo* main, const ModRec* m) {
         case MK_SET_POSITION_CONE3D: { /* position.rs:267-324; e = {height, base_radius, top_radius} */
             if (!c->is_init) { fail(c, "transform is not defined in the update shader"); break; }
             MEMO_ON_STACK(fn, c->fx->asset->n_exprs);
-            Val h0 = want(c, eval(c, fn, m->e[0]), T_F32, 1, "cone height");
-            Val rt = want(c, eval(c, fn, m->e[2]), T_F32, 1, "cone top radius");
-            Val rb = want(c, eval(c, fn, m->e[1]), T_F32, 1, "cone base radius");
+            Val h0 = want_let(c, eval(c, fn, m->e[0]), T_F32, 1, "cone height");
+            Val rt = want_let(c, eval(c, fn, m->e[2]), T_F32, 1, "cone top radius");
+            Val rb = want_let(c, eval(c, fn, m->e[1]), T_F32, 1, "cone base radius");
             const float alpha_h = f_pow(frand(c), (float)(1.0 / 3.0));
             const float h = vf(&h0, 0) * alpha_h;
             const float r0 = vf(&rb, 0) + (vf(&rt, 0) - vf(&rb, 0)) * alpha_h;
@@ -735,11 +858,11 @@ static void apply_modifier(Ctx* c, Memo* main, const ModRec* m) {
         case MK_CONFORM_TO_SPHERE: { /* force.rs:175-238; e = {origin, radius, influence_dist, attraction_accel, max_attraction_speed, shell, sticky} */
             MEMO_ON_STACK(fn, c->fx->asset->n_exprs);
             Val ce = want(c, eval(c, fn, m->e[0]), T_F32, 3, "origin");
-            Val radius = want(c, eval(c, fn, m->e[1]), T_F32, 1, "radius");
-            Val infl = want(c, eval(c, fn, m->e[2]), T_F32, 1, "influence_dist");
-            const float shell_half_thickness = (m->flags & 1u) ? vf((Val[]){want(c, eval(c, fn, m->e[5]), T_F32, 1, "shell")}, 0) : 0.1f;
-            Val maxs = want(c, eval(c, fn, m->e[4]), T_F32, 1, "max_attraction_speed");
-            Val acc = want(c, eval(c, fn, m->e[3]), T_F32, 1, "attraction_accel");
+            Val radius = want_let(c, eval(c, fn, m->e[1]), T_F32, 1, "radius");
+            Val infl = want_let(c, eval(c, fn, m->e[2]), T_F32, 1, "influence_dist");
+            const float shell_half_thickness = (m->flags & 1u) ? vf((Val[]){want_let(c, eval(c, fn, m->e[5]), T_F32, 1, "shell")}, 0) : 0.1f;
+            Val maxs = want_let(c, eval(c, fn, m->e[4]), T_F32, 1, "max_attraction_speed");
+            Val acc = want_let(c, eval(c, fn, m->e[3]), T_F32, 1, "attraction_accel");
             const float sticky = (m->flags & 2u) ? vf((Val[]){want(c, eval(c, fn, m->e[6]), T_F32, 1, "sticky")}, 0) : 2.0f;
             Val rel_pos = arith(c, B_SUB, ce, p->v[A_POSITION]);
             const float origin_dist = f_sqrt(dotf(&rel_pos, &rel_pos));
@@ -781,7 +904,7 @@ static void apply_modifier(Ctx* c, Memo* main, const ModRec* m) {
             p->v[m->attr] = c->parent->v[m->attr];
             break;
         case MK_EMIT_SPAWN_EVENT: { /* modifier/mod.rs:669-695 */
-            Val cnt = eval(c, main, m->e[0]);          /* `let count = <expr>;` evaluated unconditionally */
+            Val cnt = conc(c, eval(c, main, m->e[0])); /* `let count = <expr>;` evaluated unconditionally */
             if (cnt.elem != T_U32 || cnt.count != 1) { fail(c, "EmitSpawnEventModifier count must be u32"); break; }
             if (m->child_index >= MAX_CHANNELS) { fail(c, "event channel out of range"); break; }
             const int fire = m->condition == 1 ? (c->was_alive && !c->is_alive) : c->is_alive;  /* OnDie : Always */
