@@ -16,6 +16,9 @@ def main():
 
     assets = [effects.single_particle(16), effects.firework_trails(4096), effects.force_field(4096), effects.instancing(4096), effects.ribbon(4096)]
     assets += [effects.firework_rocket(), effects.firework_sparkle_trail(), effects.firework_trails_child()]
+    from bevy_hanabi_amd import reference_examples
+    for entries in reference_examples.catalog().values():
+        assets += [e.asset for e in entries]
     try:
         from test_lowering_cpu import ZOO
         assets += [ZOO[k]() for k in sorted(ZOO)]
