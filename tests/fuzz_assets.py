@@ -21,7 +21,8 @@ BINARY = ["add", "sub", "mul", "min", "max", "step"]
 
 
 class Gen:
-    def __init__(self, seed):
+    def __init__(self, seed, abstract=False):
+        self.abstract = abstract   # also generate i32 literals where another scalar type is expected (WGSL AbstractInt)
         self.rng = np.random.default_rng(seed)
         self.w = h.ExprWriter()
         self.readable = {}   # width -> attributes holding a value at this point
@@ -33,6 +34,8 @@ class Gen:
 
     def leaf(self, width, ctx):
         r = self.rng.random()
+        if self.abstract and r < 0.035 and width == 1:   # an i32 literal where a float is expected: `-3` is an AbstractInt in the emitted WGSL
+            return self.w.lit(int(self.rng.integers(-4, 5)))
         if r < 0.30:
             return self.lit(width)
         if r < 0.55:
@@ -153,8 +156,8 @@ class Gen:
         return asset
 
 
-def random_asset(seed, capacity=400):
-    return Gen(seed).asset(capacity)
+def random_asset(seed, capacity=400, abstract=False):
+    return Gen(seed, abstract).asset(capacity)
 
 
 def random_frames(seed, capacity, n=36):
@@ -210,6 +213,8 @@ class TypedGen(Gen):
         if (kind, width) in self.treadable and r < 0.8:
             pool = self.treadable[(kind, width)]
             return self.w.attr(pool[int(self.rng.integers(len(pool)))])
+        if self.abstract and kind == "u" and width == 1 and r > 0.93:   # an AbstractInt next to u32 operands
+            return self.w.lit(int(self.rng.integers(0, 12)))
         return self.tlit(kind, width)
 
     def texpr(self, kind, width, depth, ctx):
@@ -324,5 +329,5 @@ class TypedGen(Gen):
         return asset
 
 
-def random_typed_asset(seed, capacity=300):
-    return TypedGen(seed).asset(capacity)
+def random_typed_asset(seed, capacity=300, abstract=False):
+    return TypedGen(seed, abstract).asset(capacity)

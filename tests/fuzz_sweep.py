@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--backend", choices=["gpu", "cpu_vm"], default="gpu")
     ap.add_argument("--jit", choices=["0", "1"], default="1")
     ap.add_argument("--typed", action="store_true")
+    ap.add_argument("--abstract", action="store_true", help="i32 literals where floats / u32 are expected (WGSL AbstractInt)")
     ap.add_argument("--seeds", default="0:100")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--capacity", type=int, default=None, help="particles per effect (default: the generators' 300-400); >= 4096 covers completely alive chunks")
@@ -33,12 +34,25 @@ def main():
     bad = skipped = 0
     t0 = time.time()
     for seed in range(lo, hi):
-        asset = (random_typed_asset if args.typed else random_asset)(seed) if args.capacity is None else (random_typed_asset if args.typed else random_asset)(seed, args.capacity)
+        gen = random_typed_asset if args.typed else random_asset
+        asset = gen(seed, abstract=args.abstract) if args.capacity is None else gen(seed, args.capacity, abstract=args.abstract)
         try:
             bh.lower(asset)
-        except (bh.ExprError, bh.ShaderGenerateError) as e:
+        except bh.ShaderGenerateError as e:
             skipped += 1
             print(f"seed {seed}: not lowered: {e}")
+            continue
+        except bh.ExprError as e:   # a type error: the oracle has to refuse the asset too
+            skipped += 1
+            import oracle
+            o = OracleRunner(asset)
+            try:
+                for fr in random_frames(seed, asset.capacity, n=args.frames):
+                    o.step(fr)
+                bad += 1
+                print(f"seed {seed}: MISMATCH the lowering rejects ({e}) what the oracle runs")
+            except oracle.OracleError:
+                print(f"seed {seed}: rejected by both: {e}")
             continue
         runner = GpuRunner(asset, ctx=ctx) if ctx else CpuVmRunner(asset)
         try:

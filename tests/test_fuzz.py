@@ -11,13 +11,21 @@ CPU_SEEDS = list(range(60))
 GPU_SEEDS = list(range(100, 124))
 
 
-def _run(seed, make_runner):
-    asset = random_asset(seed)
+def _run(seed, make_runner, abstract=False):
+    asset = random_asset(seed, abstract=abstract)
     try:
         blob = bh.lower(asset)
-    except (bh.ExprError, bh.ShaderGenerateError) as e:
+    except bh.ShaderGenerateError as e:
         # register pressure of a deep random tree: a lowering error, never a wrong result; the oracle agrees it is an asset
         pytest.skip(f"seed {seed}: {e}")
+    except bh.ExprError as e:
+        # a type error of the expression language: the oracle has to refuse the same asset
+        import oracle
+        o = OracleRunner(asset)
+        with pytest.raises(oracle.OracleError):
+            for fr in random_frames(seed, asset.capacity):
+                o.step(fr)
+        pytest.skip(f"seed {seed}: rejected by both: {e}")
     bh.validate_program(blob)
     run_script(make_runner(asset), random_frames(seed, asset.capacity), OracleRunner(asset), every=6)
 
@@ -171,10 +179,20 @@ TYPED_CPU_SEEDS = list(range(2000, 2060))
 TYPED_GPU_SEEDS = list(range(2100, 2116))
 
 
-def _run_typed(seed, make_runner):
+def _run_typed(seed, make_runner, abstract=False):
     from fuzz_assets import random_typed_asset
-    asset = random_typed_asset(seed)
-    bh.validate_program(bh.lower(asset))
+    asset = random_typed_asset(seed, abstract=abstract)
+    try:
+        bh.validate_program(bh.lower(asset))
+    except bh.ExprError as e:
+        if not abstract:
+            raise
+        import oracle   # an int literal the WGSL would not accept there: the oracle has to refuse the asset too
+        o = OracleRunner(asset)
+        with pytest.raises(oracle.OracleError):
+            for fr in random_frames(seed, asset.capacity, n=24):
+                o.step(fr)
+        pytest.skip(f"seed {seed}: rejected by both: {e}")
     run_script(make_runner(asset), random_frames(seed, asset.capacity, n=24), OracleRunner(asset), every=4)
 
 
@@ -196,6 +214,34 @@ def test_fuzz_typed_gpu(ctx, seed, jit, monkeypatch):
 
     try:
         _run_typed(seed, mk)
+    finally:
+        if "g" in holder:
+            holder["g"].prog.destroy()
+
+
+# ---- i32 literals where floats / u32 are expected (WGSL abstract numerics, tests/test_abstract_numerics.py) --------------------
+ABSTRACT_SEEDS = list(range(3000, 3050))
+
+
+@pytest.mark.parametrize("seed", ABSTRACT_SEEDS)
+def test_fuzz_abstract_literals_cpu(seed):
+    if seed % 2:
+        _run_typed(seed, lambda a: CpuVmRunner(a), abstract=True)
+    else:
+        _run(seed, lambda a: CpuVmRunner(a), abstract=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", ABSTRACT_SEEDS[:16])
+def test_fuzz_abstract_literals_gpu(ctx, seed):
+    holder = {}
+
+    def mk(a):
+        holder["g"] = GpuRunner(a, ctx=ctx)
+        return holder["g"]
+
+    try:
+        (_run_typed if seed % 2 else _run)(seed, mk, abstract=True)
     finally:
         if "g" in holder:
             holder["g"].prog.destroy()
