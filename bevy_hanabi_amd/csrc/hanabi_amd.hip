@@ -99,6 +99,14 @@ struct HnbContext {
     hipStream_t stream = nullptr;       // the stream hnb_simulate enqueues on: own_stream or the caller's (hnb_ctx_set_stream)
     hipStream_t own_stream = nullptr;   // created with the context, lives as long as it does
     hipStream_t upload_stream = nullptr;  // per-frame parameter uploads, overlapped with the previous frame's kernels
+    // The per-frame parameters of EVERY program (instance rows, uniform blocks, init block starts) are staged in one pinned buffer and go to the
+    // device with one copy per frame: with a copy per program, a scene of 26 small effects spent a quarter of its frame in 26 serialised
+    // 3.5 us copy kernels and the host waiting for them (profiles/r02u_scene.md). A ring of slots: the host fills slot f % kFrameRing while the
+    // device still reads the slots of the frames before.
+    void* h_stage[kFrameRing] = {};
+    void* d_stage[kFrameRing] = {};
+    size_t stage_bytes = 0;
+    hipEvent_t stage_done[kFrameRing] = {};  // recorded on the simulation stream after the frame that used the slot
     uint32_t num_cus = 256;
     std::vector<HnbProgram*> programs;
     HnbSimParams sim{};
@@ -152,9 +160,9 @@ struct HnbProgram {
     uint32_t* d_counts = nullptr;  // per chunk: survivors this frame
     uint32_t* d_deaths = nullptr;  // [2][table_cap]: casualties per instance, frame-parity double-buffered
     // per-frame parameter blocks: a ring, so that filling frame f+1..f+3 never waits for the GPU
-    void* h_frame[kFrameRing] = {};
-    void* d_frame[kFrameRing] = {};
-    hipEvent_t kernels_done[kFrameRing] = {};  // recorded on the simulation stream after the frame that used the slot
+    bool lists_now = true;               // this frame needs k_list_rows / k_compact (false: the update rotated the counters itself)
+    bool lists_merged = false;           // ... and they are served by the context's multi-program launches after every update kernel
+    const char* d_frame_cur = nullptr;  // this frame's parameter block of the program inside the context's staging slot (HnbContext::d_stage)
     uint32_t ring = 0;          // slot of the next frame
     uint32_t init_blocks = 0;   // k_init grid of the frame being enqueued
     size_t frame_bytes = 0;
@@ -533,11 +541,6 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
 void free_tables(HnbProgram* p) {
     hipFree(p->d_inst_base); p->d_inst_base = nullptr;
     for (int i = 0; i < 2; ++i) { hipFree(p->d_meta[i]); p->d_meta[i] = nullptr; }
-    for (uint32_t i = 0; i < kFrameRing; ++i) {
-        hipFree(p->d_frame[i]); p->d_frame[i] = nullptr;
-        if (p->h_frame[i]) hipHostFree(p->h_frame[i]);
-        p->h_frame[i] = nullptr;
-    }
     hipFree(p->d_counts); p->d_counts = nullptr;
     hipFree(p->d_deaths); p->d_deaths = nullptr;
     hipFree(p->d_ev_totals); p->d_ev_totals = nullptr;
@@ -606,16 +609,7 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
         HIP_TRY(hipMemcpy(p->d_safe, inf.data(), inf.size() * 4, hipMemcpyHostToDevice));
         p->dirty = true;
     }
-    const size_t fb = frame_bytes_for(p, cap);
-    for (uint32_t i = 0; i < kFrameRing; ++i) {
-        hipFree(p->d_frame[i]);
-        if (p->h_frame[i]) hipHostFree(p->h_frame[i]);
-        p->d_frame[i] = nullptr; p->h_frame[i] = nullptr;
-        HIP_TRY(hipMalloc(&p->d_frame[i], fb));
-        HIP_TRY(hipHostMalloc(&p->h_frame[i], fb, hipHostMallocDefault));
-        if (!p->kernels_done[i]) HIP_TRY(hipEventCreateWithFlags(&p->kernels_done[i], hipEventDisableTiming));
-    }
-    p->frame_bytes = fb;
+    p->frame_bytes = frame_bytes_for(p, cap);
     p->table_cap = cap;
     return HNB_OK;
 }
@@ -740,6 +734,11 @@ int hnb_ctx_destroy(HnbContext* ctx) {
     for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     if (ctx->upload_stream) hipStreamDestroy(ctx->upload_stream);
+    for (uint32_t i = 0; i < kFrameRing; ++i) {
+        hipFree(ctx->d_stage[i]);
+        if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
+        if (ctx->stage_done[i]) hipEventDestroy(ctx->stage_done[i]);
+    }
     delete ctx;
     return HNB_OK;
 }
@@ -904,8 +903,6 @@ int hnb_program_destroy(HnbProgram* p) {
     hipStreamSynchronize(ctx->stream);
     while (!p->effects.empty()) hnb_effect_destroy(p->effects.back());
     free_tables(p);
-    for (uint32_t i = 0; i < kFrameRing; ++i)
-        if (p->kernels_done[i]) hipEventDestroy(p->kernels_done[i]);
     if (p->jit_module) hipModuleUnload(p->jit_module);
     for (auto& blk : p->slab_blocks) hipFree(blk.base);
     hipFree(p->d_plane_by_attr);
@@ -1204,6 +1201,25 @@ int hnb_effect_set_property(HnbEffect* fx, const char* name, const void* value, 
     return fail(HNB_ERR_NOT_FOUND, "unknown property '%s'", name);
 }
 
+static CompactBufs compact_bufs_of(const HnbContext* ctx, const HnbProgram* p, uint32_t n) {
+    CompactBufs cb;
+    cb.counts = p->d_counts;
+    cb.deaths = p->d_deaths;
+    cb.table_cap = p->table_cap;
+    cb.parity = p->parity;
+    cb.ev_totals = p->d_ev_totals;
+    cb.xcd_remap = (n > 1 ? 1u : 0u) | (ctx->alternate && !(p->frames_run & 1u) ? 2u : 0u);  // see chunk_of_workgroup; the first frame walks DOWN: a burst's init wrote the planes upwards
+    return cb;
+}
+static CompactArgs compact_args_of(const HnbProgram* p) {
+    CompactArgs ca{};
+    ca.capacity = p->dev.capacity; ca.chunks_per_inst = p->dev.chunks_per_inst;
+    ca.alive_off[0] = p->dev.alive_off[0]; ca.alive_off[1] = p->dev.alive_off[1]; ca.dead_off = p->dev.dead_off;
+    ca.alive_flag_off = p->dev.alive_flag_off;
+    ca.slot_order = p->slot_order ? 1u : 0u;
+    return ca;
+}
+
 // One simulated frame, in the reference's order (src/render/mod.rs:6975-7370): every effect's init
 // pass, parents before children, THEN every effect's update pass. Spawn events appended by a parent's
 // update in frame N are consumed by its children's init in frame N+1.
@@ -1226,11 +1242,34 @@ int hnb_simulate(HnbContext* ctx) {
     // ---- per-frame parameters: filled into the program's next ring slot and uploaded on the upload stream. The host
     // waits for the (tiny) copies itself, so the simulation stream carries no cross-stream wait: such a wait costs an
     // ~11 us bubble in front of every frame's first kernel (measured), the host has ~200 us of slack per frame.
+    const uint32_t slot = ctx->frame % kFrameRing;
+    {
+        size_t need = 0;
+        for (const HnbProgram* p : order) need += (frame_bytes_for(p, (uint32_t)p->effects.size()) + 255u) & ~(size_t)255u;
+        need += order.size() * sizeof(ListsJob) + 256u;   // the job table of the multi-program list launches
+        if (need > ctx->stage_bytes) {  // grows rarely (a new program, more instances): nothing may still be reading the old buffers
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            const size_t nb = std::max<size_t>(2 * need, 64u << 10);
+            for (uint32_t i = 0; i < kFrameRing; ++i) {
+                hipFree(ctx->d_stage[i]); ctx->d_stage[i] = nullptr;
+                if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
+                ctx->h_stage[i] = nullptr;
+            }
+            ctx->stage_bytes = 0;
+            for (uint32_t i = 0; i < kFrameRing; ++i) {
+                HIP_TRY(hipMalloc(&ctx->d_stage[i], nb));
+                HIP_TRY(hipHostMalloc(&ctx->h_stage[i], nb, hipHostMallocDefault));
+                if (!ctx->stage_done[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
+            }
+            ctx->stage_bytes = nb;
+        }
+        if (!order.empty()) HIP_TRY(hipEventSynchronize(ctx->stage_done[slot]));  // the frame that last used this slot (kFrameRing frames ago)
+    }
+    size_t stage_off = 0;
     for (HnbProgram* p : order) {
         const uint32_t n = (uint32_t)p->effects.size();
-        const uint32_t slot = p->ring % kFrameRing;
-        HIP_TRY(hipEventSynchronize(p->kernels_done[slot]));  // the frame that last used this slot (kFrameRing frames ago)
-        char* h = static_cast<char*>(p->h_frame[slot]);
+        char* h = static_cast<char*>(ctx->h_stage[slot]) + stage_off;
+        p->d_frame_cur = static_cast<const char*>(ctx->d_stage[slot]) + stage_off;
         DevFrameInst* fi = reinterpret_cast<DevFrameInst*>(h);
         uint32_t* ublocks = reinterpret_cast<uint32_t*>(h + (size_t)n * sizeof(DevFrameInst));
         const float sim[6] = {ctx->sim.time, ctx->sim.delta_time, ctx->sim.virtual_time, ctx->sim.virtual_delta_time,
@@ -1325,21 +1364,55 @@ int hnb_simulate(HnbContext* ctx) {
                 }
             }
         }
+        p->lists_now = !(p->update_streams && p->skip_now);  // false: proven no spawn, no casualty; the update kernel rotates the counters
+        p->lists_merged = false;
         uint32_t* init_start = ublocks + (size_t)n * nu;  // packed copy of init_block_start for k_init's search
         for (uint32_t i = 0; i < n; ++i) init_start[i] = fi[i].init_block_start;
-        const size_t bytes = (size_t)n * sizeof(DevFrameInst) + (size_t)n * nu * 4 + (size_t)n * 4;
-        HIP_TRY(hipMemcpyAsync(p->d_frame[slot], h, bytes, hipMemcpyHostToDevice, ctx->upload_stream));
+        stage_off += (frame_bytes_for(p, n) + 255u) & ~(size_t)255u;
         p->init_blocks = blocks;
         p->dev.n_inst = n;
     }
-    HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
+    // Programs whose list kernels can share two launches (see ListsJob in hnb_kernels.hip.h): every program that needs its lists, except the
+    // slot-ordered ones (two more kernels of their own). Worth it from two programs on; timed frames keep one launch pair per program so that
+    // the per-program timings stay attributable.
+    const ListsJob* d_jobs = nullptr;
+    uint32_t n_jobs = 0, job_wgs = 0;
+    {
+        uint32_t candidates = 0;
+        for (const HnbProgram* p : order) candidates += (p->lists_now && !p->slot_order) ? 1u : 0u;
+        if (candidates >= 2u && !timed) {
+            ListsJob* jobs = reinterpret_cast<ListsJob*>(static_cast<char*>(ctx->h_stage[slot]) + stage_off);
+            d_jobs = reinterpret_cast<const ListsJob*>(static_cast<const char*>(ctx->d_stage[slot]) + stage_off);
+            for (HnbProgram* p : order) {
+                if (!(p->lists_now && !p->slot_order)) continue;
+                const uint32_t n = (uint32_t)p->effects.size();
+                ListsJob jb{};
+                jb.args = compact_args_of(p);
+                jb.cb = compact_bufs_of(ctx, p, n);
+                jb.inst_base = reinterpret_cast<const uint64_t*>(p->d_inst_base);
+                jb.meta_in = p->d_meta[p->parity];
+                jb.meta_out = p->d_meta[p->parity ^ 1u];
+                jb.fi = reinterpret_cast<const DevFrameInst*>(p->d_frame_cur);
+                jb.first_wg = job_wgs;
+                jb.n_wg = n * p->dev.chunks_per_inst;
+                job_wgs += jb.n_wg;
+                jobs[n_jobs++] = jb;
+                p->lists_merged = true;
+            }
+            stage_off += ((size_t)n_jobs * sizeof(ListsJob) + 255u) & ~(size_t)255u;
+        }
+    }
+    if (stage_off) {
+        HIP_TRY(hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], stage_off, hipMemcpyHostToDevice, ctx->upload_stream));
+        HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
+    }
 
     // ---- phase A: init passes, parents first ---------------------------------------------------------------
     for (HnbProgram* p : order) {
         const uint32_t n = (uint32_t)p->effects.size();
         const uint32_t par = p->parity;
         const uint32_t blocks = p->init_blocks;
-        const char* d = static_cast<const char*>(p->d_frame[p->ring % kFrameRing]);
+        const char* d = p->d_frame_cur;
         const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
         const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
         if (blocks) {
@@ -1357,22 +1430,47 @@ int hnb_simulate(HnbContext* ctx) {
         }
     }
 
+    // ribbon sort of a program's compacted lists by (RIBBON_ID, AGE) (src/render/mod.rs:7372-7612)
+    auto ribbon_sort = [ctx](HnbProgram* p) {
+        const uint32_t n = (uint32_t)p->effects.size();
+        const uint32_t par = p->parity;
+        // The list is last frame's sorted list minus the casualties (stable compaction), every age advanced by the same
+        // non-negative tick (monotone under rounding; non-negative floats order like their bits), plus this frame's spawns
+        // at the end. Where the host can prove the premises (HnbProgram::sort_provable + this frame's values + no host write)
+        // the radix range is at most the largest spawn request: nothing to do without spawns, one single-workgroup launch
+        // for a small range. Otherwise the device decides (k_sort_fill's order check) and all launches are issued.
+        const bool proven = p->sort_provable && p->frame_sort_values_ok && !p->sort_dirty && ctx->skip_lists;
+        if (proven && p->frame_max_spawn == 0u) return;
+        SortArgs so = p->sort;
+        so.parity = p->sort_parity & 1u;
+        p->sort_parity += 1;
+        const DevMeta* mo = p->d_meta[par ^ 1];
+        const uint32_t tiles = n * so.chunks_per_inst;
+        k_sort_fill<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+        // ... or when the whole list is small: whatever range the device finds, one workgroup sorts it faster than sixteen launches
+        // are issued (a 40-particle lightning bolt whose ages are not provably ordered took 8 + 8 empty launches per frame)
+        if ((proven && p->frame_max_spawn <= kSortSmallMax) || p->dev.capacity <= kSortSmallMax / 4u) {
+            k_sort_small<<<n, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+        } else {
+            for (uint32_t pass = 0; pass < 8; ++pass) {
+                k_sort_hist<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
+                k_sort_scatter<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
+            }
+        }
+        k_sort_merge<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+        p->sort_dirty = false;
+    };
+
     // ---- phase B: update + kill + compaction (+ spawn-event ordering) ------------------------------------
     for (HnbProgram* p : order) {
         const uint32_t n = (uint32_t)p->effects.size();
         const uint32_t par = p->parity;
-        const char* d = static_cast<const char*>(p->d_frame[p->ring % kFrameRing]);
+        const char* d = p->d_frame_cur;
         const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
         const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
         // one workgroup per 4096-slot chunk of every instance
         const uint32_t total_chunks = n * p->dev.chunks_per_inst;
-        CompactBufs cb;
-        cb.counts = p->d_counts;
-        cb.deaths = p->d_deaths;
-        cb.table_cap = p->table_cap;
-        cb.parity = par;
-        cb.ev_totals = p->d_ev_totals;
-        cb.xcd_remap = (n > 1 ? 1u : 0u) | (ctx->alternate && !(p->frames_run & 1u) ? 2u : 0u);  // see chunk_of_workgroup; the first frame walks DOWN: a burst's init wrote the planes upwards
+        CompactBufs cb = compact_bufs_of(ctx, p, n);
         TimingPair tu{}, tc{};
         if (timed) { tu.a = take_event(ctx); tu.b = take_event(ctx); tc.b = take_event(ctx); hipEventRecord(tu.a, ctx->stream); }
         const uint32_t died_mark = p->slot_order ? 0u : 2u;
@@ -1412,57 +1510,39 @@ int hnb_simulate(HnbContext* ctx) {
             else k_update_slots_generic<InterpCode><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, dfi, dub, cb, died_mark);
         }
         if (timed) { hipEventRecord(tu.b, ctx->stream); ctx->t_update.push_back(tu); }
-        CompactArgs ca{};
-        ca.capacity = p->dev.capacity; ca.chunks_per_inst = p->dev.chunks_per_inst;
-        ca.alive_off[0] = p->dev.alive_off[0]; ca.alive_off[1] = p->dev.alive_off[1]; ca.dead_off = p->dev.dead_off;
-        ca.alive_flag_off = p->dev.alive_flag_off;
-        ca.slot_order = p->slot_order ? 1u : 0u;
-        const bool lists = !(p->update_streams && p->skip_now);  // false: proven no spawn, no casualty; the update rotated the counters
+        const CompactArgs ca = compact_args_of(p);
+        const bool lists = p->lists_now;
         if (!lists) p->skipped_frames += 1;
         if (lists && p->dev.n_event_channels) {  // order this frame's spawn events (by list row) into the children's buffers
             k_emit_count<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb);
             k_emit_events<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb, p->h_ev_counts, ctx->frame);
         }
         // lists: only the instances that lost particles have anything to do
-        if (lists && !p->slot_order) k_list_rows<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
-        if (lists) k_compact<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
-        if (lists && p->slot_order) {  // rebuild the lists in increasing slot order (instances without a casualty or spawn return at once)
-            k_order_count<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
-            k_order_write<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
-        }
-        if (timed) { tc.a = tu.b; hipEventRecord(tc.b, ctx->stream); ctx->t_compact.push_back(tc); }
-        if (p->has_ribbons) {  // ribbon sort of the compacted list by (RIBBON_ID, AGE) (src/render/mod.rs:7372-7612)
-            // The list is last frame's sorted list minus the casualties (stable compaction), every age advanced by the same
-            // non-negative tick (monotone under rounding; non-negative floats order like their bits), plus this frame's spawns
-            // at the end. Where the host can prove the premises (HnbProgram::sort_provable + this frame's values + no host write)
-            // the radix range is at most the largest spawn request: nothing to do without spawns, one single-workgroup launch
-            // for a small range. Otherwise the device decides (k_sort_fill's order check) and all launches are issued.
-            const bool proven = p->sort_provable && p->frame_sort_values_ok && !p->sort_dirty && ctx->skip_lists;
-            if (!(proven && p->frame_max_spawn == 0u)) {
-                SortArgs so = p->sort;
-                so.parity = p->sort_parity & 1u;
-                p->sort_parity += 1;
-                const DevMeta* mo = p->d_meta[par ^ 1];
-                const uint32_t tiles = n * so.chunks_per_inst;
-                k_sort_fill<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
-                if (proven && p->frame_max_spawn <= kSortSmallMax) {
-                    k_sort_small<<<n, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
-                } else {
-                    for (uint32_t pass = 0; pass < 8; ++pass) {
-                        k_sort_hist<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
-                        k_sort_scatter<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
-                    }
-                }
-                k_sort_merge<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
-                p->sort_dirty = false;
+        if (!p->lists_merged) {  // (merged: the lists, and the ribbon sort behind them, follow after the last program's update)
+            if (lists && !p->slot_order) k_list_rows<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
+            if (lists) k_compact<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
+            if (lists && p->slot_order) {  // rebuild the lists in increasing slot order (instances without a casualty or spawn return at once)
+                k_order_count<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
+                k_order_write<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
             }
+            if (timed) { tc.a = tu.b; hipEventRecord(tc.b, ctx->stream); ctx->t_compact.push_back(tc); }
+            if (p->has_ribbons) ribbon_sort(p);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(p->kernels_done[p->ring % kFrameRing], ctx->stream));
+    }
+    if (n_jobs) {
+        k_list_rows_multi<<<job_wgs, kBlock, 0, ctx->stream>>>(d_jobs, n_jobs);
+        k_compact_multi<<<job_wgs, kBlock, 0, ctx->stream>>>(d_jobs, n_jobs);
+        for (HnbProgram* p : order)
+            if (p->lists_merged && p->has_ribbons) ribbon_sort(p);
+        HIP_TRY(hipGetLastError());
+    }
+    for (HnbProgram* p : order) {
         p->ring += 1;
         p->parity ^= 1u;
         p->frames_run += 1;
     }
+    if (!order.empty()) HIP_TRY(hipEventRecord(ctx->stage_done[slot], ctx->stream));
     for (HnbProgram* p : order)
         for (HnbEffect* fx : p->effects) fx->spawn_count = 0;  // a spawn request is consumed by exactly one (enqueued) frame
     ctx->frame += 1;

@@ -368,9 +368,9 @@ struct CompactBufs {
 // HBM (workgroups are dispatched in increasing blockIdx order). Measured with the firework update over
 // 16,777,216 particles (tools/layout_probe.hip, profiles/r02d_layout_probe.log): 0.204 ms ascending every frame, 0.204 ms
 // descending every frame, 0.171 ms alternating. Any bijection is correct: a workgroup handles the chunk it computes here.
-__device__ __forceinline__ uint32_t chunk_of_workgroup(uint32_t mode) {
-    const uint32_t b = blockIdx.x;
-    const uint32_t total = gridDim.x;
+// (b, total): the workgroup's index and the number of workgroups of ITS program - the launch's own, or a program's share of a
+// launch that serves several programs (k_list_rows_multi / k_compact_multi).
+__device__ __forceinline__ uint32_t chunk_of_workgroup(uint32_t mode, uint32_t b, uint32_t total) {
     uint32_t c = b;
     if (mode & 1u) {
         const uint32_t xcd = b & 7u, local = b >> 3;
@@ -379,6 +379,7 @@ __device__ __forceinline__ uint32_t chunk_of_workgroup(uint32_t mode) {
     }
     return (mode & 2u) ? total - 1u - c : c;
 }
+__device__ __forceinline__ uint32_t chunk_of_workgroup(uint32_t mode) { return chunk_of_workgroup(mode, blockIdx.x, gridDim.x); }
 
 // Decode a chunk id; false when the chunk has no rows.
 template <class ARGS>
@@ -423,10 +424,10 @@ __device__ __forceinline__ void chunk_record(const ChunkCtx& c, uint32_t chunk, 
 // ---- k_compact -----------------------------------------------------------------------------------
 template <class ARGS>
 __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* inst_base, const DevMeta* meta_in, DevMeta* meta_out,
-                                              const DevFrameInst* fi, const CompactBufs& cb) {
+                                              const DevFrameInst* fi, const CompactBufs& cb, uint32_t wg, uint32_t wg_total) {
     __shared__ uint32_t s_red[kBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
+    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     ChunkCtx c;
     const bool has_rows = chunk_setup(c, chunk, args, inst_base, meta_in, fi);
     if (fi[c.k].skip) {  // not simulated this frame: counters carry over unchanged
@@ -524,7 +525,7 @@ struct CompactArgs {
 __global__ void __launch_bounds__(kBlock)
 k_compact(const CompactArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in, DevMeta* __restrict__ meta_out,
           const DevFrameInst* __restrict__ fi, const CompactBufs cb) {
-    compact_chunk(args, inst_base, meta_in, meta_out, fi, cb);
+    compact_chunk(args, inst_base, meta_in, meta_out, fi, cb, blockIdx.x, gridDim.x);
 }
 #endif
 
@@ -1081,13 +1082,12 @@ k_materialise_age(char* __restrict__ base, uint32_t capacity, uint32_t chunks_pe
 // Row-major list maintenance for the instances that lost particles this frame: every 4096-row chunk of the
 // alive list is rewritten as [survivors | casualties] (stable, in row order) from the alive bytes, and its
 // survivor count recorded; k_compact then takes the cross-chunk prefix exactly as before.
-__global__ void __launch_bounds__(kBlock)
-k_list_rows(const CompactArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
-            const DevFrameInst* __restrict__ fi, const CompactBufs cb) {
+__device__ __forceinline__ void list_rows_chunk(const CompactArgs& args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+                                                const DevFrameInst* __restrict__ fi, const CompactBufs& cb, uint32_t wg, uint32_t wg_total) {
     __shared__ uint32_t s_list[kChunk];
     __shared__ uint32_t s_wave[kBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
+    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     ChunkCtx c;
     if (!chunk_setup(c, chunk, args, inst_base, meta_in, fi)) return;
     if (cb.deaths[(size_t)cb.parity * cb.table_cap + c.k] == 0u) return;  // nothing died in this instance: the list stands
@@ -1141,6 +1141,42 @@ k_list_rows(const CompactArgs args, const uint64_t* __restrict__ inst_base, cons
     if (lane == 0) s_wave[wave] = wa | (wd << 16);
     __syncthreads();
     chunk_record<kBlock / 64>(c, chunk, cb, list, s_list, kWaveRows, s_wave);
+}
+__global__ void __launch_bounds__(kBlock)
+k_list_rows(const CompactArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+            const DevFrameInst* __restrict__ fi, const CompactBufs cb) {
+    list_rows_chunk(args, inst_base, meta_in, fi, cb, blockIdx.x, gridDim.x);
+}
+
+// The same two kernels for SEVERAL programs in one launch each. k_list_rows and k_compact are the same code for every program, only their
+// arguments differ, and in a scene of many small effects the frame is bound by the number of launches the host can issue (26 example effects:
+// 4 launches per effect, 12 us of host time per effect and frame). hnb_simulate therefore collects the programs that need their lists this
+// frame into a job table (it travels with the frame's parameter upload) and serves them with two launches after all update kernels.
+struct ListsJob {
+    CompactArgs args;
+    CompactBufs cb;
+    const uint64_t* inst_base;
+    const DevMeta* meta_in;
+    DevMeta* meta_out;
+    const DevFrameInst* fi;
+    uint32_t first_wg, n_wg;   // this program's workgroups in the launch
+    uint32_t pad[2];
+};
+__device__ __forceinline__ const ListsJob& job_of_workgroup(const ListsJob* __restrict__ jobs, uint32_t n_jobs) {
+    uint32_t lo = 0, hi = n_jobs;   // last job with first_wg <= blockIdx.x (uniform: scalar loads)
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (jobs[mid].first_wg <= blockIdx.x) lo = mid; else hi = mid; }
+    return jobs[lo];
+}
+__global__ void __launch_bounds__(kBlock)
+k_list_rows_multi(const ListsJob* __restrict__ jobs, uint32_t n_jobs) {
+    const ListsJob& jb = job_of_workgroup(jobs, n_jobs);
+    if (jb.args.slot_order) return;   // its lists are rebuilt from the alive bytes by k_order_*
+    list_rows_chunk(jb.args, jb.inst_base, jb.meta_in, jb.fi, jb.cb, blockIdx.x - jb.first_wg, jb.n_wg);
+}
+__global__ void __launch_bounds__(kBlock)
+k_compact_multi(const ListsJob* __restrict__ jobs, uint32_t n_jobs) {
+    const ListsJob& jb = job_of_workgroup(jobs, n_jobs);
+    compact_chunk(jb.args, jb.inst_base, jb.meta_in, jb.meta_out, jb.fi, jb.cb, blockIdx.x - jb.first_wg, jb.n_wg);
 }
 
 // Per 4096-row chunk of the alive list (as the update saw it): spawn events per channel, for the cross-chunk
