@@ -408,6 +408,13 @@ def main():
             except Exception as e:  # the headline line must not be lost to a side configuration
                 extra[name] = {"error": f"{type(e).__name__}: {e}"}
         out["configs"] = extra
+        # the launch-bound end of the path: 26 different small effects in one context (tools/scene_bench.py, profiles/r02u_scene.md)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import scene_bench
+            out["small_effects_scene"] = scene_bench.run(1, 300, device=D.device_index, quiet=True)
+        except Exception as e:
+            out["small_effects_scene"] = {"error": f"{type(e).__name__}: {e}"}
     if D.rank == 0 and not args.no_cpu_baseline and not D.on and args.config == "c2":
         # rank 0 at N = 1 only: the host cores are shared by the ranks otherwise
         try:

@@ -17,13 +17,11 @@ import torch  # noqa: E402,F401
 import bevy_hanabi_amd as bh  # noqa: E402
 from bevy_hanabi_amd import reference_examples as rx  # noqa: E402
 
-copies = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-frames = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 DT = 1.0 / 60.0
 
 
-def main():
-    ctx = bh.Context(0)
+def run(copies=1, frames=600, device=0, quiet=False):
+    ctx = bh.Context(device)
     players = []
     for c in range(copies):
         for name, entries in sorted(rx.catalog().items()):
@@ -32,7 +30,8 @@ def main():
             for e in entries:
                 prog = ctx.create_program(bh.lower(e.asset))
                 players.append({"e": e, "fx": prog.create_effect(), "sp": bh.EffectSpawner(e.asset.spawner), "rng": bh.Pcg32(), "seed": 17 + len(players)})
-    print(f"scene: {len(players)} effects / programs in one context")
+    if not quiet:
+        print(f"scene: {len(players)} effects / programs in one context")
 
     def frame(f):
         t = f * DT
@@ -58,10 +57,14 @@ def main():
     ctx.synchronize()
     wall = time.perf_counter() - t0
     alive = sum(p["fx"].alive_count() for p in players)
-    print(f"{frames} frames: {wall / frames * 1e3:.3f} ms per frame wall (python driving included), {host / frames * 1e3:.3f} ms inside simulate(); "
-          f"{host / frames / len(players) * 1e6:.1f} us of simulate() per effect and frame; {alive} particles alive at the end")
+    if not quiet:
+        print(f"{frames} frames: {wall / frames * 1e3:.3f} ms per frame wall (python driving included), {host / frames * 1e3:.3f} ms inside simulate(); "
+              f"{host / frames / len(players) * 1e6:.1f} us of simulate() per effect and frame; {alive} particles alive at the end")
     ctx.close()
+    return {"effects": len(players), "frames": frames, "ms_per_frame_wall": wall / frames * 1e3, "ms_per_frame_in_simulate": host / frames * 1e3,
+            "us_of_simulate_per_effect": host / frames / len(players) * 1e6, "alive_at_end": alive,
+            "workload": "every single-entity effect of the reference's examples/ (one program + one instance each) in one context, one hnb_simulate per frame"}
 
 
 if __name__ == "__main__":
-    main()
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 1, int(sys.argv[2]) if len(sys.argv) > 2 else 600)
