@@ -181,6 +181,28 @@ def test_c3_force_field_at_baseline_size(ctx):
     gpu.fx.destroy(); gpu.prog.destroy()
 
 
+def test_c2_firework_full_state_at_baseline_size(ctx):
+    """The headline workload itself: firework trails at 16,777,216 particles (BASELINE config 2), FULL state (counters, both lists,
+    every attribute plane of every slot) against the OpenMP oracle: the burst, two frames of flight at the bench's dt = 1/60 (all
+    alive: the frames the bench times; age cohorts and list-free frames engaged), then two frames of dt = 0.45 s that carry the
+    ages past the shortest lifetimes (0.8 s) and past all of them (1.2 s): the whole effect dies in two compactions."""
+    cap = 1 << 24
+    asset = effects.firework_trails(cap)
+    gpu, orc = GpuRunner(asset, ctx=ctx), OracleRunner(asset, omp=True)
+    alive, t = [], 0.0
+    for f, dt in enumerate([1 / 60, 1 / 60, 1 / 60, 0.45, 0.45, 0.45]):
+        fr = Frame(dt, cap if f == 0 else 0, frame_seed(f), time=t)
+        t += dt
+        gpu.step(fr)
+        orc.step(fr)
+        if f in (0, 2, 4, 5):
+            assert_same_state(orc.state(), gpu.state(), f"C2 16.7M frame {f}")
+        alive.append(gpu.fx.alive_count())
+    assert alive[:3] == [cap] * 3 and 0 < alive[4] < cap and alive[5] == 0, alive
+    print("C2 16,777,216: alive per frame", alive)
+    gpu.fx.destroy(); gpu.prog.destroy()
+
+
 def test_c4_instancing_one_gpu_share_at_baseline_size(ctx):
     """instancing.rs, 512 instances x 65,536 (one GPU's share of BASELINE config 4: 4096 instances over 8 GPUs, instance i
     on rank i mod 8 — rank 0 owns 0, 8, 16, ...). dt = 3 s with the rate spawner: a quarter of the capacity spawns per frame
