@@ -222,6 +222,33 @@ Modifier TangentAccelModifier(ExprHandle origin, ExprHandle axis, ExprHandle acc
     Modifier m; m.kind = Modifier::Kind::TangentAccel; m.e[0] = origin; m.e[1] = axis; m.e[2] = accel; return m;
 }
 Modifier LinearDragModifier(ExprHandle drag) { Modifier m; m.kind = Modifier::Kind::LinearDrag; m.e[0] = drag; return m; }
+static Value vec3_value(Vec3Lit v) {
+    Value r;
+    r.type = VectorType::VEC3F;
+    r.set_f(0, v.x); r.set_f(1, v.y); r.set_f(2, v.z);
+    return r;
+}
+Modifier AccelModifierConstant(Module& module, Vec3Lit acceleration) { return AccelModifier(module.lit(vec3_value(acceleration))); }
+Modifier AccelModifierViaProperty(Module& module, PropertyHandle property) { return AccelModifier(module.prop(property)); }
+Modifier RadialAccelModifierConstant(Module& module, Vec3Lit origin, float acceleration) {
+    const ExprHandle o = module.lit(vec3_value(origin));  // field order of the struct literal: origin first (accel.rs:142-146)
+    return RadialAccelModifier(o, module.lit(Value(acceleration)));
+}
+Modifier RadialAccelModifierViaProperty(Module& module, Vec3Lit origin, PropertyHandle property) {
+    const ExprHandle o = module.lit(vec3_value(origin));
+    return RadialAccelModifier(o, module.prop(property));
+}
+Modifier TangentAccelModifierConstant(Module& module, Vec3Lit origin, Vec3Lit axis, float acceleration) {
+    const ExprHandle o = module.lit(vec3_value(origin));
+    const ExprHandle a = module.lit(vec3_value(axis));
+    return TangentAccelModifier(o, a, module.lit(Value(acceleration)));
+}
+Modifier TangentAccelModifierViaProperty(Module& module, Vec3Lit origin, Vec3Lit axis, PropertyHandle property) {
+    const ExprHandle o = module.lit(vec3_value(origin));
+    const ExprHandle a = module.lit(vec3_value(axis));
+    return TangentAccelModifier(o, a, module.prop(property));
+}
+Modifier LinearDragModifierConstant(Module& module, float drag) { return LinearDragModifier(module.lit(Value(drag))); }
 Modifier ConformToSphereModifier(ExprHandle origin, ExprHandle radius, ExprHandle influence_dist, ExprHandle attraction_accel,
                                  ExprHandle max_attraction_speed, ExprHandle shell_half_thickness, ExprHandle sticky_factor) {
     Modifier m;

@@ -396,6 +396,8 @@ struct Modifier {
 
     uint32_t context() const;
     std::vector<Attribute> attributes() const;
+    // KillSphereModifier / KillAabbModifier::with_kill_inside (kill.rs:57-60, 137-140)
+    Modifier with_kill_inside(bool inside) const { Modifier m = *this; m.kill_inside = inside; return m; }
 };
 
 // Factory functions named after the reference's modifier types.
@@ -417,6 +419,16 @@ Modifier ConformToSphereModifier(ExprHandle origin, ExprHandle radius, ExprHandl
 Modifier KillSphereModifier(ExprHandle center, ExprHandle sqr_radius, bool kill_inside = false);
 Modifier KillAabbModifier(ExprHandle center, ExprHandle half_size, bool kill_inside = false);
 Modifier EmitSpawnEventModifier(EventEmitCondition condition, ExprHandle count, uint32_t child_index);
+// The reference's helper constructors (`AccelModifier::constant(&mut module, v)`, `::via_property(&mut module, ..., property)`;
+// accel.rs:52-64, 133-147, 245-266, force.rs:264-268): they add the literal / property expressions to the module themselves.
+struct Vec3Lit { float x, y, z; };
+Modifier AccelModifierConstant(Module& module, Vec3Lit acceleration);
+Modifier AccelModifierViaProperty(Module& module, PropertyHandle property);
+Modifier RadialAccelModifierConstant(Module& module, Vec3Lit origin, float acceleration);
+Modifier RadialAccelModifierViaProperty(Module& module, Vec3Lit origin, PropertyHandle property);
+Modifier TangentAccelModifierConstant(Module& module, Vec3Lit origin, Vec3Lit axis, float acceleration);
+Modifier TangentAccelModifierViaProperty(Module& module, Vec3Lit origin, Vec3Lit axis, PropertyHandle property);
+Modifier LinearDragModifierConstant(Module& module, float drag);
 // Render-only modifiers: only their attribute requirements matter here (modifier/output.rs).
 Modifier RenderModifier(const std::string& name, const std::vector<Attribute>& attributes);
 Modifier ColorOverLifetimeModifier();

@@ -206,7 +206,9 @@ PYBIND11_MODULE(_hanabi_host, m) {
     py::class_<Modifier>(m, "Modifier")
         .def_property_readonly("context", &Modifier::context)
         .def_property_readonly("attributes", &Modifier::attributes)
-        .def_property_readonly("kind", [](const Modifier& md) { return (uint32_t)md.kind; });
+        .def_property_readonly("kind", [](const Modifier& md) { return (uint32_t)md.kind; })
+        .def_property_readonly("kill_inside", [](const Modifier& md) { return md.kill_inside; })
+        .def("with_kill_inside", &Modifier::with_kill_inside);
     m.def("SetAttributeModifier", &SetAttributeModifier, py::arg("attribute"), py::arg("value"));
     m.def("InheritAttributeModifier", &InheritAttributeModifier);
     m.def("SetPositionCircleModifier", &SetPositionCircleModifier, py::arg("center"), py::arg("axis"), py::arg("radius"), py::arg("dimension"));
@@ -219,6 +221,21 @@ PYBIND11_MODULE(_hanabi_host, m) {
     m.def("RadialAccelModifier", &RadialAccelModifier, py::arg("origin"), py::arg("accel"));
     m.def("TangentAccelModifier", &TangentAccelModifier, py::arg("origin"), py::arg("axis"), py::arg("accel"));
     m.def("LinearDragModifier", &LinearDragModifier, py::arg("drag"));
+    {   // `XModifier::constant(&mut module, ...)` / `::via_property(...)` of the reference, as XModifier_constant / XModifier_via_property
+        auto v3 = [](const py::sequence& s) {
+            if (py::len(s) != 3) throw py::value_error("expected 3 components");
+            return Vec3Lit{(float)s[0].cast<double>(), (float)s[1].cast<double>(), (float)s[2].cast<double>()};
+        };
+        m.def("AccelModifier_constant", [v3](Module& md, py::sequence a) { return AccelModifierConstant(md, v3(a)); });
+        m.def("AccelModifier_via_property", &AccelModifierViaProperty);
+        m.def("RadialAccelModifier_constant", [v3](Module& md, py::sequence o, double a) { return RadialAccelModifierConstant(md, v3(o), (float)a); });
+        m.def("RadialAccelModifier_via_property", [v3](Module& md, py::sequence o, PropertyHandle p) { return RadialAccelModifierViaProperty(md, v3(o), p); });
+        m.def("TangentAccelModifier_constant",
+              [v3](Module& md, py::sequence o, py::sequence ax, double a) { return TangentAccelModifierConstant(md, v3(o), v3(ax), (float)a); });
+        m.def("TangentAccelModifier_via_property",
+              [v3](Module& md, py::sequence o, py::sequence ax, PropertyHandle p) { return TangentAccelModifierViaProperty(md, v3(o), v3(ax), p); });
+        m.def("LinearDragModifier_constant", [](Module& md, double d) { return LinearDragModifierConstant(md, (float)d); });
+    }
     m.def("ConformToSphereModifier",
           [](ExprHandle origin, ExprHandle radius, ExprHandle influence_dist, ExprHandle attraction_accel, ExprHandle max_attraction_speed,
              py::object shell_half_thickness, py::object sticky_factor) {

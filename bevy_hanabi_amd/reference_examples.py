@@ -200,7 +200,7 @@ def example_portal():
     life = h.SetAttributeModifier(A.LIFETIME, w.lit(0.6).uniform(w.lit(1.3)).expr())
     drag = h.LinearDragModifier(w.lit(2.0).expr())
     module = w.finish()
-    tangent = h.TangentAccelModifier(module.lit(ZERO3), module.lit(Z3), module.lit(30.0))
+    tangent = h.TangentAccelModifier_constant(module, ZERO3, Z3, 30.0)
     return _build(h.EffectAsset(16384, h.SpawnerSettings.rate(5000.0), module).with_name("portal"),
                   init=[pos, age, life], update=[drag, tangent],
                   render=[h.ColorOverLifetimeModifier(), h.SizeOverLifetimeModifier(), h.OrientModifier(h.OrientMode.AlongVelocity)])

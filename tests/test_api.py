@@ -300,3 +300,48 @@ def test_effect_properties_mirror():
     assert len(blob) == layout.cpu_size()
     assert blob[layout.offset("a"):layout.offset("a") + 4] == struct.pack("<f", 3.0)
     assert blob[layout.offset("b"):layout.offset("b") + 12] == struct.pack("<3f", 1.0, 1.0, 1.0)
+
+
+def test_modifier_helper_constructors():
+    """`XModifier::constant(&mut module, ...)` / `::via_property(...)` (accel.rs:52-64, 133-147, 245-266; force.rs:264-268) add
+    their literals / property reads to the module, origin first, and give the modifier `::new` gives; the weak checks of the
+    reference's own tests (mod_accel, mod_radial_accel, mod_tangent_accel, mod_drag: "the emitted code contains the literal")
+    become: the literal is an expression of the module and the modifier's operand. `with_kill_inside` (kill.rs:57-60, 137-140)."""
+    m = bh.Module()
+    n0 = len(bh.to_ron(bh.EffectAsset(4, bh.SpawnerSettings.once(1.0), m)))
+    acc = bh.AccelModifier_constant(m, (1.0, 2.0, 3.0))
+    rad = bh.RadialAccelModifier_constant(m, (-1.2, 5.3, -8.5), 6.0)
+    tan = bh.TangentAccelModifier_constant(m, (-1.2, 5.3, -8.5), (0.0, 1.0, 0.0), 6.0)
+    drag = bh.LinearDragModifier_constant(m, 3.5)
+    prop = m.add_property("my_prop", 3.0)
+    via = [bh.AccelModifier_via_property(m, m.add_property("a3", (0.0, 1.0, 0.0))), bh.RadialAccelModifier_via_property(m, (0.0, 0.0, 0.0), prop),
+           bh.TangentAccelModifier_via_property(m, (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), prop)]
+    zero, kc, kr, kh = m.lit((0.0, 0.0, 0.0)), m.lit((0.0, 0.0, 0.0)), m.lit(1.0), m.lit((1.0, 1.0, 1.0))
+    asset = bh.EffectAsset(64, bh.SpawnerSettings.once(1.0), m)   # takes the module by value (asset.rs:323), as in the reference
+    asset = asset.init(bh.SetAttributeModifier(bh.Attribute.POSITION, zero)).init(bh.SetAttributeModifier(bh.Attribute.VELOCITY, zero))
+    for md in [acc, rad, tan, drag] + via:
+        assert md.context == bh.CONTEXT_UPDATE
+        asset = asset.update(md)
+    text = bh.to_ron(asset)
+    assert len(text) > n0
+    for literal in ("1.0, 2.0, 3.0", "-1.2, 5.3, -8.5", "3.5", "6.0"):
+        assert literal in text.replace("(", "").replace(")", ""), literal
+    bh.validate_program(bh.lower(asset))
+    # the same effect written with ::new lowers to the same program
+    m2 = bh.Module()
+    mods = [bh.AccelModifier(m2.lit((1.0, 2.0, 3.0))), bh.RadialAccelModifier(m2.lit((-1.2, 5.3, -8.5)), m2.lit(6.0)),
+            bh.TangentAccelModifier(m2.lit((-1.2, 5.3, -8.5)), m2.lit((0.0, 1.0, 0.0)), m2.lit(6.0)), bh.LinearDragModifier(m2.lit(3.5))]
+    p2 = m2.add_property("my_prop", 3.0)
+    mods += [bh.AccelModifier(m2.prop(m2.add_property("a3", (0.0, 1.0, 0.0)))), bh.RadialAccelModifier(m2.lit((0.0, 0.0, 0.0)), m2.prop(p2)),
+             bh.TangentAccelModifier(m2.lit((0.0, 0.0, 0.0)), m2.lit((0.0, 0.0, 1.0)), m2.prop(p2))]
+    zero2 = m2.lit((0.0, 0.0, 0.0))
+    for _ in range(3):
+        m2.lit(0.0)   # (kc, kr, kh above: the expression ids have to line up for the blobs to be equal)
+    a2 = bh.EffectAsset(64, bh.SpawnerSettings.once(1.0), m2)
+    a2 = a2.init(bh.SetAttributeModifier(bh.Attribute.POSITION, zero2)).init(bh.SetAttributeModifier(bh.Attribute.VELOCITY, zero2))
+    for md in mods:
+        a2 = a2.update(md)
+    assert bh.lower(a2) == bh.lower(asset)
+    k = bh.KillSphereModifier(kc, kr)
+    assert not k.kill_inside and k.with_kill_inside(True).kill_inside and not k.kill_inside
+    assert bh.KillAabbModifier(kc, kh).with_kill_inside(True).kill_inside
