@@ -370,6 +370,7 @@ def main():
     ap.add_argument("--capacity", type=int, default=None, help="particles per effect instance (default: the configuration's)")
     ap.add_argument("--instances", type=int, default=None, help="c4: instances per GPU (weak) / in total (strong); default 512")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scene", action="store_true", help="N = 1: append the small-effects scene (26 example effects in one context) as \"small_effects_scene\"")
     ap.add_argument("--no-extra-configs", action="store_true", help="N = 1, c2: do not append the c3/c4/c5 lines under \"configs\"")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--force-device", type=int, default=None, help="dry runs: every rank uses this GPU instead of LOCAL_RANK")
@@ -408,7 +409,10 @@ def main():
             except Exception as e:  # the headline line must not be lost to a side configuration
                 extra[name] = {"error": f"{type(e).__name__}: {e}"}
         out["configs"] = extra
-        # the launch-bound end of the path: 26 different small effects in one context (tools/scene_bench.py, profiles/r02u_scene.md)
+    if not D.on and args.scene:
+        # the launch-bound end of the path: 26 different small effects in one context (tools/scene_bench.py, profiles/r02u_scene.md). Opt-in: the
+        # small effects share kernel instantiations with the headline workload, and the default command's rocprofv3 statistics are
+        # meant to show the headline's kernel on its own
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import scene_bench
