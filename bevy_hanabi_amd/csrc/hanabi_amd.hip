@@ -190,6 +190,23 @@ struct HnbProgram {
     uint32_t sort_parity = 0;               // frames in which the sort ran (its state double buffer)
     uint32_t frame_max_spawn = 0;           // largest spawn request of an instance in the frame being enqueued
     bool frame_sort_values_ok = false;      // this frame's init age and tick are >= +0 for every instance
+    // ... and can it prove more: that this frame's spawns sort IN FRONT of every older particle? Then the sorted list is a rotation of the
+    // list and no key is read (k_sort_rotate_*). Premises: one RIBBON_ID for every particle the effect ever had (set by the init from
+    // ONE uniform value that never changed, or never set: 0); spawns start at AGE +0 and the update ticks them once in their first frame,
+    // so the tail's keys are all (rid, tick_now); every older particle has age >= fl(t_g + tick_now) for the tick t_g of the frame
+    // it was spawned in (ages only grow: monotone addition), hence >= fl(min_tick + tick_now) with the smallest tick of any earlier
+    // frame: the host evaluates that f32 sum and asks for it to be > tick_now. A negative / NaN tick, a second RIBBON_ID value or a host
+    // write ends it for good.
+    bool sort_front_static = false;
+    uint32_t sort_life_operand = 0;         // decoded U operand of the init's LIFETIME assignment
+    uint32_t sort_rid_operand = 0;          // decoded U operand of the init's RIBBON_ID store (valid if sort_rid_set)
+    bool sort_rid_set = false;
+    bool sort_rid_known = false;
+    uint32_t sort_rid_value = 0;
+    bool sort_front_broken = false;
+    float sort_min_tick = __builtin_inff();
+    bool frame_sort_front = false;          // decision for the frame being enqueued
+    uint32_t sort_rotated_frames = 0;       // statistics: frames whose ribbon sort was a rotation
 };
 
 struct EventChannel {
@@ -860,6 +877,40 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
             }
         }
         p->sort_provable = ok;
+        // the front proof (see HnbProgram::sort_front_static): RIBBON_ID stored at most once by the init, from a uniform value
+        int rid_index = -1;
+        for (uint32_t a = 0; a < h.n_attrs; ++a) if (p->attrs[a].attr == HNB_ATTR_RIBBON_ID) rid_index = (int)a;
+        uint32_t rid_stores = 0;
+        bool front = ok && rid_index >= 0;
+        for (uint32_t i = 0; i < h.init_len && front; ++i) {
+            const uint32_t op = ic[i].x & 0xffu;
+            if (op == HNB_OP_STA && (ic[i].y >> 16) == (uint32_t)rid_index) {
+                rid_stores += 1;
+                p->sort_rid_operand = HNB_OPERAND_DECODE((ic[i].x >> 16) & 0xffu, ic[i].y >> 13);
+                front = (p->sort_rid_operand & HNB_OPERAND_DECODED_U) != 0;
+            }
+        }
+        p->sort_rid_set = rid_stores == 1;
+        // ... and every spawn must still be in the list when it is sorted (the rotation moves exactly `spawned` rows): nothing but old age
+        // kills, and the lifetime - one uniform value, compared with the tick per frame - outlasts the first frame
+        uint32_t life_sets = 0;
+        for (uint32_t i = 0; i < h.init_len && front; ++i) {
+            const uint32_t op = ic[i].x & 0xffu, dst = (ic[i].x >> 8) & 0xffu, wd = ((ic[i].y >> 8) & 3u) + 1u;
+            if (op == HNB_OP_M_PIN_SET && dst == HNB_REG_LIFETIME) {
+                life_sets += 1;
+                p->sort_life_operand = HNB_OPERAND_DECODE((ic[i].x >> 16) & 0xffu, ic[i].y >> 13);
+                front = (p->sort_life_operand & HNB_OPERAND_DECODED_U) != 0;
+            } else if (op != HNB_OP_STA && op != HNB_OP_ALIVE_SET && op != HNB_OP_ALIVE_AND && op != HNB_OP_KILL_IF && !(op >= HNB_OP_M_AGE_TICK) &&
+                       dst <= HNB_REG_LIFETIME && dst + wd > HNB_REG_LIFETIME) {
+                front = false;  // some other instruction writes the LIFETIME register
+            }
+        }
+        for (uint32_t i = 0; i < h.update_len && front; ++i) {
+            const uint32_t op = uc[i].x & 0xffu, dst = (uc[i].x >> 8) & 0xffu;
+            if (op == HNB_OP_M_KILL_SPHERE || op == HNB_OP_M_KILL_AABB || op == HNB_OP_KILL_IF || op == HNB_OP_ALIVE_SET || op == HNB_OP_ALIVE_AND) front = false;
+            if (op == HNB_OP_M_PIN_SET && dst == HNB_REG_LIFETIME) front = false;
+        }
+        p->sort_front_static = front && rid_stores <= 1 && life_sets == 1;
     }
     {
         bool kills = false;
@@ -1351,6 +1402,38 @@ int hnb_simulate(HnbContext* ctx) {
                     ok = tick_bits <= 0x7f800000u && age_bits <= 0x7f800000u;   // >= +0 and not NaN: ages stay non-negative, key order == age order
                 }
                 p->frame_sort_values_ok = ok;
+                // in front of everything? (HnbProgram::sort_front_static)
+                bool front = p->sort_front_static && ok && !p->sort_front_broken;
+                float tick_now = 0.0f;
+                bool have = false;
+                for (uint32_t i = 0; i < n; ++i) {
+                    const HnbEffect* fx = p->effects[i];
+                    if (!fx->simulated) continue;
+                    const uint32_t* ub = ublocks + (size_t)i * nu;
+                    const uint32_t tick_bits = ub[p->sort_tick_operand & 0xffu];
+                    const uint32_t age_bits = p->sort_age_init_set ? ub[p->sort_age_init_operand & 0xffu] : 0u;
+                    const uint32_t rid_bits = p->sort_rid_set ? ub[p->sort_rid_operand & 0xffu] : 0u;
+                    if (!(tick_bits <= 0x7f800000u)) p->sort_front_broken = true;   // a negative or NaN tick: ages are no longer what the proof assumes
+                    if (!p->sort_rid_known) { p->sort_rid_known = true; p->sort_rid_value = rid_bits; }
+                    else if (rid_bits != p->sort_rid_value) p->sort_front_broken = true;
+                    if (age_bits != 0u) front = false;   // spawns that do not start at +0 this frame
+                    const uint32_t life_bits = ub[p->sort_life_operand & 0xffu];
+                    float life, tk;
+                    memcpy(&life, &life_bits, 4);
+                    memcpy(&tk, &tick_bits, 4);
+                    if (!(life_bits < 0x7f800000u && tk < life)) front = false;   // a spawn would die in its first frame and miss the list
+                    float t;
+                    memcpy(&t, &tick_bits, 4);
+                    if (!have) { tick_now = t; have = true; }
+                    else if (memcmp(&t, &tick_now, 4) != 0) front = false;
+                }
+                if (p->sort_front_broken || !have) front = false;
+                if (front) {
+                    volatile float bound = p->sort_min_tick + tick_now;   // f32, as the device adds (no contraction, no excess precision)
+                    front = tick_now > 0.0f && bound > tick_now;
+                }
+                p->frame_sort_front = front;
+                if (have && tick_now == tick_now) p->sort_min_tick = tick_now < p->sort_min_tick ? tick_now : p->sort_min_tick;
             }
             p->skip_now = false;
             if (p->skip_eligible && ctx->skip_lists && !any_spawn && !any_parent && tick_known) {
@@ -1441,6 +1524,16 @@ int hnb_simulate(HnbContext* ctx) {
         // for a small range. Otherwise the device decides (k_sort_fill's order check) and all launches are issued.
         const bool proven = p->sort_provable && p->frame_sort_values_ok && !p->sort_dirty && ctx->skip_lists;
         if (proven && p->frame_max_spawn == 0u) return;
+        if (proven && p->frame_sort_front) {  // the spawns go in front: a rotation of the list, no keys (k_sort_rotate_*)
+            const SortArgs& so = p->sort;
+            const DevMeta* mo = p->d_meta[par ^ 1];
+            const uint32_t tiles = n * so.chunks_per_inst;
+            const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(p->d_frame_cur);
+            k_sort_rotate_save<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, dfi);
+            k_sort_rotate_write<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, dfi);
+            p->sort_rotated_frames += 1;
+            return;
+        }
         SortArgs so = p->sort;
         so.parity = p->sort_parity & 1u;
         p->sort_parity += 1;
@@ -1607,6 +1700,7 @@ int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t 
     HIP_TRY(hipMemcpy(static_cast<char*>(fx->slab) + p->dev.attrs[ai].plane_off, src, bytes, hipMemcpyHostToDevice));
     p->dirty = true;  // ... nor does the published no-death bound
     p->sort_dirty = true;  // ... and a ribbon list may no longer be in key order
+    p->sort_front_broken = true;  // ... nor its ages and ribbon ids what the front proof assumes
     // the chunks' lifetime bounds (lifetime culling) no longer describe the planes
     HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.lmin_off, 0, (size_t)p->dev.chunks_per_inst * 4));  // (the "completely alive" flags that follow stay valid)
     if (p->dev.age_cohort && attr == HNB_ATTR_AGE)   // the plane is the truth again: forget the cohort states (and values)
@@ -1661,6 +1755,7 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
         }
         s += "\nage cohorts: " + std::to_string(in_cohort) + " of " + std::to_string(prog->effects.size() * (size_t)prog->dev.chunks_per_inst) + " chunks";
     }
+    if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->sort_front_static ? "" : " (not eligible)");
     s += "\nlists skipped: " + std::to_string(prog->skipped_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->skip_eligible ? "" : " (not eligible)");
     snprintf(buf, buf_size, "%s", s.c_str());
     return HNB_OK;

@@ -458,3 +458,108 @@ def test_age_cohorts_engage_and_dissolve_without_a_trace(ctx):
     assert_same_state(orc.state(), gpu.state(), "after a host write of AGE")
     assert gpu.fx.metadata()["fault"] == 0
     gpu.fx.destroy(); gpu.prog.destroy()
+
+
+# ---- ribbon sort by rotation ("this frame's spawns sort in front of everything else") ---------------------------------------
+def _rotations(prog):
+    line = [l for l in prog.kernel_info().split("\n") if l.startswith("ribbon sorts by rotation")][0]
+    return int(line.split(":")[1].split("of")[0]), "not eligible" in line
+
+
+def _ribbon_asset(cap, age=0.0, lifetime=1.5, rid=None):
+    """ribbon.rs with the initial age / lifetime / ribbon id as given (`rid`: None = literal 0, or a callable on the writer)."""
+    w = bh.ExprWriter()
+    mods = [bh.SetAttributeModifier(A.POSITION, w.lit((0.0, 0.0, 0.0)).expr()),
+            bh.SetAttributeModifier(A.AGE, w.lit(age).expr()),
+            bh.SetAttributeModifier(A.LIFETIME, w.lit(lifetime).expr()),
+            bh.SetAttributeModifier(A.SIZE, w.lit(0.5).expr()),
+            bh.SetAttributeModifier(A.RIBBON_ID, (rid(w) if rid else w.lit(bh.Value.u32(0))).expr())]
+    asset = (bh.EffectAsset(cap, bh.SpawnerSettings.rate(cap / lifetime), w.finish()).with_motion_integration(bh.MotionIntegration.None_))
+    for m in mods:
+        asset = asset.init(m)
+    return asset.render(bh.SizeOverLifetimeModifier())
+
+
+def test_ribbon_sort_is_a_rotation_where_the_spawns_provably_go_in_front(ctx):
+    """ribbon.rs (one RIBBON_ID, spawns at AGE 0): after the first frame every sort is a rotation of the list by the number of spawns —
+    no key is read — through spawn, steady churn and slot reuse, with varying ticks and spawn counts, with a frozen instance next to
+    it; bit-exact against the oracle's (RIBBON_ID, AGE) sort after every frame."""
+    cap = 9000
+    asset = _ribbon_asset(cap)
+    prog = ctx.create_program(bh.lower(asset))
+    fxs = [prog.create_effect() for _ in range(3)]
+    orcs = [OracleRunner(asset) for _ in range(3)]
+    sps = [bh.EffectSpawner(asset.spawner) for _ in range(3)]
+    rng = bh.Pcg32()
+    frames = 150
+    for f in range(frames):
+        dt = [1 / 60, 1 / 30, 1 / 144][f % 3]
+        ctx.frame_begin(dt, f / 60)
+        for i, (fx, orc, sp) in enumerate(zip(fxs, orcs, sps)):
+            visible = not (i == 1 and 40 <= f < 70)
+            fx.set_simulated(visible)
+            if not visible:
+                continue
+            n, seed = sp.tick(dt, rng) if f % 7 else 0, frame_seed(f * 8 + i)
+            fx.set_frame(n, seed)
+            orc.step(Frame(dt, n, seed, time=f / 60))
+        ctx.simulate()
+        if f % 5 == 4 or f in (40, 41, 70, 71):
+            for fx, orc in zip(fxs, orcs):
+                ref = orc.state()
+                np.testing.assert_array_equal(ref["alive"], fx.alive_list(), err_msg=f"frame {f}")
+                np.testing.assert_array_equal(ref["dead"], fx.dead_list(), err_msg=f"frame {f}")
+    rot, ineligible = _rotations(prog)
+    assert not ineligible and rot >= frames - 30, prog.kernel_info()   # every frame with spawns but the first
+    c = orcs[0].state()["counters"]
+    assert c["particle_counter"] > c["alive_count"] + cap // 4 and c["alive_count"] > cap // 2   # particles died and their slots were reused
+    prog.destroy()
+
+
+@pytest.mark.parametrize("case", ["age_not_zero", "two_ribbon_ids", "dies_in_first_frame", "zero_tick", "host_write", "per_particle_rid"])
+def test_ribbon_rotation_is_suspended_where_its_premises_fail(ctx, case):
+    """Each premise of the rotation, violated: the sort falls back to keys and stays bit-exact."""
+    cap = 6000
+    kw = {}
+    if case == "age_not_zero":
+        kw["age"] = 0.25
+    if case == "dies_in_first_frame":
+        kw["lifetime"] = 0.05      # ticks of 1/15 s kill a spawn in its first frame
+    if case == "per_particle_rid":
+        kw["rid"] = lambda w: w.attr(A.PARTICLE_COUNTER) % w.lit(bh.Value.u32(3))
+    if case == "two_ribbon_ids":
+        def rid(w):
+            return w.prop(w.add_property("rid", bh.Value.u32(0)))
+        kw["rid"] = rid
+    asset = _ribbon_asset(cap, **kw)
+    gpu, orc = GpuRunner(asset, ctx=ctx), OracleRunner(asset)
+    sp, rng = bh.EffectSpawner(asset.spawner), bh.Pcg32()
+    for f in range(90):
+        dt = 1 / 60
+        if case == "zero_tick" and f in (20, 21):
+            dt = 0.0                 # spawns of these frames keep AGE 0: the next frame's spawns tie with them
+        if case == "dies_in_first_frame" and f % 4 == 0:
+            dt = 1 / 15
+        props = {}
+        if case == "two_ribbon_ids" and f == 30:
+            props = {"rid": np.array([1], dtype=np.uint32)}
+        fr = Frame(dt, sp.tick(dt if dt else 1 / 60, rng), frame_seed(f), time=f / 60, props=props)
+        gpu.step(fr)
+        orc.step(fr)
+        if case == "host_write" and f == 30:
+            ages = gpu.fx.read_attr(A.AGE.id)
+            gpu.fx.write_attr(A.AGE.id, ages)
+        if f % 3 == 2 or f in (20, 21, 22, 23, 30, 31):
+            assert_same_state(orc.state(), gpu.state(), f"{case} frame {f}")
+    rot, ineligible = _rotations(gpu.prog)
+    if case in ("age_not_zero",):
+        assert rot == 0
+    elif case == "per_particle_rid":
+        assert ineligible and rot == 0
+    elif case in ("two_ribbon_ids", "host_write"):
+        assert 20 <= rot <= 31          # rotations until the premise broke at frame 30, none after
+    elif case == "zero_tick":
+        assert rot <= 22                # the zero tick ends it for good
+    else:
+        assert 0 < rot < 89             # only the frames whose tick a new particle survives
+    gpu.fx.destroy(); gpu.prog.destroy()
