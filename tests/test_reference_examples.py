@@ -209,3 +209,28 @@ def test_gpu_worms_heads_and_bodies(ctx):
         for s in sys_:
             s.destroy()
     check_worms(st)
+
+
+# ---- committed digests of the example runs (tests/golden/example_digests.json, made by tests/golden/make_example_digests.py) ---------
+def _load_digests():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "example_digests.json")) as f:
+        return json.load(f)
+
+
+def test_oracle_reproduces_the_committed_example_digests():
+    """Drift of the checker itself: the oracle's full state of every example effect at frames 0, 29, 89 and 149."""
+    from golden.make_example_digests import play
+    assert play(OracleRunner) == _load_digests()
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_the_committed_example_digests(ctx):
+    """The product against the committed digests, no oracle in the loop."""
+    from golden.make_example_digests import play
+    got = play(lambda asset: GpuRunner(asset, ctx=ctx))
+    want = _load_digests()
+    assert got.keys() == want.keys()
+    bad = [(k, f) for k in want for f in want[k] if got[k][f] != want[k][f]]
+    assert not bad, bad
