@@ -191,7 +191,7 @@ struct HnbProgram {
     uint32_t frame_max_spawn = 0;           // largest spawn request of an instance in the frame being enqueued
     bool frame_sort_values_ok = false;      // this frame's init age and tick are >= +0 for every instance
     // ... and can it prove more: that this frame's spawns sort IN FRONT of every older particle? Then the sorted list is a rotation of the
-    // list and no key is read (k_sort_rotate_*). Premises: one RIBBON_ID for every particle the effect ever had (set by the init from
+    // compacted list and no key is read: k_compact writes the survivors rotated (CompactArgs::rotate_front) and no sort kernel runs. Premises: one RIBBON_ID for every particle the effect ever had (set by the init from
     // ONE uniform value that never changed, or never set: 0); spawns start at AGE +0 and the update ticks them once in their first frame,
     // so the tail's keys are all (rid, tick_now); every older particle has age >= fl(t_g + tick_now) for the tick t_g of the frame
     // it was spawned in (ages only grow: monotone addition), hence >= fl(min_tick + tick_now) with the smallest tick of any earlier
@@ -206,6 +206,7 @@ struct HnbProgram {
     bool sort_front_broken = false;
     float sort_min_tick = __builtin_inff();
     bool frame_sort_front = false;          // decision for the frame being enqueued
+    bool frame_rotate = false;              // ... together with everything else the rotation needs (the head provably sorted, no host write, spawns)
     uint32_t sort_rotated_frames = 0;       // statistics: frames whose ribbon sort was a rotation
 };
 
@@ -1268,6 +1269,7 @@ static CompactArgs compact_args_of(const HnbProgram* p) {
     ca.alive_off[0] = p->dev.alive_off[0]; ca.alive_off[1] = p->dev.alive_off[1]; ca.dead_off = p->dev.dead_off;
     ca.alive_flag_off = p->dev.alive_flag_off;
     ca.slot_order = p->slot_order ? 1u : 0u;
+    ca.rotate_front = p->frame_rotate ? 1u : 0u;   // k_compact writes the survivors [spawns | older ones]: see CompactArgs (ribbon programs never have slot-ordered lists)
     return ca;
 }
 
@@ -1433,6 +1435,7 @@ int hnb_simulate(HnbContext* ctx) {
                     front = tick_now > 0.0f && bound > tick_now;
                 }
                 p->frame_sort_front = front;
+                p->frame_rotate = front && p->sort_provable && p->frame_sort_values_ok && !p->sort_dirty && ctx->skip_lists && p->frame_max_spawn > 0u;
                 if (have && tick_now == tick_now) p->sort_min_tick = tick_now < p->sort_min_tick ? tick_now : p->sort_min_tick;
             }
             p->skip_now = false;
@@ -1524,13 +1527,7 @@ int hnb_simulate(HnbContext* ctx) {
         // for a small range. Otherwise the device decides (k_sort_fill's order check) and all launches are issued.
         const bool proven = p->sort_provable && p->frame_sort_values_ok && !p->sort_dirty && ctx->skip_lists;
         if (proven && p->frame_max_spawn == 0u) return;
-        if (proven && p->frame_sort_front) {  // the spawns go in front: a rotation of the list, no keys (k_sort_rotate_*)
-            const SortArgs& so = p->sort;
-            const DevMeta* mo = p->d_meta[par ^ 1];
-            const uint32_t tiles = n * so.chunks_per_inst;
-            const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(p->d_frame_cur);
-            k_sort_rotate_save<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, dfi);
-            k_sort_rotate_write<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, dfi);
+        if (p->frame_rotate) {  // the spawns go in front and k_compact has written the survivors in that order (CompactArgs::rotate_front): nothing to sort
             p->sort_rotated_frames += 1;
             return;
         }

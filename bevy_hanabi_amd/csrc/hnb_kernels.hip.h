@@ -439,7 +439,8 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     const uint32_t total_dead = deaths_cur[c.k];
     if (c.j == 0 && tid == 0) cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + c.k] = 0u;  // next frame's counter
     const bool last = c.n == 0 ? c.j == 0 : (c.start < c.n && c.start + kChunk >= c.n);
-    if (total_dead == 0u) {
+    const bool rotate = args.rotate_front != 0u && c.n_spawn != 0u;   // (uniform per instance; never set together with slot_order)
+    if (total_dead == 0u && !rotate) {
         if (last && tid == 0) {
             DevMeta o = c.m;
             o.alive_count = c.n;
@@ -464,20 +465,28 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     }
     if (!has_rows) return;
     // exclusive prefix of the survivor counts of the earlier chunks of this instance
+    // (an instance without a casualty gets here only to be rotated: k_list_rows recorded no counts for it, every row survives)
     const uint32_t* cnt = cb.counts + (size_t)c.k * args.chunks_per_inst;
-    uint32_t part = 0;
-    for (uint32_t i = tid; i < c.j; i += kBlock) part += cnt[i];
-#pragma unroll
-    for (uint32_t off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if (lane == 0) s_red[wave] = part;
-    __syncthreads();
-    uint32_t excl = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < kBlock / 64; ++w) excl += s_red[w];
     const uint32_t rows = (c.n - c.start) < kChunk ? (c.n - c.start) : kChunk;
-    const uint32_t a = cnt[c.j];
+    uint32_t excl = c.start;
+    if (total_dead != 0u) {
+        uint32_t part = 0;
+        for (uint32_t i = tid; i < c.j; i += kBlock) part += cnt[i];
+#pragma unroll
+        for (uint32_t off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (lane == 0) s_red[wave] = part;
+        __syncthreads();
+        excl = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kBlock / 64; ++w) excl += s_red[w];
+    }
+    const uint32_t a = total_dead != 0u ? cnt[c.j] : rows;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(c.base + args.alive_off[c.m.write_index]) + c.start;
-    uint32_t* dst = reinterpret_cast<uint32_t*>(c.base + args.alive_off[c.m.write_index ^ 1u]) + excl;
+    uint32_t* out = reinterpret_cast<uint32_t*>(c.base + args.alive_off[c.m.write_index ^ 1u]);
+    // survivor g of the instance goes to row g - or, rotated: the last n_spawn survivors are this frame's spawns (k_init appended them, none of
+    // them dies in its first frame: a premise of the proof) and go first, everything older follows
+    const uint32_t tail = rotate ? c.n_spawn : 0u;
+    const uint32_t head_n = (c.n - total_dead) - tail;
     uint32_t* dead = reinterpret_cast<uint32_t*>(c.base + args.dead_off);
     const uint32_t dead_before = c.start - excl;
     // survivors keep their (stable, serial) order (vfx_update.wgsl:161-165)
@@ -493,8 +502,10 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
 #pragma unroll
         for (uint32_t q = 0; q < kHalf; ++q) {
             const uint32_t i = tid + (h * kHalf + q) * kBlock;
-            if (i < a) dst[i] = v[q];
-            else if (i < rows) {
+            if (i < a) {
+                const uint32_t g = excl + i;
+                out[g >= head_n ? g - head_n : g + tail] = v[q];
+            } else if (i < rows) {
                 // the d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151); its slot is free again
                 dead[c.n - 1u - (dead_before + (i - a))] = v[q];
                 flags[v[q]] = 0u;
@@ -521,6 +532,8 @@ struct CompactArgs {
     uint32_t alive_off[2], dead_off;
     uint32_t alive_flag_off;   // u8[capacity]: 0 free, 1 alive, 2 died in this frame's update
     uint32_t slot_order;       // HNB_LIST_ORDER_SLOT: k_order_write rebuilds the lists from the alive bytes
+    uint32_t rotate_front;     // ribbon programs, host-proven (HnbProgram::sort_front_*): this frame's spawns sort in front of every older
+                               // particle, so the survivors are written [spawns | older ones] and the list needs no sort afterwards
 };
 #ifndef HNB_JIT_TU
 __global__ void __launch_bounds__(kBlock)

@@ -277,39 +277,8 @@ k_sort_scatter(const SortArgs a, const uint64_t* __restrict__ inst_base, const D
 // "This frame's spawns sort in front of everything else": where the host can prove that every key of the tail is strictly smaller than
 // every key of the head (one RIBBON_ID for the whole effect, spawns start at AGE +0 and have been ticked once, every older particle at
 // least twice - see HnbProgram::sort_front_* in hanabi_amd.hip), the sorted list is [tail rows in list order | head rows in list
-// order]: a rotation of the list by the number of spawns. No key is read. Two passes over the rows (the list column is also the
-// source): save, then write rotated.
-__global__ void __launch_bounds__(kBlock)
-k_sort_rotate_save(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta, const DevFrameInst* __restrict__ fi) {
-    uint32_t k, j; char* base;
-    sort_setup(blockIdx.x, a, inst_base, k, j, base);
-    if (fi[k].skip) return;                // a frozen instance: its counters (`spawned` too) are last frame's, its list is in order
-    const uint32_t n = meta[k].alive_count;
-    const uint32_t tail = meta[k].spawned < n ? meta[k].spawned : n;
-    if (tail == 0u || tail == n) return;   // nothing moves
-    const uint32_t* list = reinterpret_cast<const uint32_t*>(base + a.alive_off[meta[k].write_index & 1u]);
-    uint32_t* vals = reinterpret_cast<uint32_t*>(base + a.val_off[0]);
-    for (uint32_t r = 0; r < kSortTile / kBlock; ++r) {
-        const uint32_t i = j * kSortTile + r * kBlock + threadIdx.x;
-        if (i < n) vals[i] = list[i];
-    }
-}
-__global__ void __launch_bounds__(kBlock)
-k_sort_rotate_write(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta, const DevFrameInst* __restrict__ fi) {
-    uint32_t k, j; char* base;
-    sort_setup(blockIdx.x, a, inst_base, k, j, base);
-    if (fi[k].skip) return;
-    const uint32_t n = meta[k].alive_count;
-    const uint32_t tail = meta[k].spawned < n ? meta[k].spawned : n;
-    if (tail == 0u || tail == n) return;
-    const uint32_t head = n - tail;
-    uint32_t* list = reinterpret_cast<uint32_t*>(base + a.alive_off[meta[k].write_index & 1u]);
-    const uint32_t* vals = reinterpret_cast<const uint32_t*>(base + a.val_off[0]);
-    for (uint32_t r = 0; r < kSortTile / kBlock; ++r) {
-        const uint32_t i = j * kSortTile + r * kBlock + threadIdx.x;
-        if (i < n) list[i] = i < tail ? vals[head + i] : vals[i - tail];
-    }
-}
+// order]: a rotation of the compacted list by the number of spawns. No key is read and no kernel of this file runs: k_compact writes
+// the survivors in that order (CompactArgs::rotate_front in hnb_kernels.hip.h).
 
 // The whole radix sort of one instance's range by ONE workgroup: every pass whose digit varies, histogram -> digit bases ->
 // stable scatter over the range's keys in order, the passes separated by workgroup barriers only. The usual ribbon frame
