@@ -43,12 +43,17 @@ struct u2_t { uint32_t x, y; };
 struct u3_t { uint32_t x, y, z; };
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 // Streaming accesses use the default cache policy: `nontemporal` hints measured 13 % SLOWER on
-// MI355X for this kernel (profiles/r01b_summary.md).
-#ifdef HNB_NONTEMPORAL
+// MI355X for this kernel (profiles/r01b_summary.md). Round 2, with the alternating walk, separately (two A/B rounds of bench.py on one
+// box): nontemporal LOADS only 0.203 vs 0.159 ms on C2 and 0.292 vs 0.223 on C4 (they forgo the Infinity-Cache hits the walk is built
+// for), nontemporal STORES only: no difference (0.159 / 0.160 vs 0.159 / 0.161).
+#if defined(HNB_NONTEMPORAL) || defined(HNB_NONTEMPORAL_LOADS)
 #define HNB_NT_LOAD(p) __builtin_nontemporal_load(p)
-#define HNB_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
 #else
 #define HNB_NT_LOAD(p) (*(p))
+#endif
+#if defined(HNB_NONTEMPORAL) || defined(HNB_NONTEMPORAL_STORES)
+#define HNB_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
 #define HNB_NT_STORE(v, p) (*(p) = (v))
 #endif
 
