@@ -877,8 +877,42 @@ HNB_HD void apply_static(const Ins ins, Pinned<P>& X, const VmUniforms& U) {
     }
 }
 
+// The same ops on a FLAT view of the position / velocity planes: 12 consecutive-in-the-plane floats per plane that do not belong to whole
+// particles (three 16-byte words of a lane, see k_update_slots_stream's flat path). Float k of a plane is component k mod 3 of particle
+// k / 3, and these four ops are component-wise - the same IEEE operations in the same order on every float as the per-particle form,
+// with the per-component operand picked by `rot` (component of the lane's first float) + the float's position.
+HNB_HD float rot3(const V3 v, uint32_t c) { return c == 0u ? v.x : (c == 1u ? v.y : v.z); }
+template <uint32_t OP>
+HNB_HD void apply_static_flat(const Ins ins, float (&pos)[3][4], float (&vel)[3][4], uint32_t rot, const VmUniforms& U) {
+    const uint32_t a = HNB_OPERAND_DECODE((ins.x >> 16) & 0xffu, ins.y >> 13);
+    if constexpr (OP == HNB_OP_M_EULER) {
+        const float dt = uf(U, a);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pos[j][e] = pos[j][e] + vel[j][e] * dt;
+    } else if constexpr (OP == HNB_OP_M_VEL_SCALE) {
+        const float s = uf(U, a);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vel[j][e] = vel[j][e] * s;
+    } else if constexpr (OP == HNB_OP_M_VEL_ADD) {
+        const V3 v = uf3(U, a);
+        const float vr[3] = {rot3(v, rot % 3u), rot3(v, (rot + 1u) % 3u), rot3(v, (rot + 2u) % 3u)};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vel[j][e] = vel[j][e] + vr[(j + e) % 3];
+    } else {
+        static_assert(OP == HNB_OP_M_AGE_TICK, "apply_static_flat: not a component-wise op");  // the age lives in the chunk's cohort word
+    }
+}
+
 // Interpreted program (any streamable sequence).
 struct ProgInterp {
+    static constexpr bool kFlat = false;
+    HNB_HD_MEMBER static void run_flat(const Ins* __restrict__, float (&)[3][4], float (&)[3][4], uint32_t, const VmUniforms&) {}
     static constexpr uint32_t kLen = 0;
     template <int P> HNB_HD_MEMBER static void run(const Ins* __restrict__ code, uint32_t n_ins, Pinned<P>& X, const VmUniforms& U) {
         fast_run<P, true>(code, n_ins, X, U);
@@ -886,6 +920,8 @@ struct ProgInterp {
 };
 // Empty update stream (no AGE, no velocity, no update modifier): only the lists are maintained.
 struct ProgNone {
+    static constexpr bool kFlat = false;
+    HNB_HD_MEMBER static void run_flat(const Ins* __restrict__, float (&)[3][4], float (&)[3][4], uint32_t, const VmUniforms&) {}
     static constexpr uint32_t kLen = 0;
     template <int P> HNB_HD_MEMBER static void run(const Ins* __restrict__, uint32_t, Pinned<P>&, const VmUniforms&) {}
     static bool matches(const Ins*, uint32_t n_ins) { return n_ins == 0; }
@@ -894,6 +930,15 @@ struct ProgNone {
 template <uint32_t... OPS>
 struct ProgStatic {
     static constexpr uint32_t kLen = sizeof...(OPS);
+    // every op component-wise (and an AGE_TICK among them: the flat path needs the chunk's ages in a cohort word)
+    static constexpr bool kFlat = ((OPS == HNB_OP_M_AGE_TICK || OPS == HNB_OP_M_EULER || OPS == HNB_OP_M_VEL_SCALE || OPS == HNB_OP_M_VEL_ADD) && ...) &&
+                                  ((OPS == HNB_OP_M_AGE_TICK) || ...);
+    HNB_HD_MEMBER static void run_flat(const Ins* __restrict__ code, float (&pos)[3][4], float (&vel)[3][4], uint32_t rot, const VmUniforms& U) {
+        if constexpr (kFlat) {
+            uint32_t i = 0;
+            ((apply_static_flat<OPS>(code[i++], pos, vel, rot, U)), ...);
+        }
+    }
     template <int P> HNB_HD_MEMBER static void run(const Ins* __restrict__ code, uint32_t, Pinned<P>& X, const VmUniforms& U) {
         uint32_t i = 0;
         ((apply_static<OPS, P>(code[i++], X, U)), ...);
