@@ -240,6 +240,7 @@ def run_config(name, args, D, strong=False):
         prog = ctx.create_program(bh.lower(asset))
         fxs = [prog.create_effect() for _ in mine]
         gids = list(mine)
+        gid_mix = (np.asarray(gids, dtype=np.uint64) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)   # instance_seed(f, i), vectorised over i
         xf_of = np.array([instance_transform(i) for i in gids], dtype=np.float32)
         local_particles = per_inst_cap * len(fxs)
         sharding_desc = f"by instance: {total_inst} instances over {n} rank(s), {len(fxs)} on rank 0"
@@ -273,7 +274,8 @@ def run_config(name, args, D, strong=False):
         ctx.frame_begin(dt, f * dt)
         if name == "c4":
             s = spawn_of(f)
-            prog.set_frames([s] * len(fxs), [instance_seed(f, i) for i in gids], xf_of)
+            # (numpy, not a Python loop over 512 instances: the harness must not be what the step waits for)
+            prog.set_frames(np.full(len(fxs), s, dtype=np.uint32), (gid_mix ^ np.uint64(frame_seed(f))).astype(np.uint32), xf_of)
         elif name == "c5":   # the emitter moves (ribbon.rs Shape::tick, Lissajou)
             t = f * dt * 6.5
             fxs[0].set_frame(spawn_of(f), frame_seed(f), [1, 0, 0, 25.0 * np.cos(3.0 * t), 0, 1, 0, 25.0 * np.sin(2.0 * t), 0, 0, 1, 0.0])
