@@ -114,6 +114,7 @@ struct HnbContext {
     uint32_t list_order = HNB_LIST_ORDER_SPAWN;  // applied to programs created afterwards
     bool skip_lists = true;     // skip the list kernels of frames the device's no-death bound covers (HNB_SKIP_LISTS=0 turns it off)
     bool alternate = true;      // walk the chunks in alternating directions from frame to frame (HNB_ALTERNATE=0 turns it off)
+    bool transpose = true;      // vec3 planes of the per-particle update path through the wave's LDS transpose (HNB_TRANSPOSE=0 turns it off)
     uint32_t timing = 0;        // 0 = off, n = time every n-th simulated frame
     uint32_t timing_tick = 0;
     std::vector<TimingPair> t_update, t_init, t_compact;
@@ -738,6 +739,7 @@ int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     if (const char* e = getenv("HNB_ALTERNATE")) ctx->alternate = e[0] != '0';
+    if (const char* e = getenv("HNB_TRANSPOSE")) ctx->transpose = e[0] != '0';
     if (const char* e = getenv("HNB_SKIP_LISTS")) ctx->skip_lists = e[0] != '0';
     *out_ctx = ctx;
     return HNB_OK;
@@ -1577,6 +1579,7 @@ int hnb_simulate(HnbContext* ctx) {
             sa.skip_lists = p->skip_now ? 1u : 0u;
             sa.meta_in = p->d_meta[par]; sa.meta_out = p->d_meta[par ^ 1];
             sa.fault = p->d_fault;
+            sa.transpose = ctx->transpose ? 1u : 0u;
             for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
                 const DevAttr& at = p->dev.attrs[a];
                 const int pi = at.reg == HNB_REG_POSITION ? 0 : at.reg == HNB_REG_VELOCITY ? 1 : at.reg == HNB_REG_AGE ? 2 : at.reg == HNB_REG_LIFETIME ? 3 : -1;

@@ -333,6 +333,48 @@ __device__ __forceinline__ void pin_store1(const float (&src)[P], char* plane, c
         if (valid[p]) reinterpret_cast<float*>(plane)[slot[p]] = src[p];
 }
 
+// ---- vec3 planes through a wave-private LDS transpose ---------------------------------------------
+// A lane of the per-particle path owns 4 consecutive slots = 48 contiguous bytes of a vec3 plane. Accessing them directly makes every
+// 16-byte access of a wave a set of 64 words at a 48-byte lane stride: 24 cache lines touched for 1 KiB of payload, and the update runs at
+// 5.0 TB/s where contiguous accesses reach 6 (see the flat path in k_update_slots_stream). Here the wave takes the step's 192 words
+// (256 slots x 12 B = 3 KiB) with three contiguous 1 KiB accesses (lane l: words l, 64 + l, 128 + l), parks them in its own 3 KiB of LDS
+// and reads its three words 3l .. 3l + 2 back (a 48-byte lane stride is conflict-free on 64 four-byte banks: 16 lanes x 4 dwords cover every
+// bank once). The store goes the other way - and since the staging buffer still holds the plane as loaded, a lane writes only the words of
+// its ALIVE slots into it: free slots get their own bytes back, every line is stored in full, and the read-blend-store of partially alive
+// quads (pin_store3) is not needed. LDS instructions of one wave execute in order: no barrier.
+__device__ __forceinline__ void xpose_load3(V3 (&dst)[4], const char* plane, uint32_t first_slot, u4v* lds, uint32_t lane) {
+    const u4v* src = reinterpret_cast<const u4v*>(plane) + (size_t)(first_slot >> 2) * 3;
+    const u4v a = src[lane], b = src[64u + lane], c = src[128u + lane];
+    lds[lane] = a; lds[64u + lane] = b; lds[128u + lane] = c;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const u4v q0 = lds[3u * lane], q1 = lds[3u * lane + 1u], q2 = lds[3u * lane + 2u];
+    dst[0] = V3{u2f(q0.x), u2f(q0.y), u2f(q0.z)};
+    dst[1] = V3{u2f(q0.w), u2f(q1.x), u2f(q1.y)};
+    dst[2] = V3{u2f(q1.z), u2f(q1.w), u2f(q2.x)};
+    dst[3] = V3{u2f(q2.y), u2f(q2.z), u2f(q2.w)};
+}
+// `lds` must still hold what xpose_load3 put there for this plane and step.
+__device__ __forceinline__ void xpose_store3(const V3 (&src)[4], char* plane, uint32_t first_slot, u4v* lds, uint32_t lane, const bool (&valid)[4], bool full) {
+    if (full) {
+        lds[3u * lane] = u4v{f2u(src[0].x), f2u(src[0].y), f2u(src[0].z), f2u(src[1].x)};
+        lds[3u * lane + 1u] = u4v{f2u(src[1].y), f2u(src[1].z), f2u(src[2].x), f2u(src[2].y)};
+        lds[3u * lane + 2u] = u4v{f2u(src[2].z), f2u(src[3].x), f2u(src[3].y), f2u(src[3].z)};
+    } else {
+        uint32_t* w = reinterpret_cast<uint32_t*>(lds) + 12u * lane;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (valid[p]) { w[3 * p] = f2u(src[p].x); w[3 * p + 1] = f2u(src[p].y); w[3 * p + 2] = f2u(src[p].z); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    u4v* dstp = reinterpret_cast<u4v*>(plane) + (size_t)(first_slot >> 2) * 3;
+    const u4v a = lds[lane], b = lds[64u + lane], c = lds[128u + lane];
+    dstp[lane] = a; dstp[64u + lane] = b; dstp[128u + lane] = c;
+}
+
 // ---- update + kill + compaction ----------------------------------------------------------------
 // Launches per program per frame, none of which waits for another workgroup (measured alternative: a
 // single-pass decoupled look-back with ticketed persistent workgroups was 10-13 % slower on this short kernel
@@ -755,6 +797,7 @@ struct SlotArgs {
     const DevMeta* meta_in;
     DevMeta* meta_out;
     uint32_t* fault;         // set to 1 if a particle dies in a frame whose lists were skipped (never, unless the proof is wrong)
+    uint32_t transpose;      // 1: vec3 planes of the per-particle path go through the wave's LDS transpose (xpose_load3 / xpose_store3)
 };
 
 // The deaths of a frame are known on the device only after its update ran, and HIP has no indirect dispatch: the list
@@ -802,6 +845,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     __shared__ uint32_t s_alive[kBlock / 64];
     __shared__ float s_rem[kBlock / 64];
     __shared__ uint32_t s_amin[kBlock / 64], s_amax[kBlock / 64];
+    __shared__ u4v s_xp[2][kBlock / 64][kStepRows * 3u / 4u];   // position / velocity staging of each wave's step (xpose_load3): 24 KiB per workgroup
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
     const uint32_t k = chunk / args.chunks_per_inst, j = chunk - k * args.chunks_per_inst;
@@ -920,9 +964,19 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
 #pragma unroll
         for (int p = 0; p < 4; ++p) { X.pos[p] = V3{0, 0, 0}; X.vel[p] = V3{0, 0, 0}; X.age[p] = 0.0f; X.lifetime[p] = 0.0f; X.alive[p] = true; }
         bool need_life = true;  // wave-uniform
+        // (wave-uniform) the step's 256 slots lie inside the planes: its vec3 planes go through the LDS transpose, every lane taking part
+        const uint32_t step_first = s0 - lane * 4u;
+        // (... where at least half of the quads hold a live particle: in the last frames of a die-off the direct path touches fewer lines)
+        const bool xp = args.transpose != 0u && PROBE == 0 && step_first + kStepRows <= args.capacity && __popcll(__ballot(any)) >= 32;
+        if (xp) {
+            if (fl & 1u) xpose_load3(X.pos, p_pos, step_first, s_xp[0][wave], lane);
+            if (fl & 2u) xpose_load3(X.vel, p_vel, step_first, s_xp[1][wave], lane);
+        }
         if (any) {
-            if (fl & 1u) pin_load3<4>(X.pos, p_pos, slot, lanes_on, true);
-            if (fl & 2u) pin_load3<4>(X.vel, p_vel, slot, lanes_on, true);
+            if (!xp) {
+                if (fl & 1u) pin_load3<4>(X.pos, p_pos, slot, lanes_on, true);
+                if (fl & 2u) pin_load3<4>(X.vel, p_vel, slot, lanes_on, true);
+            }
             if (fl & 4u) {
                 if (!COHORT || ast != 1u) pin_load1<4>(X.age, p_age, slot, lanes_on, true);
                 if (COHORT && ast != 0u) {   // (selects, no divergence: ast is uniform, fresh[] only ever set in state 2)
@@ -947,9 +1001,13 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
         if (!need_life) loaded_all = false;
         if constexpr (!(PROBE & 8)) PROG::template run<4>(args.update_code, args.update_len, X, U);
         if constexpr (!(PROBE & 4)) {
+            // (a plane that is stored without having been loaded has no staged copy: the direct path)
+            const bool xp_pos = xp && (fl & 17u) == 17u, xp_vel = xp && (fl & 34u) == 34u;
+            if (xp_pos) xpose_store3(X.pos, p_pos, step_first, s_xp[0][wave], lane, was, full);
+            if (xp_vel) xpose_store3(X.vel, p_vel, step_first, s_xp[1][wave], lane, was, full);
             if (any) {  // a full quad is stored with 16-byte stores; otherwise only the alive slots are written
-                if (fl & 16u) pin_store3<4>(X.pos, p_pos, slot, was, full);
-                if (fl & 32u) pin_store3<4>(X.vel, p_vel, slot, was, full);
+                if ((fl & 16u) && !xp_pos) pin_store3<4>(X.pos, p_pos, slot, was, full);
+                if ((fl & 32u) && !xp_vel) pin_store3<4>(X.vel, p_vel, slot, was, full);
                 if (fl & 64u) {
                     if (!COHORT || ast != 1u) pin_store1<4>(X.age, p_age, slot, was, full);
                 }
