@@ -920,7 +920,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
             u4v* pw = reinterpret_cast<u4v*>(p_pos + (size_t)j * (kChunk * 12u)) + wave * (kWaveRows * 3u / 4u);
             u4v* vw = reinterpret_cast<u4v*>(p_vel + (size_t)j * (kChunk * 12u)) + wave * (kWaveRows * 3u / 4u);
             const uint32_t rot = lane % 3u;   // component of this lane's first float in every word it takes: (word index) mod 3 = (3 step + w + lane) mod 3, w added below
-#pragma unroll 2
+#pragma unroll 2   // (all four steps unrolled: 0.1313 instead of 0.1298 ms, three A/B rounds on one box)
             for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
                 float P[3][4], V[3][4];
 #pragma unroll
