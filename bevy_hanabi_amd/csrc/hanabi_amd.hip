@@ -190,7 +190,10 @@ struct HnbProgram {
     bool sort_dirty = true;                 // a host write (or nothing yet) since the last sort: the whole list is the range
     uint32_t sort_parity = 0;               // frames in which the sort ran (its state double buffer)
     uint32_t frame_max_spawn = 0;           // largest spawn request of an instance in the frame being enqueued
-    bool frame_sort_values_ok = false;      // this frame's init age and tick are >= +0 for every instance
+    bool frame_sort_values_ok = false;      // this frame's init age and tick are >= +0 for every instance (and were in every earlier frame)
+    bool sort_values_broken = false;        // sticky: some frame had a negative / NaN tick or initial age. Negative ages can outlive that frame's
+                                            // (device-checked) sort, and when they cross zero later their bit-pattern keys change order although
+                                            // that later frame's own values are fine: from then on only the device-side order check decides
     // ... and can it prove more: that this frame's spawns sort IN FRONT of every older particle? Then the sorted list is a rotation of the
     // compacted list and no key is read: k_compact writes the survivors rotated (CompactArgs::rotate_front) and no sort kernel runs. Premises: one RIBBON_ID for every particle the effect ever had (set by the init from
     // ONE uniform value that never changed, or never set: 0); spawns start at AGE +0 and the update ticks them once in their first frame,
@@ -1405,10 +1408,12 @@ int hnb_simulate(HnbContext* ctx) {
                     const uint32_t age_bits = p->sort_age_init_set ? ub[p->sort_age_init_operand & 0xffu] : 0u;
                     ok = tick_bits <= 0x7f800000u && age_bits <= 0x7f800000u;   // >= +0 and not NaN: ages stay non-negative, key order == age order
                 }
-                p->frame_sort_values_ok = ok;
+                if (p->sort_provable && !ok) p->sort_values_broken = true;
+                p->frame_sort_values_ok = ok && !p->sort_values_broken;
+                ok = p->frame_sort_values_ok;
                 // in front of everything? (HnbProgram::sort_front_static)
                 bool front = p->sort_front_static && ok && !p->sort_front_broken;
-                float tick_now = 0.0f;
+                float tick_now = 0.0f, frame_min_tick = __builtin_inff();   // (the smallest tick of ANY simulated instance enters sort_min_tick)
                 bool have = false;
                 for (uint32_t i = 0; i < n; ++i) {
                     const HnbEffect* fx = p->effects[i];
@@ -1428,6 +1433,7 @@ int hnb_simulate(HnbContext* ctx) {
                     if (!(life_bits < 0x7f800000u && tk < life)) front = false;   // a spawn would die in its first frame and miss the list
                     float t;
                     memcpy(&t, &tick_bits, 4);
+                    if (t == t) frame_min_tick = t < frame_min_tick ? t : frame_min_tick;
                     if (!have) { tick_now = t; have = true; }
                     else if (memcmp(&t, &tick_now, 4) != 0) front = false;
                 }
@@ -1438,7 +1444,7 @@ int hnb_simulate(HnbContext* ctx) {
                 }
                 p->frame_sort_front = front;
                 p->frame_rotate = front && p->sort_provable && p->frame_sort_values_ok && !p->sort_dirty && ctx->skip_lists && p->frame_max_spawn > 0u;
-                if (have && tick_now == tick_now) p->sort_min_tick = tick_now < p->sort_min_tick ? tick_now : p->sort_min_tick;
+                if (have) p->sort_min_tick = frame_min_tick < p->sort_min_tick ? frame_min_tick : p->sort_min_tick;
             }
             p->skip_now = false;
             if (p->skip_eligible && ctx->skip_lists && !any_spawn && !any_parent && tick_known) {
@@ -1701,6 +1707,7 @@ int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t 
     p->dirty = true;  // ... nor does the published no-death bound
     p->sort_dirty = true;  // ... and a ribbon list may no longer be in key order
     p->sort_front_broken = true;  // ... nor its ages and ribbon ids what the front proof assumes
+    if (attr == HNB_ATTR_AGE) p->sort_values_broken = true;  // ... and the written ages may be negative (they change key order when they cross zero later)
     // the chunks' lifetime bounds (lifetime culling) no longer describe the planes
     HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.lmin_off, 0, (size_t)p->dev.chunks_per_inst * 4));  // (the "completely alive" flags that follow stay valid)
     if (p->dev.age_cohort && attr == HNB_ATTR_AGE)   // the plane is the truth again: forget the cohort states (and values)

@@ -134,7 +134,18 @@ struct Parser {
         }
     }
 
+    // Nesting limit: the `ron` crate refuses documents nested deeper than its recursion limit (128 by default) with an error;
+    // without one, a buffer of a few hundred thousand '(' overflows the stack of this recursive-descent parser.
+    static constexpr int kMaxDepth = 128;
+    int depth = 0;
+    struct DepthGuard {
+        Parser& p;
+        explicit DepthGuard(Parser& q) : p(q) { if (++p.depth > kMaxDepth) p.fail("exceeded the recursion limit (128 nested values)"); }
+        ~DepthGuard() { --p.depth; }
+    };
+
     Node parse_value() {
+        DepthGuard guard(*this);
         ws();
         if (i >= s.size()) fail("unexpected end of input");
         Node n;
@@ -201,6 +212,11 @@ uint32_t u32_of(const Node& n, const char* what) {
     const double v = num(n, what);
     if (!(v >= 0.0 && v <= 4294967295.0) || v != std::floor(v)) bad(std::string(what) + ": expected an unsigned 32-bit integer");
     return (uint32_t)v;
+}
+int32_t i32_of(const Node& n, const char* what) {
+    const double v = num(n, what);   // (NaN fails the range test)
+    if (!(v >= -2147483648.0 && v <= 2147483647.0) || v != std::floor(v)) bad(std::string(what) + ": expected a signed 32-bit integer");
+    return (int32_t)v;
 }
 bool bool_of(const Node& n, const char* what) {
     if (n.kind == Node::Ident && n.text == "true") return true;
@@ -274,7 +290,7 @@ Value value_of(const Node& n) {
         const Node& x = payload(inner, 0, "ScalarValue");
         if (st == "Bool") return Value(bool_of(x, "ScalarValue::Bool"));
         if (st == "Float") return Value((float)num(x, "ScalarValue::Float"));
-        if (st == "Int") { const double d = num(x, "ScalarValue::Int"); if (d < -2147483648.0 || d > 2147483647.0 || d != std::floor(d)) bad("ScalarValue::Int out of range"); return Value((int32_t)d); }
+        if (st == "Int") return Value(i32_of(x, "ScalarValue::Int"));
         if (st == "Uint") return Value(u32_of(x, "ScalarValue::Uint"));
         bad("unknown ScalarValue::" + st);
     }
@@ -295,7 +311,7 @@ Value value_of(const Node& n) {
             if (st == ScalarType::Float) out.set_f(c, (float)num(x, "vector component"));
             else if (st == ScalarType::Bool) out.bits[c] = bool_of(x, "vector component") ? 1u : 0u;
             else if (st == ScalarType::Uint) out.bits[c] = u32_of(x, "vector component");
-            else out.bits[c] = (uint32_t)(int32_t)num(x, "vector component");
+            else out.bits[c] = (uint32_t)i32_of(x, "vector component");
         }
         return out;
     }

@@ -516,6 +516,25 @@ def test_ribbon_sort_is_a_rotation_where_the_spawns_provably_go_in_front(ctx):
     prog.destroy()
 
 
+def test_ribbon_sort_after_a_negative_tick_does_not_trust_later_frames(ctx):
+    """a negative delta_time leaves negative ages behind. The frame that had it is sorted by the device-checked path, but
+    the ages cross zero in LATER frames whose own tick is fine - their bit-pattern keys change order then. Those frames must not be
+    'proven sorted' by the host (the condition is sticky), with or without spawns."""
+    cap = 6000
+    asset = _ribbon_asset(cap)
+    gpu, orc = GpuRunner(asset, ctx=ctx), OracleRunner(asset)
+    sp, rng = bh.EffectSpawner(asset.spawner), bh.Pcg32()
+    for f in range(60):
+        dt = -0.2 if f == 20 else 1 / 60
+        spawn = sp.tick(1 / 60, rng) if (f < 20 or f >= 40) else 0    # frames 21..39: no spawns - the host used to skip the sort outright
+        fr = Frame(dt, spawn, frame_seed(f), time=f / 60)
+        gpu.step(fr)
+        orc.step(fr)
+        if f >= 19:
+            assert_same_state(orc.state(), gpu.state(), f"negative tick, frame {f}")
+    gpu.fx.destroy(); gpu.prog.destroy()
+
+
 @pytest.mark.parametrize("case", ["age_not_zero", "two_ribbon_ids", "dies_in_first_frame", "zero_tick", "host_write", "per_particle_rid"])
 def test_ribbon_rotation_is_suspended_where_its_premises_fail(ctx, case):
     """Each premise of the rotation, violated: the sort falls back to keys and stays bit-exact."""

@@ -166,6 +166,41 @@ def test_deserializer_errors():
             bh.from_ron(bad)
 
 
+def test_nesting_limit_is_an_error_not_a_crash():
+    """The `ron` crate refuses documents nested deeper than its recursion limit; here a buffer of 2,000,000 '(' used to overflow
+    the parser's stack (SIGSEGV through hnb_asset_from_ron). Every bracket kind, through the C ABI (status code, no crash)."""
+    lib = C.CDLL(hb.build_host_lib())
+    lib.hnb_host_last_error.restype = C.c_char_p
+    a = C.c_void_p()
+    for opener in (b"(", b"[", b"{", b"Some("):
+        text = opener * 2_000_000
+        assert lib.hnb_asset_from_ron(text, len(text), C.byref(a)) == -2
+        assert b"recursion limit" in lib.hnb_host_last_error()
+    with pytest.raises(Exception, match="recursion limit"):
+        bh.from_ron("(" * 200)
+    # 100 levels are fine for the parser itself (the asset is then rejected for its content, not its depth)
+    with pytest.raises(Exception) as ei:
+        bh.from_ron("(" * 100 + ")" * 100)
+    assert "recursion limit" not in str(ei.value)
+
+
+def test_int_vector_components_are_range_checked():
+    good = bh.to_ron(_ivec_asset())
+    assert "IVec3((1, -2, 3))" in good
+    assert bh.lower(bh.from_ron(good)) == bh.lower(_ivec_asset())
+    for bad in ("3000000000", "-2147483649", "1.5", "NaN", "inf"):
+        with pytest.raises(Exception, match="signed 32-bit"):
+            bh.from_ron(good.replace("IVec3((1, -2, 3))", f"IVec3((1, {bad}, 3))"))
+
+
+def _ivec_asset():
+    w = bh.ExprWriter()
+    pos = w.lit(bh.Value.vec_i([1, -2, 3])).cast(bh.VectorType.VEC3F).expr()
+    asset = bh.EffectAsset(16, bh.SpawnerSettings.once(4.0), w.finish())
+    asset.init(bh.SetAttributeModifier(bh.Attribute.POSITION, pos))
+    return asset
+
+
 def test_c_abi_round_trip():
     lib = C.CDLL(hb.build_host_lib())
     lib.hnb_host_last_error.restype = C.c_char_p
