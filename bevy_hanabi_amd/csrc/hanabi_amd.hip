@@ -161,7 +161,7 @@ struct HnbProgram {
     uint32_t* d_counts = nullptr;  // per chunk: survivors this frame
     uint32_t* d_deaths = nullptr;  // [2][table_cap]: casualties per instance, frame-parity double-buffered
     // per-frame parameter blocks: a ring, so that filling frame f+1..f+3 never waits for the GPU
-    bool lists_now = true;               // this frame needs k_list_rows / k_compact (false: the update rotated the counters itself)
+    bool lists_now = true;               // this frame needs k_count_rows / k_compact (false: the update rotated the counters itself)
     bool lists_merged = false;           // ... and they are served by the context's multi-program launches after every update kernel
     const char* d_frame_cur = nullptr;  // this frame's parameter block of the program inside the context's staging slot (HnbContext::d_stage)
     uint32_t ring = 0;          // slot of the next frame
@@ -435,6 +435,8 @@ bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgra
     for (uint32_t i = 0; i < h.n_attrs; ++i) plane[i] = place(align_up((size_t)h.capacity * attrs[i].ncomp * 4, 256));
     const uint64_t flag_off = place(align_up((size_t)h.capacity, 256));             // alive byte per slot, zeroed with the attribute planes
     const uint64_t lmin_off = place(align_up((size_t)d.chunks_per_inst * 16, 256));  // four u32 / f32 arrays per chunk: lifetime bound (0 = unknown), "completely alive" flag, age-cohort state, age-cohort value; zeroed too
+    const uint64_t bit_bytes = align_up((size_t)d.chunks_per_inst * (kChunk / 8), 256);
+    const uint64_t died_off = place(bit_bytes), rmask_off = place(bit_bytes);     // one bit per slot "died this frame", one bit per list row "survives" (k_count_rows / k_compact)
     uint64_t ev_off[HNB_MAX_EVENT_CHANNELS] = {};
     for (uint32_t c = 0; c < h.n_event_channels; ++c) ev_off[c] = place(list_bytes);  // per-slot staging of spawn events (k_update_slots_generic -> k_emit_count / k_emit_events)
     uint64_t key_off[2] = {}, val_off[2] = {}, hist_off = 0, gsum_off = 0, bits_off = 0;
@@ -457,6 +459,7 @@ bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgra
     }
     d.alive_flag_off = (uint32_t)flag_off;
     d.lmin_off = (uint32_t)lmin_off;
+    d.died_bits_off = (uint32_t)died_off; d.row_mask_off = (uint32_t)rmask_off;
     d.n_event_channels = h.n_event_channels;
     for (uint32_t c = 0; c < h.n_event_channels; ++c) d.ev_cnt_off[c] = (uint32_t)ev_off[c];
     if (ribbons) {
@@ -1273,6 +1276,7 @@ static CompactArgs compact_args_of(const HnbProgram* p) {
     ca.capacity = p->dev.capacity; ca.chunks_per_inst = p->dev.chunks_per_inst;
     ca.alive_off[0] = p->dev.alive_off[0]; ca.alive_off[1] = p->dev.alive_off[1]; ca.dead_off = p->dev.dead_off;
     ca.alive_flag_off = p->dev.alive_flag_off;
+    ca.died_bits_off = p->dev.died_bits_off; ca.row_mask_off = p->dev.row_mask_off;
     ca.slot_order = p->slot_order ? 1u : 0u;
     ca.rotate_front = p->frame_rotate ? 1u : 0u;   // k_compact writes the survivors [spawns | older ones]: see CompactArgs (ribbon programs never have slot-ordered lists)
     return ca;
@@ -1571,14 +1575,14 @@ int hnb_simulate(HnbContext* ctx) {
         CompactBufs cb = compact_bufs_of(ctx, p, n);
         TimingPair tu{}, tc{};
         if (timed) { tu.a = take_event(ctx); tu.b = take_event(ctx); tc.b = take_event(ctx); hipEventRecord(tu.a, ctx->stream); }
-        const uint32_t died_mark = p->slot_order ? 0u : 2u;
+        const uint32_t write_died = (p->lists_now && !p->slot_order) ? 1u : 0u;   // k_count_rows follows: the update leaves one died bit per slot
         if (p->update_streams) {
             SlotArgs sa{};
             sa.capacity = p->dev.capacity; sa.n_uregs = p->dev.n_uregs; sa.chunks_per_inst = p->dev.chunks_per_inst; sa.n_inst = n;
             sa.alive_flag_off = p->dev.alive_flag_off;
             sa.update_len = p->dev.update_len;
             sa.update_code = p->dev.update_code;
-            sa.died_mark = died_mark;
+            sa.died_bits_off = p->dev.died_bits_off; sa.write_died = write_died;
             sa.cull_lifetime = p->dev.cull_lifetime; sa.lmin_off = p->dev.lmin_off; sa.dt_operand = p->cull_dt_operand;
             sa.age_cohort = p->dev.age_cohort;
             if (p->skip_eligible) { sa.safe_words = p->d_safe; sa.safe_host = p->h_safe; sa.safe_parity = p->frames_run & 1u; sa.publish_tag = p->frames_run - 1u; sa.safe_stride = p->table_cap * p->dev.chunks_per_inst; }
@@ -1601,12 +1605,12 @@ int hnb_simulate(HnbContext* ctx) {
                 p->stream_launch(total_chunks, ctx->stream, sa, p->d_inst_base, dfi, dub, cb);
             }
         } else if (p->jit_update) {
-            uint32_t dm = died_mark;
+            uint32_t dm = write_died;
             void* ka[] = {&p->dev, &p->d_inst_base, &dfi, &dub, &cb, &dm};
             HIP_TRY(hipModuleLaunchKernel(p->jit_update, total_chunks, 1, 1, kBlock, 1, 1, 0, ctx->stream, ka, nullptr));
         } else {
-            if (p->wide_file) k_update_slots_generic<InterpCodeWide><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, dfi, dub, cb, died_mark);
-            else k_update_slots_generic<InterpCode><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, dfi, dub, cb, died_mark);
+            if (p->wide_file) k_update_slots_generic<InterpCodeWide><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
+            else k_update_slots_generic<InterpCode><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
         }
         if (timed) { hipEventRecord(tu.b, ctx->stream); ctx->t_update.push_back(tu); }
         const CompactArgs ca = compact_args_of(p);
@@ -1618,7 +1622,7 @@ int hnb_simulate(HnbContext* ctx) {
         }
         // lists: only the instances that lost particles have anything to do
         if (!p->lists_merged) {  // (merged: the lists, and the ribbon sort behind them, follow after the last program's update)
-            if (lists && !p->slot_order) k_list_rows<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
+            if (lists && !p->slot_order) k_count_rows<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
             if (lists) k_compact<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
             if (lists && p->slot_order) {  // rebuild the lists in increasing slot order (instances without a casualty or spawn return at once)
                 k_order_count<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
@@ -1630,7 +1634,7 @@ int hnb_simulate(HnbContext* ctx) {
         HIP_TRY(hipGetLastError());
     }
     if (n_jobs) {
-        k_list_rows_multi<<<job_wgs, kBlock, 0, ctx->stream>>>(d_jobs, n_jobs);
+        k_count_rows_multi<<<job_wgs, kBlock, 0, ctx->stream>>>(d_jobs, n_jobs);
         k_compact_multi<<<job_wgs, kBlock, 0, ctx->stream>>>(d_jobs, n_jobs);
         for (HnbProgram* p : order)
             if (p->lists_merged && p->has_ribbons) ribbon_sort(p);

@@ -32,7 +32,11 @@ struct DevProgram {
     uint32_t init_len, update_len;
     uint32_t n_inst;
     // GPU spawn events this program's update appends (EmitSpawnEventModifier): per-row staging planes in the slab
-    uint32_t alive_flag_off;   // u8[capacity]: 0 free, 1 alive, 2 died in this frame's update (drives the slot-major update)
+    uint32_t alive_flag_off;   // u8[capacity]: 0 free, 1 alive (3: alive, spawned this frame into an age-cohort chunk): drives the slot-major update
+    // List maintenance of frames with casualties (k_count_rows / k_compact): died_bits = one bit per SLOT, "died in this frame's update",
+    // rewritten completely by every update launch that is followed by the list kernels (64-bit words, bit s & 63 of word s >> 6);
+    // row_mask = one bit per alive-list ROW, "survives", written by k_count_rows for k_compact. Both [chunks_per_inst * kChunk / 8] bytes.
+    uint32_t died_bits_off, row_mask_off;
     uint32_t n_event_channels;
     uint32_t ev_cnt_off[HNB_MAX_EVENT_CHANNELS];     // u32[capacity] per channel: events appended by the particle in that slot
     // Lifetime culling (k_update_slots_stream): f32[chunks_per_inst], a lower bound of the LIFETIME of every alive particle

@@ -3,21 +3,23 @@
 //   k_init                  replaces vfx_init.wgsl:101-196   (spawn: pop dead slot, run INIT program, append to alive list)
 //   k_update_slots_stream   replaces vfx_update.wgsl:105-167 for update programs made of macro ops on POSITION / VELOCITY /
 //   k_update_slots_generic  AGE / LIFETIME (stream) or any program (generic): age / reap / modifiers / Euler / kill test
-//   k_list_rows, k_compact  the alive / dead list rebuild of vfx_update.wgsl:148-166 and the counter rotation of
+//   k_count_rows, k_compact the alive / dead list rebuild of vfx_update.wgsl:148-166 and the counter rotation of
 //                           vfx_indirect.wgsl:30-90 + vfx_prefix_sum.wgsl:13-43, only where particles died
 //   k_emit_count/_events    append_spawn_events_N (src/lib.rs:976-993) in serial order
 //
 // Design notes (MI355X-first):
-//  * SoA: one packed plane per attribute. The update walks the SLOTS, driven by one alive byte per slot (0 free, 1 alive,
-//    2 died in this frame): a lane owns 4 consecutive slots, so every attribute access is a 16-byte dwordx4 whatever the
-//    alive list looks like after hours of spawn / kill churn; the update never touches the lists.
+//  * SoA: one packed plane per attribute. The update walks the SLOTS, driven by one alive byte per slot (0 free, 1 alive):
+//    a lane owns 4 consecutive slots, so every attribute access is a 16-byte dwordx4 whatever the alive list looks like
+//    after hours of spawn / kill churn; the update never touches the lists. What it leaves for them is one bit per slot,
+//    "died in this frame" (2 MiB for 16.7M slots: it stays in every XCD's L2).
 //  * Uniform sub-expressions never reach the GPU as code: the host evaluates them into a per-instance parameter block
 //    that the kernels read with scalar loads.
 //  * The reference rebuilds the alive list with 1-3 global atomics per particle (vfx_update.wgsl:148-166). Here the lists
-//    change only in frames with casualties, and then in two light passes over the ROWS: k_list_rows partitions every
-//    4096-row chunk into [survivors | casualties] with wave ballots + popcounts staged in LDS and records the survivor
-//    count; k_compact takes the exclusive prefix of the earlier chunks' counts and moves survivors / casualties to
-//    their final rows in serial (stable) order. One non-returning atomic per workgroup with casualties, none per particle.
+//    change only in frames with casualties, and then in two light passes over the ROWS: k_count_rows reads every row's
+//    slot, looks its died bit up (the only gather of the path) and leaves one survivor bit per ROW and one survivor count per
+//    4096-row chunk - it does not move a row; k_compact takes the exclusive prefix of the earlier chunks' counts, ranks the
+//    rows of its chunk from the row bits with ballot-free popcounts and moves survivors / casualties straight to their final
+//    rows in serial (stable) order. One non-returning atomic per workgroup with casualties, none per particle.
 //  * No workgroup ever waits for another (no tickets, no look-back spin): nothing here can hang the GPU. HIP has no
 //    indirect dispatch: grids are sized on the host for the worst case the host knows (capacity, event-buffer size) and
 //    surplus workgroups exit after reading the device-resident counters, so there is no readback on the frame path.
@@ -180,6 +182,9 @@ struct InterpCodeWide : InterpCode {
 //   slot = dead[alive0 + i]; seed = pcg_hash(slot ^ spawner.seed); run INIT; alive[w][alive0+i] = slot.
 // vfx_init.wgsl:141-143 uses atomicAdd(alive_count): under serial execution thread i gets
 // alive0 + i, which is what is computed here without atomics. Counters are advanced by k_compact.
+#ifndef HNB_INIT_PROBE
+#define HNB_INIT_PROBE 0   // development only (HNB_JIT_EXTRA=-DHNB_INIT_PROBE=n): 1 = no per-chunk words, 2 = no attribute stores, 4 = no init program
+#endif
 template <class CODE>
 __global__ void __launch_bounds__(kInitBlock)
 k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
@@ -231,9 +236,18 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
             io.parent_slot = global_ptr<const DevEventBuffer>(fi[k].ev_in)->data[i];
         }
         CODE::zero_unassigned(prog, io);
+#if !(HNB_INIT_PROBE & 4)
         CODE::run_init(prog, S, U, io);
+#endif
         alive[alive0 + i] = slot;
         uint8_t alive_byte = 1u;  // the update walks the slots through these bytes
+#if HNB_INIT_PROBE & 1
+        reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = alive_byte;
+#if !(HNB_INIT_PROBE & 2)
+        CODE::store_init(prog, S, base, slot);
+#endif
+        continue;
+#endif
         if (prog.age_cohort) {  // a chunk that keeps its particles' common age in one word: this slot's age is in the plane (state 2, byte 3)
             uint32_t* astate = reinterpret_cast<uint32_t*>(base + prog.lmin_off) + 2u * prog.chunks_per_inst;
             const uint32_t st = astate[slot / kChunk];
@@ -241,7 +255,9 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
         }
         reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = alive_byte;
         if (prog.cull_lifetime) reinterpret_cast<float*>(base + prog.lmin_off)[slot / kChunk] = 0.0f;  // the chunk's lifetime bound is unknown again
+#if !(HNB_INIT_PROBE & 2)
         CODE::store_init(prog, S, base, slot);
+#endif
     }
 }
 // ---- streaming-kernel pinned attribute access (P = 4) -------------------------------------------
@@ -380,12 +396,14 @@ __device__ __forceinline__ void xpose_store3(const V3 (&src)[4], char* plane, ui
 // single-pass decoupled look-back with ticketed persistent workgroups was 10-13 % slower on this short kernel
 // because of its scheduling tail and spin-waits):
 //   k_update_slots_*  the UPDATE program over the SLOTS (see "Slot-major update" below);
-//   k_list_rows       only for instances that lost particles: every 4096-row chunk of the alive list becomes
-//                     [survivors | casualties] in row order, survivor count recorded;
+//   k_count_rows      only for instances that lost particles: one survivor bit per row of the alive list (from the died bit
+//                     of the row's slot) and the survivor count of every 4096-row chunk;
 //   k_compact         per chunk: if the instance had no casualty the list is final and the workgroup only
 //                     rotates the counters (vfx_indirect.wgsl:57-85); otherwise exclusive prefix of the earlier
 //                     chunks' survivor counts, survivors move to the other list column, casualties are pushed on
 //                     the dead list in serial order.
+constexpr uint32_t kWaveRows = kChunk / (kBlock / 64);  // 1024 slots (or list rows) per wave
+constexpr uint32_t kStepRows = 64 * 4;                  // 256 per wave step: 4 per lane
 struct ChunkCtx {
     uint32_t k, j;          // instance, chunk within instance
     uint32_t n;             // max_update of the instance
@@ -417,7 +435,7 @@ struct CompactBufs {
 // 16,777,216 particles (tools/layout_probe.hip, profiles/r02d_layout_probe.log): 0.204 ms ascending every frame, 0.204 ms
 // descending every frame, 0.171 ms alternating. Any bijection is correct: a workgroup handles the chunk it computes here.
 // (b, total): the workgroup's index and the number of workgroups of ITS program - the launch's own, or a program's share of a
-// launch that serves several programs (k_list_rows_multi / k_compact_multi).
+// launch that serves several programs (k_count_rows_multi / k_compact_multi).
 __device__ __forceinline__ uint32_t chunk_of_workgroup(uint32_t mode, uint32_t b, uint32_t total) {
     uint32_t c = b;
     if (mode & 1u) {
@@ -444,29 +462,6 @@ __device__ __forceinline__ bool chunk_setup(ChunkCtx& c, uint32_t chunk, const A
     c.start = c.j * kChunk;
     c.base = global_ptr<char>(inst_base[c.k]);
     return c.start < c.n;
-}
-
-// The chunk's survivors (front) and casualties (back) are staged in NSEG LDS segments of seg_rows
-// rows; s_cnt[w] = survivors | casualties << 16 of segment w. Called by the whole workgroup.
-template <int NSEG>
-__device__ __forceinline__ void chunk_record(const ChunkCtx& c, uint32_t chunk, const CompactBufs& cb, uint32_t* list, const uint32_t* s_list,
-                                             uint32_t seg_rows, const uint32_t* s_cnt) {
-    const uint32_t tid = threadIdx.x;
-    uint32_t a[NSEG], d[NSEG];
-    uint32_t local_alive = 0, local_dead = 0;
-#pragma unroll
-    for (int w = 0; w < NSEG; ++w) { a[w] = s_cnt[w] & 0xffffu; d[w] = s_cnt[w] >> 16; local_alive += a[w]; local_dead += d[w]; }
-    if (tid == 0) cb.counts[chunk] = local_alive;  // (the casualties were counted per instance by the update kernel)
-    if (!local_dead) return;  // rows are already [survivors]: nothing to rewrite
-    uint32_t abase = c.start, dbase = c.start + local_alive;
-#pragma unroll
-    for (int w = 0; w < NSEG; ++w) {
-        const uint32_t* sg = s_list + w * seg_rows;
-        for (uint32_t i = tid; i < a[w]; i += kBlock) list[abase + i] = sg[i];
-        for (uint32_t i = tid; i < d[w]; i += kBlock) list[dbase + i] = sg[seg_rows - 1u - i];  // casualties in serial order
-        abase += a[w];
-        dbase += d[w];
-    }
 }
 
 // ---- k_compact -----------------------------------------------------------------------------------
@@ -512,7 +507,7 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     }
     if (!has_rows) return;
     // exclusive prefix of the survivor counts of the earlier chunks of this instance
-    // (an instance without a casualty gets here only to be rotated: k_list_rows recorded no counts for it, every row survives)
+    // (an instance without a casualty gets here only to be rotated: k_count_rows recorded nothing for it, every row survives)
     const uint32_t* cnt = cb.counts + (size_t)c.k * args.chunks_per_inst;
     const uint32_t rows = (c.n - c.start) < kChunk ? (c.n - c.start) : kChunk;
     uint32_t excl = c.start;
@@ -527,7 +522,17 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
 #pragma unroll
         for (uint32_t w = 0; w < kBlock / 64; ++w) excl += s_red[w];
     }
-    const uint32_t a = total_dead != 0u ? cnt[c.j] : rows;
+    // The chunk's 64 row-mask words (bit r of word i: row 64 i + r survives), one per lane, and the survivors in front of each word:
+    // every wave ranks its own rows from them, no LDS and no barrier. (Nothing died in the instance: every row that exists survives.)
+    unsigned long long word;
+    if (total_dead != 0u) word = reinterpret_cast<const unsigned long long*>(c.base + args.row_mask_off)[(size_t)c.j * (kChunk / 64u) + lane];
+    else word = rows >= (lane + 1u) * 64u ? ~0ull : (rows > lane * 64u ? ((1ull << (rows - lane * 64u)) - 1ull) : 0ull);
+    const uint32_t wcount = (uint32_t)__popcll(word);
+    uint32_t wincl = wcount;
+#pragma unroll
+    for (uint32_t off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(wincl, off, 64); if (lane >= off) wincl += y; }
+    const uint32_t a = __shfl(wincl, 63, 64);   // survivors of this chunk ( == cnt[c.j] where k_count_rows ran)
+    const uint32_t wexcl = wincl - wcount;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(c.base + args.alive_off[c.m.write_index]) + c.start;
     uint32_t* out = reinterpret_cast<uint32_t*>(c.base + args.alive_off[c.m.write_index ^ 1u]);
     // survivor g of the instance goes to row g - or, rotated: the last n_spawn survivors are this frame's spawns (k_init appended them, none of
@@ -536,26 +541,28 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     const uint32_t head_n = (c.n - total_dead) - tail;
     uint32_t* dead = reinterpret_cast<uint32_t*>(c.base + args.dead_off);
     const uint32_t dead_before = c.start - excl;
-    // survivors keep their (stable, serial) order (vfx_update.wgsl:161-165)
-    // (several rows per thread are requested before the first store: one dependent access per row otherwise; in two
-    // halves so that the workgroups that only rotate the counters keep a small register footprint)
-    constexpr uint32_t kPer = kChunk / kBlock, kHalf = kPer / 2;
-    uint8_t* flags = reinterpret_cast<uint8_t*>(c.base + args.alive_flag_off);
+    // survivors keep their (stable, serial) order (vfx_update.wgsl:161-165). A wave owns 1024 consecutive rows, 64 per step, lane l row
+    // 64 step + l: loads and stores of a step are contiguous. (Rows are requested half a wave's share ahead of their use: one dependent
+    // access per row otherwise.)
+    constexpr uint32_t kSteps = kWaveRows / 64u, kHalf = kSteps / 2u;
+    const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll 1
     for (uint32_t h = 0; h < 2; ++h) {
         uint32_t v[kHalf];
 #pragma unroll
-        for (uint32_t q = 0; q < kHalf; ++q) { const uint32_t i = tid + (h * kHalf + q) * kBlock; v[q] = i < rows ? src[i] : 0u; }
+        for (uint32_t q = 0; q < kHalf; ++q) { const uint32_t i = wave * kWaveRows + (h * kHalf + q) * 64u + lane; v[q] = i < rows ? src[i] : 0u; }
 #pragma unroll
         for (uint32_t q = 0; q < kHalf; ++q) {
-            const uint32_t i = tid + (h * kHalf + q) * kBlock;
-            if (i < a) {
-                const uint32_t g = excl + i;
+            const uint32_t wi = wave * kSteps + h * kHalf + q;            // (wave-uniform)
+            const uint32_t i = wi * 64u + lane;                          // row within the chunk
+            const unsigned long long m = __shfl(word, wi, 64);
+            const uint32_t r = __shfl(wexcl, wi, 64) + (uint32_t)__popcll(m & below);   // survivors of the chunk in front of this row
+            if ((m >> lane) & 1ull) {
+                const uint32_t g = excl + r;
                 out[g >= head_n ? g - head_n : g + tail] = v[q];
             } else if (i < rows) {
-                // the d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151); its slot is free again
-                dead[c.n - 1u - (dead_before + (i - a))] = v[q];
-                flags[v[q]] = 0u;
+                // the d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151); its alive byte is already 0
+                dead[c.n - 1u - (dead_before + (i - r))] = v[q];
             }
         }
     }
@@ -577,7 +584,8 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
 struct CompactArgs {
     uint32_t capacity, chunks_per_inst;
     uint32_t alive_off[2], dead_off;
-    uint32_t alive_flag_off;   // u8[capacity]: 0 free, 1 alive, 2 died in this frame's update
+    uint32_t alive_flag_off;   // u8[capacity]: 0 free, 1 alive
+    uint32_t died_bits_off, row_mask_off;   // DevProgram: one bit per slot "died in this frame's update"; one bit per list row "survives"
     uint32_t slot_order;       // HNB_LIST_ORDER_SLOT: k_order_write rebuilds the lists from the alive bytes
     uint32_t rotate_front;     // ribbon programs, host-proven (HnbProgram::sort_front_*): this frame's spawns sort in front of every older
                                // particle, so the survivors are written [spawns | older ones] and the list needs no sort afterwards
@@ -762,8 +770,6 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
 #ifndef HNB_STREAM_WAVES_FULL
 #define HNB_STREAM_WAVES_FULL 5
 #endif
-constexpr uint32_t kWaveRows = kChunk / (kBlock / 64);  // 1024 slots (or list rows) per wave
-constexpr uint32_t kStepRows = 64 * 4;                  // 256 per wave step: 4 per lane
 
 // =====================================================================================================
 // Slot-major update
@@ -773,14 +779,15 @@ constexpr uint32_t kStepRows = 64 * 4;                  // 256 per wave step: 4 
 // driven by one alive byte per slot (0 free, 1 alive, 2 died in this frame), and never touches the alive
 // list: every access is a 16-byte load / store of 4 consecutive slots whatever the list looks like after hours
 // of spawn / kill churn. The row order only matters to a second, much lighter pass over the rows of the
-// instances that lost particles (k_list_rows: 4 bytes of list + one byte gather per row), which feeds the same
+// instances that lost particles (k_count_rows: 4 bytes of list + one bit gather per row), which feeds the same
 // chunk-local / cross-chunk compaction as before, and to k_emit_events.
 struct SlotArgs {
     uint32_t capacity, n_uregs, chunks_per_inst, n_inst;
     uint32_t alive_flag_off, update_len;
     uint32_t plane_off[4];   // position, velocity, age, lifetime
     uint32_t flags;          // bit i: load pinned attr i; bit 4+i: store pinned attr i
-    uint32_t died_mark;      // byte written for a particle that dies: 2 (k_list_rows pushes it on the dead list) or 0 (slot-ordered lists)
+    uint32_t died_bits_off;  // DevProgram::died_bits_off; written (all of it) iff write_died: the frame's list kernels read it
+    uint32_t write_died;
     uint32_t cull_lifetime;  // 1: lifetime culling (below); lmin_off = f32[chunks_per_inst] in the slab, dt_operand = operand a of the AGE_TICK
     uint32_t lmin_off, dt_operand;
     uint32_t age_cohort;     // 1: chunks whose alive particles all have the same AGE keep it in one word (below)
@@ -791,7 +798,7 @@ struct SlotArgs {
     uint32_t* safe_words;
     unsigned long long* safe_host;
     uint32_t safe_parity, publish_tag, safe_stride;
-    // skip_lists: the host PROVED that this frame has no spawn and no casualty (see hnb_simulate), so k_list_rows / k_compact
+    // skip_lists: the host PROVED that this frame has no spawn and no casualty (see hnb_simulate), so k_count_rows / k_compact
     // are not launched and this kernel rotates the counters itself (vfx_indirect.wgsl:57-85), one thread per instance.
     uint32_t skip_lists;
     const DevMeta* meta_in;
@@ -833,6 +840,17 @@ struct SlotArgs {
 // and skips the plane, else it stores the ages (which materialises them) and returns to state 0. Host reads of the AGE plane
 // materialise first (k_materialise_age), host writes reset the states. Eligible programs: the lifetime-culling ones (the
 // stream starts with its only AGE_TICK, nothing else writes AGE) without ribbons (the sort reads the plane); HNB_AGE_COHORT=0 off.
+
+// The died bits of one wave step (256 slots, lane l owns slots 4 l .. 4 l + 3 and brings their four bits in `nib`) as 8 dwords of the
+// linear bit array: dword d holds lanes 8 d .. 8 d + 7. An OR over every group of 8 lanes in three DPP steps (quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror), then the first lane of each group stores: 32 contiguous bytes per step.
+__device__ __forceinline__ void store_died_bits(uint32_t* __restrict__ bits, uint32_t step_first, uint32_t nib, uint32_t lane) {
+    int v = (int)(nib << (4u * (lane & 7u)));
+    v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
+    if ((lane & 7u) == 0u) bits[(step_first >> 5) + (lane >> 3)] = (uint32_t)v;
+}
 
 // PROBE (tools/stream_probe.hip only; 0 in the product): 4 = skip stores, 8 = skip the program.
 // COHORT: compile the age-cohort paths in (programs that are eligible: SlotArgs::age_cohort); false leaves the kernel as it was.
@@ -936,6 +954,8 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
                     if (fl & 32u) vw[(step * 3u + w) * 64u + lane] = u4v{f2u(V[w][0]), f2u(V[w][1]), f2u(V[w][2]), f2u(V[w][3])};
                 }
             }
+            if (args.write_died && lane < kWaveRows / 32u)                // nobody died here (the frame's list kernels read every word)
+                reinterpret_cast<uint32_t*>(base + args.died_bits_off)[((j * kChunk + wave * kWaveRows) >> 5) + lane] = 0u;
             amin = amax = f2u(A2);                                         // the survivors' common age
             loaded_all = false;                                            // no lifetime was loaded: the chunk's bound stands
             if (args.safe_words) rem_min = (Lm - A2) - 1.0e-5f * Lm;       // as the per-particle form computes it from X.lifetime = Lm, X.age = A2
@@ -954,7 +974,10 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
             lane_alive += was[p] ? 1u : 0u;
         }
         const bool any = was[0] || was[1] || was[2] || was[3];
-        if (!__any(any)) continue;
+        if (!__any(any)) {
+            if (args.write_died) store_died_bits(reinterpret_cast<uint32_t*>(base + args.died_bits_off), s0 - lane * 4u, 0u, lane);
+            continue;
+        }
         const bool full = was[0] && was[1] && was[2] && was[3];
         uint32_t slot[4];
 #pragma unroll
@@ -964,6 +987,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
 #pragma unroll
         for (int p = 0; p < 4; ++p) { X.pos[p] = V3{0, 0, 0}; X.vel[p] = V3{0, 0, 0}; X.age[p] = 0.0f; X.lifetime[p] = 0.0f; X.alive[p] = true; }
         bool need_life = true;  // wave-uniform
+        float age_was[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // the AGE quad as loaded: free slots of a partially alive quad get their own bytes back without a second read
         // (wave-uniform) the step's 256 slots lie inside the planes: its vec3 planes go through the LDS transpose, every lane taking part
         const uint32_t step_first = s0 - lane * 4u;
         // (... where at least half of the quads hold a live particle: in the last frames of a die-off the direct path touches fewer lines)
@@ -978,7 +1002,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
                 if (fl & 2u) pin_load3<4>(X.vel, p_vel, slot, lanes_on, true);
             }
             if (fl & 4u) {
-                if (!COHORT || ast != 1u) pin_load1<4>(X.age, p_age, slot, lanes_on, true);
+                if (!COHORT || ast != 1u) { pin_load1<4>(X.age, p_age, slot, lanes_on, true); for (int p = 0; p < 4; ++p) age_was[p] = X.age[p]; }
                 if (COHORT && ast != 0u) {   // (selects, no divergence: ast is uniform, fresh[] only ever set in state 2)
 #pragma unroll
                     for (int p = 0; p < 4; ++p) X.age[p] = fresh[p] ? X.age[p] : A;
@@ -1009,7 +1033,14 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
                 if ((fl & 16u) && !xp_pos) pin_store3<4>(X.pos, p_pos, slot, was, full);
                 if ((fl & 32u) && !xp_vel) pin_store3<4>(X.vel, p_vel, slot, was, full);
                 if (fl & 64u) {
-                    if (!COHORT || ast != 1u) pin_store1<4>(X.age, p_age, slot, was, full);
+                    if (!COHORT || ast != 1u) {
+                        if ((fl & 4u) && !full) {   // loaded above: blend in registers, one 16-byte store
+                            float q[4];
+#pragma unroll
+                            for (int p = 0; p < 4; ++p) q[p] = was[p] ? X.age[p] : age_was[p];
+                            pin_store1<4>(q, p_age, slot, was, true);
+                        } else pin_store1<4>(X.age, p_age, slot, was, full);
+                    }
                 }
                 if (fl & 128u) pin_store1<4>(X.lifetime, p_life, slot, was, full);
             }
@@ -1048,16 +1079,17 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
                 }
             }
         }
-        uint32_t nf = f4;
+        uint32_t nf = f4, nib = 0u;
         uint32_t died_here = 0;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const bool died = was[p] && !X.alive[p];
-            if (died) nf = (nf & ~(0xffu << (8 * p))) | (args.died_mark << (8 * p));
+            if (died) { nf &= ~(0xffu << (8 * p)); nib |= 1u << p; }   // the slot is free from now on; the lists learn it from the died bit
             else if (COHORT && fresh[p]) nf = (nf & ~(0xffu << (8 * p))) | (1u << (8 * p));   // an ordinary alive slot from now on
             died_here += (uint32_t)__popcll(__ballot(died));
         }
         if (nf != f4) flags4[s0 >> 2] = nf;
+        if (args.write_died) store_died_bits(reinterpret_cast<uint32_t*>(base + args.died_bits_off), step_first, nib, lane);
         died_total += died_here;
     }
     if (cull) {
@@ -1123,7 +1155,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
 template <class CODE>
 __global__ void __launch_bounds__(kBlock)
 k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
-                       const uint32_t* __restrict__ ublocks, const CompactBufs cb, const uint32_t died_mark) {
+                       const uint32_t* __restrict__ ublocks, const CompactBufs cb, const uint32_t write_died) {
     __shared__ uint32_t s_died[kBlock / 64], s_alive[kBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
@@ -1143,7 +1175,12 @@ k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_
         const uint32_t slot = j * kChunk + sub * kBlock + tid;
         const bool valid = chunk_full || (slot < prog.capacity && flags[slot] == 1u);
         alive_total += (uint32_t)__popcll(__ballot(valid));
-        if (!__any(valid)) continue;
+        // one died bit per slot for the list kernels: a wave's 64 consecutive slots are one word of the array (SlotArgs::died_bits_off)
+        unsigned long long* died_word = reinterpret_cast<unsigned long long*>(base + prog.died_bits_off) + ((slot - lane) >> 6);
+        if (!__any(valid)) {
+            if (write_died && lane == 0u) *died_word = 0ull;
+            continue;
+        }
         VmState<typename CODE::file_t> S;
         S.r = typename CODE::file_t{};
         CODE::load_update(prog, S, base, slot, valid);
@@ -1161,9 +1198,11 @@ k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_
                 for (uint32_t ch = 0; ch < HNB_MAX_EVENT_CHANNELS; ++ch)
                     if (ch < prog.n_event_channels) reinterpret_cast<uint32_t*>(base + prog.ev_cnt_off[ch])[slot] = S.ev[ch];
             }
-            if (!S.alive) flags[slot] = (uint8_t)died_mark;
+            if (!S.alive) flags[slot] = 0u;   // free from now on; the lists learn it from the died bit
         }
-        died_total += (uint32_t)__popcll(__ballot(valid && !S.alive));
+        const unsigned long long dm = __ballot(valid && !S.alive);
+        if (write_died && lane == 0u) *died_word = dm;
+        died_total += (uint32_t)__popcll(dm);
     }
     if (lane == 0) { s_died[wave] = died_total; s_alive[wave] = alive_total; }
     __syncthreads();
@@ -1194,76 +1233,57 @@ k_materialise_age(char* __restrict__ base, uint32_t capacity, uint32_t chunks_pe
     }
 }
 
-// Row-major list maintenance for the instances that lost particles this frame: every 4096-row chunk of the
-// alive list is rewritten as [survivors | casualties] (stable, in row order) from the alive bytes, and its
-// survivor count recorded; k_compact then takes the cross-chunk prefix exactly as before.
-__device__ __forceinline__ void list_rows_chunk(const CompactArgs& args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
-                                                const DevFrameInst* __restrict__ fi, const CompactBufs& cb, uint32_t wg, uint32_t wg_total) {
-    __shared__ uint32_t s_list[kChunk];
+// Row-major list maintenance for the instances that lost particles this frame, first pass: which rows survive? Every row's slot is
+// looked up in the died bits the update left (one bit per slot: the table of a 16.7M-slot effect is 2 MiB and stays in the L2 of every
+// XCD, where the alive BYTES it replaces - 16 MiB, a quarter of them L2 hits - cost this kernel 0.74 GB of fabric reads and 0.23 ms in
+// steady spawn / kill churn, profiles/r03a_*). Output: one survivor bit per row (ballots: lane l of a step owns row 64 step + l, so a
+// ballot IS the mask word) and the chunk's survivor count for k_compact's cross-chunk prefix. No row is moved here.
+__device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+                                                 const DevFrameInst* __restrict__ fi, const CompactBufs& cb, uint32_t wg, uint32_t wg_total) {
     __shared__ uint32_t s_wave[kBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     ChunkCtx c;
     if (!chunk_setup(c, chunk, args, inst_base, meta_in, fi)) return;
     if (cb.deaths[(size_t)cb.parity * cb.table_cap + c.k] == 0u) return;  // nothing died in this instance: the list stands
-    uint32_t* list = reinterpret_cast<uint32_t*>(c.base + args.alive_off[c.m.write_index]);
-    const uint8_t* flags = reinterpret_cast<const uint8_t*>(c.base + args.alive_flag_off);
-    const uint32_t n = c.n;
-    const uint32_t wstart = c.start + wave * kWaveRows;
-    uint32_t* seg = s_list + wave * kWaveRows;
-    uint32_t wa = 0, wd = 0;
-    const uint64_t below = (1ull << lane) - 1ull;
-    // All 16 rows of a lane are requested before anything is used, then all 16 alive bytes: the kernel is a chain of
-    // two dependent memory accesses per row, so its speed is the number of them in flight. Lane l owns rows
-    // l, 64+l, 128+l, 192+l of each of the wave's 4 steps.
-    constexpr uint32_t kSteps = kWaveRows / kStepRows;
-    uint32_t slot[kSteps][4];
-    bool valid[kSteps][4], al[kSteps][4];
+    const uint32_t* list = reinterpret_cast<const uint32_t*>(c.base + args.alive_off[c.m.write_index]) + c.start;
+    const uint32_t* died = reinterpret_cast<const uint32_t*>(c.base + args.died_bits_off);
+    unsigned long long* rmask = reinterpret_cast<unsigned long long*>(c.base + args.row_mask_off) + (size_t)c.j * (kChunk / 64u);
+    const uint32_t rows = (c.n - c.start) < kChunk ? (c.n - c.start) : kChunk;
+    // All 16 rows of a lane are requested before anything is used, then all 16 bit words: the kernel is a chain of two dependent
+    // memory accesses per row, so its speed is the number of them in flight.
+    constexpr uint32_t kSteps = kWaveRows / 64u;
+    uint32_t slot[kSteps], bits[kSteps];
 #pragma unroll
-    for (uint32_t step = 0; step < kSteps; ++step)
-#pragma unroll
-        for (uint32_t p = 0; p < 4; ++p) {
-            const uint32_t row = wstart + step * kStepRows + p * 64u + lane;
-            valid[step][p] = row < n;
-            slot[step][p] = valid[step][p] ? list[row] : 0u;
-        }
-#pragma unroll
-    for (uint32_t step = 0; step < kSteps; ++step)
-#pragma unroll
-        for (uint32_t p = 0; p < 4; ++p) al[step][p] = valid[step][p] && flags[slot[step][p]] == 1u;  // 2 = died in this frame's update
-#pragma unroll
-    for (uint32_t step = 0; step < kSteps; ++step) {
-        uint64_t ma[4], mv[4];
-#pragma unroll
-        for (uint32_t p = 0; p < 4; ++p) {
-            ma[p] = __ballot(al[step][p]);
-            mv[p] = __ballot(valid[step][p]);
-        }
-        uint32_t base_a = wa, base_d = wd;
-#pragma unroll
-        for (uint32_t p = 0; p < 4; ++p) {
-            const uint32_t ba = (uint32_t)__popcll(ma[p] & below), bv = (uint32_t)__popcll(mv[p] & below);
-            if (valid[step][p]) {
-                if (al[step][p]) seg[base_a + ba] = slot[step][p];
-                else seg[kWaveRows - 1u - (base_d + (bv - ba))] = slot[step][p];
-            }
-            base_a += (uint32_t)__popcll(ma[p]);
-            base_d += (uint32_t)__popcll(mv[p]) - (uint32_t)__popcll(ma[p]);
-        }
-        wa = base_a;
-        wd = base_d;
+    for (uint32_t s = 0; s < kSteps; ++s) {
+        const uint32_t i = wave * kWaveRows + s * 64u + lane;
+        slot[s] = i < rows ? list[i] : 0xffffffffu;
     }
-    if (lane == 0) s_wave[wave] = wa | (wd << 16);
+#pragma unroll
+    for (uint32_t s = 0; s < kSteps; ++s) bits[s] = slot[s] != 0xffffffffu ? died[slot[s] >> 5] : 0xffffffffu;
+    uint32_t wa = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < kSteps; ++s) {
+        const unsigned long long m = __ballot(((bits[s] >> (slot[s] & 31u)) & 1u) == 0u);   // (rows past the end: "died", they are nobody's)
+        if (lane == 0u) rmask[wave * kSteps + s] = m;
+        wa += (uint32_t)__popcll(m);
+    }
+    if (lane == 0u) s_wave[wave] = wa;
     __syncthreads();
-    chunk_record<kBlock / 64>(c, chunk, cb, list, s_list, kWaveRows, s_wave);
+    if (tid == 0u) {
+        uint32_t t = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kBlock / 64; ++w) t += s_wave[w];
+        cb.counts[chunk] = t;
+    }
 }
 __global__ void __launch_bounds__(kBlock)
-k_list_rows(const CompactArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
-            const DevFrameInst* __restrict__ fi, const CompactBufs cb) {
-    list_rows_chunk(args, inst_base, meta_in, fi, cb, blockIdx.x, gridDim.x);
+k_count_rows(const CompactArgs args, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+             const DevFrameInst* __restrict__ fi, const CompactBufs cb) {
+    count_rows_chunk(args, inst_base, meta_in, fi, cb, blockIdx.x, gridDim.x);
 }
 
-// The same two kernels for SEVERAL programs in one launch each. k_list_rows and k_compact are the same code for every program, only their
+// The same two kernels for SEVERAL programs in one launch each. k_count_rows and k_compact are the same code for every program, only their
 // arguments differ, and in a scene of many small effects the frame is bound by the number of launches the host can issue (26 example effects:
 // 4 launches per effect, 12 us of host time per effect and frame). hnb_simulate therefore collects the programs that need their lists this
 // frame into a job table (it travels with the frame's parameter upload) and serves them with two launches after all update kernels.
@@ -1283,10 +1303,10 @@ __device__ __forceinline__ const ListsJob& job_of_workgroup(const ListsJob* __re
     return jobs[lo];
 }
 __global__ void __launch_bounds__(kBlock)
-k_list_rows_multi(const ListsJob* __restrict__ jobs, uint32_t n_jobs) {
+k_count_rows_multi(const ListsJob* __restrict__ jobs, uint32_t n_jobs) {
     const ListsJob& jb = job_of_workgroup(jobs, n_jobs);
     if (jb.args.slot_order) return;   // its lists are rebuilt from the alive bytes by k_order_*
-    list_rows_chunk(jb.args, jb.inst_base, jb.meta_in, jb.fi, jb.cb, blockIdx.x - jb.first_wg, jb.n_wg);
+    count_rows_chunk(jb.args, jb.inst_base, jb.meta_in, jb.fi, jb.cb, blockIdx.x - jb.first_wg, jb.n_wg);
 }
 __global__ void __launch_bounds__(kBlock)
 k_compact_multi(const ListsJob* __restrict__ jobs, uint32_t n_jobs) {

@@ -21,8 +21,11 @@ def single_particle(capacity=16):
     return asset
 
 
-def firework_trails(capacity=1 << 24):
+def firework_trails(capacity=1 << 24, spawner=None):
     """The `trails` program of examples/firework.rs:184-251 made self-contained (C2).
+
+    `spawner`: None = the burst `once(capacity)` of SURVEY.md §8(d) C2; bench.py's c2_mixed passes a rate spawner
+    (capacity / mean lifetime per second) so that the same program runs in a spawn / age / die steady state.
 
     InheritAttributeModifier(POSITION) -> POSITION = lit(0,0,0); parent_attr(U32_0) colour ->
     the rocket's colour expression (firework.rs:64-66). Update: LinearDrag(4) then
@@ -41,7 +44,7 @@ def firework_trails(capacity=1 << 24):
     # `Vec3::Y * -16.` yields (-0., -16., -0.)
     update_accel = h.AccelModifier(w.lit((-0.0, -16.0, -0.0)).expr())
     update_drag = h.LinearDragModifier(w.lit(4.0).expr())
-    return (h.EffectAsset(capacity, h.SpawnerSettings.once(float(capacity)), w.finish())
+    return (h.EffectAsset(capacity, spawner if spawner is not None else h.SpawnerSettings.once(float(capacity)), w.finish())
             .with_name("trail")
             .init(init_pos).init(init_vel).init(init_age).init(init_lifetime).init(init_color)
             .update(update_drag).update(update_accel)

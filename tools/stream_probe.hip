@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
     const int blocks_per_cu = argc > 3 ? atoi(argv[3]) : 8;
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     SlotArgs sa{};
-    sa.capacity = cap; sa.n_uregs = 8; sa.chunks_per_inst = (cap + kChunk - 1) / kChunk; sa.n_inst = 1; sa.died_mark = 2;
+    sa.capacity = cap; sa.n_uregs = 8; sa.chunks_per_inst = (cap + kChunk - 1) / kChunk; sa.n_inst = 1;
     size_t off = 0;
     uint32_t alive_off[2], dead_off;
     alive_off[0] = off; off += al((size_t)cap * 4);
@@ -141,13 +141,13 @@ int main(int argc, char** argv) {
     {                                                                                                                            \
         float ms = time_ms(iters, [&] {                                                                                          \
             k_update_slots_stream<ProgDragAccel, WAVES, PROBE><<<grid, kBlock>>>(sa, dbase, dfi, dub, cb);                       \
-            if (COMPACT) { k_list_rows<<<grid, kBlock>>>(ca, dbase, dmeta, dfi, cb); k_compact<<<grid, kBlock>>>(ca, dbase, dmeta, dmeta + 1, dfi, cb); }                                       \
+            if (COMPACT) { k_count_rows<<<grid, kBlock>>>(ca, dbase, dmeta, dfi, cb); k_compact<<<grid, kBlock>>>(ca, dbase, dmeta, dmeta + 1, dfi, cb); }                                       \
         });                                                                                                                      \
         printf("%-44s %8.3f ms  %7.1f GB/s (68 B/particle)\n", NAME, ms, bytes / ms / 1e6);                                       \
     }
     RUN("k_update_slots (budget 8)", 0, 8, 0)
     RUN("k_update_slots (budget 6)", 0, 6, 0)
-    RUN("k_update_slots + k_list_rows + k_compact (6)", 0, 6, 1)
+    RUN("k_update_slots + k_count_rows + k_compact (6)", 0, 6, 1)
     RUN("k_update_slots (budget 5)", 0, 5, 0)
     RUN("k_update_slots (budget 4)", 0, 4, 0)
     RUN("no stores", 4, 6, 0)
