@@ -56,10 +56,15 @@ constexpr uint32_t kFrameRing = 4;
 // effects), plus the interpreter for every other streamable sequence.
 typedef void (*StreamLaunchFn)(uint32_t grid, hipStream_t stream, const SlotArgs& sa, const uint64_t* inst_base, const DevFrameInst* fi,
                                const uint32_t* ublocks, const CompactBufs& cb);
+#ifndef HNB_STREAM_WAVES_COHORT
+#define HNB_STREAM_WAVES_COHORT 5
+#endif
 template <class PROG, int WAVES>
 void launch_stream(uint32_t grid, hipStream_t stream, const SlotArgs& sa, const uint64_t* inst_base, const DevFrameInst* fi,
                    const uint32_t* ublocks, const CompactBufs& cb) {
-    if (sa.age_cohort) k_update_slots_stream<PROG, WAVES, 0, true><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
+    // (the age-cohort paths need a few registers more: budgeted for 6 waves (80 VGPRs) the per-particle path of the firework kernel spilled 48 bytes
+    // per lane to scratch; for 5 waves it takes 93 VGPRs and none. Round 2 measured budgets of 4 to 8 waves within 1 % of each other on this kernel.)
+    if (sa.age_cohort) k_update_slots_stream<PROG, (WAVES > HNB_STREAM_WAVES_COHORT ? HNB_STREAM_WAVES_COHORT : WAVES), 0, true><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
     else k_update_slots_stream<PROG, WAVES, 0, false><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
 }
 #define OP_(x) (uint32_t)HNB_OP_M_##x
@@ -114,6 +119,7 @@ struct HnbContext {
     uint32_t list_order = HNB_LIST_ORDER_SPAWN;  // applied to programs created afterwards
     bool skip_lists = true;     // skip the list kernels of frames the device's no-death bound covers (HNB_SKIP_LISTS=0 turns it off)
     bool alternate = true;      // walk the chunks in alternating directions from frame to frame (HNB_ALTERNATE=0 turns it off)
+    uint32_t count_load = 0;    // development: CompactArgs::gather_mode (HNB_COUNT_LOAD)
     bool transpose = true;      // vec3 planes of the per-particle update path through the wave's LDS transpose (HNB_TRANSPOSE=0 turns it off)
     uint32_t timing = 0;        // 0 = off, n = time every n-th simulated frame
     uint32_t timing_tick = 0;
@@ -718,6 +724,7 @@ jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const
     for (uint32_t i = 0; i < h.update_len; ++i) lean = lean && vm_op_is_lean(rq.update[i].x & 0xffu);
     rq.stream_waves = lean ? HNB_STREAM_WAVES : HNB_STREAM_WAVES_FULL;
     rq.stream_cohort = age_cohort_eligible(b, h, attrs, streams);
+    if (rq.stream_cohort && rq.stream_waves > HNB_STREAM_WAVES_COHORT) rq.stream_waves = HNB_STREAM_WAVES_COHORT;
     return rq;
 }
 
@@ -747,6 +754,7 @@ int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
     if (const char* e = getenv("HNB_ALTERNATE")) ctx->alternate = e[0] != '0';
     if (const char* e = getenv("HNB_TRANSPOSE")) ctx->transpose = e[0] != '0';
     if (const char* e = getenv("HNB_SKIP_LISTS")) ctx->skip_lists = e[0] != '0';
+    if (const char* e = getenv("HNB_COUNT_LOAD")) ctx->count_load = (uint32_t)atoi(e);
     *out_ctx = ctx;
     return HNB_OK;
 }
@@ -1277,6 +1285,7 @@ static CompactArgs compact_args_of(const HnbProgram* p) {
     ca.alive_off[0] = p->dev.alive_off[0]; ca.alive_off[1] = p->dev.alive_off[1]; ca.dead_off = p->dev.dead_off;
     ca.alive_flag_off = p->dev.alive_flag_off;
     ca.died_bits_off = p->dev.died_bits_off; ca.row_mask_off = p->dev.row_mask_off;
+    ca.gather_mode = p->ctx->count_load;
     ca.slot_order = p->slot_order ? 1u : 0u;
     ca.rotate_front = p->frame_rotate ? 1u : 0u;   // k_compact writes the survivors [spawns | older ones]: see CompactArgs (ribbon programs never have slot-ordered lists)
     return ca;

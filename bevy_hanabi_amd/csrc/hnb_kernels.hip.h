@@ -182,9 +182,6 @@ struct InterpCodeWide : InterpCode {
 //   slot = dead[alive0 + i]; seed = pcg_hash(slot ^ spawner.seed); run INIT; alive[w][alive0+i] = slot.
 // vfx_init.wgsl:141-143 uses atomicAdd(alive_count): under serial execution thread i gets
 // alive0 + i, which is what is computed here without atomics. Counters are advanced by k_compact.
-#ifndef HNB_INIT_PROBE
-#define HNB_INIT_PROBE 0   // development only (HNB_JIT_EXTRA=-DHNB_INIT_PROBE=n): 1 = no per-chunk words, 2 = no attribute stores, 4 = no init program
-#endif
 template <class CODE>
 __global__ void __launch_bounds__(kInitBlock)
 k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
@@ -236,18 +233,9 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
             io.parent_slot = global_ptr<const DevEventBuffer>(fi[k].ev_in)->data[i];
         }
         CODE::zero_unassigned(prog, io);
-#if !(HNB_INIT_PROBE & 4)
         CODE::run_init(prog, S, U, io);
-#endif
         alive[alive0 + i] = slot;
         uint8_t alive_byte = 1u;  // the update walks the slots through these bytes
-#if HNB_INIT_PROBE & 1
-        reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = alive_byte;
-#if !(HNB_INIT_PROBE & 2)
-        CODE::store_init(prog, S, base, slot);
-#endif
-        continue;
-#endif
         if (prog.age_cohort) {  // a chunk that keeps its particles' common age in one word: this slot's age is in the plane (state 2, byte 3)
             uint32_t* astate = reinterpret_cast<uint32_t*>(base + prog.lmin_off) + 2u * prog.chunks_per_inst;
             const uint32_t st = astate[slot / kChunk];
@@ -255,9 +243,7 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
         }
         reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = alive_byte;
         if (prog.cull_lifetime) reinterpret_cast<float*>(base + prog.lmin_off)[slot / kChunk] = 0.0f;  // the chunk's lifetime bound is unknown again
-#if !(HNB_INIT_PROBE & 2)
         CODE::store_init(prog, S, base, slot);
-#endif
     }
 }
 // ---- streaming-kernel pinned attribute access (P = 4) -------------------------------------------
@@ -586,6 +572,7 @@ struct CompactArgs {
     uint32_t alive_off[2], dead_off;
     uint32_t alive_flag_off;   // u8[capacity]: 0 free, 1 alive
     uint32_t died_bits_off, row_mask_off;   // DevProgram: one bit per slot "died in this frame's update"; one bit per list row "survives"
+    uint32_t gather_mode;      // development (HNB_COUNT_LOAD): how k_count_rows loads the died bits: 0 plain, 1 nontemporal, 2 agent-scope atomic load
     uint32_t slot_order;       // HNB_LIST_ORDER_SLOT: k_order_write rebuilds the lists from the alive bytes
     uint32_t rotate_front;     // ribbon programs, host-proven (HnbProgram::sort_front_*): this frame's spawns sort in front of every older
                                // particle, so the survivors are written [spawns | older ones] and the list needs no sort afterwards
@@ -1260,7 +1247,11 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
         slot[s] = i < rows ? list[i] : 0xffffffffu;
     }
 #pragma unroll
-    for (uint32_t s = 0; s < kSteps; ++s) bits[s] = slot[s] != 0xffffffffu ? died[slot[s] >> 5] : 0xffffffffu;
+    for (uint32_t s = 0; s < kSteps; ++s) {
+        const uint32_t* w = died + (slot[s] >> 5);
+        bits[s] = 0xffffffffu;
+        if (slot[s] != 0xffffffffu) bits[s] = args.gather_mode == 1u ? __builtin_nontemporal_load(w) : (args.gather_mode == 2u ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *w);
+    }
     uint32_t wa = 0;
 #pragma unroll
     for (uint32_t s = 0; s < kSteps; ++s) {

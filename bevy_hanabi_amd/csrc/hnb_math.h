@@ -8,11 +8,15 @@
 //   * f32 + - * / sqrt, comparisons, floor/ceil/trunc/roundEven: IEEE-754 binary32,
 //     one rounding per source-level operation (everything is built with
 //     -ffp-contract=off and correctly rounded f32 divide/sqrt).
-//   * transcendental functions: evaluated in binary64 with only + - * / and bit
+//   * transcendental functions: evaluated in binary64 with only + - * / fma and bit
 //     manipulation (no libm, no hardware approximations), then rounded once to
-//     binary32. Error before the final rounding is < 1e-15 relative, i.e. the result
-//     is the correctly rounded f32 value except in astronomically rare near-ties.
+//     binary32. Error before the final rounding is < 2^-45 relative, i.e. the result
+//     is the correctly rounded f32 value except in rare near-ties (about one argument
+//     in a million: within 1 ulp of libm always, tests/test_math.py).
 //     Trigonometric arguments with |x| > 2^40 are defined as x = 0 (sin 0, cos 1).
+//   * normalize(v) = v * (1 / length(v)): one IEEE division and three multiplications
+//     (WGSL leaves the accuracy of normalize to the implementation: "inherited from
+//     v / length(v)", whose own division may be 2.5 ulp off).
 //
 // Compiles as plain C++ (host) and as HIP device code (HNB_HD).
 #pragma once
@@ -30,6 +34,8 @@ using __hip_internal::int32_t; using __hip_internal::uint32_t; using __hip_inter
 #define HNB_HD static inline
 #define HNB_HD_MEMBER inline
 #endif
+
+#define HNB_TABLE static constexpr   // constant tables: emitted for the host and (as constant data) for the device
 
 namespace hnb {
 
@@ -68,6 +74,11 @@ HNB_HD float f_rem(float x, float y) { return x - y * f_trunc(x / y); }
 HNB_HD float f_inv_sqrt(float x) { return 1.0f / f_sqrt(x); }
 
 // ---- binary64 kernels ------------------------------------------------------------
+// Every step is ONE correctly rounded IEEE-754 binary64 operation - + - * / or a fused multiply-add (v_fma_f64 on gfx950, vfmadd
+// or the C library's exact fma() on the host: the same result everywhere, which -ffp-contract=off alone cannot promise for an
+// a * b + c the compiler is free to fuse or not) - on minimax polynomials (tools/gen_math_coeffs.py derives the coefficients and
+// prints their error): approximation errors are below 2^-47 relative, far inside the final rounding to binary32.
+HNB_HD double d_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 // Round to nearest integer (ties to even) with two IEEE additions; valid |x| < 2^51.
 HNB_HD double d_rint(double x) {
     const double magic = 6755399441055744.0;  // 1.5 * 2^52
@@ -77,34 +88,30 @@ HNB_HD double d_rint(double x) {
 
 // sin and cos of a finite double with |x| <= 2^40.
 HNB_HD void d_sincos(double x, double* s_out, double* c_out) {
-    const double two_over_pi = 0.63661977236758134308;
+    const double two_over_pi = 0x1.45f306dc9c883p-1;
     const double p1 = 1.57079632673412561417e+00;  // first 33 bits of pi/2
     const double p2 = 6.07710050630396597660e-11;  // next 33 bits
     const double p3 = 2.02226624879595063154e-21;  // remainder
-    double k = d_rint(x * two_over_pi);
-    double r = ((x - k * p1) - k * p2) - k * p3;
-    long long q = (long long)k;
-    double z = r * r;
-    // Taylor series, |r| <= pi/4 (+ slack): truncation < 1e-18
-    double ps = -1.0 / 355687428096000.0;                 // -1/17!
-    ps = ps * z + 1.0 / 1307674368000.0;                  // 1/15!
-    ps = ps * z - 1.0 / 6227020800.0;                     // -1/13!
-    ps = ps * z + 1.0 / 39916800.0;                       // 1/11!
-    ps = ps * z - 1.0 / 362880.0;                         // -1/9!
-    ps = ps * z + 1.0 / 5040.0;                           // 1/7!
-    ps = ps * z - 1.0 / 120.0;                            // -1/5!
-    ps = ps * z + 1.0 / 6.0;                              // 1/3!
-    double sn = r - (r * z) * ps;
-    double pc = 1.0 / 6402373705728000.0;                 // 1/18!
-    pc = pc * z - 1.0 / 20922789888000.0;                 // -1/16!
-    pc = pc * z + 1.0 / 87178291200.0;                    // 1/14!
-    pc = pc * z - 1.0 / 479001600.0;                      // -1/12!
-    pc = pc * z + 1.0 / 3628800.0;                        // 1/10!
-    pc = pc * z - 1.0 / 40320.0;                          // -1/8!
-    pc = pc * z + 1.0 / 720.0;                            // 1/6!
-    pc = pc * z - 1.0 / 24.0;                             // -1/4!
-    pc = pc * z + 0.5;                                    // 1/2!
-    double cs = 1.0 - z * pc;
+    const double k = d_rint(x * two_over_pi);
+    double r = d_fma(-k, p1, x);
+    r = d_fma(-k, p2, r);
+    r = d_fma(-k, p3, r);
+    const long long q = (long long)k;
+    const double z = r * r;
+    // |r| <= pi/4 (+ slack): sin r = r + r z S(z) (relative error 2^-55), cos r = 1 - z/2 + z^2 C(z) (2^-49)
+    double ps = 0x1.5e0ae6796256cp-33;
+    ps = d_fma(ps, z, -0x1.ae600a73bc9bcp-26);
+    ps = d_fma(ps, z, 0x1.71de379600d7fp-19);
+    ps = d_fma(ps, z, -0x1.a01a019e83411p-13);
+    ps = d_fma(ps, z, 0x1.1111111110bb1p-7);
+    ps = d_fma(ps, z, -0x1.5555555555555p-3);
+    const double sn = d_fma(r * z, ps, r);
+    double pc = 0x1.1c819b161a46fp-29;
+    pc = d_fma(pc, z, -0x1.27e25ef4d05dfp-22);
+    pc = d_fma(pc, z, 0x1.a019ff5333bf2p-16);
+    pc = d_fma(pc, z, -0x1.6c16c16b61208p-10);
+    pc = d_fma(pc, z, 0x1.5555555555436p-5);
+    const double cs = d_fma(z * z, pc, d_fma(-0.5, z, 1.0));
     switch ((int)(q & 3)) {
         case 0: *s_out = sn; *c_out = cs; break;
         case 1: *s_out = cs; *c_out = -sn; break;
@@ -118,104 +125,183 @@ HNB_HD double d_pow2i(long long k) { return u2d((uint64_t)(k + 1023) << 52); }
 
 // exp(x) for finite x; caller clamps to [-120, 100]
 HNB_HD double d_exp(double x) {
-    const double log2e = 1.44269504088896338700;
+    const double log2e = 0x1.71547652b82fep+0;
     const double ln2_hi = 6.93147180369123816490e-01;
     const double ln2_lo = 1.90821492927058770002e-10;
-    double k = d_rint(x * log2e);
-    double r = (x - k * ln2_hi) - k * ln2_lo;
-    double p = 1.0 / 6227020800.0;      // 1/13!
-    p = p * r + 1.0 / 479001600.0;      // 1/12!
-    p = p * r + 1.0 / 39916800.0;       // 1/11!
-    p = p * r + 1.0 / 3628800.0;        // 1/10!
-    p = p * r + 1.0 / 362880.0;         // 1/9!
-    p = p * r + 1.0 / 40320.0;          // 1/8!
-    p = p * r + 1.0 / 5040.0;           // 1/7!
-    p = p * r + 1.0 / 720.0;            // 1/6!
-    p = p * r + 1.0 / 120.0;            // 1/5!
-    p = p * r + 1.0 / 24.0;             // 1/4!
-    p = p * r + 1.0 / 6.0;              // 1/3!
-    p = p * r + 0.5;                    // 1/2!
-    p = p * r + 1.0;
-    p = p * r + 1.0;
-    return p * d_pow2i((long long)k);
+    const double k = d_rint(x * log2e);
+    double r = d_fma(-k, ln2_hi, x);
+    r = d_fma(-k, ln2_lo, r);
+    // |r| <= ln2 / 2: exp r = 1 + r + r^2 E(r), relative error 2^-49
+    double p = 0x1.2880501c9131ap-22;
+    p = d_fma(p, r, 0x1.72c7432675d87p-19);
+    p = d_fma(p, r, 0x1.a019c99a94203p-16);
+    p = d_fma(p, r, 0x1.a019ad9325b18p-13);
+    p = d_fma(p, r, 0x1.6c16c173921fdp-10);
+    p = d_fma(p, r, 0x1.1111111c4acecp-7);
+    p = d_fma(p, r, 0x1.5555555554cb3p-5);
+    p = d_fma(p, r, 0x1.5555555553b6ep-3);
+    p = d_fma(p, r, 0x1.0000000000000p-1);
+    const double t = d_fma(r * r, p, r);
+    return (1.0 + t) * d_pow2i((long long)k);
 }
 
-// natural log of a finite, strictly positive, normal double
+// natural log of a finite, strictly positive, normal double: x = 2^k z with z in [0.6875, 1.375); the 64 intervals of z (top six
+// fraction bits) each have a centre c with 1/c and log c tabulated, so log x = k ln2 + log c + log1p(r), r = z / c - 1 (one fma),
+// |r| <= 2^-6, log1p r = r - r^2/2 + r^3 L(r) with relative error 2^-48. The two intervals that meet at z = 1 use c = 1: x near 1
+// keeps its relative accuracy (log x = log1p(x - 1), x - 1 exact).
+HNB_TABLE double kLogTab[64][2] = {   // {1/c, log c}
+    {0x1.724287f46debcp+0, -0x1.79e26687cfb3dp-2},
+    {0x1.6e1f76b4337c7p+0, -0x1.6e60ee6af1973p-2},
+    {0x1.6a13cd1537290p+0, -0x1.630030b3aac48p-2},
+    {0x1.661ec6a5122f9p+0, -0x1.57bf753c8d1fbp-2},
+    {0x1.623fa77016240p+0, -0x1.4c9e09e172c3dp-2},
+    {0x1.5e75bb8d015e7p+0, -0x1.419b423d5e8c6p-2},
+    {0x1.5ac056b015ac0p+0, -0x1.36b6776be1116p-2},
+    {0x1.571ed3c506b3ap+0, -0x1.2bef07cdc9355p-2},
+    {0x1.5390948f40febp+0, -0x1.214456d0eb8d5p-2},
+    {0x1.5015015015015p+0, -0x1.16b5ccbacfb73p-2},
+    {0x1.4cab88725af6ep+0, -0x1.0c42d676162e2p-2},
+    {0x1.49539e3b2d067p+0, -0x1.01eae5626c691p-2},
+    {0x1.460cbc7f5cf9ap+0, -0x1.ef5ade4dcffe5p-3},
+    {0x1.42d6625d51f87p+0, -0x1.db13db0d48941p-3},
+    {0x1.3fb013fb013fbp+0, -0x1.c6ffbc6f00f71p-3},
+    {0x1.3c995a47babe7p+0, -0x1.b31d8575bce3bp-3},
+    {0x1.3991c2c187f63p+0, -0x1.9f6c407089663p-3},
+    {0x1.3698df3de0748p+0, -0x1.8beafeb38fe8fp-3},
+    {0x1.33ae45b57bcb2p+0, -0x1.7898d85444c74p-3},
+    {0x1.30d190130d190p+0, -0x1.6574ebe8c1339p-3},
+    {0x1.2e025c04b8097p+0, -0x1.527e5e4a1b58dp-3},
+    {0x1.2b404ad012b40p+0, -0x1.3fb45a59928cap-3},
+    {0x1.288b01288b013p+0, -0x1.2d1610c86813dp-3},
+    {0x1.25e22708092f1p+0, -0x1.1aa2b7e23f729p-3},
+    {0x1.23456789abcdfp+0, -0x1.08598b59e3a07p-3},
+    {0x1.20b470c67c0d9p+0, -0x1.ec739830a1126p-4},
+    {0x1.1e2ef3b3fb874p+0, -0x1.c885801bc4b20p-4},
+    {0x1.1bb4a4046ed29p+0, -0x1.a4e7640b1bc38p-4},
+    {0x1.19453808ca29cp+0, -0x1.8197e2f40e3f0p-4},
+    {0x1.16e0689427379p+0, -0x1.5e95a4d9791cdp-4},
+    {0x1.1485f0e0acd3bp+0, -0x1.3bdf5a7d1ee5ep-4},
+    {0x1.12358e75d3033p+0, -0x1.1973bd1465561p-4},
+    {0x1.0fef010fef011p+0, -0x1.eea31c006b87cp-5},
+    {0x1.0db20a88f4696p+0, -0x1.aaef2d0fb1108p-5},
+    {0x1.0b7e6ec259dc8p+0, -0x1.67c94f2d4bb65p-5},
+    {0x1.0953f39010954p+0, -0x1.252f32f8d1840p-5},
+    {0x1.073260a47f7c6p+0, -0x1.c63d2ec14aad7p-6},
+    {0x1.05197f7d73404p+0, -0x1.432a925980cbcp-6},
+    {0x1.03091b51f5e1ap+0, -0x1.82448a388a283p-7},
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.f44659e4a4271p-1, 0x1.7b91b07d5b126p-6},
+    {0x1.ecc07b301ecc0p-1, 0x1.39e87b9febd68p-5},
+    {0x1.e573ac901e574p-1, 0x1.b42dd711971b9p-5},
+    {0x1.de5d6e3f8868ap-1, 0x1.16536eea37ae3p-4},
+    {0x1.d77b654b82c34p-1, 0x1.51b073f06183cp-4},
+    {0x1.d0cb58f6ec074p-1, 0x1.8c345d6319b23p-4},
+    {0x1.ca4b3055ee191p-1, 0x1.c5e548f5bc743p-4},
+    {0x1.c3f8f01c3f8f0p-1, 0x1.fec9131dbeabcp-4},
+    {0x1.bdd2b899406f7p-1, 0x1.1b72ad52f67a2p-3},
+    {0x1.b7d6c3dda338bp-1, 0x1.371fc201e8f75p-3},
+    {0x1.b2036406c80d9p-1, 0x1.526e5e3a1b438p-3},
+    {0x1.ac5701ac5701bp-1, 0x1.6d60fe719d21bp-3},
+    {0x1.a6d01a6d01a6dp-1, 0x1.87fa06520c911p-3},
+    {0x1.a16d3f97a4b02p-1, 0x1.a23bc1fe2b561p-3},
+    {0x1.9c2d14ee4a102p-1, 0x1.bc286742d8cd4p-3},
+    {0x1.970e4f80cb872p-1, 0x1.d5c216b4fbb94p-3},
+    {0x1.920fb49d0e229p-1, 0x1.ef0adcbdc5935p-3},
+    {0x1.8d3018d3018d3p-1, 0x1.0402594b4d041p-2},
+    {0x1.886e5f0abb04ap-1, 0x1.1058bf9ae4ad4p-2},
+    {0x1.83c977ab2beddp-1, 0x1.1c898c16999fbp-2},
+    {0x1.7f405fd017f40p-1, 0x1.2895a13de86a4p-2},
+    {0x1.7ad2208e0ecc3p-1, 0x1.347dd9a987d56p-2},
+    {0x1.767dce434a9b1p-1, 0x1.404308686a7e4p-2},
+};
 HNB_HD double d_log(double x) {
     const double ln2_hi = 6.93147180369123816490e-01;
     const double ln2_lo = 1.90821492927058770002e-10;
-    uint64_t b = d2u(x);
-    long long e = (long long)((b >> 52) & 2047) - 1023;
-    double m = u2d((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
-    if (m > 1.41421356237309514547) { m = m * 0.5; e += 1; }
-    double f = (m - 1.0) / (m + 1.0);
-    double z = f * f;
-    double p = 1.0 / 21.0;
-    p = p * z + 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z + 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z + 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z + 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z + 1.0 / 3.0;
-    p = p * z + 1.0;
-    double lm = 2.0 * f * p;
-    double de = (double)e;
-    return de * ln2_hi + (de * ln2_lo + lm);
+    const uint64_t ix = d2u(x);
+    const uint64_t tmp = ix - 0x3fe6000000000000ull;
+    const uint32_t i = (uint32_t)(tmp >> 46) & 63u;
+    const long long k = (long long)tmp >> 52;   // arithmetic shift: floor
+    const double z = u2d(ix - (tmp & 0xfff0000000000000ull));
+    const double r = d_fma(z, kLogTab[i][0], -1.0);
+    const double r2 = r * r;
+    double p = 0x1.24a4c91a63c23p-3;
+    p = d_fma(p, r, -0x1.556a254394372p-3);
+    p = d_fma(p, r, 0x1.9999994c9b676p-3);
+    p = d_fma(p, r, -0x1.ffffffa962285p-3);
+    p = d_fma(p, r, 0x1.5555555555555p-2);
+    const double l1p = d_fma(r2 * r, p, d_fma(-0.5, r2, r));
+    const double kd = (double)k;
+    return (kd * ln2_hi + kLogTab[i][1]) + (l1p + kd * ln2_lo);
 }
 
-// sqrt of a double in [0, 2^100] whose value is representable-ish in f32 range:
-// f32 seed (IEEE sqrtf) + 2 Newton steps. Deterministic, ~1e-16 relative.
+// sqrt of a double in [2^-100, 2^100] (and 0; negative / NaN -> NaN): the binary32 root and its binary32 reciprocal (both IEEE, so
+// identical on host and device) seed ONE Heron step whose division is a multiplication by that reciprocal: relative error < 2^-46.
 HNB_HD double d_sqrt(double a) {
     if (!(a > 0.0)) return (a == 0.0) ? 0.0 : (a - a) / (a - a);  // 0 -> 0, neg/NaN -> NaN
-    double s = (double)f_sqrt((float)a);
-    s = 0.5 * (s + a / s);
-    s = 0.5 * (s + a / s);
-    return s;
+    const float sf = f_sqrt((float)a);
+    const double s0 = (double)sf, h = 0.5 * (double)(1.0f / sf);
+    return d_fma(d_fma(-s0, s0, a), h, s0);
 }
 
-// atan of any double (NaN -> NaN)
+// asin(t) = t + t z P(z), z = t^2 <= 1/4: relative error 2^-50
+HNB_HD double d_asin_poly(double z) {
+    double p = 0x1.c8ea18fd14be4p-6;
+    p = d_fma(p, z, -0x1.c05fb18feb0f9p-8);
+    p = d_fma(p, z, 0x1.fa6d9d973284ep-7);
+    p = d_fma(p, z, 0x1.5114f44b77900p-7);
+    p = d_fma(p, z, 0x1.cf629dd6ae5fdp-7);
+    p = d_fma(p, z, 0x1.1c0d42d9a72edp-6);
+    p = d_fma(p, z, 0x1.6e8f37bce829dp-6);
+    p = d_fma(p, z, 0x1.f1c6ff632bc58p-6);
+    p = d_fma(p, z, 0x1.6db6dba9ded46p-5);
+    p = d_fma(p, z, 0x1.3333333302d42p-4);
+    p = d_fma(p, z, 0x1.55555555555bcp-3);
+    return p;
+}
+// asin / acos of a double; |x| > 1 -> NaN. |x| > 1/2: asin |x| = pi/2 - 2 asin sqrt((1 - |x|) / 2)  ((1 - |x|) / 2 is exact)
+HNB_HD double d_asin(double x) {
+    const double pi_2_hi = 0x1.921fb54442d18p+0, pi_2_lo = 0x1.1a62633145c07p-54;
+    const double ax = x < 0.0 ? -x : x;
+    if (ax <= 0.5) { const double z = x * x; return d_fma(x * z, d_asin_poly(z), x); }
+    const double z = (1.0 - ax) * 0.5;
+    const double s = d_sqrt(z);
+    const double t = d_fma(s * z, d_asin_poly(z), s);
+    const double r = d_fma(-2.0, t, pi_2_hi) + pi_2_lo;
+    return x < 0.0 ? -r : r;
+}
+HNB_HD double d_acos(double x) {
+    const double pi_2_hi = 0x1.921fb54442d18p+0, pi_2_lo = 0x1.1a62633145c07p-54;
+    const double ax = x < 0.0 ? -x : x;
+    if (ax <= 0.5) { const double z = x * x; return pi_2_hi - (d_fma(x * z, d_asin_poly(z), x) - pi_2_lo); }
+    const double z = (1.0 - ax) * 0.5;
+    const double s = d_sqrt(z);
+    const double t = d_fma(s * z, d_asin_poly(z), s);
+    return x < 0.0 ? d_fma(-2.0, t, 2.0 * pi_2_hi) + 2.0 * pi_2_lo : 2.0 * t;
+}
+
+// atan of any double (NaN -> NaN): at most one division. t = |x| <= tan(pi/8): atan t; t <= tan(3 pi/8): pi/4 + atan((t-1)/(t+1));
+// beyond: pi/2 - atan(1/t); atan u = u + u z A(z), z = u^2 <= tan^2(pi/8), relative error 2^-47
 HNB_HD double d_atan(double x) {
     if (x != x) return x;
-    const double pi_2 = 1.57079632679489655800;
-    const double pi_4 = 0.78539816339744827900;
-    bool neg = d_signbit(x);
-    double t = neg ? -x : x;
-    bool inv = t > 1.0;
-    if (inv) t = 1.0 / t;
-    bool shift = t > 0.41421356237309503;  // tan(pi/8)
-    if (shift) t = (t - 1.0) / (t + 1.0);
-    double z = t * t;
-    // sum_{n=0}^{23} (-1)^n z^n / (2n+1), |z| <= 0.1716: truncation < 1e-19
-    double p = -1.0 / 47.0;
-    p = p * z + 1.0 / 45.0;
-    p = p * z - 1.0 / 43.0;
-    p = p * z + 1.0 / 41.0;
-    p = p * z - 1.0 / 39.0;
-    p = p * z + 1.0 / 37.0;
-    p = p * z - 1.0 / 35.0;
-    p = p * z + 1.0 / 33.0;
-    p = p * z - 1.0 / 31.0;
-    p = p * z + 1.0 / 29.0;
-    p = p * z - 1.0 / 27.0;
-    p = p * z + 1.0 / 25.0;
-    p = p * z - 1.0 / 23.0;
-    p = p * z + 1.0 / 21.0;
-    p = p * z - 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z - 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z - 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z - 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z - 1.0 / 3.0;
-    p = p * z + 1.0;
-    double r = t * p;
-    if (shift) r = pi_4 + r;
-    if (inv) r = pi_2 - r;
+    const double pi_2 = 0x1.921fb54442d18p+0, pi_4 = 0x1.921fb54442d18p-1;
+    const bool neg = d_signbit(x);
+    const double t = neg ? -x : x;
+    const bool mid = t > 0.41421356237309503 && t <= 2.4142135623730951, big = t > 2.4142135623730951;
+    const double num = mid ? t - 1.0 : (big ? -1.0 : t), den = mid ? t + 1.0 : (big ? t : 1.0);
+    const double u = num / den;
+    const double z = u * u;
+    double p = -0x1.be20c62f176ddp-6;
+    p = d_fma(p, z, 0x1.a769bd3353c1cp-5);
+    p = d_fma(p, z, -0x1.0c52a4b5af878p-4);
+    p = d_fma(p, z, 0x1.3a9d83feefaedp-4);
+    p = d_fma(p, z, -0x1.74563c795c0ffp-4);
+    p = d_fma(p, z, 0x1.c71c381ab56c6p-4);
+    p = d_fma(p, z, -0x1.249248aa52bc5p-3);
+    p = d_fma(p, z, 0x1.99999998d12f0p-3);
+    p = d_fma(p, z, -0x1.55555555553a3p-2);
+    double r = d_fma(u * z, p, u);
+    r = (mid ? pi_4 : (big ? pi_2 : 0.0)) + r;
     return neg ? -r : r;
 }
 
@@ -251,14 +337,8 @@ HNB_HD float f_tan(float x) {
 }
 HNB_HD float f_atan(float x) { return (float)d_atan((double)x); }
 HNB_HD float f_atan2(float y, float x) { return (float)d_atan2((double)y, (double)x); }
-HNB_HD float f_asin(float x) {
-    double xd = (double)x;
-    return (float)d_atan2(xd, d_sqrt((1.0 - xd) * (1.0 + xd)));
-}
-HNB_HD float f_acos(float x) {
-    double xd = (double)x;
-    return (float)d_atan2(d_sqrt((1.0 - xd) * (1.0 + xd)), xd);
-}
+HNB_HD float f_asin(float x) { return (float)d_asin((double)x); }
+HNB_HD float f_acos(float x) { return (float)d_acos((double)x); }
 HNB_HD float f_exp(float x) {
     if (x != x) return x;
     double xd = (double)x;

@@ -132,9 +132,10 @@ HNB_HD float rand4_get(const Rand4& r, uint32_t k) { return k == 0 ? r.v0 : (k =
 struct V3 { float x, y, z; };
 HNB_HD float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 HNB_HD V3 sub3(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+// normalize(v) = v * (1 / length(v)) (hnb_math.h): one IEEE division instead of one per component
 HNB_HD V3 normalize3(V3 a) {
-    const float l = f_sqrt(dot3(a, a));
-    return V3{a.x / l, a.y / l, a.z / l};
+    const float inv = 1.0f / f_sqrt(dot3(a, a));
+    return V3{a.x * inv, a.y * inv, a.z * inv};
 }
 HNB_HD V3 cross3(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 // transform * vec4(v, 0) (mat4x4 built from the 3x4 rows, vfx_init.wgsl:157-164)
@@ -521,8 +522,8 @@ HNB_HD void vm_exec(const Ins ins, ST& S, const VmUniforms& U, const uint32_t* p
                 if (w > 1) s = s + x1 * x1;
                 if (w > 2) s = s + x2 * x2;
                 if (w > 3) s = s + x3 * x3;
-                const float l = f_sqrt(s);
-                o = Out4{f2u(x0 / l), f2u(x1 / l), f2u(x2 / l), f2u(x3 / l)};
+                const float inv = 1.0f / f_sqrt(s);
+                o = Out4{f2u(x0 * inv), f2u(x1 * inv), f2u(x2 * inv), f2u(x3 * inv)};
             } break;
             case HNB_OP_CROSS: {
                 nout = 3;

@@ -392,10 +392,11 @@ static float dotf(const Val* a, const Val* b) {
     for (int i = 1; i < a->count; ++i) s = s + vf(a, i) * vf(b, i);
     return s;
 }
+/* normalize(v) = v * (1 / length(v)): the arithmetic definition of oracle_math.h (WGSL leaves normalize's accuracy to the implementation) */
 static Val normalize_v(const Val* a) {
-    const float l = f_sqrt(dotf(a, a));
+    const float inv = 1.0f / f_sqrt(dotf(a, a));
     Val o = mk(T_F32, a->count);
-    for (int i = 0; i < a->count; ++i) sf(&o, i, vf(a, i) / l);
+    for (int i = 0; i < a->count; ++i) sf(&o, i, vf(a, i) * inv);
     return o;
 }
 static Val cross_v(const Val* a, const Val* b) {
@@ -1305,5 +1306,24 @@ float hor_math1(int fn, float x) {
         case 5: return f_log2(x); case 6: return f_atan(x); case 7: return f_asin(x); case 8: return f_acos(x); case 9: return f_exp2(x);
         case 10: return f_sqrt(x); case 11: return f_inv_sqrt(x); default: return x;
     }
+}
+/* the binary64 kernels BEFORE the final rounding to binary32 (tests/test_math.py measures their error against libm) */
+double hor_math1d(int fn, double x) {
+#ifdef ORACLE_LIBM
+    return x;
+#else
+    double s, c;
+    switch (fn) {
+        case 0: d_sincos(x, &s, &c); return s;
+        case 1: d_sincos(x, &s, &c); return c;
+        case 3: return d_exp(x);
+        case 4: return d_log(x);
+        case 6: return d_atan(x);
+        case 7: return d_asin(x);
+        case 8: return d_acos(x);
+        case 10: return d_sqrt(x);
+        default: return x;
+    }
+#endif
 }
 float hor_math2(int fn, float x, float y) { return fn == 0 ? f_pow(x, y) : (fn == 1 ? f_atan2(x, y) : f_rem(x, y)); }

@@ -67,6 +67,8 @@ def _lib(omp=False, libm=False):
         lib.hor_round_literal.argtypes = [C.c_float]
         lib.hor_math1.restype = C.c_float
         lib.hor_math1.argtypes = [C.c_int, C.c_float]
+        lib.hor_math1d.restype = C.c_double
+        lib.hor_math1d.argtypes = [C.c_int, C.c_double]
         lib.hor_math2.restype = C.c_float
         lib.hor_math2.argtypes = [C.c_int, C.c_float, C.c_float]
         lib.hor_spawner_tick.restype = C.c_uint32
@@ -231,6 +233,11 @@ def round_literal(x):
 
 def math1(fn, x):
     return float(_lib().hor_math1(C.c_int(fn), C.c_float(x)))
+
+
+def math1d(fn, x):
+    """The binary64 kernel behind math1(fn, .), before the final rounding to binary32."""
+    return float(_lib().hor_math1d(C.c_int(fn), C.c_double(x)))
 
 
 def math2(fn, x, y):

@@ -90,3 +90,38 @@ for n in (8, 9, 10):
     e = max_err(lambda t: t + t ** 3 * horner(cs, t * t), mp.atan, mp.mpf("1e-6"), lim)
     print(f"atan: {n} coefficients: fit err {mp.nstr(err, 5)}, relative error {mp.nstr(e, 5)} = 2^{mp.nstr(mp.log(e, 2), 5)}")
     show(f"ATAN_{n}", cs)
+
+print("\n==== atan on |u| <= tan(pi/8)")
+lim = (mp.sqrt(2) - 1) * mp.mpf("1.0001")
+for n in (9, 10, 11, 12):
+    Af = lambda z: (mp.atan(mp.sqrt(z)) / mp.sqrt(z) - 1) / z if z else -mp.mpf(1) / 3
+    cs, err = fit(Af, 0, lim * lim, n)
+    e = max_err(lambda t: t + t ** 3 * horner(cs, t * t), mp.atan, mp.mpf("1e-6"), lim)
+    print(f"atan8: {n} coefficients: relative error {mp.nstr(e, 5)} = 2^{mp.nstr(mp.log(e, 2), 5)}")
+    show(f"ATAN8_{n}", cs)
+
+print("\n==== log table (64 intervals of z in [0.6875, 1.375))")
+OFF = 0x3fe6000000000000
+import struct
+def u2d(u): return struct.unpack("<d", struct.pack("<Q", u))[0]
+rows = []
+worst_r = 0
+for i in range(64):
+    lo, hi = u2d(OFF + (i << 46)), u2d(OFF + ((i + 1) << 46))
+    if i in (39, 40):
+        invc, logc = 1.0, 0.0
+    else:
+        c = (mp.mpf(lo) + mp.mpf(hi)) / 2
+        invc = float(1 / c)
+        logc = float(-mp.log(mp.mpf(invc)))
+    for z in (lo, hi):
+        worst_r = max(worst_r, abs(float(mp.mpf(z) * mp.mpf(invc) - 1)))
+    rows.append((invc, logc, lo, hi))
+print(f"// max |r| = {worst_r} = 2^{float(mp.log(worst_r, 2)):.3f}")
+for i, (invc, logc, lo, hi) in enumerate(rows):
+    print(f"    {{{invc.hex()}, {logc.hex()}}},  // {i}: z in [{lo}, {hi})")
+for name, v in (("ln2_hi", None),):
+    pass
+print("pi/2 hi/lo:", float(mp.pi / 2).hex(), float(mp.pi / 2 - mp.mpf(float(mp.pi / 2))).hex())
+print("pi hi/lo:", float(mp.pi).hex(), float(mp.pi - mp.mpf(float(mp.pi))).hex())
+print("pi/4:", float(mp.pi / 4).hex(), " 2/pi:", float(2 / mp.pi).hex(), " log2e:", float(1 / mp.log(2)).hex(), "ln2:", float(mp.log(2)).hex())
