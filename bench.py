@@ -1,21 +1,40 @@
 #!/usr/bin/env python3
 """Benchmark of the particle hot path on MI355X: particle-updates/sec + achieved HBM GB/s (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--scaling weak|strong|both]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--scaling weak|strong|both]
 
 A "step" is one simulated frame (one pass of the hot path: per-frame inputs upload, init where the frame spawns, update +
-kill + list maintenance, ribbon sort where the layout has RIBBON_ID) over particle state resident in HBM.
+kill + list maintenance, ribbon sort where the layout has RIBBON_ID) over particle state resident in HBM. After W warm-up
+frames the script times WINDOWS (default 5) windows of exactly K steps each, every one bracketed by a barrier and a device
+synchronisation; `ms_per_step` / `value` are the MEDIAN window, the others are listed under "windows" (min, all).
 
 Configurations (synthetic scalings of the reference's example assets):
   c2 (default, the headline)  examples/firework.rs `trails` effect, capacity 16,777,216 per GPU, burst spawn during warm-up,
-                              every particle alive in the timed frames; sharded by CAPACITY SLAB (rank g owns global slots
-                              [g*C, (g+1)*C), `slot_base` feeds the PRNG so the union equals a single-GPU run);
+                              every particle alive in the timed frames (BASELINE.json configs[1]); sharded by CAPACITY SLAB;
+  c2_mixed                    the same program and capacity in its GENERAL state: a rate spawner of capacity / mean lifetime
+                              particles per second in steady state - per-particle ages, lifetimes loaded, spawns into
+                              recycled slots and deaths in every frame, list kernels in every frame;
+  c2_dieoff                   frames 48..70 of the burst (1/60 s frames): the die-off, 4 % of the capacity lost per frame;
+  c2_interop                  c2 with HNB_AGE_COHORT=0: the AGE plane is kept up to date for a renderer that reads it
+                              (ColorOverLifetime / SizeOverLifetime, src/modifier/output.rs:310-312);
   c3                          examples/force_field.rs, capacity 8,388,608 per GPU, burst, capacity slabs;
   c4                          examples/instancing.rs: independent instances x 65,536, sharded BY INSTANCE
                               (sharding.instance_plan: instance i on rank i mod N); 512 instances per GPU, i.e. BASELINE's
                               4096 instances at N = 8 (`--instances 4096` puts the whole configuration on one GPU);
   c5                          examples/ribbon.rs, capacity 4,194,304 per GPU, rate spawner in steady spawn/kill churn,
                               ribbon sort included in the step.
+At N = 1 the default command runs c2 as the JSON line and appends the others under "configs".
+
+Roofline (every configuration): the dominant kernel's HBM-side traffic is MEASURED in this run - the script re-runs itself
+twice under `rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE` (separate passes; FETCH_SIZE doubled as
+guides/MI355X_MICROARCH.md prescribes for gfx950), cutting the dispatch list at marker kernels - and
+    roofline.achieved = measured bytes per launch / the kernel's average duration (HIP events, this process),
+    roofline.frac     = achieved / 8 TB/s                      (never above 1: these are bytes that crossed the fabric),
+    roofline.algorithmic = SURVEY.md §8(d)'s bytes per update (68 B for the firework) x updates / the same time: what the
+                        launch is WORTH, which exceeds what it moves where the design elides traffic (age cohorts,
+                        lifetime culling, no list traffic in frames without casualties).
+Without rocprofv3 the committed profiles/traffic.json is used if its kernel-source stamp matches this tree, else the
+fraction falls back to a stated per-configuration byte model (`traffic_source` says which).
 
 N > 1: `python bench.py --gpus N` launches itself under `python -m torch.distributed.run` (one process per GPU, RCCL); when the
 driver already started it that way (WORLD_SIZE in the environment) it just runs its rank. There is no data-path collective: the
@@ -24,11 +43,17 @@ line is the weak-scaling run (per-GPU work fixed); with N > 1 a strong-scaling r
 reported inside it under "strong".
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
 import socket
+import statistics
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -45,25 +70,40 @@ import torch  # noqa: E402,F401  (before the HIP library of this package: torch 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (guides/MI355X_MICROARCH.md)
 DT = 1.0 / 60.0
 MIN_LIFETIME = 0.8  # firework.rs: lifetime = uniform(0.8, 1.2)
+MEAN_LIFETIME = 1.0
 TIMING_PERIOD = 5   # HIP events bracket the kernels of every 5th timed frame (each costs ~20 us of stream bubbles)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")  # written by tools/prof_bench.sh from the PMC passes
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")  # written by `bench.py --write-traffic` from the PMC passes
+DIEOFF_FIRST, DIEOFF_LAST, DIEOFF_END = 48, 70, 76   # c2_dieoff: timed frames [48, 70]; by frame 76 nothing is alive (1.2 s < 73 / 60 s)
 
-# algorithmic bytes per particle update, SURVEY.md §8(d): attributes read + attributes written + 8 B alive-list entry
+# algorithmic bytes per particle update, SURVEY.md §8(d): attributes read + attributes written + 8 B alive-list entry.
+# model_bytes: what the dominant kernel of the configuration is DESIGNED to move per updated particle (fallback when no PMC pass
+# is available; DESIGN.md "Roofline" derives each figure).
 CONFIGS = {
-    "c2": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, kernel="k_update_slots_stream<ProgDragAccel>",
+    "c2": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=48, kernel="k_update_slots_stream<ProgDragAccel, cohort>",
                workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst spawner, all particles alive"),
-    "c3": dict(capacity=1 << 23, bytes_per_update=68, bytes_per_spawn=40, kernel="k_update_slots_stream<ProgForceField>",
+    "c2_mixed": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=62, kernel="k_update_slots_stream<ProgDragAccel, cohort>",
+                     workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, rate spawner (capacity / mean lifetime per second) in steady state: "
+                              "mixed ages, spawns into recycled slots + deaths + list kernels every frame"),
+    "c2_dieoff": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=62, kernel="k_update_slots_stream<ProgDragAccel, cohort>",
+                      workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst; frames 48..70 at 1/60 s: the die-off (list kernels every frame)"),
+    "c2_interop": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=56, kernel="k_update_slots_stream<ProgDragAccel>",
+                       workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst, all alive, HNB_AGE_COHORT=0 (AGE plane current every frame)"),
+    "c3": dict(capacity=1 << 23, bytes_per_update=68, bytes_per_spawn=40, model_bytes=56, kernel="k_update_slots_stream<ProgForceField>",
                workload="force_field.rs EffectAsset (2x ConformToSphere + KillAabb + KillSphere), capacity={cap:_} per GPU, burst"),
-    "c4": dict(capacity=65536, bytes_per_update=68, bytes_per_spawn=40, kernel="k_update_slots_stream<ProgAgeEuler>", instances=512,
+    "c4": dict(capacity=65536, bytes_per_update=68, bytes_per_spawn=40, model_bytes=36, kernel="k_update_slots_stream<ProgAgeEuler, cohort>", instances=512,
                workload="instancing.rs: {inst} independent effect instances x {cap:_} per GPU (one launch), burst, all alive"),
-    "c5": dict(capacity=1 << 22, bytes_per_update=20, bytes_per_spawn=36, kernel="k_update_slots_stream<ProgAge>",
+    "c5": dict(capacity=1 << 22, bytes_per_update=20, bytes_per_spawn=36, model_bytes=9, kernel="k_update_slots_stream<ProgAge>",
                workload="ribbon.rs EffectAsset, capacity={cap:_} per GPU, rate spawner in steady spawn/kill churn, ribbon sort in the step"),
 }
+EXTRA_CONFIGS = ("c2_mixed", "c2_dieoff", "c2_interop", "c3", "c4", "c5")   # appended to the N = 1 default line
+# what identifies the dominant kernel of a configuration in a rocprofv3 dispatch list
+KERNEL_MATCH = {"c2": ("k_update_slots_stream",), "c2_mixed": ("k_update_slots_stream",), "c2_dieoff": ("k_update_slots_stream",),
+                "c2_interop": ("k_update_slots_stream",), "c3": ("k_update_slots_stream",), "c4": ("k_update_slots_stream",), "c5": ("k_update_slots_stream",)}
 
 
 def frame_dt(total_frames):
-    """1/60 s like the reference's example; shrunk only if a long --steps run would outlive the
-    youngest particle (the c2 metric is defined on frames where all particles are alive)."""
+    """1/60 s like the reference's example; shrunk only if a long run would outlive the youngest
+    particle (the c2 metric is defined on frames where all particles are alive)."""
     return DT if total_frames * DT < MIN_LIFETIME * 0.95 else MIN_LIFETIME * 0.95 / total_frames
 
 
@@ -89,22 +129,44 @@ def instance_transform(i):
     return [1, 0, 0, 10.0 * (i % 64), 0, 1, 0, 0.0, 0, 0, 1, 10.0 * (i // 64)]
 
 
-def load_traffic(config, capacity, n_inst):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json, written by
-    tools/prof_bench.sh: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate rocprofv3 runs). Counters cannot be
-    collected from inside this process; None when no pass was recorded for this workload."""
+def kernel_source_stamp():
+    """sha256 over the sources every kernel of the library is built from: ties a recorded traffic figure to a kernel build."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "bevy_hanabi_amd", "csrc")
+    for name in ("hnb_math.h", "hnb_vm.h", "hnb_dev.h", "hnb_kernels.hip.h", "hnb_sort.hip.h", "hnb_jit.h", "hanabi_amd.hip"):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def git_head():
     try:
-        with open(TRAFFIC_FILE) as f:
-            t = json.load(f)
-        e = t.get(f"{config}:{capacity}x{n_inst}")
-        return (e["bytes_per_launch"], e["source"]) if e else (None, None)
-    except (OSError, ValueError, KeyError):
-        return None, None
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+    except Exception:
+        return None
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline
 # ------------------------------------------------------------------------------------------------------------------
+def host_physical_cores():
+    try:
+        cores, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                elif not ln.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+        return len(cores) or None
+    except OSError:
+        return None
+
+
 def cpu_baseline(capacity, frames=60, check_frames=2):
     """A tuned CPU port of the lowered firework update (oracle/cpu_soa.c: packed SoA planes, OpenMP over 4096-particle blocks,
     -O3 -march=native -ffp-contract=off) on the FULL configuration, timed on the host cores. The reference has no CPU
@@ -160,16 +222,18 @@ def cpu_baseline(capacity, frames=60, check_frames=2):
             best = t if best is None else min(best, t)
         tried[threads] = capacity * frames / best
     threads = max(tried, key=tried.get)
-    return {"value": tried[threads], "unit": "particle-updates/s", "cores": threads, "kind": "port",
-            "hbm_equiv_gbs": tried[threads] * 56 / 1e9, "threads_tried": {str(k): v for k, v in tried.items()},
+    return {"value": tried[threads], "unit": "particle-updates/s", "cores": threads, "threads": threads, "host_logical_cpus": hw,
+            "host_physical_cores": host_physical_cores(), "kind": "port",
+            "algorithmic_gbs": tried[threads] * CONFIGS["c2"]["bytes_per_update"] / 1e9, "bytes_per_update": CONFIGS["c2"]["bytes_per_update"],
+            "threads_tried": {str(k): v for k, v in tried.items()},
             "sample": f"{capacity} particles x {frames} frames (best of 3 repeats) of the same firework update (all alive), packed-SoA OpenMP "
                       f"port (oracle/cpu_soa.c, -O3 -march=native, threads bound {os.environ['OMP_PROC_BIND']}/{os.environ['OMP_PLACES']}); "
                       f"checked bit-equal to the oracle on all {capacity} particles x {check_frames} frames first; {time.perf_counter() - t_all:.1f} s in total. "
-                      "Note: the 0.5 GB of state fits in the host's last-level caches (2 x 256 MB L3 on the GPU box)"}
+                      "`cores` = `threads` = the OpenMP thread count that was fastest; the 0.5 GB of state fits in the host's last-level caches (2 x 256 MB L3 on the GPU box)"}
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# one configuration on one rank
+# distributed plumbing
 # ------------------------------------------------------------------------------------------------------------------
 class Dist:
     def __init__(self, args):
@@ -218,135 +282,383 @@ class Dist:
             dist.destroy_process_group()
 
 
-def run_config(name, args, D, strong=False):
-    """Runs one configuration on this rank; returns the result dict on rank 0 (None elsewhere)."""
-    import bevy_hanabi_amd as bh
-    from bevy_hanabi_amd import effects, sharding
+# ------------------------------------------------------------------------------------------------------------------
+# one configuration on one rank
+# ------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """One configuration set up on one rank: builds the effect(s), knows how to play frame f."""
 
-    cfg = CONFIGS[name]
-    n = D.world
-    steps, warmup = args.steps, args.warmup
-    base_cap = args.capacity or cfg["capacity"]
-    ctx = bh.Context(D.device_index)
-    per_inst_cap = base_cap
-    spawn_plan = None  # c5: per-frame spawn counts
-    xf_of = None
+    def __init__(self, name, args, D, strong=False):
+        import bevy_hanabi_amd as bh
+        from bevy_hanabi_amd import effects, sharding
 
-    if name == "c4":
-        inst_per_gpu = args.instances or cfg["instances"]
-        total_inst = inst_per_gpu if strong else inst_per_gpu * n
-        mine = sharding.instance_plan(total_inst, n)[D.rank]          # instance i -> rank i mod N
-        asset = effects.instancing(per_inst_cap)
-        prog = ctx.create_program(bh.lower(asset))
-        fxs = [prog.create_effect() for _ in mine]
-        gids = list(mine)
-        gid_mix = (np.asarray(gids, dtype=np.uint64) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)   # instance_seed(f, i), vectorised over i
-        xf_of = np.array([instance_transform(i) for i in gids], dtype=np.float32)
-        local_particles = per_inst_cap * len(fxs)
-        sharding_desc = f"by instance: {total_inst} instances over {n} rank(s), {len(fxs)} on rank 0"
-    else:
-        if strong:
-            total_cap = base_cap
-            slot_base, per_inst_cap = sharding.slab_plan(total_cap, n)[D.rank]
-        else:
-            total_cap = base_cap * n
-            slot_base = sharding.slab_plan(total_cap, n)[D.rank][0]   # rank g owns global slots [g*cap, (g+1)*cap)
-        asset = {"c2": effects.firework_trails, "c3": effects.force_field, "c5": effects.ribbon}[name](per_inst_cap)
-        prog = ctx.create_program(bh.lower(asset))
-        fxs = [prog.create_effect(slot_base=slot_base)]
-        gids = [0]
-        local_particles = per_inst_cap
-        sharding_desc = f"capacity slab x{n}"
-        if name == "c5":
-            sp = bh.EffectSpawner(asset.spawner)
-            rng = bh.Pcg32()
-            warmup = max(warmup, 120)    # 1.5 s lifetime at 60 Hz: 90 frames to reach the steady state
-            spawn_plan = [sp.tick(DT, rng) for _ in range(1 + warmup + steps)]
-
-    dt = frame_dt(1 + warmup + steps) if name == "c2" else DT
-
-    def spawn_of(f):
-        if spawn_plan is not None:
-            return spawn_plan[f]
-        return per_inst_cap if f == 0 else 0
-
-    def step(f):
-        ctx.frame_begin(dt, f * dt)
+        self.name, self.D, self.bh = name, D, bh
+        cfg = self.cfg = CONFIGS[name]
+        n = D.world
+        base_cap = args.capacity or cfg["capacity"]
+        self.ctx = bh.Context(D.device_index)
+        self.per_inst_cap = base_cap
+        self.spawner = self.rng = None
+        self.xf_of = None
+        self.family = "c2" if name.startswith("c2") else name
         if name == "c4":
-            s = spawn_of(f)
-            # (numpy, not a Python loop over 512 instances: the harness must not be what the step waits for)
-            prog.set_frames(np.full(len(fxs), s, dtype=np.uint32), (gid_mix ^ np.uint64(frame_seed(f))).astype(np.uint32), xf_of)
-        elif name == "c5":   # the emitter moves (ribbon.rs Shape::tick, Lissajou)
-            t = f * dt * 6.5
-            fxs[0].set_frame(spawn_of(f), frame_seed(f), [1, 0, 0, 25.0 * np.cos(3.0 * t), 0, 1, 0, 25.0 * np.sin(2.0 * t), 0, 0, 1, 0.0])
+            inst_per_gpu = args.instances or cfg["instances"]
+            total_inst = inst_per_gpu if strong else inst_per_gpu * n
+            mine = sharding.instance_plan(total_inst, n)[D.rank]          # instance i -> rank i mod N
+            asset = effects.instancing(self.per_inst_cap)
+            self.prog = self.ctx.create_program(bh.lower(asset))
+            self.fxs = [self.prog.create_effect() for _ in mine]
+            gids = list(mine)
+            self.gid_mix = (np.asarray(gids, dtype=np.uint64) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)   # instance_seed(f, i), vectorised over i
+            self.xf_of = np.array([instance_transform(i) for i in gids], dtype=np.float32)
+            self.local_particles = self.per_inst_cap * len(self.fxs)
+            self.sharding_desc = f"by instance: {total_inst} instances over {n} rank(s), {len(self.fxs)} on rank 0"
         else:
-            fxs[0].set_frame(spawn_of(f), frame_seed(f))
-        ctx.simulate()
+            if strong:
+                total_cap = base_cap
+                slot_base, self.per_inst_cap = sharding.slab_plan(total_cap, n)[D.rank]
+            else:
+                total_cap = base_cap * n
+                slot_base = sharding.slab_plan(total_cap, n)[D.rank][0]   # rank g owns global slots [g*cap, (g+1)*cap)
+            cap = self.per_inst_cap
+            if name == "c2_mixed":
+                asset = effects.firework_trails(cap, bh.SpawnerSettings.rate(float(cap) / MEAN_LIFETIME))
+            elif self.family == "c2":
+                asset = effects.firework_trails(cap)
+            else:
+                asset = {"c3": effects.force_field, "c5": effects.ribbon}[name](cap)
+            env_before = os.environ.get("HNB_AGE_COHORT")
+            if name == "c2_interop":
+                os.environ["HNB_AGE_COHORT"] = "0"     # read at program creation: the AGE plane stays the truth
+            try:
+                self.prog = self.ctx.create_program(bh.lower(asset))
+            finally:
+                if name == "c2_interop":
+                    if env_before is None:
+                        os.environ.pop("HNB_AGE_COHORT", None)
+                    else:
+                        os.environ["HNB_AGE_COHORT"] = env_before
+            self.fxs = [self.prog.create_effect(slot_base=slot_base)]
+            self.local_particles = cap
+            self.sharding_desc = f"capacity slab x{n}"
+            if name in ("c5", "c2_mixed"):
+                self.spawner, self.rng = bh.EffectSpawner(asset.spawner), bh.Pcg32()
+        self.dt = DT
+        self.f = 0   # next frame index
 
-    # warm-up: frame 0 is the burst (k_init + k_update) for c2/c3/c4, then untimed frames
+    # -- frame inputs -------------------------------------------------------------------------------------------
+    def spawn_of(self, f):
+        if self.spawner is not None:
+            return self.spawner.tick(self.dt, self.rng)
+        if self.name == "c2_dieoff":
+            return self.per_inst_cap if f % DIEOFF_END == 0 else 0      # a burst every DIEOFF_END frames: every pass replays the same die-off
+        return self.per_inst_cap if f == 0 else 0
+
+    def step(self):
+        f, ctx, dt = self.f, self.ctx, self.dt
+        ctx.frame_begin(dt, f * dt)
+        s = self.spawn_of(f)
+        if self.name == "c4":
+            # (numpy, not a Python loop over 512 instances: the harness must not be what the step waits for)
+            self.prog.set_frames(np.full(len(self.fxs), s, dtype=np.uint32), (self.gid_mix ^ np.uint64(frame_seed(f))).astype(np.uint32), self.xf_of)
+        elif self.name == "c5":   # the emitter moves (ribbon.rs Shape::tick, Lissajou)
+            t = f * dt * 6.5
+            self.fxs[0].set_frame(s, frame_seed(f), [1, 0, 0, 25.0 * np.cos(3.0 * t), 0, 1, 0, 25.0 * np.sin(2.0 * t), 0, 0, 1, 0.0])
+        else:
+            self.fxs[0].set_frame(s, frame_seed(f % DIEOFF_END if self.name == "c2_dieoff" else f))
+        ctx.simulate()
+        self.f += 1
+
+    def alive(self):
+        return sum(fx.alive_count() for fx in self.fxs)
+
+    def close(self):
+        self.ctx.close()
+
+
+def warmup_frames(name, requested):
+    if name == "c5":
+        return max(requested, 120)     # 1.5 s lifetime at 60 Hz: 90 frames to reach the steady state
+    if name == "c2_mixed":
+        return max(requested, 240)     # lifetimes of 0.8 .. 1.2 s: four mean lifetimes until ages, slots and list order are mixed
+    return requested
+
+
+def run_config(name, args, D, strong=False, pmc=None):
+    """Runs one configuration on this rank; returns the result dict on rank 0 (None elsewhere).
+    pmc: None (normal run) or a dict {"begin": tag, "end": tag}: the short run a rocprofv3 counter pass wraps - marker kernels
+    bracket a few steady-state frames, nothing is timed."""
+    w = Workload(name, args, D, strong)
+    cfg, ctx, n = w.cfg, w.ctx, D.world
+    steps, windows = args.steps, max(1, args.windows)
+    warmup = warmup_frames(name, args.warmup)
+    if name == "c2_dieoff":
+        steps = DIEOFF_LAST - DIEOFF_FIRST + 1           # a window is the die-off itself, not K steps
+    elif w.family == "c2" and name != "c2_mixed":
+        w.dt = frame_dt(1 + warmup + steps * windows)    # nobody may die in the timed frames
+
+    if pmc is not None:   # ---- counter pass: no timing, a handful of steady frames between two markers
+        frames = 6
+        if name == "c2_dieoff":
+            for _ in range(DIEOFF_FIRST):
+                w.step()
+            frames = steps
+        else:
+            w.step()
+            for _ in range(warmup if name in ("c5", "c2_mixed") else 3):
+                w.step()
+        ctx.synchronize()
+        ctx.profile_marker(pmc["begin"])
+        for _ in range(frames):
+            w.step()
+        ctx.profile_marker(pmc["end"])
+        ctx.synchronize()
+        alive = w.alive()
+        w.close()
+        return {"frames": frames, "alive_after": alive}
+
+    # ---- warm-up: frame 0 is the burst (k_init + k_update) for the burst configurations, then untimed frames
     ctx.enable_kernel_timing(1)
-    step(0)
+    w.step()
     init_ms = ctx.kernel_timing()["init_ms_avg"]
     ctx.enable_kernel_timing(0)
-    for f in range(1, warmup + 1):
-        step(f)
+    dieoff_counts = None
+    if name == "c2_dieoff":
+        # pass 0 (untimed): the alive count in front of every frame of the window, read back frame by frame. The simulation is
+        # deterministic and every pass replays the same burst (same seeds, every slot spawned), so the timed passes see the same counts.
+        dieoff_counts = []
+        while w.f < DIEOFF_END:
+            if DIEOFF_FIRST <= w.f <= DIEOFF_LAST:
+                dieoff_counts.append(w.alive())
+            w.step()
+        assert w.alive() == 0, "c2_dieoff: particles left after the die-off"
+    else:
+        for _ in range(warmup):
+            w.step()
     D.barrier(ctx)
-    alive0 = sum(fx.alive_count() for fx in fxs)
-    ctx.enable_kernel_timing(TIMING_PERIOD)
-    D.barrier(ctx)
-    t0 = time.perf_counter()
-    for f in range(warmup + 1, warmup + 1 + steps):
-        step(f)
-    D.barrier(ctx)
-    elapsed = time.perf_counter() - t0
-    timing = ctx.kernel_timing()
+    alive0 = w.alive()
+    m0 = [fx.metadata() for fx in w.fxs[:8]]
+    window_s, window_updates = [], []
+    ctx.enable_kernel_timing(TIMING_PERIOD if name != "c2_dieoff" else 0)
+    for _win in range(windows):
+        if name == "c2_dieoff":
+            while w.f % DIEOFF_END != DIEOFF_FIRST:      # untimed: burst + flight up to the first death
+                w.step()
+            ctx.enable_kernel_timing(1)                  # (kernel events only inside the window, every frame of it)
+        D.barrier(ctx)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            w.step()
+        D.barrier(ctx)
+        window_s.append(D.max_time(time.perf_counter() - t0))
+        if name == "c2_dieoff":
+            timing_d = ctx.kernel_timing()
+            ctx.enable_kernel_timing(0)
+            window_updates.append(float(sum(dieoff_counts)))
+            while w.f % DIEOFF_END != 0:                 # let the rest die: the next pass bursts into an empty effect
+                w.step()
+            w.dieoff_timing = getattr(w, "dieoff_timing", []) + [timing_d]
+    timing = ctx.kernel_timing() if name != "c2_dieoff" else None
     ctx.enable_kernel_timing(0)
-    alive1 = sum(fx.alive_count() for fx in fxs)
-    last_max_update = sum(fx.metadata()["max_update"] for fx in fxs[:8]) if name == "c5" else None
-    kinfo = prog.kernel_info().split("\n")[0]
-    ctx.close()
+    if name == "c2_dieoff":
+        ts = w.dieoff_timing
+        tot = sum(t["frames"] for t in ts) or 1
+        timing = {k: sum(t[k] * t["frames"] for t in ts) / tot for k in ("update_ms_avg", "compact_ms_avg", "init_ms_avg")}
+        timing["frames"] = tot
+    alive1 = w.alive()
+    m1 = [fx.metadata() for fx in w.fxs[:8]]
+    kinfo = w.prog.kernel_info().split("\n")[0]
+    w.close()
 
-    elapsed = D.max_time(elapsed)
     alive0_total, alive1_total = D.sum_counts([alive0, alive1])
-    if name in ("c2", "c4"):
-        expect = local_particles if not D.on else None
+    if name in ("c2", "c2_interop", "c4"):
+        expect = w.local_particles if not D.on else None
         assert expect is None or (alive0 == expect and alive1 == expect), f"{name}: expected every particle alive during the timed frames, got {alive0}, {alive1}"
     if D.rank != 0:
         return None
-    # particles processed by the update stage per frame (max_update). c2/c3/c4: constant when nothing dies; c5 (churn): the
-    # update processes alive-before + this frame's spawns, reported by the last frame's metadata in the steady state.
-    if name == "c5":
-        per_frame_local = float(last_max_update)
-        per_frame_total = per_frame_local * (alive1_total / max(alive1, 1))
+    # particles processed by the update stage per frame (max_update). Burst configurations: constant when nothing dies. Churn (c5,
+    # c2_mixed): the update processes alive-before + this frame's spawns = the last frame's max_update in the steady state.
+    scale = alive1_total / max(alive1, 1) if D.on else 1.0
+    if name in ("c5", "c2_mixed"):
+        per_frame_local = float(sum(m["max_update"] for m in m1)) * (len(w.fxs) / max(1, len(m1)))
+        per_frame_total = per_frame_local * scale
+    elif name == "c2_dieoff":
+        per_frame_local = sum(dieoff_counts) / steps
+        per_frame_total = per_frame_local * n
     else:
         per_frame_total = (alive0_total + alive1_total) / 2.0
         per_frame_local = (alive0 + alive1) / 2.0
+    med = statistics.median(window_s)
     updates = per_frame_total * steps
-    value = updates / elapsed
+    value = updates / med
     bpu = cfg["bytes_per_update"]
     k_ms = timing["update_ms_avg"]
-    achieved = per_frame_local * bpu / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    traffic, traffic_src = load_traffic(name, per_inst_cap, len(fxs))
+    spawned = sum(b["particle_counter"] - a["particle_counter"] for a, b in zip(m0, m1)) / max(1, steps * windows)
     out = {
         "metric": "particle-updates/sec", "value": value, "unit": "particle-updates/s", "n_gpus": n,
-        "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "steps": steps, "warmup": warmup, "ms_per_step": med / steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg["workload"].format(cap=per_inst_cap, inst=len(fxs)), "name": name, "capacity_per_gpu": local_particles,
-                   "instances_per_gpu": len(fxs), "dt": dt, "sharding": sharding_desc, "alive_before": alive0_total, "alive_after": alive1_total,
-                   "updates_per_frame": per_frame_total},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": traffic_src,
-                     "kernel": cfg["kernel"], "kernel_ms_avg": k_ms, "lists_ms_avg": timing["compact_ms_avg"],
-                     "kernel_samples": timing["frames"], "timing": f"HIP events on the simulation stream, every {TIMING_PERIOD}th timed frame (rank 0)",
-                     "bytes_per_update": bpu, "hbm_gbs_whole_step": updates / n * bpu / elapsed / 1e9,
-                     "frac_of_aggregate_peak_whole_step": updates * bpu / elapsed / 1e9 / (HBM_PEAK_GBS * n)},
+        "config": {"workload": cfg["workload"].format(cap=w.per_inst_cap, inst=len(w.fxs)), "name": name, "capacity_per_gpu": w.local_particles,
+                   "instances_per_gpu": len(w.fxs), "dt": w.dt, "sharding": w.sharding_desc, "alive_before": alive0_total, "alive_after": alive1_total,
+                   "updates_per_frame": per_frame_total, "spawns_per_frame": spawned},
+        "windows": {"n": windows, "steps_each": steps, "ms_per_step": [s / steps * 1e3 for s in window_s], "median_ms_per_step": med / steps * 1e3,
+                    "min_ms_per_step": min(window_s) / steps * 1e3, "value_best_window": updates / min(window_s),
+                    "timed_region_s": sum(window_s)},
+        "stages": {"init_ms_avg": timing["init_ms_avg"], "update_ms_avg": k_ms, "lists_ms_avg": timing["compact_ms_avg"],
+                   "sum_ms": timing["init_ms_avg"] + k_ms + timing["compact_ms_avg"], "samples": timing["frames"],
+                   "timing": f"HIP events on the simulation stream, every {TIMING_PERIOD if name != 'c2_dieoff' else 1}th timed frame (rank 0); lists = count + compact (+ ribbon sort, + event ordering)"},
+        "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": cfg["kernel"], "kernel_ms_avg": k_ms,
+                     "updates_per_launch": per_frame_local,
+                     "algorithmic": {"bytes_per_update": bpu, "gbs_kernel": per_frame_local * bpu / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
+                                     "gbs_whole_step": updates / n * bpu / med / 1e9,
+                                     "whole_step_over_peak": updates * bpu / med / 1e9 / (HBM_PEAK_GBS * n),
+                                     "note": "SURVEY.md §8(d) bytes x updates / time: what the work is worth, not what was moved (above the moved figure wherever the design elides traffic)"}},
         "kernels": kinfo,
     }
-    if init_ms > 0 and name != "c5":  # the burst frame's init kernel (not part of the metric)
+    if init_ms > 0 and name not in ("c5", "c2_mixed"):  # the burst frame's init kernel (not part of the metric)
         bps = cfg["bytes_per_spawn"]
-        out["init"] = {"kernel": "k_init", "kernel_ms": init_ms, "spawned": local_particles, "bytes_per_spawn": bps,
-                       "achieved_gbs": local_particles * bps / (init_ms * 1e-3) / 1e9, "frac": local_particles * bps / (init_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        out["init"] = {"kernel": "k_init", "kernel_ms": init_ms, "spawned": w.local_particles, "bytes_per_spawn": bps,
+                       "achieved_gbs": w.local_particles * bps / (init_ms * 1e-3) / 1e9, "frac": w.local_particles * bps / (init_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# HBM traffic: counter passes of this script under rocprofv3
+# ------------------------------------------------------------------------------------------------------------------
+def pmc_child(args, D):
+    """`bench.py --pmc-child`: the configurations, a few steady frames each between two marker kernels. Run under rocprofv3 --pmc."""
+    names = args.pmc_configs.split(",")
+    info = {}
+    for i, name in enumerate(names):
+        sub = argparse.Namespace(**vars(args))
+        sub.capacity = args.capacity if name == args.config else None
+        info[name] = run_config(name, sub, D, pmc={"begin": 100 + 2 * i, "end": 101 + 2 * i})
+        info[name]["begin"], info[name]["end"] = 100 + 2 * i, 101 + 2 * i
+    print("PMCINFO " + json.dumps(info), flush=True)
+
+
+def parse_counter_csv(path, counter, info):
+    """-> {config: {"dominant_kib": median per launch, "frame_kib": all kernels per frame, "per_kernel_kib": {...}}}"""
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") == counter:
+                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["Grid_Size"]), float(r["Counter_Value"])))
+    rows.sort()
+    out = {}
+    for name, meta in info.items():
+        inside, sect = False, []
+        for _id, kname, grid, val in rows:
+            if "k_marker" in kname:
+                if grid == meta["begin"]:
+                    inside = True
+                elif grid == meta["end"]:
+                    inside = False
+                continue
+            if inside:
+                sect.append((kname, val))
+        if not sect:
+            continue
+        per = {}
+        for kname, val in sect:
+            short = kname.split("(")[0].replace("void ", "").replace("hnb::", "")
+            per.setdefault(short, []).append(val)
+        dom = [v for k, vs in per.items() if any(m in k for m in KERNEL_MATCH[name]) for v in vs]
+        out[name] = {"dominant_kib": statistics.median(dom) if dom else None, "frame_kib": sum(v for _k, v in sect) / meta["frames"],
+                     "per_kernel_kib": {k[:120]: {"median": statistics.median(vs), "launches_per_frame": len(vs) / meta["frames"]} for k, vs in per.items()}}
+    return out
+
+
+def measure_traffic(args, names):
+    """Two rocprofv3 counter passes of this script (FETCH_SIZE and WRITE_SIZE cannot share a pass). Returns
+    {config: {bytes_per_launch, frame_bytes, ...}} or raises."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="hnb_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            outdir = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", outdir, "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--pmc-configs", ",".join(names), "--config", args.config]
+            if args.capacity:
+                cmd += ["--capacity", str(args.capacity)]
+            if args.instances:
+                cmd += ["--instances", str(args.instances)]
+            env = dict(os.environ)
+            env["TMPDIR"] = "/tmp"
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=args.pmc_timeout, cwd="/tmp", env=env)
+            line = next((ln for ln in p.stdout.splitlines() if ln.startswith("PMCINFO ")), None)
+            if p.returncode != 0 or line is None:
+                raise RuntimeError(f"counter pass {counter} failed (rc {p.returncode}): {(p.stderr or p.stdout)[-300:]}")
+            info = json.loads(line[len("PMCINFO "):])
+            files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                raise RuntimeError(f"counter pass {counter}: no counter_collection.csv")
+            res[counter] = parse_counter_csv(files[0], counter, info)
+            if args.keep_pmc:
+                os.makedirs(args.keep_pmc, exist_ok=True)
+                keep = os.path.join(args.keep_pmc, f"pmc_{counter}.csv")
+                with open(files[0]) as fi, open(keep, "w") as fo:   # only the library's kernels, names shortened
+                    rd = csv.DictReader(fi)
+                    cols = ["Dispatch_Id", "Grid_Size", "Workgroup_Size", "VGPR_Count", "Kernel_Name", "Counter_Name", "Counter_Value"]
+                    wr = csv.DictWriter(fo, fieldnames=cols)
+                    wr.writeheader()
+                    for r in rd:
+                        if r.get("Counter_Name") == counter and ("hnb::" in r["Kernel_Name"] or "k_marker" in r["Kernel_Name"]):
+                            r = {c: r.get(c, "") for c in cols}
+                            r["Kernel_Name"] = r["Kernel_Name"].split("(")[0][:140]
+                            wr.writerow(r)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for name in names:
+        f, wv = res["FETCH_SIZE"].get(name), res["WRITE_SIZE"].get(name)
+        if not f or not wv or f["dominant_kib"] is None or wv["dominant_kib"] is None:
+            continue
+        out[name] = {"bytes_per_launch": f["dominant_kib"] * 1024 * 2 + wv["dominant_kib"] * 1024,
+                     "fetch_size_kib": f["dominant_kib"], "write_size_kib": wv["dominant_kib"],
+                     "frame_bytes": f["frame_kib"] * 1024 * 2 + wv["frame_kib"] * 1024,
+                     "per_kernel": {k: {"fetch_kib": v["median"], "write_kib": wv["per_kernel_kib"].get(k, {}).get("median"), "launches_per_frame": v["launches_per_frame"]}
+                                    for k, v in f["per_kernel_kib"].items()}}
+    return out
+
+
+def attach_roofline(result, name, traffic, source):
+    """Completes result['roofline'] from the measured (or recorded, or modelled) traffic of the dominant kernel."""
+    r = result["roofline"]
+    k_ms, n_upd = r["kernel_ms_avg"], r["updates_per_launch"]
+    if traffic is not None:
+        b = traffic["bytes_per_launch"]
+        r["traffic"] = b
+        r["traffic_detail"] = {"fetch_size_kib": traffic["fetch_size_kib"], "write_size_kib": traffic["write_size_kib"],
+                               "formula": "FETCH_SIZE KiB x 1024 x 2 (gfx950) + WRITE_SIZE KiB x 1024, median launch of the dominant kernel; counters sit between L2 and the fabric (Infinity-Cache hits included)",
+                               "whole_frame_bytes": traffic.get("frame_bytes"), "per_kernel": traffic.get("per_kernel")}
+    else:
+        b = CONFIGS[name]["model_bytes"] * n_upd
+        r["traffic"] = None
+    r["traffic_unit"], r["traffic_source"] = "B/launch", source
+    r["moved_bytes_per_update"] = b / n_upd if n_upd else None
+    r["achieved"] = b / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    r["frac"] = r["achieved"] / HBM_PEAK_GBS
+    r["algorithmic"]["ratio_moved_to_algorithmic"] = (b / n_upd) / CONFIGS[name]["bytes_per_update"] if n_upd else None
+    if traffic is not None and traffic.get("frame_bytes"):
+        r["whole_step"] = {"moved_bytes": traffic["frame_bytes"], "gbs": traffic["frame_bytes"] / (result["ms_per_step"] * 1e-3) / 1e9,
+                           "frac": traffic["frame_bytes"] / (result["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "note": "all kernels of a frame (PMC) / the driver-timed step"}
+
+
+def load_recorded_traffic(stamp):
+    """profiles/traffic.json, only if it was recorded from this kernel build."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None, "no profiles/traffic.json"
+    if t.get("kernel_source_stamp") != stamp:
+        return None, f"profiles/traffic.json is stale (recorded for kernel sources {t.get('kernel_source_stamp')}, this tree is {stamp})"
+    return t.get("configs", {}), f"profiles/traffic.json (recorded at {t.get('head')}, kernel sources {stamp})"
 
 
 def self_launch(args):
@@ -367,13 +679,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps frames each; the line reports the median window")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both")
     ap.add_argument("--capacity", type=int, default=None, help="particles per effect instance (default: the configuration's)")
     ap.add_argument("--instances", type=int, default=None, help="c4: instances per GPU (weak) / in total (strong); default 512")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scene", action="store_true", help="N = 1: append the small-effects scene (26 example effects in one context) as \"small_effects_scene\"")
-    ap.add_argument("--no-extra-configs", action="store_true", help="N = 1, c2: do not append the c3/c4/c5 lines under \"configs\"")
+    ap.add_argument("--no-extra-configs", action="store_true", help="N = 1, c2: do not append the other configurations under \"configs\"")
+    ap.add_argument("--pmc", choices=["auto", "off"], default="auto", help="auto: measure HBM traffic in this run (two rocprofv3 counter passes of this script)")
+    ap.add_argument("--pmc-timeout", type=int, default=420)
+    ap.add_argument("--keep-pmc", default=None, help="directory: keep the filtered counter CSVs of the two passes (profiles/)")
+    ap.add_argument("--write-traffic", action="store_true", help="record the measured traffic in profiles/traffic.json (stamped with HEAD and the kernel sources)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-configs", default="c2", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--force-device", type=int, default=None, help="dry runs: every rank uses this GPU instead of LOCAL_RANK")
     args = ap.parse_args()
@@ -382,6 +701,9 @@ def main():
         sys.exit(self_launch(args))
 
     D = Dist(args)
+    if args.pmc_child:
+        pmc_child(args, D)
+        return
     if args.gpus != D.world and D.rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={D.world}", file=sys.stderr)
 
@@ -396,21 +718,48 @@ def main():
             else:
                 out["strong"] = {"value": s["value"], "ms_per_step": s["ms_per_step"], "capacity_per_gpu": s["config"]["capacity_per_gpu"],
                                  "instances_per_gpu": s["config"]["instances_per_gpu"], "kernel_ms_avg": s["roofline"]["kernel_ms_avg"],
-                                 "roofline_frac": s["roofline"]["frac"], "frac_of_aggregate_peak_whole_step": s["roofline"]["frac_of_aggregate_peak_whole_step"],
+                                 "algorithmic_whole_step_over_aggregate_peak": s["roofline"]["algorithmic"]["whole_step_over_peak"],
                                  "workload": "the N = 1 workload split over the ranks"}
+    results = {args.config: out}
     if not D.on and args.config == "c2" and not args.no_extra_configs:
-        # the other single-GPU configurations of BASELINE.json, same process, short runs: kernel time + roofline each
-        extra = {}
-        for name in ("c3", "c4", "c5"):
+        # the other single-GPU configurations, same process, same window protocol
+        for name in EXTRA_CONFIGS:
             sub = argparse.Namespace(**vars(args))
-            sub.capacity, sub.steps, sub.warmup = None, min(args.steps, 30), min(args.warmup, 5)
+            sub.capacity = None
             try:
-                r = run_config(name, sub, D)
-                extra[name] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
-                               "updates_per_frame": r["config"]["updates_per_frame"], "roofline": r["roofline"], "init": r.get("init"), "kernels": r["kernels"]}
+                results[name] = run_config(name, sub, D)
             except Exception as e:  # the headline line must not be lost to a side configuration
-                extra[name] = {"error": f"{type(e).__name__}: {e}"}
-        out["configs"] = extra
+                results[name] = {"error": f"{type(e).__name__}: {e}"}
+    if D.rank == 0:
+        # ---- HBM traffic of the dominant kernels: measured now, else recorded for this kernel build, else modelled
+        stamp = kernel_source_stamp()
+        names = [k for k, v in results.items() if v and "error" not in v]
+        measured, why = None, ("--pmc off" if args.pmc == "off" else "N > 1: counter passes are a single-GPU measurement")
+        if not D.on and args.pmc == "auto":
+            try:
+                t0 = time.perf_counter()
+                measured = measure_traffic(args, names)
+                why = f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script ({time.perf_counter() - t0:.0f} s), kernel sources {stamp}"
+            except Exception as e:
+                why = f"{type(e).__name__}: {e}"
+        recorded, rec_src = (None, None) if measured else load_recorded_traffic(stamp)
+        for name in names:
+            if measured and name in measured:
+                attach_roofline(results[name], name, measured[name], why)
+            elif recorded and name in recorded:
+                attach_roofline(results[name], name, recorded[name], rec_src)
+            else:
+                attach_roofline(results[name], name, None, f"model: {CONFIGS[name]['model_bytes']} B per update by design (no counter pass: {why}; {rec_src or ''})")
+        if measured and args.write_traffic:
+            with open(TRAFFIC_FILE, "w") as f:
+                json.dump({"kernel_source_stamp": stamp, "head": git_head(), "configs": measured}, f, indent=1)
+        out = results[args.config]
+        out["build"] = {"head": git_head(), "kernel_source_stamp": stamp}
+        extra = {k: v for k, v in results.items() if k != args.config}
+        if extra:
+            out["configs"] = {k: (v if "error" in v else {kk: v[kk] for kk in ("value", "ms_per_step", "windows", "stages", "roofline", "init", "kernels") if kk in v}
+                                  | {"workload": v["config"]["workload"], "updates_per_frame": v["config"]["updates_per_frame"], "spawns_per_frame": v["config"]["spawns_per_frame"]})
+                              for k, v in extra.items()}
     if not D.on and args.scene:
         # the launch-bound end of the path: 26 different small effects in one context (tools/scene_bench.py, profiles/r02u_scene.md). Opt-in: the
         # small effects share kernel instantiations with the headline workload, and the default command's rocprofv3 statistics are

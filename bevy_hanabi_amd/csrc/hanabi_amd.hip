@@ -1803,6 +1803,15 @@ int hnb_jit_precompile(const void* blob, size_t blob_size) {
     return HNB_OK;
 }
 
+__global__ void k_marker(uint32_t) {}
+int hnb_ctx_profile_marker(HnbContext* ctx, uint32_t tag) {
+    if (!ctx || tag == 0u || tag > 65535u) return fail(HNB_ERR_INVALID_ARG, "marker tag must be in 1..65535");
+    HIP_TRY(hipSetDevice(ctx->device));
+    k_marker<<<tag, 1, 0, ctx->stream>>>(tag);
+    HIP_TRY(hipGetLastError());
+    return HNB_OK;
+}
+
 int hnb_ctx_enable_kernel_timing(HnbContext* ctx, int enable) {
     if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "hnb_effect_metadata", "hnb_effect_alive_count", "hnb_effect_read_attr", "hnb_effect_read_alive_list",
     "hnb_effect_read_dead_list", "hnb_effect_write_attr", "hnb_effect_sort_ribbons", "hnb_ctx_enable_kernel_timing",
     "hnb_ctx_kernel_timing", "hnb_program_kernel_info", "hnb_jit_precompile", "hnb_effect_set_simulated", "hnb_ctx_set_option", "hnb_program_set_frames", "hnb_effect_index",
+    "hnb_ctx_profile_marker",
 ]
 
 
@@ -88,6 +89,7 @@ def load_library():
         lib.hnb_ctx_set_option.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         lib.hnb_program_set_frames.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.hnb_effect_index.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        lib.hnb_ctx_profile_marker.argtypes = [C.c_void_p, C.c_uint32]
         lib.hnb_program_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         lib.hnb_jit_precompile.argtypes = [C.c_char_p, C.c_size_t]
         _lib = lib
@@ -161,6 +163,10 @@ class Context:
     def enable_kernel_timing(self, every_n_frames=1):
         """0/False = off; n = bracket the kernels of every n-th simulated frame with HIP events."""
         _check(self._lib.hnb_ctx_enable_kernel_timing(self._h, int(every_n_frames)))
+
+    def profile_marker(self, tag):
+        """An empty kernel with `tag` workgroups on the simulation stream: a visible cut in rocprofv3's dispatch list."""
+        _check(self._lib.hnb_ctx_profile_marker(self._h, int(tag)))
 
     def kernel_timing(self):
         u, c, i, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint32()

@@ -163,7 +163,8 @@ def test_two_rank_instance_sharding_equals_single_process():
 
 
 def test_bench_helpers_agree_with_the_oracle_and_the_profiles():
-    """bench.py restates the PCG hash for its seed lists and reads roofline.traffic from the committed PMC summary."""
+    """bench.py restates the PCG hash for its seed lists; its roofline fraction is built from MOVED bytes (a counter pass of the same run,
+    or the committed record if - and only if - it was taken from this very kernel build), never from the algorithmic 68 B."""
     import json
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -173,11 +174,23 @@ def test_bench_helpers_agree_with_the_oracle_and_the_profiles():
     for f in (0, 1, 7, 1000, 123456):
         assert bench.frame_seed(f) == oracle.pcg_hash(0xC0FFEE + f)
         assert bench.instance_seed(f, 0) == bench.frame_seed(f) and bench.instance_seed(f, 5) != bench.frame_seed(f)
-    assert set(bench.CONFIGS) == {"c2", "c3", "c4", "c5"} and bench.CONFIGS["c2"]["capacity"] == 16_777_216 and bench.CONFIGS["c2"]["bytes_per_update"] == 68
+    assert {"c2", "c2_mixed", "c2_dieoff", "c2_interop", "c3", "c4", "c5"} == set(bench.CONFIGS)
+    assert bench.CONFIGS["c2"]["capacity"] == 16_777_216 and bench.CONFIGS["c2"]["bytes_per_update"] == 68
     assert bench.CONFIGS["c3"]["capacity"] == 8_388_608 and bench.CONFIGS["c5"]["capacity"] == 4_194_304 and bench.CONFIGS["c4"]["instances"] * 8 == 4096
-    traffic, source = bench.load_traffic("c2", 1 << 24, 1)
-    table = json.load(open(os.path.join(root, "profiles", "traffic.json")))
-    assert traffic == table["c2:16777216x1"]["bytes_per_launch"] and 40 * (1 << 24) < traffic < 68 * (1 << 24)   # less than the algorithmic 68 B per update
-    assert os.path.exists(os.path.join(root, source.split(" + ")[0]))                                               # the CSV the number comes from is committed
-    assert bench.load_traffic("c2", 12345, 1) == (None, None)
     assert bench.frame_dt(36) == bench.DT and bench.frame_dt(10_000) * 10_000 < bench.MIN_LIFETIME
+    # a recorded traffic table is only accepted for the kernel sources it was measured on
+    stamp = bench.kernel_source_stamp()
+    assert len(stamp) == 16 and bench.load_recorded_traffic("0" * 16)[0] is None
+    table = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    rec, src = bench.load_recorded_traffic(table["kernel_source_stamp"])
+    assert rec == table["configs"] and table["kernel_source_stamp"] in src
+    # the fraction: moved bytes / kernel time / 8 TB/s; the 68 B figure only ever appears under "algorithmic"
+    n = 1 << 24
+    res = {"ms_per_step": 0.14, "roofline": {"kernel_ms_avg": 0.13, "updates_per_launch": float(n), "algorithmic": {}}}
+    bench.attach_roofline(res, "c2", {"bytes_per_launch": 48.0 * n, "fetch_size_kib": 1.0, "write_size_kib": 1.0, "frame_bytes": 49.0 * n}, "unit test")
+    r = res["roofline"]
+    assert abs(r["achieved"] - 48.0 * n / 0.13e-3 / 1e9) < 1e-6 and r["frac"] == r["achieved"] / 8000.0 and r["frac"] < 1.0
+    assert abs(r["algorithmic"]["ratio_moved_to_algorithmic"] - 48 / 68) < 1e-12 and r["whole_step"]["frac"] < 1.0
+    res = {"ms_per_step": 0.14, "roofline": {"kernel_ms_avg": 0.13, "updates_per_launch": float(n), "algorithmic": {}}}
+    bench.attach_roofline(res, "c2", None, "model")
+    assert res["roofline"]["traffic"] is None and res["roofline"]["moved_bytes_per_update"] == bench.CONFIGS["c2"]["model_bytes"] and res["roofline"]["frac"] < 1.0
