@@ -674,6 +674,49 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def threads_launch(args):
+    """`--launcher threads`: the single-process host (examples/multi_gpu.c): N contexts, N submit threads, capacity-slab sharding of one giant
+    effect, alive counters all-reduced through hnb_comm_* (RCCL). Python only lowers the asset and relays the C program's numbers."""
+    import bevy_hanabi_amd as bh
+    from bevy_hanabi_amd import build as hb
+    from bevy_hanabi_amd import effects
+
+    if args.config not in ("c2", "c3"):
+        print("--launcher threads shards ONE burst effect by capacity slab: --config c2 or c3", file=sys.stderr)
+        return 2
+    cfg = CONFIGS[args.config]
+    cap = args.capacity or cfg["capacity"]
+    n = args.gpus
+    exe = hb.build_examples()
+    asset = effects.firework_trails(cap) if args.config == "c2" else effects.force_field(cap)
+    windows = max(1, args.windows)
+    dt = frame_dt(1 + args.warmup + args.steps * windows) if args.config == "c2" else DT
+    devices = ",".join(str(args.force_device if args.force_device is not None else g) for g in range(n))
+    with tempfile.NamedTemporaryFile(suffix=".blob", delete=False) as f:
+        f.write(bh.lower(asset))
+        blob = f.name
+    try:
+        p = subprocess.run([exe, blob, devices, str(args.warmup), str(args.steps), str(windows), repr(dt)], capture_output=True, text=True, timeout=900)
+    finally:
+        os.unlink(blob)
+    if p.returncode != 0:
+        print(p.stderr, file=sys.stderr)
+        return p.returncode
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    bpu = cfg["bytes_per_update"]
+    out = {"metric": "particle-updates/sec", "value": r["updates_per_s"], "unit": "particle-updates/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": cfg["workload"].format(cap=cap, inst=1), "name": args.config, "capacity_per_gpu": cap, "dt": dt, "sharding": f"capacity slab x{n}",
+                      "alive_after": r["alive_total"], "devices": r["devices"]},
+           "launcher": "threads: one process, one HnbContext + one submit thread per GPU (examples/multi_gpu.c, C99 over include/hanabi_amd.h); alive counters all-reduced by hnb_comm_allreduce_alive (RCCL)",
+           "windows": {"n": windows, "steps_each": args.steps, "ms_per_step": r["window_ms_per_step"], "median_ms_per_step": r["ms_per_step"], "min_ms_per_step": r["min_ms_per_step"]},
+           "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS * n, "unit": "GB/s", "traffic": None, "traffic_source": "not collected by this launcher (see the N = 1 line)",
+                        "algorithmic": {"bytes_per_update": bpu, "gbs_whole_step": r["updates_per_s"] * bpu / 1e9, "whole_step_over_peak": r["updates_per_s"] * bpu / 1e9 / (HBM_PEAK_GBS * n)}},
+           "build": {"head": git_head(), "kernel_source_stamp": kernel_source_stamp()}}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -693,10 +736,15 @@ def main():
     ap.add_argument("--write-traffic", action="store_true", help="record the measured traffic in profiles/traffic.json (stamped with HEAD and the kernel sources)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-configs", default="c2", help=argparse.SUPPRESS)
+    ap.add_argument("--launcher", choices=["ranks", "threads"], default="ranks",
+                    help="N > 1: ranks = one process per GPU (torch.distributed.run, RCCL through torch); threads = ONE process, one HnbContext and one "
+                         "submit thread per GPU (examples/multi_gpu.c: C99 over the C ABI, RCCL through hnb_comm_*), c2 / c3 only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--force-device", type=int, default=None, help="dry runs: every rank uses this GPU instead of LOCAL_RANK")
     args = ap.parse_args()
 
+    if args.launcher == "threads" and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        sys.exit(threads_launch(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 

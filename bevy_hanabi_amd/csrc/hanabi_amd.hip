@@ -19,6 +19,7 @@
 #include "hnb_kernels.hip.h"
 #include "hnb_jit.h"
 #include "hnb_sort.hip.h"
+#include "hnb_comm.h"
 
 using namespace hnb;
 
@@ -119,7 +120,6 @@ struct HnbContext {
     uint32_t list_order = HNB_LIST_ORDER_SPAWN;  // applied to programs created afterwards
     bool skip_lists = true;     // skip the list kernels of frames the device's no-death bound covers (HNB_SKIP_LISTS=0 turns it off)
     bool alternate = true;      // walk the chunks in alternating directions from frame to frame (HNB_ALTERNATE=0 turns it off)
-    uint32_t count_load = 0;    // development: CompactArgs::gather_mode (HNB_COUNT_LOAD)
     bool transpose = true;      // vec3 planes of the per-particle update path through the wave's LDS transpose (HNB_TRANSPOSE=0 turns it off)
     uint32_t timing = 0;        // 0 = off, n = time every n-th simulated frame
     uint32_t timing_tick = 0;
@@ -239,6 +239,15 @@ struct HnbEffect {
     uint32_t seed = 0;
     float xf[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     std::vector<uint32_t> props;
+};
+
+struct HnbComm {
+    std::vector<HnbContext*> ctxs;               // the local contexts (one in rank mode)
+    std::vector<comm::ncclComm_t> comms;         // one RCCL communicator per local context; empty: reduced through the host
+    uint32_t n_ranks = 1, rank = 0;
+    uint32_t scratch_cap = 0;                    // effects the device scratch below holds
+    std::vector<uint64_t*> d_rows;               // per local context: DevMeta row addresses of the effects to report
+    std::vector<unsigned long long*> d_counts, d_totals;
 };
 
 namespace {
@@ -754,7 +763,6 @@ int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
     if (const char* e = getenv("HNB_ALTERNATE")) ctx->alternate = e[0] != '0';
     if (const char* e = getenv("HNB_TRANSPOSE")) ctx->transpose = e[0] != '0';
     if (const char* e = getenv("HNB_SKIP_LISTS")) ctx->skip_lists = e[0] != '0';
-    if (const char* e = getenv("HNB_COUNT_LOAD")) ctx->count_load = (uint32_t)atoi(e);
     *out_ctx = ctx;
     return HNB_OK;
 }
@@ -1285,7 +1293,6 @@ static CompactArgs compact_args_of(const HnbProgram* p) {
     ca.alive_off[0] = p->dev.alive_off[0]; ca.alive_off[1] = p->dev.alive_off[1]; ca.dead_off = p->dev.dead_off;
     ca.alive_flag_off = p->dev.alive_flag_off;
     ca.died_bits_off = p->dev.died_bits_off; ca.row_mask_off = p->dev.row_mask_off;
-    ca.gather_mode = p->ctx->count_load;
     ca.slot_order = p->slot_order ? 1u : 0u;
     ca.rotate_front = p->frame_rotate ? 1u : 0u;   // k_compact writes the survivors [spawns | older ones]: see CompactArgs (ribbon programs never have slot-ordered lists)
     return ca;
@@ -1800,6 +1807,131 @@ int hnb_jit_precompile(const void* blob, size_t blob_size) {
     if (!rq.want_init && !rq.want_update_generic && !rq.want_update_stream) return HNB_OK;
     jit::Result res;
     if (!jit::build(rq, res)) return fail(HNB_ERR_BAD_PROGRAM, "kernel specialisation failed: %s", res.log.c_str());
+    return HNB_OK;
+}
+
+// ---- multi-GPU reporting (hnb_comm.h) ----------------------------------------------------------------------------------
+int hnb_comm_unique_id(void* out_id) {
+    if (!out_id) return fail(HNB_ERR_INVALID_ARG, "out_id is NULL");
+    comm::Api& a = comm::api();
+    if (!a.ok) return fail(HNB_ERR_NOT_FOUND, "RCCL is not available: %s", a.why.c_str());
+    comm::ncclUniqueId id;
+    const int rc = a.GetUniqueId(&id);
+    if (rc != comm::kNcclSuccess) return fail(HNB_ERR_HIP, "ncclGetUniqueId failed: %s", a.GetErrorString(rc));
+    memcpy(out_id, id.internal, HNB_COMM_ID_BYTES);
+    return HNB_OK;
+}
+
+int hnb_comm_create_local(HnbContext* const* ctxs, uint32_t n_ctx, HnbComm** out_comm) {
+    if (!ctxs || !n_ctx || !out_comm) return fail(HNB_ERR_INVALID_ARG, "NULL / empty argument");
+    std::vector<int> devs;
+    bool distinct = true;
+    for (uint32_t i = 0; i < n_ctx; ++i) {
+        if (!ctxs[i]) return fail(HNB_ERR_INVALID_ARG, "context #%u is NULL", i);
+        for (int d : devs) distinct = distinct && d != ctxs[i]->device;
+        devs.push_back(ctxs[i]->device);
+    }
+    HnbComm* c = new HnbComm();
+    c->ctxs.assign(ctxs, ctxs + n_ctx);
+    c->n_ranks = n_ctx;
+    if (n_ctx > 1 && distinct) {   // one communicator per device (RCCL refuses a device twice: contexts sharing one are reduced through the host)
+        comm::Api& a = comm::api();
+        if (!a.ok) { delete c; return fail(HNB_ERR_NOT_FOUND, "RCCL is not available: %s", a.why.c_str()); }
+        c->comms.resize(n_ctx);
+        const int rc = a.CommInitAll(c->comms.data(), (int)n_ctx, devs.data());
+        if (rc != comm::kNcclSuccess) { delete c; return fail(HNB_ERR_HIP, "ncclCommInitAll failed: %s", a.GetErrorString(rc)); }
+    }
+    *out_comm = c;
+    return HNB_OK;
+}
+
+int hnb_comm_create_rank(HnbContext* ctx, const void* id, uint32_t rank, uint32_t n_ranks, HnbComm** out_comm) {
+    if (!ctx || !id || !out_comm || !n_ranks || rank >= n_ranks) return fail(HNB_ERR_INVALID_ARG, "bad argument");
+    HnbComm* c = new HnbComm();
+    c->ctxs.push_back(ctx);
+    c->n_ranks = n_ranks; c->rank = rank;
+    if (n_ranks > 1) {
+        comm::Api& a = comm::api();
+        if (!a.ok) { delete c; return fail(HNB_ERR_NOT_FOUND, "RCCL is not available: %s", a.why.c_str()); }
+        HIP_TRY(hipSetDevice(ctx->device));
+        comm::ncclUniqueId uid;
+        memcpy(uid.internal, id, HNB_COMM_ID_BYTES);
+        c->comms.resize(1);
+        const int rc = a.CommInitRank(&c->comms[0], (int)n_ranks, uid, (int)rank);
+        if (rc != comm::kNcclSuccess) { delete c; return fail(HNB_ERR_HIP, "ncclCommInitRank failed: %s", a.GetErrorString(rc)); }
+    }
+    *out_comm = c;
+    return HNB_OK;
+}
+
+int hnb_comm_destroy(HnbComm* c) {
+    if (!c) return HNB_OK;
+    for (size_t i = 0; i < c->ctxs.size(); ++i) {
+        hipSetDevice(c->ctxs[i]->device);
+        hipStreamSynchronize(c->ctxs[i]->stream);
+        if (i < c->comms.size() && c->comms[i]) comm::api().CommDestroy(c->comms[i]);
+        if (i < c->d_rows.size()) { hipFree(c->d_rows[i]); hipFree(c->d_counts[i]); hipFree(c->d_totals[i]); }
+    }
+    delete c;
+    return HNB_OK;
+}
+
+// out_totals[e] = sum over every context of every rank of the alive count of its e-th effect. `effects` is context-major,
+// [local context][n_effects]; a NULL entry counts as 0 (a rank that holds no shard of that effect).
+int hnb_comm_allreduce_alive(HnbComm* c, HnbEffect* const* effects, uint32_t n_effects, uint64_t* out_totals) {
+    if (!c || !effects || !n_effects || !out_totals) return fail(HNB_ERR_INVALID_ARG, "NULL / empty argument");
+    const size_t nl = c->ctxs.size();
+    if (n_effects > c->scratch_cap) {
+        const uint32_t cap = std::max(n_effects, 2u * c->scratch_cap);
+        c->d_rows.resize(nl, nullptr); c->d_counts.resize(nl, nullptr); c->d_totals.resize(nl, nullptr);
+        for (size_t i = 0; i < nl; ++i) {
+            HIP_TRY(hipSetDevice(c->ctxs[i]->device));
+            HIP_TRY(hipStreamSynchronize(c->ctxs[i]->stream));
+            hipFree(c->d_rows[i]); hipFree(c->d_counts[i]); hipFree(c->d_totals[i]);
+            c->d_rows[i] = nullptr; c->d_counts[i] = c->d_totals[i] = nullptr;
+            HIP_TRY(hipMalloc(&c->d_rows[i], (size_t)cap * 8));
+            HIP_TRY(hipMalloc(&c->d_counts[i], (size_t)cap * 8));
+            HIP_TRY(hipMalloc(&c->d_totals[i], (size_t)cap * 8));
+        }
+        c->scratch_cap = cap;
+    }
+    std::vector<uint64_t> rows(n_effects);
+    for (size_t i = 0; i < nl; ++i) {
+        HnbContext* ctx = c->ctxs[i];
+        for (uint32_t e = 0; e < n_effects; ++e) {
+            HnbEffect* fx = effects[i * n_effects + e];
+            if (fx && fx->prog->ctx != ctx) return fail(HNB_ERR_INVALID_ARG, "effect #%u of context #%zu belongs to another context", e, i);
+            rows[e] = fx ? reinterpret_cast<uint64_t>(fx->prog->d_meta[fx->prog->parity] + fx->index) : 0ull;
+        }
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipMemcpyAsync(c->d_rows[i], rows.data(), (size_t)n_effects * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));   // (`rows` is reused for the next context; the copy is a few hundred bytes)
+        comm::k_gather_alive<<<(n_effects + 255u) / 256u, 256, 0, ctx->stream>>>(c->d_rows[i], c->d_counts[i], n_effects);
+        HIP_TRY(hipGetLastError());
+    }
+    std::vector<unsigned long long> host(n_effects);
+    if (!c->comms.empty()) {   // RCCL over xGMI: one all-reduce, n_effects x u64 (latency-bound: 8 B x #effects)
+        comm::Api& a = comm::api();
+        int rc = a.GroupStart();
+        for (size_t i = 0; i < nl && rc == comm::kNcclSuccess; ++i) {
+            hipSetDevice(c->ctxs[i]->device);
+            rc = a.AllReduce(c->d_counts[i], c->d_totals[i], n_effects, comm::kNcclUint64, comm::kNcclSum, c->comms[i], c->ctxs[i]->stream);
+        }
+        const int rc2 = a.GroupEnd();
+        if (rc != comm::kNcclSuccess || rc2 != comm::kNcclSuccess) return fail(HNB_ERR_HIP, "ncclAllReduce failed: %s", a.GetErrorString(rc != comm::kNcclSuccess ? rc : rc2));
+        for (size_t i = 0; i < nl; ++i) { HIP_TRY(hipSetDevice(c->ctxs[i]->device)); HIP_TRY(hipStreamSynchronize(c->ctxs[i]->stream)); }
+        HIP_TRY(hipSetDevice(c->ctxs[0]->device));
+        HIP_TRY(hipMemcpy(host.data(), c->d_totals[0], (size_t)n_effects * 8, hipMemcpyDeviceToHost));
+        for (uint32_t e = 0; e < n_effects; ++e) out_totals[e] = host[e];
+    } else {                   // contexts that share a device, or a single context: summed on the host
+        for (uint32_t e = 0; e < n_effects; ++e) out_totals[e] = 0;
+        for (size_t i = 0; i < nl; ++i) {
+            HIP_TRY(hipSetDevice(c->ctxs[i]->device));
+            HIP_TRY(hipStreamSynchronize(c->ctxs[i]->stream));
+            HIP_TRY(hipMemcpy(host.data(), c->d_counts[i], (size_t)n_effects * 8, hipMemcpyDeviceToHost));
+            for (uint32_t e = 0; e < n_effects; ++e) out_totals[e] += host[e];
+        }
+    }
     return HNB_OK;
 }
 

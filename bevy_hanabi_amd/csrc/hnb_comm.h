@@ -1,0 +1,69 @@
+// Multi-GPU reporting: the all-reduce of the alive-particle counters over RCCL (the ONLY collective of the
+// design - effects shard by instance / capacity slab with no inter-GPU dependency per frame).
+//
+// The reference's seam is one process (src/plugin.rs:202-256, src/render/mod.rs:126-131); the counterpart here is one process
+// with one HnbContext per GPU, each driven by its own submit thread (examples/multi_gpu.c), plus this communicator:
+//   hnb_comm_create_local   one process, n contexts           -> ncclCommInitAll over the contexts' devices
+//   hnb_comm_create_rank    one rank (context) per process    -> ncclCommInitRank with a shared ncclUniqueId
+// librccl is resolved at run time (dlopen): a single-GPU host does not need it, and a process that already loaded another copy
+// (PyTorch bundles one) keeps using that copy. RCCL refuses a communicator that names one device twice; contexts that share a
+// device (tests on a one-GPU box) are reduced through the host instead - same entry point, same result.
+#pragma once
+#include <dlfcn.h>
+
+namespace hnb {
+namespace comm {
+
+typedef struct ncclComm* ncclComm_t;
+struct ncclUniqueId { char internal[128]; };
+enum { kNcclSuccess = 0, kNcclUint64 = 5, kNcclSum = 0 };
+
+struct Api {
+    void* lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+inline Api& api() {
+    static Api a;
+    static bool tried = false;
+    if (tried) return a;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (a.lib) break;
+    }
+    if (!a.lib) { a.why = std::string("librccl not found: ") + dlerror(); return a; }
+#define HNB_SYM(field, name) *reinterpret_cast<void**>(&a.field) = dlsym(a.lib, name); if (!a.field) { a.why = std::string("librccl lacks ") + name; return a; }
+    HNB_SYM(GetUniqueId, "ncclGetUniqueId")
+    HNB_SYM(CommInitRank, "ncclCommInitRank")
+    HNB_SYM(CommInitAll, "ncclCommInitAll")
+    HNB_SYM(CommDestroy, "ncclCommDestroy")
+    HNB_SYM(AllReduce, "ncclAllReduce")
+    HNB_SYM(GroupStart, "ncclGroupStart")
+    HNB_SYM(GroupEnd, "ncclGroupEnd")
+    HNB_SYM(GetErrorString, "ncclGetErrorString")
+#undef HNB_SYM
+    a.ok = true;
+    return a;
+}
+
+// counts[i] = alive_count of the instance whose DevMeta row lives at rows[i] (0 for a null row)
+__global__ void k_gather_alive(const uint64_t* __restrict__ rows, unsigned long long* __restrict__ counts, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevMeta* m = reinterpret_cast<const DevMeta*>(rows[i]);
+    counts[i] = m ? (unsigned long long)m->alive_count : 0ull;
+}
+
+}  // namespace comm
+}  // namespace hnb

@@ -572,7 +572,6 @@ struct CompactArgs {
     uint32_t alive_off[2], dead_off;
     uint32_t alive_flag_off;   // u8[capacity]: 0 free, 1 alive
     uint32_t died_bits_off, row_mask_off;   // DevProgram: one bit per slot "died in this frame's update"; one bit per list row "survives"
-    uint32_t gather_mode;      // development (HNB_COUNT_LOAD): how k_count_rows loads the died bits: 0 plain, 1 nontemporal, 2 agent-scope atomic load
     uint32_t slot_order;       // HNB_LIST_ORDER_SLOT: k_order_write rebuilds the lists from the alive bytes
     uint32_t rotate_front;     // ribbon programs, host-proven (HnbProgram::sort_front_*): this frame's spawns sort in front of every older
                                // particle, so the survivors are written [spawns | older ones] and the list needs no sort afterwards
@@ -1247,11 +1246,7 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
         slot[s] = i < rows ? list[i] : 0xffffffffu;
     }
 #pragma unroll
-    for (uint32_t s = 0; s < kSteps; ++s) {
-        const uint32_t* w = died + (slot[s] >> 5);
-        bits[s] = 0xffffffffu;
-        if (slot[s] != 0xffffffffu) bits[s] = args.gather_mode == 1u ? __builtin_nontemporal_load(w) : (args.gather_mode == 2u ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *w);
-    }
+    for (uint32_t s = 0; s < kSteps; ++s) bits[s] = slot[s] != 0xffffffffu ? died[slot[s] >> 5] : 0xffffffffu;   // (nontemporal loads: 1.8x slower; agent-scope atomic loads: the same, profiles/r03c_count_load.log)
     uint32_t wa = 0;
 #pragma unroll
     for (uint32_t s = 0; s < kSteps; ++s) {

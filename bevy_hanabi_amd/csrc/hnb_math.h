@@ -77,14 +77,30 @@ HNB_HD float f_inv_sqrt(float x) { return 1.0f / f_sqrt(x); }
 // Every step is ONE correctly rounded IEEE-754 binary64 operation - + - * / or a fused multiply-add (v_fma_f64 on gfx950, vfmadd
 // or the C library's exact fma() on the host: the same result everywhere, which -ffp-contract=off alone cannot promise for an
 // a * b + c the compiler is free to fuse or not) - on minimax polynomials (tools/gen_math_coeffs.py derives the coefficients and
-// prints their error): approximation errors are below 2^-47 relative, far inside the final rounding to binary32.
+// prints their error; tools/gen_math_kernels.py writes this section): approximation errors are below 2^-47 relative, far inside
+// the final rounding to binary32. Branch-free where both sides of a branch would run in a wave anyway.
 HNB_HD double d_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-// Round to nearest integer (ties to even) with two IEEE additions; valid |x| < 2^51.
-HNB_HD double d_rint(double x) {
+// p * z + c with a LITERAL c: the same fma. On the device it is spelled out so that the coefficient travels in an SGPR pair
+// (v_fma_f64 v, v, v, s): the compiler's own choice, v_fmac_f64, first moves every coefficient into the destination VGPR pair -
+// two more VALU instructions per Horner step, a third of the VALU work of a sphere-shaped spawn.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double d_fma_c(double p, double z, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(c));
+    return r;
+}
+#else
+HNB_HD double d_fma_c(double p, double z, double c) { return __builtin_fma(p, z, c); }
+#endif
+// Round to nearest integer (ties to even) with two IEEE additions; valid |x| < 2^51. *low32: that integer modulo 2^32 (the low
+// mantissa bits of the biased sum), without a float -> int conversion.
+HNB_HD double d_rint_bits(double x, uint32_t* low32) {
     const double magic = 6755399441055744.0;  // 1.5 * 2^52
     double t = x + magic;  // never folded: built without fast-math / reassociation
+    *low32 = (uint32_t)d2u(t);
     return t - magic;
 }
+HNB_HD double d_rint(double x) { uint32_t lo; return d_rint_bits(x, &lo); }
 
 // sin and cos of a finite double with |x| <= 2^40.
 HNB_HD void d_sincos(double x, double* s_out, double* c_out) {
@@ -92,57 +108,56 @@ HNB_HD void d_sincos(double x, double* s_out, double* c_out) {
     const double p1 = 1.57079632673412561417e+00;  // first 33 bits of pi/2
     const double p2 = 6.07710050630396597660e-11;  // next 33 bits
     const double p3 = 2.02226624879595063154e-21;  // remainder
-    const double k = d_rint(x * two_over_pi);
+    uint32_t q;
+    const double k = d_rint_bits(x * two_over_pi, &q);
     double r = d_fma(-k, p1, x);
     r = d_fma(-k, p2, r);
     r = d_fma(-k, p3, r);
-    const long long q = (long long)k;
     const double z = r * r;
     // |r| <= pi/4 (+ slack): sin r = r + r z S(z) (relative error 2^-55), cos r = 1 - z/2 + z^2 C(z) (2^-49)
     double ps = 0x1.5e0ae6796256cp-33;
-    ps = d_fma(ps, z, -0x1.ae600a73bc9bcp-26);
-    ps = d_fma(ps, z, 0x1.71de379600d7fp-19);
-    ps = d_fma(ps, z, -0x1.a01a019e83411p-13);
-    ps = d_fma(ps, z, 0x1.1111111110bb1p-7);
-    ps = d_fma(ps, z, -0x1.5555555555555p-3);
+    ps = d_fma_c(ps, z, -0x1.ae600a73bc9bcp-26);
+    ps = d_fma_c(ps, z, 0x1.71de379600d7fp-19);
+    ps = d_fma_c(ps, z, -0x1.a01a019e83411p-13);
+    ps = d_fma_c(ps, z, 0x1.1111111110bb1p-7);
+    ps = d_fma_c(ps, z, -0x1.5555555555555p-3);
     const double sn = d_fma(r * z, ps, r);
     double pc = 0x1.1c819b161a46fp-29;
-    pc = d_fma(pc, z, -0x1.27e25ef4d05dfp-22);
-    pc = d_fma(pc, z, 0x1.a019ff5333bf2p-16);
-    pc = d_fma(pc, z, -0x1.6c16c16b61208p-10);
-    pc = d_fma(pc, z, 0x1.5555555555436p-5);
+    pc = d_fma_c(pc, z, -0x1.27e25ef4d05dfp-22);
+    pc = d_fma_c(pc, z, 0x1.a019ff5333bf2p-16);
+    pc = d_fma_c(pc, z, -0x1.6c16c16b61208p-10);
+    pc = d_fma_c(pc, z, 0x1.5555555555436p-5);
     const double cs = d_fma(z * z, pc, d_fma(-0.5, z, 1.0));
-    switch ((int)(q & 3)) {
-        case 0: *s_out = sn; *c_out = cs; break;
-        case 1: *s_out = cs; *c_out = -sn; break;
-        case 2: *s_out = -sn; *c_out = -cs; break;
-        default: *s_out = -cs; *c_out = sn; break;
-    }
+    // quadrant q mod 4: (sin, cos) = (sn, cs), (cs, -sn), (-sn, -cs), (-cs, sn)
+    const double a = (q & 1u) ? cs : sn, b = (q & 1u) ? sn : cs;
+    *s_out = (q & 2u) ? -a : a;
+    *c_out = (((q + 1u) & 2u) != 0u) ? -b : b;
 }
 
 // 2^k for integer k in [-1022, 1023]
-HNB_HD double d_pow2i(long long k) { return u2d((uint64_t)(k + 1023) << 52); }
+HNB_HD double d_pow2i(int32_t k) { return u2d((uint64_t)(uint32_t)(k + 1023) << 52); }
 
 // exp(x) for finite x; caller clamps to [-120, 100]
 HNB_HD double d_exp(double x) {
     const double log2e = 0x1.71547652b82fep+0;
     const double ln2_hi = 6.93147180369123816490e-01;
     const double ln2_lo = 1.90821492927058770002e-10;
-    const double k = d_rint(x * log2e);
+    uint32_t ki;
+    const double k = d_rint_bits(x * log2e, &ki);
     double r = d_fma(-k, ln2_hi, x);
     r = d_fma(-k, ln2_lo, r);
     // |r| <= ln2 / 2: exp r = 1 + r + r^2 E(r), relative error 2^-49
     double p = 0x1.2880501c9131ap-22;
-    p = d_fma(p, r, 0x1.72c7432675d87p-19);
-    p = d_fma(p, r, 0x1.a019c99a94203p-16);
-    p = d_fma(p, r, 0x1.a019ad9325b18p-13);
-    p = d_fma(p, r, 0x1.6c16c173921fdp-10);
-    p = d_fma(p, r, 0x1.1111111c4acecp-7);
-    p = d_fma(p, r, 0x1.5555555554cb3p-5);
-    p = d_fma(p, r, 0x1.5555555553b6ep-3);
-    p = d_fma(p, r, 0x1.0000000000000p-1);
+    p = d_fma_c(p, r, 0x1.72c7432675d87p-19);
+    p = d_fma_c(p, r, 0x1.a019c99a94203p-16);
+    p = d_fma_c(p, r, 0x1.a019ad9325b18p-13);
+    p = d_fma_c(p, r, 0x1.6c16c173921fdp-10);
+    p = d_fma_c(p, r, 0x1.1111111c4acecp-7);
+    p = d_fma_c(p, r, 0x1.5555555554cb3p-5);
+    p = d_fma_c(p, r, 0x1.5555555553b6ep-3);
+    p = d_fma_c(p, r, 0x1.0000000000000p-1);
     const double t = d_fma(r * r, p, r);
-    return (1.0 + t) * d_pow2i((long long)k);
+    return (1.0 + t) * d_pow2i((int32_t)ki);
 }
 
 // natural log of a finite, strictly positive, normal double: x = 2^k z with z in [0.6875, 1.375); the 64 intervals of z (top six
@@ -219,17 +234,17 @@ HNB_HD double d_log(double x) {
     const double ln2_hi = 6.93147180369123816490e-01;
     const double ln2_lo = 1.90821492927058770002e-10;
     const uint64_t ix = d2u(x);
-    const uint64_t tmp = ix - 0x3fe6000000000000ull;
-    const uint32_t i = (uint32_t)(tmp >> 46) & 63u;
-    const long long k = (long long)tmp >> 52;   // arithmetic shift: floor
-    const double z = u2d(ix - (tmp & 0xfff0000000000000ull));
+    const uint32_t hi = (uint32_t)(ix >> 32) - 0x3fe60000u;      // (the low word of the offset is zero: only the high word changes)
+    const uint32_t i = (hi >> 14) & 63u;
+    const int32_t k = (int32_t)hi >> 20;                          // arithmetic shift: floor
+    const double z = u2d(ix - ((uint64_t)(hi & 0xfff00000u) << 32));
     const double r = d_fma(z, kLogTab[i][0], -1.0);
     const double r2 = r * r;
     double p = 0x1.24a4c91a63c23p-3;
-    p = d_fma(p, r, -0x1.556a254394372p-3);
-    p = d_fma(p, r, 0x1.9999994c9b676p-3);
-    p = d_fma(p, r, -0x1.ffffffa962285p-3);
-    p = d_fma(p, r, 0x1.5555555555555p-2);
+    p = d_fma_c(p, r, -0x1.556a254394372p-3);
+    p = d_fma_c(p, r, 0x1.9999994c9b676p-3);
+    p = d_fma_c(p, r, -0x1.ffffffa962285p-3);
+    p = d_fma_c(p, r, 0x1.5555555555555p-2);
     const double l1p = d_fma(r2 * r, p, d_fma(-0.5, r2, r));
     const double kd = (double)k;
     return (kd * ln2_hi + kLogTab[i][1]) + (l1p + kd * ln2_lo);
@@ -238,46 +253,48 @@ HNB_HD double d_log(double x) {
 // sqrt of a double in [2^-100, 2^100] (and 0; negative / NaN -> NaN): the binary32 root and its binary32 reciprocal (both IEEE, so
 // identical on host and device) seed ONE Heron step whose division is a multiplication by that reciprocal: relative error < 2^-46.
 HNB_HD double d_sqrt(double a) {
-    if (!(a > 0.0)) return (a == 0.0) ? 0.0 : (a - a) / (a - a);  // 0 -> 0, neg/NaN -> NaN
     const float sf = f_sqrt((float)a);
     const double s0 = (double)sf, h = 0.5 * (double)(1.0f / sf);
-    return d_fma(d_fma(-s0, s0, a), h, s0);
+    const double s = d_fma(d_fma(-s0, s0, a), h, s0);
+    return (a > 0.0) ? s : ((a == 0.0) ? 0.0 : u2d(0x7ff8000000000000ull));  // 0 -> 0, negative / NaN -> NaN
 }
 
 // asin(t) = t + t z P(z), z = t^2 <= 1/4: relative error 2^-50
 HNB_HD double d_asin_poly(double z) {
     double p = 0x1.c8ea18fd14be4p-6;
-    p = d_fma(p, z, -0x1.c05fb18feb0f9p-8);
-    p = d_fma(p, z, 0x1.fa6d9d973284ep-7);
-    p = d_fma(p, z, 0x1.5114f44b77900p-7);
-    p = d_fma(p, z, 0x1.cf629dd6ae5fdp-7);
-    p = d_fma(p, z, 0x1.1c0d42d9a72edp-6);
-    p = d_fma(p, z, 0x1.6e8f37bce829dp-6);
-    p = d_fma(p, z, 0x1.f1c6ff632bc58p-6);
-    p = d_fma(p, z, 0x1.6db6dba9ded46p-5);
-    p = d_fma(p, z, 0x1.3333333302d42p-4);
-    p = d_fma(p, z, 0x1.55555555555bcp-3);
+    p = d_fma_c(p, z, -0x1.c05fb18feb0f9p-8);
+    p = d_fma_c(p, z, 0x1.fa6d9d973284ep-7);
+    p = d_fma_c(p, z, 0x1.5114f44b77900p-7);
+    p = d_fma_c(p, z, 0x1.cf629dd6ae5fdp-7);
+    p = d_fma_c(p, z, 0x1.1c0d42d9a72edp-6);
+    p = d_fma_c(p, z, 0x1.6e8f37bce829dp-6);
+    p = d_fma_c(p, z, 0x1.f1c6ff632bc58p-6);
+    p = d_fma_c(p, z, 0x1.6db6dba9ded46p-5);
+    p = d_fma_c(p, z, 0x1.3333333302d42p-4);
+    p = d_fma_c(p, z, 0x1.55555555555bcp-3);
     return p;
 }
-// asin / acos of a double; |x| > 1 -> NaN. |x| > 1/2: asin |x| = pi/2 - 2 asin sqrt((1 - |x|) / 2)  ((1 - |x|) / 2 is exact)
+// asin / acos of a double; |x| > 1 -> NaN. |x| <= 1/2: t = asin x directly; beyond: t = asin sqrt((1 - |x|) / 2) ((1 - |x|) / 2 is
+// exact) and asin |x| = pi/2 - 2 t. One polynomial evaluation either way (selects, no branch: a wave has lanes on both sides).
 HNB_HD double d_asin(double x) {
     const double pi_2_hi = 0x1.921fb54442d18p+0, pi_2_lo = 0x1.1a62633145c07p-54;
     const double ax = x < 0.0 ? -x : x;
-    if (ax <= 0.5) { const double z = x * x; return d_fma(x * z, d_asin_poly(z), x); }
-    const double z = (1.0 - ax) * 0.5;
-    const double s = d_sqrt(z);
+    const bool small = ax <= 0.5;
+    const double z = small ? x * x : (1.0 - ax) * 0.5;
+    const double s = small ? x : d_sqrt(z);
     const double t = d_fma(s * z, d_asin_poly(z), s);
     const double r = d_fma(-2.0, t, pi_2_hi) + pi_2_lo;
-    return x < 0.0 ? -r : r;
+    return small ? t : (x < 0.0 ? -r : r);
 }
 HNB_HD double d_acos(double x) {
     const double pi_2_hi = 0x1.921fb54442d18p+0, pi_2_lo = 0x1.1a62633145c07p-54;
     const double ax = x < 0.0 ? -x : x;
-    if (ax <= 0.5) { const double z = x * x; return pi_2_hi - (d_fma(x * z, d_asin_poly(z), x) - pi_2_lo); }
-    const double z = (1.0 - ax) * 0.5;
-    const double s = d_sqrt(z);
+    const bool small = ax <= 0.5;
+    const double z = small ? x * x : (1.0 - ax) * 0.5;
+    const double s = small ? x : d_sqrt(z);
     const double t = d_fma(s * z, d_asin_poly(z), s);
-    return x < 0.0 ? d_fma(-2.0, t, 2.0 * pi_2_hi) + 2.0 * pi_2_lo : 2.0 * t;
+    const double far = x < 0.0 ? d_fma(-2.0, t, 2.0 * pi_2_hi) + 2.0 * pi_2_lo : 2.0 * t;
+    return small ? pi_2_hi - (t - pi_2_lo) : far;
 }
 
 // atan of any double (NaN -> NaN): at most one division. t = |x| <= tan(pi/8): atan t; t <= tan(3 pi/8): pi/4 + atan((t-1)/(t+1));
@@ -292,14 +309,14 @@ HNB_HD double d_atan(double x) {
     const double u = num / den;
     const double z = u * u;
     double p = -0x1.be20c62f176ddp-6;
-    p = d_fma(p, z, 0x1.a769bd3353c1cp-5);
-    p = d_fma(p, z, -0x1.0c52a4b5af878p-4);
-    p = d_fma(p, z, 0x1.3a9d83feefaedp-4);
-    p = d_fma(p, z, -0x1.74563c795c0ffp-4);
-    p = d_fma(p, z, 0x1.c71c381ab56c6p-4);
-    p = d_fma(p, z, -0x1.249248aa52bc5p-3);
-    p = d_fma(p, z, 0x1.99999998d12f0p-3);
-    p = d_fma(p, z, -0x1.55555555553a3p-2);
+    p = d_fma_c(p, z, 0x1.a769bd3353c1cp-5);
+    p = d_fma_c(p, z, -0x1.0c52a4b5af878p-4);
+    p = d_fma_c(p, z, 0x1.3a9d83feefaedp-4);
+    p = d_fma_c(p, z, -0x1.74563c795c0ffp-4);
+    p = d_fma_c(p, z, 0x1.c71c381ab56c6p-4);
+    p = d_fma_c(p, z, -0x1.249248aa52bc5p-3);
+    p = d_fma_c(p, z, 0x1.99999998d12f0p-3);
+    p = d_fma_c(p, z, -0x1.55555555553a3p-2);
     double r = d_fma(u * z, p, u);
     r = (mid ? pi_4 : (big ? pi_2 : 0.0)) + r;
     return neg ? -r : r;
@@ -321,19 +338,19 @@ HNB_HD double d_atan2(double y, double x) {
 HNB_HD bool trig_in_range(float x) { return f_abs(x) <= 1099511627776.0f; }  // 2^40
 
 HNB_HD float f_sin(float x) {
-    if (!(f_abs(x) <= 3.4028234663852886e38f)) return x - x;  // NaN/inf -> NaN
-    if (!trig_in_range(x)) return 0.0f;
-    double s, c; d_sincos((double)x, &s, &c); return (float)s;
+    const bool finite = f_abs(x) <= 3.4028234663852886e38f, in_range = trig_in_range(x);
+    double s, c; d_sincos(in_range ? (double)x : 0.0, &s, &c);
+    return finite ? (in_range ? (float)s : 0.0f) : x - x;  // NaN/inf -> NaN; |x| > 2^40 -> sin 0
 }
 HNB_HD float f_cos(float x) {
-    if (!(f_abs(x) <= 3.4028234663852886e38f)) return x - x;
-    if (!trig_in_range(x)) return 1.0f;
-    double s, c; d_sincos((double)x, &s, &c); return (float)c;
+    const bool finite = f_abs(x) <= 3.4028234663852886e38f, in_range = trig_in_range(x);
+    double s, c; d_sincos(in_range ? (double)x : 0.0, &s, &c);
+    return finite ? (in_range ? (float)c : 1.0f) : x - x;
 }
 HNB_HD float f_tan(float x) {
-    if (!(f_abs(x) <= 3.4028234663852886e38f)) return x - x;
-    if (!trig_in_range(x)) return 0.0f;
-    double s, c; d_sincos((double)x, &s, &c); return (float)(s / c);
+    const bool finite = f_abs(x) <= 3.4028234663852886e38f, in_range = trig_in_range(x);
+    double s, c; d_sincos(in_range ? (double)x : 0.0, &s, &c);
+    return finite ? (in_range ? (float)(s / c) : 0.0f) : x - x;
 }
 HNB_HD float f_atan(float x) { return (float)d_atan((double)x); }
 HNB_HD float f_atan2(float y, float x) { return (float)d_atan2((double)y, (double)x); }
@@ -351,9 +368,10 @@ HNB_HD float f_exp2(float x) {
     double xd = (double)x;
     if (xd > 140.0) xd = 140.0;
     if (xd < -170.0) xd = -170.0;
-    double k = d_rint(xd);
-    double r = (xd - k) * 0.69314718055994528623;
-    return (float)(d_exp(r) * d_pow2i((long long)k));
+    uint32_t ki;
+    const double k = d_rint_bits(xd, &ki);
+    const double r = (xd - k) * 0.69314718055994528623;
+    return (float)(d_exp(r) * d_pow2i((int32_t)ki));
 }
 HNB_HD double d_log_f(float x, bool* special, float* sv) {
     *special = true;
@@ -374,15 +392,17 @@ HNB_HD float f_log2(float x) {
 }
 // WGSL pow(x, y): defined here as exp(y * ln x) for x > 0; x < 0 -> NaN.
 HNB_HD float f_pow(float x, float y) {
+    // computed for every lane, the special cases selected afterwards (d_log of a non-positive or non-finite x is garbage, never a fault)
+    double t = (double)y * d_log((double)x);
+    if (t > 100.0) t = 100.0;
+    if (t < -120.0) t = -120.0;
+    const float r = (float)d_exp(t != t ? 0.0 : t);
     if (x != x || y != y) return x + y;
     if (y == 0.0f) return 1.0f;
     if (x < 0.0f) return f_nan();
     if (x == 0.0f) return (y > 0.0f) ? 0.0f : f_inf();
     if (x == f_inf()) return (y > 0.0f) ? f_inf() : 0.0f;
-    double t = (double)y * d_log((double)x);
-    if (t > 100.0) t = 100.0;
-    if (t < -120.0) t = -120.0;
-    return (float)d_exp(t);
+    return r;
 }
 
 // ---- conversions (WGSL value constructors: truncate + saturate, NaN -> 0) -------------

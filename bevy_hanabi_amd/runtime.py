@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "hnb_effect_read_dead_list", "hnb_effect_write_attr", "hnb_effect_sort_ribbons", "hnb_ctx_enable_kernel_timing",
     "hnb_ctx_kernel_timing", "hnb_program_kernel_info", "hnb_jit_precompile", "hnb_effect_set_simulated", "hnb_ctx_set_option", "hnb_program_set_frames", "hnb_effect_index",
     "hnb_ctx_profile_marker",
+    "hnb_comm_create_local", "hnb_comm_unique_id", "hnb_comm_create_rank", "hnb_comm_allreduce_alive", "hnb_comm_destroy",
 ]
 
 
@@ -90,6 +91,11 @@ def load_library():
         lib.hnb_program_set_frames.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.hnb_effect_index.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         lib.hnb_ctx_profile_marker.argtypes = [C.c_void_p, C.c_uint32]
+        lib.hnb_comm_create_local.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.hnb_comm_unique_id.argtypes = [C.c_void_p]
+        lib.hnb_comm_create_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.hnb_comm_allreduce_alive.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint64)]
+        lib.hnb_comm_destroy.argtypes = [C.c_void_p]
         lib.hnb_program_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         lib.hnb_jit_precompile.argtypes = [C.c_char_p, C.c_size_t]
         _lib = lib
@@ -172,6 +178,52 @@ class Context:
         u, c, i, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint32()
         _check(self._lib.hnb_ctx_kernel_timing(self._h, C.byref(u), C.byref(c), C.byref(i), C.byref(n)))
         return {"update_ms_avg": u.value, "compact_ms_avg": c.value, "init_ms_avg": i.value, "frames": n.value}
+
+
+class Comm:
+    """The alive-counter all-reduce over RCCL (`hnb_comm_*`): `Comm.local(contexts)` for one process with a context per GPU,
+    `Comm.rank(ctx, unique_id, rank, n_ranks)` for one rank per process (`Comm.unique_id()` on rank 0)."""
+
+    def __init__(self, handle, contexts):
+        self._lib = load_library()
+        self._h = handle
+        self._contexts = list(contexts)
+
+    @classmethod
+    def local(cls, contexts):
+        lib = load_library()
+        arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+        h = C.c_void_p()
+        _check(lib.hnb_comm_create_local(arr, len(contexts), C.byref(h)))
+        return cls(h, contexts)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(load_library().hnb_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def rank(cls, ctx, unique_id, rank, n_ranks):
+        lib = load_library()
+        h = C.c_void_p()
+        _check(lib.hnb_comm_create_rank(ctx._h, C.c_char_p(unique_id), int(rank), int(n_ranks), C.byref(h)))
+        return cls(h, [ctx])
+
+    def allreduce_alive(self, effects_per_context):
+        """effects_per_context: one list of effects (or None) per local context, all of the same length -> totals per effect."""
+        n = len(effects_per_context[0])
+        assert len(effects_per_context) == len(self._contexts) and all(len(e) == n for e in effects_per_context)
+        flat = [None if fx is None else fx._h for row in effects_per_context for fx in row]
+        arr = (C.c_void_p * len(flat))(*flat)
+        out = (C.c_uint64 * n)()
+        _check(self._lib.hnb_comm_allreduce_alive(self._h, arr, n, out))
+        return [int(v) for v in out]
+
+    def destroy(self):
+        if self._h:
+            self._lib.hnb_comm_destroy(self._h)
+            self._h = None
 
 
 class Program:

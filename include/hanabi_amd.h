@@ -363,6 +363,24 @@ int hnb_ctx_kernel_timing(HnbContext* ctx, double* update_ms_avg, double* compac
  * a run into the sections it cares about (bench.py brackets the timed frames of every configuration with it). */
 int hnb_ctx_profile_marker(HnbContext* ctx, uint32_t tag);
 
+/* ---- multi-GPU reporting ------------------------------------------------------------------------------------------------
+ * Effects shard by instance and by capacity slab with no inter-GPU dependency per frame: one HnbContext per GPU,
+ * each driven by its own submit thread of ONE process (the reference's seam is one process: src/plugin.rs:202-256,
+ * src/render/mod.rs:126-131; examples/multi_gpu.c is such a host), or one rank per process. The only collective is the all-reduce of
+ * the alive-particle counters, over RCCL (xGMI). librccl is resolved at run time: a single-GPU host does not need it. */
+typedef struct HnbComm HnbComm;
+#define HNB_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+/* one process, n contexts (ncclCommInitAll over their devices; contexts that share a device are reduced through the host) */
+int hnb_comm_create_local(HnbContext* const* ctxs, uint32_t n_ctx, HnbComm** out_comm);
+/* one rank per process: rank 0 calls hnb_comm_unique_id and hands the 128 bytes to the others (ncclCommInitRank) */
+int hnb_comm_unique_id(void* out_id);
+int hnb_comm_create_rank(HnbContext* ctx, const void* id, uint32_t rank, uint32_t n_ranks, HnbComm** out_comm);
+/* out_totals[e] = sum over every context (of every rank) of the alive count of its e-th effect. `effects` is context-major,
+ * [local contexts][n_effects]; NULL entries count 0. Enqueued on the contexts' simulation streams behind their frames; returns when
+ * the totals are in out_totals (the one call of this API that synchronises every context). */
+int hnb_comm_allreduce_alive(HnbComm* comm, HnbEffect* const* effects, uint32_t n_effects, uint64_t* out_totals);
+int hnb_comm_destroy(HnbComm* comm);
+
 #ifdef __cplusplus
 }
 #endif

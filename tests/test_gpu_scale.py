@@ -203,6 +203,33 @@ def test_c2_firework_full_state_at_baseline_size(ctx):
     gpu.fx.destroy(); gpu.prog.destroy()
 
 
+def test_c2_mixed_full_state_at_baseline_size(ctx):
+    """bench.py's c2_mixed at full size: the firework trails program at 16,777,216 particles under a RATE spawner (capacity / mean
+    lifetime per second) - the general path of vfx_update.wgsl:105-167: per-particle ages, lifetimes loaded, spawns into recycled slots
+    and deaths in the same frame and the same chunks, the lists rebuilt every frame (died bits -> k_count_rows -> k_compact). dt = 0.25 s
+    gets there in a few frames: a quarter of the capacity spawns per frame, lives 0.8 .. 1.2 s and dies 4 or 5 frames later, so from
+    frame 4 on every frame spawns ~4M particles into slots freed in the frames before, in last-killed-first order. FULL state (counters,
+    both lists, every plane of every slot) against the OpenMP oracle."""
+    cap = 1 << 24
+    asset = effects.firework_trails(cap, bh.SpawnerSettings.rate(float(cap) / 1.0))
+    gpu, orc = GpuRunner(asset, ctx=ctx), OracleRunner(asset, omp=True)
+    sp, rng = bh.EffectSpawner(asset.spawner), bh.Pcg32()
+    dt, hist = 0.25, []
+    for f in range(10):
+        fr = Frame(dt, sp.tick(dt, rng), frame_seed(f), time=f * dt)
+        gpu.step(fr)
+        orc.step(fr)
+        m = gpu.fx.metadata()
+        hist.append((m["spawned"], m["dead_count"], m["alive_count"]))
+        if f in (3, 5, 6, 9):
+            assert_same_state(orc.state(), gpu.state(), f"c2_mixed 16.7M frame {f}")
+    # the steady state: spawns AND deaths in the same frames, slots reused (more particles spawned than the effect has slots)
+    assert all(s > cap // 8 and d > cap // 8 for s, d, _ in hist[5:]), hist
+    assert gpu.fx.metadata()["particle_counter"] > cap + cap // 2
+    print("c2_mixed 16,777,216: (spawned, died, alive) per frame", hist)
+    gpu.fx.destroy(); gpu.prog.destroy()
+
+
 def test_c4_instancing_one_gpu_share_at_baseline_size(ctx):
     """instancing.rs, 512 instances x 65,536 (one GPU's share of BASELINE config 4: 4096 instances over 8 GPUs, instance i
     on rank i mod 8 — rank 0 owns 0, 8, 16, ...). dt = 3 s with the rate spawner: a quarter of the capacity spawns per frame

@@ -1,0 +1,97 @@
+"""The multi-GPU host path that needs no Python and no second process: hnb_comm_* over RCCL and the
+single-process, thread-per-context driver examples/multi_gpu.c. One GPU is what the test box has: two contexts share device 0 (RCCL
+refuses a communicator with one device twice, so the library sums their counters through the host - the same entry point), each driven
+by its own thread; their slabs' union must equal one effect of twice the capacity, bit for bit."""
+import json
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+import bevy_hanabi_amd as bh
+from bevy_hanabi_amd import build as hb
+from bevy_hanabi_amd import effects, runtime
+from helpers import A, Frame, OracleRunner, frame_seed
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_comm_symbols_and_failure_modes_without_a_gpu():
+    lib = runtime.load_library()
+    for s in ("hnb_comm_create_local", "hnb_comm_unique_id", "hnb_comm_create_rank", "hnb_comm_allreduce_alive", "hnb_comm_destroy"):
+        assert hasattr(lib, s)
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.hnb_comm_create_local(None, 0, C.byref(h)) == -1        # HNB_ERR_INVALID_ARG
+    assert lib.hnb_comm_allreduce_alive(None, None, 0, None) == -1
+    assert lib.hnb_comm_destroy(None) == 0
+    assert os.path.exists(hb.build_examples())                          # the C99 driver builds against the public header alone
+
+
+@pytest.mark.gpu
+def test_two_contexts_two_threads_on_one_device_equal_one_effect():
+    C_ = 30000   # (not a multiple of the 4096-slot chunk)
+    frames = 70  # burst, flight, most of the die-off
+    asset = effects.firework_trails(C_)
+    blob = bh.lower(asset)
+    ctxs = [bh.Context(0), bh.Context(0)]
+    progs = [c.create_program(blob) for c in ctxs]
+    slabs = [p.create_effect(slot_base=g * C_) for g, p in enumerate(progs)]
+    errors = []
+
+    def drive(g):
+        try:
+            for f in range(frames):
+                ctxs[g].frame_begin(1 / 60, f / 60)
+                slabs[g].set_frame(C_ if f == 0 else 0, frame_seed(f))
+                ctxs[g].simulate()
+            ctxs[g].synchronize()
+        except Exception as e:   # surfaced below
+            errors.append((g, e))
+
+    threads = [threading.Thread(target=drive, args=(g,)) for g in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    comm = bh.Comm.local(ctxs)
+    total = comm.allreduce_alive([[slabs[0]], [slabs[1]]])
+    comm.destroy()
+    # one effect of capacity 2C, by the oracle
+    big = effects.firework_trails(2 * C_)
+    orc = OracleRunner(big)
+    for f in range(frames):
+        orc.step(Frame(1 / 60, 2 * C_ if f == 0 else 0, frame_seed(f), time=f / 60))
+    ref = orc.state()
+    assert total == [ref["counters"]["alive_count"]] and 0 < total[0] < 2 * C_
+    assert total[0] == slabs[0].alive_count() + slabs[1].alive_count()
+    for a in (A.POSITION, A.VELOCITY, A.AGE, A.LIFETIME, A.COLOR):
+        union = np.concatenate([fx.read_attr(a.id).view(np.uint32) for fx in slabs])
+        np.testing.assert_array_equal(union, ref["attrs"][a.name], err_msg=a.name)
+    glob = np.concatenate([fx.alive_list() + g * C_ for g, fx in enumerate(slabs)])
+    np.testing.assert_array_equal(np.sort(glob), np.sort(ref["alive"]))
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_c99_thread_per_context_driver(tmp_path):
+    exe = hb.build_examples()
+    C_ = 20000
+    blob_path = tmp_path / "trails.blob"
+    blob_path.write_bytes(bh.lower(effects.firework_trails(C_)))
+    warmup, steps, windows = 3, 5, 2
+    p = subprocess.run([exe, str(blob_path), "0,0", str(warmup), str(steps), str(windows), str(1 / 60), str(tmp_path / "dump")],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["n_ctx"] == 2 and out["devices"] == [0, 0] and out["alive_total"] == 2 * C_ and len(out["window_ms_per_step"]) == windows
+    frames = 1 + warmup + steps * windows
+    orc = OracleRunner(effects.firework_trails(2 * C_))
+    for f in range(frames):
+        orc.step(Frame(np.float32(1 / 60), 2 * C_ if f == 0 else 0, frame_seed(f), time=float(np.float32(f) * np.float32(1 / 60))))
+    pos = np.concatenate([np.fromfile(str(tmp_path / f"dump.{g}.pos"), dtype=np.uint32).reshape(-1, 3) for g in range(2)])
+    np.testing.assert_array_equal(pos, orc.state()["attrs"]["position"])
