@@ -15,6 +15,9 @@ Configurations (synthetic scalings of the reference's example as
                               particles per second in steady state - per-particle ages, lifetimes loaded, spawns into
                               recycled slots and deaths in every frame, list kernels in every frame;
   c2_dieoff                   frames 48..70 of the burst (1/60 s frames): the die-off, 4 % of the capacity lost per frame;
+  c2_events                   the REAL examples/firework.rs at scale: three linked effects - rockets whose update emits GPU spawn
+                              events, a sparkle trail (5 events per rocket and frame) and the trails (1000 events per dying rocket,
+                              capacity 16,777,216) - in steady state, event buffers sized for it;
   c2_interop                  c2 with HNB_AGE_COHORT=0: the AGE plane is kept up to date for a renderer that reads it
                               (ColorOverLifetime / SizeOverLifetime, src/modifier/output.rs:310-312);
   c3                          examples/force_field.rs, capacity 8,388,608 per GPU, burst, capacity slabs;
@@ -88,6 +91,9 @@ CONFIGS = {
                       workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst; frames 48..70 at 1/60 s: the die-off (list kernels every frame)"),
     "c2_interop": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=56, kernel="k_update_slots_stream<ProgDragAccel>",
                        workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst, all alive, HNB_AGE_COHORT=0 (AGE plane current every frame)"),
+    "c2_events": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=62, kernel="k_update_slots_stream<ProgDragAccel, cohort> (trails)",
+                      workload="the real examples/firework.rs: rocket (capacity 32_768, 16_000 rockets/s) -> sparkle_trail (1_048_576; 5 spawn events per rocket and frame) + "
+                               "trails (capacity={cap:_}; 1000 spawn events per dying rocket), GPU spawn events, steady state"),
     "c3": dict(capacity=1 << 23, bytes_per_update=68, bytes_per_spawn=40, model_bytes=56, kernel="k_update_slots_stream<ProgForceField>",
                workload="force_field.rs EffectAsset (2x ConformToSphere + KillAabb + KillSphere), capacity={cap:_} per GPU, burst"),
     "c4": dict(capacity=65536, bytes_per_update=68, bytes_per_spawn=40, model_bytes=36, kernel="k_update_slots_stream<ProgAgeEuler, cohort>", instances=512,
@@ -95,9 +101,9 @@ CONFIGS = {
     "c5": dict(capacity=1 << 22, bytes_per_update=20, bytes_per_spawn=36, model_bytes=9, kernel="k_update_slots_stream<ProgAge>",
                workload="ribbon.rs EffectAsset, capacity={cap:_} per GPU, rate spawner in steady spawn/kill churn, ribbon sort in the step"),
 }
-EXTRA_CONFIGS = ("c2_mixed", "c2_dieoff", "c2_interop", "c3", "c4", "c5")   # appended to the N = 1 default line
+EXTRA_CONFIGS = ("c2_mixed", "c2_dieoff", "c2_interop", "c2_events", "c3", "c4", "c5")   # appended to the N = 1 default line
 # what identifies the dominant kernel of a configuration in a rocprofv3 dispatch list
-KERNEL_MATCH = {"c2": ("k_update_slots_stream",), "c2_mixed": ("k_update_slots_stream",), "c2_dieoff": ("k_update_slots_stream",),
+KERNEL_MATCH = {"c2_events": ("k_update_slots_stream",), "c2": ("k_update_slots_stream",), "c2_mixed": ("k_update_slots_stream",), "c2_dieoff": ("k_update_slots_stream",),
                 "c2_interop": ("k_update_slots_stream",), "c3": ("k_update_slots_stream",), "c4": ("k_update_slots_stream",), "c5": ("k_update_slots_stream",)}
 
 
@@ -313,6 +319,21 @@ class Workload:
             self.xf_of = np.array([instance_transform(i) for i in gids], dtype=np.float32)
             self.local_particles = self.per_inst_cap * len(self.fxs)
             self.sharding_desc = f"by instance: {total_inst} instances over {n} rank(s), {len(self.fxs)} on rank 0"
+        elif name == "c2_events":
+            # examples/firework.rs:41-251 scaled so that the trails effect fills its 16,777,216 slots to ~95 %: 16,000 rockets per second,
+            # each alive for 0.8 .. 1.2 s, 1000 trail particles per explosion living 0.8 .. 1.2 s. Parent and children share the context (one GPU).
+            cap = self.per_inst_cap
+            self.rocket_asset = effects.firework_rocket(32768, 5, 1000)
+            self.rocket_asset.spawner = bh.SpawnerSettings.rate(16000.0 * cap / (1 << 24))
+            assets = [self.rocket_asset, effects.firework_sparkle_trail(max(4096, cap // 16)), effects.firework_trails_child(cap)]
+            self.progs = [self.ctx.create_program(bh.lower(a)) for a in assets]
+            self.prog = self.progs[2]
+            self.fxs = [p.create_effect() for p in self.progs]
+            self.fxs[1].set_parent(self.fxs[0], 0, max(4096, cap // 128))     # ~84k sparkle events per frame at full size
+            self.fxs[2].set_parent(self.fxs[0], 1, max(4096, cap // 32))      # ~270k explosion events per frame at full size
+            self.local_particles = cap
+            self.sharding_desc = "one context (a parent and its children live on one GPU); replicas at N > 1"
+            self.spawner, self.rng = bh.EffectSpawner(self.rocket_asset.spawner), bh.Pcg32()
         else:
             if strong:
                 total_cap = base_cap
@@ -361,6 +382,10 @@ class Workload:
         if self.name == "c4":
             # (numpy, not a Python loop over 512 instances: the harness must not be what the step waits for)
             self.prog.set_frames(np.full(len(self.fxs), s, dtype=np.uint32), (self.gid_mix ^ np.uint64(frame_seed(f))).astype(np.uint32), self.xf_of)
+        elif self.name == "c2_events":
+            self.fxs[0].set_frame(s, frame_seed(f))
+            self.fxs[1].set_frame(0, frame_seed(1000 + f))
+            self.fxs[2].set_frame(0, frame_seed(2000 + f))
         elif self.name == "c5":   # the emitter moves (ribbon.rs Shape::tick, Lissajou)
             t = f * dt * 6.5
             self.fxs[0].set_frame(s, frame_seed(f), [1, 0, 0, 25.0 * np.cos(3.0 * t), 0, 1, 0, 25.0 * np.sin(2.0 * t), 0, 0, 1, 0.0])
@@ -379,6 +404,8 @@ class Workload:
 def warmup_frames(name, requested):
     if name == "c5":
         return max(requested, 120)     # 1.5 s lifetime at 60 Hz: 90 frames to reach the steady state
+    if name == "c2_events":
+        return max(requested, 300)     # a rocket's life (<= 1.2 s) + a trail particle's (<= 1.2 s) = 144 frames to fill, then as long again to mix
     if name == "c2_mixed":
         return max(requested, 240)     # lifetimes of 0.8 .. 1.2 s: four mean lifetimes until ages, slots and list order are mixed
     return requested
@@ -394,7 +421,7 @@ def run_config(name, args, D, strong=False, pmc=None):
     warmup = warmup_frames(name, args.warmup)
     if name == "c2_dieoff":
         steps = DIEOFF_LAST - DIEOFF_FIRST + 1           # a window is the die-off itself, not K steps
-    elif w.family == "c2" and name != "c2_mixed":
+    elif name in ("c2", "c2_interop"):
         w.dt = frame_dt(1 + warmup + steps * windows)    # nobody may die in the timed frames
 
     if pmc is not None:   # ---- counter pass: no timing, a handful of steady frames between two markers
@@ -405,7 +432,7 @@ def run_config(name, args, D, strong=False, pmc=None):
             frames = steps
         else:
             w.step()
-            for _ in range(warmup if name in ("c5", "c2_mixed") else 3):
+            for _ in range(warmup if name in ("c5", "c2_mixed", "c2_events") else 3):
                 w.step()
         ctx.synchronize()
         ctx.profile_marker(pmc["begin"])
@@ -459,6 +486,12 @@ def run_config(name, args, D, strong=False, pmc=None):
                 w.step()
             w.dieoff_timing = getattr(w, "dieoff_timing", []) + [timing_d]
     timing = ctx.kernel_timing() if name != "c2_dieoff" else None
+    per_program = None
+    if name == "c2_events":   # the context's averages mix three programs: report each, the roofline kernel is the trails' update
+        per_program = {k: p.kernel_timing() for k, p in zip(("rocket", "sparkle_trail", "trails"), w.progs)}
+        timing = dict(per_program["trails"])
+        timing["init_ms_avg"] = sum(v["init_ms_avg"] for v in per_program.values())
+        timing["compact_ms_avg"] = sum(v["compact_ms_avg"] for v in per_program.values())
     ctx.enable_kernel_timing(0)
     if name == "c2_dieoff":
         ts = w.dieoff_timing
@@ -479,7 +512,7 @@ def run_config(name, args, D, strong=False, pmc=None):
     # particles processed by the update stage per frame (max_update). Burst configurations: constant when nothing dies. Churn (c5,
     # c2_mixed): the update processes alive-before + this frame's spawns = the last frame's max_update in the steady state.
     scale = alive1_total / max(alive1, 1) if D.on else 1.0
-    if name in ("c5", "c2_mixed"):
+    if name in ("c5", "c2_mixed", "c2_events"):
         per_frame_local = float(sum(m["max_update"] for m in m1)) * (len(w.fxs) / max(1, len(m1)))
         per_frame_total = per_frame_local * scale
     elif name == "c2_dieoff":
@@ -515,7 +548,10 @@ def run_config(name, args, D, strong=False, pmc=None):
                                      "note": "SURVEY.md §8(d) bytes x updates / time: what the work is worth, not what was moved (above the moved figure wherever the design elides traffic)"}},
         "kernels": kinfo,
     }
-    if init_ms > 0 and name not in ("c5", "c2_mixed"):  # the burst frame's init kernel (not part of the metric)
+    if per_program is not None:
+        out["stages"]["per_program"] = per_program
+        out["stages"]["note"] = "init / lists: sums over the three programs (lists of the rocket include its spawn-event ordering: k_emit_count + k_emit_events); update: the trails' kernel; sum_ms leaves out the two small update kernels (per_program has them)"
+    if init_ms > 0 and name not in ("c5", "c2_mixed", "c2_events"):  # the burst frame's init kernel (not part of the metric)
         bps = cfg["bytes_per_spawn"]
         out["init"] = {"kernel": "k_init", "kernel_ms": init_ms, "spawned": w.local_particles, "bytes_per_spawn": bps,
                        "achieved_gbs": w.local_particles * bps / (init_ms * 1e-3) / 1e9, "frac": w.local_particles * bps / (init_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -546,6 +582,8 @@ def parse_counter_csv(path, counter, info):
                 rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["Grid_Size"]), float(r["Counter_Value"])))
     rows.sort()
     out = {}
+    # (several launches of one kernel template per frame - c2_events: the sparkle trail and the trails run the same update kernel -: the
+    # dominant launch is the one with the largest grid)
     for name, meta in info.items():
         inside, sect = False, []
         for _id, kname, grid, val in rows:
@@ -556,15 +594,17 @@ def parse_counter_csv(path, counter, info):
                     inside = False
                 continue
             if inside:
-                sect.append((kname, val))
+                sect.append((kname, val, grid))
         if not sect:
             continue
         per = {}
-        for kname, val in sect:
+        for kname, val, _g in sect:
             short = kname.split("(")[0].replace("void ", "").replace("hnb::", "")
             per.setdefault(short, []).append(val)
-        dom = [v for k, vs in per.items() if any(m in k for m in KERNEL_MATCH[name]) for v in vs]
-        out[name] = {"dominant_kib": statistics.median(dom) if dom else None, "frame_kib": sum(v for _k, v in sect) / meta["frames"],
+        match = [(v, g) for k, v, g in sect if any(m in k for m in KERNEL_MATCH[name])]
+        gmax = max((g for _v, g in match), default=0)
+        dom = [v for v, g in match if g == gmax]
+        out[name] = {"dominant_kib": statistics.median(dom) if dom else None, "frame_kib": sum(v for _k, v, _g in sect) / meta["frames"],
                      "per_kernel_kib": {k[:120]: {"median": statistics.median(vs), "launches_per_frame": len(vs) / meta["frames"]} for k, vs in per.items()}}
     return out
 

@@ -47,7 +47,8 @@ int fail(int code, const char* fmt, ...) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-struct TimingPair { hipEvent_t a, b; };
+
+struct TimingPair { hipEvent_t a, b; const HnbProgram* prog; };
 constexpr uint32_t kFrameRing = 4;
 
 }  // namespace
@@ -1531,6 +1532,7 @@ int hnb_simulate(HnbContext* ctx) {
         const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
         if (blocks) {
             TimingPair ti{};
+            ti.prog = p;
             if (timed) { ti.a = take_event(ctx); ti.b = take_event(ctx); hipEventRecord(ti.a, ctx->stream); }
             if (p->jit_init) {
                 const DevMeta* mi = p->d_meta[par];
@@ -1590,6 +1592,7 @@ int hnb_simulate(HnbContext* ctx) {
         const uint32_t total_chunks = n * p->dev.chunks_per_inst;
         CompactBufs cb = compact_bufs_of(ctx, p, n);
         TimingPair tu{}, tc{};
+        tu.prog = tc.prog = p;
         if (timed) { tu.a = take_event(ctx); tu.b = take_event(ctx); tc.b = take_event(ctx); hipEventRecord(tu.a, ctx->stream); }
         const uint32_t write_died = (p->lists_now && !p->slot_order) ? 1u : 0u;   // k_count_rows follows: the update leaves one died bit per slot
         if (p->update_streams) {
@@ -1953,18 +1956,26 @@ int hnb_ctx_enable_kernel_timing(HnbContext* ctx, int enable) {
     return HNB_OK;
 }
 
-int hnb_ctx_kernel_timing(HnbContext* ctx, double* update_ms_avg, double* compact_ms_avg, double* init_ms_avg, uint32_t* frames) {
-    if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
+static int timing_of(HnbContext* ctx, const HnbProgram* only, double* update_ms_avg, double* compact_ms_avg, double* init_ms_avg, uint32_t* frames) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     double su = 0, si = 0, sc = 0;
-    for (auto& t : ctx->t_compact) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); sc += ms; }
-    if (compact_ms_avg) *compact_ms_avg = ctx->t_compact.empty() ? 0.0 : sc / ctx->t_compact.size();
-    for (auto& t : ctx->t_update) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); su += ms; }
-    for (auto& t : ctx->t_init) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); si += ms; }
-    if (update_ms_avg) *update_ms_avg = ctx->t_update.empty() ? 0.0 : su / ctx->t_update.size();
-    if (init_ms_avg) *init_ms_avg = ctx->t_init.empty() ? 0.0 : si / ctx->t_init.size();
-    if (frames) *frames = (uint32_t)ctx->t_update.size();
+    size_t nu = 0, ni = 0, nc = 0;
+    for (auto& t : ctx->t_compact) { if (only && t.prog != only) continue; float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); sc += ms; ++nc; }
+    for (auto& t : ctx->t_update) { if (only && t.prog != only) continue; float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); su += ms; ++nu; }
+    for (auto& t : ctx->t_init) { if (only && t.prog != only) continue; float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b)); si += ms; ++ni; }
+    if (compact_ms_avg) *compact_ms_avg = nc ? sc / nc : 0.0;
+    if (update_ms_avg) *update_ms_avg = nu ? su / nu : 0.0;
+    if (init_ms_avg) *init_ms_avg = ni ? si / ni : 0.0;
+    if (frames) *frames = (uint32_t)nu;
     return HNB_OK;
+}
+int hnb_ctx_kernel_timing(HnbContext* ctx, double* update_ms_avg, double* compact_ms_avg, double* init_ms_avg, uint32_t* frames) {
+    if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
+    return timing_of(ctx, nullptr, update_ms_avg, compact_ms_avg, init_ms_avg, frames);
+}
+int hnb_program_kernel_timing(HnbProgram* prog, double* update_ms_avg, double* compact_ms_avg, double* init_ms_avg, uint32_t* frames) {
+    if (!prog) return fail(HNB_ERR_INVALID_ARG, "prog is NULL");
+    return timing_of(prog->ctx, prog, update_ms_avg, compact_ms_avg, init_ms_avg, frames);
 }
 
 }  // extern "C"

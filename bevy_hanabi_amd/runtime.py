@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "hnb_effect_metadata", "hnb_effect_alive_count", "hnb_effect_read_attr", "hnb_effect_read_alive_list",
     "hnb_effect_read_dead_list", "hnb_effect_write_attr", "hnb_effect_sort_ribbons", "hnb_ctx_enable_kernel_timing",
     "hnb_ctx_kernel_timing", "hnb_program_kernel_info", "hnb_jit_precompile", "hnb_effect_set_simulated", "hnb_ctx_set_option", "hnb_program_set_frames", "hnb_effect_index",
-    "hnb_ctx_profile_marker",
+    "hnb_ctx_profile_marker", "hnb_program_kernel_timing",
     "hnb_comm_create_local", "hnb_comm_unique_id", "hnb_comm_create_rank", "hnb_comm_allreduce_alive", "hnb_comm_destroy",
 ]
 
@@ -91,6 +91,7 @@ def load_library():
         lib.hnb_program_set_frames.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.hnb_effect_index.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         lib.hnb_ctx_profile_marker.argtypes = [C.c_void_p, C.c_uint32]
+        lib.hnb_program_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         lib.hnb_comm_create_local.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p)]
         lib.hnb_comm_unique_id.argtypes = [C.c_void_p]
         lib.hnb_comm_create_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -245,6 +246,12 @@ class Program:
         assert sc.shape == sd.shape
         xf = None if transforms is None else np.ascontiguousarray(transforms, dtype=np.float32).reshape(len(sc), 12)
         _check(self._lib.hnb_program_set_frames(self._h, int(first), len(sc), sc.ctypes.data, sd.ctypes.data, None if xf is None else xf.ctypes.data))
+
+    def kernel_timing(self):
+        """Context.kernel_timing() restricted to this program's kernels."""
+        u, c, i, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint32()
+        _check(self._lib.hnb_program_kernel_timing(self._h, C.byref(u), C.byref(c), C.byref(i), C.byref(n)))
+        return {"update_ms_avg": u.value, "compact_ms_avg": c.value, "init_ms_avg": i.value, "frames": n.value}
 
     def kernel_info(self):
         """Which kernels run this program: 'init=jit|interp|none update=aot-stream:<name>|jit-stream|jit-generic|interp-*'."""

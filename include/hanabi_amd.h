@@ -358,6 +358,8 @@ int hnb_jit_precompile(const void* blob, size_t blob_size);
  * init kernel, over the frames simulated since the last reset (HIP events on the simulation stream). */
 int hnb_ctx_enable_kernel_timing(HnbContext* ctx, int every_n_frames); /* 0 = off; n: time every n-th hnb_simulate (events cost ~20 us of stream bubbles per timed frame) */
 int hnb_ctx_kernel_timing(HnbContext* ctx, double* update_ms_avg, double* compact_ms_avg, double* init_ms_avg, uint32_t* frames);
+/* the same averages over the kernels of ONE program of the context (a context with several programs: parent and child effects) */
+int hnb_program_kernel_timing(HnbProgram* prog, double* update_ms_avg, double* compact_ms_avg, double* init_ms_avg, uint32_t* frames);
 /* Profiling aid: enqueues an empty kernel of `tag` workgroups x 1 thread (1 <= tag <= 65535) on the simulation stream. It shows up in
  * a kernel trace / counter collection (rocprofv3) as `k_marker` with Grid_Size == tag, so that a tool can cut the dispatch list of
  * a run into the sections it cares about (bench.py brackets the timed frames of every configuration with it). */

@@ -230,6 +230,40 @@ def test_c2_mixed_full_state_at_baseline_size(ctx):
     gpu.fx.destroy(); gpu.prog.destroy()
 
 
+def test_c2_events_real_firework_at_baseline_size(ctx):
+    """bench.py's c2_events at full size: the REAL examples/firework.rs (firework.rs:41-251) - rockets whose update emits GPU spawn
+    events, the sparkle trail (5 events per rocket and frame) and the trails (1000 events per dying rocket) with the trails capacity at
+    16,777,216 and event buffers sized for the traffic. dt = 0.25 s reaches the steady state in about ten frames: ~4,000 rockets launch
+    per frame and explode 4 or 5 frames later into ~4M trail particles per frame, which die 4 or 5 frames after that while the next
+    explosions spawn into their slots. FULL state of all three effects (counters, lists, every plane of every slot) against the OpenMP
+    oracle at three frames of the steady state, all counters and event counts at every frame."""
+    from helpers import EffectSpec, GpuSystem, OracleSystem, assert_same_system_state
+    cap = 1 << 24
+    rocket = effects.firework_rocket(32768, 5, 1000)
+    rocket.spawner = bh.SpawnerSettings.rate(16000.0)
+    specs = [EffectSpec(rocket),
+             EffectSpec(effects.firework_sparkle_trail(1 << 20), parent=0, channel=0, event_capacity=1 << 17),
+             EffectSpec(effects.firework_trails_child(cap), parent=0, channel=1, event_capacity=1 << 23)]
+    g, o = GpuSystem(specs, ctx), OracleSystem(specs, omp=True)
+    sp, rng = bh.EffectSpawner(rocket.spawner), bh.Pcg32()
+    dt, hist = 0.25, []
+    for f in range(14):
+        fr = [Frame(dt, sp.tick(dt, rng), frame_seed(f), time=f * dt), Frame(dt, 0, frame_seed(1000 + f), time=f * dt), Frame(dt, 0, frame_seed(2000 + f), time=f * dt)]
+        g.step(fr)
+        o.step(fr)
+        ms = [fx.metadata() for fx in g.fx]
+        hist.append(tuple((m["spawned"], m["dead_count"], m["alive_count"]) for m in ms))
+        for fx, ofx in zip(g.fx, o.fx):
+            assert fx.metadata()["alive_count"] == ofx.alive_count(), f"frame {f}"
+        if f in (9, 11, 13):
+            assert_same_system_state(o.state(), g.state(), f"c2_events 16.7M frame {f}")
+    trails = [h[2] for h in hist]
+    assert all(s > cap // 8 and d > cap // 8 for s, d, _ in trails[10:]), trails     # explosions spawn into recycled slots while older trails die
+    assert g.fx[2].metadata()["particle_counter"] > cap
+    print("c2_events 16,777,216: (spawned, died, alive) of rocket / sparkle / trails per frame", hist)
+    g.destroy()
+
+
 def test_c4_instancing_one_gpu_share_at_baseline_size(ctx):
     """instancing.rs, 512 instances x 65,536 (one GPU's share of BASELINE config 4: 4096 instances over 8 GPUs, instance i
     on rank i mod 8 — rank 0 owns 0, 8, 16, ...). dt = 3 s with the rate spawner: a quarter of the capacity spawns per frame
