@@ -465,25 +465,25 @@ bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgra
         gsum_off = place(align_up((size_t)8 * ((sort_chunks + kSortGroup - 1) / kSortGroup) * 256 * 4, 256));
         bits_off = place(256);
     }
-    if (off > 0xffffffffull) return false;
-    d.alive_off[0] = (uint32_t)a0; d.alive_off[1] = (uint32_t)a1; d.dead_off = (uint32_t)dd;
+    if (off > ((uint64_t)0xffffffffu << 8)) return false;   // (offsets are kept in 256-byte units: 1 TiB)
+    d.alive_off[0] = soff_of(a0); d.alive_off[1] = soff_of(a1); d.dead_off = soff_of(dd);
     for (uint32_t i = 0; i < h.n_attrs; ++i) {
-        d.attrs[i].plane_off = (uint32_t)plane[i];
+        d.attrs[i].plane_off = soff_of(plane[i]);
         d.attrs[i].ncomp = attrs[i].ncomp;
         d.attrs[i].reg = attrs[i].reg;
         d.attrs[i].upd_flags = attrs[i].update_flags;
     }
-    d.alive_flag_off = (uint32_t)flag_off;
-    d.lmin_off = (uint32_t)lmin_off;
-    d.died_bits_off = (uint32_t)died_off; d.row_mask_off = (uint32_t)rmask_off;
+    d.alive_flag_off = soff_of(flag_off);
+    d.lmin_off = soff_of(lmin_off);
+    d.died_bits_off = soff_of(died_off); d.row_mask_off = soff_of(rmask_off);
     d.n_event_channels = h.n_event_channels;
-    for (uint32_t c = 0; c < h.n_event_channels; ++c) d.ev_cnt_off[c] = (uint32_t)ev_off[c];
+    for (uint32_t c = 0; c < h.n_event_channels; ++c) d.ev_cnt_off[c] = soff_of(ev_off[c]);
     if (ribbons) {
         so.capacity = h.capacity; so.chunks_per_inst = sort_chunks;
         so.alive_off[0] = d.alive_off[0]; so.alive_off[1] = d.alive_off[1];
-        for (int i = 0; i < 2; ++i) { so.key_off[i] = (uint32_t)key_off[i]; so.val_off[i] = (uint32_t)val_off[i]; }
-        so.hist_off = (uint32_t)hist_off; so.gsum_off = (uint32_t)gsum_off; so.bits_off = (uint32_t)bits_off;
-        so.rid_plane = so.age_plane = kNoPlane;
+        for (int i = 0; i < 2; ++i) { so.key_off[i] = soff_of(key_off[i]); so.val_off[i] = soff_of(val_off[i]); }
+        so.hist_off = soff_of(hist_off); so.gsum_off = soff_of(gsum_off); so.bits_off = soff_of(bits_off);
+        so.rid_plane.v = so.age_plane.v = kNoPlane;
         for (uint32_t i = 0; i < h.n_attrs; ++i) {
             if (attrs[i].attr == HNB_ATTR_RIBBON_ID) so.rid_plane = d.attrs[i].plane_off;
             if (attrs[i].attr == HNB_ATTR_AGE) so.age_plane = d.attrs[i].plane_off;
@@ -567,13 +567,13 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
     if (rc != HNB_OK) return rc;
     rc = validate_stream(p, p + h.update_off, h.update_len, h.update_regs, h, 2);
     if (rc != HNB_OK) return rc;
-    {   // the instance slab is addressed with 32-bit section offsets
+    {   // the instance slab is addressed with 32-bit section offsets in 256-byte units (1 TiB)
         std::vector<HnbAttrEntry> at(h.n_attrs);
         memcpy(at.data(), p + h.attrs_off, (size_t)h.n_attrs * sizeof(HnbAttrEntry));
         DevProgram d{};
         SortArgs so{};
         size_t bytes = 0;
-        if (!layout_slab(h, at.data(), d, so, &bytes)) return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB (capacity %u)", h.capacity);
+        if (!layout_slab(h, at.data(), d, so, &bytes)) return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 1 TiB (capacity %u)", h.capacity);
     }
     if (out_hdr) *out_hdr = h;
     return HNB_OK;
@@ -831,7 +831,7 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
 
     DevProgram& d = p->dev;
     size_t slab_bytes = 0;
-    if (!layout_slab(h, p->attrs.data(), d, p->sort, &slab_bytes)) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 4 GiB (capacity %u)", h.capacity); }
+    if (!layout_slab(h, p->attrs.data(), d, p->sort, &slab_bytes)) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 1 TiB (capacity %u)", h.capacity); }
     p->slot_order = ctx->list_order == HNB_LIST_ORDER_SLOT && !(h.flags & HNB_PROG_HAS_RIBBONS);  // ribbons are re-sorted anyway
     p->has_ribbons = (h.flags & HNB_PROG_HAS_RIBBONS) != 0;
     p->slab_bytes = slab_bytes;
@@ -840,7 +840,7 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     {
         uint32_t planes[HNB_ATTR_COUNT];
         for (uint32_t i = 0; i < HNB_ATTR_COUNT; ++i) planes[i] = kNoPlane;
-        for (uint32_t i = 0; i < h.n_attrs; ++i) planes[p->attrs[i].attr] = d.attrs[i].plane_off;
+        for (uint32_t i = 0; i < h.n_attrs; ++i) planes[p->attrs[i].attr] = d.attrs[i].plane_off.v;   // (256-byte units)
         hipError_t pe = hipMalloc(&p->d_plane_by_attr, sizeof planes);
         if (pe != hipSuccess) { delete p; return fail(HNB_ERR_OUT_OF_MEMORY, "hipMalloc failed: %s", hipGetErrorString(pe)); }
         hipMemcpy(p->d_plane_by_attr, planes, sizeof planes, hipMemcpyHostToDevice);
@@ -1097,7 +1097,7 @@ int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
     if (e != hipSuccess) { delete fx; return fail(HNB_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes) for effect slab failed: %s", p->slab_bytes, hipGetErrorString(e)); }
     char* base = static_cast<char*>(fx->slab);
     const uint32_t cap = p->dev.capacity;
-    k_reset_lists<<<(cap + 255) / 256, 256, 0, ctx->stream>>>(reinterpret_cast<uint32_t*>(base + p->dev.dead_off),
+    k_reset_lists<<<(uint32_t)(((uint64_t)cap + 255u) / 256u), 256, 0, ctx->stream>>>(reinterpret_cast<uint32_t*>(base + p->dev.dead_off),
                                                               reinterpret_cast<uint32_t*>(base + p->dev.alive_off[0]),
                                                               reinterpret_cast<uint32_t*>(base + p->dev.alive_off[1]), cap);
     // Attribute planes start zeroed (the reference pre-fills with 0xFF only in debug builds).
@@ -1383,7 +1383,7 @@ int hnb_simulate(HnbContext* ctx) {
             for (uint32_t c = 0; c < HNB_MAX_EVENT_CHANNELS; ++c) fi[i].ev_out[c] = reinterpret_cast<uint64_t>(fx->channels[c].buf);
             // never launch more init workgroups than the capacity allows (max_spawn <= capacity)
             const uint32_t cap_spawn = std::min(max_request, p->dev.capacity);
-            uint32_t inst_blocks = (cap_spawn + kInitBlock - 1) / kInitBlock;
+            uint32_t inst_blocks = (uint32_t)(((uint64_t)cap_spawn + kInitBlock - 1) / kInitBlock);
             // event-driven spawns: the count lives on the device, so launch a bounded grid that strides (k_init)
             if (fx->parent) inst_blocks = std::min<uint32_t>(inst_blocks, ctx->num_cus * 8u);
             blocks += inst_blocks;
@@ -1637,7 +1637,12 @@ int hnb_simulate(HnbContext* ctx) {
         if (!lists) p->skipped_frames += 1;
         if (lists && p->dev.n_event_channels) {  // order this frame's spawn events (by list row) into the children's buffers
             k_emit_count<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb);
-            k_emit_events<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb, p->h_ev_counts, ctx->frame);
+            // (gridDim.y splits every chunk's events over several workgroups: sized for the largest event buffer that listens, 16,384 events per split)
+            uint32_t max_ev = 0;
+            for (const HnbEffect* fx : p->effects)
+                for (const EventChannel& ch : fx->channels) max_ev = std::max(max_ev, ch.capacity);
+            const uint32_t splits = std::max(1u, std::min(64u, (max_ev / std::max(1u, total_chunks) + 16383u) / 16384u));
+            k_emit_events<<<dim3(total_chunks, splits), kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb, p->h_ev_counts, ctx->frame);
         }
         // lists: only the instances that lost particles have anything to do
         if (!p->lists_merged) {  // (merged: the lists, and the ribbon sort behind them, follow after the last program's update)

@@ -27,21 +27,21 @@ struct DevProgram {
     uint32_t n_attrs;          // stored attributes (all written by init)
     uint32_t n_uregs;          // parameter-block words per instance
     uint32_t chunks_per_inst;  // ceil(capacity / kChunk)
-    uint32_t alive_off[2];     // byte offsets of the ping/pong alive lists
-    uint32_t dead_off;         // byte offset of the dead list
+    soff_t alive_off[2];       // offsets of the ping/pong alive lists
+    soff_t dead_off;           // offset of the dead list
     uint32_t init_len, update_len;
     uint32_t n_inst;
     // GPU spawn events this program's update appends (EmitSpawnEventModifier): per-row staging planes in the slab
-    uint32_t alive_flag_off;   // u8[capacity]: 0 free, 1 alive (3: alive, spawned this frame into an age-cohort chunk): drives the slot-major update
+    soff_t alive_flag_off;     // u8[capacity]: 0 free, 1 alive (3: alive, spawned this frame into an age-cohort chunk): drives the slot-major update
     // List maintenance of frames with casualties (k_count_rows / k_compact): died_bits = one bit per SLOT, "died in this frame's update",
     // rewritten completely by every update launch that is followed by the list kernels (64-bit words, bit s & 63 of word s >> 6);
     // row_mask = one bit per alive-list ROW, "survives", written by k_count_rows for k_compact. Both [chunks_per_inst * kChunk / 8] bytes.
-    uint32_t died_bits_off, row_mask_off;
+    soff_t died_bits_off, row_mask_off;
     uint32_t n_event_channels;
-    uint32_t ev_cnt_off[HNB_MAX_EVENT_CHANNELS];     // u32[capacity] per channel: events appended by the particle in that slot
+    soff_t ev_cnt_off[HNB_MAX_EVENT_CHANNELS];       // u32[capacity] per channel: events appended by the particle in that slot
     // Lifetime culling (k_update_slots_stream): f32[chunks_per_inst], a lower bound of the LIFETIME of every alive particle
     // of the 4096-slot chunk, 0 = unknown. k_init zeroes the entry of a chunk it spawns into.
-    uint32_t lmin_off;
+    soff_t lmin_off;
     uint32_t cull_lifetime;    // 1: the streaming update keeps the bounds up to date and uses them
     uint32_t age_cohort;       // 1: chunks whose alive particles share one AGE keep it in a word (hnb_kernels.hip.h "Age cohorts")
     DevAttr attrs[kMaxAttrs];
@@ -58,7 +58,7 @@ struct DevFrameInst {
     float xf[12];               // row-major 3x4 transform
     // GPU spawn events (GpuSpawnerParams::parent_slab_offset, GpuChildInfo; src/render/event.rs:200-214)
     uint64_t parent_base;       // child: slab of the parent instance, 0 = CPU-spawned effect
-    uint64_t parent_planes;     // child: u32[HNB_ATTR_COUNT] plane byte offsets of the parent layout (kNoPlane = absent)
+    uint64_t parent_planes;     // child: u32[HNB_ATTR_COUNT] plane offsets of the parent layout in 256-byte units (kNoPlane = absent)
     uint64_t ev_in;             // child: DevEventBuffer the init pass consumes
     uint64_t ev_out[HNB_MAX_EVENT_CHANNELS];  // parent: DevEventBuffer per child channel, 0 = nobody listens
     uint32_t ev_parity;         // context frame parity: events are appended to count[ev_parity], consumed from count[ev_parity ^ 1]

@@ -569,9 +569,9 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
 
 struct CompactArgs {
     uint32_t capacity, chunks_per_inst;
-    uint32_t alive_off[2], dead_off;
-    uint32_t alive_flag_off;   // u8[capacity]: 0 free, 1 alive
-    uint32_t died_bits_off, row_mask_off;   // DevProgram: one bit per slot "died in this frame's update"; one bit per list row "survives"
+    soff_t alive_off[2], dead_off;
+    soff_t alive_flag_off;     // u8[capacity]: 0 free, 1 alive
+    soff_t died_bits_off, row_mask_off;     // DevProgram: one bit per slot "died in this frame's update"; one bit per list row "survives"
     uint32_t slot_order;       // HNB_LIST_ORDER_SLOT: k_order_write rebuilds the lists from the alive bytes
     uint32_t rotate_front;     // ribbon programs, host-proven (HnbProgram::sort_front_*): this frame's spawns sort in front of every older
                                // particle, so the survivors are written [spawns | older ones] and the list needs no sort afterwards
@@ -680,16 +680,22 @@ k_order_write(const CompactArgs args, const uint64_t* __restrict__ inst_base, co
 
 // ---- k_emit_events: order the staged spawn events (src/lib.rs:976-993 under serial thread order) ----
 // Event e of the frame is the e-th (row, repeat) pair in alive-list order; it is stored iff e < capacity.
-// One workgroup per chunk and channel loop: cross-chunk exclusive prefix of the chunk totals, then a
-// workgroup scan over the chunk's rows (16 consecutive rows per thread).
+// One workgroup per (chunk, split) and channel loop: cross-chunk exclusive prefix of the chunk totals, a workgroup scan over the
+// chunk's rows (16 consecutive rows per thread) whose per-row start offsets are parked in LDS, and then the chunk's events are written by
+// ALL threads in output order - thread t takes events t, t + 256, ... of the workgroup's share and finds each one's row by binary search
+// over the offsets (the stores are contiguous). A rocket that explodes into 1000 trail particles is 1000 events of ONE row: written by the
+// row's thread alone, 280 of them per frame took 0.25 ms (profiles/r03d_kernel_stats.csv); gridDim.y splits a chunk's events further, so
+// that an 8-chunk parent with 270,000 events per frame still fills the device.
 #ifndef HNB_JIT_TU
 __global__ void __launch_bounds__(kBlock)
 k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
               const DevFrameInst* __restrict__ fi, const CompactBufs cb, unsigned long long* __restrict__ ev_host, const uint32_t frame_tag) {
     __shared__ uint32_t s_red[kBlock / 64];
-    __shared__ uint32_t s_scan[kBlock];
+    __shared__ uint32_t s_scan[kBlock / 64];
+    __shared__ uint32_t s_start[kChunk + 1];   // events of this chunk in front of row r (chunk-relative); [rows] = the chunk's total
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
+    const uint32_t split = blockIdx.y, n_split = gridDim.y;
     ChunkCtx c;
     const bool has_rows = chunk_setup(c, chunk, prog, inst_base, meta_in, fi);
     const bool last = c.n == 0 ? c.j == 0 : (c.start < c.n && c.start + kChunk >= c.n);
@@ -710,36 +716,40 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
 #pragma unroll
         for (uint32_t w = 0; w < kBlock / 64; ++w) excl += s_red[w];
         const uint32_t mine = has_rows ? tot[(size_t)c.j * HNB_MAX_EVENT_CHANNELS] : 0u;
-        if (last && tid == 0) {
+        if (last && tid == 0 && split == 0u) {
             ev->count[fi[c.k].ev_parity] = excl + mine;  // GpuChildInfo::event_count of this frame
             // ... and a copy for the host ({frame, count} in host-mapped memory, no read-back): when it has arrived by the time the next
             // frame is enqueued, the child's init grid is sized for the events that exist instead of for the buffer's capacity
             if (ev_host) *reinterpret_cast<volatile unsigned long long*>(ev_host + (size_t)c.k * HNB_MAX_EVENT_CHANNELS + ch) = ((unsigned long long)(excl + mine) << 32) | frame_tag;
         }
-        if (mine == 0u) continue;
+        const uint32_t capacity = ev->capacity;
+        if (mine == 0u || excl >= capacity) continue;   // (uniform: every thread of the workgroup takes the same way)
         const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c.base + prog.ev_cnt_off[ch]);                 // per slot
         const uint32_t* slots = reinterpret_cast<const uint32_t*>(c.base + prog.alive_off[c.m.write_index]) + c.start;  // rows as the update saw them
-        uint32_t local = 0;
-        for (uint32_t r = 0; r < kPer; ++r) { const uint32_t row = tid * kPer + r; if (row < rows) local += cnt[slots[row]]; }
+        uint32_t n_ev[kPer], local = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < kPer; ++r) { const uint32_t row = tid * kPer + r; n_ev[r] = row < rows ? cnt[slots[row]] : 0u; local += n_ev[r]; }
         // workgroup exclusive scan of the per-thread sums
         uint32_t incl = local;
 #pragma unroll
         for (uint32_t off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
         if (lane == 63) s_scan[wave] = incl;
         __syncthreads();
-        uint32_t wbase = 0;
-        for (uint32_t w = 0; w < wave; ++w) wbase += s_scan[w];
-        uint32_t pos = excl + wbase + incl - local;
-        const uint32_t capacity = ev->capacity;
-        for (uint32_t r = 0; r < kPer && pos < capacity; ++r) {
-            const uint32_t row = tid * kPer + r;
-            if (row >= rows) break;
-            const uint32_t slot = slots[row];
-            const uint32_t n_ev = cnt[slot];
-            if (!n_ev) continue;
-            const uint32_t end = pos + n_ev < capacity ? pos + n_ev : capacity;
-            for (uint32_t e = pos; e < end; ++e) ev->data[e] = slot;
-            pos += n_ev;
+        uint32_t pos = incl - local;
+        for (uint32_t w = 0; w < wave; ++w) pos += s_scan[w];
+#pragma unroll
+        for (uint32_t r = 0; r < kPer; ++r) { s_start[tid * kPer + r] = pos; pos += n_ev[r]; }
+        if (tid == kBlock - 1u) s_start[kChunk] = pos;   // == mine
+        __syncthreads();
+        // this workgroup's share of the chunk's events, in output order; an event past the buffer's capacity is dropped
+        const uint32_t room = capacity - excl;
+        const uint32_t total = mine < room ? mine : room;
+        const uint32_t per_split = (total + n_split - 1u) / n_split;
+        const uint32_t lo_e = split * per_split, hi_e = (lo_e + per_split) < total ? (lo_e + per_split) : total;
+        for (uint32_t e = lo_e + tid; e < hi_e; e += kBlock) {
+            uint32_t lo = 0, hi = kChunk;   // the last row r with s_start[r] <= e (rows without events share their successor's start: skipped by "last")
+            while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= e) lo = mid; else hi = mid; }
+            ev->data[excl + e] = slots[lo];
         }
         __syncthreads();
     }
@@ -769,13 +779,15 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
 // chunk-local / cross-chunk compaction as before, and to k_emit_events.
 struct SlotArgs {
     uint32_t capacity, n_uregs, chunks_per_inst, n_inst;
-    uint32_t alive_flag_off, update_len;
-    uint32_t plane_off[4];   // position, velocity, age, lifetime
+    soff_t alive_flag_off;
+    uint32_t update_len;
+    soff_t plane_off[4];     // position, velocity, age, lifetime
     uint32_t flags;          // bit i: load pinned attr i; bit 4+i: store pinned attr i
-    uint32_t died_bits_off;  // DevProgram::died_bits_off; written (all of it) iff write_died: the frame's list kernels read it
+    soff_t died_bits_off;    // DevProgram::died_bits_off; written (all of it) iff write_died: the frame's list kernels read it
     uint32_t write_died;
     uint32_t cull_lifetime;  // 1: lifetime culling (below); lmin_off = f32[chunks_per_inst] in the slab, dt_operand = operand a of the AGE_TICK
-    uint32_t lmin_off, dt_operand;
+    soff_t lmin_off;
+    uint32_t dt_operand;
     uint32_t age_cohort;     // 1: chunks whose alive particles all have the same AGE keep it in one word (below)
     const Ins* update_code;
     // "No particle can die before ..." (below): safe_words = u32[2][safe_stride] float bits, the frame's minimum remaining life
@@ -1205,7 +1217,7 @@ k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_
 #ifndef HNB_JIT_TU
 // Writes the common age of every cohort chunk (state 1) into the AGE plane for its alive slots: before the host reads the plane.
 __global__ void __launch_bounds__(kBlock)
-k_materialise_age(char* __restrict__ base, uint32_t capacity, uint32_t chunks_per_inst, uint32_t lmin_off, uint32_t age_plane_off, uint32_t alive_flag_off) {
+k_materialise_age(char* __restrict__ base, uint32_t capacity, uint32_t chunks_per_inst, soff_t lmin_off, soff_t age_plane_off, soff_t alive_flag_off) {
     const uint32_t j = blockIdx.x;
     const uint32_t* astate = reinterpret_cast<const uint32_t*>(base + lmin_off) + 2u * chunks_per_inst;
     const uint32_t* aval = astate + chunks_per_inst;

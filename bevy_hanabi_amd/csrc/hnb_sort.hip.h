@@ -36,13 +36,13 @@ constexpr uint32_t kSortGroup = 32;
 
 struct SortArgs {
     uint32_t capacity, chunks_per_inst;   // chunks_per_inst = ceil(capacity / kSortTile) here
-    uint32_t alive_off[2];
-    uint32_t key_off[2];   // u64[capacity] ping-pong
-    uint32_t val_off[2];   // u32[capacity] ping-pong
-    uint32_t hist_off;     // u32[chunks_per_inst][256]: per-tile digit counts of the current pass
-    uint32_t gsum_off;     // u32[8 passes][groups][256]: digit counts per group of kSortGroup tiles (zeroed by k_sort_fill)
-    uint32_t bits_off;     // SortState[2]: per frame parity
-    uint32_t rid_plane, age_plane;  // plane offsets (kNoPlane: key half is 0)
+    soff_t alive_off[2];
+    soff_t key_off[2];     // u64[capacity] ping-pong
+    soff_t val_off[2];     // u32[capacity] ping-pong
+    soff_t hist_off;       // u32[chunks_per_inst][256]: per-tile digit counts of the current pass
+    soff_t gsum_off;       // u32[8 passes][groups][256]: digit counts per group of kSortGroup tiles (zeroed by k_sort_fill)
+    soff_t bits_off;       // SortState[2]: per frame parity
+    soff_t rid_plane, age_plane;    // plane offsets (v == kNoPlane: key half is 0)
     uint32_t parity;       // frame parity of the state double buffer
 };
 
@@ -122,8 +122,8 @@ k_sort_fill(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevM
     const uint32_t* list = reinterpret_cast<const uint32_t*>(base + a.alive_off[meta[k].write_index & 1u]);
     uint64_t* keys = reinterpret_cast<uint64_t*>(base + a.key_off[0]);
     uint32_t* vals = reinterpret_cast<uint32_t*>(base + a.val_off[0]);
-    const uint32_t* rid = a.rid_plane == kNoPlane ? nullptr : reinterpret_cast<const uint32_t*>(base + a.rid_plane);
-    const uint32_t* age = a.age_plane == kNoPlane ? nullptr : reinterpret_cast<const uint32_t*>(base + a.age_plane);
+    const uint32_t* rid = a.rid_plane.v == kNoPlane ? nullptr : reinterpret_cast<const uint32_t*>(base + a.rid_plane);
+    const uint32_t* age = a.age_plane.v == kNoPlane ? nullptr : reinterpret_cast<const uint32_t*>(base + a.age_plane);
     uint64_t or_all = 0ull, and_all = ~0ull, or_tail = 0ull, and_tail = ~0ull;
     auto key_of = [&](uint32_t slot) { return ((uint64_t)(rid ? rid[slot] : 0u) << 32) | (uint64_t)(age ? age[slot] : 0u); };
     // Is the HEAD (rows before this frame's spawns) still in non-decreasing key order? (It was a launch of its own, k_sort_check.) Every lane

@@ -69,8 +69,16 @@ constexpr uint32_t kNoPlane = 0xffffffffu;
 
 // Attribute table entry as the kernels see it, and the per-particle window onto the SoA planes
 // used by HNB_OP_LDA / HNB_OP_STA (non-pinned attributes are memory operands).
+// A byte offset inside an instance slab, kept in units of 256 bytes (every section of a slab is 256-byte aligned): 32 bits reach 1 TiB, so a
+// slab is not limited to 4 GiB - EffectAsset::capacity is a u32 (src/asset.rs:391-415), and a 100M-particle firework needs 6.6 GB. Converts
+// to size_t wherever it meets a pointer (`base + off`).
+struct soff_t {
+    uint32_t v;
+    HNB_HD_MEMBER operator size_t() const { return (size_t)v << 8; }
+};
+HNB_HD soff_t soff_of(uint64_t bytes) { soff_t o; o.v = (uint32_t)(bytes >> 8); return o; }
 struct AttrDesc {
-    uint32_t plane_off;   // byte offset of the attribute plane from the instance slab base
+    soff_t plane_off;     // offset of the attribute plane from the instance slab base
     uint8_t ncomp;        // 32-bit components per particle (packed, vec3 = 12 B)
     uint8_t reg;          // first V register (pinned attributes) or HNB_REG_NONE
     uint8_t upd_flags;    // HNB_ATTR_UPD_*
@@ -82,7 +90,7 @@ struct VmAttrIO {
     uint32_t slot;           // this particle's slot
     // parent particle that triggered this spawn (init of an effect with a parent, vfx_init.wgsl:166-171)
     const char* parent_slab = nullptr;          // parent instance slab base
-    const uint32_t* parent_planes = nullptr;    // [HNB_ATTR_COUNT] plane byte offsets of the parent layout (kNoPlane = absent)
+    const uint32_t* parent_planes = nullptr;    // [HNB_ATTR_COUNT] plane offsets of the parent layout in 256-byte units (soff_t::v; kNoPlane = absent)
     uint32_t parent_slot = 0;
 };
 HNB_HD uint32_t* vm_attr_ptr(const VmAttrIO& io, uint32_t idx) {
@@ -459,7 +467,7 @@ HNB_HD void vm_exec(const Ins ins, ST& S, const VmUniforms& U, const uint32_t* p
             case HNB_OP_LDPARENT:
                 if constexpr (!USTREAM) {
                     nout = w;
-                    const uint32_t* p = reinterpret_cast<const uint32_t*>(io.parent_slab + io.parent_planes[aux]) + (size_t)io.parent_slot * w;
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(io.parent_slab + ((size_t)io.parent_planes[aux] << 8)) + (size_t)io.parent_slot * w;
                     o.v0 = p[0];
                     o.v1 = w > 1 ? p[1] : 0u;
                     o.v2 = w > 2 ? p[2] : 0u;

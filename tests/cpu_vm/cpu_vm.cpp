@@ -152,7 +152,7 @@ CpuVm* cvm_create(const uint8_t* blob, size_t size, uint32_t slot_base) {
     size_t off = 0;
     for (auto& a : v->attrs) {
         AttrDesc d;
-        d.plane_off = (uint32_t)off; d.ncomp = a.ncomp; d.reg = a.reg; d.upd_flags = a.update_flags; d.pad = 0;
+        d.plane_off = hnb::soff_of(off); d.ncomp = a.ncomp; d.reg = a.reg; d.upd_flags = a.update_flags; d.pad = 0;
         v->adesc.push_back(d);
         off += ((size_t)h.capacity * a.ncomp * 4 + 255) / 256 * 256;
     }

@@ -264,6 +264,53 @@ def test_c2_events_real_firework_at_baseline_size(ctx):
     g.destroy()
 
 
+def test_100m_particle_firework_past_the_4_gib_slab_limit(ctx):
+    """EffectAsset::capacity is a u32 (src/asset.rs:391-415); round 2's slabs stopped at 4 GiB (87.6M firework particles). 100,000,000
+    particles are a 6.6 GB slab whose LIFETIME and COLOR planes, alive bytes, per-chunk words, died bits and row masks all lie beyond
+    4 GiB. Burst, two frames of flight, then two frames of dt = 0.45 s that kill about a third and then all of them (lists compacted at
+    100M rows). Checked: sampled 4096-slot windows of every plane against an oracle effect with that slot_base (a burst fills slot i with
+    PRNG stream i, so a window of the giant effect IS a small effect with slot_base - the capacity-slab argument of SURVEY.md 8e), and,
+    over all 100M slots, the counters, the alive list (stable compaction: ascending slots, exactly the particles with age < lifetime)
+    and the dead list (casualties in serial order)."""
+    cap = 100_000_000
+    asset = effects.firework_trails(cap)
+    r = GpuRunner(asset, ctx=ctx)
+    dts = [1 / 60, 1 / 60, 1 / 60, 0.45, 0.45, 0.45]
+    bases = [0, 4096 * 9973, 65_000_000, cap - 4096]
+    orcs = [OracleRunner(effects.firework_trails(4096), slot_base=b) for b in bases]
+    t = 0.0
+    for f, dt in enumerate(dts):
+        fr = Frame(dt, cap if f == 0 else 0, frame_seed(f), time=t)
+        t += dt
+        r.step(fr)
+        for o in orcs:
+            o.step(Frame(dt, 4096 if f == 0 else 0, frame_seed(f), time=fr.time))
+        if f in (2, 4):
+            planes = {a.name: r.fx.read_attr(a.id).view(np.uint32) for a in (A.POSITION, A.VELOCITY, A.AGE, A.LIFETIME, A.COLOR)}
+            for b, o in zip(bases, orcs):
+                ref = o.state()
+                for name, pl in planes.items():
+                    np.testing.assert_array_equal(ref["attrs"][name], pl[b:b + 4096], err_msg=f"frame {f}, window at {b}: {name}")
+            m = r.fx.metadata()
+            age = planes["age"].view(np.float32)[:, 0]
+            life = planes["lifetime"].view(np.float32)[:, 0]
+            if f == 2:
+                assert m["alive_count"] == cap and m["fault"] == 0
+                np.testing.assert_array_equal(r.fx.alive_list(), np.arange(cap, dtype=np.uint32))
+            else:
+                # a slot is alive iff its (common, burst) age is below its lifetime; dead slots keep the age they died with
+                survivors = np.flatnonzero(age < life).astype(np.uint32)
+                assert 0 < len(survivors) < cap and m["alive_count"] == len(survivors) and m["fault"] == 0
+                np.testing.assert_array_equal(r.fx.alive_list(), survivors)
+                dead = r.fx.dead_list()
+                assert len(dead) == cap - len(survivors)
+                # the frame-3 and frame-4 casualties, each frame's in serial (ascending slot) order, last-killed on top of the stack
+                assert len(np.unique(dead)) == len(dead) and not np.isin(dead[:1000], survivors[:100000]).any()
+            del planes
+    assert r.fx.alive_count() == 0
+    r.fx.destroy(); r.prog.destroy()
+
+
 def test_c4_instancing_one_gpu_share_at_baseline_size(ctx):
     """instancing.rs, 512 instances x 65,536 (one GPU's share of BASELINE config 4: 4096 instances over 8 GPUs, instance i
     on rank i mod 8 — rank 0 owns 0, 8, 16, ...). dt = 3 s with the rate spawner: a quarter of the capacity spawns per frame
