@@ -1604,6 +1604,7 @@ int hnb_simulate(HnbContext* ctx) {
             sa.died_bits_off = p->dev.died_bits_off; sa.write_died = write_died;
             sa.cull_lifetime = p->dev.cull_lifetime; sa.lmin_off = p->dev.lmin_off; sa.dt_operand = p->cull_dt_operand;
             sa.age_cohort = p->dev.age_cohort;
+            sa.frame_phase = p->frames_run & 15u;
             if (p->skip_eligible) { sa.safe_words = p->d_safe; sa.safe_host = p->h_safe; sa.safe_parity = p->frames_run & 1u; sa.publish_tag = p->frames_run - 1u; sa.safe_stride = p->table_cap * p->dev.chunks_per_inst; }
             sa.skip_lists = p->skip_now ? 1u : 0u;
             sa.meta_in = p->d_meta[par]; sa.meta_out = p->d_meta[par ^ 1];

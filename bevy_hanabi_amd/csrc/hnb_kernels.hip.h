@@ -239,7 +239,7 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
         if (prog.age_cohort) {  // a chunk that keeps its particles' common age in one word: this slot's age is in the plane (state 2, byte 3)
             uint32_t* astate = reinterpret_cast<uint32_t*>(base + prog.lmin_off) + 2u * prog.chunks_per_inst;
             const uint32_t st = astate[slot / kChunk];
-            if (st != 0u) { if (st != 2u) astate[slot / kChunk] = 2u; alive_byte = 3u; }
+            if (st == 1u || st == 2u) { if (st != 2u) astate[slot / kChunk] = 2u; alive_byte = 3u; }   // (0, 4: the plane holds every age of the chunk)
         }
         reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = alive_byte;
         if (prog.cull_lifetime) reinterpret_cast<float*>(base + prog.lmin_off)[slot / kChunk] = 0.0f;  // the chunk's lifetime bound is unknown again
@@ -680,19 +680,21 @@ k_order_write(const CompactArgs args, const uint64_t* __restrict__ inst_base, co
 
 // ---- k_emit_events: order the staged spawn events (src/lib.rs:976-993 under serial thread order) ----
 // Event e of the frame is the e-th (row, repeat) pair in alive-list order; it is stored iff e < capacity.
-// One workgroup per (chunk, split) and channel loop: cross-chunk exclusive prefix of the chunk totals, a workgroup scan over the
-// chunk's rows (16 consecutive rows per thread) whose per-row start offsets are parked in LDS, and then the chunk's events are written by
-// ALL threads in output order - thread t takes events t, t + 256, ... of the workgroup's share and finds each one's row by binary search
-// over the offsets (the stores are contiguous). A rocket that explodes into 1000 trail particles is 1000 events of ONE row: written by the
-// row's thread alone, 280 of them per frame took 0.25 ms (profiles/r03d_kernel_stats.csv); gridDim.y splits a chunk's events further, so
-// that an 8-chunk parent with 270,000 events per frame still fills the device.
+// One workgroup per (chunk, split) and channel loop: cross-chunk exclusive prefix of the chunk totals, then a workgroup scan over the
+// chunk's rows (16 consecutive rows per thread) gives every row the index of its first event. Rows with FEW events (EventEmitCondition::
+// Always: a handful per particle and frame) are written by their own thread; rows with MANY (OnDie: a rocket explodes into 1000 trail
+// particles) are queued in LDS and written by the whole workgroup, 256 contiguous events per round, the heavy rows dealt round-robin to
+// the gridDim.y workgroups of the chunk. (One thread writing its row's 1000 events alone: 0.25 ms per frame for 280 explosions; a
+// binary search per event over the row offsets in LDS: 0.28 ms, a chain of dependent LDS reads; profiles/r03d, r03e.)
 #ifndef HNB_JIT_TU
+constexpr uint32_t kEmitHeavy = 32u;   // events of one row from which the workgroup writes them together
 __global__ void __launch_bounds__(kBlock)
 k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
               const DevFrameInst* __restrict__ fi, const CompactBufs cb, unsigned long long* __restrict__ ev_host, const uint32_t frame_tag) {
     __shared__ uint32_t s_red[kBlock / 64];
     __shared__ uint32_t s_scan[kBlock / 64];
-    __shared__ uint32_t s_start[kChunk + 1];   // events of this chunk in front of row r (chunk-relative); [rows] = the chunk's total
+    __shared__ uint32_t s_heavy_n;
+    __shared__ uint32_t s_heavy[kChunk][3];   // (slot, first event, events) of the chunk's heavy rows
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
     const uint32_t split = blockIdx.y, n_split = gridDim.y;
@@ -711,6 +713,7 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
         for (uint32_t off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
         __syncthreads();
         if (lane == 0) s_red[wave] = part;
+        if (tid == 0) s_heavy_n = 0u;
         __syncthreads();
         uint32_t excl = 0;
 #pragma unroll
@@ -726,30 +729,39 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
         if (mine == 0u || excl >= capacity) continue;   // (uniform: every thread of the workgroup takes the same way)
         const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c.base + prog.ev_cnt_off[ch]);                 // per slot
         const uint32_t* slots = reinterpret_cast<const uint32_t*>(c.base + prog.alive_off[c.m.write_index]) + c.start;  // rows as the update saw them
-        uint32_t n_ev[kPer], local = 0;
+        uint32_t slot[kPer], n_ev[kPer], local = 0;
 #pragma unroll
-        for (uint32_t r = 0; r < kPer; ++r) { const uint32_t row = tid * kPer + r; n_ev[r] = row < rows ? cnt[slots[row]] : 0u; local += n_ev[r]; }
+        for (uint32_t r = 0; r < kPer; ++r) {
+            const uint32_t row = tid * kPer + r;
+            slot[r] = row < rows ? slots[row] : 0u;
+            n_ev[r] = row < rows ? cnt[slot[r]] : 0u;
+            local += n_ev[r];
+        }
         // workgroup exclusive scan of the per-thread sums
         uint32_t incl = local;
 #pragma unroll
         for (uint32_t off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
         if (lane == 63) s_scan[wave] = incl;
         __syncthreads();
-        uint32_t pos = incl - local;
+        uint32_t pos = excl + incl - local;
         for (uint32_t w = 0; w < wave; ++w) pos += s_scan[w];
 #pragma unroll
-        for (uint32_t r = 0; r < kPer; ++r) { s_start[tid * kPer + r] = pos; pos += n_ev[r]; }
-        if (tid == kBlock - 1u) s_start[kChunk] = pos;   // == mine
+        for (uint32_t r = 0; r < kPer; ++r) {
+            if (n_ev[r] >= kEmitHeavy) {          // queued for the whole workgroup (any order: every entry carries its own range)
+                const uint32_t h = atomicAdd(&s_heavy_n, 1u);
+                s_heavy[h][0] = slot[r]; s_heavy[h][1] = pos; s_heavy[h][2] = n_ev[r];
+            } else if (split == 0u) {             // a few events: this thread writes them (an event past the buffer's capacity is dropped)
+                const uint32_t end = pos + n_ev[r] < capacity ? pos + n_ev[r] : capacity;
+                for (uint32_t e = pos; e < end; ++e) ev->data[e] = slot[r];
+            }
+            pos += n_ev[r];
+        }
         __syncthreads();
-        // this workgroup's share of the chunk's events, in output order; an event past the buffer's capacity is dropped
-        const uint32_t room = capacity - excl;
-        const uint32_t total = mine < room ? mine : room;
-        const uint32_t per_split = (total + n_split - 1u) / n_split;
-        const uint32_t lo_e = split * per_split, hi_e = (lo_e + per_split) < total ? (lo_e + per_split) : total;
-        for (uint32_t e = lo_e + tid; e < hi_e; e += kBlock) {
-            uint32_t lo = 0, hi = kChunk;   // the last row r with s_start[r] <= e (rows without events share their successor's start: skipped by "last")
-            while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= e) lo = mid; else hi = mid; }
-            ev->data[excl + e] = slots[lo];
+        const uint32_t n_heavy = s_heavy_n;
+        for (uint32_t h = split; h < n_heavy; h += n_split) {
+            const uint32_t sl = s_heavy[h][0], first = s_heavy[h][1];
+            const uint32_t end = first + s_heavy[h][2] < capacity ? first + s_heavy[h][2] : capacity;
+            for (uint32_t e = first + tid; e < end; e += kBlock) ev->data[e] = sl;
         }
         __syncthreads();
     }
@@ -777,6 +789,7 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
 // of spawn / kill churn. The row order only matters to a second, much lighter pass over the rows of the
 // instances that lost particles (k_count_rows: 4 bytes of list + one bit gather per row), which feeds the same
 // chunk-local / cross-chunk compaction as before, and to k_emit_events.
+template <bool B> struct BoolTag { static constexpr bool value = B; };
 struct SlotArgs {
     uint32_t capacity, n_uregs, chunks_per_inst, n_inst;
     soff_t alive_flag_off;
@@ -789,6 +802,7 @@ struct SlotArgs {
     soff_t lmin_off;
     uint32_t dt_operand;
     uint32_t age_cohort;     // 1: chunks whose alive particles all have the same AGE keep it in one word (below)
+    uint32_t frame_phase;    // frames this program ran, mod 16: staggers the re-check of chunks known to hold mixed ages (cohort state 4)
     const Ins* update_code;
     // "No particle can die before ..." (below): safe_words = u32[2][safe_stride] float bits, the frame's minimum remaining life
     // per chunk, double-buffered by safe_parity; safe_host = host-mapped {frame tag, bound bits} the host reads without any
@@ -832,7 +846,9 @@ struct SlotArgs {
 //   state 0  the AGE plane holds every age (the default);
 //   state 1  every alive particle of the chunk has age == value; the plane is stale for the alive slots (dead slots keep the age
 //            they died with: the kernel stores the age of a particle in the frame it dies, as the reference's write-back does);
-//   state 2  state 1 + this frame's spawns, whose ages ARE in the plane and whose alive byte is 3 (k_init sets both; within a frame only).
+//   state 2  state 1 + this frame's spawns, whose ages ARE in the plane and whose alive byte is 3 (k_init sets both; within a frame only);
+//   state 4  state 0, and the last check found survivors of DIFFERENT ages: the check (min / max over the survivors' age bits in every
+//            step) is skipped in fifteen frames of sixteen, and the chunk runs the per-particle path without any cohort bookkeeping.
 // The update reads the state, takes the value instead of the plane where it may (2: per slot, by the alive byte), and after the
 // program checks whether the survivors' new ages are all equal (min == max of their bit patterns): then it writes the value
 // and skips the plane, else it stores the ages (which materialises them) and returns to state 0. Host reads of the AGE plane
@@ -909,7 +925,12 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     const bool chunk_full = cfull[j] == 1u;
     uint32_t* astate = cfull + args.chunks_per_inst;      // age cohorts: state and value per chunk
     uint32_t* aval = astate + args.chunks_per_inst;
-    const uint32_t ast = COHORT ? astate[j] : 0u;      // wave-uniform
+    // (state 4: "the chunk holds particles of different ages" - found by the check below. Such a chunk is not checked again in every frame -
+    // in a spawn / die steady state it never becomes uniform, and the bookkeeping of the check is a third of the per-particle path's
+    // instructions - but in one frame of sixteen, staggered over the chunks; everywhere else state 4 is state 0: the plane holds the ages)
+    const uint32_t ast_raw = COHORT ? astate[j] : 0u;  // wave-uniform
+    const bool mixed = COHORT && ast_raw == 4u && ((args.frame_phase + j) & 15u) != 0u;
+    const uint32_t ast = ast_raw == 4u ? 0u : ast_raw;
     const float A = COHORT ? u2f(aval[j]) : 0.0f;
     uint32_t amin = 0xffffffffu, amax = 0u;               // bit patterns of the ages of the particles that stay alive
     uint32_t lane_alive = 0;
@@ -958,23 +979,25 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
             loaded_all = false;                                            // no lifetime was loaded: the chunk's bound stands
             if (args.safe_words) rem_min = (Lm - A2) - 1.0e-5f * Lm;       // as the per-particle form computes it from X.lifetime = Lm, X.age = A2
         }
-    } else
-#pragma unroll
-    for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
+    }
+    // ---- the per-particle path, one wave step (256 slots, 4 per lane). COH: with the age-cohort bookkeeping (a chunk that is known to hold
+    // mixed ages - state 4 - runs without it: see `mixed` above)
+    auto step_body = [&](auto coh_tag, const uint32_t step) {
+        constexpr bool COH = decltype(coh_tag)::value;
         const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;  // first of this lane's 4 slots
         const uint32_t f4 = chunk_full ? 0x01010101u : (s0 < args.capacity ? flags4[s0 >> 2] : 0u);  // the plane is padded: slots past the capacity read 0
         bool was[4], fresh[4];  // fresh: spawned this frame into a chunk that kept its ages in the value word (alive byte 3, state 2 only)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const uint32_t byte = (f4 >> (8 * p)) & 0xffu;
-            fresh[p] = COHORT && byte == 3u;
+            fresh[p] = COH && byte == 3u;
             was[p] = byte == 1u || fresh[p];
             lane_alive += was[p] ? 1u : 0u;
         }
         const bool any = was[0] || was[1] || was[2] || was[3];
         if (!__any(any)) {
             if (args.write_died) store_died_bits(reinterpret_cast<uint32_t*>(base + args.died_bits_off), s0 - lane * 4u, 0u, lane);
-            continue;
+            return;
         }
         const bool full = was[0] && was[1] && was[2] && was[3];
         uint32_t slot[4];
@@ -1000,8 +1023,8 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
                 if (fl & 2u) pin_load3<4>(X.vel, p_vel, slot, lanes_on, true);
             }
             if (fl & 4u) {
-                if (!COHORT || ast != 1u) { pin_load1<4>(X.age, p_age, slot, lanes_on, true); for (int p = 0; p < 4; ++p) age_was[p] = X.age[p]; }
-                if (COHORT && ast != 0u) {   // (selects, no divergence: ast is uniform, fresh[] only ever set in state 2)
+                if (!COH || ast != 1u) { pin_load1<4>(X.age, p_age, slot, lanes_on, true); for (int p = 0; p < 4; ++p) age_was[p] = X.age[p]; }
+                if (COH && ast != 0u) {   // (selects, no divergence: ast is uniform, fresh[] only ever set in state 2)
 #pragma unroll
                     for (int p = 0; p < 4; ++p) X.age[p] = fresh[p] ? X.age[p] : A;
                 }
@@ -1031,7 +1054,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
                 if ((fl & 16u) && !xp_pos) pin_store3<4>(X.pos, p_pos, slot, was, full);
                 if ((fl & 32u) && !xp_vel) pin_store3<4>(X.vel, p_vel, slot, was, full);
                 if (fl & 64u) {
-                    if (!COHORT || ast != 1u) {
+                    if (!COH || ast != 1u) {
                         if ((fl & 4u) && !full) {   // loaded above: blend in registers, one 16-byte store
                             float q[4];
 #pragma unroll
@@ -1058,7 +1081,7 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
             for (int p = 0; p < 4; ++p)
                 if (was[p] && X.alive[p]) rem_min = fminf(rem_min, (X.lifetime[p] - X.age[p]) - 1.0e-5f * X.lifetime[p]);
         }
-        if constexpr (COHORT) {
+        if constexpr (COH) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {   // min / max of the survivors' age bits (selects)
                 const bool stays = was[p] && X.alive[p];
@@ -1083,12 +1106,21 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
         for (int p = 0; p < 4; ++p) {
             const bool died = was[p] && !X.alive[p];
             if (died) { nf &= ~(0xffu << (8 * p)); nib |= 1u << p; }   // the slot is free from now on; the lists learn it from the died bit
-            else if (COHORT && fresh[p]) nf = (nf & ~(0xffu << (8 * p))) | (1u << (8 * p));   // an ordinary alive slot from now on
+            else if (COH && fresh[p]) nf = (nf & ~(0xffu << (8 * p))) | (1u << (8 * p));   // an ordinary alive slot from now on
             died_here += (uint32_t)__popcll(__ballot(died));
         }
         if (nf != f4) flags4[s0 >> 2] = nf;
         if (args.write_died) store_died_bits(reinterpret_cast<uint32_t*>(base + args.died_bits_off), step_first, nib, lane);
         died_total += died_here;
+    };
+    if (!flat) {
+        if (mixed) {
+#pragma unroll
+            for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step);
+        } else {
+#pragma unroll
+            for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<COHORT>{}, step);
+        }
     }
     if (cull) {
 #pragma unroll
@@ -1117,15 +1149,16 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     if (lane == 0) { s_died[wave] = died_total; s_lmin[wave] = loaded_all ? wave_min : -1.0f; }
     __syncthreads();
     if (tid == 0) {
-        if constexpr (COHORT) {   // do the survivors share one age? (amin > amax: there are none)
+        if (COHORT && !mixed) {   // do the survivors share one age? (amin > amax: there are none)
             uint32_t lo = 0xffffffffu, hi = 0u;
 #pragma unroll
             for (uint32_t w = 0; w < kBlock / 64; ++w) { lo = s_amin[w] < lo ? s_amin[w] : lo; hi = s_amax[w] > hi ? s_amax[w] : hi; }
-            const uint32_t now = (lo == hi) ? 1u : 0u;
             // a chunk that was NOT in state 1 stored its ages in this launch; one that was, did not: it may only stay in state 1
-            // (same value for all survivors by construction) or empty out (lo > hi -> 0: nothing alive, the plane is right for the dead)
-            if (now) aval[j] = lo;
-            if (now != ast) astate[j] = now;
+            // (same value for all survivors by construction) or empty out (lo > hi -> 0: nothing alive, the plane is right for the dead).
+            // Survivors of different ages: state 4, the plane holds them and the check takes a rest
+            const uint32_t next = (lo == hi) ? 1u : (lo > hi ? 0u : 4u);
+            if (next == 1u) aval[j] = lo;
+            if (next != ast_raw) astate[j] = next;
         }
         uint32_t d = 0;
 #pragma unroll
