@@ -59,13 +59,13 @@ constexpr uint32_t kFrameRing = 4;
 typedef void (*StreamLaunchFn)(uint32_t grid, hipStream_t stream, const SlotArgs& sa, const uint64_t* inst_base, const DevFrameInst* fi,
                                const uint32_t* ublocks, const CompactBufs& cb);
 #ifndef HNB_STREAM_WAVES_COHORT
-#define HNB_STREAM_WAVES_COHORT 5
+#define HNB_STREAM_WAVES_COHORT 4   // 97 VGPRs, no scratch (a 5-wave budget: 96 + 8 bytes of scratch; A/B on one box, profiles/r03f_waves_ab.log: c2 the same, c2_mixed 0.215 vs 0.228 ms)
 #endif
 template <class PROG, int WAVES>
 void launch_stream(uint32_t grid, hipStream_t stream, const SlotArgs& sa, const uint64_t* inst_base, const DevFrameInst* fi,
                    const uint32_t* ublocks, const CompactBufs& cb) {
-    // (the age-cohort paths need a few registers more: budgeted for 6 waves (80 VGPRs) the per-particle path of the firework kernel spilled 48 bytes
-    // per lane to scratch; for 5 waves it takes 93 VGPRs and none. Round 2 measured budgets of 4 to 8 waves within 1 % of each other on this kernel.)
+    // (the age-cohort paths need more registers: budgeted for 6 waves (80 VGPRs) the per-particle path of the firework kernel spilled 48 bytes
+    // per lane to scratch; see HNB_STREAM_WAVES_COHORT)
     if (sa.age_cohort) k_update_slots_stream<PROG, (WAVES > HNB_STREAM_WAVES_COHORT ? HNB_STREAM_WAVES_COHORT : WAVES), 0, true><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
     else k_update_slots_stream<PROG, WAVES, 0, false><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
 }

@@ -683,7 +683,7 @@ k_order_write(const CompactArgs args, const uint64_t* __restrict__ inst_base, co
 // One workgroup per (chunk, split) and channel loop: cross-chunk exclusive prefix of the chunk totals, then a workgroup scan over the
 // chunk's rows (16 consecutive rows per thread) gives every row the index of its first event. Rows with FEW events (EventEmitCondition::
 // Always: a handful per particle and frame) are written by their own thread; rows with MANY (OnDie: a rocket explodes into 1000 trail
-// particles) are queued in LDS and written by the whole workgroup, 256 contiguous events per round, the heavy rows dealt round-robin to
+// particles) are queued in LDS and written by the whole workgroup, 256 contiguous events per round, the heavy rows dealt by row index to
 // the gridDim.y workgroups of the chunk. (One thread writing its row's 1000 events alone: 0.25 ms per frame for 280 explosions; a
 // binary search per event over the row offsets in LDS: 0.28 ms, a chain of dependent LDS reads; profiles/r03d, r03e.)
 #ifndef HNB_JIT_TU
@@ -747,9 +747,11 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
         for (uint32_t w = 0; w < wave; ++w) pos += s_scan[w];
 #pragma unroll
         for (uint32_t r = 0; r < kPer; ++r) {
-            if (n_ev[r] >= kEmitHeavy) {          // queued for the whole workgroup (any order: every entry carries its own range)
-                const uint32_t h = atomicAdd(&s_heavy_n, 1u);
-                s_heavy[h][0] = slot[r]; s_heavy[h][1] = pos; s_heavy[h][2] = n_ev[r];
+            if (n_ev[r] >= kEmitHeavy) {          // queued for the whole workgroup (any order: every entry carries its own range) - of the
+                if ((tid * kPer + r) % n_split == split) {   // split that owns the ROW (the queue order differs from workgroup to workgroup)
+                    const uint32_t h = atomicAdd(&s_heavy_n, 1u);
+                    s_heavy[h][0] = slot[r]; s_heavy[h][1] = pos; s_heavy[h][2] = n_ev[r];
+                }
             } else if (split == 0u) {             // a few events: this thread writes them (an event past the buffer's capacity is dropped)
                 const uint32_t end = pos + n_ev[r] < capacity ? pos + n_ev[r] : capacity;
                 for (uint32_t e = pos; e < end; ++e) ev->data[e] = slot[r];
@@ -758,7 +760,7 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
         }
         __syncthreads();
         const uint32_t n_heavy = s_heavy_n;
-        for (uint32_t h = split; h < n_heavy; h += n_split) {
+        for (uint32_t h = 0; h < n_heavy; ++h) {
             const uint32_t sl = s_heavy[h][0], first = s_heavy[h][1];
             const uint32_t end = first + s_heavy[h][2] < capacity ? first + s_heavy[h][2] : capacity;
             for (uint32_t e = first + tid; e < end; e += kBlock) ev->data[e] = sl;

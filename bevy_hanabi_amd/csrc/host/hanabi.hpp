@@ -551,13 +551,27 @@ class ShaderWriter {
     bool is_attribute_pointer() const { return attribute_pointer_; }
     std::string eval(const Module& module, ExprHandle handle);
     std::string make_local_var();
+    void push_stmt(const std::string& stmt) { main_code += stmt; main_code += "\n"; }   // modifier/mod.rs:325-328
+    // `make_fn` (modifier/mod.rs:330-362): the body is generated in a fresh writer whose particle is a pointer; its hoisted `let varN`
+    // statements precede the body inside the function, which is appended to extra_code.
+    template <class F>
+    void make_fn(const std::string& func_name, const std::string& args, Module& module, F&& body_of) {
+        ShaderWriter ctx = ShaderWriter(context_).with_attribute_pointer();
+        const std::string body = body_of(module, ctx);
+        extra_code += ctx.extra_code;
+        extra_code += "fn " + func_name + "(" + args + ") {\n" + ctx.main_code + body + "}";
+    }
+    void set_emits_gpu_spawn_events(bool use_events);   // modifier/mod.rs:262-281
+    int emits_gpu_spawn_events() const { return emits_events_; }   // -1: no modifier said
     std::string main_code;
+    std::string extra_code;   // functions emitted at shader top level, called from main_code
 
    private:
     std::string hoist_if_side_effect(const std::string& code, bool side_effect);
     uint32_t context_;
     bool attribute_pointer_;
     uint32_t var_counter_ = 0;
+    int emits_events_ = -1;
     std::map<uint32_t, std::string> expr_cache_;
 };
 
@@ -602,6 +616,22 @@ class EffectAsset {
     Module module_;
     std::vector<Modifier> init_, update_, render_;
 };
+
+// The simulation side of `EffectShaderSources::generate` (src/lib.rs:1026-1302) as WGSL TEXT: what the reference pastes into
+// vfx_init.wgsl ({{INIT_CODE}}, {{INIT_EXTRA}}, {{SIMULATION_SPACE_TRANSFORM_PARTICLE}}) and vfx_update.wgsl ({{AGE_CODE}}, {{REAP_CODE}},
+// {{UPDATE_CODE}} incl. the Euler integration, {{UPDATE_EXTRA}}, {{WRITEBACK_CODE}}). This library does not execute it - lower() produces
+// the program the HIP kernels run - but the text IS the reference's definition of the effect: tests/wgsl_eval interprets it with code that
+// shares nothing with lowering.cpp or the oracle and compares the three. Function names carry a hash of the modifier's fields like the
+// reference's (`calc_func_id`); the hash function itself (Rust's DefaultHasher) is not reproduced.
+struct WgslSources {
+    std::string init_code, init_extra, init_sim_space_transform;
+    std::string age_code, reap_code, update_code, update_extra, writeback_code;
+    bool consume_gpu_spawn_events = false, emit_gpu_spawn_events = false, read_parent_particle = false;
+    std::vector<Attribute> attributes;   // the particle struct, in layout order
+};
+WgslSources generate_wgsl(const EffectAsset& asset, bool has_parent = false);
+// `ToWgslString for CpuValue<f32>` (src/lib.rs:432-482): "1." / "(frand() * (2. - 1.) + 1.)"
+std::string to_wgsl_string(const CpuValue& v);
 
 // ---- lowering + serialisation ------------------------------------------------------------------------------------
 // `ToWgslString for f32` (src/lib.rs:264-269): literals reach the GPU with 6 decimals.

@@ -195,6 +195,20 @@ PYBIND11_MODULE(_hanabi_host, m) {
         .def("finish", &ExprWriter::finish);
 
     m.def("to_wgsl_string", [](py::object v) { return to_wgsl_string(value_from_py(v)); });
+    m.def("cpu_value_to_wgsl_string", [](const CpuValue& v) { return to_wgsl_string(v); });
+    // the simulation side of EffectShaderSources::generate as WGSL text (host/wgsl.cpp): a dict of the template slots of vfx_init / vfx_update
+    m.def("generate_wgsl", [](const EffectAsset& a, bool has_parent) {
+        const WgslSources w = generate_wgsl(a, has_parent);
+        py::dict d;
+        d["init_code"] = w.init_code; d["init_extra"] = w.init_extra; d["init_sim_space_transform"] = w.init_sim_space_transform;
+        d["age_code"] = w.age_code; d["reap_code"] = w.reap_code; d["update_code"] = w.update_code; d["update_extra"] = w.update_extra;
+        d["writeback_code"] = w.writeback_code;
+        d["consume_gpu_spawn_events"] = w.consume_gpu_spawn_events; d["emit_gpu_spawn_events"] = w.emit_gpu_spawn_events; d["read_parent_particle"] = w.read_parent_particle;
+        py::list attrs;
+        for (const Attribute& at : w.attributes) attrs.append(at);
+        d["attributes"] = attrs;
+        return d;
+    }, py::arg("asset"), py::arg("has_parent") = false);
     py::class_<ShaderWriter>(m, "ShaderWriter")
         .def(py::init<uint32_t, bool>(), py::arg("modifier_context"), py::arg("attribute_pointer") = false)
         .def("with_attribute_pointer", &ShaderWriter::with_attribute_pointer)
