@@ -455,7 +455,28 @@ class Lowerer {
         type_error(std::string("operator ") + what + " is not defined for this operand type");
     }
 
+    // `Expr::eval` prints a component access as `{expr}.x` and an infix operator as `({l}) op ({r})`, neither with parentheses around the
+    // whole (expr.rs:1145-1149, 1164-1176): `(a * b).x()` reaches the shader as `(a) * (b).x`, which does not compile when `b` is a scalar
+    // and otherwise selects a component of the RIGHT OPERAND only - never what the expression graph says. An independent execution of the
+    // emitted text found this (tests/wgsl_eval); such a graph is rejected here rather than given either meaning. (A hoisted rand() operand
+    // is a `varN` in the text: fine.)
+    void reject_swizzle_of_infix(const Expr& e) {
+        if (!(e.unary == UnaryOperator::X || e.unary == UnaryOperator::Y || e.unary == UnaryOperator::Z || e.unary == UnaryOperator::W)) return;
+        const Expr& in = mod_.try_get(e.a);
+        if (in.kind != Expr::Kind::Binary || in.has_side_effect()) return;
+        switch (in.binary) {
+            case BinaryOperator::Add: case BinaryOperator::Div: case BinaryOperator::GreaterThan: case BinaryOperator::GreaterThanOrEqual:
+            case BinaryOperator::LessThan: case BinaryOperator::LessThanOrEqual: case BinaryOperator::Mul: case BinaryOperator::Remainder:
+            case BinaryOperator::Sub:
+                throw ExprError(ExprError::GraphEvalError,
+                                "component access on an infix expression: the reference prints `(l) op (r).x` (no parentheses around the operation, "
+                                "src/graph/expr.rs:1145-1149), a shader that does not compile or that takes the component of the right operand only");
+            default: break;
+        }
+    }
+
     Loc eval_unary(Writer& w, const Expr& e, StreamId s) {
+        reject_swizzle_of_infix(e);
         const int base = (int)vtop_;
         Loc x = eval_abs(w, e.a);
         if (x.abs) {

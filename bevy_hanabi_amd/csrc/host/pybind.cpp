@@ -157,7 +157,8 @@ PYBIND11_MODULE(_hanabi_host, m) {
         .def("is_const", &Module::is_const)
         .def("has_side_effect", &Module::has_side_effect)
         .def_property_readonly("num_expressions", [](const Module& s) { return s.expressions().size(); })
-        .def_property_readonly("property_names", [](const Module& s) { std::vector<std::string> r; for (auto& p : s.properties()) r.push_back(p.name); return r; });
+        .def_property_readonly("property_names", [](const Module& s) { std::vector<std::string> r; for (auto& p : s.properties()) r.push_back(p.name); return r; })
+        .def_property_readonly("property_defaults", [](const Module& s) { std::vector<std::pair<std::string, Value>> r; for (auto& p : s.properties()) r.emplace_back(p.name, p.default_value); return r; });
 #define B_UN(fn) mod.def(#fn, &Module::fn);
     B_UN(abs) B_UN(acos) B_UN(asin) B_UN(atan) B_UN(all) B_UN(any) B_UN(ceil) B_UN(cos) B_UN(exp) B_UN(exp2) B_UN(floor) B_UN(fract)
     B_UN(inverse_sqrt) B_UN(length) B_UN(log) B_UN(log2) B_UN(normalize) B_UN(pack4x8snorm) B_UN(pack4x8unorm) B_UN(round) B_UN(saturate)

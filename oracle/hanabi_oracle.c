@@ -481,6 +481,16 @@ static Val eval_node(Ctx* c, Memo* memo, const ExprRec* e) {
             return c->parent->v[e->attr];
         }
         case EK_UNARY: {
+            if (e->op >= U_W && e->op <= U_Z) {
+                /* `{expr}.x` after an infix `({l}) op ({r})` prints `(l) op (r).x` (expr.rs:1145-1149, 1164-1176: no parentheses around the
+                 * operation): a shader that does not compile, or one that takes the component of the right operand only. Not given a meaning. */
+                const ExprRec* in = &c->fx->asset->exprs[e->a - 1];
+                if (in->kind == EK_BINARY && !c->fx->asset->side_effect[e->a - 1] &&
+                    (in->op == B_ADD || in->op == B_DIV || in->op == B_GT || in->op == B_GE || in->op == B_LT || in->op == B_LE || in->op == B_MUL || in->op == B_REM || in->op == B_SUB)) {
+                    fail(c, "component access on an infix expression: the reference prints `(l) op (r).x`");
+                    return mkf(0);
+                }
+            }
             Val x = eval(c, memo, e->a);
             /* abs() / sign() keep an integer an integer; every other builtin of the list only exists for floats
              * (AbstractInt -> AbstractFloat -> f32), or fails below on a scalar */

@@ -76,7 +76,8 @@ class Gen:
         if r < 0.82 and width == 1:   # reductions of a vector
             v = self.expr(int(self.rng.integers(2, 5)), depth - 1, ctx)
             k = self.rng.random()
-            return v.length() if k < 0.4 else (v.dot(v) if k < 0.7 else v.x())
+            # (.x of an infix expression prints `(l) op (r).x`: rejected by lowering and oracle alike; through a functional form it is what it says)
+            return v.length() if k < 0.4 else (v.dot(v) if k < 0.7 else v.abs().x())
         if r < 0.88 and width == 3:
             k = self.rng.random()
             a = self.expr(3, depth - 1, ctx)

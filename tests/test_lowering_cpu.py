@@ -137,15 +137,16 @@ def asset_unary_b():
 def asset_unary_c():
     w = h.ExprWriter()
     x = w.rand(h.VectorType.VEC4F) * w.lit(8.0) - w.lit(4.0)
+    xc = x.cast(h.VectorType.VEC4F)   # `vec4<f32>(...)`: a component access needs a functional operand (`(l) - (r).x` is what an infix one prints)
     u = w.rand(h.VectorType.VEC3F)
     init = [
         h.SetAttributeModifier(A.POSITION, u.expr()),
-        h.SetAttributeModifier(A.F32X2_0, (x.x().vec2(x.y())).saturate().expr()),
-        h.SetAttributeModifier(A.F32X2_1, (x.z().vec2(x.w())).sign().expr()),
+        h.SetAttributeModifier(A.F32X2_0, (xc.x().vec2(xc.y())).saturate().expr()),
+        h.SetAttributeModifier(A.F32X2_1, (xc.z().vec2(xc.w())).sign().expr()),
         h.SetAttributeModifier(A.F32_0, x.length().expr()),
         h.SetAttributeModifier(A.F32_1, u.normalized().dot(u).expr()),
         h.SetAttributeModifier(A.F32_2, u.distance(w.lit((0.5, 0.5, 0.5))).expr()),
-        h.SetAttributeModifier(A.F32_3, x.x().atan2(x.y()).expr()),
+        h.SetAttributeModifier(A.F32_3, xc.x().atan2(xc.y()).expr()),
         h.SetAttributeModifier(A.COLOR, x.saturate().pack4x8unorm().expr()),
         h.SetAttributeModifier(A.U32_0, (x * w.lit(0.3)).pack4x8snorm().expr()),
         h.SetAttributeModifier(A.HDR_COLOR, w.attr(A.COLOR).unpack4x8unorm().expr()),
@@ -178,7 +179,7 @@ def asset_binary_b():
         h.SetAttributeModifier(A.AXIS_X, a.mix(b, b.fract()).expr()),
         h.SetAttributeModifier(A.AXIS_Y, a.clamp(w.lit((-1.0, -0.5, 0.0)), w.lit((0.5, 1.0, 1.5))).expr()),
         h.SetAttributeModifier(A.AXIS_Z, a.smoothstep(w.lit((-1.0, -1.0, -1.0)), w.lit((1.0, 1.0, 1.0))).expr()),
-        h.SetAttributeModifier(A.F32_0, (a.x() * s + b.y()).expr()),
+        h.SetAttributeModifier(A.F32_0, (a.cast(h.VectorType.VEC3F).x() * s + b.cast(h.VectorType.VEC3F).y()).expr()),
         h.SetAttributeModifier(A.SIZE3, s.vec3(s * s, w.lit(2.0)).expr()),
     ]
     return _mk(300, w, init)
@@ -193,7 +194,7 @@ def asset_binary_c():
         h.SetAttributeModifier(A.POSITION, b.expr()),
         h.SetAttributeModifier(A.F32X4_0, a.vec4_xyz_w(s).expr()),
         h.SetAttributeModifier(A.F32_1, (a.gt(b).any().cast(F) + a.lt(b).all().cast(F) * w.lit(2.0) + a.ge(b).any().cast(F) * w.lit(4.0) + a.le(b).all().cast(F) * w.lit(8.0)).expr()),
-        h.SetAttributeModifier(A.F32_2, (a.x().cast(h.ValueType(h.ScalarType.Int)).cast(F) + (b.y() * w.lit(100.0)).cast(h.ValueType(h.ScalarType.Uint)).cast(F)).expr()),
+        h.SetAttributeModifier(A.F32_2, (a.cast(h.VectorType.VEC3F).x().cast(h.ValueType(h.ScalarType.Int)).cast(F) + (b.cast(h.VectorType.VEC3F).y() * w.lit(100.0)).cast(h.ValueType(h.ScalarType.Uint)).cast(F)).expr()),
         h.SetAttributeModifier(A.F32_3, w.lit(2.5).uniform(w.lit(7.5)).expr()),
         h.SetAttributeModifier(A.SIZE2, w.lit((1.0, 2.0)).normal(w.lit((0.5, 0.25))).expr()),
         h.SetAttributeModifier(A.ALPHA, w.lit(0.0).normal(w.lit(1.0)).expr()),
