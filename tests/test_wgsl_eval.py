@@ -172,3 +172,66 @@ def test_zoo(name):
     if name == "update_all_macros":
         frames[30].props = {"k": 1.25}
     print(name, "worst relative difference", play(asset, frames, check_every=4, what=name))
+
+
+# ---- every single-entity effect of the reference's examples/ --------------------------------------------------------------------------------
+from bevy_hanabi_amd import reference_examples as rx   # noqa: E402
+from test_reference_examples import FRAMES, SINGLE, Player      # noqa: E402
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_reference_example_text_runs_like_the_oracle(name):
+    """The effects of examples/*.rs (bevy_hanabi_amd/reference_examples.py), driven frame by frame the way the example's systems drive them,
+    through the emitted WGSL: one-frame maps on the oracle's state (resync), lists and counters exact."""
+    for index, entry in enumerate(rx.catalog()[name]):
+        asset = entry.asset
+        orc, wfx, player = OracleRunner(asset), wgsl_effect(asset), Player(entry, index)
+        ribbons = any(a.name == "ribbon_id" for a in asset.particle_layout())
+        before, spawned = None, 0
+        for f in range(min(FRAMES.get(name, 120), 260)):
+            fr = player.frame(f)
+            if fr is None:
+                continue
+            for k, v in fr.props.items():
+                wfx.set_property(k, prop_value(asset, k, v))
+            orc.step(fr)
+            wfx.init_pass(fr.dt, fr.spawn, fr.seed, fr.time, fr.transform)
+            wfx.update_pass(fr.dt, fr.seed, fr.time, fr.transform)
+            spawned += fr.spawn
+            compare(orc, wfx, f"{name}[{index}] frame {f}", before, sorted_list=ribbons)
+            before = orc.state()["attrs"]
+            for an, ref_bits in before.items():
+                arr = wfx.attrs[an]
+                wfx.attrs[an] = (ref_bits.view(np.float32) if arr.dtype == F32 else ref_bits.astype(arr.dtype)).reshape(arr.shape).copy()
+            if ribbons:
+                wfx.list = orc.state()["alive"].copy()
+        assert spawned > 0
+
+
+def test_real_firework_system_with_spawn_events():
+    """examples/firework.rs: rocket -> sparkle trail (Always) + trails (OnDie) through GPU spawn events, the three effects' emitted WGSL
+    executed together: events appended by a parent's update in frame N (append_spawn_events_N in list order, stored up to the buffer's
+    capacity, src/lib.rs:976-993) spawn the children in frame N + 1, which read the emitting particle (vfx_init.wgsl:166-171)."""
+    from helpers import EffectSpec, OracleSystem
+    from test_events import firework_frames, firework_system
+    specs = firework_system((4096, 65536), caps=(32, 2000, 12000))
+    osys = OracleSystem(specs)
+    wfx = [wgsl_effect(s.asset, has_parent=s.parent is not None) for s in specs]
+    pending = {1: [], 2: []}     # child index -> the parent slots of last frame's events
+    for f, frs in enumerate(firework_frames(200, specs[0].asset)):
+        osys.step(frs)
+        for i, (s, fx, fr) in enumerate(zip(specs, wfx, frs)):
+            if s.parent is None:
+                fx.init_pass(fr.dt, fr.spawn, fr.seed, fr.time, fr.transform)
+            else:
+                fx.init_pass(fr.dt, 0, fr.seed, fr.time, fr.transform, parent=wfx[s.parent], parent_events=pending[i][:s.event_capacity])
+        for fx, fr in zip(wfx, frs):
+            fx.update_pass(fr.dt, fr.seed, fr.time, fr.transform)
+        pending = {i: list(wfx[s.parent].events.get(s.channel, [])) for i, s in enumerate(specs) if s.parent is not None}
+        if f % 10 == 9:
+            for i, (o, fx) in enumerate(zip(osys.fx, wfx)):
+                class _O:   # the shape compare() expects
+                    def __init__(self, st): self._st = st
+                    def state(self): return self._st
+                compare(_O(osys.state()[i]), fx, f"firework effect #{i} frame {f}")
+    assert wfx[2].particle_counter > 1000 and wfx[1].particle_counter > 100

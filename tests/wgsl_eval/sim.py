@@ -6,7 +6,7 @@ SURVEY.md section 8(c): threads in increasing global id. Independent of oracle/ 
 """
 import numpy as np
 
-from .interp import AF, BOOL, F32, I32, U32, Interp, Mat4, Parser, Particle, Struct, concretise, is_abstract
+from .interp import BOOL, F32, I32, U32, Interp, Mat4, Parser, Particle, Ptr, Struct, concretise
 
 TAU = np.array([6.283185307179586476925286766559], F32)   # vfx_common.wgsl:261
 
@@ -129,7 +129,7 @@ class WgslEffect:
         pidx = (slots.astype(np.uint64) + self.slot_base).astype(U32)
         g = {"sim_params": sim, "tau": TAU, "properties": [props], "properties_array_index": np.array([0], U32), "transform": Mat4(cols),
              "particle_index": pidx, "seed": pcg_hash(pidx ^ U32(seed)),   # vfx_init.wgsl:152 / vfx_update.wgsl:138
-             "effect_metadata": Struct(base_child_index=np.array([0], U32))}
+             "effect_metadata": Ptr(Struct(base_child_index=np.array([0], U32)))}    # `let effect_metadata = &effect_metadatas[..]`
         if counter0 is not None:
             g["particle_counter"] = (counter0 + np.arange(n, dtype=np.uint64)).astype(U32)
         return g
