@@ -327,6 +327,22 @@ int hnb_asset_to_ron(const HnbAsset* asset, char** out_text, size_t* out_size) {
     });
 }
 
+int hnb_asset_wgsl(const HnbAsset* asset, int has_parent, char** out_text, size_t* out_size) {
+    REQUIRE(asset && out_text && out_size, "NULL argument");
+    return guarded([&] {
+        const WgslSources w = generate_wgsl(asset->a, has_parent != 0);
+        const std::string t = "// {{INIT_EXTRA}}\n" + w.init_extra + "\n// {{INIT_CODE}}\n" + w.init_code + "\n// {{SIMULATION_SPACE_TRANSFORM_PARTICLE}}\n" + w.init_sim_space_transform +
+                              "\n// {{UPDATE_EXTRA}}\n" + w.update_extra + "\n// {{AGE_CODE}}" + w.age_code + "\n// {{REAP_CODE}}\n" + w.reap_code + "\n// {{UPDATE_CODE}}\n" + w.update_code +
+                              "\n// {{WRITEBACK_CODE}}\n" + w.writeback_code;
+        char* p = static_cast<char*>(std::malloc(t.size() + 1));
+        if (!p) return fail(HNB_ERR_OUT_OF_MEMORY, "out of memory");
+        std::memcpy(p, t.c_str(), t.size() + 1);
+        *out_text = p;
+        *out_size = t.size();
+        return (int)HNB_OK;
+    });
+}
+
 int hnb_asset_from_ron(const char* text, size_t size, HnbAsset** out_asset) {
     REQUIRE(text && out_asset, "NULL argument");
     return guarded([&] { *out_asset = new HnbAsset{from_ron(std::string(text, size))}; return HNB_OK; });

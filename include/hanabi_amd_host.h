@@ -175,6 +175,10 @@ int hnb_lower(const HnbAsset* asset, void** out_blob, size_t* out_size);
  * offending field) on malformed text, unknown attributes, unknown modifier type paths, out-of-range expression handles. */
 int hnb_asset_to_ron(const HnbAsset* asset, char** out_text, size_t* out_size);
 int hnb_asset_from_ron(const char* text, size_t size, HnbAsset** out_asset);
+/* The WGSL the reference would paste into vfx_init.wgsl / vfx_update.wgsl for this asset (EffectShaderSources::generate, src/lib.rs:
+ * 1026-1302: every modifier's `apply`, aging / reaping, Euler integration, write-back) as one NUL-terminated text of `// {{SLOT}}` sections:
+ * inspection output a maintainer can diff against the reference's trace log; tests/wgsl_eval executes it. Not used by the simulation. */
+int hnb_asset_wgsl(const HnbAsset* asset, int has_parent, char** out_text, size_t* out_size);
 /* Flat authoring-level description (expressions, properties, modifiers, settings): the CPU oracle's input format. */
 int hnb_asset_serialize(const HnbAsset* asset, void** out_blob, size_t* out_size);
 

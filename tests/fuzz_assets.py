@@ -257,7 +257,8 @@ class TypedGen(Gen):
                     return sub("f", wd).dot(sub("f", wd))
                 if t < 0.8:
                     return sub("f", wd).distance(sub("f", wd))
-                return getattr(sub("f", wd), "xyzw"[int(rng.integers(wd))])()
+                # (through saturate(): a component access on an infix expression is not what the reference prints, see lowering.cpp)
+                return getattr(sub("f", wd).saturate(), "xyzw"[int(rng.integers(wd))])()
             if r < 0.86 and width == 4:
                 return sub("u", 1).unpack4x8unorm() if rng.random() < 0.5 else sub("u", 1).unpack4x8snorm()
             if r < 0.90 and width == 3:

@@ -295,3 +295,24 @@ def test_c99_program_simulates_what_the_oracle_computes(tmp_path):
     assert got_alive == want_alive and 0 < got_alive[-1] < cap
     pos = np.fromfile(dump, dtype=np.uint32).reshape(cap, 3)
     np.testing.assert_array_equal(pos, orc.read_attr(2).view(np.uint32))
+
+
+def test_emitted_wgsl_through_the_c_abi():
+    """hnb_asset_wgsl: the text EffectShaderSources::generate would paste into the templates, one `// {{SLOT}}` section per template slot."""
+    from bevy_hanabi_amd import _hanabi_host as hh
+    lib = C.CDLL(hb.build_host_lib())
+    lib.hnb_host_free.argtypes = [C.c_void_p]
+    lib.hnb_asset_destroy.argtypes = [C.c_void_p]
+    asset = effects.force_field(1000)
+    ron = bh.to_ron(asset).encode()
+    a = C.c_void_p()
+    assert lib.hnb_asset_from_ron(ron, len(ron), C.byref(a)) == 0
+    t, n = C.c_char_p(), C.c_size_t()
+    assert lib.hnb_asset_wgsl(a, 0, C.byref(t), C.byref(n)) == 0
+    text = C.string_at(t, n.value).decode()
+    w = hh.generate_wgsl(asset)
+    for slot, key in (("INIT_EXTRA", "init_extra"), ("INIT_CODE", "init_code"), ("UPDATE_CODE", "update_code"), ("REAP_CODE", "reap_code"), ("WRITEBACK_CODE", "writeback_code")):
+        assert "// {{" + slot + "}}\n" + w[key] in text, slot
+    assert "fn force_field_" in text and "let shell_factor = smoothstep(0., shell_half_thickness, abs(surface_dist));" in text
+    assert "particle_buffer.particles[base_particle + particle_index].velocity = particle.velocity;" in text
+    lib.hnb_asset_destroy(a)

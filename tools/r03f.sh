@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, sixth GPU call: cohort state 4 (mixed chunks run the lean per-particle path), k_emit_events v3; A/B of the cohort kernels' register budget
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out; export TMPDIR=/tmp
-T=${1:-r03f}
+T=${1:-r03g}
 timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/${T}_pytest.log; cat gpurun_out/${T}_pytest.log
 ( time timeout 900 python bench.py --no-cpu-baseline > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err ) 2>&1 | grep real
 python3 tools/bench_summary.py gpurun_out/${T}_bench.json | tee gpurun_out/${T}_bench_summary.txt
