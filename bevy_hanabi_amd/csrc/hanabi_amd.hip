@@ -179,6 +179,10 @@ struct HnbProgram {
     // "no particle can die before ..." (hnb_kernels.hip.h, SlotArgs): the update publishes a lower bound of the remaining life of
     // every alive particle; while the ticks accumulated since stay below it, a frame without spawn needs no list kernels.
     bool skip_eligible = false;             // streamable, lifetime-culled, no kill modifier: particles only die of old age
+    bool horizon_eligible = false;          // ... the same without the spawn-event restrictions: row-chunk death horizons are maintained (hnb_kernels.hip.h)
+    uint32_t hz_parity = 0;                 // which half of the horizon arrays is current (flips in frames whose list kernels ran)
+    bool hz_use_now = false;                // this frame's ticks are finite: k_count_rows may skip chunks
+    uint32_t hz_frames = 0;                 // statistics: frames in which the horizons were in use
     uint32_t* d_safe = nullptr;             // u32[2][table_cap * chunks_per_inst] device words (allocated with the tables)
     unsigned long long* h_safe = nullptr;   // host-mapped {tag, bound bits}
     uint32_t* d_fault = nullptr;            // set by the kernel if a particle died in a frame whose lists were skipped
@@ -453,6 +457,7 @@ bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgra
     const uint64_t lmin_off = place(align_up((size_t)d.chunks_per_inst * 16, 256));  // four u32 / f32 arrays per chunk: lifetime bound (0 = unknown), "completely alive" flag, age-cohort state, age-cohort value; zeroed too
     const uint64_t bit_bytes = align_up((size_t)d.chunks_per_inst * (kChunk / 8), 256);
     const uint64_t died_off = place(bit_bytes), rmask_off = place(bit_bytes);     // one bit per slot "died this frame", one bit per list row "survives" (k_count_rows / k_compact)
+    const uint64_t hz_off = place(align_up(256 + (size_t)d.chunks_per_inst * 24, 256));   // death horizons: clock, D[2][chunks], BF[2][chunks] (zero = "may die")
     uint64_t ev_off[HNB_MAX_EVENT_CHANNELS] = {};
     for (uint32_t c = 0; c < h.n_event_channels; ++c) ev_off[c] = place(list_bytes);  // per-slot staging of spawn events (k_update_slots_generic -> k_emit_count / k_emit_events)
     uint64_t key_off[2] = {}, val_off[2] = {}, hist_off = 0, gsum_off = 0, bits_off = 0;
@@ -476,6 +481,7 @@ bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgra
     d.alive_flag_off = soff_of(flag_off);
     d.lmin_off = soff_of(lmin_off);
     d.died_bits_off = soff_of(died_off); d.row_mask_off = soff_of(rmask_off);
+    d.horizon_off = soff_of(hz_off);
     d.n_event_channels = h.n_event_channels;
     for (uint32_t c = 0; c < h.n_event_channels; ++c) d.ev_cnt_off[c] = soff_of(ev_off[c]);
     if (ribbons) {
@@ -946,6 +952,8 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
             kills = kills || op == HNB_OP_M_KILL_SPHERE || op == HNB_OP_M_KILL_AABB;
         }
         p->skip_eligible = p->update_streams && d.cull_lifetime && !kills && h.n_event_channels == 0 && !(h.flags & HNB_PROG_READS_PARENT);
+        const char* hz_env = getenv("HNB_HORIZON");
+        p->horizon_eligible = p->update_streams && d.cull_lifetime && !kills && !p->has_ribbons && !p->slot_order && !(hz_env && hz_env[0] == '0');
         if (hipMalloc(&p->d_fault, 4) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void**>(&p->h_safe), 8, hipHostMallocDefault) != hipSuccess) {
             if (p->jit_module) hipModuleUnload(p->jit_module);
@@ -955,6 +963,7 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
         }
         hipMemset(p->d_fault, 0, 4);
         *p->h_safe = 0xffffffffull;  // tag = none
+        p->dev.horizon = p->horizon_eligible ? 1u : 0u;
     }
     const size_t code_bytes = ((size_t)h.init_len + h.update_len) * 8;
     hipError_t e = hipMalloc(&p->d_code, std::max<size_t>(code_bytes, 8));
@@ -1102,6 +1111,12 @@ int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
                                                               reinterpret_cast<uint32_t*>(base + p->dev.alive_off[1]), cap);
     // Attribute planes start zeroed (the reference pre-fills with 0xFF only in debug builds).
     HIP_TRY(hipMemsetAsync(base + p->dev.attrs[0].plane_off, 0, p->slab_bytes - p->dev.attrs[0].plane_off, ctx->stream));
+    if (p->horizon_eligible) {   // death horizons: no row yet, nobody can die (k_init takes minima into these); the clock starts at 0
+        std::vector<unsigned long long> never((size_t)p->dev.chunks_per_inst * 2, 0x7ff0000000000000ull);
+        HIP_TRY(hipMemcpyAsync(base + p->dev.horizon_off + 256, never.data(), never.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemsetAsync(base + p->dev.horizon_off + 256 + never.size() * 8, 0xff, (size_t)p->dev.chunks_per_inst * 8, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));   // (`never` goes out of scope)
+    }
     if (p->has_ribbons) {  // {OR, AND} accumulators of the sort keys, both frame parities
         SortState st[2];
         for (SortState& z : st) { z.or_all = 0ull; z.and_all = ~0ull; z.or_tail = 0ull; z.and_tail = ~0ull; z.head_unsorted = 0u; z.pad[0] = z.pad[1] = z.pad[2] = 0u; }
@@ -1294,6 +1309,9 @@ static CompactArgs compact_args_of(const HnbProgram* p) {
     ca.alive_off[0] = p->dev.alive_off[0]; ca.alive_off[1] = p->dev.alive_off[1]; ca.dead_off = p->dev.dead_off;
     ca.alive_flag_off = p->dev.alive_flag_off;
     ca.died_bits_off = p->dev.died_bits_off; ca.row_mask_off = p->dev.row_mask_off;
+    ca.horizon_off = p->dev.horizon_off;
+    ca.hz = p->horizon_eligible ? 1u : 0u; ca.hz_use = p->hz_use_now ? 1u : 0u; ca.hz_parity = p->hz_parity; ca.frame_no = p->frames_run;
+    ca.fault = p->d_fault;
     ca.slot_order = p->slot_order ? 1u : 0u;
     ca.rotate_front = p->frame_rotate ? 1u : 0u;   // k_compact writes the survivors [spawns | older ones]: see CompactArgs (ribbon programs never have slot-ordered lists)
     return ca;
@@ -1480,6 +1498,20 @@ int hnb_simulate(HnbContext* ctx) {
             }
         }
         p->lists_now = !(p->update_streams && p->skip_now);  // false: proven no spawn, no casualty; the update kernel rotates the counters
+        // death horizons (hnb_kernels.hip.h): k_count_rows may skip row chunks iff every simulated instance's tick is finite this frame
+        p->hz_use_now = false;
+        if (p->horizon_eligible) {
+            bool finite = true;
+            for (uint32_t i = 0; i < n; ++i) {
+                if (!p->effects[i]->simulated) continue;
+                const uint32_t tb = ublocks[(size_t)i * nu + (p->cull_dt_operand & 0xffu)];
+                finite = finite && (tb & 0x7f800000u) != 0x7f800000u;
+            }
+            p->hz_use_now = finite;
+            if (finite && p->lists_now) p->hz_frames += 1;
+        }
+        p->dev.hz_parity = p->hz_parity;
+        p->dev.frame_no = p->frames_run;
         p->lists_merged = false;
         uint32_t* init_start = ublocks + (size_t)n * nu;  // packed copy of init_block_start for k_init's search
         for (uint32_t i = 0; i < n; ++i) init_start[i] = fi[i].init_block_start;
@@ -1605,6 +1637,7 @@ int hnb_simulate(HnbContext* ctx) {
             sa.cull_lifetime = p->dev.cull_lifetime; sa.lmin_off = p->dev.lmin_off; sa.dt_operand = p->cull_dt_operand;
             sa.age_cohort = p->dev.age_cohort;
             sa.frame_phase = p->frames_run & 15u;
+            sa.horizon_off = p->dev.horizon_off; sa.horizon = p->horizon_eligible ? 1u : 0u;
             if (p->skip_eligible) { sa.safe_words = p->d_safe; sa.safe_host = p->h_safe; sa.safe_parity = p->frames_run & 1u; sa.publish_tag = p->frames_run - 1u; sa.safe_stride = p->table_cap * p->dev.chunks_per_inst; }
             sa.skip_lists = p->skip_now ? 1u : 0u;
             sa.meta_in = p->d_meta[par]; sa.meta_out = p->d_meta[par ^ 1];
@@ -1669,6 +1702,7 @@ int hnb_simulate(HnbContext* ctx) {
         p->ring += 1;
         p->parity ^= 1u;
         p->frames_run += 1;
+        if (p->horizon_eligible && p->lists_now) p->hz_parity ^= 1u;   // k_count_rows / k_compact moved the horizons to the other half
     }
     if (!order.empty()) HIP_TRY(hipEventRecord(ctx->stage_done[slot], ctx->stream));
     for (HnbProgram* p : order)
@@ -1736,6 +1770,8 @@ int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t 
     p->dirty = true;  // ... nor does the published no-death bound
     p->sort_dirty = true;  // ... and a ribbon list may no longer be in key order
     p->sort_front_broken = true;  // ... nor its ages and ribbon ids what the front proof assumes
+    if (p->horizon_eligible)   // the death horizons were computed from the particles as they were: zero = "may die now" (the clock restarts with them)
+        HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.horizon_off, 0, 256 + (size_t)p->dev.chunks_per_inst * 24));
     if (attr == HNB_ATTR_AGE) p->sort_values_broken = true;  // ... and the written ages may be negative (they change key order when they cross zero later)
     // the chunks' lifetime bounds (lifetime culling) no longer describe the planes
     HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.lmin_off, 0, (size_t)p->dev.chunks_per_inst * 4));  // (the "completely alive" flags that follow stay valid)
@@ -1792,6 +1828,7 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
         s += "\nage cohorts: " + std::to_string(in_cohort) + " of " + std::to_string(prog->effects.size() * (size_t)prog->dev.chunks_per_inst) + " chunks";
     }
     if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->sort_front_static ? "" : " (not eligible)");
+    if (prog->horizon_eligible) s += "\ndeath horizons in use: " + std::to_string(prog->hz_frames) + " frames";
     s += "\nlists skipped: " + std::to_string(prog->skipped_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->skip_eligible ? "" : " (not eligible)");
     snprintf(buf, buf_size, "%s", s.c_str());
     return HNB_OK;

@@ -37,6 +37,11 @@ struct DevProgram {
     // rewritten completely by every update launch that is followed by the list kernels (64-bit words, bit s & 63 of word s >> 6);
     // row_mask = one bit per alive-list ROW, "survives", written by k_count_rows for k_compact. Both [chunks_per_inst * kChunk / 8] bytes.
     soff_t died_bits_off, row_mask_off;
+    // Row-chunk death horizons (k_init / k_count_rows / k_compact, "Death horizons" in hnb_kernels.hip.h): [double clock][pad to 256 B]
+    // [u64 D[2][chunks_per_inst]][u32 BF[2][chunks_per_inst]]; horizon: 1 = the program is eligible and the arrays are maintained;
+    // hz_parity: which half is current; frame_no: frames this program ran (birth frames of the rows).
+    soff_t horizon_off;
+    uint32_t horizon, hz_parity, frame_no;
     uint32_t n_event_channels;
     soff_t ev_cnt_off[HNB_MAX_EVENT_CHANNELS];       // u32[capacity] per channel: events appended by the particle in that slot
     // Lifetime culling (k_update_slots_stream): f32[chunks_per_inst], a lower bound of the LIFETIME of every alive particle

@@ -177,6 +177,41 @@ struct InterpCodeWide : InterpCode {
     using file_t = vreg_file_wide_t;
 };
 
+// ---- death horizons ----------------------------------------------------------------------------------------------------------
+// The one gather of the list path - k_count_rows looking up the died bit of every row's slot - is spent mostly on rows that cannot have
+// died: the alive list is in BIRTH order (stable compaction, spawns appended), and in an effect whose particles only die of old age
+// (streamable update, one AGE_TICK up front, no kill modifier: DevProgram::horizon) a row chunk of young particles has no casualty for most
+// of its life. Per instance the slab keeps a CLOCK, the sum of the ticks so far (binary64, advanced once per frame by the update kernel by
+// max(tick, 0) (1 + 2^-16)), and per 4096-ROW chunk a lower bound D of the clock value at which one of its rows can die first, plus the
+// frame BF its oldest row was born in:
+//   k_init       a spawn with 0 <= age0 <= 0.74 lifetime gets D = clock + (lifetime - age0)(1 - 2^-10), else D = clock (no claim); the wave
+//                takes the minimum per row chunk of the rows it appends (of the f32 term: the clock is common) and merges it with an atomic
+//                min (u64: non-negative doubles order like their bits), BF likewise;
+//   k_count_rows a chunk with clock < D and frame - BF <= 4096 is not gathered: every row survives (mask all ones, count = rows);
+//   k_compact    rows move to lower rows: a source chunk's (D, BF) is merged into the one or two target chunks its survivors land in.
+// Why this is safe: f32 ages are accumulated with one rounding of 2^-24 relative per frame, so after N <= 4097 frames
+// age <= (age0 + sum of ticks)(1 + 2.5e-4); sum of ticks <= clock now - clock at birth < (lifetime - age0)(1 - 2^-10) gives
+// age < lifetime - 2^-10 (lifetime - age0) + 2.5e-4 lifetime <= lifetime for age0 <= 0.74 lifetime: the program's own `age < lifetime` holds,
+// the particle is alive after this frame. Non-finite ticks switch the use off for the frame (CompactArgs::hz_use); host writes reset the
+// arrays; a violated claim would make k_compact's survivor count disagree with the update's casualty count: HnbEffectMetadata::fault.
+struct HorizonView {
+    double* clock;
+    unsigned long long* D[2];
+    uint32_t* BF[2];
+};
+__device__ __forceinline__ HorizonView horizon_view(char* base, soff_t off, uint32_t chunks) {
+    HorizonView h;
+    char* p = base + off;
+    h.clock = reinterpret_cast<double*>(p);
+    h.D[0] = reinterpret_cast<unsigned long long*>(p + 256);
+    h.D[1] = h.D[0] + chunks;
+    h.BF[0] = reinterpret_cast<uint32_t*>(h.D[1] + chunks);
+    h.BF[1] = h.BF[0] + chunks;
+    return h;
+}
+constexpr unsigned long long kHorizonNever = 0x7ff0000000000000ull;   // +inf: no row, nobody can die
+constexpr uint32_t kHorizonFrames = 4096u;
+
 // ---- init -----------------------------------------------------------------------------------
 // One thread per spawned particle. Thread i of instance k (serial order == thread order):
 //   slot = dead[alive0 + i]; seed = pcg_hash(slot ^ spawner.seed); run INIT; alive[w][alive0+i] = slot.
@@ -215,7 +250,13 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
     U.u = ublocks + (size_t)k * prog.n_uregs;
     U.xf = fi[k].xf;
 
-    for (uint32_t i = (blk - first_block) * kInitBlock + threadIdx.x; i < n_spawn; i += n_blocks * kInitBlock) {
+    const HorizonView hz = horizon_view(base, prog.horizon_off, prog.chunks_per_inst);
+    const double clock_now = prog.horizon ? *hz.clock : 0.0;
+    // (the trip count is uniform over the workgroup: the horizon merge below is a wave operation)
+    for (uint32_t i0 = (blk - first_block) * kInitBlock; i0 < n_spawn; i0 += n_blocks * kInitBlock) {
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t r_bits = 0xffffffffu;   // (an idle lane)
+        if (i < n_spawn) {
         const uint32_t slot = dead[alive0 + i];
         VmState<typename CODE::file_t> S;
         S.r = typename CODE::file_t{};  // var particle = Particle();  (vfx_init.wgsl:174)
@@ -244,6 +285,37 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
         reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = alive_byte;
         if (prog.cull_lifetime) reinterpret_cast<float*>(base + prog.lmin_off)[slot / kChunk] = 0.0f;  // the chunk's lifetime bound is unknown again
         CODE::store_init(prog, S, base, slot);
+        if (prog.horizon) {   // how much clock can pass before this particle may die? (see "death horizons"; f32, rounded towards less)
+            const float age0 = u2f(S.r[HNB_REG_AGE]), life = u2f(S.r[HNB_REG_LIFETIME]);
+            float r0 = 0.0f;
+            if (age0 >= 0.0f && life > 0.0f && age0 <= 0.74f * life) r0 = (life - age0) * 0.998046875f;   // (1 - 2^-9): <= (life - age0)(1 - 2^-10) after both roundings
+            r_bits = f2u(r0);
+        }
+        }
+        if (prog.horizon) {
+            // rows alive0 + i of a wave lie in one row chunk, or in two (one wave in 64): one atomic min per chunk and wave.
+            // Non-negative floats order like their bits; the clock is the same for the whole launch: min D = clock + min r0.
+            const uint32_t lane = threadIdx.x & 63u;
+            const uint32_t row0 = alive0 + (i - lane);                 // lane 0's row (the wave's lowest; an all-idle wave merges nothing)
+            const uint32_t rc0 = row0 / kChunk, rc_last = (row0 + 63u) / kChunk;   // (wave-uniform)
+            const bool second = rc_last != rc0 && (alive0 + i) / kChunk != rc0;
+            uint32_t m0 = second ? 0xffffffffu : r_bits;
+#pragma unroll
+            for (uint32_t off = 32; off > 0; off >>= 1) { const uint32_t y = __shfl_xor(m0, off, 64); m0 = y < m0 ? y : m0; }
+            if (lane == 0u && m0 != 0xffffffffu) {
+                atomicMin(&hz.D[prog.hz_parity][rc0], d2u(clock_now + (double)u2f(m0)));
+                atomicMin(&hz.BF[prog.hz_parity][rc0], prog.frame_no);
+            }
+            if (rc_last != rc0) {
+                uint32_t m1 = second ? r_bits : 0xffffffffu;
+#pragma unroll
+                for (uint32_t off = 32; off > 0; off >>= 1) { const uint32_t y = __shfl_xor(m1, off, 64); m1 = y < m1 ? y : m1; }
+                if (lane == 0u && m1 != 0xffffffffu && rc_last < prog.chunks_per_inst) {
+                    atomicMin(&hz.D[prog.hz_parity][rc_last], d2u(clock_now + (double)u2f(m1)));
+                    atomicMin(&hz.BF[prog.hz_parity][rc_last], prog.frame_no);
+                }
+            }
+        }
     }
 }
 // ---- streaming-kernel pinned attribute access (P = 4) -------------------------------------------
@@ -459,8 +531,10 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     ChunkCtx c;
     const bool has_rows = chunk_setup(c, chunk, args, inst_base, meta_in, fi);
+    const HorizonView hz = horizon_view(c.base, args.horizon_off, args.chunks_per_inst);
     if (fi[c.k].skip) {  // not simulated this frame: counters carry over unchanged
         if (c.j == 0 && tid == 0) { meta_out[c.k] = c.m; cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + c.k] = 0u; }
+        if (args.hz && tid == 0) { hz.D[args.hz_parity ^ 1u][c.j] = hz.D[args.hz_parity][c.j]; hz.BF[args.hz_parity ^ 1u][c.j] = hz.BF[args.hz_parity][c.j]; }   // the rows stand: so do their horizons
         return;
     }
     uint32_t* deaths_cur = cb.deaths + (size_t)cb.parity * cb.table_cap;
@@ -469,6 +543,7 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     const bool last = c.n == 0 ? c.j == 0 : (c.start < c.n && c.start + kChunk >= c.n);
     const bool rotate = args.rotate_front != 0u && c.n_spawn != 0u;   // (uniform per instance; never set together with slot_order)
     if (total_dead == 0u && !rotate) {
+        if (args.hz && tid == 0) { hz.D[args.hz_parity ^ 1u][c.j] = hz.D[args.hz_parity][c.j]; hz.BF[args.hz_parity ^ 1u][c.j] = hz.BF[args.hz_parity][c.j]; }   // no row moved
         if (last && tid == 0) {
             DevMeta o = c.m;
             o.alive_count = c.n;
@@ -518,6 +593,13 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
 #pragma unroll
     for (uint32_t off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(wincl, off, 64); if (lane >= off) wincl += y; }
     const uint32_t a = __shfl(wincl, 63, 64);   // survivors of this chunk ( == cnt[c.j] where k_count_rows ran)
+    if (args.hz && tid == 0u && a != 0u) {      // this chunk's survivors land on rows [excl, excl + a): one target chunk or two inherit its horizon
+        const unsigned long long d = hz.D[args.hz_parity][c.j];
+        const uint32_t bf = hz.BF[args.hz_parity][c.j];
+        const uint32_t t0 = excl / kChunk, t1 = (excl + a - 1u) / kChunk;
+        atomicMin(&hz.D[args.hz_parity ^ 1u][t0], d); atomicMin(&hz.BF[args.hz_parity ^ 1u][t0], bf);
+        if (t1 != t0) { atomicMin(&hz.D[args.hz_parity ^ 1u][t1], d); atomicMin(&hz.BF[args.hz_parity ^ 1u][t1], bf); }
+    }
     const uint32_t wexcl = wincl - wcount;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(c.base + args.alive_off[c.m.write_index]) + c.start;
     uint32_t* out = reinterpret_cast<uint32_t*>(c.base + args.alive_off[c.m.write_index ^ 1u]);
@@ -554,6 +636,7 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     }
     if (last && tid == 0) {
         const uint32_t survivors = excl + a;
+        if (args.hz && args.fault && survivors != c.n - total_dead) *args.fault = 1u;   // a horizon claimed a chunk free of casualties that was not
         DevMeta o = c.m;
         o.alive_count = survivors;
         o.particle_counter = c.m.particle_counter + c.n_spawn;
@@ -572,6 +655,9 @@ struct CompactArgs {
     soff_t alive_off[2], dead_off;
     soff_t alive_flag_off;     // u8[capacity]: 0 free, 1 alive
     soff_t died_bits_off, row_mask_off;     // DevProgram: one bit per slot "died in this frame's update"; one bit per list row "survives"
+    soff_t horizon_off;        // death horizons (DevProgram): hz = maintained (eligible program), hz_use = this frame's ticks are finite: may skip
+    uint32_t hz, hz_use, hz_parity, frame_no;
+    uint32_t* fault;           // HnbEffectMetadata::fault
     uint32_t slot_order;       // HNB_LIST_ORDER_SLOT: k_order_write rebuilds the lists from the alive bytes
     uint32_t rotate_front;     // ribbon programs, host-proven (HnbProgram::sort_front_*): this frame's spawns sort in front of every older
                                // particle, so the survivors are written [spawns | older ones] and the list needs no sort afterwards
@@ -804,6 +890,8 @@ struct SlotArgs {
     soff_t lmin_off;
     uint32_t dt_operand;
     uint32_t age_cohort;     // 1: chunks whose alive particles all have the same AGE keep it in one word (below)
+    soff_t horizon_off;      // death horizons: the instance's clock is advanced here (horizon != 0)
+    uint32_t horizon;
     uint32_t frame_phase;    // frames this program ran, mod 16: staggers the re-check of chunks known to hold mixed ages (cohort state 4)
     const Ins* update_code;
     // "No particle can die before ..." (below): safe_words = u32[2][safe_stride] float bits, the frame's minimum remaining life
@@ -940,6 +1028,10 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     float* lmin = reinterpret_cast<float*>(base + args.lmin_off);
     const float Lm = cull ? lmin[j] : 0.0f;           // 0 (or anything not > 0): unknown, every step loads the lifetimes
     const float dt_tick = cull ? uf(U, args.dt_operand) : 0.0f;
+    if (args.horizon && j == 0u && tid == 0u) {       // the instance's clock: once per simulated frame (frozen instances returned above)
+        double* clk = horizon_view(base, args.horizon_off, args.chunks_per_inst).clock;
+        *clk = *clk + (double)(dt_tick > 0.0f ? dt_tick : 0.0f) * (1.0 + 0x1p-16);
+    }
     float wave_min = __builtin_inff();                // minimum lifetime of the particles that stay alive (steps that loaded them)
     bool loaded_all = true;                           // wave-uniform: every step with alive slots loaded the lifetimes
     // ---- the flat path: a completely alive chunk of a component-wise program (PROG::kFlat: AGE_TICK, VEL_SCALE, VEL_ADD, EULER only) whose
@@ -1277,8 +1369,23 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     ChunkCtx c;
-    if (!chunk_setup(c, chunk, args, inst_base, meta_in, fi)) return;
+    const bool has_rows = chunk_setup(c, chunk, args, inst_base, meta_in, fi);
+    const HorizonView hz = horizon_view(c.base, args.horizon_off, args.chunks_per_inst);
+    if (args.hz && tid == 0u) { hz.D[args.hz_parity ^ 1u][c.j] = kHorizonNever; hz.BF[args.hz_parity ^ 1u][c.j] = 0xffffffffu; }   // k_compact merges into these
+    if (!has_rows) return;
     if (cb.deaths[(size_t)cb.parity * cb.table_cap + c.k] == 0u) return;  // nothing died in this instance: the list stands
+    if (args.hz_use) {   // can a row of this chunk have died in this frame? (see "death horizons")
+        const double clock = *hz.clock;
+        if (clock < u2d(hz.D[args.hz_parity][c.j]) && args.frame_no - hz.BF[args.hz_parity][c.j] <= kHorizonFrames) {
+            const uint32_t rows_ = (c.n - c.start) < kChunk ? (c.n - c.start) : kChunk;
+            if (tid < kChunk / 64u) {
+                const unsigned long long m = rows_ >= (tid + 1u) * 64u ? ~0ull : (rows_ > tid * 64u ? ((1ull << (rows_ - tid * 64u)) - 1ull) : 0ull);
+                (reinterpret_cast<unsigned long long*>(c.base + args.row_mask_off) + (size_t)c.j * (kChunk / 64u))[tid] = m;
+            }
+            if (tid == 0u) cb.counts[chunk] = rows_;
+            return;
+        }
+    }
     const uint32_t* list = reinterpret_cast<const uint32_t*>(c.base + args.alive_off[c.m.write_index]) + c.start;
     const uint32_t* died = reinterpret_cast<const uint32_t*>(c.base + args.died_bits_off);
     unsigned long long* rmask = reinterpret_cast<unsigned long long*>(c.base + args.row_mask_off) + (size_t)c.j * (kChunk / 64u);
