@@ -1373,6 +1373,9 @@ int hnb_simulate(HnbContext* ctx) {
                               ctx->sim.real_time, ctx->sim.real_delta_time};
         const uint32_t nu = p->dev.n_uregs;
         uint32_t blocks = 0;
+        uint64_t cpu_spawns = 0;
+        for (uint32_t i = 0; i < n; ++i) if (p->effects[i]->simulated && !p->effects[i]->parent) cpu_spawns += p->effects[i]->spawn_count;
+        const bool big_burst = cpu_spawns >= (1ull << 20);
         for (uint32_t i = 0; i < n; ++i) {
             HnbEffect* fx = p->effects[i];
             memset(&fi[i], 0, sizeof fi[i]);
@@ -1402,6 +1405,9 @@ int hnb_simulate(HnbContext* ctx) {
             // never launch more init workgroups than the capacity allows (max_spawn <= capacity)
             const uint32_t cap_spawn = std::min(max_request, p->dev.capacity);
             uint32_t inst_blocks = (uint32_t)(((uint64_t)cap_spawn + kInitBlock - 1) / kInitBlock);
+            // a large burst: kInitRounds groups of spawns per workgroup (k_init: the search for the instance, the parameter loads and the
+            // merge of the death horizons are per workgroup and pass)
+            if (big_burst) inst_blocks = (inst_blocks + kInitRounds - 1u) / kInitRounds;
             // event-driven spawns: the count lives on the device, so launch a bounded grid that strides (k_init)
             if (fx->parent) inst_blocks = std::min<uint32_t>(inst_blocks, ctx->num_cus * 8u);
             blocks += inst_blocks;

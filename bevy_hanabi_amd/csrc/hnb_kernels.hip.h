@@ -184,9 +184,9 @@ struct InterpCodeWide : InterpCode {
 // of its life. Per instance the slab keeps a CLOCK, the sum of the ticks so far (binary64, advanced once per frame by the update kernel by
 // max(tick, 0) (1 + 2^-16)), and per 4096-ROW chunk a lower bound D of the clock value at which one of its rows can die first, plus the
 // frame BF its oldest row was born in:
-//   k_init       a spawn with 0 <= age0 <= 0.74 lifetime gets D = clock + (lifetime - age0)(1 - 2^-10), else D = clock (no claim); the wave
-//                takes the minimum per row chunk of the rows it appends (of the f32 term: the clock is common) and merges it with an atomic
-//                min (u64: non-negative doubles order like their bits), BF likewise;
+//   k_init       a spawn with 0 <= age0 <= 0.74 lifetime gets D = clock + (lifetime - age0)(1 - 2^-10), else D = clock (no claim); the
+//                workgroup takes the minimum per row chunk of the rows it appends (of the f32 term, in LDS: the clock is common) and merges
+//                it with an atomic min (u64: non-negative doubles order like their bits), BF likewise;
 //   k_count_rows a chunk with clock < D and frame - BF <= 4096 is not gathered: every row survives (mask all ones, count = rows);
 //   k_compact    rows move to lower rows: a source chunk's (D, BF) is merged into the one or two target chunks its survivors land in.
 // Why this is safe: f32 ages are accumulated with one rounding of 2^-24 relative per frame, so after N <= 4097 frames
@@ -194,19 +194,22 @@ struct InterpCodeWide : InterpCode {
 // age < lifetime - 2^-10 (lifetime - age0) + 2.5e-4 lifetime <= lifetime for age0 <= 0.74 lifetime: the program's own `age < lifetime` holds,
 // the particle is alive after this frame. Non-finite ticks switch the use off for the frame (CompactArgs::hz_use); host writes reset the
 // arrays; a violated claim would make k_compact's survivor count disagree with the update's casualty count: HnbEffectMetadata::fault.
-struct HorizonView {
+struct HorizonView {   // (no pointer ARRAYS indexed by the parity: the compiler keeps such a struct in LDS - 40 B x 256 threads - and the
+                       // launch of a small kernel with 10 KiB of LDS per workgroup took 25 us longer, profiles/r03j_kernels.log)
     double* clock;
-    unsigned long long* D[2];
-    uint32_t* BF[2];
+    unsigned long long* d0;
+    uint32_t* bf0;
+    uint32_t chunks;
+    __device__ __forceinline__ unsigned long long* D(uint32_t parity) const { return d0 + (size_t)parity * chunks; }
+    __device__ __forceinline__ uint32_t* BF(uint32_t parity) const { return bf0 + (size_t)parity * chunks; }
 };
 __device__ __forceinline__ HorizonView horizon_view(char* base, soff_t off, uint32_t chunks) {
     HorizonView h;
     char* p = base + off;
     h.clock = reinterpret_cast<double*>(p);
-    h.D[0] = reinterpret_cast<unsigned long long*>(p + 256);
-    h.D[1] = h.D[0] + chunks;
-    h.BF[0] = reinterpret_cast<uint32_t*>(h.D[1] + chunks);
-    h.BF[1] = h.BF[0] + chunks;
+    h.d0 = reinterpret_cast<unsigned long long*>(p + 256);
+    h.bf0 = reinterpret_cast<uint32_t*>(h.d0 + 2 * (size_t)chunks);
+    h.chunks = chunks;
     return h;
 }
 constexpr unsigned long long kHorizonNever = 0x7ff0000000000000ull;   // +inf: no row, nobody can die
@@ -252,8 +255,24 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
 
     const HorizonView hz = horizon_view(base, prog.horizon_off, prog.chunks_per_inst);
     const double clock_now = prog.horizon ? *hz.clock : 0.0;
-    // (the trip count is uniform over the workgroup: the horizon merge below is a wave operation)
-    for (uint32_t i0 = (blk - first_block) * kInitBlock; i0 < n_spawn; i0 += n_blocks * kInitBlock) {
+    __shared__ uint32_t s_hz[2][2];
+    uint32_t pass_no = 0;
+    if (prog.horizon) { if (threadIdx.x < 2u) s_hz[0][threadIdx.x] = 0xffffffffu; __syncthreads(); }
+    // A workgroup takes `rounds` consecutive groups of 256 spawns per pass (as many as the grid the host chose leaves to each workgroup, at
+    // most 4: hnb_simulate launches a quarter of the workgroups when the frame spawns a million particles or more - the horizon merge
+    // below costs two global atomics per PASS, and a short init program is bound by its per-workgroup preamble) and strides over the rest. Trip counts are uniform over the
+    // workgroup (the merge has a barrier).
+    const uint32_t per_round = n_blocks * kInitBlock;
+    uint32_t rounds = 1u;                                               // ceil(n_spawn / per_round), at most kInitRounds (no division: this is per workgroup)
+#pragma unroll
+    for (uint32_t r = 1; r < kInitRounds; ++r) rounds += (uint64_t)n_spawn > (uint64_t)r * per_round ? 1u : 0u;
+    const uint32_t pass_rows = rounds * kInitBlock;
+    const uint32_t pass_stride = n_blocks * pass_rows;                  // (< n_spawn + per_round: no overflow; the loop ends before p0 could wrap)
+    for (uint32_t p0 = (blk - first_block) * pass_rows; p0 < n_spawn; p0 = n_spawn - p0 <= pass_stride ? n_spawn : p0 + pass_stride) {
+    uint32_t* sw = s_hz[pass_no & 1u];
+    const uint32_t rc0 = (alive0 + p0) / kChunk;                        // (workgroup-uniform: the chunk of the pass's first row; its <= 1024 rows lie in it or the next)
+    if (prog.horizon && threadIdx.x < 2u) s_hz[(pass_no & 1u) ^ 1u][threadIdx.x] = 0xffffffffu;   // see below
+    for (uint32_t i0 = p0; i0 < p0 + pass_rows && i0 < n_spawn; i0 += kInitBlock) {
         const uint32_t i = i0 + threadIdx.x;
         uint32_t r_bits = 0xffffffffu;   // (an idle lane)
         if (i < n_spawn) {
@@ -292,30 +311,29 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
             r_bits = f2u(r0);
         }
         }
-        if (prog.horizon) {
-            // rows alive0 + i of a wave lie in one row chunk, or in two (one wave in 64): one atomic min per chunk and wave.
-            // Non-negative floats order like their bits; the clock is the same for the whole launch: min D = clock + min r0.
-            const uint32_t lane = threadIdx.x & 63u;
-            const uint32_t row0 = alive0 + (i - lane);                 // lane 0's row (the wave's lowest; an all-idle wave merges nothing)
-            const uint32_t rc0 = row0 / kChunk, rc_last = (row0 + 63u) / kChunk;   // (wave-uniform)
-            const bool second = rc_last != rc0 && (alive0 + i) / kChunk != rc0;
-            uint32_t m0 = second ? 0xffffffffu : r_bits;
-#pragma unroll
-            for (uint32_t off = 32; off > 0; off >>= 1) { const uint32_t y = __shfl_xor(m0, off, 64); m0 = y < m0 ? y : m0; }
-            if (lane == 0u && m0 != 0xffffffffu) {
-                atomicMin(&hz.D[prog.hz_parity][rc0], d2u(clock_now + (double)u2f(m0)));
-                atomicMin(&hz.BF[prog.hz_parity][rc0], prog.frame_no);
-            }
-            if (rc_last != rc0) {
-                uint32_t m1 = second ? r_bits : 0xffffffffu;
-#pragma unroll
-                for (uint32_t off = 32; off > 0; off >>= 1) { const uint32_t y = __shfl_xor(m1, off, 64); m1 = y < m1 ? y : m1; }
-                if (lane == 0u && m1 != 0xffffffffu && rc_last < prog.chunks_per_inst) {
-                    atomicMin(&hz.D[prog.hz_parity][rc_last], d2u(clock_now + (double)u2f(m1)));
-                    atomicMin(&hz.BF[prog.hz_parity][rc_last], prog.frame_no);
-                }
+        // the lanes take the minimum of their f32 terms per row chunk in LDS (ds_min_u32: the LDS pipe is idle in this kernel, the VALU is what
+        // bounds a burst; non-negative floats order like their bits; the clock is common to the launch: min D = clock + min r0)
+        if (prog.horizon && r_bits != 0xffffffffu) atomicMin(&sw[(alive0 + i) / kChunk != rc0 ? 1 : 0], r_bits);
+    }
+    if (prog.horizon) {
+        // ... and threads 0 and 1 merge the pass's two results into the chunks' words with global atomics. What bounds this is the number of
+        // global atomics (they execute beyond the XCD's L2): one pair per WAVE (no barrier at all) cost a 16.7M burst 0.07 ms, one pair per 256
+        // spawns 0.02-0.03 ms (profiles/r03l_ab.log, r03n_ab.log). Fire and forget: reading the words first, to skip atomics that cannot
+        // lower them, made the workgroup wait for the loads - 3x the time of a burst (profiles/r03m_ab.log).
+        // s_hz[pass & 1] is this pass's pair; threads 0 / 1 reset the other pair at the start of the pass (they read it themselves, after the
+        // previous pass's barrier; the other waves touch it only after this one): one barrier per pass, and one that waits for the wave's LDS
+        // operations only (__syncthreads() is also a release fence for the particle stores above - s_waitcnt vmcnt(0): the wave would sit
+        // until its ~20 scattered stores per round are acknowledged).
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (threadIdx.x < 2u) {
+            const uint32_t m = sw[threadIdx.x], rc = rc0 + threadIdx.x;
+            if (m != 0xffffffffu && rc < prog.chunks_per_inst) {
+                atomicMin(&hz.D(prog.hz_parity)[rc], d2u(clock_now + (double)u2f(m)));
+                atomicMin(&hz.BF(prog.hz_parity)[rc], prog.frame_no);
             }
         }
+        pass_no += 1u;
+    }
     }
 }
 // ---- streaming-kernel pinned attribute access (P = 4) -------------------------------------------
@@ -505,6 +523,20 @@ __device__ __forceinline__ uint32_t chunk_of_workgroup(uint32_t mode, uint32_t b
 }
 __device__ __forceinline__ uint32_t chunk_of_workgroup(uint32_t mode) { return chunk_of_workgroup(mode, blockIdx.x, gridDim.x); }
 
+// DevMeta travels as two 16-byte words (a struct copy through pointers that may alias became a memcpy through a private array in the
+// job-table kernels, which the compiler kept in LDS: 3 KiB per workgroup)
+__device__ __forceinline__ DevMeta load_meta(const DevMeta* p) {
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];
+    DevMeta m;
+    m.alive_count = a.x; m.particle_counter = a.y; m.write_index = a.z; m.max_update = a.w;
+    m.dead_count = b.x; m.spawned = b.y; m.ref_write_index = b.z; m.instance_count = b.w;
+    return m;
+}
+__device__ __forceinline__ void store_meta(DevMeta* p, const DevMeta& m) {
+    reinterpret_cast<uint4*>(p)[0] = make_uint4(m.alive_count, m.particle_counter, m.write_index, m.max_update);
+    reinterpret_cast<uint4*>(p)[1] = make_uint4(m.dead_count, m.spawned, m.ref_write_index, m.instance_count);
+}
+
 // Decode a chunk id; false when the chunk has no rows.
 template <class ARGS>
 __device__ __forceinline__ bool chunk_setup(ChunkCtx& c, uint32_t chunk, const ARGS& args, const uint64_t* inst_base, const DevMeta* meta_in,
@@ -512,7 +544,7 @@ __device__ __forceinline__ bool chunk_setup(ChunkCtx& c, uint32_t chunk, const A
     c.k = chunk / args.chunks_per_inst;
     c.j = chunk - c.k * args.chunks_per_inst;
     // vfx_indirect.wgsl:57-85 folded in: max_update = alive_count after init.
-    c.m = meta_in[c.k];
+    c.m = load_meta(meta_in + c.k);
     const uint32_t spawn = requested_spawn(fi[c.k]);
     const uint32_t max_spawn = args.capacity - c.m.alive_count;
     c.n_spawn = spawn < max_spawn ? spawn : max_spawn;
@@ -533,8 +565,8 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     const bool has_rows = chunk_setup(c, chunk, args, inst_base, meta_in, fi);
     const HorizonView hz = horizon_view(c.base, args.horizon_off, args.chunks_per_inst);
     if (fi[c.k].skip) {  // not simulated this frame: counters carry over unchanged
-        if (c.j == 0 && tid == 0) { meta_out[c.k] = c.m; cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + c.k] = 0u; }
-        if (args.hz && tid == 0) { hz.D[args.hz_parity ^ 1u][c.j] = hz.D[args.hz_parity][c.j]; hz.BF[args.hz_parity ^ 1u][c.j] = hz.BF[args.hz_parity][c.j]; }   // the rows stand: so do their horizons
+        if (c.j == 0 && tid == 0) { store_meta(meta_out + c.k, c.m); cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + c.k] = 0u; }
+        if (args.hz && tid == 0) { hz.D(args.hz_parity ^ 1u)[c.j] = hz.D(args.hz_parity)[c.j]; hz.BF(args.hz_parity ^ 1u)[c.j] = hz.BF(args.hz_parity)[c.j]; }   // the rows stand: so do their horizons
         return;
     }
     uint32_t* deaths_cur = cb.deaths + (size_t)cb.parity * cb.table_cap;
@@ -543,14 +575,14 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     const bool last = c.n == 0 ? c.j == 0 : (c.start < c.n && c.start + kChunk >= c.n);
     const bool rotate = args.rotate_front != 0u && c.n_spawn != 0u;   // (uniform per instance; never set together with slot_order)
     if (total_dead == 0u && !rotate) {
-        if (args.hz && tid == 0) { hz.D[args.hz_parity ^ 1u][c.j] = hz.D[args.hz_parity][c.j]; hz.BF[args.hz_parity ^ 1u][c.j] = hz.BF[args.hz_parity][c.j]; }   // no row moved
+        if (args.hz && tid == 0) { hz.D(args.hz_parity ^ 1u)[c.j] = hz.D(args.hz_parity)[c.j]; hz.BF(args.hz_parity ^ 1u)[c.j] = hz.BF(args.hz_parity)[c.j]; }   // no row moved
         if (last && tid == 0) {
             DevMeta o = c.m;
             o.alive_count = c.n;
             o.particle_counter = c.m.particle_counter + c.n_spawn;
             o.ref_write_index = c.m.ref_write_index ^ 1u;
             o.max_update = c.n; o.dead_count = 0; o.spawned = c.n_spawn; o.instance_count = c.n;
-            meta_out[c.k] = o;
+            store_meta(meta_out + c.k, o);
         }
         return;
     }
@@ -562,7 +594,7 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
             o.particle_counter = c.m.particle_counter + c.n_spawn;
             o.ref_write_index = c.m.ref_write_index ^ 1u;
             o.max_update = c.n; o.dead_count = total_dead; o.spawned = c.n_spawn; o.instance_count = survivors;
-            meta_out[c.k] = o;
+            store_meta(meta_out + c.k, o);
         }
         return;
     }
@@ -594,15 +626,15 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     for (uint32_t off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(wincl, off, 64); if (lane >= off) wincl += y; }
     const uint32_t a = __shfl(wincl, 63, 64);   // survivors of this chunk ( == cnt[c.j] where k_count_rows ran)
     if (args.hz && tid == 0u && a != 0u) {      // this chunk's survivors land on rows [excl, excl + a): one target chunk or two inherit its horizon
-        const unsigned long long d = hz.D[args.hz_parity][c.j];
-        const uint32_t bf = hz.BF[args.hz_parity][c.j];
+        const unsigned long long d = hz.D(args.hz_parity)[c.j];
+        const uint32_t bf = hz.BF(args.hz_parity)[c.j];
         const uint32_t t0 = excl / kChunk, t1 = (excl + a - 1u) / kChunk;
-        atomicMin(&hz.D[args.hz_parity ^ 1u][t0], d); atomicMin(&hz.BF[args.hz_parity ^ 1u][t0], bf);
-        if (t1 != t0) { atomicMin(&hz.D[args.hz_parity ^ 1u][t1], d); atomicMin(&hz.BF[args.hz_parity ^ 1u][t1], bf); }
+        atomicMin(&hz.D(args.hz_parity ^ 1u)[t0], d); atomicMin(&hz.BF(args.hz_parity ^ 1u)[t0], bf);
+        if (t1 != t0) { atomicMin(&hz.D(args.hz_parity ^ 1u)[t1], d); atomicMin(&hz.BF(args.hz_parity ^ 1u)[t1], bf); }
     }
     const uint32_t wexcl = wincl - wcount;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(c.base + args.alive_off[c.m.write_index]) + c.start;
-    uint32_t* out = reinterpret_cast<uint32_t*>(c.base + args.alive_off[c.m.write_index ^ 1u]);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(c.base + ((c.m.write_index & 1u) ? args.alive_off[1] : args.alive_off[0])) + c.start;
+    uint32_t* out = reinterpret_cast<uint32_t*>(c.base + ((c.m.write_index & 1u) ? args.alive_off[0] : args.alive_off[1]));   // (selects, not a dynamic index: the job-table variant kept the offsets in LDS otherwise)
     // survivor g of the instance goes to row g - or, rotated: the last n_spawn survivors are this frame's spawns (k_init appended them, none of
     // them dies in its first frame: a premise of the proof) and go first, everything older follows
     const uint32_t tail = rotate ? c.n_spawn : 0u;
@@ -646,7 +678,7 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
         o.dead_count = c.n - survivors;
         o.spawned = c.n_spawn;
         o.instance_count = survivors;
-        meta_out[c.k] = o;
+        store_meta(meta_out + c.k, o);
     }
 }
 
@@ -1371,12 +1403,12 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
     ChunkCtx c;
     const bool has_rows = chunk_setup(c, chunk, args, inst_base, meta_in, fi);
     const HorizonView hz = horizon_view(c.base, args.horizon_off, args.chunks_per_inst);
-    if (args.hz && tid == 0u) { hz.D[args.hz_parity ^ 1u][c.j] = kHorizonNever; hz.BF[args.hz_parity ^ 1u][c.j] = 0xffffffffu; }   // k_compact merges into these
+    if (args.hz && tid == 0u) { hz.D(args.hz_parity ^ 1u)[c.j] = kHorizonNever; hz.BF(args.hz_parity ^ 1u)[c.j] = 0xffffffffu; }   // k_compact merges into these
     if (!has_rows) return;
     if (cb.deaths[(size_t)cb.parity * cb.table_cap + c.k] == 0u) return;  // nothing died in this instance: the list stands
     if (args.hz_use) {   // can a row of this chunk have died in this frame? (see "death horizons")
         const double clock = *hz.clock;
-        if (clock < u2d(hz.D[args.hz_parity][c.j]) && args.frame_no - hz.BF[args.hz_parity][c.j] <= kHorizonFrames) {
+        if (clock < u2d(hz.D(args.hz_parity)[c.j]) && args.frame_no - hz.BF(args.hz_parity)[c.j] <= kHorizonFrames) {
             const uint32_t rows_ = (c.n - c.start) < kChunk ? (c.n - c.start) : kChunk;
             if (tid < kChunk / 64u) {
                 const unsigned long long m = rows_ >= (tid + 1u) * 64u ? ~0ull : (rows_ > tid * 64u ? ((1ull << (rows_ - tid * 64u)) - 1ull) : 0ull);
@@ -1386,7 +1418,7 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
             return;
         }
     }
-    const uint32_t* list = reinterpret_cast<const uint32_t*>(c.base + args.alive_off[c.m.write_index]) + c.start;
+    const uint32_t* list = reinterpret_cast<const uint32_t*>(c.base + ((c.m.write_index & 1u) ? args.alive_off[1] : args.alive_off[0])) + c.start;
     const uint32_t* died = reinterpret_cast<const uint32_t*>(c.base + args.died_bits_off);
     unsigned long long* rmask = reinterpret_cast<unsigned long long*>(c.base + args.row_mask_off) + (size_t)c.j * (kChunk / 64u);
     const uint32_t rows = (c.n - c.start) < kChunk ? (c.n - c.start) : kChunk;

@@ -1181,6 +1181,12 @@ int hor_effect_read_attr(const Effect* fx, uint32_t attr, void* dst) {
     memcpy(dst, fx->plane[attr], (size_t)fx->asset->capacity * k_attr[attr].count * 4u);
     return 0;
 }
+/* a host write of a whole attribute plane (the counterpart of hnb_effect_write_attr: tests change particle state behind the product's bookkeeping) */
+int hor_effect_write_attr(Effect* fx, uint32_t attr, const void* src) {
+    if (attr >= N_ATTRS || !fx->plane[attr]) return -1;
+    memcpy(fx->plane[attr], src, (size_t)fx->asset->capacity * k_attr[attr].count * 4u);
+    return 0;
+}
 /* alive list as the NEXT frame reads it (column written by the last update) */
 void hor_effect_read_alive_list(const Effect* fx, uint32_t* dst) { memcpy(dst, fx->list[fx->write_index], (size_t)fx->alive_count * 4u); }
 /* free slots, from the top of the stack (row alive_count) */

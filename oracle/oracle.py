@@ -57,6 +57,7 @@ def _lib(omp=False, libm=False):
         lib.hor_effect_error.argtypes = [C.c_void_p]
         lib.hor_effect_attr_components.argtypes = [C.c_void_p, C.c_uint32]
         lib.hor_effect_read_attr.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.hor_effect_write_attr.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         lib.hor_effect_read_alive_list.argtypes = [C.c_void_p, C.c_void_p]
         lib.hor_effect_read_dead_list.argtypes = [C.c_void_p, C.c_void_p]
         lib.hor_pcg_hash.restype = C.c_uint32
@@ -168,6 +169,12 @@ class OracleEffect:
         out = np.zeros((self.capacity, n), dtype=np.uint32)
         self._lib.hor_effect_read_attr(self._fx, int(attr_id), out.ctypes.data)
         return out.view(np.float32) if ATTR_IS_FLOAT[int(attr_id)] else out
+
+    def write_attr(self, attr_id, array):
+        a = np.ascontiguousarray(array)
+        n = self._lib.hor_effect_attr_components(self._fx, int(attr_id))
+        assert n and a.nbytes == self.capacity * n * 4
+        self._lib.hor_effect_write_attr(self._fx, int(attr_id), a.ctypes.data)
 
     def alive_list(self):
         out = np.zeros(self.alive_count(), dtype=np.uint32)

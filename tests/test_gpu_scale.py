@@ -311,6 +311,53 @@ def test_100m_particle_firework_past_the_4_gib_slab_limit(ctx):
     r.fx.destroy(); r.prog.destroy()
 
 
+def test_death_horizons_under_adverse_ticks_and_host_writes(ctx):
+    """k_count_rows skips the died-bit gather for row chunks whose particles provably cannot have died yet (the alive list is in birth order;
+    per row chunk a lower bound of the clock at which a row can die first, hnb_kernels.hip.h "death horizons"). The claim rests on the ticks the
+    particles really saw: zero, tiny, large and NEGATIVE ticks, a frame with an infinite tick (everything dies at once: the use is switched off
+    for that frame), a host write that halves every LIFETIME behind the horizons' back (they are reset), initial ages above 0.74 lifetime (no
+    claim is made for those rows) - full state against the oracle after every frame, no fault raised, and the horizons were in use."""
+    cap = 60000
+    w = bh.ExprWriter()
+    accel = w.lit((0.0, -3.0, 0.0)).expr()
+    init = [bh.SetAttributeModifier(A.POSITION, w.lit((0.0, 0.0, 0.0)).expr()),
+            bh.SetAttributeModifier(A.VELOCITY, ((w.rand(bh.VectorType.VEC3F) * w.lit(2.0) - w.lit(1.0)).normalized() * w.lit(3.0)).expr()),
+            bh.SetAttributeModifier(A.AGE, (w.rand(bh.ValueType(bh.ScalarType.Float)) * w.lit(0.9)).expr()),          # some start above 0.74 lifetime
+            bh.SetAttributeModifier(A.LIFETIME, w.lit(0.6).uniform(w.lit(1.4)).expr())]
+    asset = bh.EffectAsset(cap, bh.SpawnerSettings.rate(cap / 0.8), w.finish())
+    for m in init:
+        asset.init(m)
+    asset.update(bh.AccelModifier(accel))
+    gpu, orc = GpuRunner(asset, ctx=ctx), OracleRunner(asset, omp=True)
+    assert "death horizons" in gpu.prog.kernel_info()
+    sp, rng = bh.EffectSpawner(asset.spawner), bh.Pcg32()
+    ticks = [1 / 60, 1 / 60, 0.0, 1 / 30, -1 / 120, 1 / 60, 1e-6, 1 / 60, 0.2, 1 / 60, 1 / 240, 1 / 60]
+    t = 0.0
+    for f in range(150):
+        dt = ticks[f % len(ticks)]
+        if f == 100:
+            dt = float("inf")
+        fr = Frame(dt, sp.tick(1 / 60, rng), frame_seed(f), time=t)
+        t += dt if np.isfinite(dt) else 0.0
+        if f == 60:   # the lifetimes change behind the horizons' back
+            life = gpu.fx.read_attr(A.LIFETIME.id) * np.float32(0.5)
+            gpu.fx.write_attr(A.LIFETIME.id, life)
+            orc.fx.write_attr(A.LIFETIME.id, life)
+        if f in (80, 81, 82):
+            gpu.fx.set_simulated(f == 82)     # frozen for two frames (the clock stands still with the particles)
+            if f != 82:
+                continue
+        gpu.step(fr)
+        orc.step(fr)
+        assert_same_state(orc.state(), gpu.state(), f"death horizons frame {f}")
+    m = gpu.fx.metadata()
+    assert m["fault"] == 0 and m["particle_counter"] > 2 * cap
+    info = gpu.prog.kernel_info()
+    used = int([ln for ln in info.split("\n") if ln.startswith("death horizons in use")][0].split(":")[1].split()[0])
+    assert used > 100, info
+    gpu.fx.destroy(); gpu.prog.destroy()
+
+
 def test_c4_instancing_one_gpu_share_at_baseline_size(ctx):
     """instancing.rs, 512 instances x 65,536 (one GPU's share of BASELINE config 4: 4096 instances over 8 GPUs, instance i
     on rank i mod 8 — rank 0 owns 0, 8, 16, ...). dt = 3 s with the rate spawner: a quarter of the capacity spawns per frame

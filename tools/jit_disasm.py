@@ -18,6 +18,9 @@ for f in os.listdir(d):
     co = os.path.join(d, f + ".co")
     open(co, "wb").write(code)
     txt = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--mcpu=gfx950", co], capture_output=True, text=True).stdout
+    notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+    for m in re.finditer(r"\.group_segment_fixed_size:\s+(\d+)[\s\S]*?\.name:\s+(\S+)[\s\S]*?\.private_segment_fixed_size:\s+(\d+)[\s\S]*?\.vgpr_count:\s+(\d+)", notes):
+        print(f"{m.group(2)[:60]}: LDS {m.group(1)} B, scratch {m.group(3)} B, {m.group(4)} VGPRs")
     cur, counts = None, {}
     for ln in txt.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
