@@ -50,6 +50,8 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct TimingPair { hipEvent_t a, b; const HnbProgram* prog; };
 constexpr uint32_t kFrameRing = 4;
+constexpr uint32_t kSceneMaxChunks = 16;       // a program is "small" this frame: <= 65,536 slots over all of its instances ...
+constexpr uint32_t kSceneMaxInitBlocks = 64;   // ... and <= 16,384 spawns (hnb_simulate: merged launches)
 
 }  // namespace
 
@@ -121,6 +123,7 @@ struct HnbContext {
     uint32_t list_order = HNB_LIST_ORDER_SPAWN;  // applied to programs created afterwards
     bool skip_lists = true;     // skip the list kernels of frames the device's no-death bound covers (HNB_SKIP_LISTS=0 turns it off)
     bool alternate = true;      // walk the chunks in alternating directions from frame to frame (HNB_ALTERNATE=0 turns it off)
+    bool scene_merge = true;    // small programs share their init / update launches (ProgJob / StreamJob; HNB_SCENE_MERGE=0 turns it off)
     bool transpose = true;      // vec3 planes of the per-particle update path through the wave's LDS transpose (HNB_TRANSPOSE=0 turns it off)
     uint32_t timing = 0;        // 0 = off, n = time every n-th simulated frame
     uint32_t timing_tick = 0;
@@ -179,6 +182,9 @@ struct HnbProgram {
     // "no particle can die before ..." (hnb_kernels.hip.h, SlotArgs): the update publishes a lower bound of the remaining life of
     // every alive particle; while the ticks accumulated since stay below it, a frame without spawn needs no list kernels.
     bool skip_eligible = false;             // streamable, lifetime-culled, no kill modifier: particles only die of old age
+    bool init_merged = false, update_merged = false;   // this frame: served by the job-table launches of small programs (k_init_jobs, k_update_*_jobs)
+    bool mergeable = false;                 // no spawn events in or out, no parent: its passes are independent of every other program's
+    uint32_t merged_frames = 0;             // statistics
     bool horizon_eligible = false;          // ... the same without the spawn-event restrictions: row-chunk death horizons are maintained (hnb_kernels.hip.h)
     uint32_t hz_parity = 0;                 // which half of the horizon arrays is current (flips in frames whose list kernels ran)
     bool hz_use_now = false;                // this frame's ticks are finite: k_count_rows may skip chunks
@@ -769,6 +775,7 @@ int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     if (const char* e = getenv("HNB_ALTERNATE")) ctx->alternate = e[0] != '0';
     if (const char* e = getenv("HNB_TRANSPOSE")) ctx->transpose = e[0] != '0';
+    if (const char* e = getenv("HNB_SCENE_MERGE")) ctx->scene_merge = e[0] != '0';
     if (const char* e = getenv("HNB_SKIP_LISTS")) ctx->skip_lists = e[0] != '0';
     *out_ctx = ctx;
     return HNB_OK;
@@ -1303,6 +1310,35 @@ static CompactBufs compact_bufs_of(const HnbContext* ctx, const HnbProgram* p, u
     cb.xcd_remap = (n > 1 ? 1u : 0u) | (ctx->alternate && !(p->frames_run & 1u) ? 2u : 0u);  // see chunk_of_workgroup; the first frame walks DOWN: a burst's init wrote the planes upwards
     return cb;
 }
+// the streaming update's arguments for this frame (hnb_simulate: the program's own launch, or its row of the job table)
+static SlotArgs slot_args_of(const HnbContext* ctx, const HnbProgram* p, uint32_t n, uint32_t write_died) {
+    const uint32_t par = p->parity;
+    SlotArgs sa{};
+    sa.capacity = p->dev.capacity; sa.n_uregs = p->dev.n_uregs; sa.chunks_per_inst = p->dev.chunks_per_inst; sa.n_inst = n;
+    sa.alive_flag_off = p->dev.alive_flag_off;
+    sa.update_len = p->dev.update_len;
+    sa.update_code = p->dev.update_code;
+    sa.died_bits_off = p->dev.died_bits_off; sa.write_died = write_died;
+    sa.cull_lifetime = p->dev.cull_lifetime; sa.lmin_off = p->dev.lmin_off; sa.dt_operand = p->cull_dt_operand;
+    sa.age_cohort = p->dev.age_cohort;
+    sa.frame_phase = p->frames_run & 15u;
+    sa.horizon_off = p->dev.horizon_off; sa.horizon = p->horizon_eligible ? 1u : 0u;
+    if (p->skip_eligible) { sa.safe_words = p->d_safe; sa.safe_host = p->h_safe; sa.safe_parity = p->frames_run & 1u; sa.publish_tag = p->frames_run - 1u; sa.safe_stride = p->table_cap * p->dev.chunks_per_inst; }
+    sa.skip_lists = p->skip_now ? 1u : 0u;
+    sa.meta_in = p->d_meta[par]; sa.meta_out = p->d_meta[par ^ 1];
+    sa.fault = p->d_fault;
+    sa.transpose = ctx->transpose ? 1u : 0u;
+    for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
+        const DevAttr& at = p->dev.attrs[a];
+        const int pi = at.reg == HNB_REG_POSITION ? 0 : at.reg == HNB_REG_VELOCITY ? 1 : at.reg == HNB_REG_AGE ? 2 : at.reg == HNB_REG_LIFETIME ? 3 : -1;
+        if (pi < 0) continue;
+        sa.plane_off[pi] = at.plane_off;
+        if (at.upd_flags & HNB_ATTR_UPD_LOAD) sa.flags |= 1u << pi;
+        if (at.upd_flags & HNB_ATTR_UPD_STORE) sa.flags |= 16u << pi;
+    }
+    return sa;
+}
+
 static CompactArgs compact_args_of(const HnbProgram* p) {
     CompactArgs ca{};
     ca.capacity = p->dev.capacity; ca.chunks_per_inst = p->dev.chunks_per_inst;
@@ -1344,6 +1380,7 @@ int hnb_simulate(HnbContext* ctx) {
         size_t need = 0;
         for (const HnbProgram* p : order) need += (frame_bytes_for(p, (uint32_t)p->effects.size()) + 255u) & ~(size_t)255u;
         need += order.size() * sizeof(ListsJob) + 256u;   // the job table of the multi-program list launches
+        need += order.size() * (2u * sizeof(ProgJob) + sizeof(StreamJob)) + 6u * 256u;   // ... and of the merged init / update launches of small programs
         if (need > ctx->stage_bytes) {  // grows rarely (a new program, more instances): nothing may still be reading the old buffers
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             const size_t nb = std::max<size_t>(2 * need, 64u << 10);
@@ -1519,6 +1556,9 @@ int hnb_simulate(HnbContext* ctx) {
         p->dev.hz_parity = p->hz_parity;
         p->dev.frame_no = p->frames_run;
         p->lists_merged = false;
+        p->init_merged = p->update_merged = false;
+        p->mergeable = p->hdr.n_event_channels == 0 && !(p->hdr.flags & HNB_PROG_READS_PARENT) && n != 0u;
+        for (uint32_t i = 0; i < n; ++i) if (p->effects[i]->parent) p->mergeable = false;
         uint32_t* init_start = ublocks + (size_t)n * nu;  // packed copy of init_block_start for k_init's search
         for (uint32_t i = 0; i < n; ++i) init_start[i] = fi[i].init_block_start;
         stage_off += (frame_bytes_for(p, n) + 255u) & ~(size_t)255u;
@@ -1555,6 +1595,66 @@ int hnb_simulate(HnbContext* ctx) {
             stage_off += ((size_t)n_jobs * sizeof(ListsJob) + 255u) & ~(size_t)255u;
         }
     }
+    // Small programs share their init and update launches (ProgJob / StreamJob in hnb_kernels.hip.h): per kernel family one job table and one
+    // launch of the interpreter instantiation, from two programs on. "Small" = at most kSceneMaxChunks chunks and kSceneMaxInitBlocks init
+    // workgroups this frame; independent of every other program (no spawn events, no parent). Timed frames keep one launch per program.
+    struct Family { const void* d_jobs = nullptr; uint32_t n = 0, wgs = 0; };
+    Family fam_init[2], fam_generic[2], fam_stream[2];   // [wide register file] / [age cohorts]
+    if (ctx->scene_merge && !timed && order.size() >= 2u) {
+        auto small = [](const HnbProgram* p) { return p->mergeable && (uint32_t)p->effects.size() * p->dev.chunks_per_inst <= kSceneMaxChunks; };
+        // kinds: 0 init, 1 update on the V register file, 2 streaming update; v: wide register file (0, 1) / age cohorts (2).
+        // k_update_jobs serves streaming (no cohorts), streaming (cohorts), V register file (narrow) in this order: first_wg runs over its whole grid
+        auto member_of = [&](const HnbProgram* p, int kind, int v) {
+            if (!small(p)) return false;
+            if (kind == 0) return p->init_blocks != 0u && p->init_blocks <= kSceneMaxInitBlocks && (p->wide_file ? 1 : 0) == v;
+            if (kind == 1) return !p->update_streams && (p->wide_file ? 1 : 0) == v;
+            return p->update_streams && (p->dev.age_cohort ? 1 : 0) == v;
+        };
+        auto count_of = [&](int kind, int v) { uint32_t m = 0; for (const HnbProgram* p : order) m += member_of(p, kind, v) ? 1u : 0u; return m; };
+        const bool shared_update = count_of(2, 0) + count_of(2, 1) + count_of(1, 0) >= 2u;
+        const int seq[6][2] = {{0, 0}, {0, 1}, {2, 0}, {2, 1}, {1, 0}, {1, 1}};
+        uint32_t update_base = 0;
+        for (const auto& kv : seq) {
+            const int kind = kv[0], v = kv[1];
+            auto member = [&](const HnbProgram* p) { return member_of(p, kind, v); };
+            const bool in_shared = kind == 2 || (kind == 1 && v == 0);
+            if (in_shared ? !shared_update : count_of(kind, v) < 2u) continue;
+            if (count_of(kind, v) == 0u) continue;
+            Family& f = kind == 0 ? fam_init[v] : kind == 1 ? fam_generic[v] : fam_stream[v];
+            const uint32_t base = in_shared ? update_base : 0u;
+            char* hj = static_cast<char*>(ctx->h_stage[slot]) + stage_off;
+            f.d_jobs = static_cast<const char*>(ctx->d_stage[slot]) + stage_off;
+            for (HnbProgram* p : order) {
+                if (!member(p)) continue;
+                const uint32_t n = (uint32_t)p->effects.size();
+                const char* d = p->d_frame_cur;
+                const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
+                const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
+                const uint32_t write_died = (p->lists_now && !p->slot_order) ? 1u : 0u;
+                const uint32_t wgs = kind == 0 ? p->init_blocks : n * p->dev.chunks_per_inst * (kind == 1 ? kGenericSubs : 1u);
+                if (kind == 2) {
+                    StreamJob jb{};
+                    jb.args = slot_args_of(ctx, p, n, write_died);
+                    jb.inst_base = reinterpret_cast<const uint64_t*>(p->d_inst_base); jb.fi = dfi; jb.ublocks = dub;
+                    jb.cb = compact_bufs_of(ctx, p, n);
+                    jb.first_wg = base + f.wgs; jb.n_wg = wgs;
+                    reinterpret_cast<StreamJob*>(hj)[f.n] = jb;
+                } else {
+                    ProgJob jb{};
+                    jb.prog = p->dev;
+                    jb.inst_base = reinterpret_cast<const uint64_t*>(p->d_inst_base); jb.meta_in = p->d_meta[p->parity]; jb.fi = dfi; jb.ublocks = dub;
+                    jb.cb = compact_bufs_of(ctx, p, n);
+                    jb.write_died = write_died;
+                    jb.first_wg = base + f.wgs; jb.n_wg = wgs;
+                    reinterpret_cast<ProgJob*>(hj)[f.n] = jb;
+                }
+                f.n += 1; f.wgs += wgs;
+                if (kind == 0) p->init_merged = true; else { p->update_merged = true; p->merged_frames += 1; }
+            }
+            stage_off += ((size_t)f.n * (kind == 2 ? sizeof(StreamJob) : sizeof(ProgJob)) + 255u) & ~(size_t)255u;
+            if (in_shared) update_base += f.wgs;
+        }
+    }
     if (stage_off) {
         HIP_TRY(hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], stage_off, hipMemcpyHostToDevice, ctx->upload_stream));
         HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
@@ -1568,7 +1668,7 @@ int hnb_simulate(HnbContext* ctx) {
         const char* d = p->d_frame_cur;
         const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
         const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
-        if (blocks) {
+        if (blocks && !p->init_merged) {
             TimingPair ti{};
             ti.prog = p;
             if (timed) { ti.a = take_event(ctx); ti.b = take_event(ctx); hipEventRecord(ti.a, ctx->stream); }
@@ -1583,6 +1683,10 @@ int hnb_simulate(HnbContext* ctx) {
             if (timed) { hipEventRecord(ti.b, ctx->stream); ctx->t_init.push_back(ti); }
         }
     }
+
+    // (the merged programs have no parent and no child: their init passes are independent of the ones above)
+    if (fam_init[0].n) k_init_jobs<InterpCode><<<fam_init[0].wgs, kInitBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fam_init[0].d_jobs), fam_init[0].n);
+    if (fam_init[1].n) k_init_jobs<InterpCodeWide><<<fam_init[1].wgs, kInitBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fam_init[1].d_jobs), fam_init[1].n);
 
     // ribbon sort of a program's compacted lists by (RIBBON_ID, AGE) (src/render/mod.rs:7372-7612)
     auto ribbon_sort = [ctx](HnbProgram* p) {
@@ -1620,6 +1724,12 @@ int hnb_simulate(HnbContext* ctx) {
     };
 
     // ---- phase B: update + kill + compaction (+ spawn-event ordering) ------------------------------------
+    // (the merged updates first: every init pass is enqueued, and a merged program's own list kernels may follow in the loop below)
+    if (fam_stream[0].wgs + fam_stream[1].wgs + fam_generic[0].wgs)
+        k_update_jobs<<<fam_stream[0].wgs + fam_stream[1].wgs + fam_generic[0].wgs, kBlock, 0, ctx->stream>>>(
+            static_cast<const StreamJob*>(fam_stream[0].d_jobs), fam_stream[0].n, static_cast<const StreamJob*>(fam_stream[1].d_jobs), fam_stream[1].n,
+            static_cast<const ProgJob*>(fam_generic[0].d_jobs), fam_generic[0].n, fam_stream[0].wgs, fam_stream[0].wgs + fam_stream[1].wgs);
+    if (fam_generic[1].wgs) k_update_generic_wide_jobs<<<fam_generic[1].wgs, kBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fam_generic[1].d_jobs), fam_generic[1].n);
     for (HnbProgram* p : order) {
         const uint32_t n = (uint32_t)p->effects.size();
         const uint32_t par = p->parity;
@@ -1633,30 +1743,10 @@ int hnb_simulate(HnbContext* ctx) {
         tu.prog = tc.prog = p;
         if (timed) { tu.a = take_event(ctx); tu.b = take_event(ctx); tc.b = take_event(ctx); hipEventRecord(tu.a, ctx->stream); }
         const uint32_t write_died = (p->lists_now && !p->slot_order) ? 1u : 0u;   // k_count_rows follows: the update leaves one died bit per slot
-        if (p->update_streams) {
-            SlotArgs sa{};
-            sa.capacity = p->dev.capacity; sa.n_uregs = p->dev.n_uregs; sa.chunks_per_inst = p->dev.chunks_per_inst; sa.n_inst = n;
-            sa.alive_flag_off = p->dev.alive_flag_off;
-            sa.update_len = p->dev.update_len;
-            sa.update_code = p->dev.update_code;
-            sa.died_bits_off = p->dev.died_bits_off; sa.write_died = write_died;
-            sa.cull_lifetime = p->dev.cull_lifetime; sa.lmin_off = p->dev.lmin_off; sa.dt_operand = p->cull_dt_operand;
-            sa.age_cohort = p->dev.age_cohort;
-            sa.frame_phase = p->frames_run & 15u;
-            sa.horizon_off = p->dev.horizon_off; sa.horizon = p->horizon_eligible ? 1u : 0u;
-            if (p->skip_eligible) { sa.safe_words = p->d_safe; sa.safe_host = p->h_safe; sa.safe_parity = p->frames_run & 1u; sa.publish_tag = p->frames_run - 1u; sa.safe_stride = p->table_cap * p->dev.chunks_per_inst; }
-            sa.skip_lists = p->skip_now ? 1u : 0u;
-            sa.meta_in = p->d_meta[par]; sa.meta_out = p->d_meta[par ^ 1];
-            sa.fault = p->d_fault;
-            sa.transpose = ctx->transpose ? 1u : 0u;
-            for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
-                const DevAttr& at = p->dev.attrs[a];
-                const int pi = at.reg == HNB_REG_POSITION ? 0 : at.reg == HNB_REG_VELOCITY ? 1 : at.reg == HNB_REG_AGE ? 2 : at.reg == HNB_REG_LIFETIME ? 3 : -1;
-                if (pi < 0) continue;
-                sa.plane_off[pi] = at.plane_off;
-                if (at.upd_flags & HNB_ATTR_UPD_LOAD) sa.flags |= 1u << pi;
-                if (at.upd_flags & HNB_ATTR_UPD_STORE) sa.flags |= 16u << pi;
-            }
+        if (p->update_merged) {
+            // (k_update_stream_jobs / k_update_generic_jobs above)
+        } else if (p->update_streams) {
+            SlotArgs sa = slot_args_of(ctx, p, n, write_died);
             if (p->jit_update) {
                 void* ka[] = {&sa, &p->d_inst_base, &dfi, &dub, &cb};
                 HIP_TRY(hipModuleLaunchKernel(p->jit_update, total_chunks, 1, 1, kBlock, 1, 1, 0, ctx->stream, ka, nullptr));
@@ -1834,6 +1924,7 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
         s += "\nage cohorts: " + std::to_string(in_cohort) + " of " + std::to_string(prog->effects.size() * (size_t)prog->dev.chunks_per_inst) + " chunks";
     }
     if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->sort_front_static ? "" : " (not eligible)");
+    if (prog->merged_frames) s += "\nupdate served by a merged launch (small programs of the context share one): " + std::to_string(prog->merged_frames) + " frames";
     if (prog->horizon_eligible) s += "\ndeath horizons in use: " + std::to_string(prog->hz_frames) + " frames";
     s += "\nlists skipped: " + std::to_string(prog->skipped_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->skip_eligible ? "" : " (not eligible)");
     snprintf(buf, buf_size, "%s", s.c_str());

@@ -19,7 +19,10 @@ constexpr uint32_t kBlock = 256;      // threads per workgroup (4 waves)
 #endif
 constexpr uint32_t kChunk = HNB_CHUNK;  // alive-list rows per claimed chunk = unit of the cross-chunk scan
 constexpr uint32_t kInitBlock = 256;  // init: one particle per thread
-constexpr uint32_t kInitRounds = 4;   // ... and at most this many groups of kInitBlock consecutive spawns per workgroup and pass (k_init)
+#ifndef HNB_INIT_ROUNDS
+#define HNB_INIT_ROUNDS 4
+#endif
+constexpr uint32_t kInitRounds = HNB_INIT_ROUNDS;   // ... and at most this many groups of kInitBlock consecutive spawns per workgroup and pass (k_init)
 
 typedef AttrDesc DevAttr;
 

@@ -221,14 +221,13 @@ constexpr uint32_t kHorizonFrames = 4096u;
 // vfx_init.wgsl:141-143 uses atomicAdd(alive_count): under serial execution thread i gets
 // alive0 + i, which is what is computed here without atomics. Counters are advanced by k_compact.
 template <class CODE>
-__global__ void __launch_bounds__(kInitBlock)
-k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
-       const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks) {
+__device__ __forceinline__ void init_workgroup(const DevProgram& prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+                                               const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks,
+                                               const uint32_t blk, const uint32_t grid) {   // workgroup blk of the program's `grid` (k_init, k_init_jobs)
     // Find the instance owning this workgroup: binary search over the CPU prefix sum of init workgroups
     // (find_location_from_particle, vfx_init.wgsl:51-72, at workgroup granularity). The prefix sums sit in a
     // packed array behind the parameter blocks, so the first steps of the search hit the same cached words in
     // every workgroup (searching the 128-byte DevFrameInst rows cost ~10 dependent cache misses per workgroup).
-    const uint32_t blk = blockIdx.x;
     const uint32_t* init_start = ublocks + (size_t)prog.n_inst * prog.n_uregs;
     uint32_t lo = 0, hi = prog.n_inst;
     while (lo < hi) {
@@ -239,7 +238,7 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
     // The instance's workgroups stride over its spawns: exactly one round for CPU spawners; for effects with a
     // parent the event count is only known on the device, so the grid is capped and loops (no indirect dispatch in HIP).
     const uint32_t first_block = fi[k].init_block_start;
-    const uint32_t n_blocks = (k + 1u < prog.n_inst ? fi[k + 1u].init_block_start : gridDim.x) - first_block;
+    const uint32_t n_blocks = (k + 1u < prog.n_inst ? fi[k + 1u].init_block_start : grid) - first_block;
 
     const uint32_t alive0 = meta_in[k].alive_count;
     const uint32_t max_spawn = prog.capacity - alive0;
@@ -335,6 +334,12 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
         pass_no += 1u;
     }
     }
+}
+template <class CODE>
+__global__ void __launch_bounds__(kInitBlock)
+k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+       const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks) {
+    init_workgroup<CODE>(prog, inst_base, meta_in, fi, ublocks, blockIdx.x, gridDim.x);
 }
 // ---- streaming-kernel pinned attribute access (P = 4) -------------------------------------------
 template <int P>
@@ -990,10 +995,10 @@ __device__ __forceinline__ void store_died_bits(uint32_t* __restrict__ bits, uin
 
 // PROBE (tools/stream_probe.hip only; 0 in the product): 4 = skip stores, 8 = skip the program.
 // COHORT: compile the age-cohort paths in (programs that are eligible: SlotArgs::age_cohort); false leaves the kernel as it was.
-template <class PROG, int WAVES, int PROBE = 0, bool COHORT = false>
-__global__ void __launch_bounds__(kBlock, WAVES)
-k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
-                      const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
+template <class PROG, int PROBE, bool COHORT>
+__device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
+                                                    const uint32_t* __restrict__ ublocks, const CompactBufs& cb,
+                                                    const uint32_t wg, const uint32_t wg_total) {   // workgroup wg of the program's wg_total (k_update_slots_stream, k_update_stream_jobs)
     __shared__ uint32_t s_died[kBlock / 64];
     __shared__ float s_lmin[kBlock / 64];
     __shared__ uint32_t s_alive[kBlock / 64];
@@ -1001,12 +1006,12 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     __shared__ uint32_t s_amin[kBlock / 64], s_amax[kBlock / 64];
     __shared__ u4v s_xp[2][kBlock / 64][kStepRows * 3u / 4u];   // position / velocity staging of each wave's step (xpose_load3): 24 KiB per workgroup
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
+    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     const uint32_t k = chunk / args.chunks_per_inst, j = chunk - k * args.chunks_per_inst;
     if (args.safe_words && chunk == 0u) {  // publish the previous frame's bound: its kernel has completed, every chunk's word is final
         const uint32_t* prev = args.safe_words + (size_t)(args.safe_parity ^ 1u) * args.safe_stride;
         uint32_t m = 0x7f800000u;
-        for (uint32_t i = tid; i < gridDim.x; i += kBlock) { const uint32_t v = prev[i]; m = v < m ? v : m; }
+        for (uint32_t i = tid; i < wg_total; i += kBlock) { const uint32_t v = prev[i]; m = v < m ? v : m; }
 #pragma unroll
         for (uint32_t off = 32; off > 0; off >>= 1) { const uint32_t y = __shfl_xor(m, off, 64); m = y < m ? y : m; }
         if (lane == 0) s_alive[wave] = m;
@@ -1108,10 +1113,9 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     }
     // ---- the per-particle path, one wave step (256 slots, 4 per lane). COH: with the age-cohort bookkeeping (a chunk that is known to hold
     // mixed ages - state 4 - runs without it: see `mixed` above)
-    auto step_body = [&](auto coh_tag, const uint32_t step) {
+    auto step_body = [&](auto coh_tag, const uint32_t step, const uint32_t f4) {
         constexpr bool COH = decltype(coh_tag)::value;
         const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;  // first of this lane's 4 slots
-        const uint32_t f4 = chunk_full ? 0x01010101u : (s0 < args.capacity ? flags4[s0 >> 2] : 0u);  // the plane is padded: slots past the capacity read 0
         bool was[4], fresh[4];  // fresh: spawned this frame into a chunk that kept its ages in the value word (alive byte 3, state 2 only)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -1156,7 +1160,10 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
                 }
             }
         }
-        if (cull && Lm > 0.0f) {  // can this step lose a particle? `age + dt` is the AGE_TICK's own arithmetic
+        // can this step lose a particle? `age + dt` is the AGE_TICK's own arithmetic. (A chunk known to hold mixed ages does not ask: some
+        // particle of a step is always near its end there, and the question makes the lifetime loads wait for the ages - a third dependent
+        // memory round trip per step.)
+        if (cull && Lm > 0.0f && (COH || !mixed)) {
             bool may_die = false;
 #pragma unroll
             for (int p = 0; p < 4; ++p) may_die = may_die || (was[p] && !(X.age[p] + dt_tick < Lm));
@@ -1240,12 +1247,20 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
         died_total += died_here;
     };
     if (!flat) {
+        // the alive bytes of the wave's four steps, requested together (a step's own load would wait behind the previous step's stores to the
+        // same plane: two dependent round trips per step)
+        uint32_t f4s[kWaveRows / kStepRows];
+#pragma unroll
+        for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
+            const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;
+            f4s[step] = chunk_full ? 0x01010101u : (s0 < args.capacity ? flags4[s0 >> 2] : 0u);  // the plane is padded: slots past the capacity read 0
+        }
         if (mixed) {
 #pragma unroll
-            for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step);
+            for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4s[step]);
         } else {
 #pragma unroll
-            for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<COHORT>{}, step);
+            for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<COHORT>{}, step, f4s[step]);
         }
     }
     if (cull) {
@@ -1308,14 +1323,24 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
     }
 }
 
+template <class PROG, int WAVES, int PROBE = 0, bool COHORT = false>
+__global__ void __launch_bounds__(kBlock, WAVES)
+k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
+                      const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
+    update_stream_chunk<PROG, PROBE, COHORT>(args, inst_base, fi, ublocks, cb, blockIdx.x, gridDim.x);
+}
+
 // Any update program on the V register file: one slot per lane, same protocol.
 template <class CODE>
-__global__ void __launch_bounds__(kBlock)
-k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
-                       const uint32_t* __restrict__ ublocks, const CompactBufs cb, const uint32_t write_died) {
+__device__ __forceinline__ void update_generic_chunk(const DevProgram& prog, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
+                                                     const uint32_t* __restrict__ ublocks, const CompactBufs& cb, const uint32_t write_died,
+                                                     const uint32_t wg, const uint32_t wg_total,
+                                                     const uint32_t sub_begin = 0u, const uint32_t sub_end = kChunk / kBlock) {
+    // (sub_begin, sub_end: the 256-slot groups of the chunk this workgroup takes - all 16 in the program's own launch, one in k_update_jobs,
+    // where the latency of a single small chunk is the frame)
     __shared__ uint32_t s_died[kBlock / 64], s_alive[kBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
+    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     const uint32_t k = chunk / prog.chunks_per_inst, j = chunk - k * prog.chunks_per_inst;
     if (fi[k].skip) return;
     char* base = global_ptr<char>(inst_base[k]);
@@ -1328,7 +1353,7 @@ k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_
     // completely alive chunks skip the alive bytes (same flag and rules as in k_update_slots_stream)
     uint32_t* cfull = reinterpret_cast<uint32_t*>(base + prog.lmin_off) + prog.chunks_per_inst;
     const bool chunk_full = cfull[j] == 1u;
-    for (uint32_t sub = 0; sub < kChunk / kBlock; ++sub) {
+    for (uint32_t sub = sub_begin; sub < sub_end; ++sub) {
         const uint32_t slot = j * kChunk + sub * kBlock + tid;
         const bool valid = chunk_full || (slot < prog.capacity && flags[slot] == 1u);
         alive_total += (uint32_t)__popcll(__ballot(valid));
@@ -1369,8 +1394,15 @@ k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_
         for (uint32_t w = 0; w < kBlock / 64; ++w) { d += s_died[w]; a += s_alive[w]; }
         if (d) atomicAdd(&cb.deaths[(size_t)cb.parity * cb.table_cap + k], d);
         if (chunk_full) { if (d) cfull[j] = 0u; }
-        else if (d == 0u && a == kChunk) cfull[j] = 1u;
+        else if (d == 0u && a == kChunk) cfull[j] = 1u;   // (never reached by a workgroup that saw only a part of the chunk: the flag is an optimisation)
     }
+}
+
+template <class CODE>
+__global__ void __launch_bounds__(kBlock)
+k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
+                       const uint32_t* __restrict__ ublocks, const CompactBufs cb, const uint32_t write_died) {
+    update_generic_chunk<CODE>(prog, inst_base, fi, ublocks, cb, write_died, blockIdx.x, gridDim.x);
 }
 
 #ifndef HNB_JIT_TU
@@ -1484,6 +1516,66 @@ __global__ void __launch_bounds__(kBlock)
 k_compact_multi(const ListsJob* __restrict__ jobs, uint32_t n_jobs) {
     const ListsJob& jb = job_of_workgroup(jobs, n_jobs);
     compact_chunk(jb.args, jb.inst_base, jb.meta_in, jb.meta_out, jb.fi, jb.cb, blockIdx.x - jb.first_wg, jb.n_wg);
+}
+
+// ---- a scene of many small effects: init and update of SEVERAL programs in one launch each ------------------------------------------------
+// A game scene is dozens of different effects of a few thousand particles; each program's own (specialised) k_init and update kernel is a
+// launch of a few microseconds of work, and the frame is bound by the number of launches the host can issue (26 example effects: 0.30 ms per
+// frame, the device idle half of the time, profiles/r02u_scene.md). For programs that are small this frame hnb_simulate therefore fills job
+// tables (they travel with the frame's parameter upload, like ListsJob) and serves ALL of them with one k_init_jobs launch and one
+// k_update_jobs launch - the INTERPRETER instantiations, the only code that fits every program: 3-9x the instructions per particle of
+// the specialised kernels, and irrelevant at these sizes. Same code paths as HNB_JIT=0, same results bit for bit (tests/test_scene_merge.py).
+struct ProgJob {             // k_init_jobs (first_wg / n_wg count init workgroups), k_update_jobs / k_update_generic_wide_jobs (... groups of 256 slots)
+    DevProgram prog;
+    const uint64_t* inst_base; const DevMeta* meta_in; const DevFrameInst* fi; const uint32_t* ublocks;
+    CompactBufs cb;
+    uint32_t write_died;
+    uint32_t first_wg, n_wg;
+    uint32_t pad;
+};
+struct StreamJob {           // k_update_jobs (first_wg / n_wg count chunks)
+    SlotArgs args;
+    const uint64_t* inst_base; const DevFrameInst* fi; const uint32_t* ublocks;
+    CompactBufs cb;
+    uint32_t first_wg, n_wg;
+};
+template <class JOB>
+__device__ __forceinline__ const JOB& job_of_workgroup_t(const JOB* __restrict__ jobs, uint32_t n_jobs) {
+    uint32_t lo = 0, hi = n_jobs;   // last job with first_wg <= blockIdx.x (uniform: scalar loads)
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (jobs[mid].first_wg <= blockIdx.x) lo = mid; else hi = mid; }
+    return jobs[lo];
+}
+template <class CODE>
+__global__ void __launch_bounds__(kInitBlock)
+k_init_jobs(const ProgJob* __restrict__ jobs, uint32_t n_jobs) {
+    const ProgJob& jb = job_of_workgroup_t(jobs, n_jobs);
+    init_workgroup<CODE>(jb.prog, jb.inst_base, jb.meta_in, jb.fi, jb.ublocks, blockIdx.x - jb.first_wg, jb.n_wg);
+}
+// One launch for every small program's update: workgroups [0, b0) serve the streaming jobs without age cohorts, [b0, b1) those with, the rest
+// the programs on the V register file - there one workgroup per 256 slots (the latency of one 4096-slot chunk walked by a single workgroup
+// WAS the frame: 0.13 ms for the 26-effect scene, profiles/r03u_scene_kernel_stats.csv). first_wg counts over the whole grid.
+constexpr uint32_t kGenericSubs = kChunk / kBlock;
+__global__ void __launch_bounds__(kBlock)
+k_update_jobs(const StreamJob* __restrict__ sj0, uint32_t n0, const StreamJob* __restrict__ sj1, uint32_t n1, const ProgJob* __restrict__ pj, uint32_t np,
+              uint32_t b0, uint32_t b1) {
+    if (blockIdx.x < b0) {
+        const StreamJob& jb = job_of_workgroup_t(sj0, n0);
+        update_stream_chunk<ProgInterp, 0, false>(jb.args, jb.inst_base, jb.fi, jb.ublocks, jb.cb, blockIdx.x - jb.first_wg, jb.n_wg);
+    } else if (blockIdx.x < b1) {
+        const StreamJob& jb = job_of_workgroup_t(sj1, n1);
+        update_stream_chunk<ProgInterp, 0, true>(jb.args, jb.inst_base, jb.fi, jb.ublocks, jb.cb, blockIdx.x - jb.first_wg, jb.n_wg);
+    } else {
+        const ProgJob& jb = job_of_workgroup_t(pj, np);
+        const uint32_t w = blockIdx.x - jb.first_wg, sub = w % kGenericSubs;
+        update_generic_chunk<InterpCode>(jb.prog, jb.inst_base, jb.fi, jb.ublocks, jb.cb, jb.write_died, w / kGenericSubs, jb.n_wg / kGenericSubs, sub, sub + 1u);
+    }
+}
+// (programs on the wide register file: their own launch - the kernel needs scratch)
+__global__ void __launch_bounds__(kBlock)
+k_update_generic_wide_jobs(const ProgJob* __restrict__ jobs, uint32_t n_jobs) {
+    const ProgJob& jb = job_of_workgroup_t(jobs, n_jobs);
+    const uint32_t w = blockIdx.x - jb.first_wg, sub = w % kGenericSubs;
+    update_generic_chunk<InterpCodeWide>(jb.prog, jb.inst_base, jb.fi, jb.ublocks, jb.cb, jb.write_died, w / kGenericSubs, jb.n_wg / kGenericSubs, sub, sub + 1u);
 }
 
 // Per 4096-row chunk of the alive list (as the update saw it): spawn events per channel, for the cross-chunk
