@@ -768,7 +768,9 @@ def main():
     ap.add_argument("--capacity", type=int, default=None, help="particles per effect instance (default: the configuration's)")
     ap.add_argument("--instances", type=int, default=None, help="c4: instances per GPU (weak) / in total (strong); default 512")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scene", action="store_true", help="N = 1: append the small-effects scene (26 example effects in one context) as \"small_effects_scene\"")
+    ap.add_argument("--scene", dest="scene", action="store_true", default=True,
+                    help="N = 1: append the small-effects scene (26 example effects in one context, tools/scene_bench.py) as \"small_effects_scene\" (default)")
+    ap.add_argument("--no-scene", dest="scene", action="store_false")
     ap.add_argument("--no-extra-configs", action="store_true", help="N = 1, c2: do not append the other configurations under \"configs\"")
     ap.add_argument("--pmc", choices=["auto", "off"], default="auto", help="auto: measure HBM traffic in this run (two rocprofv3 counter passes of this script)")
     ap.add_argument("--pmc-timeout", type=int, default=420)
@@ -848,10 +850,10 @@ def main():
             out["configs"] = {k: (v if "error" in v else {kk: v[kk] for kk in ("value", "ms_per_step", "windows", "stages", "roofline", "init", "kernels") if kk in v}
                                   | {"workload": v["config"]["workload"], "updates_per_frame": v["config"]["updates_per_frame"], "spawns_per_frame": v["config"]["spawns_per_frame"]})
                               for k, v in extra.items()}
-    if not D.on and args.scene:
-        # the launch-bound end of the path: 26 different small effects in one context (tools/scene_bench.py, profiles/r02u_scene.md). Opt-in: the
-        # small effects share kernel instantiations with the headline workload, and the default command's rocprofv3 statistics are
-        # meant to show the headline's kernel on its own
+    if not D.on and args.scene and args.config == "c2" and not args.no_extra_configs and not args.pmc_child:
+        # the launch-bound end of the path: 26 different small effects in one context (tools/scene_bench.py, profiles/r03v_scene.log). Their
+        # passes run in the job-table kernels (k_init_jobs, k_update_jobs, k_count_rows_multi, k_compact_multi): the statistics of the
+        # headline's kernels in a rocprofv3 run of this command stay the headline's own
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import scene_bench

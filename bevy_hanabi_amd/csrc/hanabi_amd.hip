@@ -726,6 +726,8 @@ bool age_cohort_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbA
     if (!cull_eligible(b, h, attrs, streams, nullptr) || (h.flags & HNB_PROG_HAS_RIBBONS) || (getenv("HNB_AGE_COHORT") && getenv("HNB_AGE_COHORT")[0] == '0')) return false;
     // only the lean (bandwidth-bound) stacks: an update that is bound by VALU issue (ConformToSphere, Radial / TangentAccel: divisions, square
     // roots) gains nothing from 8 bytes less per particle and pays for the bookkeeping (force_field: 0.0955 -> 0.099 ms with it, measured)
+    // (HNB_AGE_COHORT=2: every eligible stack, for A/B runs)
+    if (getenv("HNB_AGE_COHORT") && getenv("HNB_AGE_COHORT")[0] == '2') return true;
     const Ins* uc = reinterpret_cast<const Ins*>(b + h.update_off);
     for (uint32_t i = 0; i < h.update_len; ++i)
         if (!vm_op_is_lean(uc[i].x & 0xffu)) return false;
