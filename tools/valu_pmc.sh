@@ -28,7 +28,7 @@ for cfg in ("c2", "c2_mixed", "c2_dieoff", "c3", "c4"):
         print(f"{cfg} {kind}: " + ", ".join(f"{n}={v:.4g}" for n, v in sorted(pick.items())))
         if g:
             simds = 1024.0
-            print(f"   VALU issue cycles per SIMD / kernel cycles (gfx94x VALUBusy formula: ACTIVE_INST_VALU*4/SIMDs/GUI_ACTIVE) = {pick.get('SQ_ACTIVE_INST_VALU', 0) * 4 / simds / g:.3f};"
+            print(f"   VALU issue cycles per SIMD / kernel cycles (gfx94x VALUBusy formula: ACTIVE_INST_VALU*4/SIMDs/(GUI_ACTIVE/8 XCDs)) = {pick.get('SQ_ACTIVE_INST_VALU', 0) * 4 / simds / (g / 8.0):.3f};"
                   f"  VALU instructions per wave = {pick.get('SQ_INSTS_VALU', 0) / max(pick.get('SQ_WAVES', 1), 1):.1f};"
                   f"  wave cycles: active {pick.get('SQ_ACTIVE_INST_ANY', 0) / max(pick.get('SQ_WAVE_CYCLES', 1), 1):.3f}, waiting on memory/barrier {pick.get('SQ_WAIT_ANY', 0) / max(pick.get('SQ_WAVE_CYCLES', 1), 1):.3f}, issue-stalled {pick.get('SQ_WAIT_INST_ANY', 0) / max(pick.get('SQ_WAVE_CYCLES', 1), 1):.3f}")
 PY
