@@ -52,6 +52,8 @@ struct TimingPair { hipEvent_t a, b; const HnbProgram* prog; };
 constexpr uint32_t kFrameRing = 4;
 constexpr uint32_t kSceneMaxChunks = 16;       // a program is "small" this frame: <= 65,536 slots over all of its instances ...
 constexpr uint32_t kSceneMaxInitBlocks = 64;   // ... and <= 16,384 spawns (hnb_simulate: merged launches)
+constexpr uint32_t kSceneMaxCodeLen = 64;      // ... and a pass of at most this many instructions: the merged launches INTERPRET, and one long program (the
+                                               // lightning bolt's 510-instruction init: 43 us interpreted, 5 us specialised) would set the latency of all
 
 }  // namespace
 
@@ -1608,8 +1610,8 @@ int hnb_simulate(HnbContext* ctx) {
         // k_update_jobs serves streaming (no cohorts), streaming (cohorts), V register file (narrow) in this order: first_wg runs over its whole grid
         auto member_of = [&](const HnbProgram* p, int kind, int v) {
             if (!small(p)) return false;
-            if (kind == 0) return p->init_blocks != 0u && p->init_blocks <= kSceneMaxInitBlocks && (p->wide_file ? 1 : 0) == v;
-            if (kind == 1) return !p->update_streams && (p->wide_file ? 1 : 0) == v;
+            if (kind == 0) return p->init_blocks != 0u && p->init_blocks <= kSceneMaxInitBlocks && p->dev.init_len <= kSceneMaxCodeLen && (p->wide_file ? 1 : 0) == v;
+            if (kind == 1) return !p->update_streams && p->dev.update_len <= kSceneMaxCodeLen && (p->wide_file ? 1 : 0) == v;
             return p->update_streams && (p->dev.age_cohort ? 1 : 0) == v;
         };
         auto count_of = [&](int kind, int v) { uint32_t m = 0; for (const HnbProgram* p : order) m += member_of(p, kind, v) ? 1u : 0u; return m; };
