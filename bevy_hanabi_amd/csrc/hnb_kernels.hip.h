@@ -608,6 +608,17 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     // (an instance without a casualty gets here only to be rotated: k_count_rows recorded nothing for it, every row survives)
     const uint32_t* cnt = cb.counts + (size_t)c.k * args.chunks_per_inst;
     const uint32_t rows = (c.n - c.start) < kChunk ? (c.n - c.start) : kChunk;
+    // Everything this workgroup reads is requested BEFORE the prefix over the earlier chunks' counts is waited for: its 4096 rows (16 per
+    // lane) and the chunk's row-mask words. (The prefix ends in a barrier; issued behind it, the rows were a further dependent round trip
+    // in a kernel that is a chain of them: metadata -> counts -> mask -> rows -> stores.)
+    constexpr uint32_t kSteps = kWaveRows / 64u;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(c.base + ((c.m.write_index & 1u) ? args.alive_off[1] : args.alive_off[0])) + c.start;
+    uint32_t v[kSteps];
+#pragma unroll
+    for (uint32_t q = 0; q < kSteps; ++q) { const uint32_t i = wave * kWaveRows + q * 64u + lane; v[q] = i < rows ? src[i] : 0u; }
+    unsigned long long word;   // (bit r of word i: row 64 i + r survives; nothing died in the instance: every row that exists survives)
+    if (total_dead != 0u) word = reinterpret_cast<const unsigned long long*>(c.base + args.row_mask_off)[(size_t)c.j * (kChunk / 64u) + lane];
+    else word = rows >= (lane + 1u) * 64u ? ~0ull : (rows > lane * 64u ? ((1ull << (rows - lane * 64u)) - 1ull) : 0ull);
     uint32_t excl = c.start;
     if (total_dead != 0u) {
         uint32_t part = 0;
@@ -620,11 +631,8 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
 #pragma unroll
         for (uint32_t w = 0; w < kBlock / 64; ++w) excl += s_red[w];
     }
-    // The chunk's 64 row-mask words (bit r of word i: row 64 i + r survives), one per lane, and the survivors in front of each word:
-    // every wave ranks its own rows from them, no LDS and no barrier. (Nothing died in the instance: every row that exists survives.)
-    unsigned long long word;
-    if (total_dead != 0u) word = reinterpret_cast<const unsigned long long*>(c.base + args.row_mask_off)[(size_t)c.j * (kChunk / 64u) + lane];
-    else word = rows >= (lane + 1u) * 64u ? ~0ull : (rows > lane * 64u ? ((1ull << (rows - lane * 64u)) - 1ull) : 0ull);
+    // The chunk's 64 row-mask words, one per lane, and the survivors in front of each word: every wave ranks its own rows from them, no LDS
+    // and no barrier.
     const uint32_t wcount = (uint32_t)__popcll(word);
     uint32_t wincl = wcount;
 #pragma unroll
@@ -638,7 +646,6 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
         if (t1 != t0) { atomicMin(&hz.D(args.hz_parity ^ 1u)[t1], d); atomicMin(&hz.BF(args.hz_parity ^ 1u)[t1], bf); }
     }
     const uint32_t wexcl = wincl - wcount;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(c.base + ((c.m.write_index & 1u) ? args.alive_off[1] : args.alive_off[0])) + c.start;
     uint32_t* out = reinterpret_cast<uint32_t*>(c.base + ((c.m.write_index & 1u) ? args.alive_off[0] : args.alive_off[1]));   // (selects, not a dynamic index: the job-table variant kept the offsets in LDS otherwise)
     // survivor g of the instance goes to row g - or, rotated: the last n_spawn survivors are this frame's spawns (k_init appended them, none of
     // them dies in its first frame: a premise of the proof) and go first, everything older follows
@@ -647,28 +654,20 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     uint32_t* dead = reinterpret_cast<uint32_t*>(c.base + args.dead_off);
     const uint32_t dead_before = c.start - excl;
     // survivors keep their (stable, serial) order (vfx_update.wgsl:161-165). A wave owns 1024 consecutive rows, 64 per step, lane l row
-    // 64 step + l: loads and stores of a step are contiguous. (Rows are requested half a wave's share ahead of their use: one dependent
-    // access per row otherwise.)
-    constexpr uint32_t kSteps = kWaveRows / 64u, kHalf = kSteps / 2u;
+    // 64 step + l: loads and stores of a step are contiguous.
     const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll 1
-    for (uint32_t h = 0; h < 2; ++h) {
-        uint32_t v[kHalf];
 #pragma unroll
-        for (uint32_t q = 0; q < kHalf; ++q) { const uint32_t i = wave * kWaveRows + (h * kHalf + q) * 64u + lane; v[q] = i < rows ? src[i] : 0u; }
-#pragma unroll
-        for (uint32_t q = 0; q < kHalf; ++q) {
-            const uint32_t wi = wave * kSteps + h * kHalf + q;            // (wave-uniform)
-            const uint32_t i = wi * 64u + lane;                          // row within the chunk
-            const unsigned long long m = __shfl(word, wi, 64);
-            const uint32_t r = __shfl(wexcl, wi, 64) + (uint32_t)__popcll(m & below);   // survivors of the chunk in front of this row
-            if ((m >> lane) & 1ull) {
-                const uint32_t g = excl + r;
-                out[g >= head_n ? g - head_n : g + tail] = v[q];
-            } else if (i < rows) {
-                // the d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151); its alive byte is already 0
-                dead[c.n - 1u - (dead_before + (i - r))] = v[q];
-            }
+    for (uint32_t q = 0; q < kSteps; ++q) {
+        const uint32_t wi = wave * kSteps + q;                       // (wave-uniform)
+        const uint32_t i = wi * 64u + lane;                          // row within the chunk
+        const unsigned long long m = __shfl(word, wi, 64);
+        const uint32_t r = __shfl(wexcl, wi, 64) + (uint32_t)__popcll(m & below);   // survivors of the chunk in front of this row
+        if ((m >> lane) & 1ull) {
+            const uint32_t g = excl + r;
+            out[g >= head_n ? g - head_n : g + tail] = v[q];
+        } else if (i < rows) {
+            // the d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151); its alive byte is already 0
+            dead[c.n - 1u - (dead_before + (i - r))] = v[q];
         }
     }
     if (last && tid == 0) {
