@@ -125,6 +125,7 @@ struct HnbContext {
     uint32_t list_order = HNB_LIST_ORDER_SPAWN;  // applied to programs created afterwards
     bool skip_lists = true;     // skip the list kernels of frames the device's no-death bound covers (HNB_SKIP_LISTS=0 turns it off)
     bool alternate = true;      // walk the chunks in alternating directions from frame to frame (HNB_ALTERNATE=0 turns it off)
+    bool suffix_proof = true;   // ribbon programs: "the casualties are the last rows of the sorted list" replaces k_count_rows where the host can prove it (HNB_SUFFIX=0 turns it off)
     bool scene_merge = true;    // small programs share their init / update launches (ProgJob / StreamJob; HNB_SCENE_MERGE=0 turns it off)
     bool transpose = true;      // vec3 planes of the per-particle update path through the wave's LDS transpose (HNB_TRANSPOSE=0 turns it off)
     uint32_t timing = 0;        // 0 = off, n = time every n-th simulated frame
@@ -230,6 +231,13 @@ struct HnbProgram {
     float sort_min_tick = __builtin_inff();
     bool frame_sort_front = false;          // decision for the frame being enqueued
     bool frame_rotate = false;              // ... together with everything else the rotation needs (the head provably sorted, no host write, spawns)
+    // "the casualties are the LAST rows of the sorted list": one ribbon, the list in age order, every particle with the same lifetime (one uniform
+    // value that never changed) - then `age + tick < lifetime` is monotone along the rows and k_count_rows has nothing to find out
+    // (CompactArgs::suffix_dead; k_compact verifies it against the died bits and raises `fault` otherwise)
+    bool sort_life_known = false, sort_life_changed = false;
+    uint32_t sort_life_value = 0;
+    bool frame_suffix = false;
+    uint32_t suffix_frames = 0;             // statistics
     uint32_t sort_rotated_frames = 0;       // statistics: frames whose ribbon sort was a rotation
 };
 
@@ -780,6 +788,7 @@ int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
     if (const char* e = getenv("HNB_ALTERNATE")) ctx->alternate = e[0] != '0';
     if (const char* e = getenv("HNB_TRANSPOSE")) ctx->transpose = e[0] != '0';
     if (const char* e = getenv("HNB_SCENE_MERGE")) ctx->scene_merge = e[0] != '0';
+    if (const char* e = getenv("HNB_SUFFIX")) ctx->suffix_proof = e[0] != '0';
     if (const char* e = getenv("HNB_SKIP_LISTS")) ctx->skip_lists = e[0] != '0';
     *out_ctx = ctx;
     return HNB_OK;
@@ -1353,6 +1362,7 @@ static CompactArgs compact_args_of(const HnbProgram* p) {
     ca.hz = p->horizon_eligible ? 1u : 0u; ca.hz_use = p->hz_use_now ? 1u : 0u; ca.hz_parity = p->hz_parity; ca.frame_no = p->frames_run;
     ca.fault = p->d_fault;
     ca.slot_order = p->slot_order ? 1u : 0u;
+    ca.suffix_dead = p->frame_suffix ? 1u : 0u;
     ca.rotate_front = p->frame_rotate ? 1u : 0u;   // k_compact writes the survivors [spawns | older ones]: see CompactArgs (ribbon programs never have slot-ordered lists)
     return ca;
 }
@@ -1513,6 +1523,8 @@ int hnb_simulate(HnbContext* ctx) {
                     else if (rid_bits != p->sort_rid_value) p->sort_front_broken = true;
                     if (age_bits != 0u) front = false;   // spawns that do not start at +0 this frame
                     const uint32_t life_bits = ub[p->sort_life_operand & 0xffu];
+                    if (!p->sort_life_known) { p->sort_life_known = true; p->sort_life_value = life_bits; }
+                    else if (life_bits != p->sort_life_value) p->sort_life_changed = true;   // older particles keep the lifetime they were born with
                     float life, tk;
                     memcpy(&life, &life_bits, 4);
                     memcpy(&tk, &tick_bits, 4);
@@ -1530,6 +1542,7 @@ int hnb_simulate(HnbContext* ctx) {
                 }
                 p->frame_sort_front = front;
                 p->frame_rotate = front && p->sort_provable && p->frame_sort_values_ok && !p->sort_dirty && ctx->skip_lists && p->frame_max_spawn > 0u;
+                p->frame_suffix = front && p->sort_provable && p->frame_sort_values_ok && !p->sort_dirty && ctx->skip_lists && !p->sort_life_changed && ctx->suffix_proof;
                 if (have) p->sort_min_tick = frame_min_tick < p->sort_min_tick ? frame_min_tick : p->sort_min_tick;
             }
             p->skip_now = false;
@@ -1769,6 +1782,7 @@ int hnb_simulate(HnbContext* ctx) {
         const CompactArgs ca = compact_args_of(p);
         const bool lists = p->lists_now;
         if (!lists) p->skipped_frames += 1;
+        else if (ca.suffix_dead) p->suffix_frames += 1;
         if (lists && p->dev.n_event_channels) {  // order this frame's spawn events (by list row) into the children's buffers
             k_emit_count<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb);
             // (gridDim.y splits every chunk's events over several workgroups: sized for the largest event buffer that listens, 16,384 events per split)
@@ -1780,7 +1794,7 @@ int hnb_simulate(HnbContext* ctx) {
         }
         // lists: only the instances that lost particles have anything to do
         if (!p->lists_merged) {  // (merged: the lists, and the ribbon sort behind them, follow after the last program's update)
-            if (lists && !p->slot_order) k_count_rows<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
+            if (lists && !p->slot_order && !ca.suffix_dead) k_count_rows<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
             if (lists) k_compact<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
             if (lists && p->slot_order) {  // rebuild the lists in increasing slot order (instances without a casualty or spawn return at once)
                 k_order_count<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
@@ -1927,6 +1941,7 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
         }
         s += "\nage cohorts: " + std::to_string(in_cohort) + " of " + std::to_string(prog->effects.size() * (size_t)prog->dev.chunks_per_inst) + " chunks";
     }
+    if (prog->has_ribbons && prog->suffix_frames) s += "\ncasualties proven to be the list's last rows (no k_count_rows): " + std::to_string(prog->suffix_frames) + " frames";
     if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->sort_front_static ? "" : " (not eligible)");
     if (prog->merged_frames) s += "\nupdate served by a merged launch (small programs of the context share one): " + std::to_string(prog->merged_frames) + " frames";
     if (prog->horizon_eligible) s += "\ndeath horizons in use: " + std::to_string(prog->hz_frames) + " frames";

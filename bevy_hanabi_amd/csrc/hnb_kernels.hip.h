@@ -617,10 +617,20 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
 #pragma unroll
     for (uint32_t q = 0; q < kSteps; ++q) { const uint32_t i = wave * kWaveRows + q * 64u + lane; v[q] = i < rows ? src[i] : 0u; }
     unsigned long long word;   // (bit r of word i: row 64 i + r survives; nothing died in the instance: every row that exists survives)
-    if (total_dead != 0u) word = reinterpret_cast<const unsigned long long*>(c.base + args.row_mask_off)[(size_t)c.j * (kChunk / 64u) + lane];
+    const bool suffix = args.suffix_dead != 0u && total_dead != 0u;
+    const uint32_t alive0 = c.m.alive_count;                                  // rows the frame started with; this frame's spawns follow
+    const uint32_t first_dead = alive0 >= total_dead ? alive0 - total_dead : 0u;   // suffix: rows [first_dead, alive0) are the casualties
+    if (suffix) {
+        auto below_mask = [](long long x) { return x <= 0 ? 0ull : (x >= 64 ? ~0ull : ((1ull << x) - 1ull)); };
+        const long long b0 = (long long)c.start + 64ll * lane;               // first row of this lane's word
+        word = below_mask((long long)c.n - b0) & (below_mask((long long)first_dead - b0) | ~below_mask((long long)alive0 - b0));
+    } else if (total_dead != 0u) word = reinterpret_cast<const unsigned long long*>(c.base + args.row_mask_off)[(size_t)c.j * (kChunk / 64u) + lane];
     else word = rows >= (lane + 1u) * 64u ? ~0ull : (rows > lane * 64u ? ((1ull << (rows - lane * 64u)) - 1ull) : 0ull);
     uint32_t excl = c.start;
-    if (total_dead != 0u) {
+    if (suffix) {   // survivors in front of row c.start, in closed form
+        excl = c.start <= first_dead ? c.start : (c.start < alive0 ? first_dead : c.start - total_dead);
+        if (total_dead > alive0 && tid == 0u && args.fault) *args.fault = 1u;
+    } else if (total_dead != 0u) {
         uint32_t part = 0;
         for (uint32_t i = tid; i < c.j; i += kBlock) part += cnt[i];
 #pragma unroll
@@ -668,6 +678,10 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
         } else if (i < rows) {
             // the d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151); its alive byte is already 0
             dead[c.n - 1u - (dead_before + (i - r))] = v[q];
+            if (suffix) {   // the host's proof, checked: this row's particle must be one of the frame's casualties
+                const uint32_t bits = reinterpret_cast<const uint32_t*>(c.base + args.died_bits_off)[v[q] >> 5];
+                if (((bits >> (v[q] & 31u)) & 1u) == 0u && args.fault) *args.fault = 1u;
+            }
         }
     }
     if (last && tid == 0) {
@@ -694,6 +708,10 @@ struct CompactArgs {
     soff_t horizon_off;        // death horizons (DevProgram): hz = maintained (eligible program), hz_use = this frame's ticks are finite: may skip
     uint32_t hz, hz_use, hz_parity, frame_no;
     uint32_t* fault;           // HnbEffectMetadata::fault
+    uint32_t suffix_dead;      // ribbon programs, host-proven (HnbProgram::frame_suffix): the list is in age order and every particle has the same
+                               // lifetime, so the frame's casualties are rows [alive_count - deaths, alive_count) - the oldest of the rows the frame
+                               // started with; this frame's spawns behind them survive. k_count_rows does not run; k_compact checks the died bit of
+                               // every row it treats as a casualty (they are `deaths` distinct slots: all set <=> the sets are equal) or raises `fault`
     uint32_t slot_order;       // HNB_LIST_ORDER_SLOT: k_order_write rebuilds the lists from the alive bytes
     uint32_t rotate_front;     // ribbon programs, host-proven (HnbProgram::sort_front_*): this frame's spawns sort in front of every older
                                // particle, so the survivors are written [spawns | older ones] and the list needs no sort afterwards
@@ -1444,6 +1462,7 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
     const HorizonView hz = horizon_view(c.base, args.horizon_off, args.chunks_per_inst);
     if (args.hz && tid == 0u) { hz.D(args.hz_parity ^ 1u)[c.j] = kHorizonNever; hz.BF(args.hz_parity ^ 1u)[c.j] = 0xffffffffu; }   // k_compact merges into these
     if (!has_rows) return;
+    if (args.suffix_dead) return;   // (the job-table launch: this program's casualties are known to be its list's last rows, CompactArgs)
     if (cb.deaths[(size_t)cb.parity * cb.table_cap + c.k] == 0u) return;  // nothing died in this instance: the list stands
     if (args.hz_use) {   // can a row of this chunk have died in this frame? (see "death horizons")
         const double clock = *hz.clock;

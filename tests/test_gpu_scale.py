@@ -621,12 +621,19 @@ def _rotations(prog):
     return int(line.split(":")[1].split("of")[0]), "not eligible" in line
 
 
-def _ribbon_asset(cap, age=0.0, lifetime=1.5, rid=None):
-    """ribbon.rs with the initial age / lifetime / ribbon id as given (`rid`: None = literal 0, or a callable on the writer)."""
+def _suffix_frames(prog):
+    line = [l for l in prog.kernel_info().split("\n") if l.startswith("casualties proven to be the list's last rows")]
+    return int(line[0].split(":")[1].split()[0]) if line else 0
+
+
+def _ribbon_asset(cap, age=0.0, lifetime=1.5, rid=None, lifetime_prop=False):
+    """ribbon.rs with the initial age / lifetime / ribbon id as given (`rid`: None = literal 0, or a callable on the writer;
+    lifetime_prop: the lifetime comes from the property "life")."""
     w = bh.ExprWriter()
+    life = w.prop(w.add_property("life", bh.Value.f32(lifetime))) if lifetime_prop else w.lit(lifetime)
     mods = [bh.SetAttributeModifier(A.POSITION, w.lit((0.0, 0.0, 0.0)).expr()),
             bh.SetAttributeModifier(A.AGE, w.lit(age).expr()),
-            bh.SetAttributeModifier(A.LIFETIME, w.lit(lifetime).expr()),
+            bh.SetAttributeModifier(A.LIFETIME, life.expr()),
             bh.SetAttributeModifier(A.SIZE, w.lit(0.5).expr()),
             bh.SetAttributeModifier(A.RIBBON_ID, (rid(w) if rid else w.lit(bh.Value.u32(0))).expr())]
     asset = (bh.EffectAsset(cap, bh.SpawnerSettings.rate(cap / lifetime), w.finish()).with_motion_integration(bh.MotionIntegration.None_))
@@ -666,6 +673,9 @@ def test_ribbon_sort_is_a_rotation_where_the_spawns_provably_go_in_front(ctx):
                 np.testing.assert_array_equal(ref["dead"], fx.dead_list(), err_msg=f"frame {f}")
     rot, ineligible = _rotations(prog)
     assert not ineligible and rot >= frames - 30, prog.kernel_info()   # every frame with spawns but the first
+    # ... and in those frames the casualties are known to be the oldest rows: no k_count_rows (checked on the device against the died bits)
+    assert _suffix_frames(prog) >= frames - 30, prog.kernel_info()
+    assert all(fx.metadata()["fault"] == 0 for fx in fxs)
     c = orcs[0].state()["counters"]
     assert c["particle_counter"] > c["alive_count"] + cap // 4 and c["alive_count"] > cap // 2   # particles died and their slots were reused
     prog.destroy()
@@ -690,7 +700,7 @@ def test_ribbon_sort_after_a_negative_tick_does_not_trust_later_frames(ctx):
     gpu.fx.destroy(); gpu.prog.destroy()
 
 
-@pytest.mark.parametrize("case", ["age_not_zero", "two_ribbon_ids", "dies_in_first_frame", "zero_tick", "host_write", "per_particle_rid"])
+@pytest.mark.parametrize("case", ["age_not_zero", "two_ribbon_ids", "dies_in_first_frame", "zero_tick", "host_write", "per_particle_rid", "lifetime_changes"])
 def test_ribbon_rotation_is_suspended_where_its_premises_fail(ctx, case):
     """Each premise of the rotation, violated: the sort falls back to keys and stays bit-exact."""
     cap = 6000
@@ -705,6 +715,8 @@ def test_ribbon_rotation_is_suspended_where_its_premises_fail(ctx, case):
         def rid(w):
             return w.prop(w.add_property("rid", bh.Value.u32(0)))
         kw["rid"] = rid
+    if case == "lifetime_changes":
+        kw["lifetime_prop"] = True   # frame 30: new particles live 0.4 s and die BEFORE the older ones - the casualties are no longer the last rows
     asset = _ribbon_asset(cap, **kw)
     gpu, orc = GpuRunner(asset, ctx=ctx), OracleRunner(asset)
     sp, rng = bh.EffectSpawner(asset.spawner), bh.Pcg32()
@@ -717,6 +729,8 @@ def test_ribbon_rotation_is_suspended_where_its_premises_fail(ctx, case):
         props = {}
         if case == "two_ribbon_ids" and f == 30:
             props = {"rid": np.array([1], dtype=np.uint32)}
+        if case == "lifetime_changes" and f == 30:
+            props = {"life": np.array([0.4], dtype=np.float32)}
         fr = Frame(dt, sp.tick(dt if dt else 1 / 60, rng), frame_seed(f), time=f / 60, props=props)
         gpu.step(fr)
         orc.step(fr)
@@ -734,6 +748,9 @@ def test_ribbon_rotation_is_suspended_where_its_premises_fail(ctx, case):
         assert 20 <= rot <= 31          # rotations until the premise broke at frame 30, none after
     elif case == "zero_tick":
         assert rot <= 22                # the zero tick ends it for good
+    elif case == "lifetime_changes":
+        assert rot >= 80 and 20 <= _suffix_frames(gpu.prog) <= 31    # the rotation's premises still hold; "the casualties are the last rows" ended at frame 30
+        assert gpu.fx.metadata()["fault"] == 0
     else:
         assert 0 < rot < 89             # only the frames whose tick a new particle survives
     gpu.fx.destroy(); gpu.prog.destroy()
