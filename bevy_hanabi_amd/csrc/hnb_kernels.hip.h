@@ -1266,13 +1266,13 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
     if (!flat) {
         // the alive bytes of the wave's four steps, requested together (a step's own load would wait behind the previous step's stores to the
         // same plane: two dependent round trips per step)
-        // (the cohort instantiations, budgeted for 4 waves, have the registers for it: -1 % on the churn frames; the others - C3's force
-        // field at 5 waves - lost 2.5 % to it and load each step's word where it is used, profiles/r03s_ab.log)
+        // (the cohort instantiations, budgeted for 4 waves, and the component-wise programs have the registers for it: -1 % on the churn
+        // frames; the others - C3's force field at 5 waves - lost 2.5 % to it and load each step's word where it is used, profiles/r03s_ab.log)
         auto f4_of = [&](const uint32_t step) {
             const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;
             return chunk_full ? 0x01010101u : (s0 < args.capacity ? flags4[s0 >> 2] : 0u);  // the plane is padded: slots past the capacity read 0
         };
-        if constexpr (COHORT) {
+        if constexpr (COHORT || PROG::kFlat) {
             uint32_t f4s[kWaveRows / kStepRows];
 #pragma unroll
             for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) f4s[step] = f4_of(step);
@@ -1281,7 +1281,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
                 for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4s[step]);
             } else {
 #pragma unroll
-                for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<true>{}, step, f4s[step]);
+                for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<COHORT>{}, step, f4s[step]);
             }
         } else {
 #pragma unroll
