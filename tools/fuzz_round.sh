@@ -8,5 +8,6 @@ timeout 500 python tests/fuzz_sweep.py --backend gpu --jit 1 --typed --seeds 740
 timeout 500 python tests/fuzz_sweep.py --backend gpu --jit 1 --capacity 9000 --frames 40 --seeds 7600:7700 2>&1 | tail -3 >> $L
 timeout 500 python tests/fuzz_sweep.py --backend gpu --jit 1 --abstract --seeds 7700:7850 2>&1 | tail -3 >> $L
 timeout 500 python tests/fuzz_sweep.py --backend gpu --jit 1 --abstract --typed --seeds 7850:8000 2>&1 | tail -3 >> $L
+timeout 400 python tests/fuzz_sweep.py --backend gpu --jit 0 --scene 8 --seeds 9000:9400 2>&1 | tail -3 >> $L
 SOAK_LO=${SOAK_LO:-300} SOAK_HI=${SOAK_HI:-340} timeout 900 python tools/soak_fuzz.py 2>&1 | grep -E "MISMATCH|soak:" >> $L
 cat $L
