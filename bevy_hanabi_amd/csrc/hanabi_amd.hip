@@ -1131,11 +1131,10 @@ int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
                                                               reinterpret_cast<uint32_t*>(base + p->dev.alive_off[1]), cap);
     // Attribute planes start zeroed (the reference pre-fills with 0xFF only in debug builds).
     HIP_TRY(hipMemsetAsync(base + p->dev.attrs[0].plane_off, 0, p->slab_bytes - p->dev.attrs[0].plane_off, ctx->stream));
-    if (p->horizon_eligible) {   // death horizons: no row yet, nobody can die (k_init takes minima into these); the clock starts at 0
-        std::vector<unsigned long long> never((size_t)p->dev.chunks_per_inst * 2, 0x7ff0000000000000ull);
-        HIP_TRY(hipMemcpyAsync(base + p->dev.horizon_off + 256, never.data(), never.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemsetAsync(base + p->dev.horizon_off + 256 + never.size() * 8, 0xff, (size_t)p->dev.chunks_per_inst * 8, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));   // (`never` goes out of scope)
+    if (p->horizon_eligible) {   // death horizons: no row yet, nobody can die (k_init takes minima into these); the clock starts at 0 (zeroed above)
+        const size_t d_bytes = (size_t)p->dev.chunks_per_inst * 16;   // D[2][chunks]: kHorizonNever is the byte 0x7f repeated; BF[2][chunks]: 0xffffffff
+        HIP_TRY(hipMemsetAsync(base + p->dev.horizon_off + 256, 0x7f, d_bytes, ctx->stream));
+        HIP_TRY(hipMemsetAsync(base + p->dev.horizon_off + 256 + d_bytes, 0xff, (size_t)p->dev.chunks_per_inst * 8, ctx->stream));
     }
     if (p->has_ribbons) {  // {OR, AND} accumulators of the sort keys, both frame parities
         SortState st[2];
@@ -1618,7 +1617,7 @@ int hnb_simulate(HnbContext* ctx) {
     struct Family { const void* d_jobs = nullptr; uint32_t n = 0, wgs = 0; };
     Family fam_init[2], fam_generic[2], fam_stream[2];   // [wide register file] / [age cohorts]
     if (ctx->scene_merge && !timed && order.size() >= 2u) {
-        auto small = [](const HnbProgram* p) { return p->mergeable && (uint32_t)p->effects.size() * p->dev.chunks_per_inst <= kSceneMaxChunks; };
+        auto small = [](const HnbProgram* p) { return p->mergeable && (uint64_t)p->effects.size() * p->dev.chunks_per_inst <= kSceneMaxChunks; };
         // kinds: 0 init, 1 update on the V register file, 2 streaming update; v: wide register file (0, 1) / age cohorts (2).
         // k_update_jobs serves streaming (no cohorts), streaming (cohorts), V register file (narrow) in this order: first_wg runs over its whole grid
         auto member_of = [&](const HnbProgram* p, int kind, int v) {

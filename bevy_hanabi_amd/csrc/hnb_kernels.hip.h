@@ -212,7 +212,7 @@ __device__ __forceinline__ HorizonView horizon_view(char* base, soff_t off, uint
     h.chunks = chunks;
     return h;
 }
-constexpr unsigned long long kHorizonNever = 0x7ff0000000000000ull;   // +inf: no row, nobody can die
+constexpr unsigned long long kHorizonNever = 0x7f7f7f7f7f7f7f7full;   // 1.4e306, above every clock: no row, nobody can die (one repeated byte: the host sets it with a memset)
 constexpr uint32_t kHorizonFrames = 4096u;
 
 // ---- init -----------------------------------------------------------------------------------
