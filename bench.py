@@ -5,7 +5,7 @@
 
 A "step" is one simulated frame (one pass of the hot path: per-frame inputs upload, init where the frame spawns, update +
 kill + list maintenance, ribbon sort where the layout has RIBBON_ID) over particle state resident in HBM. After W warm-up
-frames the script times WINDOWS (default 5) windows of exactly K steps each, every one bracketed by a barrier and a device
+frames the script times WINDOWS (default 11) windows of exactly K steps each, every one bracketed by a barrier and a device
 synchronisation; `ms_per_step` / `value` are the MEDIAN window, the others are listed under "windows" (min, all).
 
 Configurations (synthetic scalings of the reference's example assets):
@@ -18,7 +18,7 @@ Configurations (synthetic scalings of the reference's example as
   c2_events                   the REAL examples/firework.rs at scale: three linked effects - rockets whose update emits GPU spawn
                               events, a sparkle trail (5 events per rocket and frame) and the trails (1000 events per dying rocket,
                               capacity 16,777,216) - in steady state, event buffers sized for it;
-  c2_interop                  c2 with HNB_AGE_COHORT=0: the AGE plane is kept up to date for a renderer that reads it
+  c2_interop                  c2 with HNB_OPT_AGE_COHORT off: the AGE plane is kept up to date for a renderer that reads it
                               (ColorOverLifetime / SizeOverLifetime, src/modifier/output.rs:310-312);
   c3                          examples/force_field.rs, capacity 8,388,608 per GPU, burst, capacity slabs;
   c4                          examples/instancing.rs: independent instances x 65,536, sharded BY INSTANCE
@@ -38,6 +38,17 @@ guides/MI355X_MICROARCH.md prescribes for gfx950), cutting the dispatch list at 
                         lifetime culling, no list traffic in frames without casualties).
 Without rocprofv3 the committed profiles/traffic.json is used if its kernel-source stamp matches this tree, else the
 fraction falls back to a stated per-configuration byte model (`traffic_source` says which).
+
+Parity gate (BASELINE.md §3 "same run"): before a configuration's number is accepted, the state its timed frames produced is compared bit
+for bit with the CPU oracle (oracle/, the restatement of the reference's WGSL semantics): burst configurations (c2, c2_interop, c3, c4) on one
+slab of slots of the FULL-SIZE effect after all timed frames (a burst fills slot i with PRNG stream i: the slab IS a small effect with that
+slot_base); churn configurations (c2_mixed, c2_dieoff, c2_events, c5) by replaying the same regime (same dt, warm-up and frame count) at a reduced
+capacity against the oracle, full state. Slab / capacity are sized to the oracle's measured speed (a few seconds per configuration). The line
+carries "parity": {"checked": [...], "ok": true}; if a comparison fails the line carries "value": null and the exit code is 1.
+
+Output: the LAST stdout line is the short result (<= 4 KB: the c2 headline with roofline, cpu_baseline, parity and a one-row summary of every
+other configuration); the complete record (every window, stage, counter and per-kernel figure) goes to profiles/bench_full.json (and
+gpurun_out/bench_full.json when that directory exists) and to stderr.
 
 N > 1: `python bench.py --gpus N` launches itself under `python -m torch.distributed.run` (one process per GPU, RCCL); when the
 driver already started it that way (WORLD_SIZE in the environment) it just runs its rank. There is no data-path collective: the
@@ -90,7 +101,7 @@ CONFIGS = {
     "c2_dieoff": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=62, kernel="k_update_slots_stream<ProgDragAccel, cohort>",
                       workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst; frames 48..70 at 1/60 s: the die-off (list kernels every frame)"),
     "c2_interop": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=56, kernel="k_update_slots_stream<ProgDragAccel>",
-                       workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst, all alive, HNB_AGE_COHORT=0 (AGE plane current every frame)"),
+                       workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst, all alive, hnb_ctx_set_option(HNB_OPT_AGE_COHORT, OFF) (AGE plane current every frame)"),
     "c2_events": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=62, kernel="k_update_slots_stream<ProgDragAccel, cohort> (trails)",
                       workload="the real examples/firework.rs: rocket (capacity 32_768, 16_000 rockets/s) -> sparkle_trail (1_048_576; 5 spawn events per rocket and frame) + "
                                "trails (capacity={cap:_}; 1000 spawn events per dying rocket), GPU spawn events, steady state"),
@@ -307,11 +318,15 @@ class Workload:
         self.spawner = self.rng = None
         self.xf_of = None
         self.family = "c2" if name.startswith("c2") else name
+        self.shadow = None       # parity gate: callable(f, dt, [(spawn, seed, transform) per effect]) stepped in lockstep with the GPU
+        self.assets, self.event_caps, self.slot_base = [], [None, None, None], 0
         if name == "c4":
             inst_per_gpu = args.instances or cfg["instances"]
             total_inst = inst_per_gpu if strong else inst_per_gpu * n
             mine = sharding.instance_plan(total_inst, n)[D.rank]          # instance i -> rank i mod N
             asset = effects.instancing(self.per_inst_cap)
+            self.assets = [asset]
+            self.gids = list(mine)
             self.prog = self.ctx.create_program(bh.lower(asset))
             self.fxs = [self.prog.create_effect() for _ in mine]
             gids = list(mine)
@@ -326,11 +341,13 @@ class Workload:
             self.rocket_asset = effects.firework_rocket(32768, 5, 1000)
             self.rocket_asset.spawner = bh.SpawnerSettings.rate(16000.0 * cap / (1 << 24))
             assets = [self.rocket_asset, effects.firework_sparkle_trail(max(4096, cap // 16)), effects.firework_trails_child(cap)]
+            self.assets = assets
+            self.event_caps = [None, (0, 0, max(4096, cap // 128)), (0, 1, max(4096, cap // 32))]   # (parent, channel, event capacity)
             self.progs = [self.ctx.create_program(bh.lower(a)) for a in assets]
             self.prog = self.progs[2]
             self.fxs = [p.create_effect() for p in self.progs]
-            self.fxs[1].set_parent(self.fxs[0], 0, max(4096, cap // 128))     # ~84k sparkle events per frame at full size
-            self.fxs[2].set_parent(self.fxs[0], 1, max(4096, cap // 32))      # ~270k explosion events per frame at full size
+            self.fxs[1].set_parent(self.fxs[0], 0, self.event_caps[1][2])     # ~84k sparkle events per frame at full size
+            self.fxs[2].set_parent(self.fxs[0], 1, self.event_caps[2][2])     # ~270k explosion events per frame at full size
             self.local_particles = cap
             self.sharding_desc = "one context (a parent and its children live on one GPU); replicas at N > 1"
             self.spawner, self.rng = bh.EffectSpawner(self.rocket_asset.spawner), bh.Pcg32()
@@ -348,18 +365,11 @@ class Workload:
                 asset = effects.firework_trails(cap)
             else:
                 asset = {"c3": effects.force_field, "c5": effects.ribbon}[name](cap)
-            env_before = os.environ.get("HNB_AGE_COHORT")
             if name == "c2_interop":
-                os.environ["HNB_AGE_COHORT"] = "0"     # read at program creation: the AGE plane stays the truth
-            try:
-                self.prog = self.ctx.create_program(bh.lower(asset))
-            finally:
-                if name == "c2_interop":
-                    if env_before is None:
-                        os.environ.pop("HNB_AGE_COHORT", None)
-                    else:
-                        os.environ["HNB_AGE_COHORT"] = env_before
+                self.ctx.set_option("age_cohort", 0)   # HNB_AGE_COHORT_OFF, fixed in the program at creation: the AGE plane is current after every frame
+            self.prog = self.ctx.create_program(bh.lower(asset))
             self.fxs = [self.prog.create_effect(slot_base=slot_base)]
+            self.assets, self.slot_base = [asset], slot_base
             self.local_particles = cap
             self.sharding_desc = f"capacity slab x{n}"
             if name in ("c5", "c2_mixed"):
@@ -375,6 +385,16 @@ class Workload:
             return self.per_inst_cap if f % DIEOFF_END == 0 else 0      # a burst every DIEOFF_END frames: every pass replays the same die-off
         return self.per_inst_cap if f == 0 else 0
 
+    def inputs_of(self, f, s):
+        """Per-frame inputs (spawn count, seed, transform) of the effects of this rank in frame f, given the spawner's count s.
+        c4 is vectorised in step(); here only the instances the parity gate asks for (inputs_of_instance)."""
+        if self.name == "c2_events":
+            return [(s, frame_seed(f), None), (0, frame_seed(1000 + f), None), (0, frame_seed(2000 + f), None)]
+        if self.name == "c5":   # the emitter moves (ribbon.rs Shape::tick, Lissajou)
+            t = f * self.dt * 6.5
+            return [(s, frame_seed(f), [1, 0, 0, 25.0 * np.cos(3.0 * t), 0, 1, 0, 25.0 * np.sin(2.0 * t), 0, 0, 1, 0.0])]
+        return [(s, frame_seed(f % DIEOFF_END if self.name == "c2_dieoff" else f), None)]
+
     def step(self):
         f, ctx, dt = self.f, self.ctx, self.dt
         ctx.frame_begin(dt, f * dt)
@@ -382,15 +402,12 @@ class Workload:
         if self.name == "c4":
             # (numpy, not a Python loop over 512 instances: the harness must not be what the step waits for)
             self.prog.set_frames(np.full(len(self.fxs), s, dtype=np.uint32), (self.gid_mix ^ np.uint64(frame_seed(f))).astype(np.uint32), self.xf_of)
-        elif self.name == "c2_events":
-            self.fxs[0].set_frame(s, frame_seed(f))
-            self.fxs[1].set_frame(0, frame_seed(1000 + f))
-            self.fxs[2].set_frame(0, frame_seed(2000 + f))
-        elif self.name == "c5":   # the emitter moves (ribbon.rs Shape::tick, Lissajou)
-            t = f * dt * 6.5
-            self.fxs[0].set_frame(s, frame_seed(f), [1, 0, 0, 25.0 * np.cos(3.0 * t), 0, 1, 0, 25.0 * np.sin(2.0 * t), 0, 0, 1, 0.0])
         else:
-            self.fxs[0].set_frame(s, frame_seed(f % DIEOFF_END if self.name == "c2_dieoff" else f))
+            inputs = self.inputs_of(f, s)
+            for fx, (sp, seed, xf) in zip(self.fxs, inputs):
+                fx.set_frame(sp, seed, xf)
+            if self.shadow is not None:
+                self.shadow(f, dt, inputs)
         ctx.simulate()
         self.f += 1
 
@@ -399,6 +416,146 @@ class Workload:
 
     def close(self):
         self.ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# parity gate: the state the timed frames produced, against the CPU oracle, before a number is accepted
+# ------------------------------------------------------------------------------------------------------------------
+PARITY_BUDGET_S = 5.0          # oracle time per configuration (the slab / the reduced capacity is sized to the oracle's measured speed)
+PARITY_KEYS = ("capacity", "alive_count", "max_update", "max_spawn", "indirect_write_index", "particle_counter", "instance_count", "dead_count")
+BURST_PARITY = ("c2", "c2_interop", "c3", "c4")
+_ORACLE_RATE = None
+
+
+def oracle_rate():
+    """particle-updates/s of the OpenMP oracle on this host (firework update), measured once on 16,384 particles."""
+    global _ORACLE_RATE
+    if _ORACLE_RATE is None:
+        import bevy_hanabi_amd as bh
+        import oracle
+        from bevy_hanabi_amd import effects
+        oracle.build()
+        n = 16384
+        o = oracle.OracleEffect(bh.serialize_asset(effects.firework_trails(n)), omp=True)
+        o.step(1e-3, n, 1)
+        t0 = time.perf_counter()
+        for f in range(1, 5):
+            o.step(1e-3, 0, 1 + f, time=f * 1e-3)
+        _ORACLE_RATE = 4 * n / max(time.perf_counter() - t0, 1e-6)
+        o.close()
+    return _ORACLE_RATE
+
+
+def _first_difference(ref, got, is_float):
+    """None if the two u32 planes are equal (two NaNs of a float attribute compare equal whatever their bits: WGSL leaves the pattern
+    unspecified and x86 / gfx950 default NaNs differ in sign), else a description of the first differing element."""
+    if np.array_equal(ref, got):
+        return None
+    diff = ref != got
+    if is_float:
+        isnan = lambda x: ((x & 0x7F800000) == 0x7F800000) & ((x & 0x007FFFFF) != 0)
+        diff &= ~(isnan(ref) & isnan(got))
+        if not diff.any():
+            return None
+    i = int(np.argwhere(diff)[0][0])
+    return f"{int(diff.sum())} differing words, first at row {i}: oracle {ref[i]} device {got[i]}"
+
+
+def _stored_attrs(asset):
+    return [a for a in asset.particle_layout() if a.id >= 2]
+
+
+def parity_burst_slab(w, D):
+    """c2, c2_interop, c3, c4 after ALL the frames played so far (burst, warm-up, every timed window): slots [B, B + S) of the full-size
+    effect (c4: of one instance) against an oracle effect of capacity S and slot_base B that is fed the same frames. A burst of `capacity`
+    particles into a fresh effect gives slot i the PRNG stream of particle index slot_base + i and nothing a particle does afterwards
+    depends on another slot, so the slab of the big effect IS that small effect (the capacity-slab argument of SURVEY.md 8e)."""
+    import bevy_hanabi_amd as bh
+    import oracle
+    from bevy_hanabi_amd import effects
+    t0 = time.perf_counter()
+    frames, cap = w.f, w.per_inst_cap
+    S = int(PARITY_BUDGET_S * oracle_rate() / max(frames, 1)) // 4096 * 4096
+    S = max(4096, min(65536, S, cap // 4096 * 4096 or cap))
+    B = min(cap // 2 // 4096 * 4096, cap - S)
+    inst = len(w.fxs) // 3 if w.name == "c4" else 0            # c4: a slab of one instance in the middle of the batch
+    make = {"c2": effects.firework_trails, "c3": effects.force_field, "c4": effects.instancing}[w.family]
+    asset = make(S)
+    base = (0 if w.name == "c4" else w.slot_base) + B
+    o = oracle.OracleEffect(bh.serialize_asset(asset), base, omp=True)
+    xf = None if w.name != "c4" else instance_transform(w.gids[inst])
+    for f in range(frames):
+        seed = instance_seed(f, w.gids[inst]) if w.name == "c4" else frame_seed(f)
+        o.step(w.dt, S if f == 0 else 0, seed, time=f * w.dt, transform=xf)
+    fx = w.fxs[inst]
+    problems = []
+    for a in _stored_attrs(asset):
+        d = _first_difference(o.read_attr(a.id).view(np.uint32), fx.read_attr(a.id).view(np.uint32)[B:B + S], a.value_type.elem == bh.ScalarType.Float)
+        if d:
+            problems.append(f"{a.name}: {d}")
+    alive = fx.alive_list()
+    mine = np.sort(alive[(alive >= B) & (alive < B + S)] - B)
+    if not np.array_equal(mine, np.sort(o.alive_list())):
+        problems.append(f"alive slots of the slab: device {len(mine)}, oracle {o.alive_count()}")
+    n_alive = o.alive_count()
+    o.close()
+    return {"config": w.name, "kind": "slab of the full-size effect after the timed frames", "slots": [B, B + S], "instance": inst if w.name == "c4" else None,
+            "frames": frames, "alive_in_slab": n_alive, "attrs": [a.name for a in _stored_attrs(asset)], "seconds": time.perf_counter() - t0,
+            "ok": not problems, "problems": problems}
+
+
+def parity_regime(name, args, D, frames):
+    """c2_mixed, c2_dieoff, c2_events, c5: the same regime - same dt, same warm-up, same number of frames, the same spawner - replayed at a
+    reduced capacity on the device and, frame by frame, by the oracle; then the FULL state (counters, both lists, every plane of every slot)."""
+    import bevy_hanabi_amd as bh
+    import oracle
+    t0 = time.perf_counter()
+    full = CONFIGS[name]["capacity"] if not args.capacity else args.capacity
+    if name == "c2_dieoff":
+        frames = min(frames, 2 * DIEOFF_END)     # two passes: the second bursts into the dead list the first die-off left
+    cap = int(PARITY_BUDGET_S * oracle_rate() / max(frames, 1))
+    cap = max(16384, min(1 << (max(cap, 1).bit_length() - 1), max(16384, full // 16)))
+    sub = argparse.Namespace(**vars(args))
+    sub.capacity = cap
+    w = Workload(name, sub, D)
+    orcs = [oracle.OracleEffect(bh.serialize_asset(a), w.slot_base, omp=True) for a in w.assets]
+    for o, link in zip(orcs, w.event_caps):
+        if link is not None:
+            o.set_parent(orcs[link[0]], link[1], link[2])
+
+    def shadow(f, dt, inputs):   # the reference's frame order: every init pass, parents first, then every update pass
+        for o, (sp, seed, xf) in zip(orcs, inputs):
+            o.init_pass(dt, sp, seed, time=f * dt, transform=xf)
+        for o, (sp, seed, xf) in zip(orcs, inputs):
+            o.update_pass(dt, seed, time=f * dt, transform=xf)
+
+    w.shadow = shadow
+    for _ in range(frames):
+        w.step()
+    w.ctx.synchronize()
+    problems, alive = [], []
+    for i, (o, fx, asset) in enumerate(zip(orcs, w.fxs, w.assets)):
+        m, c = fx.metadata(), o.counters()
+        alive.append(c["alive_count"])
+        if {k: m[k] for k in PARITY_KEYS} != c:
+            problems.append(f"effect {i} counters: device {[m[k] for k in PARITY_KEYS]} oracle {[c[k] for k in PARITY_KEYS]}")
+            continue
+        if m["fault"]:
+            problems.append(f"effect {i}: device fault flag {m['fault']}")
+        for what, a, b in (("alive list", o.alive_list(), fx.alive_list()), ("dead list", o.dead_list(), fx.dead_list())):
+            d = _first_difference(a, b, False)
+            if d:
+                problems.append(f"effect {i} {what}: {d}")
+        for a in _stored_attrs(asset):
+            d = _first_difference(o.read_attr(a.id).view(np.uint32), fx.read_attr(a.id).view(np.uint32), a.value_type.elem == bh.ScalarType.Float)
+            if d:
+                problems.append(f"effect {i} {a.name}: {d}")
+    kinfo = w.prog.kernel_info().split("\n")
+    for o in orcs:
+        o.close()
+    w.close()
+    return {"config": name, "kind": "the same regime at reduced capacity, full state", "capacity": cap, "frames": frames, "alive_at_end": alive,
+            "kernels": kinfo[0], "seconds": time.perf_counter() - t0, "ok": not problems, "problems": problems}
 
 
 def warmup_frames(name, requested):
@@ -501,6 +658,16 @@ def run_config(name, args, D, strong=False, pmc=None):
     alive1 = w.alive()
     m1 = [fx.metadata() for fx in w.fxs[:8]]
     kinfo = w.prog.kernel_info().split("\n")[0]
+    parity = None
+    if args.parity and D.rank == 0 and not strong:
+        try:
+            if name in BURST_PARITY:
+                parity = parity_burst_slab(w, D)
+            else:
+                w.close()
+                parity = parity_regime(name, args, D, w.f)
+        except Exception as e:
+            parity = {"config": name, "ok": False, "problems": [f"{type(e).__name__}: {e}"]}
     w.close()
 
     alive0_total, alive1_total = D.sum_counts([alive0, alive1])
@@ -547,6 +714,7 @@ def run_config(name, args, D, strong=False, pmc=None):
                                      "whole_step_over_peak": updates * bpu / med / 1e9 / (HBM_PEAK_GBS * n),
                                      "note": "SURVEY.md §8(d) bytes x updates / time: what the work is worth, not what was moved (above the moved figure wherever the design elides traffic)"}},
         "kernels": kinfo,
+        "parity": parity,
     }
     if per_program is not None:
         out["stages"]["per_program"] = per_program
@@ -609,6 +777,37 @@ def parse_counter_csv(path, counter, info):
     return out
 
 
+def parse_kernel_trace(path, info):
+    """rocprofv3 --kernel-trace CSV of the marker-cut child -> {config: {"dominant_ms": avg duration of the dominant kernel's launches,
+    "dominant_n": launches, "per_kernel_ms": {kernel: {"avg", "min", "max", "launches_per_frame"}}}}: the per-configuration kernel durations
+    a reader can re-derive `frac` from without trusting this process's HIP events."""
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["Grid_Size_X"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6))
+    rows.sort()
+    out = {}
+    for name, meta in info.items():
+        inside, sect = False, []
+        for _id, kname, grid, ms in rows:
+            if "k_marker" in kname:
+                inside = grid == meta["begin"] if grid in (meta["begin"], meta["end"]) else inside
+                continue
+            if inside:
+                sect.append((kname, ms, grid))
+        if not sect:
+            continue
+        per = {}
+        for kname, ms, _g in sect:
+            per.setdefault(kname.split("(")[0].replace("void ", "").replace("hnb::", "")[:120], []).append(ms)
+        match = [(ms, g) for k, ms, g in sect if any(m in k for m in KERNEL_MATCH[name])]
+        gmax = max((g for _ms, g in match), default=0)
+        dom = [ms for ms, g in match if g == gmax]
+        out[name] = {"dominant_ms": sum(dom) / len(dom) if dom else None, "dominant_n": len(dom), "frames": meta["frames"],
+                     "per_kernel_ms": {k: {"avg": sum(v) / len(v), "min": min(v), "max": max(v), "launches_per_frame": len(v) / meta["frames"]} for k, v in per.items()}}
+    return out
+
+
 def measure_traffic(args, names):
     """Two rocprofv3 counter passes of this script (FETCH_SIZE and WRITE_SIZE cannot share a pass). Returns
     {config: {bytes_per_launch, frame_bytes, ...}} or raises."""
@@ -618,9 +817,10 @@ def measure_traffic(args, names):
     res = {}
     tmp = tempfile.mkdtemp(prefix="hnb_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "DURATION"):
             outdir = os.path.join(tmp, counter)
-            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", outdir, "--", sys.executable, os.path.abspath(__file__),
+            # (DURATION: a third pass with the kernel trace alone - counter collection perturbs the durations it would report)
+            cmd = [exe, "--kernel-trace"] + (["--pmc", counter] if counter != "DURATION" else []) + ["--output-format", "csv", "-d", outdir, "--", sys.executable, os.path.abspath(__file__),
                    "--pmc-child", "--pmc-configs", ",".join(names), "--config", args.config]
             if args.capacity:
                 cmd += ["--capacity", str(args.capacity)]
@@ -633,6 +833,16 @@ def measure_traffic(args, names):
             if p.returncode != 0 or line is None:
                 raise RuntimeError(f"counter pass {counter} failed (rc {p.returncode}): {(p.stderr or p.stdout)[-300:]}")
             info = json.loads(line[len("PMCINFO "):])
+            if counter == "DURATION":
+                files = glob.glob(os.path.join(outdir, "**", "*kernel_trace.csv"), recursive=True)
+                if not files:
+                    raise RuntimeError("duration pass: no kernel_trace.csv")
+                res[counter] = parse_kernel_trace(files[0], info)
+                if args.keep_pmc:
+                    os.makedirs(args.keep_pmc, exist_ok=True)
+                    with open(os.path.join(args.keep_pmc, "kernel_durations.json"), "w") as fo:
+                        json.dump(res[counter], fo, indent=1)
+                continue
             files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 raise RuntimeError(f"counter pass {counter}: no counter_collection.csv")
@@ -661,7 +871,8 @@ def measure_traffic(args, names):
                      "fetch_size_kib": f["dominant_kib"], "write_size_kib": wv["dominant_kib"],
                      "frame_bytes": f["frame_kib"] * 1024 * 2 + wv["frame_kib"] * 1024,
                      "per_kernel": {k: {"fetch_kib": v["median"], "write_kib": wv["per_kernel_kib"].get(k, {}).get("median"), "launches_per_frame": v["launches_per_frame"]}
-                                    for k, v in f["per_kernel_kib"].items()}}
+                                    for k, v in f["per_kernel_kib"].items()},
+                     "rocprof": res.get("DURATION", {}).get(name)}
     return out
 
 
@@ -678,6 +889,11 @@ def attach_roofline(result, name, traffic, source):
     else:
         b = CONFIGS[name]["model_bytes"] * n_upd
         r["traffic"] = None
+    if traffic is not None and traffic.get("rocprof") and traffic["rocprof"].get("dominant_ms"):
+        rp = traffic["rocprof"]
+        r["kernel_ms_rocprof"] = rp["dominant_ms"]     # rocprofv3 --kernel-trace, same marker-cut frames as the counters (a separate child process)
+        r["frac_rocprof"] = traffic["bytes_per_launch"] / (rp["dominant_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        r["rocprof_detail"] = {"launches": rp["dominant_n"], "per_kernel_ms": rp["per_kernel_ms"]}
     r["traffic_unit"], r["traffic_source"] = "B/launch", source
     r["moved_bytes_per_update"] = b / n_upd if n_upd else None
     r["achieved"] = b / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
@@ -762,12 +978,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps frames each; the line reports the median window")
+    ap.add_argument("--windows", type=int, default=11, help="timed windows of --steps frames each; the line reports the median window")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both")
     ap.add_argument("--capacity", type=int, default=None, help="particles per effect instance (default: the configuration's)")
     ap.add_argument("--instances", type=int, default=None, help="c4: instances per GPU (weak) / in total (strong); default 512")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", dest="parity", action="store_false", default=True,
+                    help="skip the oracle comparison of the state the timed frames produced (A/B tooling only: the line then says parity.ok = null)")
+    ap.add_argument("--full-json", default=os.path.join(ROOT, "profiles", "bench_full.json"), help="where the complete record goes (the last stdout line is the short one)")
     ap.add_argument("--scene", dest="scene", action="store_true", default=True,
                     help="N = 1: append the small-effects scene (26 example effects in one context, tools/scene_bench.py) as \"small_effects_scene\" (default)")
     ap.add_argument("--no-scene", dest="scene", action="store_false")
@@ -866,9 +1085,110 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.capacity or CONFIGS["c2"]["capacity"])
         except Exception as e:
             out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    rc = 0
     if D.rank == 0:
-        print(json.dumps(out), flush=True)
+        short = short_line(out, args)
+        text = json.dumps(out)
+        for path in [args.full_json] + ([os.path.join(ROOT, "gpurun_out", "bench_full.json")] if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else []):
+            try:
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                with open(path, "w") as f:
+                    f.write(text + "\n")
+            except OSError as e:
+                print(f"note: could not write {path}: {e}", file=sys.stderr)
+        print(text, file=sys.stderr, flush=True)          # the complete record, for a log; stdout carries the short line LAST
+        print(encode_line(short), flush=True)
+        rc = 0 if short["parity"]["ok"] is not False else 1
     D.close()
+    sys.exit(rc)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def _r(x, digits=4):
+    """floats rounded to `digits` significant digits (the short line only; bench_full.json keeps everything)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def encode_line(short):
+    return json.dumps(short, separators=(",", ":"))
+
+
+def short_line(full, args):
+    """The LAST stdout line: what the driver parses (<= 4 KB; tests/test_bench_line.py builds a worst case and asserts < 6000 bytes).
+    The headline configuration with roofline, cpu_baseline and parity, plus one row per other configuration; everything else is in the
+    complete record (--full-json)."""
+    ro, win = full.get("roofline", {}), full.get("windows", {})
+    ms = win.get("ms_per_step") or [full.get("ms_per_step")]
+    parity_all = [full.get("parity")] + [v.get("parity") for v in full.get("configs", {}).values() if isinstance(v, dict)]
+    parity_all = [p for p in parity_all if p]
+    failed = [p["config"] for p in parity_all if not p.get("ok")]
+    errored = [k for k, v in full.get("configs", {}).items() if "error" in v]
+    parity = {"checked": [p["config"] for p in parity_all if p.get("ok")], "ok": (not failed) if (parity_all or args.parity) else None, "against": "oracle/, bit-exact (burst: slab of the full-size effect after the timed frames; churn: same regime, reduced capacity, full state)"}
+    if failed:
+        parity["failed"] = {p["config"]: (p.get("problems") or ["?"])[0][:120] for p in parity_all if not p.get("ok")}
+    if not args.parity:
+        parity["skipped"] = "--no-parity"
+    short = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    if parity["ok"] is False:
+        short["value"] = None            # a number whose state differs from the oracle's is not a result
+        short["refused"] = "parity gate failed: " + ", ".join(failed)
+    cfg = full.get("config", {})
+    short["config"] = {k: (cfg.get(k)[:260] if k == "workload" else cfg.get(k)) for k in ("workload", "name", "capacity_per_gpu", "instances_per_gpu", "dt", "sharding", "updates_per_frame") if k in cfg}
+    short["windows"] = {"n": win.get("n"), "steps_each": win.get("steps_each"), "ms_per_step_min_median_max": [_r(min(ms)), _r(statistics.median(ms)), _r(max(ms))],
+                        "timed_region_s": _r(win.get("timed_region_s"))}
+    short["roofline"] = {"bound": ro.get("bound"), "kernel": ro.get("kernel"), "kernel_ms_avg": _r(ro.get("kernel_ms_avg")), "kernel_ms_rocprof": _r(ro.get("kernel_ms_rocprof")),
+                         "traffic": ro.get("traffic"), "traffic_unit": ro.get("traffic_unit"), "traffic_source": (ro.get("traffic_source") or "")[:90],
+                         "moved_bytes_per_update": _r(ro.get("moved_bytes_per_update")), "achieved": _r(ro.get("achieved")), "peak": ro.get("peak"), "unit": ro.get("unit"),
+                         "frac": _r(ro.get("frac")), "frac_rocprof": _r(ro.get("frac_rocprof")),
+                         "algorithmic": {"bytes_per_update": ro.get("algorithmic", {}).get("bytes_per_update"), "whole_step_over_peak": _r(ro.get("algorithmic", {}).get("whole_step_over_peak"))},
+                         "whole_step": {"frac": _r(ro.get("whole_step", {}).get("frac"))}}
+    cb = full.get("cpu_baseline")
+    if cb:
+        short["cpu_baseline"] = cb if "error" in cb else {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "threads": cb["threads"], "host_physical_cores": cb.get("host_physical_cores"),
+                                                          "host_logical_cpus": cb.get("host_logical_cpus"), "cpu_model": cpu_model(), "kind": cb["kind"], "sample": cb["sample"][:120]}
+    short["parity"] = parity
+    rows = {}
+    for k, v in full.get("configs", {}).items():
+        if "error" in v:
+            rows[k] = {"error": v["error"][:120]}
+            continue
+        r2 = v.get("roofline", {})
+        # (value, ms_per_step: median window; kernel_ms: HIP events, kernel_ms_rocprof: rocprofv3 kernel trace; frac = moved bytes / kernel time / 8 TB/s;
+        #  B_upd = moved bytes per update; whole_step_frac = all kernels' moved bytes / step time / peak; ws68 = 68 B x updates / step time / peak;
+        #  stages_ms = [init, update, lists])
+        rows[k] = {"value": _r(v.get("value")), "ms_per_step": _r(v.get("ms_per_step")), "kernel_ms": _r(r2.get("kernel_ms_avg")),
+                   "kernel_ms_rocprof": _r(r2.get("kernel_ms_rocprof")), "frac": _r(r2.get("frac"), 3), "B_upd": _r(r2.get("moved_bytes_per_update"), 3),
+                   "whole_step_frac": _r(r2.get("whole_step", {}).get("frac"), 3), "ws68": _r(r2.get("algorithmic", {}).get("whole_step_over_peak"), 3),
+                   "stages_ms": [_r(v.get("stages", {}).get(x), 3) for x in ("init_ms_avg", "update_ms_avg", "lists_ms_avg")],
+                   "parity": (v.get("parity") or {}).get("ok")}
+        if v.get("init"):
+            rows[k]["init_frac"] = _r(v["init"].get("frac"), 3)
+    if rows:
+        short["configs"] = rows
+    if full.get("init"):
+        short["burst_init"] = {"kernel_ms": _r(full["init"].get("kernel_ms")), "frac": _r(full["init"].get("frac"), 3)}
+    sc = full.get("small_effects_scene")
+    if sc:
+        short["small_effects_scene"] = sc if "error" in sc else {"effects": sc.get("effects"), "ms_per_frame_wall": _r(sc.get("ms_per_frame_wall")), "ms_per_frame_in_simulate": _r(sc.get("ms_per_frame_in_simulate"))}
+    if full.get("strong"):
+        short["strong"] = {k: _r(v) for k, v in full["strong"].items() if k != "workload"}
+    short["build"] = full.get("build")
+    short["full_record"] = os.path.relpath(args.full_json, ROOT)
+    if errored:
+        short["config_errors"] = errored
+    return short
 
 
 if __name__ == "__main__":

@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -105,6 +106,13 @@ void select_stream_kernel(const Ins* code, uint32_t n, StreamLaunchFn* fn, const
     *name = "ProgInterp";
 }
 
+// What hnb_program_create fixes in a program (hnb_ctx_set_option before the program is created; hnb_jit_precompile uses the defaults)
+struct ProgramOptions {
+    uint32_t age_cohort = HNB_AGE_COHORT_LEAN;   // HNB_OPT_AGE_COHORT
+    bool cull_lifetime = true;                   // HNB_OPT_CULL_LIFETIME
+    bool horizon = true;                         // HNB_OPT_HORIZON
+};
+
 struct HnbContext {
     int device = 0;
     hipStream_t stream = nullptr;       // the stream hnb_simulate enqueues on: own_stream or the caller's (hnb_ctx_set_stream)
@@ -122,16 +130,20 @@ struct HnbContext {
     std::vector<HnbProgram*> programs;
     HnbSimParams sim{};
     uint32_t frame = 0;         // simulated frames: parity double-buffers the spawn-event counters
-    uint32_t list_order = HNB_LIST_ORDER_SPAWN;  // applied to programs created afterwards
-    bool skip_lists = true;     // skip the list kernels of frames the device's no-death bound covers (HNB_SKIP_LISTS=0 turns it off)
-    bool alternate = true;      // walk the chunks in alternating directions from frame to frame (HNB_ALTERNATE=0 turns it off)
-    bool suffix_proof = true;   // ribbon programs: "the casualties are the last rows of the sorted list" replaces k_count_rows where the host can prove it (HNB_SUFFIX=0 turns it off)
-    bool scene_merge = true;    // small programs share their init / update launches (ProgJob / StreamJob; HNB_SCENE_MERGE=0 turns it off)
-    bool transpose = true;      // vec3 planes of the per-particle update path through the wave's LDS transpose (HNB_TRANSPOSE=0 turns it off)
+    // Options (hnb_ctx_set_option; none of them is read from the environment). The first four are fixed in a program when it is created:
+    uint32_t list_order = HNB_LIST_ORDER_SPAWN;
+    ProgramOptions popt;        // age cohorts, lifetime culling, death horizons
+    // ... the others are scheduling choices that apply from the next hnb_simulate on:
+    bool skip_lists = true;     // skip the list kernels of frames the device's no-death bound covers (HNB_OPT_SKIP_LISTS)
+    bool alternate = true;      // walk the chunks in alternating directions from frame to frame (HNB_OPT_ALTERNATE)
+    bool suffix_proof = true;   // ribbon programs: "the casualties are the last rows of the sorted list" replaces k_count_rows where the host can prove it (HNB_OPT_SUFFIX_PROOF)
+    bool scene_merge = true;    // small programs share their init / update launches (ProgJob / StreamJob; HNB_OPT_SCENE_MERGE)
+    bool transpose = true;      // vec3 planes of the per-particle update path through the wave's LDS transpose (HNB_OPT_TRANSPOSE)
     uint32_t timing = 0;        // 0 = off, n = time every n-th simulated frame
     uint32_t timing_tick = 0;
     std::vector<TimingPair> t_update, t_init, t_compact;
     std::vector<hipEvent_t> event_pool;  // timing events are recycled, never created on the frame path once the pool is warm
+    uint32_t comm_refs = 0;     // HnbComm objects that hold this context: it cannot be destroyed before them
 };
 
 struct HnbProgram {
@@ -262,6 +274,7 @@ struct HnbEffect {
     std::vector<uint32_t> props;
 };
 
+static_assert(HNB_COMM_ID_BYTES == comm::kNcclUniqueIdBytes, "HNB_COMM_ID_BYTES is sizeof(ncclUniqueId)");
 struct HnbComm {
     std::vector<HnbContext*> ctxs;               // the local contexts (one in rank mode)
     std::vector<comm::ncclComm_t> comms;         // one RCCL communicator per local context; empty: reduced through the host
@@ -685,6 +698,7 @@ int find_attr(const HnbProgram* p, uint32_t attr) {
 
 int read_meta(HnbEffect* fx, DevMeta* out) {
     HnbProgram* p = fx->prog;
+    HIP_TRY(hipSetDevice(p->ctx->device));   // (a host with one context per GPU: the calling thread's current device may be another one)
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     HIP_TRY(hipMemcpy(out, p->d_meta[p->parity] + fx->index, sizeof(DevMeta), hipMemcpyDeviceToHost));
     return HNB_OK;
@@ -714,8 +728,8 @@ bool update_is_streamable(const uint8_t* b, const HnbProgramHeader& h, const Hnb
 // Eligible: the stream starts with the only AGE_TICK, which tests the lifetime; nothing else writes AGE or LIFETIME. The age
 // cohorts rest on the same structure (nothing but that one AGE_TICK changes AGE) and on nobody else reading the AGE plane on
 // the device (no ribbon sort).
-bool cull_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams, uint32_t* dt_operand) {
-    if (!streams || h.update_len == 0 || (getenv("HNB_CULL_LIFETIME") && getenv("HNB_CULL_LIFETIME")[0] == '0')) return false;
+bool cull_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams, const ProgramOptions& opt, uint32_t* dt_operand) {
+    if (!streams || h.update_len == 0 || !opt.cull_lifetime) return false;
     const Ins* uc = reinterpret_cast<const Ins*>(b + h.update_off);
     bool ok = (uc[0].x & 0xffu) == HNB_OP_M_AGE_TICK && ((uc[0].y >> 16) & 1u);
     for (uint32_t i = 1; i < h.update_len && ok; ++i) {
@@ -732,12 +746,12 @@ bool cull_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEnt
     if (dt_operand) *dt_operand = HNB_OPERAND_DECODE((uc[0].x >> 16) & 0xffu, uc[0].y >> 13);
     return true;
 }
-bool age_cohort_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams) {
-    if (!cull_eligible(b, h, attrs, streams, nullptr) || (h.flags & HNB_PROG_HAS_RIBBONS) || (getenv("HNB_AGE_COHORT") && getenv("HNB_AGE_COHORT")[0] == '0')) return false;
+bool age_cohort_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams, const ProgramOptions& opt) {
+    if (!cull_eligible(b, h, attrs, streams, opt, nullptr) || (h.flags & HNB_PROG_HAS_RIBBONS) || opt.age_cohort == HNB_AGE_COHORT_OFF) return false;
     // only the lean (bandwidth-bound) stacks: an update that is bound by VALU issue (ConformToSphere, Radial / TangentAccel: divisions, square
     // roots) gains nothing from 8 bytes less per particle and pays for the bookkeeping (force_field: 0.0955 -> 0.099 ms with it, measured)
-    // (HNB_AGE_COHORT=2: every eligible stack, for A/B runs)
-    if (getenv("HNB_AGE_COHORT") && getenv("HNB_AGE_COHORT")[0] == '2') return true;
+    // (HNB_AGE_COHORT_ALL: every eligible stack, for A/B runs)
+    if (opt.age_cohort == HNB_AGE_COHORT_ALL) return true;
     const Ins* uc = reinterpret_cast<const Ins*>(b + h.update_off);
     for (uint32_t i = 0; i < h.update_len; ++i)
         if (!vm_op_is_lean(uc[i].x & 0xffu)) return false;
@@ -745,7 +759,7 @@ bool age_cohort_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbA
 }
 
 // What to specialise for a program (see hnb_jit.h). `aot_static`: a pre-built ProgStatic kernel matches.
-jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams, bool aot_static) {
+jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams, bool aot_static, const ProgramOptions& opt) {
     jit::Request rq;
     rq.attrs = attrs; rq.n_attrs = h.n_attrs;
     rq.init = reinterpret_cast<const Ins*>(b + h.init_off); rq.init_len = h.init_len;
@@ -757,7 +771,7 @@ jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const
     bool lean = true;
     for (uint32_t i = 0; i < h.update_len; ++i) lean = lean && vm_op_is_lean(rq.update[i].x & 0xffu);
     rq.stream_waves = lean ? HNB_STREAM_WAVES : HNB_STREAM_WAVES_FULL;
-    rq.stream_cohort = age_cohort_eligible(b, h, attrs, streams);
+    rq.stream_cohort = age_cohort_eligible(b, h, attrs, streams, opt);
     if (rq.stream_cohort && rq.stream_waves > HNB_STREAM_WAVES_COHORT) rq.stream_waves = HNB_STREAM_WAVES_COHORT;
     return rq;
 }
@@ -785,17 +799,13 @@ int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
     if (e != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return fail(HNB_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
-    if (const char* e = getenv("HNB_ALTERNATE")) ctx->alternate = e[0] != '0';
-    if (const char* e = getenv("HNB_TRANSPOSE")) ctx->transpose = e[0] != '0';
-    if (const char* e = getenv("HNB_SCENE_MERGE")) ctx->scene_merge = e[0] != '0';
-    if (const char* e = getenv("HNB_SUFFIX")) ctx->suffix_proof = e[0] != '0';
-    if (const char* e = getenv("HNB_SKIP_LISTS")) ctx->skip_lists = e[0] != '0';
     *out_ctx = ctx;
     return HNB_OK;
 }
 
 int hnb_ctx_destroy(HnbContext* ctx) {
     if (!ctx) return HNB_OK;
+    if (ctx->comm_refs) return fail(HNB_ERR_INVALID_ARG, "the context is still part of %u communicator(s): call hnb_comm_destroy first", ctx->comm_refs);
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     while (!ctx->programs.empty()) hnb_program_destroy(ctx->programs.back());
@@ -828,6 +838,15 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
             return HNB_OK;
         case HNB_OPT_ALTERNATE: ctx->alternate = value != 0u; return HNB_OK;
         case HNB_OPT_SKIP_LISTS: ctx->skip_lists = value != 0u; return HNB_OK;
+        case HNB_OPT_AGE_COHORT:
+            if (value > HNB_AGE_COHORT_ALL) return fail(HNB_ERR_INVALID_ARG, "unknown age-cohort mode %u", value);
+            ctx->popt.age_cohort = value;
+            return HNB_OK;
+        case HNB_OPT_CULL_LIFETIME: ctx->popt.cull_lifetime = value != 0u; return HNB_OK;
+        case HNB_OPT_HORIZON: ctx->popt.horizon = value != 0u; return HNB_OK;
+        case HNB_OPT_TRANSPOSE: ctx->transpose = value != 0u; return HNB_OK;
+        case HNB_OPT_SCENE_MERGE: ctx->scene_merge = value != 0u; return HNB_OK;
+        case HNB_OPT_SUFFIX_PROOF: ctx->suffix_proof = value != 0u; return HNB_OK;
         default: return fail(HNB_ERR_INVALID_ARG, "unknown option %u", option);
     }
 }
@@ -875,16 +894,16 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     if (h.uniform_len) memcpy(p->uniform_code.data(), b + h.uniform_off, (size_t)h.uniform_len * 8);
     p->update_streams = update_is_streamable(b, h, p->attrs.data());
     p->wide_file = std::max(h.init_regs, h.update_regs) > HNB_VM_MAX_REGS;
-    if (cull_eligible(b, h, p->attrs.data(), p->update_streams, &p->cull_dt_operand)) {
+    if (cull_eligible(b, h, p->attrs.data(), p->update_streams, ctx->popt, &p->cull_dt_operand)) {
         d.cull_lifetime = 1u;
-        d.age_cohort = age_cohort_eligible(b, h, p->attrs.data(), p->update_streams) ? 1u : 0u;
+        d.age_cohort = age_cohort_eligible(b, h, p->attrs.data(), p->update_streams, ctx->popt) ? 1u : 0u;
     }
     if (p->update_streams) select_stream_kernel(reinterpret_cast<const Ins*>(b + h.update_off), h.update_len, &p->stream_launch, &p->stream_kernel_name);
     const bool aot_static = p->update_streams && strcmp(p->stream_kernel_name, "ProgInterp") != 0;
     p->kernel_info = std::string(p->wide_file ? "wide-file " : "") + "init=" + (h.init_len ? "interp" : "none") + " update=" +
                      (p->update_streams ? (aot_static ? std::string("aot-stream:") + p->stream_kernel_name : std::string("interp-stream")) : std::string("interp-generic"));
     if (jit::enabled()) {
-        const jit::Request rq = make_jit_request(b, h, p->attrs.data(), p->update_streams, aot_static);
+        const jit::Request rq = make_jit_request(b, h, p->attrs.data(), p->update_streams, aot_static, ctx->popt);
         jit::Result res;
         if (jit::build(rq, res)) {
             hipError_t je = hipModuleLoadData(&p->jit_module, res.code.data());
@@ -972,8 +991,7 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
             kills = kills || op == HNB_OP_M_KILL_SPHERE || op == HNB_OP_M_KILL_AABB;
         }
         p->skip_eligible = p->update_streams && d.cull_lifetime && !kills && h.n_event_channels == 0 && !(h.flags & HNB_PROG_READS_PARENT);
-        const char* hz_env = getenv("HNB_HORIZON");
-        p->horizon_eligible = p->update_streams && d.cull_lifetime && !kills && !p->has_ribbons && !p->slot_order && !(hz_env && hz_env[0] == '0');
+        p->horizon_eligible = p->update_streams && d.cull_lifetime && !kills && !p->has_ribbons && !p->slot_order && ctx->popt.horizon;
         if (hipMalloc(&p->d_fault, 4) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void**>(&p->h_safe), 8, hipHostMallocDefault) != hipSuccess) {
             if (p->jit_module) hipModuleUnload(p->jit_module);
@@ -1624,7 +1642,7 @@ int hnb_simulate(HnbContext* ctx) {
             if (!small(p)) return false;
             if (kind == 0) return p->init_blocks != 0u && p->init_blocks <= kSceneMaxInitBlocks && p->dev.init_len <= kSceneMaxCodeLen && (p->wide_file ? 1 : 0) == v;
             if (kind == 1) return !p->update_streams && p->dev.update_len <= kSceneMaxCodeLen && (p->wide_file ? 1 : 0) == v;
-            return p->update_streams && (p->dev.age_cohort ? 1 : 0) == v;
+            return p->update_streams && p->dev.update_len <= kSceneMaxCodeLen && (p->dev.age_cohort ? 1 : 0) == v;
         };
         auto count_of = [&](int kind, int v) { uint32_t m = 0; for (const HnbProgram* p : order) m += member_of(p, kind, v) ? 1u : 0u; return m; };
         const bool shared_update = count_of(2, 0) + count_of(2, 1) + count_of(1, 0) >= 2u;
@@ -1863,6 +1881,7 @@ int hnb_effect_read_attr(HnbEffect* fx, uint32_t attr, void* dst, size_t dst_siz
     if (ai < 0) return fail(HNB_ERR_NOT_FOUND, "attribute %u is not part of the particle layout", attr);
     const size_t bytes = (size_t)p->dev.capacity * p->attrs[ai].ncomp * 4;
     if (dst_size < bytes) return fail(HNB_ERR_INVALID_ARG, "destination too small (%zu < %zu)", dst_size, bytes);
+    HIP_TRY(hipSetDevice(p->ctx->device));
     if (p->dev.age_cohort && attr == HNB_ATTR_AGE)   // chunks whose particles share one age keep it in a word: write it out first
         k_materialise_age<<<p->dev.chunks_per_inst, kBlock, 0, p->ctx->stream>>>(static_cast<char*>(fx->slab), p->dev.capacity, p->dev.chunks_per_inst, p->dev.lmin_off,
                                                                                   p->dev.attrs[ai].plane_off, p->dev.alive_flag_off);
@@ -1878,18 +1897,75 @@ int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t 
     if (ai < 0) return fail(HNB_ERR_NOT_FOUND, "attribute %u is not part of the particle layout", attr);
     const size_t bytes = (size_t)p->dev.capacity * p->attrs[ai].ncomp * 4;
     if (src_size != bytes) return fail(HNB_ERR_INVALID_ARG, "source size %zu != plane size %zu", src_size, bytes);
-    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(static_cast<char*>(fx->slab) + p->dev.attrs[ai].plane_off, src, bytes, hipMemcpyHostToDevice));
     p->dirty = true;  // ... nor does the published no-death bound
     p->sort_dirty = true;  // ... and a ribbon list may no longer be in key order
     p->sort_front_broken = true;  // ... nor its ages and ribbon ids what the front proof assumes
+    // (the resets below are enqueued on the context's stream - the device the slab lives on -, then waited for)
     if (p->horizon_eligible)   // the death horizons were computed from the particles as they were: zero = "may die now" (the clock restarts with them)
-        HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.horizon_off, 0, 256 + (size_t)p->dev.chunks_per_inst * 24));
+        HIP_TRY(hipMemsetAsync(static_cast<char*>(fx->slab) + p->dev.horizon_off, 0, 256 + (size_t)p->dev.chunks_per_inst * 24, st));
     if (attr == HNB_ATTR_AGE) p->sort_values_broken = true;  // ... and the written ages may be negative (they change key order when they cross zero later)
     // the chunks' lifetime bounds (lifetime culling) no longer describe the planes
-    HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.lmin_off, 0, (size_t)p->dev.chunks_per_inst * 4));  // (the "completely alive" flags that follow stay valid)
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(fx->slab) + p->dev.lmin_off, 0, (size_t)p->dev.chunks_per_inst * 4, st));  // (the "completely alive" flags that follow stay valid)
     if (p->dev.age_cohort && attr == HNB_ATTR_AGE)   // the plane is the truth again: forget the cohort states (and values)
-        HIP_TRY(hipMemset(static_cast<char*>(fx->slab) + p->dev.lmin_off + (size_t)p->dev.chunks_per_inst * 8, 0, (size_t)p->dev.chunks_per_inst * 8));
+        HIP_TRY(hipMemsetAsync(static_cast<char*>(fx->slab) + p->dev.lmin_off + (size_t)p->dev.chunks_per_inst * 8, 0, (size_t)p->dev.chunks_per_inst * 8, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return HNB_OK;
+}
+
+// ---- device-side output boundary (include/hanabi_amd.h "Device-side output") ---------------------------------------------------
+// What the reference's render passes bind after `simulate` (src/render/mod.rs:5152-5820: the particle buffer, the indirect index buffer,
+// the effect metadata row vfx_indirect.wgsl:57-85 turned into draw-indirect arguments) as device pointers. Nothing here synchronises.
+static_assert(sizeof(HnbDeviceMeta) == sizeof(DevMeta), "HnbDeviceMeta is the public face of DevMeta");
+static_assert(offsetof(HnbDeviceMeta, alive_count) == offsetof(DevMeta, alive_count) && offsetof(HnbDeviceMeta, list_column) == offsetof(DevMeta, write_index) &&
+              offsetof(HnbDeviceMeta, max_update) == offsetof(DevMeta, max_update) && offsetof(HnbDeviceMeta, indirect_write_index) == offsetof(DevMeta, ref_write_index) &&
+              offsetof(HnbDeviceMeta, instance_count) == offsetof(DevMeta, instance_count), "HnbDeviceMeta field order");
+static_assert(HNB_VIEW_MAX_ATTRS >= kMaxAttrs, "a view holds every attribute a layout may have");
+
+int hnb_effect_device_view(HnbEffect* fx, HnbDeviceView* out) {
+    if (!fx || !out) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    HnbProgram* p = fx->prog;
+    char* base = static_cast<char*>(fx->slab);
+    memset(out, 0, sizeof *out);
+    out->struct_size = (uint32_t)sizeof *out;
+    out->device = p->ctx->device;
+    out->stream = p->ctx->stream;
+    out->capacity = p->dev.capacity;
+    out->slot_base = fx->slot_base;
+    out->n_attrs = p->dev.n_attrs;
+    out->stale_attr_mask = p->dev.age_cohort ? (1ull << HNB_ATTR_AGE) : 0ull;
+    out->alive_list[0] = reinterpret_cast<const uint32_t*>(base + p->dev.alive_off[0]);
+    out->alive_list[1] = reinterpret_cast<const uint32_t*>(base + p->dev.alive_off[1]);
+    out->dead_list = reinterpret_cast<const uint32_t*>(base + p->dev.dead_off);
+    out->meta = reinterpret_cast<const HnbDeviceMeta*>(p->d_meta[p->parity] + fx->index);
+    out->meta_next = reinterpret_cast<const HnbDeviceMeta*>(p->d_meta[p->parity ^ 1u] + fx->index);
+    for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
+        HnbDeviceAttr& v = out->attrs[a];
+        v.attr = p->attrs[a].attr;
+        v.ncomp = p->attrs[a].ncomp;
+        v.scalar_type = p->attrs[a].scalar_type;
+        v.stride_bytes = (uint16_t)(p->attrs[a].ncomp * 4u);
+        v.plane = base + p->dev.attrs[a].plane_off;
+    }
+    return HNB_OK;
+}
+
+int hnb_effect_materialise(HnbEffect* fx, uint64_t attr_mask) {
+    if (!fx) return fail(HNB_ERR_INVALID_ARG, "fx is NULL");
+    HnbProgram* p = fx->prog;
+    for (uint32_t a = 0; a < HNB_ATTR_COUNT; ++a)
+        if ((attr_mask >> a & 1ull) && find_attr(p, a) < 0) return fail(HNB_ERR_NOT_FOUND, "attribute %u is not part of the particle layout", a);
+    if (attr_mask >> HNB_ATTR_COUNT) return fail(HNB_ERR_INVALID_ARG, "attribute mask 0x%llx names attributes that do not exist", (unsigned long long)attr_mask);
+    if (p->dev.age_cohort && (attr_mask >> HNB_ATTR_AGE & 1ull)) {   // the one plane the update may leave stale: chunks whose particles share one age keep it in a word
+        HIP_TRY(hipSetDevice(p->ctx->device));
+        const int ai = find_attr(p, HNB_ATTR_AGE);
+        k_materialise_age<<<p->dev.chunks_per_inst, kBlock, 0, p->ctx->stream>>>(static_cast<char*>(fx->slab), p->dev.capacity, p->dev.chunks_per_inst, p->dev.lmin_off,
+                                                                                  p->dev.attrs[ai].plane_off, p->dev.alive_flag_off);
+        HIP_TRY(hipGetLastError());
+    }
     return HNB_OK;
 }
 
@@ -1964,7 +2040,7 @@ int hnb_jit_precompile(const void* blob, size_t blob_size) {
         select_stream_kernel(reinterpret_cast<const Ins*>(b + h.update_off), h.update_len, &fn, &name);
         aot_static = strcmp(name, "ProgInterp") != 0;
     }
-    const jit::Request rq = make_jit_request(b, h, attrs.data(), streams, aot_static);
+    const jit::Request rq = make_jit_request(b, h, attrs.data(), streams, aot_static, ProgramOptions());   // (the default options: what a context starts with)
     if (!rq.want_init && !rq.want_update_generic && !rq.want_update_stream) return HNB_OK;
     jit::Result res;
     if (!jit::build(rq, res)) return fail(HNB_ERR_BAD_PROGRAM, "kernel specialisation failed: %s", res.log.c_str());
@@ -1983,48 +2059,66 @@ int hnb_comm_unique_id(void* out_id) {
     return HNB_OK;
 }
 
+int hnb_comm_set_library(const char* path, uint32_t flags) {
+    if (flags & ~(uint32_t)HNB_COMM_LIB_DUPLICATE_DEVICES) return fail(HNB_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+    comm::LibraryChoice& ch = comm::library_choice();
+    std::lock_guard<std::mutex> g(ch.mu);
+    if (ch.loaded) return fail(HNB_ERR_INVALID_ARG, "the collective library is already loaded: hnb_comm_set_library must precede the first hnb_comm_* call of the process");
+    ch.path = path ? path : "";
+    ch.duplicate_devices = (flags & HNB_COMM_LIB_DUPLICATE_DEVICES) != 0u;
+    return HNB_OK;
+}
+
 int hnb_comm_create_local(HnbContext* const* ctxs, uint32_t n_ctx, HnbComm** out_comm) {
     if (!ctxs || !n_ctx || !out_comm) return fail(HNB_ERR_INVALID_ARG, "NULL / empty argument");
     std::vector<int> devs;
     bool distinct = true;
     for (uint32_t i = 0; i < n_ctx; ++i) {
         if (!ctxs[i]) return fail(HNB_ERR_INVALID_ARG, "context #%u is NULL", i);
+        for (uint32_t j = 0; j < i; ++j) if (ctxs[j] == ctxs[i]) return fail(HNB_ERR_INVALID_ARG, "context #%u is listed twice", i);
         for (int d : devs) distinct = distinct && d != ctxs[i]->device;
         devs.push_back(ctxs[i]->device);
     }
     HnbComm* c = new HnbComm();
     c->ctxs.assign(ctxs, ctxs + n_ctx);
     c->n_ranks = n_ctx;
-    if (n_ctx > 1 && distinct) {   // one communicator per device (RCCL refuses a device twice: contexts sharing one are reduced through the host)
+    // one communicator per device. RCCL refuses a device twice: contexts sharing one are reduced through the host - unless the library
+    // chosen with hnb_comm_set_library says it takes duplicates (the stand-in of tests/fake_rccl, which lets the collective branch run on a one-GPU box)
+    bool duplicates_ok = false;   // (asked of the CHOICE, not of the library: a one-GPU host whose contexts share a device never loads librccl)
+    { comm::LibraryChoice& ch = comm::library_choice(); std::lock_guard<std::mutex> g(ch.mu); duplicates_ok = ch.duplicate_devices; }
+    if (n_ctx > 1 && (distinct || duplicates_ok)) {
         comm::Api& a = comm::api();
         if (!a.ok) { delete c; return fail(HNB_ERR_NOT_FOUND, "RCCL is not available: %s", a.why.c_str()); }
         c->comms.resize(n_ctx);
         const int rc = a.CommInitAll(c->comms.data(), (int)n_ctx, devs.data());
         if (rc != comm::kNcclSuccess) { delete c; return fail(HNB_ERR_HIP, "ncclCommInitAll failed: %s", a.GetErrorString(rc)); }
     }
+    for (HnbContext* x : c->ctxs) x->comm_refs += 1;
     *out_comm = c;
     return HNB_OK;
 }
 
 int hnb_comm_create_rank(HnbContext* ctx, const void* id, uint32_t rank, uint32_t n_ranks, HnbComm** out_comm) {
     if (!ctx || !id || !out_comm || !n_ranks || rank >= n_ranks) return fail(HNB_ERR_INVALID_ARG, "bad argument");
-    HnbComm* c = new HnbComm();
+    std::unique_ptr<HnbComm> c(new HnbComm());   // (released on every error path)
     c->ctxs.push_back(ctx);
     c->n_ranks = n_ranks; c->rank = rank;
     if (n_ranks > 1) {
         comm::Api& a = comm::api();
-        if (!a.ok) { delete c; return fail(HNB_ERR_NOT_FOUND, "RCCL is not available: %s", a.why.c_str()); }
+        if (!a.ok) return fail(HNB_ERR_NOT_FOUND, "RCCL is not available: %s", a.why.c_str());
         HIP_TRY(hipSetDevice(ctx->device));
         comm::ncclUniqueId uid;
         memcpy(uid.internal, id, HNB_COMM_ID_BYTES);
         c->comms.resize(1);
         const int rc = a.CommInitRank(&c->comms[0], (int)n_ranks, uid, (int)rank);
-        if (rc != comm::kNcclSuccess) { delete c; return fail(HNB_ERR_HIP, "ncclCommInitRank failed: %s", a.GetErrorString(rc)); }
+        if (rc != comm::kNcclSuccess) return fail(HNB_ERR_HIP, "ncclCommInitRank failed: %s", a.GetErrorString(rc));
     }
-    *out_comm = c;
+    ctx->comm_refs += 1;
+    *out_comm = c.release();
     return HNB_OK;
 }
 
+// (a communicator holds its contexts: hnb_ctx_destroy refuses a context that is still part of one)
 int hnb_comm_destroy(HnbComm* c) {
     if (!c) return HNB_OK;
     for (size_t i = 0; i < c->ctxs.size(); ++i) {
@@ -2032,6 +2126,7 @@ int hnb_comm_destroy(HnbComm* c) {
         hipStreamSynchronize(c->ctxs[i]->stream);
         if (i < c->comms.size() && c->comms[i]) comm::api().CommDestroy(c->comms[i]);
         if (i < c->d_rows.size()) { hipFree(c->d_rows[i]); hipFree(c->d_counts[i]); hipFree(c->d_totals[i]); }
+        if (c->ctxs[i]->comm_refs) c->ctxs[i]->comm_refs -= 1;
     }
     delete c;
     return HNB_OK;

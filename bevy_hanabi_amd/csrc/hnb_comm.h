@@ -11,38 +11,54 @@
 #pragma once
 #include <dlfcn.h>
 
+#include <mutex>
+#include <string>
+
+#include "hnb_comm_decl.h"
+
 namespace hnb {
 namespace comm {
 
-typedef struct ncclComm* ncclComm_t;
-struct ncclUniqueId { char internal[128]; };
-enum { kNcclSuccess = 0, kNcclUint64 = 5, kNcclSum = 0 };
-
 struct Api {
     void* lib = nullptr;
-    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    GetUniqueId_fn GetUniqueId = nullptr;
+    CommInitRank_fn CommInitRank = nullptr;
+    CommInitAll_fn CommInitAll = nullptr;
+    CommDestroy_fn CommDestroy = nullptr;
+    AllReduce_fn AllReduce = nullptr;
+    GroupStart_fn GroupStart = nullptr;
+    GroupEnd_fn GroupEnd = nullptr;
+    GetErrorString_fn GetErrorString = nullptr;
     bool ok = false;
+    bool allows_duplicate_devices = false;   // hnb_comm_set_library(.., HNB_COMM_LIB_DUPLICATE_DEVICES): a stand-in library that accepts one device twice
     std::string why;
 };
 
-inline Api& api() {
-    static Api a;
-    static bool tried = false;
-    if (tried) return a;
-    tried = true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-        a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (a.lib) break;
+// hnb_comm_set_library: an explicit library path (and what the library tolerates), honoured by the FIRST use of the API only
+struct LibraryChoice { std::mutex mu; std::string path; bool duplicate_devices = false; bool loaded = false; };
+inline LibraryChoice& library_choice() { static LibraryChoice c; return c; }
+
+inline Api load_api() {
+    Api a;
+    LibraryChoice& ch = library_choice();
+    std::string path;
+    {
+        std::lock_guard<std::mutex> g(ch.mu);
+        ch.loaded = true;
+        path = ch.path;
+        a.allows_duplicate_devices = ch.duplicate_devices;
     }
-    if (!a.lib) { a.why = std::string("librccl not found: ") + dlerror(); return a; }
+    if (!path.empty()) {
+        a.lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!a.lib) { a.why = std::string("cannot load ") + path + ": " + dlerror(); return a; }
+    } else {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) { a.why = std::string("librccl not found: ") + dlerror(); return a; }
+    }
 #define HNB_SYM(field, name) *reinterpret_cast<void**>(&a.field) = dlsym(a.lib, name); if (!a.field) { a.why = std::string("librccl lacks ") + name; return a; }
     HNB_SYM(GetUniqueId, "ncclGetUniqueId")
     HNB_SYM(CommInitRank, "ncclCommInitRank")
@@ -54,6 +70,12 @@ inline Api& api() {
     HNB_SYM(GetErrorString, "ncclGetErrorString")
 #undef HNB_SYM
     a.ok = true;
+    return a;
+}
+// One load per process, safe against concurrent first calls (a function-local static is initialised exactly once: the submit threads of
+// several contexts may reach hnb_comm_* together).
+inline Api& api() {
+    static Api a = load_api();
     return a;
 }
 

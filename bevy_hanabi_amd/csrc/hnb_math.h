@@ -16,7 +16,10 @@
 //     Trigonometric arguments with |x| > 2^40 are defined as x = 0 (sin 0, cos 1).
 //   * normalize(v) = v * (1 / length(v)): one IEEE division and three multiplications
 //     (WGSL leaves the accuracy of normalize to the implementation: "inherited from
-//     v / length(v)", whose own division may be 2.5 ulp off).
+//     v / length(v)", whose own division may be 2.5 ulp off). Domain: the reciprocal never
+//     overflows where v / length(v) is finite - dot(v, v) is an f32, so it is either 0
+//     (length 0: both forms give inf / NaN) or >= 2^-149, length >= 2^-74.5 and
+//     1 / length <= 2^74.5 (tests/test_math.py::test_normalize_reciprocal_domain).
 //
 // Compiles as plain C++ (host) and as HIP device code (HNB_HD).
 #pragma once

@@ -26,8 +26,13 @@ ABI_SYMBOLS = [
     "hnb_effect_read_dead_list", "hnb_effect_write_attr", "hnb_effect_sort_ribbons", "hnb_ctx_enable_kernel_timing",
     "hnb_ctx_kernel_timing", "hnb_program_kernel_info", "hnb_jit_precompile", "hnb_effect_set_simulated", "hnb_ctx_set_option", "hnb_program_set_frames", "hnb_effect_index",
     "hnb_ctx_profile_marker", "hnb_program_kernel_timing",
-    "hnb_comm_create_local", "hnb_comm_unique_id", "hnb_comm_create_rank", "hnb_comm_allreduce_alive", "hnb_comm_destroy",
+    "hnb_comm_create_local", "hnb_comm_unique_id", "hnb_comm_create_rank", "hnb_comm_allreduce_alive", "hnb_comm_destroy", "hnb_comm_set_library",
+    "hnb_effect_device_view", "hnb_effect_materialise",
 ]
+
+# hnb_ctx_set_option (include/hanabi_amd.h): name -> option id
+OPTIONS = {"list_order": 1, "alternate": 2, "skip_lists": 3, "age_cohort": 4, "cull_lifetime": 5, "horizon": 6, "transpose": 7, "scene_merge": 8,
+           "suffix_proof": 9}
 
 
 class HanabiError(RuntimeError):
@@ -48,6 +53,30 @@ class EffectMetadata(C.Structure):
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+
+class DeviceMeta(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("alive_count", "particle_counter", "list_column", "max_update", "dead_count", "spawned",
+                                          "indirect_write_index", "instance_count")]
+
+
+class DeviceAttr(C.Structure):
+    _fields_ = [("attr", C.c_uint16), ("ncomp", C.c_uint8), ("scalar_type", C.c_uint8), ("stride_bytes", C.c_uint16), ("reserved", C.c_uint16),
+                ("plane", C.c_void_p)]
+
+
+class DeviceView(C.Structure):
+    """HnbDeviceView: device pointers of an effect's planes, lists and metadata row (hnb_effect_device_view)."""
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("stream", C.c_void_p),
+                ("capacity", C.c_uint32), ("slot_base", C.c_uint32), ("n_attrs", C.c_uint32), ("reserved", C.c_uint32),
+                ("stale_attr_mask", C.c_uint64), ("alive_list", C.c_void_p * 2), ("dead_list", C.c_void_p),
+                ("meta", C.c_void_p), ("meta_next", C.c_void_p), ("attrs", DeviceAttr * 40)]
+
+    def plane(self, attr_id):
+        for i in range(self.n_attrs):
+            if self.attrs[i].attr == int(attr_id):
+                return self.attrs[i]
+        raise KeyError(attr_id)
 
 
 _lib = None
@@ -97,6 +126,9 @@ def load_library():
         lib.hnb_comm_create_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         lib.hnb_comm_allreduce_alive.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint64)]
         lib.hnb_comm_destroy.argtypes = [C.c_void_p]
+        lib.hnb_comm_set_library.argtypes = [C.c_char_p, C.c_uint32]
+        lib.hnb_effect_device_view.argtypes = [C.c_void_p, C.POINTER(DeviceView)]
+        lib.hnb_effect_materialise.argtypes = [C.c_void_p, C.c_uint64]
         lib.hnb_program_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         lib.hnb_jit_precompile.argtypes = [C.c_char_p, C.c_size_t]
         _lib = lib
@@ -126,6 +158,11 @@ class Context:
         self._h = C.c_void_p()
         _check(self._lib.hnb_ctx_create(device_id, C.byref(self._h)))
         self._programs = []
+        # A/B harness convenience (tools/, bench.py): HNB_CTX_OPTIONS="age_cohort=0,horizon=0" is applied to every context THIS BINDING creates.
+        # The library itself reads no environment variable for its options (include/hanabi_amd.h, hnb_ctx_set_option).
+        for kv in filter(None, os.environ.get("HNB_CTX_OPTIONS", "").split(",")):
+            k, v = kv.split("=")
+            self.set_option(k.strip(), int(v))
 
     def close(self):
         if self._h:
@@ -153,8 +190,10 @@ class Context:
         _check(self._lib.hnb_ctx_set_option(self._h, 1, {"spawn": 0, "slot": 1}[order]))
 
     def set_option(self, option, value):
-        """hnb_ctx_set_option: 2 = HNB_OPT_ALTERNATE, 3 = HNB_OPT_SKIP_LISTS (scheduling choices; results do not change)."""
-        _check(self._lib.hnb_ctx_set_option(self._h, int(option), int(value)))
+        """hnb_ctx_set_option by id or by name (OPTIONS): "age_cohort" (0 off / 1 lean stacks / 2 all; fixed in a program at creation; the one
+        option that changes device-visible state: the AGE plane), "cull_lifetime", "horizon", "alternate", "skip_lists", "transpose",
+        "scene_merge", "suffix_proof" (scheduling choices; results do not change)."""
+        _check(self._lib.hnb_ctx_set_option(self._h, OPTIONS[option] if isinstance(option, str) else int(option), int(value)))
 
     def create_program(self, blob: bytes):
         return Program(self, blob)
@@ -179,6 +218,11 @@ class Context:
         u, c, i, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint32()
         _check(self._lib.hnb_ctx_kernel_timing(self._h, C.byref(u), C.byref(c), C.byref(i), C.byref(n)))
         return {"update_ms_avg": u.value, "compact_ms_avg": c.value, "init_ms_avg": i.value, "frames": n.value}
+
+
+def comm_set_library(path, duplicate_devices=False):
+    """hnb_comm_set_library: which collective library hnb_comm_* binds; before the first Comm of the process."""
+    _check(load_library().hnb_comm_set_library(None if path is None else os.fsencode(path), 1 if duplicate_devices else 0))
 
 
 class Comm:
@@ -321,6 +365,19 @@ class Effect:
             except HanabiError as e:
                 if e.code != HNB_ERR_NOT_FOUND:   # a value for a property this effect's asset does not declare is not an error
                     raise
+
+    def device_view(self):
+        """hnb_effect_device_view: the effect's device pointers after the frames enqueued so far (no synchronisation)."""
+        v = DeviceView()
+        _check(self._lib.hnb_effect_device_view(self._h, C.byref(v)))
+        return v
+
+    def materialise(self, attr_ids):
+        """hnb_effect_materialise: make these attributes' planes current for device-side readers (enqueued on the simulation stream)."""
+        mask = 0
+        for a in attr_ids:
+            mask |= 1 << int(a)
+        _check(self._lib.hnb_effect_materialise(self._h, mask))
 
     def metadata(self):
         m = EffectMetadata()

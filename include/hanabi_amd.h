@@ -273,13 +273,31 @@ int hnb_ctx_synchronize(HnbContext* ctx);
 #define HNB_OPT_LIST_ORDER 1u
 #define HNB_LIST_ORDER_SPAWN 0u
 #define HNB_LIST_ORDER_SLOT 1u
-/* HNB_OPT_ALTERNATE (default 1; environment HNB_ALTERNATE): the update walks an effect's chunks in alternating directions from
+/* HNB_OPT_ALTERNATE (default 1): the update walks an effect's chunks in alternating directions from
  *   frame to frame, so that each frame starts on what the previous one wrote last and finds it in the 256 MiB Infinity Cache.
- * HNB_OPT_SKIP_LISTS (default 1; environment HNB_SKIP_LISTS): frames in which provably no particle can die or spawn (the update
+ * HNB_OPT_SKIP_LISTS (default 1): frames in which provably no particle can die or spawn (the update
  *   kernel publishes a lower bound of every particle's remaining life) do not launch the list kernels.
  * Both are pure scheduling choices: results are identical with either value. They apply from the next hnb_simulate on. */
 #define HNB_OPT_ALTERNATE 2u
 #define HNB_OPT_SKIP_LISTS 3u
+/* HNB_OPT_AGE_COHORT (fixed in a program when it is created; default HNB_AGE_COHORT_LEAN): a 4096-slot chunk whose alive particles share one
+ *   AGE, bit for bit - every burst effect - keeps it in one word instead of reading and writing 8 bytes per particle and frame. THE ONE OPTION
+ *   THAT CHANGES DEVICE-VISIBLE STATE: the AGE plane of such a chunk is stale until hnb_effect_materialise (or a host read, which does the
+ *   same) - see "Device-side output" below. OFF: the plane is current after every frame. LEAN: bandwidth-bound update stacks only
+ *   (drag / gravity / Euler); ALL: every eligible stack (measured slower for issue-bound stacks such as force_field.rs).
+ * HNB_OPT_CULL_LIFETIME, HNB_OPT_HORIZON (fixed at program creation; default 1), HNB_OPT_TRANSPOSE, HNB_OPT_SCENE_MERGE, HNB_OPT_SUFFIX_PROOF
+ *   (from the next hnb_simulate on; default 1): lifetime culling, row-chunk death horizons, the LDS transpose of vec3 planes, shared launches
+ *   for small programs, the ribbon "casualties are the last rows" proof. Results are identical with either value: they exist for
+ *   A/B measurements. The library reads NO environment variable for any of these. */
+#define HNB_OPT_AGE_COHORT 4u
+#define HNB_AGE_COHORT_OFF 0u
+#define HNB_AGE_COHORT_LEAN 1u
+#define HNB_AGE_COHORT_ALL 2u
+#define HNB_OPT_CULL_LIFETIME 5u
+#define HNB_OPT_HORIZON 6u
+#define HNB_OPT_TRANSPOSE 7u
+#define HNB_OPT_SCENE_MERGE 8u
+#define HNB_OPT_SUFFIX_PROOF 9u
 int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value);
 
 /* Replaces EffectShaderSources::generate + pipeline specialisation (src/lib.rs:805-1336). */
@@ -326,6 +344,57 @@ int hnb_effect_set_property(HnbEffect* fx, const char* name, const void* value, 
  * (src/render/mod.rs:6942-7613). Asynchronous. */
 int hnb_simulate(HnbContext* ctx);
 
+/* ---- Device-side output -------------------------------------------------------------------------------------------------------
+ * Where the reference's hot path ENDS: GPU-resident buffers the next stage binds directly - the particle buffer, the indirect index
+ * buffer and the effect metadata row that vfx_indirect.wgsl:57-85 turns into draw-indirect arguments (bind groups
+ * src/render/mod.rs:5152-5820; vfx_render.wgsl reads particle_buffer[indirect_buffer[instance_index * 3 + column]]). A consumer on the
+ * same GPU (a renderer through external-memory interop, a baking kernel, a physics query) gets the same three things as device pointers,
+ * without a copy and without a synchronisation:
+ *     HnbDeviceView v; hnb_effect_device_view(fx, &v);
+ *     consumer<<<.., (hipStream_t)v.stream>>>(v);    // row r < v.meta->alive_count: slot = v.alive_list[v.meta->list_column][r];
+ *                                                    //   position = ((const float*)v.attrs[i].plane) + 3 * slot   (attrs[i].attr == HNB_ATTR_POSITION)
+ * Stream-ordering contract: the view describes the effect AFTER every hnb_simulate enqueued so far. Kernels enqueued on v.stream (or on
+ * another stream behind an event recorded on v.stream) after the call and before the next hnb_simulate see exactly that state; they must
+ * have completed (or the next hnb_simulate be ordered behind them, which it is on v.stream) before the planes are written again.
+ * Lifetime of the pointers: planes and lists live as long as the effect; `meta` / `meta_next` ALTERNATE from frame to frame and move when an
+ * effect of the program is created or destroyed - fetch the view again after each hnb_simulate (a few stores, no HIP call).
+ * Attributes in stale_attr_mask (AGE under HNB_OPT_AGE_COHORT) are current only after hnb_effect_materialise(fx, mask), which is enqueued on
+ * the simulation stream like a frame; programs created with HNB_AGE_COHORT_OFF have no stale attribute (ColorOverLifetime / SizeOverLifetime
+ * read AGE and LIFETIME in the render shader, src/modifier/output.rs:310-312). Free slots hold the values their last particle died with. */
+typedef struct HnbDeviceMeta {          /* one 32-byte row per effect instance, device-resident; written by the frame's last kernel */
+    uint32_t alive_count;               /* EffectMetadata::alive_count after the frame */
+    uint32_t particle_counter;
+    uint32_t list_column;               /* which of HnbDeviceView::alive_list[2] holds the alive list (changes only in frames with casualties) */
+    uint32_t max_update;                /* rows the frame's update pass processed */
+    uint32_t dead_count, spawned;
+    uint32_t indirect_write_index;      /* EffectMetadata::indirect_write_index as the reference counts it (flips every frame) */
+    uint32_t instance_count;            /* render instance count == alive_count: a draw-indirect source (vfx_indirect.wgsl:66-75) */
+} HnbDeviceMeta;
+typedef struct HnbDeviceAttr {
+    uint16_t attr;                      /* HnbAttr */
+    uint8_t ncomp, scalar_type;         /* 1..4 components of 4 bytes; HnbScalarType */
+    uint16_t stride_bytes;              /* ncomp * 4: planes are packed (vec3 = 12 bytes per slot) */
+    uint16_t reserved;
+    void* plane;                        /* device pointer, indexed by SLOT: capacity * stride_bytes bytes */
+} HnbDeviceAttr;
+#define HNB_VIEW_MAX_ATTRS 40u
+typedef struct HnbDeviceView {
+    uint32_t struct_size;               /* sizeof(HnbDeviceView) of the library that filled it */
+    int32_t device;                     /* HIP device ordinal the pointers belong to */
+    void* stream;                       /* hipStream_t the simulation is enqueued on */
+    uint32_t capacity, slot_base, n_attrs, reserved;
+    uint64_t stale_attr_mask;           /* bit a: plane of HnbAttr a needs hnb_effect_materialise before a device-side read */
+    const uint32_t* alive_list[2];      /* both list columns: capacity slot indices each; rows [0, meta->alive_count) of column meta->list_column are the list */
+    const uint32_t* dead_list;          /* rows [meta->alive_count, capacity): the free slots, next spawn first */
+    const HnbDeviceMeta* meta;          /* this effect's row after the frames enqueued so far */
+    const HnbDeviceMeta* meta_next;     /* the row the NEXT hnb_simulate will write (the two alternate) */
+    HnbDeviceAttr attrs[HNB_VIEW_MAX_ATTRS];   /* [n_attrs], layout order */
+} HnbDeviceView;
+int hnb_effect_device_view(HnbEffect* fx, HnbDeviceView* out_view);
+/* Makes the planes of the attributes in `attr_mask` (bit a = HnbAttr a) current for device-side readers; enqueued on the simulation stream,
+ * returns at once. A no-op for attributes that are never stale. */
+int hnb_effect_materialise(HnbEffect* fx, uint64_t attr_mask);
+
 /* Readback (synchronising; reporting / parity only, never on the frame path). */
 int hnb_effect_metadata(HnbEffect* fx, HnbEffectMetadata* out);
 int hnb_effect_alive_count(HnbEffect* fx, uint32_t* out);
@@ -356,7 +425,9 @@ int hnb_jit_precompile(const void* blob, size_t blob_size);
 /* Timing helper: average device time in ms of the update kernel, of the compaction kernel that
  * follows it (event after update -> event after compact, i.e. including the launch gap) and of the
  * init kernel, over the frames simulated since the last reset (HIP events on the simulation stream). */
-int hnb_ctx_enable_kernel_timing(HnbContext* ctx, int every_n_frames); /* 0 = off; n: time every n-th hnb_simulate (events cost ~20 us of stream bubbles per timed frame) */
+int hnb_ctx_enable_kernel_timing(HnbContext* ctx, int every_n_frames); /* 0 = off; n: time every n-th hnb_simulate (events cost ~20 us of stream bubbles per timed frame).
+ * A timed frame runs one launch per program and stage: the shared launches of small programs (HNB_OPT_SCENE_MERGE) are not used in it, so the
+ * averages describe each program's own specialised kernels, not the merged interpreter launches the untimed frames of a small-effect scene run. */
 int hnb_ctx_kernel_timing(HnbContext* ctx, double* update_ms_avg, double* compact_ms_avg, double* init_ms_avg, uint32_t* frames);
 /* the same averages over the kernels of ONE program of the context (a context with several programs: parent and child effects) */
 int hnb_program_kernel_timing(HnbProgram* prog, double* update_ms_avg, double* compact_ms_avg, double* init_ms_avg, uint32_t* frames);
@@ -372,7 +443,14 @@ int hnb_ctx_profile_marker(HnbContext* ctx, uint32_t tag);
  * the alive-particle counters, over RCCL (xGMI). librccl is resolved at run time: a single-GPU host does not need it. */
 typedef struct HnbComm HnbComm;
 #define HNB_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
-/* one process, n contexts (ncclCommInitAll over their devices; contexts that share a device are reduced through the host) */
+/* Which collective library hnb_comm_* binds (dlopen). Default (never called, or path NULL): librccl by name. Must precede the first
+ * hnb_comm_* call of the process that needs the library; afterwards it fails. HNB_COMM_LIB_DUPLICATE_DEVICES: the library accepts a
+ * communicator that names one device twice (real RCCL does not) - for stand-ins such as tests/fake_rccl, which let the collective
+ * branch run with two contexts on a one-GPU box. */
+#define HNB_COMM_LIB_DUPLICATE_DEVICES 1u
+int hnb_comm_set_library(const char* path, uint32_t flags);
+/* one process, n contexts (ncclCommInitAll over their devices; contexts that share a device are reduced through the host).
+ * A communicator holds its contexts: destroy it before them (hnb_ctx_destroy refuses otherwise). */
 int hnb_comm_create_local(HnbContext* const* ctxs, uint32_t n_ctx, HnbComm** out_comm);
 /* one rank per process: rank 0 calls hnb_comm_unique_id and hands the 128 bytes to the others (ncclCommInitRank) */
 int hnb_comm_unique_id(void* out_id);

@@ -29,6 +29,20 @@ def pytest_configure(config):
     deps = [src] + [os.path.join(ROOT, "bevy_hanabi_amd", "csrc", f) for f in ("hnb_vm.h", "hnb_math.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas", src, "-o", so])
+    # tests/fake_rccl: the stand-in collective library (built here, where the RCCL header is; the .so travels to the GPU box)
+    fr_dir = os.path.join(ROOT, "tests", "fake_rccl")
+    fr_so, fr_src = os.path.join(fr_dir, "libfake_rccl.so"), os.path.join(fr_dir, "fake_rccl.cpp")
+    if os.path.exists("/opt/rocm/include/rccl/rccl.h") and (not os.path.exists(fr_so) or os.path.getmtime(fr_src) > os.path.getmtime(fr_so)):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", fr_src, "-o", fr_so,
+                               "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+
+
+    # tests/device_view: the HIP consumer kernel of the device-side output boundary
+    dv_dir = os.path.join(ROOT, "tests", "device_view")
+    dv_so, dv_src = os.path.join(dv_dir, "libconsumer.so"), os.path.join(dv_dir, "consumer.hip")
+    hdr = os.path.join(ROOT, "include", "hanabi_amd.h")
+    if (os.path.exists(hipcc) or shutil.which("hipcc")) and (not os.path.exists(dv_so) or max(os.path.getmtime(dv_src), os.path.getmtime(hdr)) > os.path.getmtime(dv_so)):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), dv_src, "-o", dv_so])
 
 
 def _has_gpu():

@@ -1,0 +1,112 @@
+"""The device-side output boundary: hnb_effect_device_view / hnb_effect_materialise. A HIP consumer kernel
+(tests/device_view/consumer.hip, written against include/hanabi_amd.h alone) gathers an attribute by alive-list ROW through the view
+- counters, list column and planes all read on the device, enqueued on the view's stream while frames keep being enqueued - and must
+see what hnb_effect_read_attr[hnb_effect_read_alive_list] gives the host, with age cohorts on (materialise) and off."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bevy_hanabi_amd as bh
+from bevy_hanabi_amd import effects, runtime
+from helpers import A, frame_seed
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_view_struct_matches_the_header_without_a_gpu():
+    """The ctypes mirror and the C struct agree on size and on the offsets a consumer relies on (checked by compiling the header)."""
+    import subprocess
+    import tempfile
+    src = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "hanabi_amd.h"
+    int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(HnbDeviceView), offsetof(HnbDeviceView, stale_attr_mask), offsetof(HnbDeviceView, alive_list),
+                            offsetof(HnbDeviceView, meta), offsetof(HnbDeviceView, attrs), sizeof(HnbDeviceAttr), sizeof(HnbDeviceMeta)); return 0; }
+    '''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        got = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
+    V = runtime.DeviceView
+    assert got == [C.sizeof(V), V.stale_attr_mask.offset, V.alive_list.offset, V.meta.offset, V.attrs.offset, C.sizeof(runtime.DeviceAttr), C.sizeof(runtime.DeviceMeta)]
+    lib = runtime.load_library()
+    assert lib.hnb_effect_device_view(None, None) == -1 and lib.hnb_effect_materialise(None, 0) == -1
+
+
+def _consumer():
+    lib = C.CDLL(os.path.join(ROOT, "tests", "device_view", "libconsumer.so"))
+    lib.consumer_gather.argtypes = [C.POINTER(runtime.DeviceView), C.c_uint32, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def _gather(cons, fx, attr, ncomp, cap):
+    """-> (rows gathered on the device, instance_count the device saw); nothing here waits before the gather is enqueued"""
+    out = torch.zeros(cap * ncomp, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()                      # (the two allocations above; the simulation stream is not torch's)
+    v = fx.device_view()
+    assert cons.consumer_gather(C.byref(v), int(attr), out.data_ptr(), cnt.data_ptr()) == 0
+    return v, out, cnt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cohort", [1, 0])
+def test_consumer_kernel_reads_what_the_host_reads(cohort):
+    cons = _consumer()
+    cap = 50_000
+    ctx = bh.Context(0)
+    ctx.set_option("age_cohort", cohort)
+    fx = ctx.create_program(bh.lower(effects.firework_trails(cap))).create_effect()
+    v0 = fx.device_view()
+    assert v0.struct_size == C.sizeof(runtime.DeviceView) and v0.capacity == cap and v0.n_attrs == 5 and v0.device == 0
+    assert v0.stale_attr_mask == ((1 << A.AGE.id) if cohort else 0)
+    checked_partial = False
+    for f in range(75):
+        ctx.frame_begin(1 / 60, f / 60)
+        fx.set_frame(cap if f == 0 else 0, frame_seed(f))
+        ctx.simulate()
+        if f not in (0, 3, 50, 55, 60, 66):
+            continue
+        # enqueue the consumer BEHIND the frame, before anything synchronises
+        fx.materialise([A.AGE.id])
+        v, pos, cnt = _gather(cons, fx, A.POSITION.id, 3, cap)
+        _, age, _ = _gather(cons, fx, A.AGE.id, 1, cap)
+        _, col, _ = _gather(cons, fx, A.COLOR.id, 1, cap)
+        assert (v.meta, v.meta_next) != (v0.meta, v0.meta_next) or f % 2 == 1   # the rows alternate from frame to frame
+        ctx.synchronize()
+        n = fx.alive_count()
+        alive = fx.alive_list()
+        assert int(cnt.item()) == n == len(alive)
+        for name, got, attr, nc in (("position", pos, A.POSITION, 3), ("age", age, A.AGE, 1), ("color", col, A.COLOR, 1)):
+            ref = fx.read_attr(attr.id).view(np.uint32)[alive]
+            np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32)[: n * nc].reshape(n, nc), ref, err_msg=f"{name} frame {f}")
+        checked_partial = checked_partial or 0 < n < cap
+    assert checked_partial, "the die-off (partially alive list, second list column) was not covered"
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_age_plane_is_stale_without_materialise_and_current_with_it():
+    """What stale_attr_mask promises: with cohorts the AGE plane of a burst is NOT what the particles' ages are until materialise runs."""
+    cons = _consumer()
+    cap = 20_000
+    ctx = bh.Context(0)
+    fx = ctx.create_program(bh.lower(effects.firework_trails(cap))).create_effect()
+    for f in range(10):
+        ctx.frame_begin(1 / 60, f / 60)
+        fx.set_frame(cap if f == 0 else 0, frame_seed(f))
+        ctx.simulate()
+    _, stale, _ = _gather(cons, fx, A.AGE.id, 1, cap)
+    fx.materialise([A.AGE.id])
+    _, fresh, _ = _gather(cons, fx, A.AGE.id, 1, cap)
+    ctx.synchronize()
+    ref = fx.read_attr(A.AGE.id).view(np.uint32)[fx.alive_list()].reshape(-1)
+    np.testing.assert_array_equal(fresh.cpu().numpy().view(np.uint32)[: len(ref)], ref)
+    assert not np.array_equal(stale.cpu().numpy().view(np.uint32)[: len(ref)], ref)
+    with pytest.raises(bh.HanabiError):
+        fx.materialise([A.SIZE.id])                 # not in the layout
+    ctx.close()

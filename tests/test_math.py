@@ -103,3 +103,24 @@ def test_binary64_kernels_before_the_final_rounding():
         ok = np.isfinite(want) & (want != 0)
         rel = np.abs(got[ok] - want[ok]) / np.abs(want[ok])
         assert rel.max() < 2.0 ** -45, (fn, float(rel.max()), float(xs[ok][rel.argmax()]))
+
+
+def test_normalize_reciprocal_domain():
+    """normalize(v) = v * (1 / length(v)) (hnb_math.h): ADVICE r03 asked whether 1 / length can overflow for a tiny vector where
+    v / length would have been finite. It cannot: the squared length is an f32 - zero, or at least 2^-149 - so a non-zero length is at
+    least 2^-74.5 and its reciprocal at most 2^74.5. Checked on the extreme vectors with the same f32 operations the kernels use."""
+    f = np.float32
+    tiny = [f(2.0) ** f(e) for e in (-149, -140, -126, -100, -75, -74, -70, -64)]
+    with np.errstate(all="ignore"):
+        for t in tiny:
+            for v in (np.array([t, 0, 0], f), np.array([t, t, t], f), np.array([t, -t, f(0.5) * t], f)):
+                d = f(f(v[0] * v[0]) + f(v[1] * v[1])) + f(v[2] * v[2])
+                ln = np.sqrt(f(d))
+                if d == 0:      # the squares underflowed: the division form is non-finite as well
+                    assert not np.isfinite(v / ln).all() and not np.isfinite(v * (f(1) / ln)).all()
+                    continue
+                inv = f(1) / ln
+                assert np.isfinite(inv) and inv <= f(2.0) ** f(75)
+                n = v * inv
+                assert np.isfinite(n).all() and abs(float(np.sqrt((n.astype(np.float64) ** 2).sum())) - 1.0) < 0.3   # (subnormal squares lose bits; unit-ish)
+                assert np.abs(n - v / ln).max() <= 2 * np.spacing(np.abs(n).max())

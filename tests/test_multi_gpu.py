@@ -20,14 +20,33 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_comm_symbols_and_failure_modes_without_a_gpu():
     lib = runtime.load_library()
-    for s in ("hnb_comm_create_local", "hnb_comm_unique_id", "hnb_comm_create_rank", "hnb_comm_allreduce_alive", "hnb_comm_destroy"):
+    for s in ("hnb_comm_create_local", "hnb_comm_unique_id", "hnb_comm_create_rank", "hnb_comm_allreduce_alive", "hnb_comm_destroy", "hnb_comm_set_library"):
         assert hasattr(lib, s)
     import ctypes as C
     h = C.c_void_p()
     assert lib.hnb_comm_create_local(None, 0, C.byref(h)) == -1        # HNB_ERR_INVALID_ARG
     assert lib.hnb_comm_allreduce_alive(None, None, 0, None) == -1
     assert lib.hnb_comm_destroy(None) == 0
+    assert lib.hnb_comm_set_library(None, 0x80) == -1                   # unknown flag
+    assert os.path.exists(os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so"))   # (built by conftest where rccl.h is)
     assert os.path.exists(hb.build_examples())                          # the C99 driver builds against the public header alone
+
+
+@pytest.mark.gpu
+def test_collective_branch_runs_through_a_stand_in_library():
+    """the RCCL branch of hnb_comm_* (CommInitAll, grouped AllReduce on the contexts' streams, read-back) had
+    never executed. tests/fake_rccl is a host-memory stand-in with RCCL's signatures (it includes rccl.h) that accepts one device twice,
+    selected with hnb_comm_set_library: the branch runs on the one-GPU box, two contexts, two effects each."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fake_rccl", "run_fake_comm.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    (a0, b0), (a1, b1) = out["local"]
+    assert out["totals"] == [a0 + a1, b0 + b1] and 0 < a0 < 30000 and 0 < a1 < 12345
+    assert out["totals2"] == [a0, b1]
+    assert out["calls"] == [1, 4, 2, 2], out["calls"]   # one CommInitAll, 2 x 2 AllReduce calls, two completed group reductions, two CommDestroy
+    assert out["late"] and "already loaded" in out["late"]
+    assert out["ctx_destroy_while_held"] == -1
 
 
 @pytest.mark.gpu

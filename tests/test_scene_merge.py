@@ -22,15 +22,8 @@ class SceneRunner:
     """All entries in one context, one simulate() per frame."""
 
     def __init__(self, entries, merge):
-        old = os.environ.get("HNB_SCENE_MERGE")
-        os.environ["HNB_SCENE_MERGE"] = "1" if merge else "0"
-        try:
-            self.ctx = bh.Context(0)
-        finally:
-            if old is None:
-                os.environ.pop("HNB_SCENE_MERGE", None)
-            else:
-                os.environ["HNB_SCENE_MERGE"] = old
+        self.ctx = bh.Context(0)
+        self.ctx.set_option("scene_merge", 1 if merge else 0)
         self.runners = [GpuRunner(e.asset, ctx=self.ctx) for e in entries]
 
     def step(self, frames):

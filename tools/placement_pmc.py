@@ -3,7 +3,7 @@ each walked 12 frames in one direction and 12 frames in alternating directions. 
 `rocprofv3 --kernel-trace --pmc <counters>`; tools/placement_pmc_report.py turns the counter CSVs into a table."""
 import os, sys
 os.environ["HNB_SLAB_CANDIDATES"] = "1"
-os.environ["HNB_SKIP_LISTS"] = "0"
+os.environ["HNB_CTX_OPTIONS"] = "skip_lists=0"   # (read by the Python binding, not by the library)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bevy_hanabi_amd as bh
 from bevy_hanabi_amd import effects
