@@ -1066,7 +1066,7 @@ def main():
         out["build"] = {"head": git_head(), "kernel_source_stamp": stamp}
         extra = {k: v for k, v in results.items() if k != args.config}
         if extra:
-            out["configs"] = {k: (v if "error" in v else {kk: v[kk] for kk in ("value", "ms_per_step", "windows", "stages", "roofline", "init", "kernels") if kk in v}
+            out["configs"] = {k: (v if "error" in v else {kk: v[kk] for kk in ("value", "ms_per_step", "windows", "stages", "roofline", "init", "kernels", "parity") if kk in v}
                                   | {"workload": v["config"]["workload"], "updates_per_frame": v["config"]["updates_per_frame"], "spawns_per_frame": v["config"]["spawns_per_frame"]})
                               for k, v in extra.items()}
     if not D.on and args.scene and args.config == "c2" and not args.no_extra_configs and not args.pmc_child:

@@ -184,6 +184,7 @@ struct HnbProgram {
     unsigned long long* h_ev_counts = nullptr;  // host-mapped [table_cap][HNB_MAX_EVENT_CHANNELS] {frame, event count} written by k_emit_events (emitting programs)
     uint32_t level = 0;                   // dependency level: parents are simulated before their children
     uint32_t* d_counts = nullptr;  // per chunk: survivors this frame
+    uint32_t* d_gsums = nullptr;   // per group of kCountGroup chunks: their sum (CompactBufs::gsums)
     uint32_t* d_deaths = nullptr;  // [2][table_cap]: casualties per instance, frame-parity double-buffered
     // per-frame parameter blocks: a ring, so that filling frame f+1..f+3 never waits for the GPU
     bool lists_now = true;               // this frame needs k_count_rows / k_compact (false: the update rotated the counters itself)
@@ -618,6 +619,7 @@ void free_tables(HnbProgram* p) {
     hipFree(p->d_inst_base); p->d_inst_base = nullptr;
     for (int i = 0; i < 2; ++i) { hipFree(p->d_meta[i]); p->d_meta[i] = nullptr; }
     hipFree(p->d_counts); p->d_counts = nullptr;
+    hipFree(p->d_gsums); p->d_gsums = nullptr;
     hipFree(p->d_deaths); p->d_deaths = nullptr;
     hipFree(p->d_ev_totals); p->d_ev_totals = nullptr;
     if (p->h_ev_counts) hipHostFree(p->h_ev_counts);
@@ -649,6 +651,10 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
     const size_t n_counts = (size_t)cap * p->dev.chunks_per_inst;
     HIP_TRY(hipMalloc(&ns, n_counts * 4));
     HIP_TRY(hipMemset(ns, 0, n_counts * 4));
+    uint32_t* ng = nullptr;
+    const size_t n_groups = (size_t)cap * ((p->dev.chunks_per_inst + kCountGroup - 1u) / kCountGroup);
+    HIP_TRY(hipMalloc(&ng, n_groups * 4));
+    HIP_TRY(hipMemset(ng, 0, n_groups * 4));
     // casualty counters are zero between frames (k_compact re-arms them), so a fresh table is valid
     HIP_TRY(hipMalloc(&nd, (size_t)2 * cap * 4));
     HIP_TRY(hipMemset(nd, 0, (size_t)2 * cap * 4));
@@ -661,6 +667,7 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
     hipFree(p->d_meta[0]);
     hipFree(p->d_meta[1]);
     hipFree(p->d_counts);
+    hipFree(p->d_gsums);
     hipFree(p->d_deaths);
     if (p->dev.n_event_channels) {
         hipFree(p->d_ev_totals);
@@ -676,6 +683,7 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
     p->d_meta[0] = nm[0];
     p->d_meta[1] = nm[1];
     p->d_counts = ns;
+    p->d_gsums = ng;
     p->d_deaths = nd;
     {   // no-death bounds per chunk and frame parity: start at +inf; growing the tables restarts them (effect creation marks the program dirty)
         hipFree(p->d_safe);
@@ -1337,6 +1345,8 @@ static CompactBufs compact_bufs_of(const HnbContext* ctx, const HnbProgram* p, u
     cb.table_cap = p->table_cap;
     cb.parity = p->parity;
     cb.ev_totals = p->d_ev_totals;
+    cb.gsums = p->d_gsums;
+    cb.groups_per_inst = (p->dev.chunks_per_inst + kCountGroup - 1u) / kCountGroup;
     cb.xcd_remap = (n > 1 ? 1u : 0u) | (ctx->alternate && !(p->frames_run & 1u) ? 2u : 0u);  // see chunk_of_workgroup; the first frame walks DOWN: a burst's init wrote the planes upwards
     return cb;
 }

@@ -501,7 +501,14 @@ struct CompactBufs {
     uint32_t parity;
     uint32_t* ev_totals;  // [n_inst * chunks_per_inst][HNB_MAX_EVENT_CHANNELS] spawn events per chunk (emitting programs)
     uint32_t xcd_remap;   // workgroup -> chunk mapping (chunk_of_workgroup): bit 0 XCD-aware (batches of instances), bit 1 descending order (every other frame)
+    // Two-level survivor prefix (k_compact): gsums[k * groups_per_inst + g] = survivors of the chunks [64 g, 64 g + 64) of instance k this frame.
+    // Zeroed by the frame's update kernel (its workgroup of the group's first chunk; write_died says that list kernels follow), accumulated by
+    // k_count_rows with one fire-and-forget atomic per chunk, read by k_compact: a workgroup then takes <= 64 group sums + <= 63 chunk counts -
+    // 508 bytes in one round of loads - instead of every earlier chunk's count (8 KB on average for a 16.7M-row list, several dependent rounds).
+    uint32_t* gsums;
+    uint32_t groups_per_inst;
 };
+constexpr uint32_t kCountGroup = 64u;   // chunks per group sum
 
 // Workgroup -> chunk. The hardware deals workgroups to the 8 XCDs round-robin (workgroup b runs on XCD b mod 8,
 // each XCD with its own L2). In a batch of instances, mapping b straight to chunk b pins chunk j of EVERY instance
@@ -631,8 +638,12 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
         excl = c.start <= first_dead ? c.start : (c.start < alive0 ? first_dead : c.start - total_dead);
         if (total_dead > alive0 && tid == 0u && args.fault) *args.fault = 1u;
     } else if (total_dead != 0u) {
+        // (c.j <= 4096 * 64 chunks: one load per lane covers the group sums, one the chunk counts of the own group)
         uint32_t part = 0;
-        for (uint32_t i = tid; i < c.j; i += kBlock) part += cnt[i];
+        const uint32_t g = c.j / kCountGroup;
+        const uint32_t* gs = cb.gsums + (size_t)c.k * cb.groups_per_inst;
+        for (uint32_t i = tid; i < g; i += kBlock) part += gs[i];
+        for (uint32_t i = g * kCountGroup + tid; i < c.j; i += kBlock) part += cnt[i];
 #pragma unroll
         for (uint32_t off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
         if (lane == 0) s_red[wave] = part;
@@ -1048,6 +1059,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         args.meta_out[k] = o;
         cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + k] = 0u;
     }
+    if (args.write_died && (j % kCountGroup) == 0u && tid == 0u) cb.gsums[(size_t)k * cb.groups_per_inst + j / kCountGroup] = 0u;   // k_count_rows accumulates into it (CompactBufs)
     if (fi[k].skip) return;  // frozen instance
     char* base = global_ptr<char>(inst_base[k]);
     VmUniforms U;
@@ -1367,6 +1379,7 @@ __device__ __forceinline__ void update_generic_chunk(const DevProgram& prog, con
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     const uint32_t k = chunk / prog.chunks_per_inst, j = chunk - k * prog.chunks_per_inst;
+    if (write_died && (j % kCountGroup) == 0u && sub_begin == 0u && tid == 0u) cb.gsums[(size_t)k * cb.groups_per_inst + j / kCountGroup] = 0u;   // k_count_rows accumulates into it (CompactBufs)
     if (fi[k].skip) return;
     char* base = global_ptr<char>(inst_base[k]);
     uint8_t* flags = reinterpret_cast<uint8_t*>(base + prog.alive_flag_off);
@@ -1472,7 +1485,7 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
                 const unsigned long long m = rows_ >= (tid + 1u) * 64u ? ~0ull : (rows_ > tid * 64u ? ((1ull << (rows_ - tid * 64u)) - 1ull) : 0ull);
                 (reinterpret_cast<unsigned long long*>(c.base + args.row_mask_off) + (size_t)c.j * (kChunk / 64u))[tid] = m;
             }
-            if (tid == 0u) cb.counts[chunk] = rows_;
+            if (tid == 0u) { cb.counts[chunk] = rows_; atomicAdd(&cb.gsums[(size_t)c.k * cb.groups_per_inst + c.j / kCountGroup], rows_); }
             return;
         }
     }
@@ -1505,6 +1518,7 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
 #pragma unroll
         for (uint32_t w = 0; w < kBlock / 64; ++w) t += s_wave[w];
         cb.counts[chunk] = t;
+        atomicAdd(&cb.gsums[(size_t)c.k * cb.groups_per_inst + c.j / kCountGroup], t);   // (result unused: a fire-and-forget atomic)
     }
 }
 __global__ void __launch_bounds__(kBlock)

@@ -8,12 +8,12 @@
 //   * f32 + - * / sqrt, comparisons, floor/ceil/trunc/roundEven: IEEE-754 binary32,
 //     one rounding per source-level operation (everything is built with
 //     -ffp-contract=off and correctly rounded f32 divide/sqrt).
-//   * transcendental functions: evaluated in binary64 with only + - * / fma and bit
-//     manipulation (no libm, no hardware approximations), then rounded once to
-//     binary32. Error before the final rounding is < 2^-45 relative, i.e. the result
-//     is the correctly rounded f32 value except in rare near-ties (about one argument
-//     in a million: within 1 ulp of libm always, tests/test_math.py).
-//     Trigonometric arguments with |x| > 2^40 are defined as x = 0 (sin 0, cos 1).
+//   * transcendental functions (hanabi-math v3): binary32 kernels built from + - * / sqrt
+//     and fused multiply-adds only (no libm, no hardware approximations), <= 2 ulp of the
+//     correctly rounded result for sin cos asin acos atan atan2 exp exp2 log log2, <= 4 ulp
+//     for tan, <= 8 ulp for pow - measured over ALL binary32 arguments (tools/math_sweep.c;
+//     the contract of the path is 1e-5 relative). Trigonometric arguments with
+//     |x| > 65536 take a binary64 reduction; |x| > 2^40 are defined as x = 0 (sin 0, cos 1).
 //   * normalize(v) = v * (1 / length(v)): one IEEE division and three multiplications
 //     (WGSL leaves the accuracy of normalize to the implementation: "inherited from
 //     v / length(v)", whose own division may be 2.5 ulp off). Domain: the reciprocal never
@@ -76,25 +76,21 @@ HNB_HD float f_smoothstep(float lo, float hi, float x) {
 HNB_HD float f_rem(float x, float y) { return x - y * f_trunc(x / y); }
 HNB_HD float f_inv_sqrt(float x) { return 1.0f / f_sqrt(x); }
 
-// ---- binary64 kernels ------------------------------------------------------------
-// Every step is ONE correctly rounded IEEE-754 binary64 operation - + - * / or a fused multiply-add (v_fma_f64 on gfx950, vfmadd
-// or the C library's exact fma() on the host: the same result everywhere, which -ffp-contract=off alone cannot promise for an
-// a * b + c the compiler is free to fuse or not) - on minimax polynomials (tools/gen_math_coeffs.py derives the coefficients and
-// prints their error; tools/gen_math_kernels.py writes this section): approximation errors are below 2^-47 relative, far inside
-// the final rounding to binary32. Branch-free where both sides of a branch would run in a wave anyway.
+// ---- transcendental builtins ---------------------------------------------------------
+// hanabi-math v3. The contract of the path is 1e-5 relative on positions and velocities (BASELINE.json north_star), not the last bit
+// of libm: every builtin is a binary32 kernel whose every step is ONE correctly rounded IEEE-754 binary32 operation - + - * / sqrt or
+// a fused multiply-add (v_fma_f32 on gfx950; vfmadd or the C library's exact fmaf() on the host: the same result everywhere, which
+// -ffp-contract=off alone cannot promise for an a * b + c the compiler is free to fuse or not) - on polynomials whose coefficients
+// tools/gen_math_coeffs.py derives and tools/gen_math_kernels.py writes into both copies of this section. Accuracy against the
+// host's binary64 libm over ALL binary32 arguments (tools/math_sweep.c, profiles/r04_math_sweep.txt): sin cos asin atan atan2 <= 2 ulp,
+// exp exp2 log log2 acos <= 1 ulp, tan <= 4 ulp, pow <= 8 ulp (<= 2 ulp for |y log2 x| <= 32). (Rounds 1-3 evaluated the same
+// functions in binary64 and rounded once: <= 1 ulp, at half rate on this part - v_fma_f64 - and 3-4x the instructions: the burst
+// inits of sphere- and cone-shaped spawns were bound by it.)
+//
+// The one binary64 piece left: sin / cos / tan of |x| > 65536, where a three-term binary32 Cody-Waite reduction runs out of bits.
+// Such arguments take a (divergent, rarely entered) branch to the round-3 kernel: x - k pi/2 in binary64, minimax polynomials,
+// one rounding to binary32; |x| > 2^40 is defined as x = 0 (sin 0, cos 1), NaN / inf -> NaN.
 HNB_HD double d_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-// p * z + c with a LITERAL c: the same fma. On the device it is spelled out so that the coefficient travels in an SGPR pair
-// (v_fma_f64 v, v, v, s): the compiler's own choice, v_fmac_f64, first moves every coefficient into the destination VGPR pair -
-// two more VALU instructions per Horner step, a third of the VALU work of a sphere-shaped spawn.
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ double d_fma_c(double p, double z, double c) {
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(c));
-    return r;
-}
-#else
-HNB_HD double d_fma_c(double p, double z, double c) { return __builtin_fma(p, z, c); }
-#endif
 // Round to nearest integer (ties to even) with two IEEE additions; valid |x| < 2^51. *low32: that integer modulo 2^32 (the low
 // mantissa bits of the biased sum), without a float -> int conversion.
 HNB_HD double d_rint_bits(double x, uint32_t* low32) {
@@ -103,8 +99,6 @@ HNB_HD double d_rint_bits(double x, uint32_t* low32) {
     *low32 = (uint32_t)d2u(t);
     return t - magic;
 }
-HNB_HD double d_rint(double x) { uint32_t lo; return d_rint_bits(x, &lo); }
-
 // sin and cos of a finite double with |x| <= 2^40.
 HNB_HD void d_sincos(double x, double* s_out, double* c_out) {
     const double two_over_pi = 0x1.45f306dc9c883p-1;
@@ -119,293 +113,273 @@ HNB_HD void d_sincos(double x, double* s_out, double* c_out) {
     const double z = r * r;
     // |r| <= pi/4 (+ slack): sin r = r + r z S(z) (relative error 2^-55), cos r = 1 - z/2 + z^2 C(z) (2^-49)
     double ps = 0x1.5e0ae6796256cp-33;
-    ps = d_fma_c(ps, z, -0x1.ae600a73bc9bcp-26);
-    ps = d_fma_c(ps, z, 0x1.71de379600d7fp-19);
-    ps = d_fma_c(ps, z, -0x1.a01a019e83411p-13);
-    ps = d_fma_c(ps, z, 0x1.1111111110bb1p-7);
-    ps = d_fma_c(ps, z, -0x1.5555555555555p-3);
+    ps = d_fma(ps, z, -0x1.ae600a73bc9bcp-26);
+    ps = d_fma(ps, z, 0x1.71de379600d7fp-19);
+    ps = d_fma(ps, z, -0x1.a01a019e83411p-13);
+    ps = d_fma(ps, z, 0x1.1111111110bb1p-7);
+    ps = d_fma(ps, z, -0x1.5555555555555p-3);
     const double sn = d_fma(r * z, ps, r);
     double pc = 0x1.1c819b161a46fp-29;
-    pc = d_fma_c(pc, z, -0x1.27e25ef4d05dfp-22);
-    pc = d_fma_c(pc, z, 0x1.a019ff5333bf2p-16);
-    pc = d_fma_c(pc, z, -0x1.6c16c16b61208p-10);
-    pc = d_fma_c(pc, z, 0x1.5555555555436p-5);
+    pc = d_fma(pc, z, -0x1.27e25ef4d05dfp-22);
+    pc = d_fma(pc, z, 0x1.a019ff5333bf2p-16);
+    pc = d_fma(pc, z, -0x1.6c16c16b61208p-10);
+    pc = d_fma(pc, z, 0x1.5555555555436p-5);
     const double cs = d_fma(z * z, pc, d_fma(-0.5, z, 1.0));
     // quadrant q mod 4: (sin, cos) = (sn, cs), (cs, -sn), (-sn, -cs), (-cs, sn)
     const double a = (q & 1u) ? cs : sn, b = (q & 1u) ? sn : cs;
     *s_out = (q & 2u) ? -a : a;
     *c_out = (((q + 1u) & 2u) != 0u) ? -b : b;
 }
-
-// 2^k for integer k in [-1022, 1023]
-HNB_HD double d_pow2i(int32_t k) { return u2d((uint64_t)(uint32_t)(k + 1023) << 52); }
-
-// exp(x) for finite x; caller clamps to [-120, 100]
-HNB_HD double d_exp(double x) {
-    const double log2e = 0x1.71547652b82fep+0;
-    const double ln2_hi = 6.93147180369123816490e-01;
-    const double ln2_lo = 1.90821492927058770002e-10;
-    uint32_t ki;
-    const double k = d_rint_bits(x * log2e, &ki);
-    double r = d_fma(-k, ln2_hi, x);
-    r = d_fma(-k, ln2_lo, r);
-    // |r| <= ln2 / 2: exp r = 1 + r + r^2 E(r), relative error 2^-49
-    double p = 0x1.2880501c9131ap-22;
-    p = d_fma_c(p, r, 0x1.72c7432675d87p-19);
-    p = d_fma_c(p, r, 0x1.a019c99a94203p-16);
-    p = d_fma_c(p, r, 0x1.a019ad9325b18p-13);
-    p = d_fma_c(p, r, 0x1.6c16c173921fdp-10);
-    p = d_fma_c(p, r, 0x1.1111111c4acecp-7);
-    p = d_fma_c(p, r, 0x1.5555555554cb3p-5);
-    p = d_fma_c(p, r, 0x1.5555555553b6ep-3);
-    p = d_fma_c(p, r, 0x1.0000000000000p-1);
-    const double t = d_fma(r * r, p, r);
-    return (1.0 + t) * d_pow2i((int32_t)ki);
+// which: 0 sin, 1 cos, 2 tan of a binary32 with |x| > 65536 (or NaN)
+HNB_HD float f_trig_big(float x, int which) {
+    const bool finite = f_abs(x) <= 3.4028234663852886e38f, in_range = f_abs(x) <= 1099511627776.0f;  // 2^40
+    double s, c; d_sincos(in_range ? (double)x : 0.0, &s, &c);
+    const float r = which == 0 ? (float)s : (which == 1 ? (float)c : (float)(s / c));
+    return finite ? r : x - x;  // NaN / inf -> NaN
 }
 
-// natural log of a finite, strictly positive, normal double: x = 2^k z with z in [0.6875, 1.375); the 64 intervals of z (top six
-// fraction bits) each have a centre c with 1/c and log c tabulated, so log x = k ln2 + log c + log1p(r), r = z / c - 1 (one fma),
-// |r| <= 2^-6, log1p r = r - r^2/2 + r^3 L(r) with relative error 2^-48. The two intervals that meet at z = 1 use c = 1: x near 1
-// keeps its relative accuracy (log x = log1p(x - 1), x - 1 exact).
-HNB_TABLE double kLogTab[64][2] = {   // {1/c, log c}
-    {0x1.724287f46debcp+0, -0x1.79e26687cfb3dp-2},
-    {0x1.6e1f76b4337c7p+0, -0x1.6e60ee6af1973p-2},
-    {0x1.6a13cd1537290p+0, -0x1.630030b3aac48p-2},
-    {0x1.661ec6a5122f9p+0, -0x1.57bf753c8d1fbp-2},
-    {0x1.623fa77016240p+0, -0x1.4c9e09e172c3dp-2},
-    {0x1.5e75bb8d015e7p+0, -0x1.419b423d5e8c6p-2},
-    {0x1.5ac056b015ac0p+0, -0x1.36b6776be1116p-2},
-    {0x1.571ed3c506b3ap+0, -0x1.2bef07cdc9355p-2},
-    {0x1.5390948f40febp+0, -0x1.214456d0eb8d5p-2},
-    {0x1.5015015015015p+0, -0x1.16b5ccbacfb73p-2},
-    {0x1.4cab88725af6ep+0, -0x1.0c42d676162e2p-2},
-    {0x1.49539e3b2d067p+0, -0x1.01eae5626c691p-2},
-    {0x1.460cbc7f5cf9ap+0, -0x1.ef5ade4dcffe5p-3},
-    {0x1.42d6625d51f87p+0, -0x1.db13db0d48941p-3},
-    {0x1.3fb013fb013fbp+0, -0x1.c6ffbc6f00f71p-3},
-    {0x1.3c995a47babe7p+0, -0x1.b31d8575bce3bp-3},
-    {0x1.3991c2c187f63p+0, -0x1.9f6c407089663p-3},
-    {0x1.3698df3de0748p+0, -0x1.8beafeb38fe8fp-3},
-    {0x1.33ae45b57bcb2p+0, -0x1.7898d85444c74p-3},
-    {0x1.30d190130d190p+0, -0x1.6574ebe8c1339p-3},
-    {0x1.2e025c04b8097p+0, -0x1.527e5e4a1b58dp-3},
-    {0x1.2b404ad012b40p+0, -0x1.3fb45a59928cap-3},
-    {0x1.288b01288b013p+0, -0x1.2d1610c86813dp-3},
-    {0x1.25e22708092f1p+0, -0x1.1aa2b7e23f729p-3},
-    {0x1.23456789abcdfp+0, -0x1.08598b59e3a07p-3},
-    {0x1.20b470c67c0d9p+0, -0x1.ec739830a1126p-4},
-    {0x1.1e2ef3b3fb874p+0, -0x1.c885801bc4b20p-4},
-    {0x1.1bb4a4046ed29p+0, -0x1.a4e7640b1bc38p-4},
-    {0x1.19453808ca29cp+0, -0x1.8197e2f40e3f0p-4},
-    {0x1.16e0689427379p+0, -0x1.5e95a4d9791cdp-4},
-    {0x1.1485f0e0acd3bp+0, -0x1.3bdf5a7d1ee5ep-4},
-    {0x1.12358e75d3033p+0, -0x1.1973bd1465561p-4},
-    {0x1.0fef010fef011p+0, -0x1.eea31c006b87cp-5},
-    {0x1.0db20a88f4696p+0, -0x1.aaef2d0fb1108p-5},
-    {0x1.0b7e6ec259dc8p+0, -0x1.67c94f2d4bb65p-5},
-    {0x1.0953f39010954p+0, -0x1.252f32f8d1840p-5},
-    {0x1.073260a47f7c6p+0, -0x1.c63d2ec14aad7p-6},
-    {0x1.05197f7d73404p+0, -0x1.432a925980cbcp-6},
-    {0x1.03091b51f5e1ap+0, -0x1.82448a388a283p-7},
-    {0x1.0000000000000p+0, 0x0.0p+0},
-    {0x1.0000000000000p+0, 0x0.0p+0},
-    {0x1.f44659e4a4271p-1, 0x1.7b91b07d5b126p-6},
-    {0x1.ecc07b301ecc0p-1, 0x1.39e87b9febd68p-5},
-    {0x1.e573ac901e574p-1, 0x1.b42dd711971b9p-5},
-    {0x1.de5d6e3f8868ap-1, 0x1.16536eea37ae3p-4},
-    {0x1.d77b654b82c34p-1, 0x1.51b073f06183cp-4},
-    {0x1.d0cb58f6ec074p-1, 0x1.8c345d6319b23p-4},
-    {0x1.ca4b3055ee191p-1, 0x1.c5e548f5bc743p-4},
-    {0x1.c3f8f01c3f8f0p-1, 0x1.fec9131dbeabcp-4},
-    {0x1.bdd2b899406f7p-1, 0x1.1b72ad52f67a2p-3},
-    {0x1.b7d6c3dda338bp-1, 0x1.371fc201e8f75p-3},
-    {0x1.b2036406c80d9p-1, 0x1.526e5e3a1b438p-3},
-    {0x1.ac5701ac5701bp-1, 0x1.6d60fe719d21bp-3},
-    {0x1.a6d01a6d01a6dp-1, 0x1.87fa06520c911p-3},
-    {0x1.a16d3f97a4b02p-1, 0x1.a23bc1fe2b561p-3},
-    {0x1.9c2d14ee4a102p-1, 0x1.bc286742d8cd4p-3},
-    {0x1.970e4f80cb872p-1, 0x1.d5c216b4fbb94p-3},
-    {0x1.920fb49d0e229p-1, 0x1.ef0adcbdc5935p-3},
-    {0x1.8d3018d3018d3p-1, 0x1.0402594b4d041p-2},
-    {0x1.886e5f0abb04ap-1, 0x1.1058bf9ae4ad4p-2},
-    {0x1.83c977ab2beddp-1, 0x1.1c898c16999fbp-2},
-    {0x1.7f405fd017f40p-1, 0x1.2895a13de86a4p-2},
-    {0x1.7ad2208e0ecc3p-1, 0x1.347dd9a987d56p-2},
-    {0x1.767dce434a9b1p-1, 0x1.404308686a7e4p-2},
-};
-HNB_HD double d_log(double x) {
-    const double ln2_hi = 6.93147180369123816490e-01;
-    const double ln2_lo = 1.90821492927058770002e-10;
-    const uint64_t ix = d2u(x);
-    const uint32_t hi = (uint32_t)(ix >> 32) - 0x3fe60000u;      // (the low word of the offset is zero: only the high word changes)
-    const uint32_t i = (hi >> 14) & 63u;
-    const int32_t k = (int32_t)hi >> 20;                          // arithmetic shift: floor
-    const double z = u2d(ix - ((uint64_t)(hi & 0xfff00000u) << 32));
-    const double r = d_fma(z, kLogTab[i][0], -1.0);
-    const double r2 = r * r;
-    double p = 0x1.24a4c91a63c23p-3;
-    p = d_fma_c(p, r, -0x1.556a254394372p-3);
-    p = d_fma_c(p, r, 0x1.9999994c9b676p-3);
-    p = d_fma_c(p, r, -0x1.ffffffa962285p-3);
-    p = d_fma_c(p, r, 0x1.5555555555555p-2);
-    const double l1p = d_fma(r2 * r, p, d_fma(-0.5, r2, r));
-    const double kd = (double)k;
-    return (kd * ln2_hi + kLogTab[i][1]) + (l1p + kd * ln2_lo);
+// ---- binary32 kernels ------------------------------------------------------------------
+HNB_HD float f_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// Round to nearest integer (ties to even) with two IEEE additions; valid |x| < 2^22. *low32: that integer modulo 2^32 (two's complement,
+// from the low mantissa bits of the biased sum), without a float -> int conversion.
+HNB_HD float f_rint_bits(float x, uint32_t* low32) {
+    const float magic = 12582912.0f;  // 1.5 * 2^23
+    const float t = x + magic;  // never folded: built without fast-math / reassociation
+    *low32 = f2u(t) - 0x4b400000u;
+    return t - magic;
 }
-
-// sqrt of a double in [2^-100, 2^100] (and 0; negative / NaN -> NaN): the binary32 root and its binary32 reciprocal (both IEEE, so
-// identical on host and device) seed ONE Heron step whose division is a multiplication by that reciprocal: relative error < 2^-46.
-HNB_HD double d_sqrt(double a) {
-    const float sf = f_sqrt((float)a);
-    const double s0 = (double)sf, h = 0.5 * (double)(1.0f / sf);
-    const double s = d_fma(d_fma(-s0, s0, a), h, s0);
-    return (a > 0.0) ? s : ((a == 0.0) ? 0.0 : u2d(0x7ff8000000000000ull));  // 0 -> 0, negative / NaN -> NaN
+// sin and cos of a float with |x| <= 65536: k = rint(x 2/pi), r = x - k pi/2 with pi/2 in three binary32 pieces (one fma each: the
+// products are exact inside the fma), |r| <= pi/4 + 2^-9; sin r = r + r z S(z), cos r = 1 - z/2 + z^2 C(z), z = r^2
+HNB_HD void f_sincos_small(float x, float* s_out, float* c_out) {
+    uint32_t q;
+    const float k = f_rint_bits(x * 0x1.45f306p-1f, &q);
+    float r = f_fma(-k, 0x1.921fb6p+0f, x);
+    r = f_fma(-k, -0x1.777a5cp-25f, r);
+    r = f_fma(-k, -0x1.ee59dap-50f, r);
+    const float z = r * r;
+    float ps = -0x1.9ac63ep-13f;
+    ps = f_fma(ps, z, 0x1.110c22p-7f);
+    ps = f_fma(ps, z, -0x1.555552p-3f);
+    const float sn = f_fma(r * z, ps, r);
+    float pc = 0x1.9bd5d8p-16f;
+    pc = f_fma(pc, z, -0x1.6c12cep-10f);
+    pc = f_fma(pc, z, 0x1.555554p-5f);
+    const float cs = f_fma(z * z, pc, f_fma(-0.5f, z, 1.0f));
+    // quadrant q mod 4: (sin, cos) = (sn, cs), (cs, -sn), (-sn, -cs), (-cs, sn)
+    const float a = (q & 1u) ? cs : sn, b = (q & 1u) ? sn : cs;
+    *s_out = (q & 2u) ? -a : a;
+    *c_out = (((q + 1u) & 2u) != 0u) ? -b : b;
 }
-
-// asin(t) = t + t z P(z), z = t^2 <= 1/4: relative error 2^-50
-HNB_HD double d_asin_poly(double z) {
-    double p = 0x1.c8ea18fd14be4p-6;
-    p = d_fma_c(p, z, -0x1.c05fb18feb0f9p-8);
-    p = d_fma_c(p, z, 0x1.fa6d9d973284ep-7);
-    p = d_fma_c(p, z, 0x1.5114f44b77900p-7);
-    p = d_fma_c(p, z, 0x1.cf629dd6ae5fdp-7);
-    p = d_fma_c(p, z, 0x1.1c0d42d9a72edp-6);
-    p = d_fma_c(p, z, 0x1.6e8f37bce829dp-6);
-    p = d_fma_c(p, z, 0x1.f1c6ff632bc58p-6);
-    p = d_fma_c(p, z, 0x1.6db6dba9ded46p-5);
-    p = d_fma_c(p, z, 0x1.3333333302d42p-4);
-    p = d_fma_c(p, z, 0x1.55555555555bcp-3);
-    return p;
+// 2^k as a float, k in [-126, 127]
+HNB_HD float f_pow2i(int32_t k) { return u2f((uint32_t)(k + 127) << 23); }
+// p 2^k for p in [1/2, 5/2] and any k: two scalings, the first exact, the second rounding once (into the subnormals, to zero or to infinity)
+HNB_HD float f_scale2(float p, int32_t k) {
+    k = k < -252 ? -252 : (k > 254 ? 254 : k);
+    const int32_t k1 = k >> 1;   // floor(k / 2): both halves in [-126, 127]
+    return (p * f_pow2i(k1)) * f_pow2i(k - k1);
 }
-// asin / acos of a double; |x| > 1 -> NaN. |x| <= 1/2: t = asin x directly; beyond: t = asin sqrt((1 - |x|) / 2) ((1 - |x|) / 2 is
-// exact) and asin |x| = pi/2 - 2 t. One polynomial evaluation either way (selects, no branch: a wave has lanes on both sides).
-HNB_HD double d_asin(double x) {
-    const double pi_2_hi = 0x1.921fb54442d18p+0, pi_2_lo = 0x1.1a62633145c07p-54;
-    const double ax = x < 0.0 ? -x : x;
-    const bool small = ax <= 0.5;
-    const double z = small ? x * x : (1.0 - ax) * 0.5;
-    const double s = small ? x : d_sqrt(z);
-    const double t = d_fma(s * z, d_asin_poly(z), s);
-    const double r = d_fma(-2.0, t, pi_2_hi) + pi_2_lo;
-    return small ? t : (x < 0.0 ? -r : r);
+// exp(r) for |r| <= ln2/2 + 2^-9: 1 + r + r^2 E(r)
+HNB_HD float f_exp_poly(float r) {
+    float p = 0x1.6d127p-10f;
+    p = f_fma(p, r, 0x1.120cd4p-7f);
+    p = f_fma(p, r, 0x1.555518p-5f);
+    p = f_fma(p, r, 0x1.5554dcp-3f);
+    p = f_fma(p, r, 0x1.0p-1f);
+    return f_fma(r * r, p, r) + 1.0f;
 }
-HNB_HD double d_acos(double x) {
-    const double pi_2_hi = 0x1.921fb54442d18p+0, pi_2_lo = 0x1.1a62633145c07p-54;
-    const double ax = x < 0.0 ? -x : x;
-    const bool small = ax <= 0.5;
-    const double z = small ? x * x : (1.0 - ax) * 0.5;
-    const double s = small ? x : d_sqrt(z);
-    const double t = d_fma(s * z, d_asin_poly(z), s);
-    const double far = x < 0.0 ? d_fma(-2.0, t, 2.0 * pi_2_hi) + 2.0 * pi_2_lo : 2.0 * t;
-    return small ? pi_2_hi - (t - pi_2_lo) : far;
+// 2^r for |r| <= 1/2 + 2^-9: 1 + r E2(r)
+HNB_HD float f_exp2_poly(float r) {
+    float p = 0x1.44149ap-13f;
+    p = f_fma(p, r, 0x1.5f0a1cp-10f);
+    p = f_fma(p, r, 0x1.3b2a52p-7f);
+    p = f_fma(p, r, 0x1.c6af6ap-5f);
+    p = f_fma(p, r, 0x1.ebfbep-3f);
+    p = f_fma(p, r, 0x1.62e43p-1f);
+    return f_fma(r, p, 1.0f);
 }
-
-// atan of any double (NaN -> NaN): at most one division. t = |x| <= tan(pi/8): atan t; t <= tan(3 pi/8): pi/4 + atan((t-1)/(t+1));
-// beyond: pi/2 - atan(1/t); atan u = u + u z A(z), z = u^2 <= tan^2(pi/8), relative error 2^-47
-HNB_HD double d_atan(double x) {
-    if (x != x) return x;
-    const double pi_2 = 0x1.921fb54442d18p+0, pi_4 = 0x1.921fb54442d18p-1;
-    const bool neg = d_signbit(x);
-    const double t = neg ? -x : x;
-    const bool mid = t > 0.41421356237309503 && t <= 2.4142135623730951, big = t > 2.4142135623730951;
-    const double num = mid ? t - 1.0 : (big ? -1.0 : t), den = mid ? t + 1.0 : (big ? t : 1.0);
-    const double u = num / den;
-    const double z = u * u;
-    double p = -0x1.be20c62f176ddp-6;
-    p = d_fma_c(p, z, 0x1.a769bd3353c1cp-5);
-    p = d_fma_c(p, z, -0x1.0c52a4b5af878p-4);
-    p = d_fma_c(p, z, 0x1.3a9d83feefaedp-4);
-    p = d_fma_c(p, z, -0x1.74563c795c0ffp-4);
-    p = d_fma_c(p, z, 0x1.c71c381ab56c6p-4);
-    p = d_fma_c(p, z, -0x1.249248aa52bc5p-3);
-    p = d_fma_c(p, z, 0x1.99999998d12f0p-3);
-    p = d_fma_c(p, z, -0x1.55555555553a3p-2);
-    double r = d_fma(u * z, p, u);
-    r = (mid ? pi_4 : (big ? pi_2 : 0.0)) + r;
-    return neg ? -r : r;
+// a finite x > 0 as m 2^e with m in [2/3, 4/3): returns f = m - 1 (exact)
+HNB_HD float f_log_reduce(float x, float* e_out) {
+    uint32_t ix = f2u(x);
+    float bias = 0.0f;
+    if (ix < 0x00800000u) { ix = f2u(x * 8388608.0f); bias = -23.0f; }   // subnormal: scaled by 2^23 (exact)
+    const uint32_t i = (ix - 0x3f2aaaabu) & 0xff800000u;
+    *e_out = (float)((int32_t)i >> 23) + bias;
+    return u2f(ix - i) - 1.0f;
 }
-
-HNB_HD double d_atan2(double y, double x) {
-    const double pi = 3.14159265358979311600;
-    const double pi_2 = 1.57079632679489655800;
-    if (x != x || y != y) return x + y;
-    if (x > 0.0) return d_atan(y / x);
-    if (x < 0.0) return d_atan(y / x) + (d_signbit(y) ? -pi : pi);
-    if (y > 0.0) return pi_2;
-    if (y < 0.0) return -pi_2;
-    if (d_signbit(x)) return d_signbit(y) ? -pi : pi;
-    return y;
+// ln(1 + f) for |f| <= 1/3 as head + *lo (|*lo| <= ulp(head) / 2; relative error of the sum 2^-28): f - f^2/2 + f^3 L(f), with f^2
+// carried exactly (product and its fma residual) and the rounding error of f - f^2/2 recovered
+HNB_HD float f_ln1p_parts(float f, float* lo) {
+    const float h = f * f, hl = f_fma(f, f, -h);          // f^2 = h + hl exactly
+    float p = 0x1.9fe062p-4f;
+    p = f_fma(p, f, -0x1.c129fcp-4f);
+    p = f_fma(p, f, 0x1.687256p-4f);
+    p = f_fma(p, f, -0x1.8cdb84p-4f);
+    p = f_fma(p, f, 0x1.c7b586p-4f);
+    p = f_fma(p, f, -0x1.0051d4p-3f);
+    p = f_fma(p, f, 0x1.2490bcp-3f);
+    p = f_fma(p, f, -0x1.5553aep-3f);
+    p = f_fma(p, f, 0x1.99999cp-3f);
+    p = f_fma(p, f, -0x1.000002p-2f);
+    p = f_fma(p, f, 0x1.555556p-2f);
+    const float c = (h * f) * p;                          // f^3 L(f)
+    const float s = f_fma(-0.5f, h, f);                   // f - h/2, rounded ...
+    const float serr = f_fma(-0.5f, h, f - s);            // ... and what the rounding lost ((f - s) is exact: |h/2| <= |f|/6)
+    const float t = serr + f_fma(-0.5f, hl, c);           // (|t| < |s| / 8)
+    const float head = s + t;
+    *lo = (s - head) + t;                                  // exact: head + *lo == s + t
+    return head;
+}
+// log2(x) of a finite x > 0 as head + *tail (relative error of the sum 2^-28): what pow needs to keep y log2 x accurate
+HNB_HD float f_log2_parts(float x, float* tail) {
+    float e, lo;
+    const float f = f_log_reduce(x, &e);
+    const float s = f_ln1p_parts(f, &lo);
+    const float th = s * 0x1.715476p+0f;
+    const float tl = f_fma(s, 0x1.715476p+0f, -th) + f_fma(s, 0x1.4ae0cp-26f, lo * 0x1.715476p+0f);
+    const float hi = e + th;                               // |e| >= 1 > |th| or e == 0: (e - hi) + th is the exact rounding error
+    const float t2 = ((e - hi) + th) + tl;
+    const float head = hi + t2;
+    *tail = (hi - head) + t2;
+    return head;
+}
+// asin(s) = s + s z P(z) for z = s^2 <= 1/4
+HNB_HD float f_asin_core(float s, float z) {
+    float p = 0x1.3810d4p-5f;
+    p = f_fma(p, z, 0x1.b3018ep-6f);
+    p = f_fma(p, z, 0x1.70a7dp-5f);
+    p = f_fma(p, z, 0x1.33272cp-4f);
+    p = f_fma(p, z, 0x1.55555ep-3f);
+    return f_fma(s * z, p, s);
 }
 
 // ---- binary32 entry points (what WGSL `sin(x)` etc. mean in this framework) ----------
-HNB_HD bool trig_in_range(float x) { return f_abs(x) <= 1099511627776.0f; }  // 2^40
-
+HNB_HD bool trig_small(float x) { return f_abs(x) <= 65536.0f; }
 HNB_HD float f_sin(float x) {
-    const bool finite = f_abs(x) <= 3.4028234663852886e38f, in_range = trig_in_range(x);
-    double s, c; d_sincos(in_range ? (double)x : 0.0, &s, &c);
-    return finite ? (in_range ? (float)s : 0.0f) : x - x;  // NaN/inf -> NaN; |x| > 2^40 -> sin 0
+    if (!trig_small(x)) return f_trig_big(x, 0);
+    float s, c; f_sincos_small(x, &s, &c);
+    return s;
 }
 HNB_HD float f_cos(float x) {
-    const bool finite = f_abs(x) <= 3.4028234663852886e38f, in_range = trig_in_range(x);
-    double s, c; d_sincos(in_range ? (double)x : 0.0, &s, &c);
-    return finite ? (in_range ? (float)c : 1.0f) : x - x;
+    if (!trig_small(x)) return f_trig_big(x, 1);
+    float s, c; f_sincos_small(x, &s, &c);
+    return c;
 }
 HNB_HD float f_tan(float x) {
-    const bool finite = f_abs(x) <= 3.4028234663852886e38f, in_range = trig_in_range(x);
-    double s, c; d_sincos(in_range ? (double)x : 0.0, &s, &c);
-    return finite ? (in_range ? (float)(s / c) : 0.0f) : x - x;
+    if (!trig_small(x)) return f_trig_big(x, 2);
+    float s, c; f_sincos_small(x, &s, &c);
+    return s / c;
 }
-HNB_HD float f_atan(float x) { return (float)d_atan((double)x); }
-HNB_HD float f_atan2(float y, float x) { return (float)d_atan2((double)y, (double)x); }
-HNB_HD float f_asin(float x) { return (float)d_asin((double)x); }
-HNB_HD float f_acos(float x) { return (float)d_acos((double)x); }
 HNB_HD float f_exp(float x) {
     if (x != x) return x;
-    double xd = (double)x;
-    if (xd > 100.0) xd = 100.0;
-    if (xd < -120.0) xd = -120.0;
-    return (float)d_exp(xd);
+    const float xc = x > 90.0f ? 90.0f : (x < -105.0f ? -105.0f : x);   // (beyond: infinity / zero either way)
+    uint32_t ki;
+    const float k = f_rint_bits(xc * 0x1.715476p+0f, &ki);
+    float r = f_fma(-k, 0x1.62e43p-1f, xc);
+    r = f_fma(-k, -0x1.05c61p-29f, r);
+    return f_scale2(f_exp_poly(r), (int32_t)ki);
 }
 HNB_HD float f_exp2(float x) {
     if (x != x) return x;
-    double xd = (double)x;
-    if (xd > 140.0) xd = 140.0;
-    if (xd < -170.0) xd = -170.0;
+    const float xc = x > 130.0f ? 130.0f : (x < -152.0f ? -152.0f : x);
     uint32_t ki;
-    const double k = d_rint_bits(xd, &ki);
-    const double r = (xd - k) * 0.69314718055994528623;
-    return (float)(d_exp(r) * d_pow2i((int32_t)ki));
+    const float k = f_rint_bits(xc, &ki);
+    return f_scale2(f_exp2_poly(xc - k), (int32_t)ki);
 }
-HNB_HD double d_log_f(float x, bool* special, float* sv) {
+// log of NaN, a negative number, zero, infinity
+HNB_HD float f_log_special(float x, bool* special) {
     *special = true;
-    if (x != x) { *sv = x; return 0.0; }
-    if (x < 0.0f) { *sv = f_nan(); return 0.0; }
-    if (x == 0.0f) { *sv = -f_inf(); return 0.0; }
-    if (x == f_inf()) { *sv = x; return 0.0; }
+    if (x != x) return x;
+    if (x < 0.0f) return f_nan();
+    if (x == 0.0f) return -f_inf();
+    if (x == f_inf()) return x;
     *special = false;
-    return d_log((double)x);
+    return 0.0f;
 }
 HNB_HD float f_log(float x) {
-    bool sp; float sv; double l = d_log_f(x, &sp, &sv);
-    return sp ? sv : (float)l;
+    bool sp; const float sv = f_log_special(x, &sp);
+    if (sp) return sv;
+    float e, lo;
+    const float f = f_log_reduce(x, &e);
+    const float s = f_ln1p_parts(f, &lo);
+    return f_fma(e, 0x1.62e43p-1f, s + f_fma(e, -0x1.05c61p-29f, lo));   // e ln2 + ln m, ln2 in two pieces
 }
 HNB_HD float f_log2(float x) {
-    bool sp; float sv; double l = d_log_f(x, &sp, &sv);
-    return sp ? sv : (float)(l * 1.44269504088896338700);
+    bool sp; const float sv = f_log_special(x, &sp);
+    if (sp) return sv;
+    float tl;
+    const float hi = f_log2_parts(x, &tl);
+    return hi + tl;
 }
-// WGSL pow(x, y): defined here as exp(y * ln x) for x > 0; x < 0 -> NaN.
+// WGSL pow(x, y): defined here as exp2(y * log2 x) for x > 0 (log2 x carried as head + tail); x < 0 -> NaN.
 HNB_HD float f_pow(float x, float y) {
-    // computed for every lane, the special cases selected afterwards (d_log of a non-positive or non-finite x is garbage, never a fault)
-    double t = (double)y * d_log((double)x);
-    if (t > 100.0) t = 100.0;
-    if (t < -120.0) t = -120.0;
-    const float r = (float)d_exp(t != t ? 0.0 : t);
     if (x != x || y != y) return x + y;
     if (y == 0.0f) return 1.0f;
     if (x < 0.0f) return f_nan();
     if (x == 0.0f) return (y > 0.0f) ? 0.0f : f_inf();
     if (x == f_inf()) return (y > 0.0f) ? f_inf() : 0.0f;
-    return r;
+    float tl;
+    const float hi = f_log2_parts(x, &tl);
+    float ph = y * hi;
+    const float pl = f_fma(y, hi, -ph) + y * tl;
+    const bool sat = !(f_abs(ph) < 200.0f);                // infinite / huge: the result saturates whatever the low bits are
+    if (sat) ph = ph > 0.0f ? 200.0f : -200.0f;
+    uint32_t ki;
+    const float k = f_rint_bits(ph, &ki);
+    const float r = (ph - k) + (sat ? 0.0f : pl);
+    return f_scale2(f_exp2_poly(r), (int32_t)ki);
+}
+// asin / acos; |x| > 1 -> NaN. |x| <= 1/2: t = asin x directly; beyond: t = asin sqrt((1 - |x|) / 2) ((1 - |x|) / 2 is exact) and
+// asin |x| = pi/2 - 2 t. One polynomial evaluation either way (selects, no branch: a wave has lanes on both sides).
+HNB_HD float f_asin(float x) {
+    const float ax = f_abs(x);
+    if (!(ax <= 1.0f)) return f_nan();
+    const bool small = ax <= 0.5f;
+    const float z = small ? x * x : (1.0f - ax) * 0.5f;
+    const float s = small ? x : f_sqrt(z);
+    const float t = f_asin_core(s, z);
+    const float r = f_fma(-2.0f, t, 0x1.921fb6p+0f) + -0x1.777a5cp-25f;
+    return small ? t : (x < 0.0f ? -r : r);
+}
+HNB_HD float f_acos(float x) {
+    const float ax = f_abs(x);
+    if (!(ax <= 1.0f)) return f_nan();
+    const bool small = ax <= 0.5f;
+    const float z = small ? x * x : (1.0f - ax) * 0.5f;
+    const float s = small ? x : f_sqrt(z);
+    const float t = f_asin_core(s, z);
+    const float far = x < 0.0f ? f_fma(-2.0f, t, 0x1.921fb6p+1f) + -0x1.777a5cp-24f : 2.0f * t;
+    return small ? (0x1.921fb6p+0f - t) + -0x1.777a5cp-25f : far;
+}
+// atan (NaN -> NaN): at most one division. t = |x| <= tan(pi/8): atan t; t <= tan(3 pi/8): pi/4 + atan((t-1)/(t+1)); beyond:
+// pi/2 - atan(1/t); atan u = u + u z A(z), z = u^2 <= tan^2(pi/8); pi/4 and pi/2 in two pieces
+HNB_HD float f_atan(float x) {
+    if (x != x) return x;
+    const bool neg = f_signbit(x);
+    const float t = f_abs(x);
+    const bool mid = t > 0x1.a8279ap-2f && t <= 0x1.3504f4p+1f, big = t > 0x1.3504f4p+1f;
+    const float num = mid ? t - 1.0f : (big ? -1.0f : t), den = mid ? t + 1.0f : (big ? t : 1.0f);
+    const float u = num / den;
+    const float z = u * u;
+    float p = -0x1.083894p-4f;
+    p = f_fma(p, z, 0x1.b80c54p-4f);
+    p = f_fma(p, z, -0x1.242008p-3f);
+    p = f_fma(p, z, 0x1.99973p-3f);
+    p = f_fma(p, z, -0x1.555554p-2f);
+    float r = f_fma(u * z, p, u);
+    r = (mid ? 0x1.921fb6p-1f : (big ? 0x1.921fb6p+0f : 0.0f)) + (r + (mid ? -0x1.777a5cp-26f : (big ? -0x1.777a5cp-25f : 0.0f)));
+    return neg ? -r : r;
+}
+HNB_HD float f_atan2(float y, float x) {
+    if (x != x || y != y) return x + y;
+    if (x > 0.0f) return f_atan(y / x);
+    if (x < 0.0f) {
+        const float a = f_atan(y / x);
+        return f_signbit(y) ? (a - -0x1.777a5cp-24f) - 0x1.921fb6p+1f : (a + -0x1.777a5cp-24f) + 0x1.921fb6p+1f;
+    }
+    if (y > 0.0f) return 0x1.921fb6p+0f;
+    if (y < 0.0f) return -0x1.921fb6p+0f;
+    if (f_signbit(x)) return f_signbit(y) ? -0x1.921fb6p+1f : 0x1.921fb6p+1f;
+    return y;
 }
 
 // ---- conversions (WGSL value constructors: truncate + saturate, NaN -> 0) -------------

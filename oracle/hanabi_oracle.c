@@ -1323,23 +1323,10 @@ float hor_math1(int fn, float x) {
         case 10: return f_sqrt(x); case 11: return f_inv_sqrt(x); default: return x;
     }
 }
-/* the binary64 kernels BEFORE the final rounding to binary32 (tests/test_math.py measures their error against libm) */
+/* the one binary64 kernel left (sin / cos of |x| > 65536) BEFORE its rounding to binary32 (tests/test_math.py measures it against libm) */
 double hor_math1d(int fn, double x) {
-#ifdef ORACLE_LIBM
-    return x;
-#else
     double s, c;
-    switch (fn) {
-        case 0: d_sincos(x, &s, &c); return s;
-        case 1: d_sincos(x, &s, &c); return c;
-        case 3: return d_exp(x);
-        case 4: return d_log(x);
-        case 6: return d_atan(x);
-        case 7: return d_asin(x);
-        case 8: return d_acos(x);
-        case 10: return d_sqrt(x);
-        default: return x;
-    }
-#endif
+    d_sincos(x, &s, &c);
+    return fn == 0 ? s : (fn == 1 ? c : x);
 }
 float hor_math2(int fn, float x, float y) { return fn == 0 ? f_pow(x, y) : (fn == 1 ? f_atan2(x, y) : f_rem(x, y)); }

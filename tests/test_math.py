@@ -1,8 +1,9 @@
-"""hanabi-math (oracle/oracle_math.h == bevy_hanabi_amd/csrc/hnb_math.h): the transcendental
-functions are defined as "evaluate in binary64 with + - * / fma only, round once to binary32".
-Checked here against numpy's binary64 libm rounded to f32: at most 1 ulp apart (in practice 0),
-and exact on the special values WGSL defines. The product copy of the same header is compared
-bit-for-bit against this one through tests/test_lowering_cpu.py (host build) and the GPU tests."""
+"""hanabi-math v3 (oracle/oracle_math.h == bevy_hanabi_amd/csrc/hnb_math.h): the transcendental functions are binary32 kernels
+built from + - * / sqrt and fmaf only. Checked here on samples against numpy's binary64 libm rounded to f32 with the bounds the
+exhaustive sweep established (tools/math_sweep.c over ALL binary32 arguments, profiles/r04_math_sweep.txt: sin cos asin atan atan2
+<= 2 ulp, tan <= 4, exp exp2 log log2 acos <= 1, pow <= 8 and <= 2 where |y log2 x| <= 32), and exact on the special values WGSL
+defines. The product copy of the same header is compared bit-for-bit against this one through tests/test_lowering_cpu.py (host
+build) and the GPU tests."""
 import math
 
 import numpy as np
@@ -29,6 +30,9 @@ FN1 = {
 }
 
 
+MAX_ULP = {"sin": 2, "cos": 2, "tan": 4, "asin": 2, "atan": 2, "inverseSqrt": 1}   # (inverseSqrt: 1 / sqrt(x), two IEEE roundings); every other function: 1
+
+
 def ulp_diff(a, b):
     a = np.float32(a).view(np.int32).astype(np.int64)
     b = np.float32(b).view(np.int32).astype(np.int64)
@@ -38,29 +42,33 @@ def ulp_diff(a, b):
 
 
 @pytest.mark.parametrize("name", sorted(FN1))
-def test_unary_within_one_ulp_of_libm(name):
+def test_unary_within_its_ulp_bound_of_libm(name):
     code, ref, gen = FN1[name]
     xs = gen().astype(np.float32)
     got = np.array([oracle.math1(code, float(x)) for x in xs], dtype=np.float32)
     want = ref(xs.astype(np.float64)).astype(np.float32)
     finite = np.isfinite(want)
     d = ulp_diff(got[finite], want[finite])
-    assert d.max() <= 1, f"{name}: max {d.max()} ulp at x={xs[finite][d.argmax()]!r}"
+    assert d.max() <= MAX_ULP.get(name, 1), f"{name}: max {d.max()} ulp at x={xs[finite][d.argmax()]!r}"
+    assert d.mean() < 0.5, f"{name}: mean distance to the correctly rounded result {d.mean():.3f} ulp"
     assert (np.isfinite(got) == finite).all()
 
 
-def test_pow_and_atan2_within_one_ulp():
+def test_pow_and_atan2_within_their_ulp_bounds():
     xs = np.exp(RNG.uniform(-10, 10, N)).astype(np.float32)
     ys = RNG.uniform(-8, 8, N).astype(np.float32)
     got = np.array([oracle.math2(0, float(x), float(y)) for x, y in zip(xs, ys)], dtype=np.float32)
     want = np.power(xs.astype(np.float64), ys.astype(np.float64)).astype(np.float32)
-    ok = np.isfinite(want) & (want != 0)
-    assert ulp_diff(got[ok], want[ok]).max() <= 1
+    ok = np.isfinite(want) & (want != 0) & (np.abs(want) > 1.2e-38)
+    d = ulp_diff(got[ok], want[ok])
+    assert d.max() <= 8
+    moderate = np.abs(ys.astype(np.float64) * np.log2(xs.astype(np.float64)))[ok] <= 32.0
+    assert d[moderate].max() <= 2 and d[moderate].mean() < 0.5
     a = RNG.uniform(-100, 100, N).astype(np.float32)
     b = RNG.uniform(-100, 100, N).astype(np.float32)
     got = np.array([oracle.math2(1, float(x), float(y)) for x, y in zip(a, b)], dtype=np.float32)
     want = np.arctan2(a.astype(np.float64), b.astype(np.float64)).astype(np.float32)
-    assert ulp_diff(got, want).max() <= 1
+    assert ulp_diff(got, want).max() <= 2
 
 
 def test_special_values():
@@ -78,31 +86,40 @@ def test_special_values():
 
 
 def test_large_argument_reduction():
-    # Cody-Waite/Payne-Hanek range: sin/cos stay within 1 ulp far from zero
-    for x in (1e4, 12345.678, 1e6, 3.4e7, -7.7e6):
+    # |x| <= 65536: the three-term binary32 Cody-Waite reduction (<= 2 ulp); beyond: the binary64 reduction (<= 1 ulp); both sides of the seam
+    for x in (1e4, 12345.678, 65535.996, 65536.0, 65536.008, 1e6, 3.4e7, -7.7e6):
         x32 = float(np.float32(x))
         for code, ref in ((0, math.sin), (1, math.cos)):
             got, want = np.float32(oracle.math1(code, x32)), np.float32(ref(x32))
-            assert ulp_diff(got, want) <= 1, (x, code, got, want)
+            assert ulp_diff(got, want) <= (2 if abs(x32) <= 65536.0 else 1), (x, code, got, want)
+    # |x| > 2^40 is defined as x = 0; NaN / inf -> NaN
+    assert oracle.math1(0, 2.0e12) == 0.0 and oracle.math1(1, 2.0e12) == 1.0 and oracle.math1(2, -2.0e12) == 0.0
+    assert math.isnan(oracle.math1(0, math.inf)) and math.isnan(oracle.math1(1, -math.inf)) and math.isnan(oracle.math1(2, math.nan))
 
 
-def test_binary64_kernels_before_the_final_rounding():
-    """The binary64 kernels themselves (minimax polynomials + fma, tools/gen_math_coeffs.py) against libm's binary64 functions:
-    relative error below 2^-45 everywhere sampled, i.e. about 2^21 times finer than the binary32 result they are rounded to."""
+def test_the_binary64_reduction_before_its_rounding():
+    """The one binary64 kernel left - sin / cos of 65536 < |x| <= 2^40 - against libm's binary64 functions: relative error below 2^-45
+    everywhere sampled, about 2^21 times finer than the binary32 result it is rounded to."""
     rng = np.random.default_rng(77)
-    n = 20000
-    f32 = lambda a: a.astype(np.float32).astype(np.float64)
-    cases = [(0, f32(rng.uniform(-50, 50, n)), np.sin), (1, f32(rng.uniform(-50, 50, n)), np.cos),
-             (7, f32(rng.uniform(-1, 1, n)), np.arcsin), (8, f32(rng.uniform(-1, 1, n)), np.arccos),
-             (3, f32(rng.uniform(-80, 80, n)), np.exp), (4, f32(np.exp(rng.uniform(-80, 80, n))), np.log),
-             (4, f32(1 + rng.uniform(-0.05, 0.05, n)), np.log), (6, f32(rng.uniform(-1e3, 1e3, n)), np.arctan),
-             (6, f32(rng.uniform(-3, 3, n)), np.arctan), (10, np.exp(rng.uniform(-17, -1.3, n)), np.sqrt)]
-    for fn, xs, ref in cases:
+    xs = (rng.uniform(65536.0, 2.0 ** 40, 20000) * rng.choice([-1.0, 1.0], 20000)).astype(np.float32).astype(np.float64)
+    for fn, ref in ((0, np.sin), (1, np.cos)):
         got = np.array([oracle.math1d(fn, float(x)) for x in xs])
         want = ref(xs)
-        ok = np.isfinite(want) & (want != 0)
+        ok = want != 0
         rel = np.abs(got[ok] - want[ok]) / np.abs(want[ok])
         assert rel.max() < 2.0 ** -45, (fn, float(rel.max()), float(xs[ok][rel.argmax()]))
+
+
+def test_exp_and_pow_saturate_and_round_into_the_subnormals_once():
+    m1, m2 = oracle.math1, oracle.math2
+    f = lambda v: float(np.float32(v))
+    assert m1(3, 88.0) == f(math.exp(88.0)) or abs(m1(3, 88.0) / math.exp(88.0) - 1) < 2e-7
+    assert m1(3, 89.0) == math.inf and m1(3, 1e30) == math.inf and m1(3, -104.0) == 0.0 and m1(3, -1e30) == 0.0
+    assert m1(9, 127.0) == 2.0 ** 127 and m1(9, 128.0) == math.inf and m1(9, -149.0) == 2.0 ** -149 and m1(9, -150.0) == 0.0 and m1(9, -126.0) == 2.0 ** -126
+    assert m1(9, -140.5) == f(2.0 ** -140.5)                       # a subnormal result: one rounding
+    assert m2(0, 2.0, 127.0) == 2.0 ** 127 and m2(0, 2.0, 128.0) == math.inf and m2(0, 2.0, -149.0) == 2.0 ** -149 and m2(0, 0.5, 150.0) == 0.0
+    assert m2(0, 1e30, 1e30) == math.inf and m2(0, 1e-30, 1e30) == 0.0 and m2(0, 1e30, -1e30) == 0.0
+    assert m1(4, f(2.0 ** -140)) == f(math.log(2.0 ** -140)) and m1(5, f(2.0 ** -149)) == -149.0   # subnormal arguments of log / log2
 
 
 def test_normalize_reciprocal_domain():

@@ -40,9 +40,10 @@ def prop_value(asset, name, value):
     return np.atleast_1d(np.asarray(value)).astype(dt)
 
 
-def compare(orc, wfx, what, before=None, sorted_list=False):
+def compare(orc, wfx, what, before=None, sorted_list=False, impulse=0.0):
     """before: the particle state both sides started the frame from (resync protocol): a component the frame produced by cancellation
-    (velocity + impulse near a force field's shell) is held against the size of what was cancelled."""
+    (velocity + impulse near a force field's shell) is held against the size of what was cancelled - the vector before the frame and
+    `impulse`, the largest velocity change one frame of the asset's modifiers can apply (|acceleration| x dt)."""
     st = orc.state()
     c = st["counters"]
     assert (c["alive_count"], c["particle_counter"], c["max_update"], c["dead_count"]) == (wfx.alive_count, wfx.particle_counter, wfx.max_update, wfx.dead_count), what
@@ -66,6 +67,8 @@ def compare(orc, wfx, what, before=None, sorted_list=False):
                 scale = np.nanmax(np.maximum(np.abs(a), np.abs(b)), axis=1, keepdims=True)
                 if before is not None and name in before:
                     scale = np.maximum(scale, np.nanmax(np.abs(before[name].view(np.float32).astype(np.float64)), axis=1, keepdims=True))
+                if name == "velocity":
+                    scale = np.maximum(scale, impulse)
                 bound = REL_TOL * scale * np.ones_like(a)
                 bad = (err > bound) & ~both_nan & ~same_inf & ~(err < 1e-30)
             assert not bad.any(), f"{what}: {name}: {int(bad.sum())} components beyond {REL_TOL}; first at {np.argwhere(bad)[0]}: oracle {a[bad][0]!r} wgsl {b[bad][0]!r}"
@@ -77,7 +80,7 @@ def compare(orc, wfx, what, before=None, sorted_list=False):
     return worst
 
 
-def play(asset, frames, check_every=1, what="", resync=False):
+def play(asset, frames, check_every=1, what="", resync=False, impulse=0.0):
     """resync: after every (compared) frame the WGSL side continues from the ORACLE's particle state: each frame is then a test of the
     one-frame map on identical inputs. For dynamics that amplify a last-bit difference - ConformToSphere's sign / min / smoothstep corners
     turn 3e-7 into 1e-3 within twenty frames, measured - that is the meaningful comparison; stable effects run free for the whole script."""
@@ -91,7 +94,7 @@ def play(asset, frames, check_every=1, what="", resync=False):
         wfx.init_pass(fr.dt, fr.spawn, fr.seed, fr.time, fr.transform)
         wfx.update_pass(fr.dt, fr.seed, fr.time, fr.transform)
         if resync or f % check_every == 0 or f == len(frames) - 1:
-            worst = max(worst, compare(orc, wfx, f"{what} frame {f}", before if resync else None, sorted_list=ribbons))
+            worst = max(worst, compare(orc, wfx, f"{what} frame {f}", before if resync else None, sorted_list=ribbons, impulse=impulse))
         if resync:
             before = orc.state()["attrs"]
             for name, ref_bits in before.items():
@@ -127,7 +130,10 @@ def test_c3_force_field():
     asset = effects.force_field(3000)
     frames = burst_then_run(3000, 100)
     frames[40].props = {"repulsor_position": (0.1, 0.2, 0.0), "repulsor_accel": -25.0}
-    print("c3 worst relative difference (one-frame map)", play(asset, frames, what="c3", resync=True))
+    # (force_field.rs: attraction_accel 20, repulsor up to 25 in this script, 1/60 s frames: a frame changes a velocity by up to 25 / 60; a
+    # component left over from cancelling such an impulse carries the impulse's rounding error, not one of its own size. Which frame
+    # meets such a corner depends on the trajectory: it moved when hanabi-math v3 changed the last bits of the spawn positions.)
+    print("c3 worst relative difference (one-frame map)", play(asset, frames, what="c3", resync=True, impulse=25.0 / 60.0))
 
 
 def test_c4_instancing_with_churn():
