@@ -84,7 +84,8 @@ def _assert_close_state(ref, got, what, lists_only=False):
             continue
         a = ref["attrs"][k].view(np.float32).astype(np.float64)
         b = got["attrs"][k].view(np.float32).astype(np.float64)
-        ok = ~(np.isnan(a).any(axis=1) & np.isnan(b).any(axis=1))
+        assert (np.isnan(a) == np.isnan(b)).all(), f"{what}: {k}: NaNs in different places"
+        ok = ~np.isnan(a).any(axis=1)
         err = np.linalg.norm(a[ok] - b[ok], axis=1)
         scale = np.maximum(np.linalg.norm(a[ok], axis=1), np.linalg.norm(b[ok], axis=1))
         bad = err > REL_TOL * scale
