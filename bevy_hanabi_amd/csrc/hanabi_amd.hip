@@ -21,6 +21,7 @@
 #include "hnb_jit.h"
 #include "hnb_sort.hip.h"
 #include "hnb_comm.h"
+#include "hnb_plan.h"
 
 using namespace hnb;
 
@@ -184,72 +185,27 @@ struct HnbProgram {
     unsigned long long* h_ev_counts = nullptr;  // host-mapped [table_cap][HNB_MAX_EVENT_CHANNELS] {frame, event count} written by k_emit_events (emitting programs)
     uint32_t level = 0;                   // dependency level: parents are simulated before their children
     uint32_t* d_counts = nullptr;  // per chunk: survivors this frame
-    uint32_t* d_gsums = nullptr;   // per group of kCountGroup chunks: their sum (CompactBufs::gsums)
     uint32_t* d_deaths = nullptr;  // [2][table_cap]: casualties per instance, frame-parity double-buffered
-    // per-frame parameter blocks: a ring, so that filling frame f+1..f+3 never waits for the GPU
-    bool lists_now = true;               // this frame needs k_count_rows / k_compact (false: the update rotated the counters itself)
-    bool lists_merged = false;           // ... and they are served by the context's multi-program launches after every update kernel
+    // ---- frame planning (hnb_plan.h): static facts, the history each proof carries, and the plan of the frame being enqueued ----
+    plan::SkipFacts skip_facts;             // list-free frames: eligible = streamable, lifetime-culled, no kill modifier, no spawn events in or out
+    plan::SkipHistory skip_hist;            // (skip_hist.dirty: something outside the frame inputs changed the particles since the last frame)
+    plan::RibbonFacts ribbon_facts;         // what program creation established about AGE / RIBBON_ID / LIFETIME of a ribbon effect
+    plan::RibbonHistory ribbon_hist;        // sticky violations, the one RIBBON_ID / lifetime value seen so far, the smallest tick
+    plan::FramePlan plan;                   // decided once per hnb_simulate, read by every launch of the frame
     const char* d_frame_cur = nullptr;  // this frame's parameter block of the program inside the context's staging slot (HnbContext::d_stage)
     uint32_t ring = 0;          // slot of the next frame
-    uint32_t init_blocks = 0;   // k_init grid of the frame being enqueued
     size_t frame_bytes = 0;
     uint32_t parity = 0;
     uint32_t frames_run = 0;    // frames this program was simulated in: the chunk walk alternates its direction with it
-    // "no particle can die before ..." (hnb_kernels.hip.h, SlotArgs): the update publishes a lower bound of the remaining life of
-    // every alive particle; while the ticks accumulated since stay below it, a frame without spawn needs no list kernels.
-    bool skip_eligible = false;             // streamable, lifetime-culled, no kill modifier: particles only die of old age
-    bool init_merged = false, update_merged = false;   // this frame: served by the job-table launches of small programs (k_init_jobs, k_update_*_jobs)
-    bool mergeable = false;                 // no spawn events in or out, no parent: its passes are independent of every other program's
     uint32_t merged_frames = 0;             // statistics
-    bool horizon_eligible = false;          // ... the same without the spawn-event restrictions: row-chunk death horizons are maintained (hnb_kernels.hip.h)
+    bool horizon_eligible = false;          // streamable, lifetime-culled, no kill modifier, no ribbons: row-chunk death horizons are maintained (hnb_kernels.hip.h)
     uint32_t hz_parity = 0;                 // which half of the horizon arrays is current (flips in frames whose list kernels ran)
-    bool hz_use_now = false;                // this frame's ticks are finite: k_count_rows may skip chunks
     uint32_t hz_frames = 0;                 // statistics: frames in which the horizons were in use
     uint32_t* d_safe = nullptr;             // u32[2][table_cap * chunks_per_inst] device words (allocated with the tables)
-    unsigned long long* h_safe = nullptr;   // host-mapped {tag, bound bits}
+    unsigned long long* h_safe = nullptr;   // host-mapped {tag, bound bits}: what prove_skip_lists reads (no read-back)
     uint32_t* d_fault = nullptr;            // set by the kernel if a particle died in a frame whose lists were skipped
-    double cum_tick[128] = {};              // sum of the AGE_TICK operands of frames 0..F, ring indexed by F & 127
-    uint32_t last_dirty = 0;                // a bound must come from this frame or later (spawn, host write, (un)freeze, unknown tick)
-    bool dirty = true;                      // something outside the frame inputs changed the particles since the last frame
     uint32_t skipped_frames = 0;            // statistics: frames whose list kernels were skipped
-    bool skip_now = false;                  // decision for the frame being enqueued
-    // Ribbon sort: can the host prove that the head of the list (everything but this frame's spawns) is still sorted? Then the
-    // radix range is at most the frame's spawns, which the host can bound. Static part (program creation): the update only
-    // advances AGE through its AGE_TICK and never stores RIBBON_ID, the init sets AGE from a uniform value or not at all.
-    bool sort_provable = false;
-    uint32_t sort_age_init_operand = 0;     // decoded U operand of the init stream's AGE assignment (valid if sort_age_init_set)
-    bool sort_age_init_set = false;
-    uint32_t sort_tick_operand = 0;         // decoded U operand of the update's AGE_TICK
-    bool sort_dirty = true;                 // a host write (or nothing yet) since the last sort: the whole list is the range
     uint32_t sort_parity = 0;               // frames in which the sort ran (its state double buffer)
-    uint32_t frame_max_spawn = 0;           // largest spawn request of an instance in the frame being enqueued
-    bool frame_sort_values_ok = false;      // this frame's init age and tick are >= +0 for every instance (and were in every earlier frame)
-    bool sort_values_broken = false;        // sticky: some frame had a negative / NaN tick or initial age. Negative ages can outlive that frame's
-                                            // (device-checked) sort, and when they cross zero later their bit-pattern keys change order although
-                                            // that later frame's own values are fine: from then on only the device-side order check decides
-    // ... and can it prove more: that this frame's spawns sort IN FRONT of every older particle? Then the sorted list is a rotation of the
-    // compacted list and no key is read: k_compact writes the survivors rotated (CompactArgs::rotate_front) and no sort kernel runs. Premises: one RIBBON_ID for every particle the effect ever had (set by the init from
-    // ONE uniform value that never changed, or never set: 0); spawns start at AGE +0 and the update ticks them once in their first frame,
-    // so the tail's keys are all (rid, tick_now); every older particle has age >= fl(t_g + tick_now) for the tick t_g of the frame
-    // it was spawned in (ages only grow: monotone addition), hence >= fl(min_tick + tick_now) with the smallest tick of any earlier
-    // frame: the host evaluates that f32 sum and asks for it to be > tick_now. A negative / NaN tick, a second RIBBON_ID value or a host
-    // write ends it for good.
-    bool sort_front_static = false;
-    uint32_t sort_life_operand = 0;         // decoded U operand of the init's LIFETIME assignment
-    uint32_t sort_rid_operand = 0;          // decoded U operand of the init's RIBBON_ID store (valid if sort_rid_set)
-    bool sort_rid_set = false;
-    bool sort_rid_known = false;
-    uint32_t sort_rid_value = 0;
-    bool sort_front_broken = false;
-    float sort_min_tick = __builtin_inff();
-    bool frame_sort_front = false;          // decision for the frame being enqueued
-    bool frame_rotate = false;              // ... together with everything else the rotation needs (the head provably sorted, no host write, spawns)
-    // "the casualties are the LAST rows of the sorted list": one ribbon, the list in age order, every particle with the same lifetime (one uniform
-    // value that never changed) - then `age + tick < lifetime` is monotone along the rows and k_count_rows has nothing to find out
-    // (CompactArgs::suffix_dead; k_compact verifies it against the died bits and raises `fault` otherwise)
-    bool sort_life_known = false, sort_life_changed = false;
-    uint32_t sort_life_value = 0;
-    bool frame_suffix = false;
     uint32_t suffix_frames = 0;             // statistics
     uint32_t sort_rotated_frames = 0;       // statistics: frames whose ribbon sort was a rotation
 };
@@ -619,7 +575,6 @@ void free_tables(HnbProgram* p) {
     hipFree(p->d_inst_base); p->d_inst_base = nullptr;
     for (int i = 0; i < 2; ++i) { hipFree(p->d_meta[i]); p->d_meta[i] = nullptr; }
     hipFree(p->d_counts); p->d_counts = nullptr;
-    hipFree(p->d_gsums); p->d_gsums = nullptr;
     hipFree(p->d_deaths); p->d_deaths = nullptr;
     hipFree(p->d_ev_totals); p->d_ev_totals = nullptr;
     if (p->h_ev_counts) hipHostFree(p->h_ev_counts);
@@ -651,10 +606,6 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
     const size_t n_counts = (size_t)cap * p->dev.chunks_per_inst;
     HIP_TRY(hipMalloc(&ns, n_counts * 4));
     HIP_TRY(hipMemset(ns, 0, n_counts * 4));
-    uint32_t* ng = nullptr;
-    const size_t n_groups = (size_t)cap * ((p->dev.chunks_per_inst + kCountGroup - 1u) / kCountGroup);
-    HIP_TRY(hipMalloc(&ng, n_groups * 4));
-    HIP_TRY(hipMemset(ng, 0, n_groups * 4));
     // casualty counters are zero between frames (k_compact re-arms them), so a fresh table is valid
     HIP_TRY(hipMalloc(&nd, (size_t)2 * cap * 4));
     HIP_TRY(hipMemset(nd, 0, (size_t)2 * cap * 4));
@@ -667,7 +618,6 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
     hipFree(p->d_meta[0]);
     hipFree(p->d_meta[1]);
     hipFree(p->d_counts);
-    hipFree(p->d_gsums);
     hipFree(p->d_deaths);
     if (p->dev.n_event_channels) {
         hipFree(p->d_ev_totals);
@@ -683,7 +633,6 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
     p->d_meta[0] = nm[0];
     p->d_meta[1] = nm[1];
     p->d_counts = ns;
-    p->d_gsums = ng;
     p->d_deaths = nd;
     {   // no-death bounds per chunk and frame parity: start at +inf; growing the tables restarts them (effect creation marks the program dirty)
         hipFree(p->d_safe);
@@ -691,7 +640,7 @@ int ensure_tables(HnbProgram* p, uint32_t need) {
         HIP_TRY(hipMalloc(&p->d_safe, 2 * n_counts * 4));
         std::vector<uint32_t> inf(2 * n_counts, 0x7f800000u);
         HIP_TRY(hipMemcpy(p->d_safe, inf.data(), inf.size() * 4, hipMemcpyHostToDevice));
-        p->dirty = true;
+        p->skip_hist.dirty = true;
     }
     p->frame_bytes = frame_bytes_for(p, cap);
     p->table_cap = cap;
@@ -931,13 +880,13 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
             p->jit_log = res.log;
         }
     }
-    if (p->has_ribbons && p->update_streams) {  // ribbon sort: static part of "the head stays sorted" (see HnbProgram::sort_provable)
+    if (p->has_ribbons && p->update_streams) {  // ribbon sort: static part of "the head stays sorted" (see plan::RibbonFacts::provable)
         bool ok = true;
         uint32_t ticks = 0;
         const Ins* uc = reinterpret_cast<const Ins*>(b + h.update_off);
         for (uint32_t i = 0; i < h.update_len && ok; ++i) {
             const uint32_t op = uc[i].x & 0xffu, dst = (uc[i].x >> 8) & 0xffu;
-            if (op == HNB_OP_M_AGE_TICK) { ticks += 1; p->sort_tick_operand = HNB_OPERAND_DECODE((uc[i].x >> 16) & 0xffu, uc[i].y >> 13); ok = (p->sort_tick_operand & HNB_OPERAND_DECODED_U) != 0; }
+            if (op == HNB_OP_M_AGE_TICK) { ticks += 1; p->ribbon_facts.tick_operand = HNB_OPERAND_DECODE((uc[i].x >> 16) & 0xffu, uc[i].y >> 13); ok = (p->ribbon_facts.tick_operand & HNB_OPERAND_DECODED_U) != 0; }
             if (op == HNB_OP_M_PIN_SET && dst == HNB_REG_AGE) ok = false;
         }
         ok = ok && ticks == 1;
@@ -947,16 +896,16 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
         for (uint32_t i = 0; i < h.init_len && ok; ++i) {
             const uint32_t op = ic[i].x & 0xffu, dst = (ic[i].x >> 8) & 0xffu, wd = ((ic[i].y >> 8) & 3u) + 1u;
             if (op == HNB_OP_M_PIN_SET && dst == HNB_REG_AGE) {
-                p->sort_age_init_operand = HNB_OPERAND_DECODE((ic[i].x >> 16) & 0xffu, ic[i].y >> 13);
-                p->sort_age_init_set = true;
-                ok = (p->sort_age_init_operand & HNB_OPERAND_DECODED_U) != 0;   // a per-particle age could be negative: key order != age order
+                p->ribbon_facts.age_init_operand = HNB_OPERAND_DECODE((ic[i].x >> 16) & 0xffu, ic[i].y >> 13);
+                p->ribbon_facts.age_init_set = true;
+                ok = (p->ribbon_facts.age_init_operand & HNB_OPERAND_DECODED_U) != 0;   // a per-particle age could be negative: key order != age order
             } else if (op != HNB_OP_STA && op != HNB_OP_ALIVE_SET && op != HNB_OP_ALIVE_AND && op != HNB_OP_KILL_IF && !(op >= HNB_OP_M_AGE_TICK) &&
                        dst <= HNB_REG_AGE && dst + wd > HNB_REG_AGE) {
                 ok = false;  // some other instruction writes the AGE register
             }
         }
-        p->sort_provable = ok;
-        // the front proof (see HnbProgram::sort_front_static): RIBBON_ID stored at most once by the init, from a uniform value
+        p->ribbon_facts.provable = ok;
+        // the front proof (see plan::RibbonFacts::front_static): RIBBON_ID stored at most once by the init, from a uniform value
         int rid_index = -1;
         for (uint32_t a = 0; a < h.n_attrs; ++a) if (p->attrs[a].attr == HNB_ATTR_RIBBON_ID) rid_index = (int)a;
         uint32_t rid_stores = 0;
@@ -965,11 +914,11 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
             const uint32_t op = ic[i].x & 0xffu;
             if (op == HNB_OP_STA && (ic[i].y >> 16) == (uint32_t)rid_index) {
                 rid_stores += 1;
-                p->sort_rid_operand = HNB_OPERAND_DECODE((ic[i].x >> 16) & 0xffu, ic[i].y >> 13);
-                front = (p->sort_rid_operand & HNB_OPERAND_DECODED_U) != 0;
+                p->ribbon_facts.rid_operand = HNB_OPERAND_DECODE((ic[i].x >> 16) & 0xffu, ic[i].y >> 13);
+                front = (p->ribbon_facts.rid_operand & HNB_OPERAND_DECODED_U) != 0;
             }
         }
-        p->sort_rid_set = rid_stores == 1;
+        p->ribbon_facts.rid_set = rid_stores == 1;
         // ... and every spawn must still be in the list when it is sorted (the rotation moves exactly `spawned` rows): nothing but old age
         // kills, and the lifetime - one uniform value, compared with the tick per frame - outlasts the first frame
         uint32_t life_sets = 0;
@@ -977,8 +926,8 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
             const uint32_t op = ic[i].x & 0xffu, dst = (ic[i].x >> 8) & 0xffu, wd = ((ic[i].y >> 8) & 3u) + 1u;
             if (op == HNB_OP_M_PIN_SET && dst == HNB_REG_LIFETIME) {
                 life_sets += 1;
-                p->sort_life_operand = HNB_OPERAND_DECODE((ic[i].x >> 16) & 0xffu, ic[i].y >> 13);
-                front = (p->sort_life_operand & HNB_OPERAND_DECODED_U) != 0;
+                p->ribbon_facts.life_operand = HNB_OPERAND_DECODE((ic[i].x >> 16) & 0xffu, ic[i].y >> 13);
+                front = (p->ribbon_facts.life_operand & HNB_OPERAND_DECODED_U) != 0;
             } else if (op != HNB_OP_STA && op != HNB_OP_ALIVE_SET && op != HNB_OP_ALIVE_AND && op != HNB_OP_KILL_IF && !(op >= HNB_OP_M_AGE_TICK) &&
                        dst <= HNB_REG_LIFETIME && dst + wd > HNB_REG_LIFETIME) {
                 front = false;  // some other instruction writes the LIFETIME register
@@ -989,7 +938,7 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
             if (op == HNB_OP_M_KILL_SPHERE || op == HNB_OP_M_KILL_AABB || op == HNB_OP_KILL_IF || op == HNB_OP_ALIVE_SET || op == HNB_OP_ALIVE_AND) front = false;
             if (op == HNB_OP_M_PIN_SET && dst == HNB_REG_LIFETIME) front = false;
         }
-        p->sort_front_static = front && rid_stores <= 1 && life_sets == 1;
+        p->ribbon_facts.front_static = front && rid_stores <= 1 && life_sets == 1;
     }
     {
         bool kills = false;
@@ -998,7 +947,8 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
             const uint32_t op = uc[i].x & 0xffu;
             kills = kills || op == HNB_OP_M_KILL_SPHERE || op == HNB_OP_M_KILL_AABB;
         }
-        p->skip_eligible = p->update_streams && d.cull_lifetime && !kills && h.n_event_channels == 0 && !(h.flags & HNB_PROG_READS_PARENT);
+        p->skip_facts.eligible = p->update_streams && d.cull_lifetime && !kills && h.n_event_channels == 0 && !(h.flags & HNB_PROG_READS_PARENT);
+        p->skip_facts.dt_operand = p->cull_dt_operand;
         p->horizon_eligible = p->update_streams && d.cull_lifetime && !kills && !p->has_ribbons && !p->slot_order && ctx->popt.horizon;
         if (hipMalloc(&p->d_fault, 4) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void**>(&p->h_safe), 8, hipHostMallocDefault) != hipSuccess) {
@@ -1180,7 +1130,7 @@ int hnb_effect_create(HnbProgram* p, uint32_t slot_base, HnbEffect** out_fx) {
         for (uint32_t c = 0; c < pe.ncomp; ++c) fx->props[pe.word_offset + c] = pe.default_bits[c];
     p->effects.push_back(fx);
     p->dev.n_inst = (uint32_t)p->effects.size();
-    p->dirty = true;
+    p->skip_hist.dirty = true;
     *out_fx = fx;
     return HNB_OK;
 }
@@ -1215,7 +1165,7 @@ int hnb_effect_destroy(HnbEffect* fx) {
     }
     p->effects.pop_back();
     p->dev.n_inst = (uint32_t)p->effects.size();
-    p->dirty = true;
+    p->skip_hist.dirty = true;
     p->free_slabs.push_back(fx->slab);  // the block itself is released with the program
     delete fx;
     return HNB_OK;
@@ -1271,7 +1221,7 @@ int hnb_effect_set_parent(HnbEffect* child, HnbEffect* parent, uint32_t channel,
     ch.child = child;
     child->parent = parent;
     child->parent_channel = channel;
-    cp->dirty = true;
+    cp->skip_hist.dirty = true;
     // parents before children: dependency level per program. The program graph is acyclic (checked above), so the levels
     // settle within one pass per program; the bound is a backstop, never a hang.
     const size_t n_prog = cp->ctx->programs.size();
@@ -1321,7 +1271,7 @@ int hnb_effect_index(HnbEffect* fx, uint32_t* out_index) {
 
 int hnb_effect_set_simulated(HnbEffect* fx, int simulated) {
     if (!fx) return fail(HNB_ERR_INVALID_ARG, "fx is NULL");
-    if (fx->simulated != (simulated != 0)) fx->prog->dirty = true;  // a thawed instance ages again: older no-death bounds do not cover it
+    if (fx->simulated != (simulated != 0)) fx->prog->skip_hist.dirty = true;  // a thawed instance ages again: older no-death bounds do not cover it
     fx->simulated = simulated != 0;
     return HNB_OK;
 }
@@ -1345,8 +1295,6 @@ static CompactBufs compact_bufs_of(const HnbContext* ctx, const HnbProgram* p, u
     cb.table_cap = p->table_cap;
     cb.parity = p->parity;
     cb.ev_totals = p->d_ev_totals;
-    cb.gsums = p->d_gsums;
-    cb.groups_per_inst = (p->dev.chunks_per_inst + kCountGroup - 1u) / kCountGroup;
     cb.xcd_remap = (n > 1 ? 1u : 0u) | (ctx->alternate && !(p->frames_run & 1u) ? 2u : 0u);  // see chunk_of_workgroup; the first frame walks DOWN: a burst's init wrote the planes upwards
     return cb;
 }
@@ -1363,8 +1311,8 @@ static SlotArgs slot_args_of(const HnbContext* ctx, const HnbProgram* p, uint32_
     sa.age_cohort = p->dev.age_cohort;
     sa.frame_phase = p->frames_run & 15u;
     sa.horizon_off = p->dev.horizon_off; sa.horizon = p->horizon_eligible ? 1u : 0u;
-    if (p->skip_eligible) { sa.safe_words = p->d_safe; sa.safe_host = p->h_safe; sa.safe_parity = p->frames_run & 1u; sa.publish_tag = p->frames_run - 1u; sa.safe_stride = p->table_cap * p->dev.chunks_per_inst; }
-    sa.skip_lists = p->skip_now ? 1u : 0u;
+    if (p->skip_facts.eligible) { sa.safe_words = p->d_safe; sa.safe_host = p->h_safe; sa.safe_parity = p->frames_run & 1u; sa.publish_tag = p->frames_run - 1u; sa.safe_stride = p->table_cap * p->dev.chunks_per_inst; }
+    sa.skip_lists = p->plan.skip_lists ? 1u : 0u;
     sa.meta_in = p->d_meta[par]; sa.meta_out = p->d_meta[par ^ 1];
     sa.fault = p->d_fault;
     sa.transpose = ctx->transpose ? 1u : 0u;
@@ -1386,333 +1334,265 @@ static CompactArgs compact_args_of(const HnbProgram* p) {
     ca.alive_flag_off = p->dev.alive_flag_off;
     ca.died_bits_off = p->dev.died_bits_off; ca.row_mask_off = p->dev.row_mask_off;
     ca.horizon_off = p->dev.horizon_off;
-    ca.hz = p->horizon_eligible ? 1u : 0u; ca.hz_use = p->hz_use_now ? 1u : 0u; ca.hz_parity = p->hz_parity; ca.frame_no = p->frames_run;
+    ca.hz = p->horizon_eligible ? 1u : 0u; ca.hz_use = p->plan.hz_use ? 1u : 0u; ca.hz_parity = p->hz_parity; ca.frame_no = p->frames_run;
     ca.fault = p->d_fault;
     ca.slot_order = p->slot_order ? 1u : 0u;
-    ca.suffix_dead = p->frame_suffix ? 1u : 0u;
-    ca.rotate_front = p->frame_rotate ? 1u : 0u;   // k_compact writes the survivors [spawns | older ones]: see CompactArgs (ribbon programs never have slot-ordered lists)
+    ca.suffix_dead = p->plan.ribbon.suffix ? 1u : 0u;
+    ca.rotate_front = p->plan.ribbon.rotate ? 1u : 0u;   // k_compact writes the survivors [spawns | older ones]: see CompactArgs (ribbon programs never have slot-ordered lists)
     return ca;
 }
 
-// One simulated frame, in the reference's order (src/render/mod.rs:6975-7370): every effect's init
-// pass, parents before children, THEN every effect's update pass. Spawn events appended by a parent's
-// update in frame N are consumed by its children's init in frame N+1.
-int hnb_simulate(HnbContext* ctx) {
-    if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
-    HIP_TRY(hipSetDevice(ctx->device));
-    std::vector<HnbProgram*> order;
-    for (HnbProgram* p : ctx->programs)
-        if (!p->effects.empty()) order.push_back(p);
-    std::stable_sort(order.begin(), order.end(), [](const HnbProgram* x, const HnbProgram* y) { return x->level < y->level; });
-    const bool timed = ctx->timing && (ctx->timing_tick % ctx->timing) == 0;
-    const uint32_t ev_parity = ctx->frame & 1u;
-    // validate every instance before any per-frame state is touched: a failed call must leave the frame's inputs intact
-    for (HnbProgram* p : order)
-        if (!p->parent_attrs.empty())
-            for (size_t i = 0; i < p->effects.size(); ++i)
-                if (!p->effects[i]->parent)
-                    return fail(HNB_ERR_INVALID_ARG, "effect #%zu reads its parent particle (InheritAttributeModifier / parent_attr) but has no parent: call hnb_effect_set_parent", i);
-
-    // ---- per-frame parameters: filled into the program's next ring slot and uploaded on the upload stream. The host
-    // waits for the (tiny) copies itself, so the simulation stream carries no cross-stream wait: such a wait costs an
-    // ~11 us bubble in front of every frame's first kernel (measured), the host has ~200 us of slack per frame.
-    const uint32_t slot = ctx->frame % kFrameRing;
-    {
-        size_t need = 0;
-        for (const HnbProgram* p : order) need += (frame_bytes_for(p, (uint32_t)p->effects.size()) + 255u) & ~(size_t)255u;
-        need += order.size() * sizeof(ListsJob) + 256u;   // the job table of the multi-program list launches
-        need += order.size() * (2u * sizeof(ProgJob) + sizeof(StreamJob)) + 6u * 256u;   // ... and of the merged init / update launches of small programs
-        if (need > ctx->stage_bytes) {  // grows rarely (a new program, more instances): nothing may still be reading the old buffers
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            const size_t nb = std::max<size_t>(2 * need, 64u << 10);
-            for (uint32_t i = 0; i < kFrameRing; ++i) {
-                hipFree(ctx->d_stage[i]); ctx->d_stage[i] = nullptr;
-                if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
-                ctx->h_stage[i] = nullptr;
-            }
-            ctx->stage_bytes = 0;
-            for (uint32_t i = 0; i < kFrameRing; ++i) {
-                HIP_TRY(hipMalloc(&ctx->d_stage[i], nb));
-                HIP_TRY(hipHostMalloc(&ctx->h_stage[i], nb, hipHostMallocDefault));
-                if (!ctx->stage_done[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
-            }
-            ctx->stage_bytes = nb;
-        }
-        if (!order.empty()) HIP_TRY(hipEventSynchronize(ctx->stage_done[slot]));  // the frame that last used this slot (kFrameRing frames ago)
-    }
-    size_t stage_off = 0;
-    for (HnbProgram* p : order) {
-        const uint32_t n = (uint32_t)p->effects.size();
-        char* h = static_cast<char*>(ctx->h_stage[slot]) + stage_off;
-        p->d_frame_cur = static_cast<const char*>(ctx->d_stage[slot]) + stage_off;
-        DevFrameInst* fi = reinterpret_cast<DevFrameInst*>(h);
-        uint32_t* ublocks = reinterpret_cast<uint32_t*>(h + (size_t)n * sizeof(DevFrameInst));
-        const float sim[6] = {ctx->sim.time, ctx->sim.delta_time, ctx->sim.virtual_time, ctx->sim.virtual_delta_time,
-                              ctx->sim.real_time, ctx->sim.real_delta_time};
-        const uint32_t nu = p->dev.n_uregs;
-        uint32_t blocks = 0;
-        uint64_t cpu_spawns = 0;
-        for (uint32_t i = 0; i < n; ++i) if (p->effects[i]->simulated && !p->effects[i]->parent) cpu_spawns += p->effects[i]->spawn_count;
-        const bool big_burst = cpu_spawns >= (1ull << 20);
-        for (uint32_t i = 0; i < n; ++i) {
-            HnbEffect* fx = p->effects[i];
-            memset(&fi[i], 0, sizeof fi[i]);
-            fi[i].spawn_count = fx->parent ? 0u : fx->spawn_count;  // the CPU spawner of a child effect is unused (firework.rs:161)
-            fi[i].seed = fx->seed;
-            fi[i].slot_base = fx->slot_base;
-            fi[i].init_block_start = blocks;
-            fi[i].ev_parity = ev_parity;
-            fi[i].skip = fx->simulated ? 0u : 1u;
-            uint32_t max_request = fx->simulated ? fx->spawn_count : 0u;
-            if (fx->parent && fx->simulated) {
-                const EventChannel& ch = fx->parent->channels[fx->parent_channel];
-                fi[i].parent_base = reinterpret_cast<uint64_t>(fx->parent->slab);
-                fi[i].parent_planes = reinterpret_cast<uint64_t>(fx->parent->prog->d_plane_by_attr);
-                fi[i].ev_in = reinterpret_cast<uint64_t>(ch.buf);
-                max_request = ch.capacity;  // the event count lives on the device: launch for the worst case ...
-                // ... unless last frame's count has already arrived in host memory (k_emit_events): then the grid is sized for it. The kernel
-                // reads the true count itself and strides, so this only ever changes how many workgroups are launched - except for
-                // zero, which is exact (the tag says the copy is last frame's).
-                const HnbProgram* pp = fx->parent->prog;
-                if (pp->h_ev_counts && ctx->frame > 0u) {
-                    const unsigned long long v = *reinterpret_cast<volatile unsigned long long*>(pp->h_ev_counts + (size_t)fx->parent->index * HNB_MAX_EVENT_CHANNELS + fx->parent_channel);
-                    if ((uint32_t)v == ctx->frame - 1u) max_request = std::min<uint32_t>((uint32_t)(v >> 32), ch.capacity);
-                }
-            }
-            for (uint32_t c = 0; c < HNB_MAX_EVENT_CHANNELS; ++c) fi[i].ev_out[c] = reinterpret_cast<uint64_t>(fx->channels[c].buf);
-            // never launch more init workgroups than the capacity allows (max_spawn <= capacity)
-            const uint32_t cap_spawn = std::min(max_request, p->dev.capacity);
-            uint32_t inst_blocks = (uint32_t)(((uint64_t)cap_spawn + kInitBlock - 1) / kInitBlock);
-            // a large burst: kInitRounds groups of spawns per workgroup (k_init: the search for the instance, the parameter loads and the
-            // merge of the death horizons are per workgroup and pass)
-            if (big_burst) inst_blocks = (inst_blocks + kInitRounds - 1u) / kInitRounds;
-            // event-driven spawns: the count lives on the device, so launch a bounded grid that strides (k_init)
-            if (fx->parent) inst_blocks = std::min<uint32_t>(inst_blocks, ctx->num_cus * 8u);
-            blocks += inst_blocks;
-            memcpy(fi[i].xf, fx->xf, sizeof fx->xf);
-            // Parameter block: the uniform stream (literals, properties, sim params and every
-            // expression built only from them) evaluated here, once per instance per frame.
-            // (instances with the same property values share the result: thousands of instances of one effect cost one evaluation)
-            if (nu) {
-                if (i > 0 && fx->props == p->effects[i - 1]->props) memcpy(ublocks + (size_t)i * nu, ublocks + (size_t)(i - 1) * nu, (size_t)nu * 4);
-                else uniform_run(p->uniform_code.data(), (uint32_t)p->uniform_code.size(), fx->props.data(), sim, ublocks + (size_t)i * nu, nu);
-            }
-        }
-        {   // can this frame lose or gain a particle? (see SlotArgs in hnb_kernels.hip.h)
-            const uint32_t F = p->frames_run;
-            bool any_spawn = false, any_parent = false, tick_known = p->skip_eligible;
-            float tick = 0.0f;
-            bool have_tick = false;
-            for (uint32_t i = 0; i < n && p->skip_eligible; ++i) {
-                const HnbEffect* fx = p->effects[i];
-                any_parent = any_parent || fx->parent != nullptr;
-                if (!fx->simulated) continue;
-                any_spawn = any_spawn || fx->spawn_count != 0u;
-                float t;
-                memcpy(&t, ublocks + (size_t)i * nu + (p->cull_dt_operand & 0xffu), 4);
-                if (!have_tick) { tick = t; have_tick = true; }
-                else if (memcmp(&t, &tick, 4) != 0) tick_known = false;
-            }
-            if (!(tick >= 0.0f)) tick_known = false;  // negative or NaN ticks: no statement about the future
-            if (any_spawn || any_parent || p->dirty || !tick_known) p->last_dirty = F;  // only a bound computed in this frame or later covers it
-            p->dirty = false;
-            p->cum_tick[F & 127u] = (F ? p->cum_tick[(F - 1u) & 127u] : 0.0) + (tick_known ? (double)tick : 0.0);
-            if (p->has_ribbons) {
-                p->frame_max_spawn = 0;
-                bool ok = p->sort_provable;
-                for (uint32_t i = 0; i < n; ++i) {
-                    const HnbEffect* fx = p->effects[i];
-                    if (!fx->simulated) continue;
-                    const uint32_t req = fx->parent ? fx->parent->channels[fx->parent_channel].capacity : fx->spawn_count;
-                    p->frame_max_spawn = std::max(p->frame_max_spawn, std::min(req, p->dev.capacity));
-                    if (!ok) continue;
-                    const uint32_t* ub = ublocks + (size_t)i * nu;
-                    const uint32_t tick_bits = ub[p->sort_tick_operand & 0xffu];
-                    const uint32_t age_bits = p->sort_age_init_set ? ub[p->sort_age_init_operand & 0xffu] : 0u;
-                    ok = tick_bits <= 0x7f800000u && age_bits <= 0x7f800000u;   // >= +0 and not NaN: ages stay non-negative, key order == age order
-                }
-                if (p->sort_provable && !ok) p->sort_values_broken = true;
-                p->frame_sort_values_ok = ok && !p->sort_values_broken;
-                ok = p->frame_sort_values_ok;
-                // in front of everything? (HnbProgram::sort_front_static)
-                bool front = p->sort_front_static && ok && !p->sort_front_broken;
-                float tick_now = 0.0f, frame_min_tick = __builtin_inff();   // (the smallest tick of ANY simulated instance enters sort_min_tick)
-                bool have = false;
-                for (uint32_t i = 0; i < n; ++i) {
-                    const HnbEffect* fx = p->effects[i];
-                    if (!fx->simulated) continue;
-                    const uint32_t* ub = ublocks + (size_t)i * nu;
-                    const uint32_t tick_bits = ub[p->sort_tick_operand & 0xffu];
-                    const uint32_t age_bits = p->sort_age_init_set ? ub[p->sort_age_init_operand & 0xffu] : 0u;
-                    const uint32_t rid_bits = p->sort_rid_set ? ub[p->sort_rid_operand & 0xffu] : 0u;
-                    if (!(tick_bits <= 0x7f800000u)) p->sort_front_broken = true;   // a negative or NaN tick: ages are no longer what the proof assumes
-                    if (!p->sort_rid_known) { p->sort_rid_known = true; p->sort_rid_value = rid_bits; }
-                    else if (rid_bits != p->sort_rid_value) p->sort_front_broken = true;
-                    if (age_bits != 0u) front = false;   // spawns that do not start at +0 this frame
-                    const uint32_t life_bits = ub[p->sort_life_operand & 0xffu];
-                    if (!p->sort_life_known) { p->sort_life_known = true; p->sort_life_value = life_bits; }
-                    else if (life_bits != p->sort_life_value) p->sort_life_changed = true;   // older particles keep the lifetime they were born with
-                    float life, tk;
-                    memcpy(&life, &life_bits, 4);
-                    memcpy(&tk, &tick_bits, 4);
-                    if (!(life_bits < 0x7f800000u && tk < life)) front = false;   // a spawn would die in its first frame and miss the list
-                    float t;
-                    memcpy(&t, &tick_bits, 4);
-                    if (t == t) frame_min_tick = t < frame_min_tick ? t : frame_min_tick;
-                    if (!have) { tick_now = t; have = true; }
-                    else if (memcmp(&t, &tick_now, 4) != 0) front = false;
-                }
-                if (p->sort_front_broken || !have) front = false;
-                if (front) {
-                    volatile float bound = p->sort_min_tick + tick_now;   // f32, as the device adds (no contraction, no excess precision)
-                    front = tick_now > 0.0f && bound > tick_now;
-                }
-                p->frame_sort_front = front;
-                p->frame_rotate = front && p->sort_provable && p->frame_sort_values_ok && !p->sort_dirty && ctx->skip_lists && p->frame_max_spawn > 0u;
-                p->frame_suffix = front && p->sort_provable && p->frame_sort_values_ok && !p->sort_dirty && ctx->skip_lists && !p->sort_life_changed && ctx->suffix_proof;
-                if (have) p->sort_min_tick = frame_min_tick < p->sort_min_tick ? frame_min_tick : p->sort_min_tick;
-            }
-            p->skip_now = false;
-            if (p->skip_eligible && ctx->skip_lists && !any_spawn && !any_parent && tick_known) {
-                const unsigned long long pub = *reinterpret_cast<volatile unsigned long long*>(p->h_safe);
-                const uint32_t tag = (uint32_t)pub, bits = (uint32_t)(pub >> 32);
-                float bound;
-                memcpy(&bound, &bits, 4);
-                if (tag != 0xffffffffu && tag < F && tag >= p->last_dirty && F - tag <= 64u && bits <= 0x7f800000u) {
-                    const double ticks = p->cum_tick[F & 127u] - p->cum_tick[tag & 127u];   // frames tag+1 .. F
-                    p->skip_now = ticks * (1.0 + 1e-6) < (double)bound;
-                }
-            }
-        }
-        p->lists_now = !(p->update_streams && p->skip_now);  // false: proven no spawn, no casualty; the update kernel rotates the counters
-        // death horizons (hnb_kernels.hip.h): k_count_rows may skip row chunks iff every simulated instance's tick is finite this frame
-        p->hz_use_now = false;
-        if (p->horizon_eligible) {
-            bool finite = true;
-            for (uint32_t i = 0; i < n; ++i) {
-                if (!p->effects[i]->simulated) continue;
-                const uint32_t tb = ublocks[(size_t)i * nu + (p->cull_dt_operand & 0xffu)];
-                finite = finite && (tb & 0x7f800000u) != 0x7f800000u;
-            }
-            p->hz_use_now = finite;
-            if (finite && p->lists_now) p->hz_frames += 1;
-        }
-        p->dev.hz_parity = p->hz_parity;
-        p->dev.frame_no = p->frames_run;
-        p->lists_merged = false;
-        p->init_merged = p->update_merged = false;
-        p->mergeable = p->hdr.n_event_channels == 0 && !(p->hdr.flags & HNB_PROG_READS_PARENT) && n != 0u;
-        for (uint32_t i = 0; i < n; ++i) if (p->effects[i]->parent) p->mergeable = false;
-        uint32_t* init_start = ublocks + (size_t)n * nu;  // packed copy of init_block_start for k_init's search
-        for (uint32_t i = 0; i < n; ++i) init_start[i] = fi[i].init_block_start;
-        stage_off += (frame_bytes_for(p, n) + 255u) & ~(size_t)255u;
-        p->init_blocks = blocks;
-        p->dev.n_inst = n;
-    }
-    // Programs whose list kernels can share two launches (see ListsJob in hnb_kernels.hip.h): every program that needs its lists, except the
-    // slot-ordered ones (two more kernels of their own). Worth it from two programs on; timed frames keep one launch pair per program so that
-    // the per-program timings stay attributable.
-    const ListsJob* d_jobs = nullptr;
-    uint32_t n_jobs = 0, job_wgs = 0;
-    {
-        uint32_t candidates = 0;
-        for (const HnbProgram* p : order) candidates += (p->lists_now && !p->slot_order) ? 1u : 0u;
-        if (candidates >= 2u && !timed) {
-            ListsJob* jobs = reinterpret_cast<ListsJob*>(static_cast<char*>(ctx->h_stage[slot]) + stage_off);
-            d_jobs = reinterpret_cast<const ListsJob*>(static_cast<const char*>(ctx->d_stage[slot]) + stage_off);
-            for (HnbProgram* p : order) {
-                if (!(p->lists_now && !p->slot_order)) continue;
-                const uint32_t n = (uint32_t)p->effects.size();
-                ListsJob jb{};
-                jb.args = compact_args_of(p);
-                jb.cb = compact_bufs_of(ctx, p, n);
-                jb.inst_base = reinterpret_cast<const uint64_t*>(p->d_inst_base);
-                jb.meta_in = p->d_meta[p->parity];
-                jb.meta_out = p->d_meta[p->parity ^ 1u];
-                jb.fi = reinterpret_cast<const DevFrameInst*>(p->d_frame_cur);
-                jb.first_wg = job_wgs;
-                jb.n_wg = n * p->dev.chunks_per_inst;
-                job_wgs += jb.n_wg;
-                jobs[n_jobs++] = jb;
-                p->lists_merged = true;
-            }
-            stage_off += ((size_t)n_jobs * sizeof(ListsJob) + 255u) & ~(size_t)255u;
-        }
-    }
-    // Small programs share their init and update launches (ProgJob / StreamJob in hnb_kernels.hip.h): per kernel family one job table and one
-    // launch of the interpreter instantiation, from two programs on. "Small" = at most kSceneMaxChunks chunks and kSceneMaxInitBlocks init
-    // workgroups this frame; independent of every other program (no spawn events, no parent). Timed frames keep one launch per program.
+// ---- one simulated frame ---------------------------------------------------------------------------------------------------------------
+// hnb_simulate = (1) make room in the staging ring, (2) per program: stage the frame's inputs and PLAN the frame (hnb_plan.h: every
+// proof is a pure function, its result an immutable FramePlan), (3) fill the job tables of the launches several programs share,
+// (4) one upload, (5) every init pass, parents first, (6) every update pass with its list maintenance, (7) advance the frame.
+struct FrameJobs {           // the launches several programs share this frame (tables inside the frame's staging slot)
     struct Family { const void* d_jobs = nullptr; uint32_t n = 0, wgs = 0; };
-    Family fam_init[2], fam_generic[2], fam_stream[2];   // [wide register file] / [age cohorts]
-    if (ctx->scene_merge && !timed && order.size() >= 2u) {
-        auto small = [](const HnbProgram* p) { return p->mergeable && (uint64_t)p->effects.size() * p->dev.chunks_per_inst <= kSceneMaxChunks; };
-        // kinds: 0 init, 1 update on the V register file, 2 streaming update; v: wide register file (0, 1) / age cohorts (2).
-        // k_update_jobs serves streaming (no cohorts), streaming (cohorts), V register file (narrow) in this order: first_wg runs over its whole grid
-        auto member_of = [&](const HnbProgram* p, int kind, int v) {
-            if (!small(p)) return false;
-            if (kind == 0) return p->init_blocks != 0u && p->init_blocks <= kSceneMaxInitBlocks && p->dev.init_len <= kSceneMaxCodeLen && (p->wide_file ? 1 : 0) == v;
-            if (kind == 1) return !p->update_streams && p->dev.update_len <= kSceneMaxCodeLen && (p->wide_file ? 1 : 0) == v;
-            return p->update_streams && p->dev.update_len <= kSceneMaxCodeLen && (p->dev.age_cohort ? 1 : 0) == v;
-        };
-        auto count_of = [&](int kind, int v) { uint32_t m = 0; for (const HnbProgram* p : order) m += member_of(p, kind, v) ? 1u : 0u; return m; };
-        const bool shared_update = count_of(2, 0) + count_of(2, 1) + count_of(1, 0) >= 2u;
-        const int seq[6][2] = {{0, 0}, {0, 1}, {2, 0}, {2, 1}, {1, 0}, {1, 1}};
-        uint32_t update_base = 0;
-        for (const auto& kv : seq) {
-            const int kind = kv[0], v = kv[1];
-            auto member = [&](const HnbProgram* p) { return member_of(p, kind, v); };
-            const bool in_shared = kind == 2 || (kind == 1 && v == 0);
-            if (in_shared ? !shared_update : count_of(kind, v) < 2u) continue;
-            if (count_of(kind, v) == 0u) continue;
-            Family& f = kind == 0 ? fam_init[v] : kind == 1 ? fam_generic[v] : fam_stream[v];
-            const uint32_t base = in_shared ? update_base : 0u;
-            char* hj = static_cast<char*>(ctx->h_stage[slot]) + stage_off;
-            f.d_jobs = static_cast<const char*>(ctx->d_stage[slot]) + stage_off;
-            for (HnbProgram* p : order) {
-                if (!member(p)) continue;
-                const uint32_t n = (uint32_t)p->effects.size();
-                const char* d = p->d_frame_cur;
-                const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
-                const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
-                const uint32_t write_died = (p->lists_now && !p->slot_order) ? 1u : 0u;
-                const uint32_t wgs = kind == 0 ? p->init_blocks : n * p->dev.chunks_per_inst * (kind == 1 ? kGenericSubs : 1u);
-                if (kind == 2) {
-                    StreamJob jb{};
-                    jb.args = slot_args_of(ctx, p, n, write_died);
-                    jb.inst_base = reinterpret_cast<const uint64_t*>(p->d_inst_base); jb.fi = dfi; jb.ublocks = dub;
-                    jb.cb = compact_bufs_of(ctx, p, n);
-                    jb.first_wg = base + f.wgs; jb.n_wg = wgs;
-                    reinterpret_cast<StreamJob*>(hj)[f.n] = jb;
-                } else {
-                    ProgJob jb{};
-                    jb.prog = p->dev;
-                    jb.inst_base = reinterpret_cast<const uint64_t*>(p->d_inst_base); jb.meta_in = p->d_meta[p->parity]; jb.fi = dfi; jb.ublocks = dub;
-                    jb.cb = compact_bufs_of(ctx, p, n);
-                    jb.write_died = write_died;
-                    jb.first_wg = base + f.wgs; jb.n_wg = wgs;
-                    reinterpret_cast<ProgJob*>(hj)[f.n] = jb;
-                }
-                f.n += 1; f.wgs += wgs;
-                if (kind == 0) p->init_merged = true; else { p->update_merged = true; p->merged_frames += 1; }
+    const ListsJob* d_lists = nullptr;
+    uint32_t n_lists = 0, lists_wgs = 0;
+    Family init[2], generic[2], stream[2];   // [wide register file] / [age cohorts]
+};
+
+// (1) The per-frame parameters of every program are filled into the context's next ring slot and uploaded on the upload stream. The host
+// waits for the (tiny) copy itself, so the simulation stream carries no cross-stream wait: such a wait costs an ~11 us bubble in front
+// of every frame's first kernel (measured), the host has ~200 us of slack per frame.
+static int ensure_stage(HnbContext* ctx, const std::vector<HnbProgram*>& order, uint32_t slot) {
+    size_t need = 0;
+    for (const HnbProgram* p : order) need += (frame_bytes_for(p, (uint32_t)p->effects.size()) + 255u) & ~(size_t)255u;
+    need += order.size() * sizeof(ListsJob) + 256u;   // the job table of the multi-program list launches
+    need += order.size() * (2u * sizeof(ProgJob) + sizeof(StreamJob)) + 6u * 256u;   // ... and of the merged init / update launches of small programs
+    if (need > ctx->stage_bytes) {  // grows rarely (a new program, more instances): nothing may still be reading the old buffers
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const size_t nb = std::max<size_t>(2 * need, 64u << 10);
+        for (uint32_t i = 0; i < kFrameRing; ++i) {
+            hipFree(ctx->d_stage[i]); ctx->d_stage[i] = nullptr;
+            if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
+            ctx->h_stage[i] = nullptr;
+        }
+        ctx->stage_bytes = 0;
+        for (uint32_t i = 0; i < kFrameRing; ++i) {
+            HIP_TRY(hipMalloc(&ctx->d_stage[i], nb));
+            HIP_TRY(hipHostMalloc(&ctx->h_stage[i], nb, hipHostMallocDefault));
+            if (!ctx->stage_done[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
+        }
+        ctx->stage_bytes = nb;
+    }
+    if (!order.empty()) HIP_TRY(hipEventSynchronize(ctx->stage_done[slot]));  // the frame that last used this slot (kFrameRing frames ago)
+    return HNB_OK;
+}
+
+// (2) One program's inputs of the frame (DevFrameInst rows, parameter blocks, init grid) into the staging slot, and the frame's plan.
+static void stage_program_frame(HnbContext* ctx, HnbProgram* p, uint32_t slot, size_t& stage_off, std::vector<plan::InstanceFrame>& inst_frames) {
+    const uint32_t ev_parity = ctx->frame & 1u;
+    const uint32_t n = (uint32_t)p->effects.size();
+    char* h = static_cast<char*>(ctx->h_stage[slot]) + stage_off;
+    p->d_frame_cur = static_cast<const char*>(ctx->d_stage[slot]) + stage_off;
+    DevFrameInst* fi = reinterpret_cast<DevFrameInst*>(h);
+    uint32_t* ublocks = reinterpret_cast<uint32_t*>(h + (size_t)n * sizeof(DevFrameInst));
+    const float sim[6] = {ctx->sim.time, ctx->sim.delta_time, ctx->sim.virtual_time, ctx->sim.virtual_delta_time,
+                          ctx->sim.real_time, ctx->sim.real_delta_time};
+    const uint32_t nu = p->dev.n_uregs;
+    uint32_t blocks = 0;
+    uint64_t cpu_spawns = 0;
+    for (uint32_t i = 0; i < n; ++i) if (p->effects[i]->simulated && !p->effects[i]->parent) cpu_spawns += p->effects[i]->spawn_count;
+    const bool big_burst = cpu_spawns >= (1ull << 20);
+    inst_frames.assign(n, plan::InstanceFrame());
+    for (uint32_t i = 0; i < n; ++i) {
+        HnbEffect* fx = p->effects[i];
+        memset(&fi[i], 0, sizeof fi[i]);
+        fi[i].spawn_count = fx->parent ? 0u : fx->spawn_count;  // the CPU spawner of a child effect is unused (firework.rs:161)
+        fi[i].seed = fx->seed;
+        fi[i].slot_base = fx->slot_base;
+        fi[i].init_block_start = blocks;
+        fi[i].ev_parity = ev_parity;
+        fi[i].skip = fx->simulated ? 0u : 1u;
+        plan::InitGridInputs gi;
+        gi.simulated = fx->simulated; gi.has_parent = fx->parent != nullptr; gi.spawn_count = fx->spawn_count;
+        if (fx->parent && fx->simulated) {
+            const EventChannel& ch = fx->parent->channels[fx->parent_channel];
+            fi[i].parent_base = reinterpret_cast<uint64_t>(fx->parent->slab);
+            fi[i].parent_planes = reinterpret_cast<uint64_t>(fx->parent->prog->d_plane_by_attr);
+            fi[i].ev_in = reinterpret_cast<uint64_t>(ch.buf);
+            gi.event_capacity = ch.capacity;  // the event count lives on the device: the grid is sized for the worst case ...
+            // ... unless last frame's count has already arrived in host memory (k_emit_events writes {frame, count} there): plan::size_init_grid
+            const HnbProgram* pp = fx->parent->prog;
+            if (pp->h_ev_counts && ctx->frame > 0u) {
+                const unsigned long long v = *reinterpret_cast<volatile unsigned long long*>(pp->h_ev_counts + (size_t)fx->parent->index * HNB_MAX_EVENT_CHANNELS + fx->parent_channel);
+                gi.events_known = (uint32_t)v == ctx->frame - 1u;
+                gi.known_events = (uint32_t)(v >> 32);
             }
-            stage_off += ((size_t)f.n * (kind == 2 ? sizeof(StreamJob) : sizeof(ProgJob)) + 255u) & ~(size_t)255u;
-            if (in_shared) update_base += f.wgs;
+        }
+        for (uint32_t c = 0; c < HNB_MAX_EVENT_CHANNELS; ++c) fi[i].ev_out[c] = reinterpret_cast<uint64_t>(fx->channels[c].buf);
+        blocks += plan::size_init_grid(gi, p->dev.capacity, kInitBlock, kInitRounds, big_burst, ctx->num_cus);
+        plan::InstanceFrame& inf = inst_frames[i];
+        inf.simulated = fx->simulated; inf.has_parent = fx->parent != nullptr; inf.spawn_count = fx->spawn_count;
+        inf.event_capacity = fx->parent ? fx->parent->channels[fx->parent_channel].capacity : 0u;
+        inf.ublock = ublocks + (size_t)i * nu;
+        memcpy(fi[i].xf, fx->xf, sizeof fx->xf);
+        // Parameter block: the uniform stream (literals, properties, sim params and every
+        // expression built only from them) evaluated here, once per instance per frame.
+        // (instances with the same property values share the result: thousands of instances of one effect cost one evaluation)
+        if (nu) {
+            if (i > 0 && fx->props == p->effects[i - 1]->props) memcpy(ublocks + (size_t)i * nu, ublocks + (size_t)(i - 1) * nu, (size_t)nu * 4);
+            else uniform_run(p->uniform_code.data(), (uint32_t)p->uniform_code.size(), fx->props.data(), sim, ublocks + (size_t)i * nu, nu);
         }
     }
-    if (stage_off) {
-        HIP_TRY(hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], stage_off, hipMemcpyHostToDevice, ctx->upload_stream));
-        HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
+    // ---- the frame's proofs (hnb_plan.h): pure functions of the facts fixed at program creation, the history they carry and these inputs
+    plan::FramePlan& pl = p->plan;
+    pl = plan::FramePlan();
+    {
+        const unsigned long long pub = *reinterpret_cast<volatile unsigned long long*>(p->h_safe);   // {frame, bound} the device published: no read-back
+        pl.skip_lists = plan::prove_skip_lists(p->skip_facts, p->skip_hist, p->frames_run, inst_frames.data(), n, plan::SkipPublished{(uint32_t)pub, (uint32_t)(pub >> 32)}, ctx->skip_lists);
+    }
+    if (p->has_ribbons) pl.ribbon = plan::prove_ribbon_order(p->ribbon_facts, p->ribbon_hist, p->dev.capacity, inst_frames.data(), n, ctx->skip_lists, ctx->suffix_proof);
+    pl.lists = !(p->update_streams && pl.skip_lists);  // false: proven no spawn, no casualty; the update kernel rotates the counters
+    pl.hz_use = plan::horizon_usable(p->horizon_eligible, p->cull_dt_operand, inst_frames.data(), n);   // k_count_rows may skip row chunks
+    if (pl.hz_use && pl.lists) p->hz_frames += 1;
+    p->dev.hz_parity = p->hz_parity;
+    p->dev.frame_no = p->frames_run;
+    pl.independent = p->hdr.n_event_channels == 0 && !(p->hdr.flags & HNB_PROG_READS_PARENT) && n != 0u;
+    for (uint32_t i = 0; i < n; ++i) if (p->effects[i]->parent) pl.independent = false;
+    uint32_t* init_start = ublocks + (size_t)n * nu;  // packed copy of init_block_start for k_init's search
+    for (uint32_t i = 0; i < n; ++i) init_start[i] = fi[i].init_block_start;
+    stage_off += (frame_bytes_for(p, n) + 255u) & ~(size_t)255u;
+    pl.init_blocks = blocks;
+    p->dev.n_inst = n;
+
+}
+
+// (3a) Programs whose list kernels can share two launches
+static void fill_lists_jobs(HnbContext* ctx, const std::vector<HnbProgram*>& order, uint32_t slot, size_t& stage_off, bool timed, FrameJobs& jobs_out) {
+    uint32_t candidates = 0;
+    for (const HnbProgram* p : order) candidates += (p->plan.lists && !p->slot_order) ? 1u : 0u;
+    if (candidates >= 2u && !timed) {
+        ListsJob* jobs = reinterpret_cast<ListsJob*>(static_cast<char*>(ctx->h_stage[slot]) + stage_off);
+        jobs_out.d_lists = reinterpret_cast<const ListsJob*>(static_cast<const char*>(ctx->d_stage[slot]) + stage_off);
+        for (HnbProgram* p : order) {
+            if (!(p->plan.lists && !p->slot_order)) continue;
+            const uint32_t n = (uint32_t)p->effects.size();
+            ListsJob jb{};
+            jb.args = compact_args_of(p);
+            jb.cb = compact_bufs_of(ctx, p, n);
+            jb.inst_base = reinterpret_cast<const uint64_t*>(p->d_inst_base);
+            jb.meta_in = p->d_meta[p->parity];
+            jb.meta_out = p->d_meta[p->parity ^ 1u];
+            jb.fi = reinterpret_cast<const DevFrameInst*>(p->d_frame_cur);
+            jb.first_wg = jobs_out.lists_wgs;
+            jb.n_wg = n * p->dev.chunks_per_inst;
+            jobs_out.lists_wgs += jb.n_wg;
+            jobs[jobs_out.n_lists++] = jb;
+            p->plan.lists_merged = true;
+        }
+        stage_off += ((size_t)jobs_out.n_lists * sizeof(ListsJob) + 255u) & ~(size_t)255u;
     }
 
-    // ---- phase A: init passes, parents first ---------------------------------------------------------------
+}
+
+// (3b) Small programs share their init and update launches
+static void fill_merge_jobs(HnbContext* ctx, const std::vector<HnbProgram*>& order, uint32_t slot, size_t& stage_off, bool timed, FrameJobs& fj) {
+    std::vector<plan::MergeFacts> facts(order.size());
+    std::vector<plan::MergeDecision> decisions(order.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        const HnbProgram* p = order[i];
+        plan::MergeFacts& f = facts[i];
+        f.independent = p->plan.independent;
+        f.total_chunks = (uint32_t)std::min<uint64_t>((uint64_t)p->effects.size() * p->dev.chunks_per_inst, 0xffffffffull);
+        f.init_blocks = p->plan.init_blocks; f.init_len = p->dev.init_len; f.update_len = p->dev.update_len;
+        f.wide_file = p->wide_file; f.update_streams = p->update_streams; f.age_cohort = p->dev.age_cohort != 0u;
+    }
+    plan::MergeLimits lim;
+    lim.max_chunks = kSceneMaxChunks; lim.max_init_blocks = kSceneMaxInitBlocks; lim.max_code_len = kSceneMaxCodeLen;
+    plan::plan_merged_launches(facts.data(), decisions.data(), (uint32_t)order.size(), ctx->scene_merge, timed, lim);
+    for (size_t i = 0; i < order.size(); ++i) order[i]->plan.merge = decisions[i];
+    // k_update_jobs serves streaming (no cohorts), streaming (cohorts), V register file (narrow) in this order: first_wg runs over its whole grid
+    const int seq[6][2] = {{0, 0}, {0, 1}, {2, plan::kStream}, {2, plan::kStreamCohort}, {1, plan::kGeneric}, {1, plan::kGenericWide}};   // {kind: 0 init / 1 generic / 2 stream, family}
+    uint32_t update_base = 0;
+    for (const auto& kv : seq) {
+        const int kind = kv[0], fam = kv[1];
+        auto member = [&](const HnbProgram* p) { return kind == 0 ? p->plan.merge.init_family == fam : p->plan.merge.update_family == fam; };
+        const bool in_shared = kind == 2 || fam == plan::kGeneric;
+        FrameJobs::Family& f = kind == 0 ? fj.init[fam] : kind == 1 ? fj.generic[fam == plan::kGenericWide ? 1 : 0] : fj.stream[fam == plan::kStreamCohort ? 1 : 0];
+        const uint32_t base = in_shared ? update_base : 0u;
+        char* hj = static_cast<char*>(ctx->h_stage[slot]) + stage_off;
+        f.d_jobs = static_cast<const char*>(ctx->d_stage[slot]) + stage_off;
+        for (HnbProgram* p : order) {
+            if (!member(p)) continue;
+            const uint32_t n = (uint32_t)p->effects.size();
+            const char* d = p->d_frame_cur;
+            const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
+            const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
+            const uint32_t write_died = (p->plan.lists && !p->slot_order) ? 1u : 0u;
+            const uint32_t wgs = kind == 0 ? p->plan.init_blocks : n * p->dev.chunks_per_inst * (kind == 1 ? kGenericSubs : 1u);
+            if (kind == 2) {
+                StreamJob jb{};
+                jb.args = slot_args_of(ctx, p, n, write_died);
+                jb.inst_base = reinterpret_cast<const uint64_t*>(p->d_inst_base); jb.fi = dfi; jb.ublocks = dub;
+                jb.cb = compact_bufs_of(ctx, p, n);
+                jb.first_wg = base + f.wgs; jb.n_wg = wgs;
+                reinterpret_cast<StreamJob*>(hj)[f.n] = jb;
+            } else {
+                ProgJob jb{};
+                jb.prog = p->dev;
+                jb.inst_base = reinterpret_cast<const uint64_t*>(p->d_inst_base); jb.meta_in = p->d_meta[p->parity]; jb.fi = dfi; jb.ublocks = dub;
+                jb.cb = compact_bufs_of(ctx, p, n);
+                jb.write_died = write_died;
+                jb.first_wg = base + f.wgs; jb.n_wg = wgs;
+                reinterpret_cast<ProgJob*>(hj)[f.n] = jb;
+            }
+            f.n += 1; f.wgs += wgs;
+            if (kind != 0) p->merged_frames += 1;
+        }
+        stage_off += ((size_t)f.n * (kind == 2 ? sizeof(StreamJob) : sizeof(ProgJob)) + 255u) & ~(size_t)255u;
+        if (in_shared) update_base += f.wgs;
+    }
+
+}
+
+// ribbon sort of a program's compacted lists by (RIBBON_ID, AGE) (src/render/mod.rs:7372-7612)
+static void enqueue_ribbon_sort(HnbContext* ctx, HnbProgram* p) {
+    const uint32_t n = (uint32_t)p->effects.size();
+    const uint32_t par = p->parity;
+    // The list is last frame's sorted list minus the casualties (stable compaction), every age advanced by the same
+    // non-negative tick (monotone under rounding; non-negative floats order like their bits), plus this frame's spawns
+    // at the end. Where the host can prove the premises (plan::RibbonFacts::provable + this frame's values + no host write)
+    // the radix range is at most the largest spawn request: nothing to do without spawns, one single-workgroup launch
+    // for a small range. Otherwise the device decides (k_sort_fill's order check) and all launches are issued.
+    const bool proven = p->plan.ribbon.head_sorted;
+    if (proven && p->plan.ribbon.max_spawn == 0u) return;
+    if (p->plan.ribbon.rotate) {  // the spawns go in front and k_compact has written the survivors in that order (CompactArgs::rotate_front): nothing to sort
+        p->sort_rotated_frames += 1;
+        return;
+    }
+    SortArgs so = p->sort;
+    so.parity = p->sort_parity & 1u;
+    p->sort_parity += 1;
+    const DevMeta* mo = p->d_meta[par ^ 1];
+    const uint32_t tiles = n * so.chunks_per_inst;
+    k_sort_fill<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+    // ... or when the whole list is small: whatever range the device finds, one workgroup sorts it faster than sixteen launches
+    // are issued (a 40-particle lightning bolt whose ages are not provably ordered took 8 + 8 empty launches per frame)
+    if ((proven && p->plan.ribbon.max_spawn <= kSortSmallMax) || p->dev.capacity <= kSortSmallMax / 4u) {
+        k_sort_small<<<n, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+    } else {
+        for (uint32_t pass = 0; pass < 8; ++pass) {
+            k_sort_hist<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
+            k_sort_scatter<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
+        }
+    }
+    k_sort_merge<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+    p->ribbon_hist.dirty = false;
+}
+
+// (5) init passes, parents first
+static int enqueue_init_passes(HnbContext* ctx, const std::vector<HnbProgram*>& order, const FrameJobs& fj, bool timed) {
     for (HnbProgram* p : order) {
         const uint32_t n = (uint32_t)p->effects.size();
         const uint32_t par = p->parity;
-        const uint32_t blocks = p->init_blocks;
+        const uint32_t blocks = p->plan.init_blocks;
         const char* d = p->d_frame_cur;
         const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
         const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
-        if (blocks && !p->init_merged) {
+        if (blocks && !(p->plan.merge.init_family >= 0)) {
             TimingPair ti{};
             ti.prog = p;
             if (timed) { ti.a = take_event(ctx); ti.b = take_event(ctx); hipEventRecord(ti.a, ctx->stream); }
@@ -1729,51 +1609,19 @@ int hnb_simulate(HnbContext* ctx) {
     }
 
     // (the merged programs have no parent and no child: their init passes are independent of the ones above)
-    if (fam_init[0].n) k_init_jobs<InterpCode><<<fam_init[0].wgs, kInitBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fam_init[0].d_jobs), fam_init[0].n);
-    if (fam_init[1].n) k_init_jobs<InterpCodeWide><<<fam_init[1].wgs, kInitBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fam_init[1].d_jobs), fam_init[1].n);
+    if (fj.init[0].n) k_init_jobs<InterpCode><<<fj.init[0].wgs, kInitBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fj.init[0].d_jobs), fj.init[0].n);
+    if (fj.init[1].n) k_init_jobs<InterpCodeWide><<<fj.init[1].wgs, kInitBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fj.init[1].d_jobs), fj.init[1].n);
+    return HNB_OK;
+}
 
-    // ribbon sort of a program's compacted lists by (RIBBON_ID, AGE) (src/render/mod.rs:7372-7612)
-    auto ribbon_sort = [ctx](HnbProgram* p) {
-        const uint32_t n = (uint32_t)p->effects.size();
-        const uint32_t par = p->parity;
-        // The list is last frame's sorted list minus the casualties (stable compaction), every age advanced by the same
-        // non-negative tick (monotone under rounding; non-negative floats order like their bits), plus this frame's spawns
-        // at the end. Where the host can prove the premises (HnbProgram::sort_provable + this frame's values + no host write)
-        // the radix range is at most the largest spawn request: nothing to do without spawns, one single-workgroup launch
-        // for a small range. Otherwise the device decides (k_sort_fill's order check) and all launches are issued.
-        const bool proven = p->sort_provable && p->frame_sort_values_ok && !p->sort_dirty && ctx->skip_lists;
-        if (proven && p->frame_max_spawn == 0u) return;
-        if (p->frame_rotate) {  // the spawns go in front and k_compact has written the survivors in that order (CompactArgs::rotate_front): nothing to sort
-            p->sort_rotated_frames += 1;
-            return;
-        }
-        SortArgs so = p->sort;
-        so.parity = p->sort_parity & 1u;
-        p->sort_parity += 1;
-        const DevMeta* mo = p->d_meta[par ^ 1];
-        const uint32_t tiles = n * so.chunks_per_inst;
-        k_sort_fill<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
-        // ... or when the whole list is small: whatever range the device finds, one workgroup sorts it faster than sixteen launches
-        // are issued (a 40-particle lightning bolt whose ages are not provably ordered took 8 + 8 empty launches per frame)
-        if ((proven && p->frame_max_spawn <= kSortSmallMax) || p->dev.capacity <= kSortSmallMax / 4u) {
-            k_sort_small<<<n, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
-        } else {
-            for (uint32_t pass = 0; pass < 8; ++pass) {
-                k_sort_hist<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
-                k_sort_scatter<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
-            }
-        }
-        k_sort_merge<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
-        p->sort_dirty = false;
-    };
-
-    // ---- phase B: update + kill + compaction (+ spawn-event ordering) ------------------------------------
+// (6) update + kill + compaction (+ spawn-event ordering, + ribbon sort)
+static int enqueue_update_passes(HnbContext* ctx, const std::vector<HnbProgram*>& order, const FrameJobs& fj, bool timed) {
     // (the merged updates first: every init pass is enqueued, and a merged program's own list kernels may follow in the loop below)
-    if (fam_stream[0].wgs + fam_stream[1].wgs + fam_generic[0].wgs)
-        k_update_jobs<<<fam_stream[0].wgs + fam_stream[1].wgs + fam_generic[0].wgs, kBlock, 0, ctx->stream>>>(
-            static_cast<const StreamJob*>(fam_stream[0].d_jobs), fam_stream[0].n, static_cast<const StreamJob*>(fam_stream[1].d_jobs), fam_stream[1].n,
-            static_cast<const ProgJob*>(fam_generic[0].d_jobs), fam_generic[0].n, fam_stream[0].wgs, fam_stream[0].wgs + fam_stream[1].wgs);
-    if (fam_generic[1].wgs) k_update_generic_wide_jobs<<<fam_generic[1].wgs, kBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fam_generic[1].d_jobs), fam_generic[1].n);
+    if (fj.stream[0].wgs + fj.stream[1].wgs + fj.generic[0].wgs)
+        k_update_jobs<<<fj.stream[0].wgs + fj.stream[1].wgs + fj.generic[0].wgs, kBlock, 0, ctx->stream>>>(
+            static_cast<const StreamJob*>(fj.stream[0].d_jobs), fj.stream[0].n, static_cast<const StreamJob*>(fj.stream[1].d_jobs), fj.stream[1].n,
+            static_cast<const ProgJob*>(fj.generic[0].d_jobs), fj.generic[0].n, fj.stream[0].wgs, fj.stream[0].wgs + fj.stream[1].wgs);
+    if (fj.generic[1].wgs) k_update_generic_wide_jobs<<<fj.generic[1].wgs, kBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fj.generic[1].d_jobs), fj.generic[1].n);
     for (HnbProgram* p : order) {
         const uint32_t n = (uint32_t)p->effects.size();
         const uint32_t par = p->parity;
@@ -1786,8 +1634,8 @@ int hnb_simulate(HnbContext* ctx) {
         TimingPair tu{}, tc{};
         tu.prog = tc.prog = p;
         if (timed) { tu.a = take_event(ctx); tu.b = take_event(ctx); tc.b = take_event(ctx); hipEventRecord(tu.a, ctx->stream); }
-        const uint32_t write_died = (p->lists_now && !p->slot_order) ? 1u : 0u;   // k_count_rows follows: the update leaves one died bit per slot
-        if (p->update_merged) {
+        const uint32_t write_died = (p->plan.lists && !p->slot_order) ? 1u : 0u;   // k_count_rows follows: the update leaves one died bit per slot
+        if ((p->plan.merge.update_family >= 0)) {
             // (k_update_stream_jobs / k_update_generic_jobs above)
         } else if (p->update_streams) {
             SlotArgs sa = slot_args_of(ctx, p, n, write_died);
@@ -1807,7 +1655,7 @@ int hnb_simulate(HnbContext* ctx) {
         }
         if (timed) { hipEventRecord(tu.b, ctx->stream); ctx->t_update.push_back(tu); }
         const CompactArgs ca = compact_args_of(p);
-        const bool lists = p->lists_now;
+        const bool lists = p->plan.lists;
         if (!lists) p->skipped_frames += 1;
         else if (ca.suffix_dead) p->suffix_frames += 1;
         if (lists && p->dev.n_event_channels) {  // order this frame's spawn events (by list row) into the children's buffers
@@ -1816,11 +1664,11 @@ int hnb_simulate(HnbContext* ctx) {
             uint32_t max_ev = 0;
             for (const HnbEffect* fx : p->effects)
                 for (const EventChannel& ch : fx->channels) max_ev = std::max(max_ev, ch.capacity);
-            const uint32_t splits = std::max(1u, std::min(64u, (max_ev / std::max(1u, total_chunks) + 16383u) / 16384u));
+            const uint32_t splits = plan::size_event_grid(max_ev, total_chunks);
             k_emit_events<<<dim3(total_chunks, splits), kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb, p->h_ev_counts, ctx->frame);
         }
         // lists: only the instances that lost particles have anything to do
-        if (!p->lists_merged) {  // (merged: the lists, and the ribbon sort behind them, follow after the last program's update)
+        if (!p->plan.lists_merged) {  // (merged: the lists, and the ribbon sort behind them, follow after the last program's update)
             if (lists && !p->slot_order && !ca.suffix_dead) k_count_rows<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
             if (lists) k_compact<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
             if (lists && p->slot_order) {  // rebuild the lists in increasing slot order (instances without a casualty or spawn return at once)
@@ -1828,22 +1676,59 @@ int hnb_simulate(HnbContext* ctx) {
                 k_order_write<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
             }
             if (timed) { tc.a = tu.b; hipEventRecord(tc.b, ctx->stream); ctx->t_compact.push_back(tc); }
-            if (p->has_ribbons) ribbon_sort(p);
+            if (p->has_ribbons) enqueue_ribbon_sort(ctx, p);
         }
         HIP_TRY(hipGetLastError());
     }
-    if (n_jobs) {
-        k_count_rows_multi<<<job_wgs, kBlock, 0, ctx->stream>>>(d_jobs, n_jobs);
-        k_compact_multi<<<job_wgs, kBlock, 0, ctx->stream>>>(d_jobs, n_jobs);
+    if (fj.n_lists) {
+        k_count_rows_multi<<<fj.lists_wgs, kBlock, 0, ctx->stream>>>(fj.d_lists, fj.n_lists);
+        k_compact_multi<<<fj.lists_wgs, kBlock, 0, ctx->stream>>>(fj.d_lists, fj.n_lists);
         for (HnbProgram* p : order)
-            if (p->lists_merged && p->has_ribbons) ribbon_sort(p);
+            if (p->plan.lists_merged && p->has_ribbons) enqueue_ribbon_sort(ctx, p);
         HIP_TRY(hipGetLastError());
     }
+    return HNB_OK;
+}
+
+// One simulated frame, in the reference's order (src/render/mod.rs:6975-7370): every effect's init
+// pass, parents before children, THEN every effect's update pass. Spawn events appended by a parent's
+// update in frame N are consumed by its children's init in frame N+1.
+int hnb_simulate(HnbContext* ctx) {
+    if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<HnbProgram*> order;
+    for (HnbProgram* p : ctx->programs)
+        if (!p->effects.empty()) order.push_back(p);
+    std::stable_sort(order.begin(), order.end(), [](const HnbProgram* x, const HnbProgram* y) { return x->level < y->level; });
+    const bool timed = ctx->timing && (ctx->timing_tick % ctx->timing) == 0;
+    // validate every instance before any per-frame state is touched: a failed call must leave the frame's inputs intact
+    for (HnbProgram* p : order)
+        if (!p->parent_attrs.empty())
+            for (size_t i = 0; i < p->effects.size(); ++i)
+                if (!p->effects[i]->parent)
+                    return fail(HNB_ERR_INVALID_ARG, "effect #%zu reads its parent particle (InheritAttributeModifier / parent_attr) but has no parent: call hnb_effect_set_parent", i);
+    const uint32_t slot = ctx->frame % kFrameRing;
+    int rc = ensure_stage(ctx, order, slot);
+    if (rc != HNB_OK) return rc;
+    size_t stage_off = 0;
+    std::vector<plan::InstanceFrame> inst_frames;
+    for (HnbProgram* p : order) stage_program_frame(ctx, p, slot, stage_off, inst_frames);
+    FrameJobs fj;
+    fill_lists_jobs(ctx, order, slot, stage_off, timed, fj);
+    fill_merge_jobs(ctx, order, slot, stage_off, timed, fj);
+    if (stage_off) {
+        HIP_TRY(hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], stage_off, hipMemcpyHostToDevice, ctx->upload_stream));
+        HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
+    }
+    rc = enqueue_init_passes(ctx, order, fj, timed);
+    if (rc != HNB_OK) return rc;
+    rc = enqueue_update_passes(ctx, order, fj, timed);
+    if (rc != HNB_OK) return rc;
     for (HnbProgram* p : order) {
         p->ring += 1;
         p->parity ^= 1u;
         p->frames_run += 1;
-        if (p->horizon_eligible && p->lists_now) p->hz_parity ^= 1u;   // k_count_rows / k_compact moved the horizons to the other half
+        if (p->horizon_eligible && p->plan.lists) p->hz_parity ^= 1u;   // k_count_rows / k_compact moved the horizons to the other half
     }
     if (!order.empty()) HIP_TRY(hipEventRecord(ctx->stage_done[slot], ctx->stream));
     for (HnbProgram* p : order)
@@ -1911,13 +1796,13 @@ int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t 
     hipStream_t st = p->ctx->stream;
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(static_cast<char*>(fx->slab) + p->dev.attrs[ai].plane_off, src, bytes, hipMemcpyHostToDevice));
-    p->dirty = true;  // ... nor does the published no-death bound
-    p->sort_dirty = true;  // ... and a ribbon list may no longer be in key order
-    p->sort_front_broken = true;  // ... nor its ages and ribbon ids what the front proof assumes
+    p->skip_hist.dirty = true;  // ... nor does the published no-death bound
+    p->ribbon_hist.dirty = true;  // ... and a ribbon list may no longer be in key order
+    p->ribbon_hist.front_broken = true;  // ... nor its ages and ribbon ids what the front proof assumes
     // (the resets below are enqueued on the context's stream - the device the slab lives on -, then waited for)
     if (p->horizon_eligible)   // the death horizons were computed from the particles as they were: zero = "may die now" (the clock restarts with them)
         HIP_TRY(hipMemsetAsync(static_cast<char*>(fx->slab) + p->dev.horizon_off, 0, 256 + (size_t)p->dev.chunks_per_inst * 24, st));
-    if (attr == HNB_ATTR_AGE) p->sort_values_broken = true;  // ... and the written ages may be negative (they change key order when they cross zero later)
+    if (attr == HNB_ATTR_AGE) p->ribbon_hist.values_broken = true;  // ... and the written ages may be negative (they change key order when they cross zero later)
     // the chunks' lifetime bounds (lifetime culling) no longer describe the planes
     HIP_TRY(hipMemsetAsync(static_cast<char*>(fx->slab) + p->dev.lmin_off, 0, (size_t)p->dev.chunks_per_inst * 4, st));  // (the "completely alive" flags that follow stay valid)
     if (p->dev.age_cohort && attr == HNB_ATTR_AGE)   // the plane is the truth again: forget the cohort states (and values)
@@ -2027,10 +1912,10 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
         s += "\nage cohorts: " + std::to_string(in_cohort) + " of " + std::to_string(prog->effects.size() * (size_t)prog->dev.chunks_per_inst) + " chunks";
     }
     if (prog->has_ribbons && prog->suffix_frames) s += "\ncasualties proven to be the list's last rows (no k_count_rows): " + std::to_string(prog->suffix_frames) + " frames";
-    if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->sort_front_static ? "" : " (not eligible)");
+    if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->ribbon_facts.front_static ? "" : " (not eligible)");
     if (prog->merged_frames) s += "\nupdate served by a merged launch (small programs of the context share one): " + std::to_string(prog->merged_frames) + " frames";
     if (prog->horizon_eligible) s += "\ndeath horizons in use: " + std::to_string(prog->hz_frames) + " frames";
-    s += "\nlists skipped: " + std::to_string(prog->skipped_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->skip_eligible ? "" : " (not eligible)");
+    s += "\nlists skipped: " + std::to_string(prog->skipped_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->skip_facts.eligible ? "" : " (not eligible)");
     snprintf(buf, buf_size, "%s", s.c_str());
     return HNB_OK;
 }

@@ -501,14 +501,7 @@ struct CompactBufs {
     uint32_t parity;
     uint32_t* ev_totals;  // [n_inst * chunks_per_inst][HNB_MAX_EVENT_CHANNELS] spawn events per chunk (emitting programs)
     uint32_t xcd_remap;   // workgroup -> chunk mapping (chunk_of_workgroup): bit 0 XCD-aware (batches of instances), bit 1 descending order (every other frame)
-    // Two-level survivor prefix (k_compact): gsums[k * groups_per_inst + g] = survivors of the chunks [64 g, 64 g + 64) of instance k this frame.
-    // Zeroed by the frame's update kernel (its workgroup of the group's first chunk; write_died says that list kernels follow), accumulated by
-    // k_count_rows with one fire-and-forget atomic per chunk, read by k_compact: a workgroup then takes <= 64 group sums + <= 63 chunk counts -
-    // 508 bytes in one round of loads - instead of every earlier chunk's count (8 KB on average for a 16.7M-row list, several dependent rounds).
-    uint32_t* gsums;
-    uint32_t groups_per_inst;
 };
-constexpr uint32_t kCountGroup = 64u;   // chunks per group sum
 
 // Workgroup -> chunk. The hardware deals workgroups to the 8 XCDs round-robin (workgroup b runs on XCD b mod 8,
 // each XCD with its own L2). In a batch of instances, mapping b straight to chunk b pins chunk j of EVERY instance
@@ -638,12 +631,18 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
         excl = c.start <= first_dead ? c.start : (c.start < alive0 ? first_dead : c.start - total_dead);
         if (total_dead > alive0 && tid == 0u && args.fault) *args.fault = 1u;
     } else if (total_dead != 0u) {
-        // (c.j <= 4096 * 64 chunks: one load per lane covers the group sums, one the chunk counts of the own group)
+        // (Round 4: a two-level prefix - group sums accumulated by k_count_rows with one fire-and-forget atomic per chunk, 508 bytes of
+        // counts per workgroup here - made THIS kernel 2 us faster and k_count_rows 16 us slower at 4096 chunks: 64 atomics to one word from
+        // 8 XCDs serialise beyond the L2, profiles/r04b_kernel_durations.json. The counts are read 16 bytes per lane instead.)
         uint32_t part = 0;
-        const uint32_t g = c.j / kCountGroup;
-        const uint32_t* gs = cb.gsums + (size_t)c.k * cb.groups_per_inst;
-        for (uint32_t i = tid; i < g; i += kBlock) part += gs[i];
-        for (uint32_t i = g * kCountGroup + tid; i < c.j; i += kBlock) part += cnt[i];
+        const uint32_t head = (uint32_t)((16u - ((size_t)cnt & 15u)) & 15u) / 4u;   // counts in front of the first 16-byte boundary
+        for (uint32_t i = tid; i < (head < c.j ? head : c.j); i += kBlock) part += cnt[i];
+        if (c.j > head) {
+            const uint4* c4 = reinterpret_cast<const uint4*>(cnt + head);
+            const uint32_t n4 = (c.j - head) / 4u;
+            for (uint32_t i = tid; i < n4; i += kBlock) { const uint4 v = c4[i]; part += (v.x + v.y) + (v.z + v.w); }
+            for (uint32_t i = head + n4 * 4u + tid; i < c.j; i += kBlock) part += cnt[i];
+        }
 #pragma unroll
         for (uint32_t off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
         if (lane == 0) s_red[wave] = part;
@@ -1059,7 +1058,6 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         args.meta_out[k] = o;
         cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + k] = 0u;
     }
-    if (args.write_died && (j % kCountGroup) == 0u && tid == 0u) cb.gsums[(size_t)k * cb.groups_per_inst + j / kCountGroup] = 0u;   // k_count_rows accumulates into it (CompactBufs)
     if (fi[k].skip) return;  // frozen instance
     char* base = global_ptr<char>(inst_base[k]);
     VmUniforms U;
@@ -1379,7 +1377,6 @@ __device__ __forceinline__ void update_generic_chunk(const DevProgram& prog, con
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     const uint32_t k = chunk / prog.chunks_per_inst, j = chunk - k * prog.chunks_per_inst;
-    if (write_died && (j % kCountGroup) == 0u && sub_begin == 0u && tid == 0u) cb.gsums[(size_t)k * cb.groups_per_inst + j / kCountGroup] = 0u;   // k_count_rows accumulates into it (CompactBufs)
     if (fi[k].skip) return;
     char* base = global_ptr<char>(inst_base[k]);
     uint8_t* flags = reinterpret_cast<uint8_t*>(base + prog.alive_flag_off);
@@ -1485,7 +1482,7 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
                 const unsigned long long m = rows_ >= (tid + 1u) * 64u ? ~0ull : (rows_ > tid * 64u ? ((1ull << (rows_ - tid * 64u)) - 1ull) : 0ull);
                 (reinterpret_cast<unsigned long long*>(c.base + args.row_mask_off) + (size_t)c.j * (kChunk / 64u))[tid] = m;
             }
-            if (tid == 0u) { cb.counts[chunk] = rows_; atomicAdd(&cb.gsums[(size_t)c.k * cb.groups_per_inst + c.j / kCountGroup], rows_); }
+            if (tid == 0u) cb.counts[chunk] = rows_;
             return;
         }
     }
@@ -1518,7 +1515,6 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
 #pragma unroll
         for (uint32_t w = 0; w < kBlock / 64; ++w) t += s_wave[w];
         cb.counts[chunk] = t;
-        atomicAdd(&cb.gsums[(size_t)c.k * cb.groups_per_inst + c.j / kCountGroup], t);   // (result unused: a fire-and-forget atomic)
     }
 }
 __global__ void __launch_bounds__(kBlock)

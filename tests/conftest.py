@@ -29,6 +29,12 @@ def pytest_configure(config):
     deps = [src] + [os.path.join(ROOT, "bevy_hanabi_amd", "csrc", f) for f in ("hnb_vm.h", "hnb_math.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas", src, "-o", so])
+    # tests/cpu_plan: the frame-planning proofs of hnb_simulate (hnb_plan.h) compiled for the host
+    cp_dir = os.path.join(ROOT, "tests", "cpu_plan")
+    cp_so, cp_src = os.path.join(cp_dir, "libcpu_plan.so"), os.path.join(cp_dir, "cpu_plan.cpp")
+    cp_dep = os.path.join(ROOT, "bevy_hanabi_amd", "csrc", "hnb_plan.h")
+    if not os.path.exists(cp_so) or max(os.path.getmtime(cp_src), os.path.getmtime(cp_dep)) > os.path.getmtime(cp_so):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", cp_src, "-o", cp_so])
     # tests/fake_rccl: the stand-in collective library (built here, where the RCCL header is; the .so travels to the GPU box)
     fr_dir = os.path.join(ROOT, "tests", "fake_rccl")
     fr_so, fr_src = os.path.join(fr_dir, "libfake_rccl.so"), os.path.join(fr_dir, "fake_rccl.cpp")
