@@ -421,7 +421,7 @@ class Workload:
 # ------------------------------------------------------------------------------------------------------------------
 # parity gate: the state the timed frames produced, against the CPU oracle, before a number is accepted
 # ------------------------------------------------------------------------------------------------------------------
-PARITY_BUDGET_S = 1.0          # oracle time per configuration (the slab / the reduced capacity is sized to the oracle's measured speed)
+PARITY_BUDGET_S = 0.5          # oracle time per configuration (the slab / the reduced capacity is sized to the oracle's measured speed)
 PARITY_KEYS = ("capacity", "alive_count", "max_update", "max_spawn", "indirect_write_index", "particle_counter", "instance_count", "dead_count")
 BURST_PARITY = ("c2", "c2_interop", "c3", "c4")
 _ORACLE_RATE = None

@@ -119,6 +119,9 @@ struct HnbContext {
     hipStream_t stream = nullptr;       // the stream hnb_simulate enqueues on: own_stream or the caller's (hnb_ctx_set_stream)
     hipStream_t own_stream = nullptr;   // created with the context, lives as long as it does
     hipStream_t upload_stream = nullptr;  // per-frame parameter uploads, overlapped with the previous frame's kernels
+    hipStream_t side_stream = nullptr;    // update phase of the LIGHT programs of a frame, next to the heavy one's on `stream` (enqueue_update_passes)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap_updates = true;          // HNB_OPT_OVERLAP_UPDATES
     // The per-frame parameters of EVERY program (instance rows, uniform blocks, init block starts) are staged in one pinned buffer and go to the
     // device with one copy per frame: with a copy per program, a scene of 26 small effects spent a quarter of its frame in 26 serialised
     // 3.5 us copy kernels and the host waiting for them (profiles/r02u_scene.md). A ring of slots: the host fills slot f % kFrameRing while the
@@ -754,6 +757,11 @@ int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
     ctx->own_stream = ctx->stream;
     e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return fail(HNB_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->overlap_updates = false;   // (the frame then runs on one stream, as it did before round 4)
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     *out_ctx = ctx;
@@ -770,6 +778,9 @@ int hnb_ctx_destroy(HnbContext* ctx) {
     for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     if (ctx->upload_stream) hipStreamDestroy(ctx->upload_stream);
+    if (ctx->side_stream) { hipStreamSynchronize(ctx->side_stream); hipStreamDestroy(ctx->side_stream); }
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     for (uint32_t i = 0; i < kFrameRing; ++i) {
         hipFree(ctx->d_stage[i]);
         if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
@@ -804,6 +815,7 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
         case HNB_OPT_TRANSPOSE: ctx->transpose = value != 0u; return HNB_OK;
         case HNB_OPT_SCENE_MERGE: ctx->scene_merge = value != 0u; return HNB_OK;
         case HNB_OPT_SUFFIX_PROOF: ctx->suffix_proof = value != 0u; return HNB_OK;
+        case HNB_OPT_OVERLAP_UPDATES: ctx->overlap_updates = value != 0u && ctx->side_stream != nullptr; return HNB_OK;
         default: return fail(HNB_ERR_INVALID_ARG, "unknown option %u", option);
     }
 }
@@ -1351,7 +1363,27 @@ struct FrameJobs {           // the launches several programs share this frame (
     const ListsJob* d_lists = nullptr;
     uint32_t n_lists = 0, lists_wgs = 0;
     Family init[2], generic[2], stream[2];   // [wide register file] / [age cohorts]
+    const HnbProgram* heavy = nullptr;       // enqueue_update_passes: the one program whose update phase stays on the context's stream while
+                                             // every other program's runs next to it on the side stream (null: one stream)
 };
+
+// The update phase of a frame is one independent chain per program - update -> spawn-event ordering -> lists -> ribbon sort touch only the
+// program's own slabs and the event buffers it appends to, which nobody reads before the next frame's init passes. When one program is
+// much heavier than the rest (a 16.7M-particle trail effect next to the rockets that spawn it: c2_events), the light chains - a dozen
+// launches of microseconds each, 0.1 ms of dependent latency - hide behind the heavy update on a second stream.
+constexpr uint32_t kOverlapMinChunks = 256;   // the heavy program: >= 1M slots ...
+static const HnbProgram* pick_heavy_program(const HnbContext* ctx, const std::vector<HnbProgram*>& order, bool timed) {
+    if (!ctx->overlap_updates || timed || order.size() < 2u) return nullptr;
+    const HnbProgram* best = nullptr;
+    uint64_t best_chunks = 0, others = 0;
+    for (const HnbProgram* p : order) {
+        const uint64_t c = (uint64_t)p->effects.size() * p->dev.chunks_per_inst;
+        others += c;
+        if (c > best_chunks) { best_chunks = c; best = p; }
+    }
+    others -= best_chunks;
+    return (best_chunks >= kOverlapMinChunks && best_chunks >= 4u * others) ? best : nullptr;   // ... and at least 4x the rest together
+}
 
 // (1) The per-frame parameters of every program are filled into the context's next ring slot and uploaded on the upload stream. The host
 // waits for the (tiny) copy itself, so the simulation stream carries no cross-stream wait: such a wait costs an ~11 us bubble in front
@@ -1463,12 +1495,13 @@ static void stage_program_frame(HnbContext* ctx, HnbProgram* p, uint32_t slot, s
 // (3a) Programs whose list kernels can share two launches
 static void fill_lists_jobs(HnbContext* ctx, const std::vector<HnbProgram*>& order, uint32_t slot, size_t& stage_off, bool timed, FrameJobs& jobs_out) {
     uint32_t candidates = 0;
-    for (const HnbProgram* p : order) candidates += (p->plan.lists && !p->slot_order) ? 1u : 0u;
+    auto shares = [&](const HnbProgram* p) { return p->plan.lists && !p->slot_order && p != jobs_out.heavy; };   // (the heavy program's lists follow its update on the main stream)
+    for (const HnbProgram* p : order) candidates += shares(p) ? 1u : 0u;
     if (candidates >= 2u && !timed) {
         ListsJob* jobs = reinterpret_cast<ListsJob*>(static_cast<char*>(ctx->h_stage[slot]) + stage_off);
         jobs_out.d_lists = reinterpret_cast<const ListsJob*>(static_cast<const char*>(ctx->d_stage[slot]) + stage_off);
         for (HnbProgram* p : order) {
-            if (!(p->plan.lists && !p->slot_order)) continue;
+            if (!shares(p)) continue;
             const uint32_t n = (uint32_t)p->effects.size();
             ListsJob jb{};
             jb.args = compact_args_of(p);
@@ -1549,7 +1582,7 @@ static void fill_merge_jobs(HnbContext* ctx, const std::vector<HnbProgram*>& ord
 }
 
 // ribbon sort of a program's compacted lists by (RIBBON_ID, AGE) (src/render/mod.rs:7372-7612)
-static void enqueue_ribbon_sort(HnbContext* ctx, HnbProgram* p) {
+static void enqueue_ribbon_sort(HnbContext* ctx, HnbProgram* p, hipStream_t st) {
     const uint32_t n = (uint32_t)p->effects.size();
     const uint32_t par = p->parity;
     // The list is last frame's sorted list minus the casualties (stable compaction), every age advanced by the same
@@ -1568,18 +1601,18 @@ static void enqueue_ribbon_sort(HnbContext* ctx, HnbProgram* p) {
     p->sort_parity += 1;
     const DevMeta* mo = p->d_meta[par ^ 1];
     const uint32_t tiles = n * so.chunks_per_inst;
-    k_sort_fill<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+    k_sort_fill<<<tiles, kBlock, 0, st>>>(so, p->d_inst_base, mo);
     // ... or when the whole list is small: whatever range the device finds, one workgroup sorts it faster than sixteen launches
     // are issued (a 40-particle lightning bolt whose ages are not provably ordered took 8 + 8 empty launches per frame)
     if ((proven && p->plan.ribbon.max_spawn <= kSortSmallMax) || p->dev.capacity <= kSortSmallMax / 4u) {
-        k_sort_small<<<n, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+        k_sort_small<<<n, kBlock, 0, st>>>(so, p->d_inst_base, mo);
     } else {
         for (uint32_t pass = 0; pass < 8; ++pass) {
-            k_sort_hist<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
-            k_sort_scatter<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo, pass);
+            k_sort_hist<<<tiles, kBlock, 0, st>>>(so, p->d_inst_base, mo, pass);
+            k_sort_scatter<<<tiles, kBlock, 0, st>>>(so, p->d_inst_base, mo, pass);
         }
     }
-    k_sort_merge<<<tiles, kBlock, 0, ctx->stream>>>(so, p->d_inst_base, mo);
+    k_sort_merge<<<tiles, kBlock, 0, st>>>(so, p->d_inst_base, mo);
     p->ribbon_hist.dirty = false;
 }
 
@@ -1615,77 +1648,99 @@ static int enqueue_init_passes(HnbContext* ctx, const std::vector<HnbProgram*>& 
 }
 
 // (6) update + kill + compaction (+ spawn-event ordering, + ribbon sort)
+// One program's update phase on stream `st`: update (unless a merged launch serves it), spawn-event ordering, lists, ribbon sort.
+static int enqueue_program_update(HnbContext* ctx, HnbProgram* p, hipStream_t st, bool timed) {
+    const uint32_t n = (uint32_t)p->effects.size();
+    const uint32_t par = p->parity;
+    const char* d = p->d_frame_cur;
+    const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
+    const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
+    // one workgroup per 4096-slot chunk of every instance
+    const uint32_t total_chunks = n * p->dev.chunks_per_inst;
+    CompactBufs cb = compact_bufs_of(ctx, p, n);
+    TimingPair tu{}, tc{};
+    tu.prog = tc.prog = p;
+    if (timed) { tu.a = take_event(ctx); tu.b = take_event(ctx); tc.b = take_event(ctx); hipEventRecord(tu.a, st); }
+    const uint32_t write_died = (p->plan.lists && !p->slot_order) ? 1u : 0u;   // k_count_rows follows: the update leaves one died bit per slot
+    if ((p->plan.merge.update_family >= 0)) {
+        // (k_update_stream_jobs / k_update_generic_jobs above)
+    } else if (p->update_streams) {
+        SlotArgs sa = slot_args_of(ctx, p, n, write_died);
+        if (p->jit_update) {
+            void* ka[] = {&sa, &p->d_inst_base, &dfi, &dub, &cb};
+            HIP_TRY(hipModuleLaunchKernel(p->jit_update, total_chunks, 1, 1, kBlock, 1, 1, 0, st, ka, nullptr));
+        } else {
+            p->stream_launch(total_chunks, st, sa, p->d_inst_base, dfi, dub, cb);
+        }
+    } else if (p->jit_update) {
+        uint32_t dm = write_died;
+        void* ka[] = {&p->dev, &p->d_inst_base, &dfi, &dub, &cb, &dm};
+        HIP_TRY(hipModuleLaunchKernel(p->jit_update, total_chunks, 1, 1, kBlock, 1, 1, 0, st, ka, nullptr));
+    } else {
+        if (p->wide_file) k_update_slots_generic<InterpCodeWide><<<total_chunks, kBlock, 0, st>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
+        else k_update_slots_generic<InterpCode><<<total_chunks, kBlock, 0, st>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
+    }
+    if (timed) { hipEventRecord(tu.b, st); ctx->t_update.push_back(tu); }
+    const CompactArgs ca = compact_args_of(p);
+    const bool lists = p->plan.lists;
+    if (!lists) p->skipped_frames += 1;
+    else if (ca.suffix_dead) p->suffix_frames += 1;
+    if (lists && p->dev.n_event_channels) {  // order this frame's spawn events (by list row) into the children's buffers
+        k_emit_count<<<total_chunks, kBlock, 0, st>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb);
+        // (gridDim.y splits every chunk's events over several workgroups: sized for the largest event buffer that listens, 16,384 events per split)
+        uint32_t max_ev = 0;
+        for (const HnbEffect* fx : p->effects)
+            for (const EventChannel& ch : fx->channels) max_ev = std::max(max_ev, ch.capacity);
+        const uint32_t splits = plan::size_event_grid(max_ev, total_chunks);
+        k_emit_events<<<dim3(total_chunks, splits), kBlock, 0, st>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb, p->h_ev_counts, ctx->frame);
+    }
+    // lists: only the instances that lost particles have anything to do
+    if (!p->plan.lists_merged) {  // (merged: the lists, and the ribbon sort behind them, follow after the last program's update)
+        if (lists && !p->slot_order && !ca.suffix_dead) k_count_rows<<<total_chunks, kBlock, 0, st>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
+        if (lists) k_compact<<<total_chunks, kBlock, 0, st>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
+        if (lists && p->slot_order) {  // rebuild the lists in increasing slot order (instances without a casualty or spawn return at once)
+            k_order_count<<<total_chunks, kBlock, 0, st>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
+            k_order_write<<<total_chunks, kBlock, 0, st>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
+        }
+        if (timed) { tc.a = tu.b; hipEventRecord(tc.b, st); ctx->t_compact.push_back(tc); }
+        if (p->has_ribbons) enqueue_ribbon_sort(ctx, p, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return HNB_OK;
+}
+
 static int enqueue_update_passes(HnbContext* ctx, const std::vector<HnbProgram*>& order, const FrameJobs& fj, bool timed) {
+    // fork: the light programs' chains (and every shared launch) go to the side stream behind everything enqueued so far (the init passes);
+    // the heavy program's chain stays on the context's stream; the context's stream waits for the side stream at the end of the frame
+    hipStream_t light = ctx->stream;
+    if (fj.heavy) {
+        light = ctx->side_stream;
+        HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(light, ctx->ev_fork, 0));
+    }
     // (the merged updates first: every init pass is enqueued, and a merged program's own list kernels may follow in the loop below)
     if (fj.stream[0].wgs + fj.stream[1].wgs + fj.generic[0].wgs)
-        k_update_jobs<<<fj.stream[0].wgs + fj.stream[1].wgs + fj.generic[0].wgs, kBlock, 0, ctx->stream>>>(
+        k_update_jobs<<<fj.stream[0].wgs + fj.stream[1].wgs + fj.generic[0].wgs, kBlock, 0, light>>>(
             static_cast<const StreamJob*>(fj.stream[0].d_jobs), fj.stream[0].n, static_cast<const StreamJob*>(fj.stream[1].d_jobs), fj.stream[1].n,
             static_cast<const ProgJob*>(fj.generic[0].d_jobs), fj.generic[0].n, fj.stream[0].wgs, fj.stream[0].wgs + fj.stream[1].wgs);
-    if (fj.generic[1].wgs) k_update_generic_wide_jobs<<<fj.generic[1].wgs, kBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fj.generic[1].d_jobs), fj.generic[1].n);
+    if (fj.generic[1].wgs) k_update_generic_wide_jobs<<<fj.generic[1].wgs, kBlock, 0, light>>>(static_cast<const ProgJob*>(fj.generic[1].d_jobs), fj.generic[1].n);
     for (HnbProgram* p : order) {
-        const uint32_t n = (uint32_t)p->effects.size();
-        const uint32_t par = p->parity;
-        const char* d = p->d_frame_cur;
-        const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
-        const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
-        // one workgroup per 4096-slot chunk of every instance
-        const uint32_t total_chunks = n * p->dev.chunks_per_inst;
-        CompactBufs cb = compact_bufs_of(ctx, p, n);
-        TimingPair tu{}, tc{};
-        tu.prog = tc.prog = p;
-        if (timed) { tu.a = take_event(ctx); tu.b = take_event(ctx); tc.b = take_event(ctx); hipEventRecord(tu.a, ctx->stream); }
-        const uint32_t write_died = (p->plan.lists && !p->slot_order) ? 1u : 0u;   // k_count_rows follows: the update leaves one died bit per slot
-        if ((p->plan.merge.update_family >= 0)) {
-            // (k_update_stream_jobs / k_update_generic_jobs above)
-        } else if (p->update_streams) {
-            SlotArgs sa = slot_args_of(ctx, p, n, write_died);
-            if (p->jit_update) {
-                void* ka[] = {&sa, &p->d_inst_base, &dfi, &dub, &cb};
-                HIP_TRY(hipModuleLaunchKernel(p->jit_update, total_chunks, 1, 1, kBlock, 1, 1, 0, ctx->stream, ka, nullptr));
-            } else {
-                p->stream_launch(total_chunks, ctx->stream, sa, p->d_inst_base, dfi, dub, cb);
-            }
-        } else if (p->jit_update) {
-            uint32_t dm = write_died;
-            void* ka[] = {&p->dev, &p->d_inst_base, &dfi, &dub, &cb, &dm};
-            HIP_TRY(hipModuleLaunchKernel(p->jit_update, total_chunks, 1, 1, kBlock, 1, 1, 0, ctx->stream, ka, nullptr));
-        } else {
-            if (p->wide_file) k_update_slots_generic<InterpCodeWide><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
-            else k_update_slots_generic<InterpCode><<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
-        }
-        if (timed) { hipEventRecord(tu.b, ctx->stream); ctx->t_update.push_back(tu); }
-        const CompactArgs ca = compact_args_of(p);
-        const bool lists = p->plan.lists;
-        if (!lists) p->skipped_frames += 1;
-        else if (ca.suffix_dead) p->suffix_frames += 1;
-        if (lists && p->dev.n_event_channels) {  // order this frame's spawn events (by list row) into the children's buffers
-            k_emit_count<<<total_chunks, kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb);
-            // (gridDim.y splits every chunk's events over several workgroups: sized for the largest event buffer that listens, 16,384 events per split)
-            uint32_t max_ev = 0;
-            for (const HnbEffect* fx : p->effects)
-                for (const EventChannel& ch : fx->channels) max_ev = std::max(max_ev, ch.capacity);
-            const uint32_t splits = plan::size_event_grid(max_ev, total_chunks);
-            k_emit_events<<<dim3(total_chunks, splits), kBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, cb, p->h_ev_counts, ctx->frame);
-        }
-        // lists: only the instances that lost particles have anything to do
-        if (!p->plan.lists_merged) {  // (merged: the lists, and the ribbon sort behind them, follow after the last program's update)
-            if (lists && !p->slot_order && !ca.suffix_dead) k_count_rows<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
-            if (lists) k_compact<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
-            if (lists && p->slot_order) {  // rebuild the lists in increasing slot order (instances without a casualty or spawn return at once)
-                k_order_count<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], dfi, cb);
-                k_order_write<<<total_chunks, kBlock, 0, ctx->stream>>>(ca, p->d_inst_base, p->d_meta[par], p->d_meta[par ^ 1], dfi, cb);
-            }
-            if (timed) { tc.a = tu.b; hipEventRecord(tc.b, ctx->stream); ctx->t_compact.push_back(tc); }
-            if (p->has_ribbons) enqueue_ribbon_sort(ctx, p);
-        }
-        HIP_TRY(hipGetLastError());
+        if (p == fj.heavy) continue;
+        const int rc = enqueue_program_update(ctx, p, light, timed);
+        if (rc != HNB_OK) return rc;
     }
     if (fj.n_lists) {
-        k_count_rows_multi<<<fj.lists_wgs, kBlock, 0, ctx->stream>>>(fj.d_lists, fj.n_lists);
-        k_compact_multi<<<fj.lists_wgs, kBlock, 0, ctx->stream>>>(fj.d_lists, fj.n_lists);
+        k_count_rows_multi<<<fj.lists_wgs, kBlock, 0, light>>>(fj.d_lists, fj.n_lists);
+        k_compact_multi<<<fj.lists_wgs, kBlock, 0, light>>>(fj.d_lists, fj.n_lists);
         for (HnbProgram* p : order)
-            if (p->plan.lists_merged && p->has_ribbons) enqueue_ribbon_sort(ctx, p);
+            if (p->plan.lists_merged && p->has_ribbons) enqueue_ribbon_sort(ctx, p, light);
         HIP_TRY(hipGetLastError());
+    }
+    if (fj.heavy) {
+        const int rc = enqueue_program_update(ctx, const_cast<HnbProgram*>(fj.heavy), ctx->stream, timed);
+        if (rc != HNB_OK) return rc;
+        HIP_TRY(hipEventRecord(ctx->ev_join, light));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));   // join: whatever follows on the context's stream sees the whole frame
     }
     return HNB_OK;
 }
@@ -1714,6 +1769,7 @@ int hnb_simulate(HnbContext* ctx) {
     std::vector<plan::InstanceFrame> inst_frames;
     for (HnbProgram* p : order) stage_program_frame(ctx, p, slot, stage_off, inst_frames);
     FrameJobs fj;
+    fj.heavy = pick_heavy_program(ctx, order, timed);
     fill_lists_jobs(ctx, order, slot, stage_off, timed, fj);
     fill_merge_jobs(ctx, order, slot, stage_off, timed, fj);
     if (stage_off) {

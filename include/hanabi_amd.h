@@ -298,6 +298,11 @@ int hnb_ctx_synchronize(HnbContext* ctx);
 #define HNB_OPT_TRANSPOSE 7u
 #define HNB_OPT_SCENE_MERGE 8u
 #define HNB_OPT_SUFFIX_PROOF 9u
+/* HNB_OPT_OVERLAP_UPDATES (default 1; from the next hnb_simulate on): when one program of the context holds at least four times the slots
+ *   of all the others together (and >= 1M), the update phase of the others - update, spawn-event ordering, lists, sort: independent chains -
+ *   runs on an internal second stream next to the heavy program's update and joins the context's stream before hnb_simulate returns.
+ *   Same results; frames on which kernel timing is sampled use one stream. */
+#define HNB_OPT_OVERLAP_UPDATES 10u
 int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value);
 
 /* Replaces EffectShaderSources::generate + pipeline specialisation (src/lib.rs:805-1336). */

@@ -244,3 +244,33 @@ def test_gpu_real_firework_slot_order():
             assert_same_system_state(o.state(), g.state(), f"frame {f}")
     assert g.state()[2]["counters"]["particle_counter"] > 1000
     c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_gpu_update_phase_on_two_streams_equals_one_stream_and_the_oracle(overlap):
+    """HNB_OPT_OVERLAP_UPDATES: with one program at least four times heavier than the rest (here the 1M-slot trails next to rockets and
+    sparkles), the light programs' update phase - update, event ordering, lists - runs on a second stream next to the heavy update and
+    joins before hnb_simulate returns. Same state as with one stream, bit for bit, and as the oracle; a consumer enqueued right behind the
+    frame (a host read here) sees the joined frame."""
+    cap = 1 << 20
+    rocket = effects.firework_rocket(8192, 5, 1000)
+    rocket.spawner = bh.SpawnerSettings.rate(1000.0)
+    specs = [EffectSpec(rocket), EffectSpec(effects.firework_sparkle_trail(1 << 16), parent=0, channel=0, event_capacity=1 << 14),
+             EffectSpec(effects.firework_trails_child(cap), parent=0, channel=1, event_capacity=1 << 19)]
+    ctx = bh.Context(0)
+    ctx.set_option("overlap_updates", overlap)
+    g, o = GpuSystem(specs, ctx), OracleSystem(specs, omp=True)
+    sp, rng = bh.EffectSpawner(rocket.spawner), bh.Pcg32()
+    dt = 0.25
+    for f in range(12):
+        fr = [Frame(dt, sp.tick(dt, rng), frame_seed(f), time=f * dt), Frame(dt, 0, frame_seed(1000 + f), time=f * dt), Frame(dt, 0, frame_seed(2000 + f), time=f * dt)]
+        g.step(fr)
+        o.step(fr)
+        for fx, ofx in zip(g.fx, o.fx):      # (read straight behind the frame, every frame: the join must cover the side stream's counters)
+            assert fx.metadata()["alive_count"] == ofx.alive_count(), f"frame {f}"
+        if f in (7, 11):
+            assert_same_system_state(o.state(), g.state(), f"overlap={overlap} frame {f}")
+    assert g.fx[2].metadata()["particle_counter"] > cap // 4 and all(fx.metadata()["fault"] == 0 for fx in g.fx)
+    g.destroy()
+    ctx.close()
