@@ -59,6 +59,19 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 #define HNB_NT_STORE(v, p) (*(p) = (v))
 #endif
 
+// The list kernels (k_count_rows, k_compact) and the list side of k_init stream through data nobody reads again before the next frame's
+// update has walked its gigabyte of planes; their list accesses carry the nontemporal hint, so that what the 256 MiB Infinity Cache keeps
+// from one update launch to the next is more of the planes the alternating walk starts on. Measured on the c2_mixed regime (16.7M slots,
+// 277k spawns + deaths per frame, same box, two rounds, profiles/r04f_ab_lnt.log): init 0.0492 -> 0.0464 ms, update 0.209 -> 0.204,
+// lists 0.0735 -> 0.065, frame 0.3285 -> 0.312 ms. (HNB_LIST_NT_OFF: the default policy, for A/B runs.)
+#if !defined(HNB_LIST_NT_OFF)
+#define HNB_LNT_LOAD(p) __builtin_nontemporal_load(p)
+#define HNB_LNT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define HNB_LNT_LOAD(p) (*(p))
+#define HNB_LNT_STORE(v, p) (*(p) = (v))
+#endif
+
 // ---- reset: dead_index[i] = i (effect_cache.rs:298-323) ------------------------------------
 #ifndef HNB_JIT_TU
 __global__ void k_reset_lists(uint32_t* __restrict__ dead, uint32_t* __restrict__ alive0, uint32_t* __restrict__ alive1, uint32_t capacity) {
@@ -91,14 +104,37 @@ __global__ void __launch_bounds__(256) k_probe_placement(char* __restrict__ base
 }
 #endif
 
+// Read-only planes of the streaming update (LIFETIME, the alive bytes: 5 of the 33 bytes of distinct memory per particle) are loaded with the
+// nontemporal hint: they need not take Infinity-Cache space from the position / velocity / age lines the next frame's walk starts on.
+// c2_mixed, same box, two rounds (profiles/r04g_ab_nt2.log): update 0.2046 -> 0.1990 ms, frame 0.3118 -> 0.3084 ms. The same hint on the init's
+// scattered plane stores (HNB_INIT_NT) measured nothing (0.3123): it stays off. (HNB_RO_NT_OFF: default policy, for A/B runs.)
+#if defined(HNB_INIT_NT)
+#define HNB_PST(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define HNB_PST(v, p) (*(p) = (v))
+#endif
+#if !defined(HNB_RO_NT_OFF)
+#define HNB_RO_NT 1
+#define HNB_RO_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define HNB_RO_LOAD(p) (*(p))
+#endif
+
 // ---- V-file attribute access (generic kernels, one particle per lane) -----------------------
 template <class FILE_T>
 __device__ __forceinline__ void vfile_store_attr(const FILE_T& r, uint32_t ncomp, uint32_t reg, char* plane, uint32_t slot) {
     switch (ncomp) {
+#if defined(HNB_INIT_NT)
+        case 1: HNB_PST(r[reg], reinterpret_cast<uint32_t*>(plane) + slot); break;
+        case 2: { uint32_t* q = reinterpret_cast<uint32_t*>(plane) + 2u * (size_t)slot; HNB_PST(r[reg], q); HNB_PST(r[reg + 1], q + 1); } break;
+        case 3: { uint32_t* q = reinterpret_cast<uint32_t*>(plane) + 3u * (size_t)slot; HNB_PST(r[reg], q); HNB_PST(r[reg + 1], q + 1); HNB_PST(r[reg + 2], q + 2); } break;
+        default: { uint32_t* q = reinterpret_cast<uint32_t*>(plane) + 4u * (size_t)slot; HNB_PST(r[reg], q); HNB_PST(r[reg + 1], q + 1); HNB_PST(r[reg + 2], q + 2); HNB_PST(r[reg + 3], q + 3); } break;
+#else
         case 1: reinterpret_cast<uint32_t*>(plane)[slot] = r[reg]; break;
         case 2: reinterpret_cast<u2_t*>(plane)[slot] = u2_t{r[reg], r[reg + 1]}; break;
         case 3: reinterpret_cast<u3_t*>(plane)[slot] = u3_t{r[reg], r[reg + 1], r[reg + 2]}; break;
         default: reinterpret_cast<uint4*>(plane)[slot] = make_uint4(r[reg], r[reg + 1], r[reg + 2], r[reg + 3]); break;
+#endif
     }
 }
 // Returns the loaded components; the caller writes them at ONE indexed store site.
@@ -275,7 +311,7 @@ __device__ __forceinline__ void init_workgroup(const DevProgram& prog, const uin
         const uint32_t i = i0 + threadIdx.x;
         uint32_t r_bits = 0xffffffffu;   // (an idle lane)
         if (i < n_spawn) {
-        const uint32_t slot = dead[alive0 + i];
+        const uint32_t slot = HNB_LNT_LOAD(dead + (alive0 + i));
         VmState<typename CODE::file_t> S;
         S.r = typename CODE::file_t{};  // var particle = Particle();  (vfx_init.wgsl:174)
         S.pindex = slot + fi[k].slot_base;
@@ -293,7 +329,7 @@ __device__ __forceinline__ void init_workgroup(const DevProgram& prog, const uin
         }
         CODE::zero_unassigned(prog, io);
         CODE::run_init(prog, S, U, io);
-        alive[alive0 + i] = slot;
+        HNB_LNT_STORE(slot, alive + (alive0 + i));
         uint8_t alive_byte = 1u;  // the update walks the slots through these bytes
         if (prog.age_cohort) {  // a chunk that keeps its particles' common age in one word: this slot's age is in the plane (state 2, byte 3)
             uint32_t* astate = reinterpret_cast<uint32_t*>(base + prog.lmin_off) + 2u * prog.chunks_per_inst;
@@ -615,7 +651,7 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     const uint32_t* src = reinterpret_cast<const uint32_t*>(c.base + ((c.m.write_index & 1u) ? args.alive_off[1] : args.alive_off[0])) + c.start;
     uint32_t v[kSteps];
 #pragma unroll
-    for (uint32_t q = 0; q < kSteps; ++q) { const uint32_t i = wave * kWaveRows + q * 64u + lane; v[q] = i < rows ? src[i] : 0u; }
+    for (uint32_t q = 0; q < kSteps; ++q) { const uint32_t i = wave * kWaveRows + q * 64u + lane; v[q] = i < rows ? HNB_LNT_LOAD(src + i) : 0u; }
     unsigned long long word;   // (bit r of word i: row 64 i + r survives; nothing died in the instance: every row that exists survives)
     const bool suffix = args.suffix_dead != 0u && total_dead != 0u;
     const uint32_t alive0 = c.m.alive_count;                                  // rows the frame started with; this frame's spawns follow
@@ -684,10 +720,10 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
         const uint32_t r = __shfl(wexcl, wi, 64) + (uint32_t)__popcll(m & below);   // survivors of the chunk in front of this row
         if ((m >> lane) & 1ull) {
             const uint32_t g = excl + r;
-            out[g >= head_n ? g - head_n : g + tail] = v[q];
+            HNB_LNT_STORE(v[q], out + (g >= head_n ? g - head_n : g + tail));
         } else if (i < rows) {
             // the d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151); its alive byte is already 0
-            dead[c.n - 1u - (dead_before + (i - r))] = v[q];
+            HNB_LNT_STORE(v[q], dead + (c.n - 1u - (dead_before + (i - r))));
             if (suffix) {   // the host's proof, checked: this row's particle must be one of the frame's casualties
                 const uint32_t bits = reinterpret_cast<const uint32_t*>(c.base + args.died_bits_off)[v[q] >> 5];
                 if (((bits >> (v[q] & 31u)) & 1u) == 0u && args.fault) *args.fault = 1u;
@@ -1197,7 +1233,14 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
             need_life = __any(may_die);
         }
         if (any && (fl & 8u)) {
-            if (need_life) pin_load1<4>(X.lifetime, p_life, slot, lanes_on, true);
+            if (need_life) {
+#if defined(HNB_RO_NT)
+                const u4v ql = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p_life) + (slot[0] >> 2));
+                X.lifetime[0] = u2f(ql.x); X.lifetime[1] = u2f(ql.y); X.lifetime[2] = u2f(ql.z); X.lifetime[3] = u2f(ql.w);
+#else
+                pin_load1<4>(X.lifetime, p_life, slot, lanes_on, true);
+#endif
+            }
             else {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) X.lifetime[p] = Lm;  // age + dt < Lm holds for every alive slot of the step
@@ -1280,7 +1323,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         // frames; the others - C3's force field at 5 waves - lost 2.5 % to it and load each step's word where it is used, profiles/r03s_ab.log)
         auto f4_of = [&](const uint32_t step) {
             const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;
-            return chunk_full ? 0x01010101u : (s0 < args.capacity ? flags4[s0 >> 2] : 0u);  // the plane is padded: slots past the capacity read 0
+            return chunk_full ? 0x01010101u : (s0 < args.capacity ? HNB_RO_LOAD(flags4 + (s0 >> 2)) : 0u);  // the plane is padded: slots past the capacity read 0
         };
         if constexpr (COHORT || PROG::kFlat) {
             uint32_t f4s[kWaveRows / kStepRows];
@@ -1497,7 +1540,7 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
 #pragma unroll
     for (uint32_t s = 0; s < kSteps; ++s) {
         const uint32_t i = wave * kWaveRows + s * 64u + lane;
-        slot[s] = i < rows ? list[i] : 0xffffffffu;
+        slot[s] = i < rows ? HNB_LNT_LOAD(list + i) : 0xffffffffu;
     }
 #pragma unroll
     for (uint32_t s = 0; s < kSteps; ++s) bits[s] = slot[s] != 0xffffffffu ? died[slot[s] >> 5] : 0xffffffffu;   // (nontemporal loads: 1.8x slower; agent-scope atomic loads: the same, profiles/r03c_count_load.log)
