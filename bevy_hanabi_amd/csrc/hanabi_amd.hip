@@ -122,6 +122,7 @@ struct HnbContext {
     hipStream_t side_stream = nullptr;    // update phase of the LIGHT programs of a frame, next to the heavy one's on `stream` (enqueue_update_passes)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap_updates = true;          // HNB_OPT_OVERLAP_UPDATES
+    bool stream_hints = true;             // HNB_OPT_STREAM_HINTS
     // The per-frame parameters of EVERY program (instance rows, uniform blocks, init block starts) are staged in one pinned buffer and go to the
     // device with one copy per frame: with a copy per program, a scene of 26 small effects spent a quarter of its frame in 26 serialised
     // 3.5 us copy kernels and the host waiting for them (profiles/r02u_scene.md). A ring of slots: the host fills slot f % kFrameRing while the
@@ -815,6 +816,7 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
         case HNB_OPT_TRANSPOSE: ctx->transpose = value != 0u; return HNB_OK;
         case HNB_OPT_SCENE_MERGE: ctx->scene_merge = value != 0u; return HNB_OK;
         case HNB_OPT_SUFFIX_PROOF: ctx->suffix_proof = value != 0u; return HNB_OK;
+        case HNB_OPT_STREAM_HINTS: ctx->stream_hints = value != 0u; return HNB_OK;
         case HNB_OPT_OVERLAP_UPDATES: ctx->overlap_updates = value != 0u && ctx->side_stream != nullptr; return HNB_OK;
         default: return fail(HNB_ERR_INVALID_ARG, "unknown option %u", option);
     }
@@ -1328,6 +1330,7 @@ static SlotArgs slot_args_of(const HnbContext* ctx, const HnbProgram* p, uint32_
     sa.meta_in = p->d_meta[par]; sa.meta_out = p->d_meta[par ^ 1];
     sa.fault = p->d_fault;
     sa.transpose = ctx->transpose ? 1u : 0u;
+    sa.stream_hint = p->plan.stream_hint ? 1u : 0u;
     for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
         const DevAttr& at = p->dev.attrs[a];
         const int pi = at.reg == HNB_REG_POSITION ? 0 : at.reg == HNB_REG_VELOCITY ? 1 : at.reg == HNB_REG_AGE ? 2 : at.reg == HNB_REG_LIFETIME ? 3 : -1;
@@ -1350,6 +1353,7 @@ static CompactArgs compact_args_of(const HnbProgram* p) {
     ca.fault = p->d_fault;
     ca.slot_order = p->slot_order ? 1u : 0u;
     ca.suffix_dead = p->plan.ribbon.suffix ? 1u : 0u;
+    ca.stream_hint = p->plan.stream_hint ? 1u : 0u;
     ca.rotate_front = p->plan.ribbon.rotate ? 1u : 0u;   // k_compact writes the survivors [spawns | older ones]: see CompactArgs (ribbon programs never have slot-ordered lists)
     return ca;
 }

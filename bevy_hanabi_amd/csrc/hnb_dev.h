@@ -53,6 +53,7 @@ struct DevProgram {
     soff_t lmin_off;
     uint32_t cull_lifetime;    // 1: the streaming update keeps the bounds up to date and uses them
     uint32_t age_cohort;       // 1: chunks whose alive particles share one AGE keep it in a word (hnb_kernels.hip.h "Age cohorts")
+    uint32_t stream_hint;      // this frame: list traffic of k_init carries the nontemporal hint (hnb_kernels.hip.h "cache policy of streamed data")
     DevAttr attrs[kMaxAttrs];
     const Ins* init_code;
     const Ins* update_code;

@@ -59,18 +59,17 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 #define HNB_NT_STORE(v, p) (*(p) = (v))
 #endif
 
-// The list kernels (k_count_rows, k_compact) and the list side of k_init stream through data nobody reads again before the next frame's
-// update has walked its gigabyte of planes; their list accesses carry the nontemporal hint, so that what the 256 MiB Infinity Cache keeps
-// from one update launch to the next is more of the planes the alternating walk starts on. Measured on the c2_mixed regime (16.7M slots,
-// 277k spawns + deaths per frame, same box, two rounds, profiles/r04f_ab_lnt.log): init 0.0492 -> 0.0464 ms, update 0.209 -> 0.204,
-// lists 0.0735 -> 0.065, frame 0.3285 -> 0.312 ms. (HNB_LIST_NT_OFF: the default policy, for A/B runs.)
-#if !defined(HNB_LIST_NT_OFF)
-#define HNB_LNT_LOAD(p) __builtin_nontemporal_load(p)
-#define HNB_LNT_STORE(v, p) __builtin_nontemporal_store(v, p)
-#else
-#define HNB_LNT_LOAD(p) (*(p))
-#define HNB_LNT_STORE(v, p) (*(p) = (v))
-#endif
+// ---- cache policy of streamed data ----------------------------------------------------------------------------------------------
+// In a spawn / die steady state of a LARGE effect the update's time is set by how much of its planes the 256 MiB Infinity Cache still holds
+// when the next frame's (reversed) walk starts, and between two update launches the init, k_count_rows and k_compact move a quarter of a
+// gigabyte of their own. With `stream_hint` (decided per program and frame on the host: plan::use_streaming_hints - the frame touches more
+// than the cache holds) the list accesses of those kernels and the update's loads of its READ-ONLY planes (LIFETIME, alive bytes) carry the
+// nontemporal hint. Same-box A/B, two rounds each (profiles/r04f_ab_lnt.log, r04g_ab_nt2.log, r04i_ab_nt3.log): c2_mixed 0.382 -> 0.352 ms,
+// c2_dieoff 0.270 -> 0.252, c2_events 0.461 -> 0.430; C3 / c2_interop unchanged. A SMALL effect is served by the caches the hint gives up:
+// C5 (4.19M particles) 0.0402 -> 0.0451 ms with the hint, hence the size criterion. The hint on the init's scattered plane stores measured
+// nothing and is not made.
+template <class T> __device__ __forceinline__ T ld_hint(const T* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+template <class T> __device__ __forceinline__ void st_hint(T v, T* p, bool nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
 
 // ---- reset: dead_index[i] = i (effect_cache.rs:298-323) ------------------------------------
 #ifndef HNB_JIT_TU
@@ -104,37 +103,14 @@ __global__ void __launch_bounds__(256) k_probe_placement(char* __restrict__ base
 }
 #endif
 
-// Read-only planes of the streaming update (LIFETIME, the alive bytes: 5 of the 33 bytes of distinct memory per particle) are loaded with the
-// nontemporal hint: they need not take Infinity-Cache space from the position / velocity / age lines the next frame's walk starts on.
-// c2_mixed, same box, two rounds (profiles/r04g_ab_nt2.log): update 0.2046 -> 0.1990 ms, frame 0.3118 -> 0.3084 ms. The same hint on the init's
-// scattered plane stores (HNB_INIT_NT) measured nothing (0.3123): it stays off. (HNB_RO_NT_OFF: default policy, for A/B runs.)
-#if defined(HNB_INIT_NT)
-#define HNB_PST(v, p) __builtin_nontemporal_store(v, p)
-#else
-#define HNB_PST(v, p) (*(p) = (v))
-#endif
-#if !defined(HNB_RO_NT_OFF)
-#define HNB_RO_NT 1
-#define HNB_RO_LOAD(p) __builtin_nontemporal_load(p)
-#else
-#define HNB_RO_LOAD(p) (*(p))
-#endif
-
 // ---- V-file attribute access (generic kernels, one particle per lane) -----------------------
 template <class FILE_T>
 __device__ __forceinline__ void vfile_store_attr(const FILE_T& r, uint32_t ncomp, uint32_t reg, char* plane, uint32_t slot) {
     switch (ncomp) {
-#if defined(HNB_INIT_NT)
-        case 1: HNB_PST(r[reg], reinterpret_cast<uint32_t*>(plane) + slot); break;
-        case 2: { uint32_t* q = reinterpret_cast<uint32_t*>(plane) + 2u * (size_t)slot; HNB_PST(r[reg], q); HNB_PST(r[reg + 1], q + 1); } break;
-        case 3: { uint32_t* q = reinterpret_cast<uint32_t*>(plane) + 3u * (size_t)slot; HNB_PST(r[reg], q); HNB_PST(r[reg + 1], q + 1); HNB_PST(r[reg + 2], q + 2); } break;
-        default: { uint32_t* q = reinterpret_cast<uint32_t*>(plane) + 4u * (size_t)slot; HNB_PST(r[reg], q); HNB_PST(r[reg + 1], q + 1); HNB_PST(r[reg + 2], q + 2); HNB_PST(r[reg + 3], q + 3); } break;
-#else
         case 1: reinterpret_cast<uint32_t*>(plane)[slot] = r[reg]; break;
         case 2: reinterpret_cast<u2_t*>(plane)[slot] = u2_t{r[reg], r[reg + 1]}; break;
         case 3: reinterpret_cast<u3_t*>(plane)[slot] = u3_t{r[reg], r[reg + 1], r[reg + 2]}; break;
         default: reinterpret_cast<uint4*>(plane)[slot] = make_uint4(r[reg], r[reg + 1], r[reg + 2], r[reg + 3]); break;
-#endif
     }
 }
 // Returns the loaded components; the caller writes them at ONE indexed store site.
@@ -311,7 +287,7 @@ __device__ __forceinline__ void init_workgroup(const DevProgram& prog, const uin
         const uint32_t i = i0 + threadIdx.x;
         uint32_t r_bits = 0xffffffffu;   // (an idle lane)
         if (i < n_spawn) {
-        const uint32_t slot = HNB_LNT_LOAD(dead + (alive0 + i));
+        const uint32_t slot = ld_hint(dead + (alive0 + i), prog.stream_hint != 0u);
         VmState<typename CODE::file_t> S;
         S.r = typename CODE::file_t{};  // var particle = Particle();  (vfx_init.wgsl:174)
         S.pindex = slot + fi[k].slot_base;
@@ -329,7 +305,7 @@ __device__ __forceinline__ void init_workgroup(const DevProgram& prog, const uin
         }
         CODE::zero_unassigned(prog, io);
         CODE::run_init(prog, S, U, io);
-        HNB_LNT_STORE(slot, alive + (alive0 + i));
+        st_hint(slot, alive + (alive0 + i), prog.stream_hint != 0u);
         uint8_t alive_byte = 1u;  // the update walks the slots through these bytes
         if (prog.age_cohort) {  // a chunk that keeps its particles' common age in one word: this slot's age is in the plane (state 2, byte 3)
             uint32_t* astate = reinterpret_cast<uint32_t*>(base + prog.lmin_off) + 2u * prog.chunks_per_inst;
@@ -650,8 +626,14 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     constexpr uint32_t kSteps = kWaveRows / 64u;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(c.base + ((c.m.write_index & 1u) ? args.alive_off[1] : args.alive_off[0])) + c.start;
     uint32_t v[kSteps];
+    const bool nt = args.stream_hint != 0u;   // (uniform: one scalar branch around each unrolled run of accesses)
+    if (nt) {
 #pragma unroll
-    for (uint32_t q = 0; q < kSteps; ++q) { const uint32_t i = wave * kWaveRows + q * 64u + lane; v[q] = i < rows ? HNB_LNT_LOAD(src + i) : 0u; }
+        for (uint32_t q = 0; q < kSteps; ++q) { const uint32_t i = wave * kWaveRows + q * 64u + lane; v[q] = i < rows ? __builtin_nontemporal_load(src + i) : 0u; }
+    } else {
+#pragma unroll
+        for (uint32_t q = 0; q < kSteps; ++q) { const uint32_t i = wave * kWaveRows + q * 64u + lane; v[q] = i < rows ? src[i] : 0u; }
+    }
     unsigned long long word;   // (bit r of word i: row 64 i + r survives; nothing died in the instance: every row that exists survives)
     const bool suffix = args.suffix_dead != 0u && total_dead != 0u;
     const uint32_t alive0 = c.m.alive_count;                                  // rows the frame started with; this frame's spawns follow
@@ -720,10 +702,10 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
         const uint32_t r = __shfl(wexcl, wi, 64) + (uint32_t)__popcll(m & below);   // survivors of the chunk in front of this row
         if ((m >> lane) & 1ull) {
             const uint32_t g = excl + r;
-            HNB_LNT_STORE(v[q], out + (g >= head_n ? g - head_n : g + tail));
+            st_hint(v[q], out + (g >= head_n ? g - head_n : g + tail), nt);
         } else if (i < rows) {
             // the d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151); its alive byte is already 0
-            HNB_LNT_STORE(v[q], dead + (c.n - 1u - (dead_before + (i - r))));
+            st_hint(v[q], dead + (c.n - 1u - (dead_before + (i - r))), nt);
             if (suffix) {   // the host's proof, checked: this row's particle must be one of the frame's casualties
                 const uint32_t bits = reinterpret_cast<const uint32_t*>(c.base + args.died_bits_off)[v[q] >> 5];
                 if (((bits >> (v[q] & 31u)) & 1u) == 0u && args.fault) *args.fault = 1u;
@@ -759,6 +741,7 @@ struct CompactArgs {
                                // started with; this frame's spawns behind them survive. k_count_rows does not run; k_compact checks the died bit of
                                // every row it treats as a casualty (they are `deaths` distinct slots: all set <=> the sets are equal) or raises `fault`
     uint32_t slot_order;       // HNB_LIST_ORDER_SLOT: k_order_write rebuilds the lists from the alive bytes
+    uint32_t stream_hint;      // 1: list rows are read and written with the nontemporal hint ("cache policy of streamed data")
     uint32_t rotate_front;     // ribbon programs, host-proven (HnbProgram::sort_front_*): this frame's spawns sort in front of every older
                                // particle, so the survivors are written [spawns | older ones] and the list needs no sort afterwards
 };
@@ -1007,6 +990,7 @@ struct SlotArgs {
     DevMeta* meta_out;
     uint32_t* fault;         // set to 1 if a particle dies in a frame whose lists were skipped (never, unless the proof is wrong)
     uint32_t transpose;      // 1: vec3 planes of the per-particle path go through the wave's LDS transpose (xpose_load3 / xpose_store3)
+    uint32_t stream_hint;    // 1: read-only planes (LIFETIME, alive bytes) are loaded with the nontemporal hint ("cache policy of streamed data")
 };
 
 // The deaths of a frame are known on the device only after its update ran, and HIP has no indirect dispatch: the list
@@ -1234,12 +1218,10 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         }
         if (any && (fl & 8u)) {
             if (need_life) {
-#if defined(HNB_RO_NT)
-                const u4v ql = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p_life) + (slot[0] >> 2));
-                X.lifetime[0] = u2f(ql.x); X.lifetime[1] = u2f(ql.y); X.lifetime[2] = u2f(ql.z); X.lifetime[3] = u2f(ql.w);
-#else
-                pin_load1<4>(X.lifetime, p_life, slot, lanes_on, true);
-#endif
+                if (args.stream_hint) {   // (a read-only plane: see "cache policy of streamed data")
+                    const u4v ql = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p_life) + (slot[0] >> 2));
+                    X.lifetime[0] = u2f(ql.x); X.lifetime[1] = u2f(ql.y); X.lifetime[2] = u2f(ql.z); X.lifetime[3] = u2f(ql.w);
+                } else pin_load1<4>(X.lifetime, p_life, slot, lanes_on, true);
             }
             else {
 #pragma unroll
@@ -1323,7 +1305,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         // frames; the others - C3's force field at 5 waves - lost 2.5 % to it and load each step's word where it is used, profiles/r03s_ab.log)
         auto f4_of = [&](const uint32_t step) {
             const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;
-            return chunk_full ? 0x01010101u : (s0 < args.capacity ? HNB_RO_LOAD(flags4 + (s0 >> 2)) : 0u);  // the plane is padded: slots past the capacity read 0
+            return chunk_full ? 0x01010101u : (s0 < args.capacity ? ld_hint(flags4 + (s0 >> 2), args.stream_hint != 0u) : 0u);  // the plane is padded: slots past the capacity read 0
         };
         if constexpr (COHORT || PROG::kFlat) {
             uint32_t f4s[kWaveRows / kStepRows];
@@ -1540,7 +1522,7 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
 #pragma unroll
     for (uint32_t s = 0; s < kSteps; ++s) {
         const uint32_t i = wave * kWaveRows + s * 64u + lane;
-        slot[s] = i < rows ? HNB_LNT_LOAD(list + i) : 0xffffffffu;
+        slot[s] = i < rows ? ld_hint(list + i, args.stream_hint != 0u) : 0xffffffffu;
     }
 #pragma unroll
     for (uint32_t s = 0; s < kSteps; ++s) bits[s] = slot[s] != 0xffffffffu ? died[slot[s] >> 5] : 0xffffffffu;   // (nontemporal loads: 1.8x slower; agent-scope atomic loads: the same, profiles/r03c_count_load.log)

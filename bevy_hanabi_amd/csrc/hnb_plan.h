@@ -10,6 +10,7 @@
 //   size_init_grid        init workgroups of one instance (HIP has no indirect dispatch: sized on the host for what the host knows)
 //   size_event_grid       splits of a chunk's spawn events over workgroups
 //   plan_merged_launches  which small, independent programs share the job-table launches of the frame
+//   use_streaming_hints   cache policy: is the program big enough for its list traffic to be streamed past the Infinity Cache
 //
 // What each proof assumes about the device code is stated at the device side (hnb_kernels.hip.h); a wrong proof is reported by the
 // kernels through HnbEffectMetadata::fault, never silently.
@@ -238,12 +239,23 @@ inline void plan_merged_launches(const MergeFacts* progs, MergeDecision* out, ui
     }
 }
 
+// ---- cache policy ----------------------------------------------------------------------------------------------------------------------------
+// Streaming hints (nontemporal list traffic, nontemporal loads of the update's read-only planes: hnb_kernels.hip.h "cache policy of streamed
+// data") pay when one frame of the program touches more than the 256 MiB Infinity Cache holds - a 16.7M-particle effect moves a gigabyte per
+// frame, and what the cache keeps of it should be the planes the next frame starts on, not the lists - and cost a small effect the cache hits
+// it lives on (C5, 4.19M particles, 35 MB per frame: 12 % slower with the hints; profiles/r04i_ab_nt3.log).
+constexpr uint64_t kStreamHintBytes = 256ull << 20;
+inline bool use_streaming_hints(uint64_t total_slots, uint32_t update_bytes_per_slot) {
+    return total_slots * (uint64_t)(update_bytes_per_slot + 8u) > kStreamHintBytes;   // attributes the update loads + stores, + the list rows
+}
+
 // ---- the plan of one program for one frame ------------------------------------------------------------------------------------------------
 struct FramePlan {
     bool skip_lists = false;        // proven: no spawn, no casualty - the update kernel is the program's only launch
     bool lists = true;              // k_count_rows / k_compact (or the slot-order kernels) run
     bool lists_merged = false;      // ... inside the context's multi-program list launches
     bool hz_use = false;            // k_count_rows may trust the death horizons
+    bool stream_hint = false;       // the frame touches more than the Infinity Cache holds: list traffic and read-only planes are streamed
     RibbonDecision ribbon;
     bool independent = false;
     MergeDecision merge;

@@ -303,6 +303,9 @@ int hnb_ctx_synchronize(HnbContext* ctx);
  *   runs on an internal second stream next to the heavy program's update and joins the context's stream before hnb_simulate returns.
  *   Same results; frames on which kernel timing is sampled use one stream. */
 #define HNB_OPT_OVERLAP_UPDATES 10u
+/* HNB_OPT_STREAM_HINTS (default 1; from the next hnb_simulate on): programs whose frame touches more than the 256 MiB Infinity Cache holds
+ *   read and write their lists, and read the update's read-only planes, with the nontemporal hint (a cache-policy choice: same results). */
+#define HNB_OPT_STREAM_HINTS 11u
 int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value);
 
 /* Replaces EffectShaderSources::generate + pipeline specialisation (src/lib.rs:805-1336). */

@@ -46,6 +46,7 @@ def lib():
     lib.cpl_init_grid.restype = C.c_uint32
     lib.cpl_event_grid.argtypes = [C.c_uint32, C.c_uint32]
     lib.cpl_event_grid.restype = C.c_uint32
+    lib.cpl_stream_hints.argtypes = [C.c_uint64, C.c_uint32]
     lib.cpl_merge.argtypes = [C.POINTER(MergeRow), C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int32)]
     return lib
 
@@ -263,6 +264,16 @@ def test_init_and_event_grids(lib):
     assert g(has_parent=1, evcap=4096, simulated=0, known=1, events=50) == 0
     e = lib.cpl_event_grid
     assert e(0, 1) == 1 and e(256, 1) == 1 and e(16384, 1) == 1 and e(16385, 1) == 2 and e(1 << 23, 8) == 64 and e(1 << 23, 4096) == 1 and e(1 << 30, 1) == 64 and e(1000, 0) == 1
+
+
+def test_streaming_hints_are_for_programs_bigger_than_the_infinity_cache(lib):
+    h = lib.cpl_stream_hints
+    assert h(1 << 24, 60) == 1            # the 16.7M firework: pos / vel / age in and out + lifetime = 60 B per slot, a gigabyte per frame
+    assert h(1 << 23, 60) == 1            # force field 8.4M
+    assert h(512 * 65536, 28) == 1        # 512 instances x 65,536
+    assert h(1 << 22, 8) == 0             # the ribbon effect: age in and out, 4.19M slots: 67 MB per frame - the caches serve it better
+    assert h(65536, 60) == 0 and h(0, 60) == 0
+    assert h((256 << 20) // 68, 60) == 0 and h((256 << 20) // 68 + 1, 60) == 1     # the boundary: slots x (bytes + 8 B of list) > 256 MiB
 
 
 # ---- plan_merged_launches --------------------------------------------------------------------------------------------------------------------------
