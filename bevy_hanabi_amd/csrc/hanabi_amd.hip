@@ -1486,6 +1486,15 @@ static void stage_program_frame(HnbContext* ctx, HnbProgram* p, uint32_t slot, s
     if (pl.hz_use && pl.lists) p->hz_frames += 1;
     p->dev.hz_parity = p->hz_parity;
     p->dev.frame_no = p->frames_run;
+    {   // cache policy: bytes of attribute planes the update loads + stores per slot
+        uint32_t bytes = 0;
+        for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
+            const DevAttr& at = p->dev.attrs[a];
+            bytes += ((at.upd_flags & HNB_ATTR_UPD_LOAD) ? 4u * at.ncomp : 0u) + ((at.upd_flags & HNB_ATTR_UPD_STORE) ? 4u * at.ncomp : 0u);
+        }
+        pl.stream_hint = ctx->stream_hints && plan::use_streaming_hints((uint64_t)n * p->dev.capacity, bytes);
+        p->dev.stream_hint = pl.stream_hint ? 1u : 0u;
+    }
     pl.independent = p->hdr.n_event_channels == 0 && !(p->hdr.flags & HNB_PROG_READS_PARENT) && n != 0u;
     for (uint32_t i = 0; i < n; ++i) if (p->effects[i]->parent) pl.independent = false;
     uint32_t* init_start = ublocks + (size_t)n * nu;  // packed copy of init_block_start for k_init's search
