@@ -1638,7 +1638,7 @@ static int enqueue_init_passes(HnbContext* ctx, const std::vector<HnbProgram*>& 
         const char* d = p->d_frame_cur;
         const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
         const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
-        if (blocks && !(p->plan.merge.init_family >= 0)) {
+        if (blocks && p->plan.merge.init_family < 0) {   // (>= 0: served by k_init_jobs below)
             TimingPair ti{};
             ti.prog = p;
             if (timed) { ti.a = take_event(ctx); ti.b = take_event(ctx); hipEventRecord(ti.a, ctx->stream); }
@@ -1675,8 +1675,8 @@ static int enqueue_program_update(HnbContext* ctx, HnbProgram* p, hipStream_t st
     tu.prog = tc.prog = p;
     if (timed) { tu.a = take_event(ctx); tu.b = take_event(ctx); tc.b = take_event(ctx); hipEventRecord(tu.a, st); }
     const uint32_t write_died = (p->plan.lists && !p->slot_order) ? 1u : 0u;   // k_count_rows follows: the update leaves one died bit per slot
-    if ((p->plan.merge.update_family >= 0)) {
-        // (k_update_stream_jobs / k_update_generic_jobs above)
+    if (p->plan.merge.update_family >= 0) {
+        // (served by k_update_jobs / k_update_generic_wide_jobs: enqueue_update_passes)
     } else if (p->update_streams) {
         SlotArgs sa = slot_args_of(ctx, p, n, write_died);
         if (p->jit_update) {

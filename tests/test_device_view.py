@@ -110,3 +110,38 @@ def test_age_plane_is_stale_without_materialise_and_current_with_it():
     with pytest.raises(bh.HanabiError):
         fx.materialise([A.SIZE.id])                 # not in the layout
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_view_of_a_light_program_behind_a_two_stream_frame():
+    """HNB_OPT_OVERLAP_UPDATES runs the update phase of the light programs on an internal side stream beside the heavy program's. The
+    view's contract does not change: a consumer enqueued on view.stream right behind hnb_simulate sees the whole frame - here it gathers
+    the ROCKETS (updated, event-ordered and compacted on the side stream) and the sparkles while the trails (1M slots, the heavy program)
+    ran on the context's stream - and equals the host read-back taken after a synchronisation."""
+    from helpers import EffectSpec, GpuSystem, Frame
+    cons = _consumer()
+    cap = 1 << 20
+    rocket = effects.firework_rocket(8192, 5, 1000)
+    rocket.spawner = bh.SpawnerSettings.rate(2000.0)
+    specs = [EffectSpec(rocket), EffectSpec(effects.firework_sparkle_trail(1 << 16), parent=0, channel=0, event_capacity=1 << 15),
+             EffectSpec(effects.firework_trails_child(cap), parent=0, channel=1, event_capacity=1 << 19)]
+    ctx = bh.Context(0)
+    g = GpuSystem(specs, ctx)
+    sp, rng = bh.EffectSpawner(rocket.spawner), bh.Pcg32()
+    dt = 0.2
+    seen_rockets = 0
+    for f in range(10):
+        g.step([Frame(dt, sp.tick(dt, rng), frame_seed(f), time=f * dt), Frame(dt, 0, frame_seed(1000 + f), time=f * dt), Frame(dt, 0, frame_seed(2000 + f), time=f * dt)])
+        gathered = []
+        for fx, nrows in ((g.fx[0], 8192), (g.fx[1], 1 << 16)):
+            gathered.append(_gather(cons, fx, A.POSITION.id, 3, nrows))
+        ctx.synchronize()
+        for fx, (v, pos, cnt) in zip((g.fx[0], g.fx[1]), gathered):
+            n, alive = fx.alive_count(), fx.alive_list()
+            assert int(cnt.item()) == n == len(alive), f"frame {f}"
+            ref = fx.read_attr(A.POSITION.id).view(np.uint32)[alive]
+            np.testing.assert_array_equal(pos.cpu().numpy().view(np.uint32)[: n * 3].reshape(n, 3), ref, err_msg=f"frame {f}")
+        seen_rockets = max(seen_rockets, g.fx[0].alive_count())
+    assert seen_rockets > 100 and g.fx[2].alive_count() > cap // 8
+    g.destroy()
+    ctx.close()
