@@ -5,7 +5,7 @@
 
 A "step" is one simulated frame (one pass of the hot path: per-frame inputs upload, init where the frame spawns, update +
 kill + list maintenance, ribbon sort where the layout has RIBBON_ID) over particle state resident in HBM. After W warm-up
-frames the script times WINDOWS (default 11) windows of exactly K steps each, every one bracketed by a barrier and a device
+frames the script times WINDOWS (default 25) windows of exactly K steps each, every one bracketed by a barrier and a device
 synchronisation; `ms_per_step` / `value` are the MEDIAN window, the others are listed under "windows" (min, all).
 
 Configurations (synthetic scalings of the reference's example assets):
@@ -979,7 +979,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--windows", type=int, default=11, help="timed windows of --steps frames each; the line reports the median window")
+    ap.add_argument("--windows", type=int, default=25, help="timed windows of --steps frames each; the line reports the median window")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both")
     ap.add_argument("--capacity", type=int, default=None, help="particles per effect instance (default: the configuration's)")
