@@ -1331,6 +1331,7 @@ static SlotArgs slot_args_of(const HnbContext* ctx, const HnbProgram* p, uint32_
     sa.fault = p->d_fault;
     sa.transpose = ctx->transpose ? 1u : 0u;
     sa.stream_hint = p->plan.stream_hint ? 1u : 0u;
+    sa.store_hint = p->plan.store_hint ? 1u : 0u;
     for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
         const DevAttr& at = p->dev.attrs[a];
         const int pi = at.reg == HNB_REG_POSITION ? 0 : at.reg == HNB_REG_VELOCITY ? 1 : at.reg == HNB_REG_AGE ? 2 : at.reg == HNB_REG_LIFETIME ? 3 : -1;
@@ -1487,12 +1488,14 @@ static void stage_program_frame(HnbContext* ctx, HnbProgram* p, uint32_t slot, s
     p->dev.hz_parity = p->hz_parity;
     p->dev.frame_no = p->frames_run;
     {   // cache policy: bytes of attribute planes the update loads + stores per slot
-        uint32_t bytes = 0;
+        uint32_t bytes = 0, stored = 0;
         for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
             const DevAttr& at = p->dev.attrs[a];
             bytes += ((at.upd_flags & HNB_ATTR_UPD_LOAD) ? 4u * at.ncomp : 0u) + ((at.upd_flags & HNB_ATTR_UPD_STORE) ? 4u * at.ncomp : 0u);
+            stored += (at.upd_flags & HNB_ATTR_UPD_STORE) ? 4u * at.ncomp : 0u;
         }
         pl.stream_hint = ctx->stream_hints && plan::use_streaming_hints((uint64_t)n * p->dev.capacity, bytes);
+        pl.store_hint = pl.stream_hint && plan::use_store_hints((uint64_t)n * p->dev.capacity, stored);
         p->dev.stream_hint = pl.stream_hint ? 1u : 0u;
     }
     pl.independent = p->hdr.n_event_channels == 0 && !(p->hdr.flags & HNB_PROG_READS_PARENT) && n != 0u;

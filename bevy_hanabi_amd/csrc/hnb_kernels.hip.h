@@ -420,8 +420,12 @@ __device__ __forceinline__ void pin_load1(float (&dst)[P], const char* plane, co
     for (int p = 0; p < P; ++p) dst[p] = valid[p] ? reinterpret_cast<const float*>(plane)[slot[p]] : 0.0f;
 }
 template <int P>
-__device__ __forceinline__ void pin_store1(const float (&src)[P], char* plane, const uint32_t (&slot)[P], const bool (&valid)[P], bool dense) {
+__device__ __forceinline__ void pin_store1(const float (&src)[P], char* plane, const uint32_t (&slot)[P], const bool (&valid)[P], bool dense, bool nt = false) {
     if constexpr (P == 4) {
+        if (dense && nt) {
+            __builtin_nontemporal_store((u4v{f2u(src[0]), f2u(src[1]), f2u(src[2]), f2u(src[3])}), reinterpret_cast<u4v*>(plane) + (slot[0] >> 2));
+            return;
+        }
         if (dense) {
             HNB_NT_STORE((u4v{f2u(src[0]), f2u(src[1]), f2u(src[2]), f2u(src[3])}), reinterpret_cast<u4v*>(plane) + (slot[0] >> 2));
             return;
@@ -465,7 +469,7 @@ __device__ __forceinline__ void xpose_load3(V3 (&dst)[4], const char* plane, uin
     dst[3] = V3{u2f(q2.y), u2f(q2.z), u2f(q2.w)};
 }
 // `lds` must still hold what xpose_load3 put there for this plane and step.
-__device__ __forceinline__ void xpose_store3(const V3 (&src)[4], char* plane, uint32_t first_slot, u4v* lds, uint32_t lane, const bool (&valid)[4], bool full) {
+__device__ __forceinline__ void xpose_store3(const V3 (&src)[4], char* plane, uint32_t first_slot, u4v* lds, uint32_t lane, const bool (&valid)[4], bool full, bool nt = false) {
     if (full) {
         lds[3u * lane] = u4v{f2u(src[0].x), f2u(src[0].y), f2u(src[0].z), f2u(src[1].x)};
         lds[3u * lane + 1u] = u4v{f2u(src[1].y), f2u(src[1].z), f2u(src[2].x), f2u(src[2].y)};
@@ -481,7 +485,8 @@ __device__ __forceinline__ void xpose_store3(const V3 (&src)[4], char* plane, ui
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     u4v* dstp = reinterpret_cast<u4v*>(plane) + (size_t)(first_slot >> 2) * 3;
     const u4v a = lds[lane], b = lds[64u + lane], c = lds[128u + lane];
-    dstp[lane] = a; dstp[64u + lane] = b; dstp[128u + lane] = c;
+    if (nt) { __builtin_nontemporal_store(a, dstp + lane); __builtin_nontemporal_store(b, dstp + 64u + lane); __builtin_nontemporal_store(c, dstp + 128u + lane); }
+    else { dstp[lane] = a; dstp[64u + lane] = b; dstp[128u + lane] = c; }
 }
 
 // ---- update + kill + compaction ----------------------------------------------------------------
@@ -991,6 +996,7 @@ struct SlotArgs {
     uint32_t* fault;         // set to 1 if a particle dies in a frame whose lists were skipped (never, unless the proof is wrong)
     uint32_t transpose;      // 1: vec3 planes of the per-particle path go through the wave's LDS transpose (xpose_load3 / xpose_store3)
     uint32_t stream_hint;    // 1: read-only planes (LIFETIME, alive bytes) are loaded with the nontemporal hint ("cache policy of streamed data")
+    uint32_t store_hint;     // 1: the per-particle path stores its planes with the nontemporal hint (update_stream_chunk)
 };
 
 // The deaths of a frame are known on the device only after its update ran, and HIP has no indirect dispatch: the list
@@ -1055,6 +1061,10 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     const uint32_t k = chunk / args.chunks_per_inst, j = chunk - k * args.chunks_per_inst;
+    // Plane stores of a program whose WRITTEN planes exceed the Infinity Cache by half (SlotArgs::store_hint, plan::use_store_hints): nontemporal.
+    // Same-box A/B (profiles/r04o_ab_walk.log, r04p_ab_walk2.log): c2_mixed 0.327 -> 0.316 ms, c2_events 0.456 -> 0.438; C3 - 8.4M particles,
+    // 235 MB of written planes: they FIT the cache and the next frame's walk finds them there - 0.097 -> 0.120 ms with the hint, hence the size rule.
+    const bool store_nt = args.store_hint != 0u;
     if (args.safe_words && chunk == 0u) {  // publish the previous frame's bound: its kernel has completed, every chunk's word is final
         const uint32_t* prev = args.safe_words + (size_t)(args.safe_parity ^ 1u) * args.safe_stride;
         uint32_t m = 0x7f800000u;
@@ -1233,8 +1243,8 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         if constexpr (!(PROBE & 4)) {
             // (a plane that is stored without having been loaded has no staged copy: the direct path)
             const bool xp_pos = xp && (fl & 17u) == 17u, xp_vel = xp && (fl & 34u) == 34u;
-            if (xp_pos) xpose_store3(X.pos, p_pos, step_first, s_xp[0][wave], lane, was, full);
-            if (xp_vel) xpose_store3(X.vel, p_vel, step_first, s_xp[1][wave], lane, was, full);
+            if (xp_pos) xpose_store3(X.pos, p_pos, step_first, s_xp[0][wave], lane, was, full, store_nt);
+            if (xp_vel) xpose_store3(X.vel, p_vel, step_first, s_xp[1][wave], lane, was, full, store_nt);
             if (any) {  // a full quad is stored with 16-byte stores; otherwise only the alive slots are written
                 if ((fl & 16u) && !xp_pos) pin_store3<4>(X.pos, p_pos, slot, was, full);
                 if ((fl & 32u) && !xp_vel) pin_store3<4>(X.vel, p_vel, slot, was, full);
@@ -1244,8 +1254,8 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
                             float q[4];
 #pragma unroll
                             for (int p = 0; p < 4; ++p) q[p] = was[p] ? X.age[p] : age_was[p];
-                            pin_store1<4>(q, p_age, slot, was, true);
-                        } else pin_store1<4>(X.age, p_age, slot, was, full);
+                            pin_store1<4>(q, p_age, slot, was, true, store_nt);
+                        } else pin_store1<4>(X.age, p_age, slot, was, full, store_nt);
                     }
                 }
                 if (fl & 128u) pin_store1<4>(X.lifetime, p_life, slot, was, full);

@@ -249,6 +249,11 @@ inline bool use_streaming_hints(uint64_t total_slots, uint32_t update_bytes_per_
     return total_slots * (uint64_t)(update_bytes_per_slot + 8u) > kStreamHintBytes;   // attributes the update loads + stores, + the list rows
 }
 
+// ... and the update's own plane STORES are streamed only when the planes it writes exceed the cache by half: what fits (force_field.rs at
+// 8.4M particles writes 235 MB) is found there by the next frame's reversed walk, and the hint would throw that away (C3: +22 %).
+constexpr uint64_t kStoreHintBytes = 384ull << 20;
+inline bool use_store_hints(uint64_t total_slots, uint32_t stored_bytes_per_slot) { return total_slots * (uint64_t)stored_bytes_per_slot > kStoreHintBytes; }
+
 // ---- the plan of one program for one frame ------------------------------------------------------------------------------------------------
 struct FramePlan {
     bool skip_lists = false;        // proven: no spawn, no casualty - the update kernel is the program's only launch
@@ -256,6 +261,7 @@ struct FramePlan {
     bool lists_merged = false;      // ... inside the context's multi-program list launches
     bool hz_use = false;            // k_count_rows may trust the death horizons
     bool stream_hint = false;       // the frame touches more than the Infinity Cache holds: list traffic and read-only planes are streamed
+    bool store_hint = false;        // ... and the planes the update writes exceed it by half: its plane stores are streamed too
     RibbonDecision ribbon;
     bool independent = false;
     MergeDecision merge;

@@ -64,6 +64,7 @@ uint32_t cpl_init_grid(int simulated, int has_parent, uint32_t spawn_count, uint
     return size_init_grid(in, capacity, init_block, rounds, big_burst != 0, num_cus);
 }
 int cpl_stream_hints(uint64_t total_slots, uint32_t update_bytes_per_slot) { return use_streaming_hints(total_slots, update_bytes_per_slot) ? 1 : 0; }
+int cpl_store_hints(uint64_t total_slots, uint32_t stored_bytes_per_slot) { return use_store_hints(total_slots, stored_bytes_per_slot) ? 1 : 0; }
 uint32_t cpl_event_grid(uint32_t max_event_capacity, uint32_t total_chunks) { return size_event_grid(max_event_capacity, total_chunks); }
 
 struct MergeRow { uint32_t independent, total_chunks, init_blocks, init_len, update_len, wide_file, update_streams, age_cohort; };

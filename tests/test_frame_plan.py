@@ -47,6 +47,7 @@ def lib():
     lib.cpl_event_grid.argtypes = [C.c_uint32, C.c_uint32]
     lib.cpl_event_grid.restype = C.c_uint32
     lib.cpl_stream_hints.argtypes = [C.c_uint64, C.c_uint32]
+    lib.cpl_store_hints.argtypes = [C.c_uint64, C.c_uint32]
     lib.cpl_merge.argtypes = [C.POINTER(MergeRow), C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int32)]
     return lib
 
@@ -274,6 +275,11 @@ def test_streaming_hints_are_for_programs_bigger_than_the_infinity_cache(lib):
     assert h(1 << 22, 8) == 0             # the ribbon effect: age in and out, 4.19M slots: 67 MB per frame - the caches serve it better
     assert h(65536, 60) == 0 and h(0, 60) == 0
     assert h((256 << 20) // 68, 60) == 0 and h((256 << 20) // 68 + 1, 60) == 1     # the boundary: slots x (bytes + 8 B of list) > 256 MiB
+    # the update's own plane stores: only when the WRITTEN planes exceed the cache by half (what fits is found there by the next frame)
+    st = lib.cpl_store_hints
+    assert st(1 << 24, 28) == 1           # firework 16.7M: position + velocity + age = 470 MB written per frame
+    assert st(1 << 23, 28) == 0           # force field 8.4M: 235 MB - it fits, and the hint cost C3 22 % (profiles/r04p_ab_walk2.log)
+    assert st(1 << 22, 4) == 0 and st(100_000_000, 28) == 1
 
 
 # ---- plan_merged_launches --------------------------------------------------------------------------------------------------------------------------
