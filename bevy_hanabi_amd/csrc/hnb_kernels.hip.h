@@ -1033,7 +1033,7 @@ struct SlotArgs {
 // program checks whether the survivors' new ages are all equal (min == max of their bit patterns): then it writes the value
 // and skips the plane, else it stores the ages (which materialises them) and returns to state 0. Host reads of the AGE plane
 // materialise first (k_materialise_age), host writes reset the states. Eligible programs: the lifetime-culling ones (the
-// stream starts with its only AGE_TICK, nothing else writes AGE) without ribbons (the sort reads the plane); HNB_AGE_COHORT=0 off.
+// stream starts with its only AGE_TICK, nothing else writes AGE) without ribbons (the sort reads the plane); HNB_OPT_AGE_COHORT = OFF switches them off.
 
 // The died bits of one wave step (256 slots, lane l owns slots 4 l .. 4 l + 3 and brings their four bits in `nib`) as 8 dwords of the
 // linear bit array: dword d holds lanes 8 d .. 8 d + 7. An OR over every group of 8 lanes in three DPP steps (quad_perm [1,0,3,2],
