@@ -817,7 +817,7 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
         case HNB_OPT_SCENE_MERGE: ctx->scene_merge = value != 0u; return HNB_OK;
         case HNB_OPT_SUFFIX_PROOF: ctx->suffix_proof = value != 0u; return HNB_OK;
         case HNB_OPT_STREAM_HINTS: ctx->stream_hints = value != 0u; return HNB_OK;
-        case HNB_OPT_OVERLAP_UPDATES: ctx->overlap_updates = value != 0u && ctx->side_stream != nullptr; return HNB_OK;
+        case HNB_OPT_OVERLAP_UPDATES: ctx->overlap_updates = value != 0u && ctx->side_stream && ctx->ev_fork && ctx->ev_join; return HNB_OK;   // (all three exist unless their creation failed)
         default: return fail(HNB_ERR_INVALID_ARG, "unknown option %u", option);
     }
 }
