@@ -74,7 +74,7 @@ struct DevFrameInst {
     uint32_t ev_parity;         // context frame parity: events are appended to count[ev_parity], consumed from count[ev_parity ^ 1]
     uint32_t skip;              // 1: the instance is not simulated this frame (SimulationCondition::WhenVisible and not visible): state frozen
 };
-static_assert(sizeof(DevFrameInst) == 128, "DevFrameInst layout");
+static_assert(sizeof(DevFrameInst) == 96 + 8 * HNB_MAX_EVENT_CHANNELS, "DevFrameInst layout");
 
 // Spawn events of one (parent instance, channel). `count` keeps growing past the capacity like the
 // reference's GpuChildInfo::event_count (src/lib.rs:976-993); it is double-buffered by frame parity so

@@ -88,7 +88,7 @@ typedef enum HnbScalarType { HNB_BOOL = 0, HNB_F32 = 1, HNB_I32 = 2, HNB_U32 = 3
                                     HNB_VM_MAX_REGS run on the wide file: specialised kernels scalarise it, the
                                     interpreter kernels index it in scratch memory (correct, slower). */
 #define HNB_VM_MAX_UREGS 256u  /* U registers per instance */
-#define HNB_MAX_EVENT_CHANNELS 4u /* child event channels per parent effect (EmitSpawnEventModifier::child_index < 4) */
+#define HNB_MAX_EVENT_CHANNELS 8u /* child event channels per parent effect (EmitSpawnEventModifier::child_index < 4) */
 #define HNB_OPERAND_U 0x80u
 /* Decoded operand of a varying stream (what the VM works with): bit 8 = U register, bits 7:0 = index. */
 #define HNB_OPERAND_DECODED_U 0x100u

@@ -86,7 +86,7 @@ typedef struct {
     uint8_t* side_effect; /* per expression */
 } Asset;
 
-#define MAX_CHANNELS 4
+#define MAX_CHANNELS 8   /* == HNB_MAX_EVENT_CHANNELS of include/hanabi_amd.h */
 typedef struct Effect_ {
     Asset* asset;
     uint32_t slot_base;

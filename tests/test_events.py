@@ -274,3 +274,53 @@ def test_gpu_update_phase_on_two_streams_equals_one_stream_and_the_oracle(overla
     assert g.fx[2].metadata()["particle_counter"] > cap // 4 and all(fx.metadata()["fault"] == 0 for fx in g.fx)
     g.destroy()
     ctx.close()
+
+
+def six_channel_system():
+    """One parent appending to SIX child channels (the reference loops over any number of event bindings, src/lib.rs:964-1002; this library's
+    limit is HNB_MAX_EVENT_CHANNELS = 8): channels 0 / 2 / 4 every frame (1, 2, 3 events), channels 1 / 3 / 5 on death (4, 5, 6 events)."""
+    w = bh.ExprWriter()
+    init = [bh.SetAttributeModifier(A.POSITION, w.lit((1.0, 2.0, 3.0)).expr()), bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()),
+            bh.SetAttributeModifier(A.LIFETIME, w.lit(0.05).expr()), bh.SetAttributeModifier(A.U32_0, w.attr(A.ID).expr())]
+    emits = []
+    for ch in range(6):
+        cond = bh.EventEmitCondition.Always if ch % 2 == 0 else bh.EventEmitCondition.OnDie
+        emits.append(bh.EmitSpawnEventModifier(cond, w.lit(bh.Value.u32(ch // 2 + 1 if ch % 2 == 0 else ch // 2 + 4)).expr(), ch))
+    parent = bh.EffectAsset(16, bh.SpawnerSettings.once(5.0), w.finish())
+    for m in init:
+        parent.init(m)
+    for m in emits:
+        parent.update(m)
+    return [EffectSpec(parent)] + [EffectSpec(tiny_child(256), parent=0, channel=ch, event_capacity=64) for ch in range(6)]
+
+
+def six_channel_frames(n):
+    return [[Frame(1 / 60, 5 if f in (0, 4) else 0, 7 + f, time=f / 60)] + [Frame(1 / 60, 0, 100 * (c + 1) + f, time=f / 60) for c in range(6)] for f in range(n)]
+
+
+def test_oracle_six_event_channels():
+    o = OracleSystem(six_channel_system())
+    frames = six_channel_frames(8)
+    for fr in frames:
+        o.step(fr)
+    st = o.state()
+    # 5 parents live 3 frames (0.05 s at 1/60 s: alive after 1, 2, 3 ticks? age 3/60 = 0.05 is not < 0.05: they die in their third update), twice
+    spawned = [s["counters"]["particle_counter"] for s in st]
+    assert spawned[0] == 10
+    assert spawned[1] > 0 and spawned[3] == 2 * spawned[1] and spawned[5] == 3 * spawned[1]      # Always channels: 1, 2, 3 events per alive parent and frame
+    assert spawned[2] == 10 * 4 and spawned[4] == 10 * 5 and spawned[6] == 10 * 6                  # OnDie channels: 4, 5, 6 events per dying parent
+    with pytest.raises(Exception):                                                                 # channel 8 is beyond the limit
+        w = bh.ExprWriter()
+        pos, emit = bh.SetAttributeModifier(A.POSITION, w.lit((0.0, 0.0, 0.0)).expr()), bh.EmitSpawnEventModifier(bh.EventEmitCondition.Always, w.lit(bh.Value.u32(1)).expr(), 8)
+        bh.lower(bh.EffectAsset(4, bh.SpawnerSettings.once(1.0), w.finish()).init(pos).update(emit))
+
+
+@pytest.mark.gpu
+def test_gpu_six_event_channels(ctx, kernels):
+    specs = six_channel_system()
+    g, o = GpuSystem(specs, ctx), OracleSystem(specs)
+    for f, fr in enumerate(six_channel_frames(10)):
+        g.step(fr)
+        o.step(fr)
+        assert_same_system_state(o.state(), g.state(), f"six channels frame {f}")
+    g.destroy()
