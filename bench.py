@@ -1078,6 +1078,9 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import scene_bench
             out["small_effects_scene"] = scene_bench.run(1, 300, device=D.device_index, quiet=True)
+            # ... and with the merged launches on the byte-code interpreters (HNB_OPT_SET_MODULE off: what a set without a compiled module gets)
+            interp = scene_bench.run(1, 300, device=D.device_index, quiet=True, set_module=0)
+            out["small_effects_scene"]["ms_per_frame_wall_interpreters"] = interp["ms_per_frame_wall"]
         except Exception as e:
             out["small_effects_scene"] = {"error": f"{type(e).__name__}: {e}"}
     if D.rank == 0 and not args.no_cpu_baseline and not D.on and args.config == "c2":
@@ -1182,7 +1185,8 @@ def short_line(full, args):
         short["burst_init"] = {"kernel_ms": _r(full["init"].get("kernel_ms")), "frac": _r(full["init"].get("frac"), 3)}
     sc = full.get("small_effects_scene")
     if sc:
-        short["small_effects_scene"] = sc if "error" in sc else {"effects": sc.get("effects"), "ms_per_frame_wall": _r(sc.get("ms_per_frame_wall")), "ms_per_frame_in_simulate": _r(sc.get("ms_per_frame_in_simulate"))}
+        short["small_effects_scene"] = sc if "error" in sc else {"effects": sc.get("effects"), "ms_per_frame_wall": _r(sc.get("ms_per_frame_wall")), "ms_per_frame_in_simulate": _r(sc.get("ms_per_frame_in_simulate")),
+                                                                                "ms_per_frame_wall_interpreters": _r(sc.get("ms_per_frame_wall_interpreters")), "in_set_module": sc.get("programs_served_by_the_set_module")}
     if full.get("strong"):
         short["strong"] = {k: _r(v) for k, v in full["strong"].items() if k != "workload"}
     short["build"] = full.get("build")

@@ -18,4 +18,4 @@ except ImportError:  # a fresh checkout: the host library (g++, no GPU toolchain
         raise ImportError("bevy_hanabi_amd._hanabi_host could not be built: run `python -m bevy_hanabi_amd.build`") from _e
 from . import _hanabi_host as host  # noqa: F401,E402
 
-from .runtime import Comm, Context, Effect, EffectMetadata, HanabiError, Program, SimParams, jit_precompile, validate_program  # noqa: F401,E402
+from .runtime import Comm, Context, Effect, EffectMetadata, HanabiError, Program, SimParams, jit_precompile, jit_precompile_set, validate_program  # noqa: F401,E402

@@ -149,6 +149,18 @@ struct HnbContext {
     std::vector<TimingPair> t_update, t_init, t_compact;
     std::vector<hipEvent_t> event_pool;  // timing events are recycled, never created on the frame path once the pool is warm
     uint32_t comm_refs = 0;     // HnbComm objects that hold this context: it cannot be destroyed before them
+    // The set module of the context's small programs (hnb_jit.h, hnb_kernels.hip.h "SET MODULES"): HNB_OPT_SET_MODULE
+    uint32_t set_mode = HNB_SET_MODULE_CACHED;
+    struct SetModule {
+        hipModule_t module = nullptr;
+        hipFunction_t init = nullptr, update = nullptr;
+        jit::SetPlan plan;
+        uint32_t gen = 0;           // bumped with every module loaded: HnbProgram::set_gen / set_case are valid for one generation
+    } set;
+    uint64_t set_tried = 0;         // the population (hash over the candidates' signatures) the last lookup / build was made for
+    uint64_t set_seen = 0;          // ... and the one the previous merged frame had: a population is looked up once it has stood for two frames
+    uint32_t set_frames = 0;        // statistics: frames with a launch served by the set kernels
+    std::string set_log;            // why the last build failed
 };
 
 struct HnbProgram {
@@ -168,6 +180,11 @@ struct HnbProgram {
     hipModule_t jit_module = nullptr;
     hipFunction_t jit_init = nullptr, jit_update = nullptr;
     std::string kernel_info, jit_log;
+    // what a set module generates this program's cases from (narrow register file only; empty: never a member), and its case in the loaded module
+    std::vector<Ins> h_init, h_update;
+    std::string set_sig;
+    uint64_t set_sig_hash = 0;
+    uint32_t set_gen = 0, set_case = kNoSetCase, set_frames = 0;
     std::vector<Ins> uniform_code;  // evaluated on the host per instance per frame
     std::vector<HnbEffect*> effects;
     // device tables, sized for `table_cap` instances
@@ -737,6 +754,22 @@ jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const
     return rq;
 }
 
+// A program as a member of a set module: the cases of every pass, whether or not it has instructions (an init pass without code still
+// zeroes the attributes and marks the slots; the family of the update - streaming plain / cohort, V register file - is the one
+// plan_merged_launches sorts it into)
+jit::Request make_set_request(const Ins* init, uint32_t init_len, const Ins* update, uint32_t update_len, const HnbAttrEntry* attrs, uint32_t n_attrs,
+                              bool streams, bool cohort) {
+    jit::Request rq;
+    rq.attrs = attrs; rq.n_attrs = n_attrs;
+    rq.init = init; rq.init_len = init_len; rq.update = update; rq.update_len = update_len;
+    rq.want_init = true;
+    rq.want_update_stream = streams;
+    rq.want_update_generic = !streams;
+    rq.stream_cohort = streams && cohort;
+    rq.wide_file = false;
+    return rq;
+}
+
 }  // namespace
 
 extern "C" {
@@ -775,6 +808,7 @@ int hnb_ctx_destroy(HnbContext* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     while (!ctx->programs.empty()) hnb_program_destroy(ctx->programs.back());
+    if (ctx->set.module) hipModuleUnload(ctx->set.module);
     recycle_timing_events(ctx);
     for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -817,6 +851,11 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
         case HNB_OPT_SCENE_MERGE: ctx->scene_merge = value != 0u; return HNB_OK;
         case HNB_OPT_SUFFIX_PROOF: ctx->suffix_proof = value != 0u; return HNB_OK;
         case HNB_OPT_STREAM_HINTS: ctx->stream_hints = value != 0u; return HNB_OK;
+        case HNB_OPT_SET_MODULE:
+            if (value > HNB_SET_MODULE_COMPILE) return fail(HNB_ERR_INVALID_ARG, "unknown set-module mode %u", value);
+            ctx->set_mode = value;
+            ctx->set_tried = ctx->set_seen = 0;   // (look again: the mode decides whether a missing module is compiled)
+            return HNB_OK;
         case HNB_OPT_OVERLAP_UPDATES: ctx->overlap_updates = value != 0u && ctx->side_stream && ctx->ev_fork && ctx->ev_join; return HNB_OK;   // (all three exist unless their creation failed)
         default: return fail(HNB_ERR_INVALID_ARG, "unknown option %u", option);
     }
@@ -870,6 +909,12 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
         d.age_cohort = age_cohort_eligible(b, h, p->attrs.data(), p->update_streams, ctx->popt) ? 1u : 0u;
     }
     if (p->update_streams) select_stream_kernel(reinterpret_cast<const Ins*>(b + h.update_off), h.update_len, &p->stream_launch, &p->stream_kernel_name);
+    if (!p->wide_file && jit::enabled()) {
+        p->h_init.assign(reinterpret_cast<const Ins*>(b + h.init_off), reinterpret_cast<const Ins*>(b + h.init_off) + h.init_len);
+        p->h_update.assign(reinterpret_cast<const Ins*>(b + h.update_off), reinterpret_cast<const Ins*>(b + h.update_off) + h.update_len);
+        p->set_sig = jit::set_signature(make_set_request(p->h_init.data(), h.init_len, p->h_update.data(), h.update_len, p->attrs.data(), h.n_attrs, p->update_streams, d.age_cohort != 0u));
+        p->set_sig_hash = jit::fnv1a(p->set_sig);
+    }
     const bool aot_static = p->update_streams && strcmp(p->stream_kernel_name, "ProgInterp") != 0;
     p->kernel_info = std::string(p->wide_file ? "wide-file " : "") + "init=" + (h.init_len ? "interp" : "none") + " update=" +
                      (p->update_streams ? (aot_static ? std::string("aot-stream:") + p->stream_kernel_name : std::string("interp-stream")) : std::string("interp-generic"));
@@ -1368,6 +1413,7 @@ struct FrameJobs {           // the launches several programs share this frame (
     const ListsJob* d_lists = nullptr;
     uint32_t n_lists = 0, lists_wgs = 0;
     Family init[2], generic[2], stream[2];   // [wide register file] / [age cohorts]
+    bool init_set = false, update_set = false;   // every job of init[0] / of the shared update launch has its case in the context's set module: hnb_set_init / hnb_set_update serve it
     const HnbProgram* heavy = nullptr;       // enqueue_update_passes: the one program whose update phase stays on the context's stream while
                                              // every other program's runs next to it on the side stream (null: one stream)
 };
@@ -1537,6 +1583,63 @@ static void fill_lists_jobs(HnbContext* ctx, const std::vector<HnbProgram*>& ord
 
 }
 
+// The set module of the context's small programs (hnb_kernels.hip.h "SET MODULES"). The POPULATION is every program that can take part in merged
+// launches at all (independent, small, narrow register file); a module is looked up - in the cache, or compiled: HNB_OPT_SET_MODULE - when a merged
+// frame finds a candidate without a case and the population has stood for two frames (an application that creates an effect per frame must not
+// generate a module source per frame). A module is replaced, never extended; programs it does not know leave their launches to the interpreters.
+static uint32_t set_case_of(HnbContext* ctx, HnbProgram* p) {
+    if (p->set_gen != ctx->set.gen) { p->set_gen = ctx->set.gen; p->set_case = ctx->set.module ? ctx->set.plan.case_of(p->set_sig) : kNoSetCase; }
+    return p->set_case;
+}
+static void refresh_set_module(HnbContext* ctx, const std::vector<HnbProgram*>& order, const std::vector<plan::MergeFacts>& facts) {
+    if (ctx->set_mode == HNB_SET_MODULE_OFF) return;
+    std::vector<HnbProgram*> cand;
+    bool covered = ctx->set.module != nullptr;
+    for (size_t i = 0; i < order.size(); ++i) {
+        HnbProgram* p = order[i];
+        if (p->set_sig.empty() || !facts[i].independent || facts[i].total_chunks > kSceneMaxChunks) continue;
+        cand.push_back(p);
+        if (covered && set_case_of(ctx, p) == kNoSetCase) covered = false;
+    }
+    if (covered || cand.size() < 2u) return;
+    std::vector<uint64_t> hs;
+    for (const HnbProgram* p : cand) hs.push_back(p->set_sig_hash);
+    std::sort(hs.begin(), hs.end());
+    hs.erase(std::unique(hs.begin(), hs.end()), hs.end());
+    const uint64_t pop = jit::hash_bytes(reinterpret_cast<const char*>(hs.data()), hs.size() * sizeof(uint64_t)) | 1ull;
+    if (pop == ctx->set_tried) return;
+    if (pop != ctx->set_seen) { ctx->set_seen = pop; return; }
+    ctx->set_tried = pop;
+    std::vector<jit::Request> members;
+    for (const HnbProgram* p : cand)
+        members.push_back(make_set_request(p->h_init.data(), (uint32_t)p->h_init.size(), p->h_update.data(), (uint32_t)p->h_update.size(), p->attrs.data(),
+                                           (uint32_t)p->attrs.size(), p->update_streams, p->dev.age_cohort != 0u));
+    jit::SetResult res;
+    if (!jit::build_set(members, res, ctx->set_mode == HNB_SET_MODULE_CACHED)) {
+        ctx->set_log = res.log.empty() ? std::string("no cache entry for this set of ") + std::to_string(res.plan.signatures.size()) + " programs (hnb_jit_precompile_set, or HNB_SET_MODULE_COMPILE)" : res.log;
+        return;
+    }
+    hipModule_t mod = nullptr;
+    hipFunction_t fi = nullptr, fu = nullptr;
+    hipError_t e = hipModuleLoadData(&mod, res.code.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&fi, mod, "hnb_set_init");
+    if (e == hipSuccess) e = hipModuleGetFunction(&fu, mod, "hnb_set_update");
+    if (e != hipSuccess) {
+        ctx->set_log = std::string("loading the set module failed: ") + hipGetErrorString(e);
+        if (mod) hipModuleUnload(mod);
+        (void)hipGetLastError();
+        return;
+    }
+    if (ctx->set.module) {   // (kernels of the module being replaced may still be running)
+        hipStreamSynchronize(ctx->stream);
+        hipModuleUnload(ctx->set.module);
+    }
+    ctx->set.module = mod; ctx->set.init = fi; ctx->set.update = fu;
+    ctx->set.plan = std::move(res.plan);
+    ctx->set.gen += 1;
+    ctx->set_log = std::to_string(ctx->set.plan.signatures.size()) + " programs" + (res.from_cache ? " (jit cache hit)" : " (compiled)");
+}
+
 // (3b) Small programs share their init and update launches
 static void fill_merge_jobs(HnbContext* ctx, const std::vector<HnbProgram*>& order, uint32_t slot, size_t& stage_off, bool timed, FrameJobs& fj) {
     std::vector<plan::MergeFacts> facts(order.size());
@@ -1552,7 +1655,10 @@ static void fill_merge_jobs(HnbContext* ctx, const std::vector<HnbProgram*>& ord
     plan::MergeLimits lim;
     lim.max_chunks = kSceneMaxChunks; lim.max_init_blocks = kSceneMaxInitBlocks; lim.max_code_len = kSceneMaxCodeLen;
     plan::plan_merged_launches(facts.data(), decisions.data(), (uint32_t)order.size(), ctx->scene_merge, timed, lim);
-    for (size_t i = 0; i < order.size(); ++i) order[i]->plan.merge = decisions[i];
+    bool any_merged = false;
+    for (size_t i = 0; i < order.size(); ++i) { order[i]->plan.merge = decisions[i]; any_merged = any_merged || decisions[i].init_family >= 0 || decisions[i].update_family >= 0; }
+    if (any_merged) refresh_set_module(ctx, order, facts);
+    bool init_cased = ctx->set.module != nullptr, update_cased = ctx->set.module != nullptr;
     // k_update_jobs serves streaming (no cohorts), streaming (cohorts), V register file (narrow) in this order: first_wg runs over its whole grid
     const int seq[6][2] = {{0, 0}, {0, 1}, {2, plan::kStream}, {2, plan::kStreamCohort}, {1, plan::kGeneric}, {1, plan::kGenericWide}};   // {kind: 0 init / 1 generic / 2 stream, family}
     uint32_t update_base = 0;
@@ -1578,6 +1684,8 @@ static void fill_merge_jobs(HnbContext* ctx, const std::vector<HnbProgram*>& ord
                 jb.inst_base = reinterpret_cast<const uint64_t*>(p->d_inst_base); jb.fi = dfi; jb.ublocks = dub;
                 jb.cb = compact_bufs_of(ctx, p, n);
                 jb.first_wg = base + f.wgs; jb.n_wg = wgs;
+                jb.set_case = set_case_of(ctx, p);
+                update_cased = update_cased && jb.set_case != kNoSetCase;
                 reinterpret_cast<StreamJob*>(hj)[f.n] = jb;
             } else {
                 ProgJob jb{};
@@ -1586,6 +1694,9 @@ static void fill_merge_jobs(HnbContext* ctx, const std::vector<HnbProgram*>& ord
                 jb.cb = compact_bufs_of(ctx, p, n);
                 jb.write_died = write_died;
                 jb.first_wg = base + f.wgs; jb.n_wg = wgs;
+                jb.set_case = set_case_of(ctx, p);
+                if (kind == 0 && fam == 0) init_cased = init_cased && jb.set_case != kNoSetCase;
+                if (kind == 1 && fam == plan::kGeneric) update_cased = update_cased && jb.set_case != kNoSetCase;
                 reinterpret_cast<ProgJob*>(hj)[f.n] = jb;
             }
             f.n += 1; f.wgs += wgs;
@@ -1593,6 +1704,13 @@ static void fill_merge_jobs(HnbContext* ctx, const std::vector<HnbProgram*>& ord
         }
         stage_off += ((size_t)f.n * (kind == 2 ? sizeof(StreamJob) : sizeof(ProgJob)) + 255u) & ~(size_t)255u;
         if (in_shared) update_base += f.wgs;
+    }
+    fj.init_set = init_cased && fj.init[0].n != 0u;
+    fj.update_set = update_cased && (fj.stream[0].wgs + fj.stream[1].wgs + fj.generic[0].wgs) != 0u;
+    if (fj.init_set || fj.update_set) {
+        ctx->set_frames += 1;
+        for (HnbProgram* p : order)
+            if ((fj.init_set && p->plan.merge.init_family == 0) || (fj.update_set && p->plan.merge.update_family >= 0 && p->plan.merge.update_family != plan::kGenericWide)) p->set_frames += 1;
     }
 
 }
@@ -1658,7 +1776,12 @@ static int enqueue_init_passes(HnbContext* ctx, const std::vector<HnbProgram*>& 
     }
 
     // (the merged programs have no parent and no child: their init passes are independent of the ones above)
-    if (fj.init[0].n) k_init_jobs<InterpCode><<<fj.init[0].wgs, kInitBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fj.init[0].d_jobs), fj.init[0].n);
+    if (fj.init_set) {
+        const void* jobs = fj.init[0].d_jobs;
+        uint32_t n_jobs = fj.init[0].n;
+        void* ka[] = {&jobs, &n_jobs};
+        HIP_TRY(hipModuleLaunchKernel(ctx->set.init, fj.init[0].wgs, 1, 1, kInitBlock, 1, 1, 0, ctx->stream, ka, nullptr));
+    } else if (fj.init[0].n) k_init_jobs<InterpCode><<<fj.init[0].wgs, kInitBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fj.init[0].d_jobs), fj.init[0].n);
     if (fj.init[1].n) k_init_jobs<InterpCodeWide><<<fj.init[1].wgs, kInitBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fj.init[1].d_jobs), fj.init[1].n);
     return HNB_OK;
 }
@@ -1735,7 +1858,12 @@ static int enqueue_update_passes(HnbContext* ctx, const std::vector<HnbProgram*>
         HIP_TRY(hipStreamWaitEvent(light, ctx->ev_fork, 0));
     }
     // (the merged updates first: every init pass is enqueued, and a merged program's own list kernels may follow in the loop below)
-    if (fj.stream[0].wgs + fj.stream[1].wgs + fj.generic[0].wgs)
+    if (fj.update_set) {
+        const void *sj0 = fj.stream[0].d_jobs, *sj1 = fj.stream[1].d_jobs, *pj = fj.generic[0].d_jobs;
+        uint32_t n0 = fj.stream[0].n, n1 = fj.stream[1].n, np = fj.generic[0].n, b0 = fj.stream[0].wgs, b1 = fj.stream[0].wgs + fj.stream[1].wgs;
+        void* ka[] = {&sj0, &n0, &sj1, &n1, &pj, &np, &b0, &b1};
+        HIP_TRY(hipModuleLaunchKernel(ctx->set.update, fj.stream[0].wgs + fj.stream[1].wgs + fj.generic[0].wgs, 1, 1, kBlock, 1, 1, 0, light, ka, nullptr));
+    } else if (fj.stream[0].wgs + fj.stream[1].wgs + fj.generic[0].wgs)
         k_update_jobs<<<fj.stream[0].wgs + fj.stream[1].wgs + fj.generic[0].wgs, kBlock, 0, light>>>(
             static_cast<const StreamJob*>(fj.stream[0].d_jobs), fj.stream[0].n, static_cast<const StreamJob*>(fj.stream[1].d_jobs), fj.stream[1].n,
             static_cast<const ProgJob*>(fj.generic[0].d_jobs), fj.generic[0].n, fj.stream[0].wgs, fj.stream[0].wgs + fj.stream[1].wgs);
@@ -1986,6 +2114,8 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
     if (prog->has_ribbons && prog->suffix_frames) s += "\ncasualties proven to be the list's last rows (no k_count_rows): " + std::to_string(prog->suffix_frames) + " frames";
     if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->ribbon_facts.front_static ? "" : " (not eligible)");
     if (prog->merged_frames) s += "\nupdate served by a merged launch (small programs of the context share one): " + std::to_string(prog->merged_frames) + " frames";
+    if (prog->set_frames) s += "\n... by the context's set module (the program's specialised code behind the shared launch): " + std::to_string(prog->set_frames) + " frames";
+    if (!prog->ctx->set_log.empty()) s += "\nset module: " + prog->ctx->set_log;
     if (prog->horizon_eligible) s += "\ndeath horizons in use: " + std::to_string(prog->hz_frames) + " frames";
     s += "\nlists skipped: " + std::to_string(prog->skipped_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->skip_facts.eligible ? "" : " (not eligible)");
     snprintf(buf, buf_size, "%s", s.c_str());
@@ -2011,6 +2141,40 @@ int hnb_jit_precompile(const void* blob, size_t blob_size) {
     if (!rq.want_init && !rq.want_update_generic && !rq.want_update_stream) return HNB_OK;
     jit::Result res;
     if (!jit::build(rq, res)) return fail(HNB_ERR_BAD_PROGRAM, "kernel specialisation failed: %s", res.log.c_str());
+    return HNB_OK;
+}
+
+int hnb_jit_precompile_set(const void* const* blobs, const size_t* blob_sizes, uint32_t n_blobs) {
+    if (!blobs || !blob_sizes || n_blobs == 0u) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    struct Member { std::vector<HnbAttrEntry> attrs; std::vector<Ins> init, update; bool streams = false, cohort = false; };
+    std::vector<Member> mem;
+    mem.reserve(n_blobs);
+    for (uint32_t i = 0; i < n_blobs; ++i) {
+        HnbProgramHeader h;
+        const int rc = validate_blob(blobs[i], blob_sizes[i], &h);
+        if (rc != HNB_OK) return rc;
+        // what can never take part in a merged launch is skipped, as hnb_simulate skips it: the wide register file, more slots than a "small"
+        // program may have with a single instance, spawn events in or out
+        if (std::max(h.init_regs, h.update_regs) > HNB_VM_MAX_REGS) continue;
+        if ((uint64_t)h.capacity > (uint64_t)kSceneMaxChunks * kChunk || h.n_event_channels != 0u || (h.flags & HNB_PROG_READS_PARENT)) continue;
+        const uint8_t* b = static_cast<const uint8_t*>(blobs[i]);
+        Member m;
+        m.attrs.resize(h.n_attrs);
+        memcpy(m.attrs.data(), b + h.attrs_off, h.n_attrs * sizeof(HnbAttrEntry));
+        m.init.assign(reinterpret_cast<const Ins*>(b + h.init_off), reinterpret_cast<const Ins*>(b + h.init_off) + h.init_len);
+        m.update.assign(reinterpret_cast<const Ins*>(b + h.update_off), reinterpret_cast<const Ins*>(b + h.update_off) + h.update_len);
+        m.streams = update_is_streamable(b, h, m.attrs.data());
+        uint32_t dt_operand = 0;
+        const ProgramOptions opt;   // (the default options: what a context starts with)
+        m.cohort = cull_eligible(b, h, m.attrs.data(), m.streams, opt, &dt_operand) && age_cohort_eligible(b, h, m.attrs.data(), m.streams, opt);
+        mem.push_back(std::move(m));
+    }
+    std::vector<jit::Request> members;
+    for (const Member& m : mem)
+        members.push_back(make_set_request(m.init.data(), (uint32_t)m.init.size(), m.update.data(), (uint32_t)m.update.size(), m.attrs.data(), (uint32_t)m.attrs.size(), m.streams, m.cohort));
+    if (members.size() < 2u) return HNB_OK;   // (a set module serves launches that at least two programs share)
+    jit::SetResult res;
+    if (!jit::build_set(members, res, false)) return fail(HNB_ERR_BAD_PROGRAM, "set module: kernel specialisation failed: %s", res.log.c_str());
     return HNB_OK;
 }
 

@@ -1046,18 +1046,36 @@ __device__ __forceinline__ void store_died_bits(uint32_t* __restrict__ bits, uin
     if ((lane & 7u) == 0u) bits[(step_first >> 5) + (lane >> 3)] = (uint32_t)v;
 }
 
+// The workgroup's LDS of update_stream_chunk, ONE object however many instantiations of the template a kernel holds (a function-local
+// __shared__ array of a template is one allocation per instantiation: k_update_jobs with its two paid 48 KiB, a set module -
+// hnb_jit.h, one instantiation per program of the scene - would not fit at all).
+struct StreamLds {
+    uint32_t died[kBlock / 64];
+    float lmin[kBlock / 64];
+    uint32_t alive[kBlock / 64];
+    float rem[kBlock / 64];
+    uint32_t amin[kBlock / 64], amax[kBlock / 64];
+    u4v xp[2][kBlock / 64][kStepRows * 3u / 4u];   // position / velocity staging of each wave's step (xpose_load3): 24 KiB per workgroup
+};
+__device__ __forceinline__ StreamLds& stream_lds() {
+    __shared__ StreamLds s;
+    return s;
+}
+
 // PROBE (tools/stream_probe.hip only; 0 in the product): 4 = skip stores, 8 = skip the program.
 // COHORT: compile the age-cohort paths in (programs that are eligible: SlotArgs::age_cohort); false leaves the kernel as it was.
 template <class PROG, int PROBE, bool COHORT>
 __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
                                                     const uint32_t* __restrict__ ublocks, const CompactBufs& cb,
                                                     const uint32_t wg, const uint32_t wg_total) {   // workgroup wg of the program's wg_total (k_update_slots_stream, k_update_stream_jobs)
-    __shared__ uint32_t s_died[kBlock / 64];
-    __shared__ float s_lmin[kBlock / 64];
-    __shared__ uint32_t s_alive[kBlock / 64];
-    __shared__ float s_rem[kBlock / 64];
-    __shared__ uint32_t s_amin[kBlock / 64], s_amax[kBlock / 64];
-    __shared__ u4v s_xp[2][kBlock / 64][kStepRows * 3u / 4u];   // position / velocity staging of each wave's step (xpose_load3): 24 KiB per workgroup
+    StreamLds& lds = stream_lds();
+    uint32_t (&s_died)[kBlock / 64] = lds.died;
+    float (&s_lmin)[kBlock / 64] = lds.lmin;
+    uint32_t (&s_alive)[kBlock / 64] = lds.alive;
+    float (&s_rem)[kBlock / 64] = lds.rem;
+    uint32_t (&s_amin)[kBlock / 64] = lds.amin;
+    uint32_t (&s_amax)[kBlock / 64] = lds.amax;
+    u4v (&s_xp)[2][kBlock / 64][kStepRows * 3u / 4u] = lds.xp;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     const uint32_t k = chunk / args.chunks_per_inst, j = chunk - k * args.chunks_per_inst;
@@ -1170,7 +1188,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
     }
     // ---- the per-particle path, one wave step (256 slots, 4 per lane). COH: with the age-cohort bookkeeping (a chunk that is known to hold
     // mixed ages - state 4 - runs without it: see `mixed` above)
-    auto step_body = [&](auto coh_tag, const uint32_t step, const uint32_t f4) {
+    auto step_body = [&](auto coh_tag, const uint32_t step, const uint32_t f4, const u4v* pre_age = nullptr) {
         constexpr bool COH = decltype(coh_tag)::value;
         const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;  // first of this lane's 4 slots
         bool was[4], fresh[4];  // fresh: spawned this frame into a chunk that kept its ages in the value word (alive byte 3, state 2 only)
@@ -1210,7 +1228,11 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
                 if (fl & 2u) pin_load3<4>(X.vel, p_vel, slot, lanes_on, true);
             }
             if (fl & 4u) {
-                if (!COH || ast != 1u) { pin_load1<4>(X.age, p_age, slot, lanes_on, true); for (int p = 0; p < 4; ++p) age_was[p] = X.age[p]; }
+                if (!COH || ast != 1u) {
+                    if (pre_age) { X.age[0] = u2f(pre_age->x); X.age[1] = u2f(pre_age->y); X.age[2] = u2f(pre_age->z); X.age[3] = u2f(pre_age->w); }   // (requested with the alive bytes: age-only programs)
+                    else pin_load1<4>(X.age, p_age, slot, lanes_on, true);
+                    for (int p = 0; p < 4; ++p) age_was[p] = X.age[p];
+                }
                 if (COH && ast != 0u) {   // (selects, no divergence: ast is uniform, fresh[] only ever set in state 2)
 #pragma unroll
                     for (int p = 0; p < 4; ++p) X.age[p] = fresh[p] ? X.age[p] : A;
@@ -1321,6 +1343,22 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
             uint32_t f4s[kWaveRows / kStepRows];
 #pragma unroll
             for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) f4s[step] = f4_of(step);
+            // Age-only programs (PROG::kAgeOnly: ribbon.rs - a trail that does not move): the step is two dependent round trips for 8 bytes per
+            // particle - alive bytes, then the ages - four times in a row, and a 4M-particle effect is one round of workgroups: the kernel is
+            // those latencies. The ages of all four steps are requested together with the alive bytes (16 registers, only in these instantiations).
+            if constexpr (PROG::kAgeOnly && !COHORT) {
+                if ((fl & 4u) && !(fl & 3u)) {
+                    u4v ages[kWaveRows / kStepRows];
+#pragma unroll
+                    for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
+                        const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;
+                        ages[step] = s0 < args.capacity ? reinterpret_cast<const u4v*>(p_age)[s0 >> 2] : u4v{0u, 0u, 0u, 0u};   // (planes are padded to 256 B: a quad never straddles the end)
+                    }
+#pragma unroll
+                    for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4s[step], &ages[step]);
+                    goto steps_done;
+                }
+            }
             if (mixed) {
 #pragma unroll
                 for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4s[step]);
@@ -1333,6 +1371,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
             for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4_of(step));
         }
     }
+steps_done:
     if (cull) {
 #pragma unroll
         for (uint32_t off = 32; off > 0; off >>= 1) wave_min = fminf(wave_min, __shfl_xor(wave_min, off, 64));
@@ -1596,19 +1635,28 @@ k_compact_multi(const ListsJob* __restrict__ jobs, uint32_t n_jobs) {
 // tables (they travel with the frame's parameter upload, like ListsJob) and serves ALL of them with one k_init_jobs launch and one
 // k_update_jobs launch - the INTERPRETER instantiations, the only code that fits every program: 3-9x the instructions per particle of
 // the specialised kernels, and irrelevant at these sizes. Same code paths as HNB_JIT=0, same results bit for bit (tests/test_scene_merge.py).
+//
+// SET MODULES (round 4; hnb_jit.h make_set_source): the interpreters' latency is the floor of such a scene - k_init_jobs 35 us, k_update_jobs
+// 28 us for microseconds of work, every op a cold instruction-cache miss behind the previous one. For the SET of small programs a context
+// holds, hiprtc compiles one module with two kernels of the same signatures - hnb_set_init / hnb_set_update - whose bodies are a switch over
+// the job's `set_case` into the SPECIALISED instantiation of each program (the code its own launch would run). Same job tables, same
+// launches; a launch is served by the set kernels when every job of it has a case in the loaded module, by the interpreters otherwise.
+#endif  // HNB_JIT_TU (the job tables are shared with the set modules)
+constexpr uint32_t kNoSetCase = 0xffffffffu;
 struct ProgJob {             // k_init_jobs (first_wg / n_wg count init workgroups), k_update_jobs / k_update_generic_wide_jobs (... groups of 256 slots)
     DevProgram prog;
     const uint64_t* inst_base; const DevMeta* meta_in; const DevFrameInst* fi; const uint32_t* ublocks;
     CompactBufs cb;
     uint32_t write_died;
     uint32_t first_wg, n_wg;
-    uint32_t pad;
+    uint32_t set_case;       // the program's case in the context's set module (kNoSetCase: none)
 };
 struct StreamJob {           // k_update_jobs (first_wg / n_wg count chunks)
     SlotArgs args;
     const uint64_t* inst_base; const DevFrameInst* fi; const uint32_t* ublocks;
     CompactBufs cb;
     uint32_t first_wg, n_wg;
+    uint32_t set_case, pad;
 };
 template <class JOB>
 __device__ __forceinline__ const JOB& job_of_workgroup_t(const JOB* __restrict__ jobs, uint32_t n_jobs) {
@@ -1616,6 +1664,8 @@ __device__ __forceinline__ const JOB& job_of_workgroup_t(const JOB* __restrict__
     while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (jobs[mid].first_wg <= blockIdx.x) lo = mid; else hi = mid; }
     return jobs[lo];
 }
+constexpr uint32_t kGenericSubs = kChunk / kBlock;   // k_update_jobs: one workgroup per 256 slots of a program on the V register file
+#ifndef HNB_JIT_TU
 template <class CODE>
 __global__ void __launch_bounds__(kInitBlock)
 k_init_jobs(const ProgJob* __restrict__ jobs, uint32_t n_jobs) {
@@ -1625,7 +1675,6 @@ k_init_jobs(const ProgJob* __restrict__ jobs, uint32_t n_jobs) {
 // One launch for every small program's update: workgroups [0, b0) serve the streaming jobs without age cohorts, [b0, b1) those with, the rest
 // the programs on the V register file - there one workgroup per 256 slots (the latency of one 4096-slot chunk walked by a single workgroup
 // WAS the frame: 0.13 ms for the 26-effect scene, profiles/r03u_scene_kernel_stats.csv). first_wg counts over the whole grid.
-constexpr uint32_t kGenericSubs = kChunk / kBlock;
 __global__ void __launch_bounds__(kBlock)
 k_update_jobs(const StreamJob* __restrict__ sj0, uint32_t n0, const StreamJob* __restrict__ sj1, uint32_t n1, const ProgJob* __restrict__ pj, uint32_t np,
               uint32_t b0, uint32_t b1) {

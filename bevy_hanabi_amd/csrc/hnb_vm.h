@@ -921,6 +921,7 @@ HNB_HD void apply_static_flat(const Ins ins, float (&pos)[3][4], float (&vel)[3]
 // Interpreted program (any streamable sequence).
 struct ProgInterp {
     static constexpr bool kFlat = false;
+    static constexpr bool kAgeOnly = false;
     HNB_HD_MEMBER static void run_flat(const Ins* __restrict__, float (&)[3][4], float (&)[3][4], uint32_t, const VmUniforms&) {}
     static constexpr uint32_t kLen = 0;
     template <int P> HNB_HD_MEMBER static void run(const Ins* __restrict__ code, uint32_t n_ins, Pinned<P>& X, const VmUniforms& U) {
@@ -930,6 +931,7 @@ struct ProgInterp {
 // Empty update stream (no AGE, no velocity, no update modifier): only the lists are maintained.
 struct ProgNone {
     static constexpr bool kFlat = false;
+    static constexpr bool kAgeOnly = false;
     HNB_HD_MEMBER static void run_flat(const Ins* __restrict__, float (&)[3][4], float (&)[3][4], uint32_t, const VmUniforms&) {}
     static constexpr uint32_t kLen = 0;
     template <int P> HNB_HD_MEMBER static void run(const Ins* __restrict__, uint32_t, Pinned<P>&, const VmUniforms&) {}
@@ -942,6 +944,9 @@ struct ProgStatic {
     // every op component-wise (and an AGE_TICK among them: the flat path needs the chunk's ages in a cohort word)
     static constexpr bool kFlat = ((OPS == HNB_OP_M_AGE_TICK || OPS == HNB_OP_M_EULER || OPS == HNB_OP_M_VEL_SCALE || OPS == HNB_OP_M_VEL_ADD) && ...) &&
                                   ((OPS == HNB_OP_M_AGE_TICK) || ...);
+    // nothing but AGE_TICK (ribbon.rs: MotionIntegration::None): the update reads and writes ONE scalar plane - see the age prefetch of
+    // update_stream_chunk
+    static constexpr bool kAgeOnly = sizeof...(OPS) > 0 && ((OPS == HNB_OP_M_AGE_TICK) && ...);
     HNB_HD_MEMBER static void run_flat(const Ins* __restrict__ code, float (&pos)[3][4], float (&vel)[3][4], uint32_t rot, const VmUniforms& U) {
         if constexpr (kFlat) {
             uint32_t i = 0;

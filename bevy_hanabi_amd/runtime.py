@@ -27,12 +27,13 @@ ABI_SYMBOLS = [
     "hnb_ctx_kernel_timing", "hnb_program_kernel_info", "hnb_jit_precompile", "hnb_effect_set_simulated", "hnb_ctx_set_option", "hnb_program_set_frames", "hnb_effect_index",
     "hnb_ctx_profile_marker", "hnb_program_kernel_timing",
     "hnb_comm_create_local", "hnb_comm_unique_id", "hnb_comm_create_rank", "hnb_comm_allreduce_alive", "hnb_comm_destroy", "hnb_comm_set_library",
-    "hnb_effect_device_view", "hnb_effect_materialise",
+    "hnb_effect_device_view", "hnb_effect_materialise", "hnb_jit_precompile_set",
 ]
 
 # hnb_ctx_set_option (include/hanabi_amd.h): name -> option id
 OPTIONS = {"list_order": 1, "alternate": 2, "skip_lists": 3, "age_cohort": 4, "cull_lifetime": 5, "horizon": 6, "transpose": 7, "scene_merge": 8,
-           "suffix_proof": 9, "overlap_updates": 10, "stream_hints": 11}
+           "suffix_proof": 9, "overlap_updates": 10, "stream_hints": 11, "set_module": 12}
+SET_MODULE_OFF, SET_MODULE_CACHED, SET_MODULE_COMPILE = 0, 1, 2
 
 
 class HanabiError(RuntimeError):
@@ -131,6 +132,7 @@ def load_library():
         lib.hnb_effect_materialise.argtypes = [C.c_void_p, C.c_uint64]
         lib.hnb_program_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         lib.hnb_jit_precompile.argtypes = [C.c_char_p, C.c_size_t]
+        lib.hnb_jit_precompile_set.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_uint32]
         _lib = lib
     return _lib
 
@@ -148,6 +150,15 @@ def validate_program(blob: bytes):
 def jit_precompile(blob: bytes):
     """Compile and cache the kernels specialised for this program (hiprtc; needs no GPU)."""
     _check(load_library().hnb_jit_precompile(blob, len(blob)))
+
+
+def jit_precompile_set(blobs):
+    """Compile and cache the set module of these programs (HNB_OPT_SET_MODULE: the specialised code of the small programs of a context behind
+    their shared launches; needs no GPU). Order and duplicates do not matter."""
+    blobs = list(blobs)
+    arr = (C.c_char_p * len(blobs))(*blobs)
+    sizes = (C.c_size_t * len(blobs))(*[len(b) for b in blobs])
+    _check(load_library().hnb_jit_precompile_set(arr, sizes, len(blobs)))
 
 
 class Context:

@@ -306,6 +306,21 @@ int hnb_ctx_synchronize(HnbContext* ctx);
 /* HNB_OPT_STREAM_HINTS (default 1; from the next hnb_simulate on): programs whose frame touches more than the 256 MiB Infinity Cache holds
  *   read and write their lists, and read the update's read-only planes, with the nontemporal hint (a cache-policy choice: same results). */
 #define HNB_OPT_STREAM_HINTS 11u
+/* HNB_OPT_SET_MODULE (default HNB_SET_MODULE_CACHED; from the next hnb_simulate on): the launches the small programs of a context share
+ *   (HNB_OPT_SCENE_MERGE) run the byte-code INTERPRETERS - the only code that fits every program - unless the context has a SET MODULE: one
+ *   hiprtc module whose two kernels switch, per job, into the SPECIALISED code of each program (the counterpart of the reference compiling one
+ *   WGSL module per effect, src/lib.rs:805-1336, for effects that share a dispatch here). The set is every program of the context that can take
+ *   part in merged launches (independent of other effects, <= 65,536 slots over its instances, narrow register file); the module is keyed by the
+ *   set (not by creation order or multiplicity) and lives in the same on-disk cache as the per-program kernels.
+ *     OFF      the interpreters serve the merged launches (rounds 3's behaviour)
+ *     CACHED   a module is used when the cache holds it (hnb_jit_precompile_set, or an earlier run with COMPILE); nothing is compiled on the frame path
+ *     COMPILE  a missing module is compiled inside hnb_simulate (seconds to a minute, once per set: loading screens, tests, benchmarks)
+ *   Same results bit for bit in every mode; programs created after the module was built keep their launches on the interpreters until the set has
+ *   stood for two merged frames and a module for it is found (or compiled). */
+#define HNB_OPT_SET_MODULE 12u
+#define HNB_SET_MODULE_OFF 0u
+#define HNB_SET_MODULE_CACHED 1u
+#define HNB_SET_MODULE_COMPILE 2u
 int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value);
 
 /* Replaces EffectShaderSources::generate + pipeline specialisation (src/lib.rs:805-1336). */
@@ -429,6 +444,11 @@ int hnb_effect_sort_ribbons(HnbEffect* fx);
 int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size);
 /* Compile and cache the specialised kernels of a program blob. Needs no device (build boxes). */
 int hnb_jit_precompile(const void* blob, size_t blob_size);
+/* Compile and cache the SET MODULE (HNB_OPT_SET_MODULE) of the given program blobs: what a context that holds exactly these programs as its
+ * small effects looks up. Order and duplicates do not matter; blobs that can never join a merged launch are skipped as hnb_simulate skips them
+ * (wide register file, capacity > 65,536, spawn events in or out). The runtime set also leaves out programs whose INSTANCES rule them out (more
+ * than 65,536 slots over all instances, an instance with a parent): pass the blobs of the effects that stay small. Needs no device. */
+int hnb_jit_precompile_set(const void* const* blobs, const size_t* blob_sizes, uint32_t n_blobs);
 
 /* Timing helper: average device time in ms of the update kernel, of the compaction kernel that
  * follows it (event after update -> event after compact, i.e. including the launch gap) and of the

@@ -36,6 +36,20 @@ def main():
     for a in assets:
         bh.jit_precompile(bh.lower(a))
     print(f"warm_jit_cache: {len(assets)} programs in {time.time() - t0:.1f} s")
+    # Set modules (HNB_OPT_SET_MODULE): the scene of every single-entity example effect (bench.py's small_effects_scene, tests/test_scene_merge.py)
+    # and the small sets of tests/test_set_module.py
+    t0 = time.time()
+    sets = []
+    cat = reference_examples.catalog()
+    sets.append([e.asset for name in sorted(cat) if all(x.parent is None for x in cat[name]) for e in cat[name]])
+    try:
+        from test_set_module import warm_sets
+        sets += warm_sets()
+    except Exception as e:
+        print("warm_jit_cache: test sets skipped:", e)
+    for members in sets:
+        bh.jit_precompile_set([bh.lower(a) for a in members])
+    print(f"warm_jit_cache: {len(sets)} set modules in {time.time() - t0:.1f} s")
 
 
 if __name__ == "__main__":
