@@ -93,7 +93,7 @@ typedef ProgStatic<OP_(AGE_TICK), OP_(CONFORM_SPHERE), OP_(CONFORM_SPHERE), OP_(
 void select_stream_kernel(const Ins* code, uint32_t n, StreamLaunchFn* fn, const char** name) {
 #define TRY_(PROG, WAVES) if (PROG::matches(code, n)) { *fn = &launch_stream<PROG, WAVES>; *name = #PROG; return; }
     TRY_(ProgNone, HNB_STREAM_WAVES)
-    TRY_(ProgAge, HNB_STREAM_WAVES)
+    TRY_(ProgAge, 4)   // (the age prefetch of update_stream_chunk: 16 more registers, and one scalar plane never needs more than four waves per SIMD)
     TRY_(ProgAgeEuler, HNB_STREAM_WAVES)
     TRY_(ProgAccel, HNB_STREAM_WAVES)
     TRY_(ProgDrag, HNB_STREAM_WAVES)
@@ -2115,7 +2115,7 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
     if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->ribbon_facts.front_static ? "" : " (not eligible)");
     if (prog->merged_frames) s += "\nupdate served by a merged launch (small programs of the context share one): " + std::to_string(prog->merged_frames) + " frames";
     if (prog->set_frames) s += "\n... by the context's set module (the program's specialised code behind the shared launch): " + std::to_string(prog->set_frames) + " frames";
-    if (!prog->ctx->set_log.empty()) s += "\nset module: " + prog->ctx->set_log;
+    if (!prog->ctx->set_log.empty() && !prog->set_sig.empty()) s += "\nset module: " + prog->ctx->set_log;
     if (prog->horizon_eligible) s += "\ndeath horizons in use: " + std::to_string(prog->hz_frames) + " frames";
     s += "\nlists skipped: " + std::to_string(prog->skipped_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->skip_facts.eligible ? "" : " (not eligible)");
     snprintf(buf, buf_size, "%s", s.c_str());

@@ -654,6 +654,11 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
         excl = c.start <= first_dead ? c.start : (c.start < alive0 ? first_dead : c.start - total_dead);
         if (total_dead > alive0 && tid == 0u && args.fault) *args.fault = 1u;
     } else if (total_dead != 0u) {
+        // (Round 4, also tried: count and compact in ONE kernel - a workgroup keeps its rows and masks in registers, publishes its survivor count as
+        // a tagged 8-byte word and polls the words of its group of 64 chunks and one total per earlier group. Bit-equal on the whole GPU suite and
+        // SLOWER: c2_mixed 0.332 vs 0.316 ms, c2_events 0.410 vs 0.393, c2_dieoff 0.253 vs 0.248 (profiles/r04u_ab_fused_lists.log): under the
+        // kernel's own streaming load a hand-off between workgroups costs 3-5 us per hop (the poll queues behind the CU's own loads), two hops
+        // per workgroup, against 1.7 us for the kernel boundary it replaces and a second read of the rows that mostly hits the Infinity Cache.)
         // (Round 4: a two-level prefix - group sums accumulated by k_count_rows with one fire-and-forget atomic per chunk, 508 bytes of
         // counts per workgroup here - made THIS kernel 2 us faster and k_count_rows 16 us slower at 4096 chunks: 64 atomics to one word from
         // 8 XCDs serialise beyond the L2, profiles/r04b_kernel_durations.json. The counts are read 16 bytes per lane instead.)
