@@ -1413,6 +1413,7 @@ struct FrameJobs {           // the launches several programs share this frame (
     const ListsJob* d_lists = nullptr;
     uint32_t n_lists = 0, lists_wgs = 0;
     Family init[2], generic[2], stream[2];   // [wide register file] / [age cohorts]
+    bool forked = false;                     // enqueue_init_passes: the side stream already waits behind the heavy program's init
     bool init_set = false, update_set = false;   // every job of init[0] / of the shared update launch has its case in the context's set module: hnb_set_init / hnb_set_update serve it
     const HnbProgram* heavy = nullptr;       // enqueue_update_passes: the one program whose update phase stays on the context's stream while
                                              // every other program's runs next to it on the side stream (null: one stream)
@@ -1750,9 +1751,44 @@ static void enqueue_ribbon_sort(HnbContext* ctx, HnbProgram* p, hipStream_t st) 
     p->ribbon_hist.dirty = false;
 }
 
-// (5) init passes, parents first
-static int enqueue_init_passes(HnbContext* ctx, const std::vector<HnbProgram*>& order, const FrameJobs& fj, bool timed) {
-    for (HnbProgram* p : order) {
+// (5) init passes, parents first. With a heavy program (enqueue_update_passes) the frame forks HERE, behind the heavy program's own init: what
+// has to precede that - the programs its instances' parents belong to, transitively: the init reads the parent particle - and what must not run
+// beside its update - the programs that read ITS particles at init - stay on the context's stream in front of the fork; every other init pass
+// goes to the side stream, in the same order, followed there by the light programs' update phases (c2_events: the sparkle effect's init no
+// longer stands between the trails' init and update).
+static bool reads_particles_of(const HnbProgram* child, const HnbProgram* parent) {
+    for (const HnbEffect* fx : child->effects)
+        if (fx->parent && fx->parent->prog == parent) return true;
+    return false;
+}
+static int enqueue_init_passes(HnbContext* ctx, const std::vector<HnbProgram*>& order, FrameJobs& fj, bool timed) {
+    std::vector<char> on_side(order.size(), 0);
+    if (fj.heavy) {
+        std::vector<const HnbProgram*> family{fj.heavy};   // the heavy program and its ancestors
+        for (size_t i = 0; i < family.size(); ++i)
+            for (const HnbEffect* fx : family[i]->effects)
+                if (fx->parent && std::find(family.begin(), family.end(), fx->parent->prog) == family.end()) family.push_back(fx->parent->prog);
+        for (size_t i = 0; i < order.size(); ++i)
+            on_side[i] = std::find(family.begin(), family.end(), order[i]) == family.end() && !reads_particles_of(order[i], fj.heavy);
+        for (bool changed = true; changed;) {   // parents first, also across the fork: the parents of whatever stays in front of it stay as well
+            changed = false;
+            for (size_t i = 0; i < order.size(); ++i)
+                if (!on_side[i])
+                    for (size_t k = 0; k < order.size(); ++k)
+                        if (on_side[k] && reads_particles_of(order[i], order[k])) { on_side[k] = 0; changed = true; }
+        }
+    }
+    for (int pass = 0; pass < (fj.heavy ? 2 : 1); ++pass) {
+    hipStream_t st = ctx->stream;
+    if (pass == 1) {   // fork
+        st = ctx->side_stream;
+        HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_fork, 0));
+        fj.forked = true;
+    }
+    for (size_t pi = 0; pi < order.size(); ++pi) {
+        HnbProgram* p = order[pi];
+        if ((int)on_side[pi] != pass) continue;
         const uint32_t n = (uint32_t)p->effects.size();
         const uint32_t par = p->parity;
         const uint32_t blocks = p->plan.init_blocks;
@@ -1762,27 +1798,29 @@ static int enqueue_init_passes(HnbContext* ctx, const std::vector<HnbProgram*>& 
         if (blocks && p->plan.merge.init_family < 0) {   // (>= 0: served by k_init_jobs below)
             TimingPair ti{};
             ti.prog = p;
-            if (timed) { ti.a = take_event(ctx); ti.b = take_event(ctx); hipEventRecord(ti.a, ctx->stream); }
+            if (timed) { ti.a = take_event(ctx); ti.b = take_event(ctx); hipEventRecord(ti.a, st); }
             if (p->jit_init) {
                 const DevMeta* mi = p->d_meta[par];
                 void* ka[] = {&p->dev, &p->d_inst_base, &mi, &dfi, &dub};
-                HIP_TRY(hipModuleLaunchKernel(p->jit_init, blocks, 1, 1, kInitBlock, 1, 1, 0, ctx->stream, ka, nullptr));
+                HIP_TRY(hipModuleLaunchKernel(p->jit_init, blocks, 1, 1, kInitBlock, 1, 1, 0, st, ka, nullptr));
             } else {
-                if (p->wide_file) k_init<InterpCodeWide><<<blocks, kInitBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub);
-                else k_init<InterpCode><<<blocks, kInitBlock, 0, ctx->stream>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub);
+                if (p->wide_file) k_init<InterpCodeWide><<<blocks, kInitBlock, 0, st>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub);
+                else k_init<InterpCode><<<blocks, kInitBlock, 0, st>>>(p->dev, p->d_inst_base, p->d_meta[par], dfi, dub);
             }
-            if (timed) { hipEventRecord(ti.b, ctx->stream); ctx->t_init.push_back(ti); }
+            if (timed) { hipEventRecord(ti.b, st); ctx->t_init.push_back(ti); }
         }
     }
+    }
 
-    // (the merged programs have no parent and no child: their init passes are independent of the ones above)
+    // (the merged programs have no parent and no child: their init passes are independent of the ones above - behind the fork, if there is one)
+    hipStream_t ms = fj.forked ? ctx->side_stream : ctx->stream;
     if (fj.init_set) {
         const void* jobs = fj.init[0].d_jobs;
         uint32_t n_jobs = fj.init[0].n;
         void* ka[] = {&jobs, &n_jobs};
-        HIP_TRY(hipModuleLaunchKernel(ctx->set.init, fj.init[0].wgs, 1, 1, kInitBlock, 1, 1, 0, ctx->stream, ka, nullptr));
-    } else if (fj.init[0].n) k_init_jobs<InterpCode><<<fj.init[0].wgs, kInitBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fj.init[0].d_jobs), fj.init[0].n);
-    if (fj.init[1].n) k_init_jobs<InterpCodeWide><<<fj.init[1].wgs, kInitBlock, 0, ctx->stream>>>(static_cast<const ProgJob*>(fj.init[1].d_jobs), fj.init[1].n);
+        HIP_TRY(hipModuleLaunchKernel(ctx->set.init, fj.init[0].wgs, 1, 1, kInitBlock, 1, 1, 0, ms, ka, nullptr));
+    } else if (fj.init[0].n) k_init_jobs<InterpCode><<<fj.init[0].wgs, kInitBlock, 0, ms>>>(static_cast<const ProgJob*>(fj.init[0].d_jobs), fj.init[0].n);
+    if (fj.init[1].n) k_init_jobs<InterpCodeWide><<<fj.init[1].wgs, kInitBlock, 0, ms>>>(static_cast<const ProgJob*>(fj.init[1].d_jobs), fj.init[1].n);
     return HNB_OK;
 }
 
@@ -1849,13 +1887,15 @@ static int enqueue_program_update(HnbContext* ctx, HnbProgram* p, hipStream_t st
 }
 
 static int enqueue_update_passes(HnbContext* ctx, const std::vector<HnbProgram*>& order, const FrameJobs& fj, bool timed) {
-    // fork: the light programs' chains (and every shared launch) go to the side stream behind everything enqueued so far (the init passes);
+    // fork (unless enqueue_init_passes did): the light programs' chains (and every shared launch) go to the side stream behind everything enqueued so far (the init passes);
     // the heavy program's chain stays on the context's stream; the context's stream waits for the side stream at the end of the frame
     hipStream_t light = ctx->stream;
     if (fj.heavy) {
         light = ctx->side_stream;
-        HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
-        HIP_TRY(hipStreamWaitEvent(light, ctx->ev_fork, 0));
+        if (!fj.forked) {
+            HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(light, ctx->ev_fork, 0));
+        }
     }
     // (the merged updates first: every init pass is enqueued, and a merged program's own list kernels may follow in the loop below)
     if (fj.update_set) {

@@ -76,6 +76,11 @@ def test_a_bad_blob_is_refused():
 
 
 # ---- GPU ------------------------------------------------------------------------------------------------------------------------------------
+def _in_cache(assets):
+    """CACHED finds what an earlier hnb_jit_precompile_set left (tools/warm_jit_cache.py on the build box; compiled here if the cache did not travel)."""
+    bh.jit_precompile_set([bh.lower(a) for a in assets])
+
+
 class Scene:
     def __init__(self, assets, set_module):
         self.ctx = bh.Context(0)
@@ -120,6 +125,8 @@ class Scene:
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["off", "cached", "compile"])
 def test_gpu_a_small_set_is_the_oracle_in_every_mode(mode):
+    if mode == "cached":
+        _in_cache(_trio())
     sc = Scene(_trio(), {"off": 0, "cached": 1, "compile": 2}[mode])
     sc.step(120)            # (the oldest particles of the firework die within these frames: lists, sorts)
     sc.check()
@@ -135,6 +142,8 @@ def test_gpu_a_small_set_is_the_oracle_in_every_mode(mode):
 
 @pytest.mark.gpu
 def test_gpu_a_program_created_later_runs_interpreted_until_its_set_has_a_module():
+    _in_cache(_trio())
+    _in_cache(_quartet())
     sc = Scene(_trio(), 1)
     sc.step(24)
     before = sc.set_frames()
