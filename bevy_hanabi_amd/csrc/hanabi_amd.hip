@@ -1736,6 +1736,11 @@ static void enqueue_ribbon_sort(HnbContext* ctx, HnbProgram* p, hipStream_t st) 
     p->sort_parity += 1;
     const DevMeta* mo = p->d_meta[par ^ 1];
     const uint32_t tiles = n * so.chunks_per_inst;
+    if (so.chunks_per_inst == 1u) {   // the instance is one tile: fill, the range's radix passes and the merge in one launch
+        k_sort_tile1<<<n, kBlock, 0, st>>>(so, p->d_inst_base, mo);
+        p->ribbon_hist.dirty = false;
+        return;
+    }
     k_sort_fill<<<tiles, kBlock, 0, st>>>(so, p->d_inst_base, mo);
     // ... or when the whole list is small: whatever range the device finds, one workgroup sorts it faster than sixteen launches
     // are issued (a 40-particle lightning bolt whose ages are not provably ordered took 8 + 8 empty launches per frame)

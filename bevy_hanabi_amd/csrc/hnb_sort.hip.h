@@ -60,14 +60,16 @@ struct SortRange {
     uint64_t varying;  // key bits that differ inside the range
 };
 // n after this frame's update + compaction, and the range to sort
-__device__ __forceinline__ SortRange sort_range(const char* base, const SortArgs& a, const DevMeta& m) {
-    const SortState* st = reinterpret_cast<const SortState*>(base + a.bits_off) + a.parity;
+__device__ __forceinline__ SortRange sort_range_of(const SortState& st, const DevMeta& m) {
     SortRange r;
     r.n = m.alive_count;
     const uint32_t tail = m.spawned < r.n ? m.spawned : r.n;
-    if (st->head_unsorted) { r.lo = 0u; r.varying = st->or_all ^ st->and_all; }
-    else { r.lo = r.n - tail; r.varying = tail ? (st->or_tail ^ st->and_tail) : 0ull; }
+    if (st.head_unsorted) { r.lo = 0u; r.varying = st.or_all ^ st.and_all; }
+    else { r.lo = r.n - tail; r.varying = tail ? (st.or_tail ^ st.and_tail) : 0ull; }
     return r;
+}
+__device__ __forceinline__ SortRange sort_range(const char* base, const SortArgs& a, const DevMeta& m) {
+    return sort_range_of(*(reinterpret_cast<const SortState*>(base + a.bits_off) + a.parity), m);
 }
 
 struct SortPass { bool active; uint32_t src; };
@@ -98,12 +100,15 @@ __device__ __forceinline__ uint64_t wave_and(uint64_t v) {
     return v;
 }
 
-__global__ void __launch_bounds__(kBlock)
-k_sort_fill(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta) {
+// One tile of k_sort_fill. `whole`: the tile IS the instance (k_sort_tile1): the state words it would publish for the other tiles and the
+// later launches are returned to the caller instead (same values: nobody else contributes).
+__device__ __forceinline__ SortState sort_fill_tile(const SortArgs& a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta, uint32_t chunk, bool whole) {
     __shared__ uint64_t s_acc[4][kBlock / 64];
+    __shared__ uint32_t s_bad;
     uint32_t k, j; char* base;
-    sort_setup(blockIdx.x, a, inst_base, k, j, base);
+    sort_setup(chunk, a, inst_base, k, j, base);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (whole && tid == 0u) s_bad = 0u;
     const uint32_t n = meta[k].alive_count;
     const uint32_t tail = meta[k].spawned < n ? meta[k].spawned : n;
     const uint32_t tail_lo = n - tail;
@@ -162,6 +167,15 @@ k_sort_fill(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevM
     or_all = wave_or(or_all); and_all = wave_and(and_all); or_tail = wave_or(or_tail); and_tail = wave_and(and_tail);
     if (lane == 0) { s_acc[0][wave] = or_all; s_acc[1][wave] = and_all; s_acc[2][wave] = or_tail; s_acc[3][wave] = and_tail; }
     __syncthreads();
+    SortState out;
+    out.or_all = 0ull; out.and_all = ~0ull; out.or_tail = 0ull; out.and_tail = ~0ull; out.head_unsorted = 0u; out.pad[0] = out.pad[1] = out.pad[2] = 0u;
+    if (whole) {   // (the first barrier above orders the clearing of s_bad before this)
+        if (__any(bad) && lane == 0u) atomicOr(&s_bad, 1u);
+        __syncthreads();
+        for (uint32_t w = 0; w < kBlock / 64; ++w) { out.or_all |= s_acc[0][w]; out.and_all &= s_acc[1][w]; out.or_tail |= s_acc[2][w]; out.and_tail &= s_acc[3][w]; }
+        out.head_unsorted = s_bad;
+        return out;
+    }
     if (__any(bad) && lane == 0u) (st + a.parity)->head_unsorted = 1u;
     if (tid == 0 && j * kSortTile < n) {
         for (uint32_t w = 1; w < kBlock / 64; ++w) { or_all |= s_acc[0][w]; and_all &= s_acc[1][w]; or_tail |= s_acc[2][w]; and_tail &= s_acc[3][w]; }
@@ -173,6 +187,11 @@ k_sort_fill(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevM
             atomicAnd(reinterpret_cast<unsigned long long*>(&cur->and_tail), (unsigned long long)and_tail);
         }
     }
+    return out;
+}
+__global__ void __launch_bounds__(kBlock)
+k_sort_fill(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta) {
+    sort_fill_tile(a, inst_base, meta, blockIdx.x, false);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -286,13 +305,9 @@ k_sort_scatter(const SortArgs a, const uint64_t* __restrict__ inst_base, const D
 // find nothing to do cost 4 us apiece; this is one. hnb_simulate uses it when it can bound the range on the host (see there);
 // it is correct for any range, just slow for a large one.
 constexpr uint32_t kSortSmallMax = 65536;
-__global__ void __launch_bounds__(kBlock)
-k_sort_small(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta) {
+__device__ __forceinline__ void sort_small_range(const SortArgs& a, char* base, const SortRange rg) {
     __shared__ uint32_t s_base[256];
     __shared__ uint32_t s_cnt[kBlock / 64][256];
-    const uint32_t k = blockIdx.x;
-    char* base = global_ptr<char>(inst_base[k]);
-    const SortRange rg = sort_range(base, a, meta[k]);
     const uint32_t n = rg.n - rg.lo;
     if (n == 0u || rg.varying == 0ull) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -356,6 +371,11 @@ k_sort_small(const SortArgs a, const uint64_t* __restrict__ inst_base, const Dev
         src ^= 1u;   // (== sort_pass_info(varying, pass + 1).src: k_sort_merge finds the result where the multi-launch path leaves it)
     }
 }
+__global__ void __launch_bounds__(kBlock)
+k_sort_small(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta) {
+    char* base = global_ptr<char>(inst_base[blockIdx.x]);
+    sort_small_range(a, base, sort_range(base, a, meta[blockIdx.x]));
+}
 
 // number of keys < x (strict) or <= x in the sorted run keys[0..count)
 __device__ __forceinline__ uint32_t sorted_rank(const uint64_t* keys, uint32_t count, uint64_t x, bool strict) {
@@ -373,11 +393,7 @@ __device__ __forceinline__ uint32_t sorted_rank(const uint64_t* keys, uint32_t c
     return lo;
 }
 
-__global__ void __launch_bounds__(kBlock)
-k_sort_merge(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta) {
-    uint32_t k, j; char* base;
-    sort_setup(blockIdx.x, a, inst_base, k, j, base);
-    const SortRange rg = sort_range(base, a, meta[k]);
+__device__ __forceinline__ void sort_merge_tile(const SortArgs& a, char* base, const DevMeta* __restrict__ meta, uint32_t k, uint32_t j, const SortRange rg) {
     if (j * kSortTile >= rg.n) return;
     const uint32_t m = rg.n - rg.lo;
     if (m == 0u) return;                              // no spawn, head in order: the list stands
@@ -394,6 +410,28 @@ k_sort_merge(const SortArgs a, const uint64_t* __restrict__ inst_base, const Dev
         if (i < rg.lo) list[i + sorted_rank(tkey, m, hkey[i], true)] = hval[i];                       // head element: strictly smaller tail keys go first
         else list[(i - rg.lo) + sorted_rank(hkey, rg.lo, tkey[i - rg.lo], false)] = tval[i - rg.lo];  // tail element: head keys <= go first
     }
+}
+__global__ void __launch_bounds__(kBlock)
+k_sort_merge(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta) {
+    uint32_t k, j; char* base;
+    sort_setup(blockIdx.x, a, inst_base, k, j, base);
+    sort_merge_tile(a, base, meta, k, j, sort_range(base, a, meta[k]));
+}
+
+// The whole sort of an instance that fits ONE tile (capacity <= kSortTile: a lightning bolt, a small trail) by one workgroup and in one launch:
+// k_sort_fill's tile, k_sort_small's passes and k_sort_merge's tile back to back. The three communicate through the key / value buffers in
+// global memory as they do across launches (a workgroup sees its own stores behind a barrier) and through the state words, which stay in
+// registers here. Three dependent launches of microseconds each were 14 us of the 26-effect scene's 55 (profiles/r04t_scene.log).
+__global__ void __launch_bounds__(kBlock)
+k_sort_tile1(const SortArgs a, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta) {
+    const uint32_t k = blockIdx.x;   // (chunks_per_inst == 1: tile == instance)
+    char* base = global_ptr<char>(inst_base[k]);
+    const SortState st = sort_fill_tile(a, inst_base, meta, k, true);
+    const SortRange rg = sort_range_of(st, meta[k]);
+    __syncthreads();
+    sort_small_range(a, base, rg);
+    __syncthreads();
+    sort_merge_tile(a, base, meta, k, 0u, rg);
 }
 
 }  // namespace hnb
