@@ -545,6 +545,22 @@ __device__ __forceinline__ uint32_t chunk_of_workgroup(uint32_t mode, uint32_t b
 }
 __device__ __forceinline__ uint32_t chunk_of_workgroup(uint32_t mode) { return chunk_of_workgroup(mode, blockIdx.x, gridDim.x); }
 
+// The job of this workgroup: the last one whose first workgroup is <= blockIdx.x (they ascend, the first job starts at or below every workgroup
+// that looks here). Every lane looks at one job: one round trip per 64 jobs. (Until round 4: a binary search - log2(n) DEPENDENT scalar loads
+// from a table the frame's upload left in HBM, 4-5 us in front of each of a small scene's four shared launches.)
+template <class JOB>
+__device__ __forceinline__ const JOB& job_of_workgroup_t(const JOB* __restrict__ jobs, uint32_t n_jobs) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t idx = 0;
+    for (uint32_t b = 0; b < n_jobs; b += 64u) {
+        const uint32_t i = b + lane;
+        const uint32_t c = (uint32_t)__popcll(__ballot(i < n_jobs && jobs[i].first_wg <= blockIdx.x));   // (wave-uniform)
+        idx += c;
+        if (c < 64u) break;
+    }
+    return jobs[__builtin_amdgcn_readfirstlane(idx - 1u)];
+}
+
 // DevMeta travels as two 16-byte words (a struct copy through pointers that may alias became a memcpy through a private array in the
 // job-table kernels, which the compiler kept in LDS: 3 KiB per workgroup)
 __device__ __forceinline__ DevMeta load_meta(const DevMeta* p) {
@@ -1616,11 +1632,7 @@ struct ListsJob {
     uint32_t first_wg, n_wg;   // this program's workgroups in the launch
     uint32_t pad[2];
 };
-__device__ __forceinline__ const ListsJob& job_of_workgroup(const ListsJob* __restrict__ jobs, uint32_t n_jobs) {
-    uint32_t lo = 0, hi = n_jobs;   // last job with first_wg <= blockIdx.x (uniform: scalar loads)
-    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (jobs[mid].first_wg <= blockIdx.x) lo = mid; else hi = mid; }
-    return jobs[lo];
-}
+__device__ __forceinline__ const ListsJob& job_of_workgroup(const ListsJob* __restrict__ jobs, uint32_t n_jobs) { return job_of_workgroup_t(jobs, n_jobs); }
 __global__ void __launch_bounds__(kBlock)
 k_count_rows_multi(const ListsJob* __restrict__ jobs, uint32_t n_jobs) {
     const ListsJob& jb = job_of_workgroup(jobs, n_jobs);
@@ -1663,12 +1675,6 @@ struct StreamJob {           // k_update_jobs (first_wg / n_wg count chunks)
     uint32_t first_wg, n_wg;
     uint32_t set_case, pad;
 };
-template <class JOB>
-__device__ __forceinline__ const JOB& job_of_workgroup_t(const JOB* __restrict__ jobs, uint32_t n_jobs) {
-    uint32_t lo = 0, hi = n_jobs;   // last job with first_wg <= blockIdx.x (uniform: scalar loads)
-    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (jobs[mid].first_wg <= blockIdx.x) lo = mid; else hi = mid; }
-    return jobs[lo];
-}
 constexpr uint32_t kGenericSubs = kChunk / kBlock;   // k_update_jobs: one workgroup per 256 slots of a program on the V register file
 #ifndef HNB_JIT_TU
 template <class CODE>
