@@ -79,7 +79,7 @@ def scene_sweep(args, lo, hi):
     import bevy_hanabi_amd as bh
     from fuzz_assets import random_asset, random_frames, random_typed_asset
     from helpers import Frame, GpuRunner, OracleRunner, assert_same_state
-    bad = skipped = merged = total = 0
+    bad = skipped = merged = total = in_set = 0
     t0 = time.time()
     for g in range(lo, hi, args.scene):
         seeds, assets = [], []
@@ -117,12 +117,13 @@ def scene_sweep(args, lo, hi):
             print(f"seeds {seeds[0]}..{seeds[-1]}: MISMATCH {str(e)[:300]}")
         total += len(runners)
         merged += sum(1 for r in runners if "merged launch" in r.prog.kernel_info())
+        in_set += sum(1 for r in runners if "set module (the program" in r.prog.kernel_info())   # (HNB_CTX_OPTIONS=set_module=2: compiled per scene)
         for r in runners:
             r.fx.destroy()
             r.prog.destroy()
         ctx.close()
     print(f"{hi - lo} seeds in scenes of {args.scene} (gpu, jit={args.jit}): {bad} mismatching scenes, {skipped} not lowered, "
-          f"{merged} of {total} programs took the merged launches, {time.time() - t0:.1f} s")
+          f"{merged} of {total} programs took the merged launches, {in_set} were served by a set module, {time.time() - t0:.1f} s")
     return 1 if bad else 0
 
 
