@@ -10,11 +10,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hnb_kernels.hip.h"
@@ -114,6 +116,18 @@ struct ProgramOptions {
     bool horizon = true;                         // HNB_OPT_HORIZON
 };
 
+// A set module being compiled beside the frames (HNB_SET_MODULE_BACKGROUND). The job owns copies of everything the generated source is made from: the
+// programs it was started for may be destroyed while hiprtc runs. `done` is the hand-over: the worker writes `res` / `ok`, then sets it (release);
+// hnb_simulate reads it (acquire), joins and loads the module on its own thread (the device context is current there).
+struct SetBuildJob {
+    struct Member { std::vector<HnbAttrEntry> attrs; std::vector<Ins> init, update; bool streams = false, cohort = false; };
+    std::vector<Member> members;
+    jit::SetResult res;
+    bool ok = false;
+    std::atomic<bool> done{false};
+    std::thread worker;
+};
+
 struct HnbContext {
     int device = 0;
     hipStream_t stream = nullptr;       // the stream hnb_simulate enqueues on: own_stream or the caller's (hnb_ctx_set_stream)
@@ -157,6 +171,7 @@ struct HnbContext {
         jit::SetPlan plan;
         uint32_t gen = 0;           // bumped with every module loaded: HnbProgram::set_gen / set_case are valid for one generation
     } set;
+    std::shared_ptr<SetBuildJob> set_job;   // HNB_SET_MODULE_BACKGROUND: the compilation in flight (joined when its result is taken, or with the context)
     uint64_t set_tried = 0;         // the population (hash over the candidates' signatures) the last lookup / build was made for
     uint64_t set_seen = 0;          // ... and the one the previous merged frame had: a population is looked up once it has stood for two frames
     uint32_t set_frames = 0;        // statistics: frames with a launch served by the set kernels
@@ -808,6 +823,7 @@ int hnb_ctx_destroy(HnbContext* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     while (!ctx->programs.empty()) hnb_program_destroy(ctx->programs.back());
+    if (ctx->set_job) { ctx->set_job->worker.join(); ctx->set_job.reset(); }   // (hiprtc cannot be interrupted: destroying a context waits for a compilation it started)
     if (ctx->set.module) hipModuleUnload(ctx->set.module);
     recycle_timing_events(ctx);
     for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
@@ -852,7 +868,7 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
         case HNB_OPT_SUFFIX_PROOF: ctx->suffix_proof = value != 0u; return HNB_OK;
         case HNB_OPT_STREAM_HINTS: ctx->stream_hints = value != 0u; return HNB_OK;
         case HNB_OPT_SET_MODULE:
-            if (value > HNB_SET_MODULE_COMPILE) return fail(HNB_ERR_INVALID_ARG, "unknown set-module mode %u", value);
+            if (value > HNB_SET_MODULE_BACKGROUND) return fail(HNB_ERR_INVALID_ARG, "unknown set-module mode %u", value);
             ctx->set_mode = value;
             ctx->set_tried = ctx->set_seen = 0;   // (look again: the mode decides whether a missing module is compiled)
             return HNB_OK;
@@ -1592,8 +1608,16 @@ static uint32_t set_case_of(HnbContext* ctx, HnbProgram* p) {
     if (p->set_gen != ctx->set.gen) { p->set_gen = ctx->set.gen; p->set_case = ctx->set.module ? ctx->set.plan.case_of(p->set_sig) : kNoSetCase; }
     return p->set_case;
 }
+static void install_set_module(HnbContext* ctx, jit::SetResult& res);
 static void refresh_set_module(HnbContext* ctx, const std::vector<HnbProgram*>& order, const std::vector<plan::MergeFacts>& facts) {
-    if (ctx->set_mode == HNB_SET_MODULE_OFF) return;
+    if (ctx->set_job && ctx->set_job->done.load(std::memory_order_acquire)) {   // a background compilation has finished: take its module, whatever the mode is now
+        ctx->set_job->worker.join();
+        if (ctx->set_job->ok) install_set_module(ctx, ctx->set_job->res);
+        else ctx->set_log = ctx->set_job->res.log;
+        ctx->set_job.reset();
+        ctx->set_tried = 0;   // (the population may have moved on while it was compiled: look again)
+    }
+    if (ctx->set_mode == HNB_SET_MODULE_OFF || ctx->set_job) return;   // (while a compilation runs nothing is looked up: generating a module source costs a millisecond)
     std::vector<HnbProgram*> cand;
     bool covered = ctx->set.module != nullptr;
     for (size_t i = 0; i < order.size(); ++i) {
@@ -1616,10 +1640,32 @@ static void refresh_set_module(HnbContext* ctx, const std::vector<HnbProgram*>& 
         members.push_back(make_set_request(p->h_init.data(), (uint32_t)p->h_init.size(), p->h_update.data(), (uint32_t)p->h_update.size(), p->attrs.data(),
                                            (uint32_t)p->attrs.size(), p->update_streams, p->dev.age_cohort != 0u));
     jit::SetResult res;
-    if (!jit::build_set(members, res, ctx->set_mode == HNB_SET_MODULE_CACHED)) {
-        ctx->set_log = res.log.empty() ? std::string("no cache entry for this set of ") + std::to_string(res.plan.signatures.size()) + " programs (hnb_jit_precompile_set, or HNB_SET_MODULE_COMPILE)" : res.log;
+    if (!jit::build_set(members, res, ctx->set_mode != HNB_SET_MODULE_COMPILE)) {
+        if (ctx->set_mode == HNB_SET_MODULE_BACKGROUND && res.log.empty()) {   // not in the cache: compile it beside the frames (one job at a time)
+            auto job = std::make_shared<SetBuildJob>();
+            for (const HnbProgram* p : cand) {
+                SetBuildJob::Member m;
+                m.attrs = p->attrs; m.init = p->h_init; m.update = p->h_update; m.streams = p->update_streams; m.cohort = p->dev.age_cohort != 0u;
+                job->members.push_back(std::move(m));
+            }
+            SetBuildJob* j = job.get();   // (the context keeps the job alive until it has joined the worker)
+            job->worker = std::thread([j]() {
+                std::vector<jit::Request> rq;
+                for (const SetBuildJob::Member& m : j->members)
+                    rq.push_back(make_set_request(m.init.data(), (uint32_t)m.init.size(), m.update.data(), (uint32_t)m.update.size(), m.attrs.data(), (uint32_t)m.attrs.size(), m.streams, m.cohort));
+                j->ok = jit::build_set(rq, j->res, false);
+                j->done.store(true, std::memory_order_release);
+            });
+            ctx->set_job = std::move(job);
+            ctx->set_log = "compiling a module for this set of " + std::to_string(res.plan.signatures.size()) + " programs in the background";
+            return;
+        }
+        ctx->set_log = res.log.empty() ? std::string("no cache entry for this set of ") + std::to_string(res.plan.signatures.size()) + " programs (hnb_jit_precompile_set, or HNB_SET_MODULE_COMPILE / _BACKGROUND)" : res.log;
         return;
     }
+    install_set_module(ctx, res);
+}
+static void install_set_module(HnbContext* ctx, jit::SetResult& res) {
     hipModule_t mod = nullptr;
     hipFunction_t fi = nullptr, fu = nullptr;
     hipError_t e = hipModuleLoadData(&mod, res.code.data());

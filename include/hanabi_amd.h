@@ -315,12 +315,15 @@ int hnb_ctx_synchronize(HnbContext* ctx);
  *     OFF      the interpreters serve the merged launches (rounds 3's behaviour)
  *     CACHED   a module is used when the cache holds it (hnb_jit_precompile_set, or an earlier run with COMPILE); nothing is compiled on the frame path
  *     COMPILE  a missing module is compiled inside hnb_simulate (seconds to a minute, once per set: loading screens, tests, benchmarks)
+ *     BACKGROUND  a missing module is compiled on a thread of the library's own while the frames go on (on the interpreters); hnb_simulate loads it
+ *              when it is ready. One compilation at a time; hnb_ctx_destroy waits for one in flight (hiprtc cannot be interrupted)
  *   Same results bit for bit in every mode; programs created after the module was built keep their launches on the interpreters until the set has
  *   stood for two merged frames and a module for it is found (or compiled). */
 #define HNB_OPT_SET_MODULE 12u
 #define HNB_SET_MODULE_OFF 0u
 #define HNB_SET_MODULE_CACHED 1u
 #define HNB_SET_MODULE_COMPILE 2u
+#define HNB_SET_MODULE_BACKGROUND 3u
 int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value);
 
 /* Replaces EffectShaderSources::generate + pipeline specialisation (src/lib.rs:805-1336). */

@@ -12,6 +12,7 @@ import os
 import re
 import struct
 import subprocess
+import time
 
 import numpy as np
 import pytest
@@ -165,3 +166,38 @@ def test_gpu_a_context_of_one_program_has_no_set():
     sc = Scene(_trio()[:1], 2)
     sc.step(16)
     assert sc.set_frames() == [0] and "merged launch" not in sc.runs[0].prog.kernel_info()
+
+
+@pytest.mark.gpu
+def test_gpu_background_compilation_hands_the_module_over(tmp_path, monkeypatch):
+    """HNB_SET_MODULE_BACKGROUND with an empty cache: the frames go on (interpreted, equal to the oracle) while a thread of the library compiles the set;
+    the module serves the launches from the frame that finds it ready."""
+    monkeypatch.setenv("HNB_JIT_CACHE", str(tmp_path))
+    sc = Scene([effects.instancing(4096), effects.single_particle(16)], 3)
+    sc.step(4)
+    assert "in the background" in sc.runs[0].prog.kernel_info()
+    t0, served = time.time(), [0, 0]
+    while min(served) == 0 and time.time() - t0 < 180:
+        sc.step(8)
+        served = sc.set_frames()
+        if min(served) == 0:
+            time.sleep(0.25)
+    assert min(served) > 0, ("no module after 180 s", sc.runs[0].prog.kernel_info())
+    before = sc.set_frames()
+    sc.step(24)
+    sc.check()
+    assert min(a - b for a, b in zip(sc.set_frames(), before)) >= 20
+    assert "(compiled)" in sc.runs[0].prog.kernel_info()
+    assert len(_entries(tmp_path)) == 3      # two programs' own kernels and their set
+    sc.ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_a_context_destroyed_while_its_set_compiles(tmp_path, monkeypatch):
+    monkeypatch.setenv("HNB_JIT_CACHE", str(tmp_path))
+    sc = Scene([effects.ribbon(4096), effects.single_particle(16)], 3)
+    sc.step(4)
+    assert "in the background" in sc.runs[0].prog.kernel_info()
+    sc.check()
+    sc.ctx.close()                           # waits for the compilation (hiprtc cannot be interrupted): no crash, and the entry is in the cache afterwards
+    assert len(_entries(tmp_path)) == 3
