@@ -172,8 +172,7 @@ struct HnbContext {
         uint32_t gen = 0;           // bumped with every module loaded: HnbProgram::set_gen / set_case are valid for one generation
     } set;
     std::shared_ptr<SetBuildJob> set_job;   // HNB_SET_MODULE_BACKGROUND: the compilation in flight (joined when its result is taken, or with the context)
-    uint64_t set_tried = 0;         // the population (hash over the candidates' signatures) the last lookup / build was made for
-    uint64_t set_seen = 0;          // ... and the one the previous merged frame had: a population is looked up once it has stood for two frames
+    plan::SetLookupState set_lookup;   // the population the last lookup / build was made for, and the one the previous merged frame had (hnb_plan.h)
     uint32_t set_frames = 0;        // statistics: frames with a launch served by the set kernels
     std::string set_log;            // why the last build failed
 };
@@ -870,7 +869,7 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
         case HNB_OPT_SET_MODULE:
             if (value > HNB_SET_MODULE_BACKGROUND) return fail(HNB_ERR_INVALID_ARG, "unknown set-module mode %u", value);
             ctx->set_mode = value;
-            ctx->set_tried = ctx->set_seen = 0;   // (look again: the mode decides whether a missing module is compiled)
+            ctx->set_lookup = plan::SetLookupState();   // (look again: the mode decides whether a missing module is compiled)
             return HNB_OK;
         case HNB_OPT_OVERLAP_UPDATES: ctx->overlap_updates = value != 0u && ctx->side_stream && ctx->ev_fork && ctx->ev_join; return HNB_OK;   // (all three exist unless their creation failed)
         default: return fail(HNB_ERR_INVALID_ARG, "unknown option %u", option);
@@ -1615,7 +1614,7 @@ static void refresh_set_module(HnbContext* ctx, const std::vector<HnbProgram*>& 
         if (ctx->set_job->ok) install_set_module(ctx, ctx->set_job->res);
         else ctx->set_log = ctx->set_job->res.log;
         ctx->set_job.reset();
-        ctx->set_tried = 0;   // (the population may have moved on while it was compiled: look again)
+        ctx->set_lookup.tried = 0;   // (the population may have moved on while it was compiled: look again)
     }
     if (ctx->set_mode == HNB_SET_MODULE_OFF || ctx->set_job) return;   // (while a compilation runs nothing is looked up: generating a module source costs a millisecond)
     std::vector<HnbProgram*> cand;
@@ -1632,9 +1631,7 @@ static void refresh_set_module(HnbContext* ctx, const std::vector<HnbProgram*>& 
     std::sort(hs.begin(), hs.end());
     hs.erase(std::unique(hs.begin(), hs.end()), hs.end());
     const uint64_t pop = jit::hash_bytes(reinterpret_cast<const char*>(hs.data()), hs.size() * sizeof(uint64_t)) | 1ull;
-    if (pop == ctx->set_tried) return;
-    if (pop != ctx->set_seen) { ctx->set_seen = pop; return; }
-    ctx->set_tried = pop;
+    if (!plan::set_lookup_due(ctx->set_lookup, true, false, false, (uint32_t)cand.size(), pop)) return;
     std::vector<jit::Request> members;
     for (const HnbProgram* p : cand)
         members.push_back(make_set_request(p->h_init.data(), (uint32_t)p->h_init.size(), p->h_update.data(), (uint32_t)p->h_update.size(), p->attrs.data(),
@@ -1813,21 +1810,16 @@ static bool reads_particles_of(const HnbProgram* child, const HnbProgram* parent
     return false;
 }
 static int enqueue_init_passes(HnbContext* ctx, const std::vector<HnbProgram*>& order, FrameJobs& fj, bool timed) {
-    std::vector<char> on_side(order.size(), 0);
-    if (fj.heavy) {
-        std::vector<const HnbProgram*> family{fj.heavy};   // the heavy program and its ancestors
-        for (size_t i = 0; i < family.size(); ++i)
-            for (const HnbEffect* fx : family[i]->effects)
-                if (fx->parent && std::find(family.begin(), family.end(), fx->parent->prog) == family.end()) family.push_back(fx->parent->prog);
-        for (size_t i = 0; i < order.size(); ++i)
-            on_side[i] = std::find(family.begin(), family.end(), order[i]) == family.end() && !reads_particles_of(order[i], fj.heavy);
-        for (bool changed = true; changed;) {   // parents first, also across the fork: the parents of whatever stays in front of it stay as well
-            changed = false;
-            for (size_t i = 0; i < order.size(); ++i)
-                if (!on_side[i])
-                    for (size_t k = 0; k < order.size(); ++k)
-                        if (on_side[k] && reads_particles_of(order[i], order[k])) { on_side[k] = 0; changed = true; }
+    const uint32_t np = (uint32_t)order.size();
+    std::vector<uint8_t> on_side(np, 0);
+    if (fj.heavy) {   // (contexts with a heavy program hold a handful of programs: the n x n relation is small)
+        std::vector<uint8_t> reads((size_t)np * np, 0);
+        int heavy = -1;
+        for (uint32_t c = 0; c < np; ++c) {
+            if (order[c] == fj.heavy) heavy = (int)c;
+            for (uint32_t p = 0; p < np; ++p) reads[(size_t)c * np + p] = reads_particles_of(order[c], order[p]) ? 1u : 0u;
         }
+        plan::partition_init_passes(reads.data(), np, heavy, on_side.data());
     }
     for (int pass = 0; pass < (fj.heavy ? 2 : 1); ++pass) {
     hipStream_t st = ctx->stream;

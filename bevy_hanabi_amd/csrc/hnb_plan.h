@@ -239,6 +239,38 @@ inline void plan_merged_launches(const MergeFacts* progs, MergeDecision* out, ui
     }
 }
 
+// ---- which init passes stay in front of the fork (enqueue_init_passes) -------------------------------------------------------------------------
+// With a heavy program the frame forks behind its own init pass. `reads[c * n + p]`: an instance of program c has its parent in program p (the init
+// of c reads p's particles and must follow p's init; p's UPDATE must not run beside it). In front of the fork stay: the heavy program, the programs
+// it reads from (transitively: parents first), the programs that read ITS particles, and - again parents first - whatever those read from. Every
+// other init pass goes to the side stream. side[i] = 1: behind the fork.
+inline void partition_init_passes(const uint8_t* reads, uint32_t n, int heavy, uint8_t* side) {
+    for (uint32_t i = 0; i < n; ++i) side[i] = heavy >= 0 ? 1u : 0u;
+    if (heavy < 0) return;
+    side[heavy] = 0u;
+    for (uint32_t c = 0; c < n; ++c)
+        if (reads[c * n + (uint32_t)heavy]) side[c] = 0u;          // would race with the heavy update
+    for (bool changed = true; changed;) {                            // parents first, also across the fork
+        changed = false;
+        for (uint32_t c = 0; c < n; ++c)
+            if (!side[c])
+                for (uint32_t p = 0; p < n; ++p)
+                    if (side[p] && reads[c * n + p]) { side[p] = 0u; changed = true; }
+    }
+}
+
+// ---- set modules: when a context looks for (or builds) the module of its small programs (refresh_set_module) ----------------------------------------
+// covered: every candidate has a case in the loaded module; population: hash over the candidates' signatures (never 0). A population is looked up
+// once, and only after it has stood for two merged frames; nothing is looked up while a background compilation runs.
+struct SetLookupState { uint64_t seen = 0, tried = 0; };
+inline bool set_lookup_due(SetLookupState& st, bool enabled, bool job_running, bool covered, uint32_t n_candidates, uint64_t population) {
+    if (!enabled || job_running || covered || n_candidates < 2u) return false;
+    if (population == st.tried) return false;
+    if (population != st.seen) { st.seen = population; return false; }
+    st.tried = population;
+    return true;
+}
+
 // ---- cache policy ----------------------------------------------------------------------------------------------------------------------------
 // Streaming hints (nontemporal list traffic, nontemporal loads of the update's read-only planes: hnb_kernels.hip.h "cache policy of streamed
 // data") pay when one frame of the program touches more than the 256 MiB Infinity Cache holds - a 16.7M-particle effect moves a gigabyte per

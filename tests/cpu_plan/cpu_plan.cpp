@@ -80,4 +80,12 @@ void cpl_merge(const MergeRow* rows, uint32_t n, int option, int timed, int32_t*
     plan_merged_launches(f.data(), d.data(), n, option != 0, timed != 0);
     for (uint32_t i = 0; i < n; ++i) { out[2 * i] = d[i].init_family; out[2 * i + 1] = d[i].update_family; }
 }
+
+void cpl_partition_init_passes(const uint8_t* reads, uint32_t n, int heavy, uint8_t* side) { partition_init_passes(reads, n, heavy, side); }
+void* cpl_set_lookup_new() { return new SetLookupState(); }
+void cpl_set_lookup_free(void* h) { delete static_cast<SetLookupState*>(h); }
+void cpl_set_lookup_reset_tried(void* h) { static_cast<SetLookupState*>(h)->tried = 0; }
+int cpl_set_lookup_due(void* h, int enabled, int job_running, int covered, uint32_t n_candidates, uint64_t population) {
+    return set_lookup_due(*static_cast<SetLookupState*>(h), enabled != 0, job_running != 0, covered != 0, n_candidates, population) ? 1 : 0;
+}
 }

@@ -49,6 +49,11 @@ def lib():
     lib.cpl_stream_hints.argtypes = [C.c_uint64, C.c_uint32]
     lib.cpl_store_hints.argtypes = [C.c_uint64, C.c_uint32]
     lib.cpl_merge.argtypes = [C.POINTER(MergeRow), C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int32)]
+    lib.cpl_partition_init_passes.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+    lib.cpl_set_lookup_new.restype = C.c_void_p
+    lib.cpl_set_lookup_free.argtypes = [C.c_void_p]
+    lib.cpl_set_lookup_reset_tried.argtypes = [C.c_void_p]
+    lib.cpl_set_lookup_due.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint64]
     return lib
 
 
@@ -317,3 +322,48 @@ def test_merged_launches(lib):
     assert merge(lib, [dict(update_streams=1, init_blocks=65), stream, cohort]) == [(-1, 0), (0, 0), (0, 1)]
     # one init family member only: its init stays alone even if the updates share
     assert merge(lib, [dict(update_streams=1, init_blocks=0), stream]) == [(-1, 0), (-1, 0)]
+
+
+# ---- partition_init_passes: which init passes stay in front of the fork behind the heavy program's init ------------------------------------
+def _partition(lib, n, heavy, reads):
+    """reads: pairs (child, parent) - an instance of program `child` has its parent in program `parent`"""
+    m = np.zeros((n, n), dtype=np.uint8)
+    for c, p in reads:
+        m[c, p] = 1
+    side = np.zeros(n, dtype=np.uint8)
+    lib.cpl_partition_init_passes(m.ctypes.data, n, heavy, side.ctypes.data)
+    return [int(x) for x in side]
+
+
+def test_the_fork_behind_the_heavy_init(lib):
+    # no heavy program: one stream
+    assert _partition(lib, 3, -1, [(1, 0), (2, 0)]) == [0, 0, 0]
+    # firework.rs: 0 rocket, 1 sparkle trail (child of the rocket), 2 trails (child of the rocket, heavy): the rocket's init precedes the
+    # trails' init; the sparkles' init needs neither and goes behind the fork
+    assert _partition(lib, 3, 2, [(1, 0), (2, 0)]) == [0, 1, 0]
+    # independent programs beside a heavy one: all of them behind the fork
+    assert _partition(lib, 4, 1, []) == [1, 0, 1, 1]
+    # a program that reads the HEAVY program's particles at init must not run beside its update ...
+    assert _partition(lib, 3, 0, [(1, 0)]) == [0, 0, 1]
+    # ... and its OTHER parent stays in front with it (parents first, also across the fork), transitively
+    assert _partition(lib, 5, 0, [(1, 0), (1, 2), (2, 3)]) == [0, 0, 0, 0, 1]
+    # grandparents of the heavy program
+    assert _partition(lib, 4, 3, [(3, 2), (2, 1)]) == [1, 0, 0, 0]
+    # a chain among light programs only: both behind the fork, in their order
+    assert _partition(lib, 3, 0, [(2, 1)]) == [0, 1, 1]
+
+
+# ---- set_lookup_due: when a context looks its set module up -----------------------------------------------------------------------------------
+def test_a_population_is_looked_up_once_after_two_frames(lib):
+    h = lib.cpl_set_lookup_new()
+    due = lambda pop, enabled=1, job=0, covered=0, n=3: bool(lib.cpl_set_lookup_due(h, enabled, job, covered, n, pop))
+    assert not due(11)                       # first merged frame with this population: remembered
+    assert due(11)                           # it stood: looked up - once
+    assert not due(11) and not due(11)
+    assert not due(12) and not due(13)       # an application that creates an effect per frame never generates a module source
+    assert not due(13, job=1) and not due(13, covered=1) and not due(13, enabled=0) and not due(13, n=1)
+    assert due(13)                           # (none of the refusals above consumed the population)
+    assert not due(11) and due(11)           # back to an earlier population: looked up again (a cache entry may exist by now)
+    lib.cpl_set_lookup_reset_tried(h)        # a background compilation finished: look again, even at the same population
+    assert due(11)
+    lib.cpl_set_lookup_free(h)
