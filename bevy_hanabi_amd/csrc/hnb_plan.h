@@ -11,6 +11,8 @@
 //   size_event_grid       splits of a chunk's spawn events over workgroups
 //   plan_merged_launches  which small, independent programs share the job-table launches of the frame
 //   use_streaming_hints   cache policy: is the program big enough for its list traffic to be streamed past the Infinity Cache
+//   partition_init_passes which init passes stay in front of the fork behind a heavy program's own init (parents first; nobody beside its update)
+//   set_lookup_due        when a context looks the set module of its small programs up (once per population, after two merged frames)
 //
 // What each proof assumes about the device code is stated at the device side (hnb_kernels.hip.h); a wrong proof is reported by the
 // kernels through HnbEffectMetadata::fault, never silently.
