@@ -312,7 +312,7 @@ int hnb_ctx_synchronize(HnbContext* ctx);
  *   WGSL module per effect, src/lib.rs:805-1336, for effects that share a dispatch here). The set is every program of the context that can take
  *   part in merged launches (independent of other effects, <= 65,536 slots over its instances, narrow register file); the module is keyed by the
  *   set (not by creation order or multiplicity) and lives in the same on-disk cache as the per-program kernels.
- *     OFF      the interpreters serve the merged launches (rounds 3's behaviour)
+ *     OFF      the interpreters serve the merged launches (round 3's behaviour)
  *     CACHED   a module is used when the cache holds it (hnb_jit_precompile_set, or an earlier run with COMPILE); nothing is compiled on the frame path
  *     COMPILE  a missing module is compiled inside hnb_simulate (seconds to a minute, once per set: loading screens, tests, benchmarks)
  *     BACKGROUND  a missing module is compiled on a thread of the library's own while the frames go on (on the interpreters); hnb_simulate loads it
