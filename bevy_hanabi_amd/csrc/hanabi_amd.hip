@@ -11,10 +11,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -128,6 +131,28 @@ struct SetBuildJob {
     std::thread worker;
 };
 
+// Specialisation of single programs beside the frames (HNB_OPT_JIT_ASYNC): hnb_program_create returns with the ahead-of-time / interpreter kernels
+// and queues the compilation; one worker thread per context compiles job after job; hnb_simulate installs what is ready into the programs that still
+// exist (identified by a serial number: a program may be destroyed while its job waits or runs). Jobs own a copy of the program blob.
+struct JitJob {
+    uint64_t program_serial = 0;
+    std::vector<uint8_t> blob;
+    HnbProgramHeader hdr{};
+    std::vector<HnbAttrEntry> attrs;
+    bool streams = false, aot_static = false;
+    ProgramOptions opt;
+    jit::Result res;
+    bool ok = false;
+};
+struct JitWorker {
+    std::thread thread;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<JitJob>> queue, done;
+    bool stop = false;
+    uint32_t in_flight = 0;   // queued or compiling
+};
+
 struct HnbContext {
     int device = 0;
     hipStream_t stream = nullptr;       // the stream hnb_simulate enqueues on: own_stream or the caller's (hnb_ctx_set_stream)
@@ -171,6 +196,9 @@ struct HnbContext {
         jit::SetPlan plan;
         uint32_t gen = 0;           // bumped with every module loaded: HnbProgram::set_gen / set_case are valid for one generation
     } set;
+    bool jit_async = false;               // HNB_OPT_JIT_ASYNC
+    std::unique_ptr<JitWorker> jit_worker;
+    uint64_t next_program_serial = 1;
     std::shared_ptr<SetBuildJob> set_job;   // HNB_SET_MODULE_BACKGROUND: the compilation in flight (joined when its result is taken, or with the context)
     plan::SetLookupState set_lookup;   // the population the last lookup / build was made for, and the one the previous merged frame had (hnb_plan.h)
     uint32_t set_frames = 0;        // statistics: frames with a launch served by the set kernels
@@ -193,6 +221,8 @@ struct HnbProgram {
     // kernels specialised for this program at creation (hnb_jit.h); null = the ahead-of-time kernels run
     hipModule_t jit_module = nullptr;
     hipFunction_t jit_init = nullptr, jit_update = nullptr;
+    uint64_t serial = 0;            // identity across destruction (HNB_OPT_JIT_ASYNC: a finished compilation looks its program up by it)
+    bool jit_pending = false;
     std::string kernel_info, jit_log;
     // what a set module generates this program's cases from (narrow register file only; empty: never a member), and its case in the loaded module
     std::vector<Ins> h_init, h_update;
@@ -768,6 +798,66 @@ jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const
     return rq;
 }
 
+// The specialised kernels of one program: load the code object, take the functions, say so in kernel_info.
+void install_program_jit(HnbProgram* p, const jit::Result& res) {
+    const bool aot_static = p->update_streams && strcmp(p->stream_kernel_name, "ProgInterp") != 0;
+    hipModule_t mod = nullptr;
+    hipFunction_t fi = nullptr, fu = nullptr;
+    hipError_t je = hipModuleLoadData(&mod, res.code.data());
+    if (je == hipSuccess && !res.init_name.empty()) je = hipModuleGetFunction(&fi, mod, res.init_name.c_str());
+    if (je == hipSuccess && !res.update_name.empty()) je = hipModuleGetFunction(&fu, mod, res.update_name.c_str());
+    if (je != hipSuccess) {
+        p->jit_log = std::string("loading the specialised code object failed: ") + hipGetErrorString(je);
+        if (mod) hipModuleUnload(mod);
+        (void)hipGetLastError();
+        return;
+    }
+    p->jit_module = mod; p->jit_init = fi; p->jit_update = fu;
+    p->kernel_info = std::string(p->wide_file ? "wide-file " : "") + "init=" + (p->jit_init ? "jit" : (p->hdr.init_len ? "interp" : "none")) + " update=" +
+                     (p->jit_update ? (p->update_streams ? "jit-stream" : "jit-generic")
+                                    : (p->update_streams ? (aot_static ? std::string("aot-stream:") + p->stream_kernel_name : std::string("interp-stream"))
+                                                         : std::string("interp-generic")));
+    if (res.from_cache) p->kernel_info += " (jit cache hit)";
+}
+
+// HNB_OPT_JIT_ASYNC: the context's compilation thread (JitWorker)
+void jit_worker_main(JitWorker* w) {
+    for (;;) {
+        std::unique_ptr<JitJob> job;
+        {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->stop || !w->queue.empty(); });
+            if (w->stop) return;   // (jobs still queued are dropped with the context)
+            job = std::move(w->queue.front());
+            w->queue.pop_front();
+        }
+        const jit::Request rq = make_jit_request(job->blob.data(), job->hdr, job->attrs.data(), job->streams, job->aot_static, job->opt);
+        job->ok = jit::build(rq, job->res);
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->done.push_back(std::move(job));
+    }
+}
+// ... and hnb_simulate's side of it: what has been compiled since the last frame goes into the programs that still exist. The kernels it
+// replaces computed the same bits (tests run every program both ways), so the hand-over needs no synchronisation with frames in flight.
+void install_finished_jit(HnbContext* ctx) {
+    if (!ctx->jit_worker) return;
+    std::deque<std::unique_ptr<JitJob>> done;
+    {
+        std::lock_guard<std::mutex> lk(ctx->jit_worker->mu);
+        done.swap(ctx->jit_worker->done);
+        ctx->jit_worker->in_flight -= (uint32_t)done.size();
+    }
+    for (std::unique_ptr<JitJob>& j : done) {
+        HnbProgram* p = nullptr;
+        for (HnbProgram* q : ctx->programs)
+            if (q->serial == j->program_serial) p = q;
+        if (!p) continue;   // destroyed in the meantime
+        p->jit_pending = false;
+        if (j->ok) install_program_jit(p, j->res);
+        else if (!j->res.log.empty()) p->jit_log = j->res.log;
+    }
+}
+
 // A program as a member of a set module: the cases of every pass, whether or not it has instructions (an init pass without code still
 // zeroes the attributes and marks the slots; the family of the update - streaming plain / cohort, V register file - is the one
 // plan_merged_launches sorts it into)
@@ -822,6 +912,12 @@ int hnb_ctx_destroy(HnbContext* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     while (!ctx->programs.empty()) hnb_program_destroy(ctx->programs.back());
+    if (ctx->jit_worker) {   // (as below: a compilation in flight is waited for; queued ones are dropped)
+        { std::lock_guard<std::mutex> lk(ctx->jit_worker->mu); ctx->jit_worker->stop = true; }
+        ctx->jit_worker->cv.notify_all();
+        ctx->jit_worker->thread.join();
+        ctx->jit_worker.reset();
+    }
     if (ctx->set_job) { ctx->set_job->worker.join(); ctx->set_job.reset(); }   // (hiprtc cannot be interrupted: destroying a context waits for a compilation it started)
     if (ctx->set.module) hipModuleUnload(ctx->set.module);
     recycle_timing_events(ctx);
@@ -866,6 +962,7 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
         case HNB_OPT_SCENE_MERGE: ctx->scene_merge = value != 0u; return HNB_OK;
         case HNB_OPT_SUFFIX_PROOF: ctx->suffix_proof = value != 0u; return HNB_OK;
         case HNB_OPT_STREAM_HINTS: ctx->stream_hints = value != 0u; return HNB_OK;
+        case HNB_OPT_JIT_ASYNC: ctx->jit_async = value != 0u; return HNB_OK;
         case HNB_OPT_SET_MODULE:
             if (value > HNB_SET_MODULE_BACKGROUND) return fail(HNB_ERR_INVALID_ARG, "unknown set-module mode %u", value);
             ctx->set_mode = value;
@@ -933,23 +1030,29 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     const bool aot_static = p->update_streams && strcmp(p->stream_kernel_name, "ProgInterp") != 0;
     p->kernel_info = std::string(p->wide_file ? "wide-file " : "") + "init=" + (h.init_len ? "interp" : "none") + " update=" +
                      (p->update_streams ? (aot_static ? std::string("aot-stream:") + p->stream_kernel_name : std::string("interp-stream")) : std::string("interp-generic"));
+    p->serial = ctx->next_program_serial++;
     if (jit::enabled()) {
         const jit::Request rq = make_jit_request(b, h, p->attrs.data(), p->update_streams, aot_static, ctx->popt);
         jit::Result res;
-        if (jit::build(rq, res)) {
-            hipError_t je = hipModuleLoadData(&p->jit_module, res.code.data());
-            if (je == hipSuccess && !res.init_name.empty()) je = hipModuleGetFunction(&p->jit_init, p->jit_module, res.init_name.c_str());
-            if (je == hipSuccess && !res.update_name.empty()) je = hipModuleGetFunction(&p->jit_update, p->jit_module, res.update_name.c_str());
-            if (je != hipSuccess) {
-                p->jit_log = std::string("loading the specialised code object failed: ") + hipGetErrorString(je);
-                p->jit_init = p->jit_update = nullptr;
-            } else {
-                p->kernel_info = std::string(p->wide_file ? "wide-file " : "") + "init=" + (p->jit_init ? "jit" : (h.init_len ? "interp" : "none")) + " update=" +
-                                 (p->jit_update ? (p->update_streams ? "jit-stream" : "jit-generic")
-                                                : (p->update_streams ? (aot_static ? std::string("aot-stream:") + p->stream_kernel_name : std::string("interp-stream"))
-                                                                     : std::string("interp-generic")));
-                if (res.from_cache) p->kernel_info += " (jit cache hit)";
+        if (jit::build(rq, res, /*cache_only=*/ctx->jit_async)) {
+            install_program_jit(p, res);
+        } else if (ctx->jit_async && res.log.empty() && (rq.want_init || rq.want_update_generic || rq.want_update_stream)) {
+            // not in the cache: the ahead-of-time / interpreter kernels run until the context's compilation thread has the program's own
+            if (!ctx->jit_worker) {
+                ctx->jit_worker.reset(new JitWorker());
+                ctx->jit_worker->thread = std::thread(jit_worker_main, ctx->jit_worker.get());
             }
+            std::unique_ptr<JitJob> job(new JitJob());
+            job->program_serial = p->serial;
+            job->blob.assign(b, b + blob_size);
+            job->hdr = h; job->attrs = p->attrs; job->streams = p->update_streams; job->aot_static = aot_static; job->opt = ctx->popt;
+            {
+                std::lock_guard<std::mutex> lk(ctx->jit_worker->mu);
+                ctx->jit_worker->queue.push_back(std::move(job));
+                ctx->jit_worker->in_flight += 1;
+            }
+            ctx->jit_worker->cv.notify_one();
+            p->jit_pending = true;
         } else if (!res.log.empty()) {
             p->jit_log = res.log;
         }
@@ -1978,6 +2081,7 @@ static int enqueue_update_passes(HnbContext* ctx, const std::vector<HnbProgram*>
 int hnb_simulate(HnbContext* ctx) {
     if (!ctx) return fail(HNB_ERR_INVALID_ARG, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
+    install_finished_jit(ctx);
     std::vector<HnbProgram*> order;
     for (HnbProgram* p : ctx->programs)
         if (!p->effects.empty()) order.push_back(p);
@@ -2183,6 +2287,7 @@ int hnb_effect_sort_ribbons(HnbEffect* fx) {
 int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
     if (!prog || !buf || !buf_size) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
     std::string s = prog->kernel_info;
+    if (prog->jit_pending) s += " (specialisation pending: HNB_OPT_JIT_ASYNC)";
     if (!prog->jit_log.empty()) s += "\njit log: " + prog->jit_log;
     if (prog->dev.age_cohort) {   // (debug statistics: synchronises and reads the per-chunk state words of every instance)
         hipStreamSynchronize(prog->ctx->stream);

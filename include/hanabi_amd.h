@@ -306,6 +306,12 @@ int hnb_ctx_synchronize(HnbContext* ctx);
 /* HNB_OPT_STREAM_HINTS (default 1; from the next hnb_simulate on): programs whose frame touches more than the 256 MiB Infinity Cache holds
  *   read and write their lists, and read the update's read-only planes, with the nontemporal hint (a cache-policy choice: same results). */
 #define HNB_OPT_STREAM_HINTS 11u
+/* HNB_OPT_JIT_ASYNC (default 0; applies to programs created afterwards): hnb_program_create does not wait for hiprtc. A program whose specialised
+ *   kernels are not in the cache starts on the ahead-of-time / interpreter kernels (same results bit for bit) and a thread of the library's own compiles
+ *   them, one program after the other; the first hnb_simulate that finds them ready uses them. (The reference's pipelines are compiled asynchronously too,
+ *   and an effect whose pipelines are not ready is SKIPPED, src/render/mod.rs:3852-3900; here it is simulated from its first frame.) hnb_ctx_destroy waits
+ *   for a compilation in flight. */
+#define HNB_OPT_JIT_ASYNC 13u
 /* HNB_OPT_SET_MODULE (default HNB_SET_MODULE_CACHED; from the next hnb_simulate on): the launches the small programs of a context share
  *   (HNB_OPT_SCENE_MERGE) run the byte-code INTERPRETERS - the only code that fits every program - unless the context has a SET MODULE: one
  *   hiprtc module whose two kernels switch, per job, into the SPECIALISED code of each program (the counterpart of the reference compiling one

@@ -201,3 +201,44 @@ def test_gpu_a_context_destroyed_while_its_set_compiles(tmp_path, monkeypatch):
     sc.check()
     sc.ctx.close()                           # waits for the compilation (hiprtc cannot be interrupted): no crash, and the entry is in the cache afterwards
     assert len(_entries(tmp_path)) == 3
+
+
+@pytest.mark.gpu
+def test_gpu_asynchronous_specialisation_of_single_programs(tmp_path, monkeypatch):
+    """HNB_OPT_JIT_ASYNC with an empty cache: hnb_program_create returns at once, the program runs on the ahead-of-time / interpreter kernels (equal to
+    the oracle) until the context's compilation thread has its own, and goes on equal to the oracle afterwards; a program destroyed while it waits."""
+    monkeypatch.setenv("HNB_JIT_CACHE", str(tmp_path))
+    ctx = bh.Context(0)
+    ctx.set_option("jit_async", 1)
+    ctx.set_option("scene_merge", 0)          # (every program on its own launches: what is being swapped is the program's own kernels)
+    t0 = time.time()
+    assets = [effects.firework_trails(4096), effects.force_field(4096), effects.instancing(4096)]
+    runs = [GpuRunner(a, ctx=ctx) for a in assets]
+    assert time.time() - t0 < 2.0, "program creation waited for hiprtc"
+    oracles = [OracleRunner(a) for a in assets]
+    assert all("specialisation pending" in r.prog.kernel_info() for r in runs)
+    doomed = GpuRunner(effects.ribbon(4096), ctx=ctx)   # queued behind the three: destroyed before its turn (or during it)
+    doomed.fx.destroy()
+    doomed.prog.destroy()
+
+    def frames(n, f0):
+        for f in range(f0, f0 + n):
+            ctx.frame_begin(1 / 60.0, f / 60.0)
+            for i, (r, o) in enumerate(zip(runs, oracles)):
+                spawn = r.asset.capacity // 2 if f == 0 else (29 + 7 * i if f % 2 == 0 else 0)
+                seed = frame_seed(f, base=0xA5A500 + 31 * i)
+                r.fx.set_frame(spawn, seed, None)
+                o.step(Frame(1 / 60.0, spawn, seed, None, f / 60.0))
+            ctx.simulate()
+        for i, (r, o) in enumerate(zip(runs, oracles)):
+            assert_same_state(o.state(), r.state(), f"effect {i} after frame {f0 + n - 1}")
+        return f0 + n
+
+    f = frames(6, 0)
+    while any("pending" in r.prog.kernel_info() for r in runs) and time.time() - t0 < 180:
+        f = frames(4, f)
+        time.sleep(0.2)
+    infos = [r.prog.kernel_info().split("\n")[0] for r in runs]
+    assert all("pending" not in s and "init=jit" in s for s in infos), infos
+    frames(40, f)
+    ctx.close()
