@@ -43,8 +43,11 @@ Parity gate (BASELINE.md §3 "same run"): before a configuration's number is acc
 for bit with the CPU oracle (oracle/, the restatement of the reference's WGSL semantics): burst configurations (c2, c2_interop, c3, c4) on one
 slab of slots of the FULL-SIZE effect after all timed frames (a burst fills slot i with PRNG stream i: the slab IS a small effect with that
 slot_base); churn configurations (c2_mixed, c2_dieoff, c2_events, c5) by replaying the same regime (same dt, warm-up and frame count) at a reduced
-capacity against the oracle, full state. Slab / capacity are sized to the oracle's measured speed (a few seconds per configuration). The line
-carries "parity": {"checked": [...], "ok": true}; if a comparison fails the line carries "value": null and the exit code is 1.
+capacity against the oracle, full state - AND, on the state the timed frames themselves left at full size: hnb_effect_check (fault flag, the two
+lists a permutation of the slots, alive bytes, age < lifetime, all on the device) and hnb_effect_compare against a second context that replayed the
+same frames with every proof and hint switched off (PLAIN_OPTIONS), bit for bit. Slab / capacity are sized to the oracle's measured speed (a few
+seconds per configuration). The line carries "parity": {"checked": [...], "ok": true}; if a comparison fails the line carries "value": null and
+the exit code is 1.
 
 Output: the LAST stdout line is the short result (<= 4 KB: the c2 headline with roofline, cpu_baseline, parity and a one-row summary of every
 other configuration); the complete record (every window, stage, counter and per-kernel figure) goes to profiles/bench_full.json (and
@@ -311,7 +314,7 @@ class Dist:
 class Workload:
     """One configuration set up on one rank: builds the effect(s), knows how to play frame f."""
 
-    def __init__(self, name, args, D, strong=False):
+    def __init__(self, name, args, D, strong=False, options=None):
         import bevy_hanabi_amd as bh
         from bevy_hanabi_amd import effects, sharding
 
@@ -320,6 +323,8 @@ class Workload:
         n = D.world
         base_cap = args.capacity or cfg["capacity"]
         self.ctx = bh.Context(D.device_index)
+        for k, v in (options or {}).items():   # (the parity gate's plain replay: every proof and hint off; a test's broken proof)
+            self.ctx.set_option(k, v)
         self.per_inst_cap = base_cap
         self.spawner = self.rng = None
         self.xf_of = None
@@ -511,6 +516,42 @@ def parity_burst_slab(w, D):
             "ok": not problems, "problems": problems}
 
 
+# every proof, hint and shortcut hnb_ctx_set_option can switch off: what is left is one init, one update, k_count_rows + k_compact per
+# program and frame, per-particle ages and lifetimes, direct spawn stores, one stream
+PLAIN_OPTIONS = {"horizon": 0, "age_cohort": 0, "cull_lifetime": 0, "skip_lists": 0, "stream_hints": 0, "overlap_updates": 0, "spawn_nursery": 0,
+                 "suffix_proof": 0, "alternate": 0, "transpose": 0, "scene_merge": 0}
+
+
+def parity_timed_state(w, args, D, options=None):
+    """c2_mixed, c2_dieoff, c2_events, c5 at FULL size, on the state the timed frames left in `w`:
+    (a) hnb_effect_check on every effect - fault flag clear, alive rows + dead rows a permutation of the slots, alive bytes consistent with the
+        lists, every alive particle younger than its lifetime - evaluated on the device;
+    (b) a second context replays the same frames (same dt, inputs, spawner sequence) with every proof and hint off (PLAIN_OPTIONS) and
+        hnb_effect_compare holds the two effects against each other bit for bit: counters, both lists, every plane of every slot.
+    The oracle leg (the same regime at reduced capacity, full state) is parity_regime."""
+    t0 = time.perf_counter()
+    problems = []
+    checks = [fx.check() for fx in w.fxs]
+    for i, c in enumerate(checks):
+        if not c["ok"]:
+            problems.append(f"effect {i} invariants: {c}")
+    sub = argparse.Namespace(**vars(args))
+    sub.capacity = w.per_inst_cap
+    w2 = Workload(w.name, sub, D, options=dict(PLAIN_OPTIONS, **(options or {})))
+    w2.dt = w.dt
+    for _ in range(w.f):
+        w2.step()
+    w2.ctx.synchronize()
+    diffs = [a.compare(b) for a, b in zip(w.fxs, w2.fxs)]
+    for i, d in enumerate(diffs):
+        if not d["equal"]:
+            problems.append(f"effect {i} differs from the plain replay: {d}")
+    plain_kernels = w2.prog.kernel_info().split("\n")[0]
+    w2.close()
+    return {"kind": "timed state: invariants on the device + plain-path differential at full size", "frames": w.f, "capacity": w.per_inst_cap,
+            "checks": checks, "diffs": diffs, "plain_kernels": plain_kernels, "seconds": time.perf_counter() - t0, "ok": not problems, "problems": problems}
+
+
 def parity_regime(name, args, D, frames):
     """c2_mixed, c2_dieoff, c2_events, c5: the same regime - same dt, same warm-up, same number of frames, the same spawner - replayed at a
     reduced capacity on the device and, frame by frame, by the oracle; then the FULL state (counters, both lists, every plane of every slot)."""
@@ -563,6 +604,38 @@ def parity_regime(name, args, D, frames):
     w.close()
     return {"config": name, "kind": "the same regime at reduced capacity, full state", "capacity": cap, "frames": frames, "alive_at_end": alive,
             "kernels": kinfo[0], "seconds": time.perf_counter() - t0, "ok": not problems, "problems": problems}
+
+
+_COMM_STUCK = False
+
+
+def comm_alive_total(w, timeout_s=90.0):
+    """N = 1: the alive total of the headline configuration through the library's OWN collective - a one-context communicator built with the real
+    librccl (hnb_comm_set_library(NULL, HNB_COMM_LIB_SINGLE_RANK) at start-up: ncclCommInitAll over one device, a grouped ncclAllReduce(ncclUint64,
+    ncclSum) on the simulation stream) - so that the record of a one-GPU run shows that hnb_comm_* works, not only torch.distributed at N > 1.
+    Guarded by a timeout (a collective library that cannot initialise on this host must not cost the line)."""
+    global _COMM_STUCK
+    import threading
+    out = {}
+
+    def body():
+        try:
+            comm = w.bh.Comm.local([w.ctx])
+            desc = comm.describe()
+            totals = comm.allreduce_alive([list(w.fxs)])
+            comm.destroy()
+            kind, _, rest = desc.partition(" ")
+            out.update({"library": rest.split(" ranks=")[0] if kind == "rccl" else kind, "ranks": 1, "effects": len(totals), "alive_total": int(sum(totals))})
+        except Exception as e:
+            out["error"] = f"{type(e).__name__}: {e}"[:200]
+
+    t = threading.Thread(target=body, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        _COMM_STUCK = True
+        return {"error": f"hnb_comm_* did not return within {timeout_s:.0f} s"}
+    return out
 
 
 def warmup_frames(name, requested):
@@ -666,6 +739,11 @@ def run_config(name, args, D, strong=False, pmc=None):
         timing["frames"] = tot
     alive1 = w.alive()
     m1 = [fx.metadata() for fx in w.fxs[:8]]
+    comm_info = None
+    if getattr(args, "comm", False) and not D.on and not strong and name == args.config:
+        comm_info = comm_alive_total(w)
+        if "alive_total" in comm_info:
+            assert comm_info["alive_total"] == alive1, f"hnb_comm_allreduce_alive says {comm_info['alive_total']}, the effects' counters {alive1}"
     kinfo = w.prog.kernel_info().split("\n")[0]
     parity = None
     if args.parity and D.rank == 0 and not strong:
@@ -673,8 +751,12 @@ def run_config(name, args, D, strong=False, pmc=None):
             if name in BURST_PARITY:
                 parity = parity_burst_slab(w, D)
             else:
+                timed = parity_timed_state(w, args, D)
                 w.close()
                 parity = parity_regime(name, args, D, w.f)
+                parity["timed_state"] = timed
+                parity["ok"] = parity["ok"] and timed["ok"]
+                parity["problems"] = parity["problems"] + timed["problems"]
         except Exception as e:
             parity = {"config": name, "ok": False, "problems": [f"{type(e).__name__}: {e}"]}
     w.close()
@@ -725,6 +807,8 @@ def run_config(name, args, D, strong=False, pmc=None):
         "kernels": kinfo,
         "parity": parity,
     }
+    if comm_info is not None:
+        out["comm"] = comm_info
     if per_program is not None:
         out["stages"]["per_program"] = per_program
         out["stages"]["note"] = "init / lists: sums over the three programs (lists of the rocket include its spawn-event ordering: k_emit_count + k_emit_events); update: the trails' kernel; sum_ms leaves out the two small update kernels (per_program has them)"
@@ -1009,6 +1093,8 @@ def main():
     ap.add_argument("--launcher", choices=["ranks", "threads"], default="ranks",
                     help="N > 1: ranks = one process per GPU (torch.distributed.run, RCCL through torch); threads = ONE process, one HnbContext and one "
                          "submit thread per GPU (examples/multi_gpu.c: C99 over the C ABI, RCCL through hnb_comm_*), c2 / c3 only")
+    ap.add_argument("--no-comm", dest="comm", action="store_false", default=True,
+                    help="N = 1: do not take the headline's alive total through hnb_comm_allreduce_alive (a one-rank communicator of the real librccl)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--force-device", type=int, default=None, help="dry runs: every rank uses this GPU instead of LOCAL_RANK")
     args = ap.parse_args()
@@ -1022,6 +1108,14 @@ def main():
     if args.pmc_child:
         pmc_child(args, D)
         return
+    if args.comm and not D.on:   # (before the first hnb_comm_* call of the process)
+        try:
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            from bevy_hanabi_amd import runtime as _rt
+            _rt.comm_set_library(None, single_rank=True)
+        except Exception as e:
+            print(f"note: hnb_comm_set_library: {e}", file=sys.stderr)
+            args.comm = False
     if args.gpus != D.world and D.rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={D.world}", file=sys.stderr)
 
@@ -1112,6 +1206,10 @@ def main():
         print(encode_line(short), flush=True)
         rc = 0 if short["parity"]["ok"] is not False else 1
     D.close()
+    if _COMM_STUCK:   # (a thread is still inside the collective library: do not wait for it at interpreter shutdown)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(rc)
     sys.exit(rc)
 
 
@@ -1147,7 +1245,11 @@ def short_line(full, args):
     parity_all = [p for p in parity_all if p]
     failed = [p["config"] for p in parity_all if not p.get("ok")]
     errored = [k for k, v in full.get("configs", {}).items() if "error" in v]
-    parity = {"checked": [p["config"] for p in parity_all if p.get("ok")], "ok": (not failed) if (parity_all or args.parity) else None, "against": "oracle/, bit-exact (burst: slab of the full-size effect after the timed frames; churn: same regime, reduced capacity, full state)"}
+    parity = {"checked": [p["config"] for p in parity_all if p.get("ok")], "ok": (not failed) if (parity_all or args.parity) else None, "against": "oracle/, bit-exact", "burst": "slab of the full-size effect after the timed frames vs the oracle",
+              "churn": "timed state: invariants + plain-path differential at full size; oracle at reduced capacity"}
+    timed = [p.get("timed_state") for p in parity_all if p.get("timed_state")]
+    if timed:   # (the churn configurations' full-size leg: how many effects were checked / compared on the device)
+        parity["timed_state"] = {"effects_checked": sum(len(t["checks"]) for t in timed), "effects_compared": sum(len(t["diffs"]) for t in timed), "ok": all(t["ok"] for t in timed)}
     if failed:
         parity["failed"] = {p["config"]: (p.get("problems") or ["?"])[0][:120] for p in parity_all if not p.get("ok")}
     if not args.parity:
@@ -1171,6 +1273,8 @@ def short_line(full, args):
         short["cpu_baseline"] = cb if "error" in cb else {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "threads": cb["threads"], "host_physical_cores": cb.get("host_physical_cores"),
                                                           "host_logical_cpus": cb.get("host_logical_cpus"), "cpu_model": cpu_model(), "kind": cb["kind"], "sample": cb["sample"][:120]}
     short["parity"] = parity
+    if full.get("comm"):
+        short["comm"] = full["comm"]
     rows = {}
     for k, v in full.get("configs", {}).items():
         if "error" in v:

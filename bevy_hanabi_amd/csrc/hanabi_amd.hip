@@ -72,13 +72,20 @@ typedef void (*StreamLaunchFn)(uint32_t grid, hipStream_t stream, const SlotArgs
 #ifndef HNB_STREAM_WAVES_COHORT
 #define HNB_STREAM_WAVES_COHORT 4   // 97 VGPRs, no scratch (a 5-wave budget: 96 + 8 bytes of scratch; A/B on one box, profiles/r03f_waves_ab.log: c2 the same, c2_mixed 0.215 vs 0.228 ms)
 #endif
+#ifndef HNB_STREAM_WAVES_NURSERY
+#define HNB_STREAM_WAVES_NURSERY 5   // the plain instantiations with the spawn-record substitution: 96 VGPRs (budgeted for 6 waves they spilled 44 bytes per lane)
+#endif
 template <class PROG, int WAVES>
 void launch_stream(uint32_t grid, hipStream_t stream, const SlotArgs& sa, const uint64_t* inst_base, const DevFrameInst* fi,
                    const uint32_t* ublocks, const CompactBufs& cb) {
     // (the age-cohort paths need more registers: budgeted for 6 waves (80 VGPRs) the per-particle path of the firework kernel spilled 48 bytes
     // per lane to scratch; see HNB_STREAM_WAVES_COHORT)
-    if (sa.age_cohort) k_update_slots_stream<PROG, (WAVES > HNB_STREAM_WAVES_COHORT ? HNB_STREAM_WAVES_COHORT : WAVES), 0, true><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
-    else k_update_slots_stream<PROG, WAVES, 0, false><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
+    // (... and so does the spawn-record substitution, SlotArgs::nursery: the instantiations without it are the kernels as they were)
+    constexpr int WC = WAVES > HNB_STREAM_WAVES_COHORT ? HNB_STREAM_WAVES_COHORT : WAVES, WN = WAVES > HNB_STREAM_WAVES_NURSERY ? HNB_STREAM_WAVES_NURSERY : WAVES;
+    if (sa.age_cohort && sa.nursery) k_update_slots_stream<PROG, WC, 0, true, true><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
+    else if (sa.age_cohort) k_update_slots_stream<PROG, WC, 0, true, false><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
+    else if (sa.nursery) k_update_slots_stream<PROG, WN, 0, false, true><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
+    else k_update_slots_stream<PROG, WAVES, 0, false, false><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
 }
 #define OP_(x) (uint32_t)HNB_OP_M_##x
 typedef ProgStatic<OP_(AGE_TICK)> ProgAge;                                                        // ribbon.rs
@@ -114,9 +121,10 @@ void select_stream_kernel(const Ins* code, uint32_t n, StreamLaunchFn* fn, const
 
 // What hnb_program_create fixes in a program (hnb_ctx_set_option before the program is created; hnb_jit_precompile uses the defaults)
 struct ProgramOptions {
-    uint32_t age_cohort = HNB_AGE_COHORT_LEAN;   // HNB_OPT_AGE_COHORT
+    uint32_t age_cohort = HNB_AGE_COHORT_AUTO;   // HNB_OPT_AGE_COHORT
     bool cull_lifetime = true;                   // HNB_OPT_CULL_LIFETIME
     bool horizon = true;                         // HNB_OPT_HORIZON
+    bool nursery = true;                         // HNB_OPT_SPAWN_NURSERY
 };
 
 // A set module being compiled beside the frames (HNB_SET_MODULE_BACKGROUND). The job owns copies of everything the generated source is made from: the
@@ -162,6 +170,7 @@ struct HnbContext {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap_updates = true;          // HNB_OPT_OVERLAP_UPDATES
     bool stream_hints = true;             // HNB_OPT_STREAM_HINTS
+    bool break_proof = false;             // HNB_OPT_TEST_BREAK_PROOF (a test hook: see stage_program_frame)
     // The per-frame parameters of EVERY program (instance rows, uniform blocks, init block starts) are staged in one pinned buffer and go to the
     // device with one copy per frame: with a copy per program, a scene of 26 small effects spent a quarter of its frame in 26 serialised
     // 3.5 us copy kernels and the host waiting for them (profiles/r02u_scene.md). A ring of slots: the host fills slot f % kFrameRing while the
@@ -216,6 +225,7 @@ struct HnbProgram {
     bool wide_file = false;       // init_regs / update_regs above HNB_VM_MAX_REGS: generic kernels use the wide V file
     uint32_t cull_dt_operand = 0; // lifetime culling: decoded operand a of the update stream's AGE_TICK (dev.cull_lifetime)
     bool update_streams = false;  // update stream runs on the streaming kernel (macro ops, U operands)
+    bool auto_materialise = false;  // HNB_AGE_COHORT_AUTO and the render modifiers read AGE: the plane is made current at the end of every frame
     StreamLaunchFn stream_launch = nullptr;  // specialised (or interpreted) streaming kernel for this update stream
     const char* stream_kernel_name = "";
     // kernels specialised for this program at creation (hnb_jit.h); null = the ahead-of-time kernels run
@@ -491,7 +501,7 @@ int validate_stream(const uint8_t* blob_base, const uint8_t* code, uint32_t len,
 // The alive list moves to the other column only in frames where particles died (k_compact). Every section offset is a
 // u32 in the device structs: the layout is computed in 64 bits and rejected as a whole when it does not fit (offsets grow
 // monotonically, so the total bounds every one of them).
-bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgram& d, SortArgs& so, size_t* out_bytes) {
+bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgram& d, SortArgs& so, size_t* out_bytes, bool nursery = false) {
     d.capacity = h.capacity;
     d.n_attrs = h.n_attrs;
     d.n_uregs = h.n_uregs;
@@ -521,7 +531,17 @@ bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgra
         gsum_off = place(align_up((size_t)8 * ((sort_chunks + kSortGroup - 1) / kSortGroup) * 256 * 4, 256));
         bits_off = place(256);
     }
+    // spawn nursery (hnb_kernels.hip.h): a counter per 256-slot group, then a bucket of 256 32-byte records per group - LAST in the slab, so that
+    // the planes the update streams keep their offsets (and their placement) whether or not a program is eligible
+    uint64_t ncnt_off = 0, nrec_off = 0;
+    if (nursery) {
+        const uint64_t groups = (uint64_t)d.chunks_per_inst * (kChunk / kNurseryGroup);
+        ncnt_off = place(align_up((size_t)groups * 4, 256));
+        nrec_off = place(groups * kNurseryGroup * 32u);
+    }
     if (off > ((uint64_t)0xffffffffu << 8)) return false;   // (offsets are kept in 256-byte units: 1 TiB)
+    d.nursery = nursery ? 1u : 0u;
+    d.nursery_cnt_off = soff_of(ncnt_off); d.nursery_off = soff_of(nrec_off);
     d.alive_off[0] = soff_of(a0); d.alive_off[1] = soff_of(a1); d.dead_off = soff_of(dd);
     for (uint32_t i = 0; i < h.n_attrs; ++i) {
         d.attrs[i].plane_off = soff_of(plane[i]);
@@ -569,6 +589,8 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
     if (h.n_event_channels > HNB_MAX_EVENT_CHANNELS)
         return fail(HNB_ERR_BAD_PROGRAM, "program appends to %u event channels, limit %u", h.n_event_channels, HNB_MAX_EVENT_CHANNELS);
     if (h.parent_n_attrs > HNB_ATTR_COUNT) return fail(HNB_ERR_BAD_PROGRAM, "invalid parent attribute count %u", h.parent_n_attrs);
+    static_assert(HNB_ATTR_COUNT <= 64, "HnbProgramHeader::render_reads_* is a 64-bit mask");
+    if ((((uint64_t)h.render_reads_hi << 32) | h.render_reads_lo) >> HNB_ATTR_COUNT) return fail(HNB_ERR_BAD_PROGRAM, "render_reads mask names attributes that do not exist");
     if ((h.uniform_off & 7) || (h.init_off & 7) || (h.update_off & 7)) return fail(HNB_ERR_BAD_PROGRAM, "code sections must be 8-byte aligned");
     if (h.init_regs > HNB_VM_MAX_REGS_WIDE || h.update_regs > HNB_VM_MAX_REGS_WIDE)
         return fail(HNB_ERR_BAD_PROGRAM, "program needs %u V registers, the VM has %u", std::max(h.init_regs, h.update_regs),
@@ -630,7 +652,7 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
         DevProgram d{};
         SortArgs so{};
         size_t bytes = 0;
-        if (!layout_slab(h, at.data(), d, so, &bytes)) return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 1 TiB (capacity %u)", h.capacity);
+        if (!layout_slab(h, at.data(), d, so, &bytes, /*nursery=*/true)) return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 1 TiB (capacity %u)", h.capacity);
     }
     if (out_hdr) *out_hdr = h;
     return HNB_OK;
@@ -780,6 +802,21 @@ bool age_cohort_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbA
     return true;
 }
 
+// Spawn nursery (hnb_kernels.hip.h): the update must be the streaming kernel and rewrite the POSITION plane (what a record saves is the
+// scattered partial-sector stores of the planes the update streams anyway); a program that emits spawn events is read by its children's
+// init passes in the same init phase (LDPARENT reads the parent's PLANES); a ribbon effect's spawns arrive in slot order, nothing to gain.
+// Only the lean (bandwidth-bound) stacks, as with the age cohorts: the substitution costs the update 11-16 VGPRs, which the force-field kernel
+// (5 waves, 96 VGPRs, VALU-bound) would pay for in scratch.
+bool nursery_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams, const ProgramOptions& opt) {
+    if (!opt.nursery || !streams || h.n_event_channels != 0 || (h.flags & HNB_PROG_HAS_RIBBONS)) return false;
+    const Ins* uc = reinterpret_cast<const Ins*>(b + h.update_off);
+    for (uint32_t i = 0; i < h.update_len; ++i)
+        if (!vm_op_is_lean(uc[i].x & 0xffu)) return false;
+    for (uint32_t a = 0; a < h.n_attrs; ++a)
+        if (attrs[a].reg == HNB_REG_POSITION && (attrs[a].update_flags & HNB_ATTR_UPD_STORE)) return true;
+    return false;
+}
+
 // What to specialise for a program (see hnb_jit.h). `aot_static`: a pre-built ProgStatic kernel matches.
 jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams, bool aot_static, const ProgramOptions& opt) {
     jit::Request rq;
@@ -795,6 +832,8 @@ jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const
     rq.stream_waves = lean ? HNB_STREAM_WAVES : HNB_STREAM_WAVES_FULL;
     rq.stream_cohort = age_cohort_eligible(b, h, attrs, streams, opt);
     if (rq.stream_cohort && rq.stream_waves > HNB_STREAM_WAVES_COHORT) rq.stream_waves = HNB_STREAM_WAVES_COHORT;
+    rq.stream_nursery = nursery_eligible(b, h, attrs, streams, opt);
+    if (rq.stream_nursery && rq.stream_waves > HNB_STREAM_WAVES_NURSERY) rq.stream_waves = HNB_STREAM_WAVES_NURSERY;
     return rq;
 }
 
@@ -870,6 +909,7 @@ jit::Request make_set_request(const Ins* init, uint32_t init_len, const Ins* upd
     rq.want_update_stream = streams;
     rq.want_update_generic = !streams;
     rq.stream_cohort = streams && cohort;
+    rq.stream_nursery = streams;   // (every streaming case carries the spawn-record substitution: whether a member uses it is SlotArgs::nursery)
     rq.wide_file = false;
     return rq;
 }
@@ -953,11 +993,13 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
         case HNB_OPT_ALTERNATE: ctx->alternate = value != 0u; return HNB_OK;
         case HNB_OPT_SKIP_LISTS: ctx->skip_lists = value != 0u; return HNB_OK;
         case HNB_OPT_AGE_COHORT:
-            if (value > HNB_AGE_COHORT_ALL) return fail(HNB_ERR_INVALID_ARG, "unknown age-cohort mode %u", value);
+            if (value > HNB_AGE_COHORT_AUTO) return fail(HNB_ERR_INVALID_ARG, "unknown age-cohort mode %u", value);
             ctx->popt.age_cohort = value;
             return HNB_OK;
         case HNB_OPT_CULL_LIFETIME: ctx->popt.cull_lifetime = value != 0u; return HNB_OK;
         case HNB_OPT_HORIZON: ctx->popt.horizon = value != 0u; return HNB_OK;
+        case HNB_OPT_SPAWN_NURSERY: ctx->popt.nursery = value != 0u; return HNB_OK;
+        case HNB_OPT_TEST_BREAK_PROOF: ctx->break_proof = value != 0u; return HNB_OK;
         case HNB_OPT_TRANSPOSE: ctx->transpose = value != 0u; return HNB_OK;
         case HNB_OPT_SCENE_MERGE: ctx->scene_merge = value != 0u; return HNB_OK;
         case HNB_OPT_SUFFIX_PROOF: ctx->suffix_proof = value != 0u; return HNB_OK;
@@ -998,7 +1040,8 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
 
     DevProgram& d = p->dev;
     size_t slab_bytes = 0;
-    if (!layout_slab(h, p->attrs.data(), d, p->sort, &slab_bytes)) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 1 TiB (capacity %u)", h.capacity); }
+    p->update_streams = update_is_streamable(b, h, p->attrs.data());
+    if (!layout_slab(h, p->attrs.data(), d, p->sort, &slab_bytes, nursery_eligible(b, h, p->attrs.data(), p->update_streams, ctx->popt))) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 1 TiB (capacity %u)", h.capacity); }
     p->slot_order = ctx->list_order == HNB_LIST_ORDER_SLOT && !(h.flags & HNB_PROG_HAS_RIBBONS);  // ribbons are re-sorted anyway
     p->has_ribbons = (h.flags & HNB_PROG_HAS_RIBBONS) != 0;
     p->slab_bytes = slab_bytes;
@@ -1014,12 +1057,12 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     }
     p->uniform_code.resize(h.uniform_len);
     if (h.uniform_len) memcpy(p->uniform_code.data(), b + h.uniform_off, (size_t)h.uniform_len * 8);
-    p->update_streams = update_is_streamable(b, h, p->attrs.data());
     p->wide_file = std::max(h.init_regs, h.update_regs) > HNB_VM_MAX_REGS;
     if (cull_eligible(b, h, p->attrs.data(), p->update_streams, ctx->popt, &p->cull_dt_operand)) {
         d.cull_lifetime = 1u;
         d.age_cohort = age_cohort_eligible(b, h, p->attrs.data(), p->update_streams, ctx->popt) ? 1u : 0u;
     }
+    p->auto_materialise = ctx->popt.age_cohort == HNB_AGE_COHORT_AUTO && d.age_cohort != 0u && (h.render_reads_lo >> HNB_ATTR_AGE & 1u) != 0u;
     if (p->update_streams) select_stream_kernel(reinterpret_cast<const Ins*>(b + h.update_off), h.update_len, &p->stream_launch, &p->stream_kernel_name);
     if (!p->wide_file && jit::enabled()) {
         p->h_init.assign(reinterpret_cast<const Ins*>(b + h.init_off), reinterpret_cast<const Ins*>(b + h.init_off) + h.init_len);
@@ -1495,6 +1538,7 @@ static SlotArgs slot_args_of(const HnbContext* ctx, const HnbProgram* p, uint32_
     sa.transpose = ctx->transpose ? 1u : 0u;
     sa.stream_hint = p->plan.stream_hint ? 1u : 0u;
     sa.store_hint = p->plan.store_hint ? 1u : 0u;
+    sa.nursery = p->dev.nursery; sa.nursery_off = p->dev.nursery_off; sa.nursery_cnt_off = p->dev.nursery_cnt_off;
     for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
         const DevAttr& at = p->dev.attrs[a];
         const int pi = at.reg == HNB_REG_POSITION ? 0 : at.reg == HNB_REG_VELOCITY ? 1 : at.reg == HNB_REG_AGE ? 2 : at.reg == HNB_REG_LIFETIME ? 3 : -1;
@@ -1645,6 +1689,11 @@ static void stage_program_frame(HnbContext* ctx, HnbProgram* p, uint32_t slot, s
     {
         const unsigned long long pub = *reinterpret_cast<volatile unsigned long long*>(p->h_safe);   // {frame, bound} the device published: no read-back
         pl.skip_lists = plan::prove_skip_lists(p->skip_facts, p->skip_hist, p->frames_run, inst_frames.data(), n, plan::SkipPublished{(uint32_t)pub, (uint32_t)(pub >> 32)}, ctx->skip_lists);
+    }
+    if (ctx->break_proof && p->skip_facts.eligible && !pl.skip_lists) {   // the test hook: "nothing can die" claimed without proof in every frame that spawns nothing.
+        bool spawns = false;                                                // The verification paths must notice (fault flag, hnb_effect_check, bench.py's gate): tests only.
+        for (uint32_t i = 0; i < n; ++i) spawns = spawns || (inst_frames[i].simulated && (inst_frames[i].has_parent || inst_frames[i].spawn_count != 0u));
+        pl.skip_lists = !spawns && p->frames_run > 0u;
     }
     if (p->has_ribbons) pl.ribbon = plan::prove_ribbon_order(p->ribbon_facts, p->ribbon_hist, p->dev.capacity, inst_frames.data(), n, ctx->skip_lists, ctx->suffix_proof);
     pl.lists = !(p->update_streams && pl.skip_lists);  // false: proven no spawn, no casualty; the update kernel rotates the counters
@@ -2003,6 +2052,10 @@ static int enqueue_program_update(HnbContext* ctx, HnbProgram* p, hipStream_t st
         if (p->wide_file) k_update_slots_generic<InterpCodeWide><<<total_chunks, kBlock, 0, st>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
         else k_update_slots_generic<InterpCode><<<total_chunks, kBlock, 0, st>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
     }
+    if (p->auto_materialise) {   // HNB_AGE_COHORT_AUTO: the render modifiers read AGE after every frame (counted with the update in timed frames)
+        const int ai = find_attr(p, HNB_ATTR_AGE);
+        k_materialise_age<<<total_chunks, kBlock, 0, st>>>(p->d_inst_base, p->dev.capacity, p->dev.chunks_per_inst, p->dev.lmin_off, p->dev.attrs[ai].plane_off, p->dev.alive_flag_off);
+    }
     if (timed) { hipEventRecord(tu.b, st); ctx->t_update.push_back(tu); }
     const CompactArgs ca = compact_args_of(p);
     const bool lists = p->plan.lists;
@@ -2165,7 +2218,7 @@ int hnb_effect_read_attr(HnbEffect* fx, uint32_t attr, void* dst, size_t dst_siz
     if (dst_size < bytes) return fail(HNB_ERR_INVALID_ARG, "destination too small (%zu < %zu)", dst_size, bytes);
     HIP_TRY(hipSetDevice(p->ctx->device));
     if (p->dev.age_cohort && attr == HNB_ATTR_AGE)   // chunks whose particles share one age keep it in a word: write it out first
-        k_materialise_age<<<p->dev.chunks_per_inst, kBlock, 0, p->ctx->stream>>>(static_cast<char*>(fx->slab), p->dev.capacity, p->dev.chunks_per_inst, p->dev.lmin_off,
+        k_materialise_age<<<p->dev.chunks_per_inst, kBlock, 0, p->ctx->stream>>>(p->d_inst_base + fx->index, p->dev.capacity, p->dev.chunks_per_inst, p->dev.lmin_off,
                                                                                   p->dev.attrs[ai].plane_off, p->dev.alive_flag_off);
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     HIP_TRY(hipMemcpy(dst, static_cast<char*>(fx->slab) + p->dev.attrs[ai].plane_off, bytes, hipMemcpyDeviceToHost));
@@ -2218,7 +2271,7 @@ int hnb_effect_device_view(HnbEffect* fx, HnbDeviceView* out) {
     out->capacity = p->dev.capacity;
     out->slot_base = fx->slot_base;
     out->n_attrs = p->dev.n_attrs;
-    out->stale_attr_mask = p->dev.age_cohort ? (1ull << HNB_ATTR_AGE) : 0ull;
+    out->stale_attr_mask = (p->dev.age_cohort && !p->auto_materialise) ? (1ull << HNB_ATTR_AGE) : 0ull;   // (AUTO: hnb_simulate leaves the plane current)
     out->alive_list[0] = reinterpret_cast<const uint32_t*>(base + p->dev.alive_off[0]);
     out->alive_list[1] = reinterpret_cast<const uint32_t*>(base + p->dev.alive_off[1]);
     out->dead_list = reinterpret_cast<const uint32_t*>(base + p->dev.dead_off);
@@ -2235,6 +2288,32 @@ int hnb_effect_device_view(HnbEffect* fx, HnbDeviceView* out) {
     return HNB_OK;
 }
 
+int hnb_program_device_view(HnbProgram* p, HnbProgramView* out) {
+    if (!p || !out) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    memset(out, 0, sizeof *out);
+    out->struct_size = (uint32_t)sizeof *out;
+    out->device = p->ctx->device;
+    out->stream = p->ctx->stream;
+    out->capacity = p->dev.capacity;
+    out->n_instances = (uint32_t)p->effects.size();
+    out->n_attrs = p->dev.n_attrs;
+    out->stale_attr_mask = (p->dev.age_cohort && !p->auto_materialise) ? (1ull << HNB_ATTR_AGE) : 0ull;
+    out->slabs = p->d_inst_base;
+    out->meta = reinterpret_cast<const HnbDeviceMeta*>(p->d_meta[p->parity]);
+    out->meta_next = reinterpret_cast<const HnbDeviceMeta*>(p->d_meta[p->parity ^ 1u]);
+    out->alive_list_off[0] = (uint64_t)(size_t)p->dev.alive_off[0]; out->alive_list_off[1] = (uint64_t)(size_t)p->dev.alive_off[1];
+    out->dead_list_off = (uint64_t)(size_t)p->dev.dead_off;
+    for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
+        HnbProgramAttr& v = out->attrs[a];
+        v.attr = p->attrs[a].attr;
+        v.ncomp = p->attrs[a].ncomp;
+        v.scalar_type = p->attrs[a].scalar_type;
+        v.stride_bytes = (uint16_t)(p->attrs[a].ncomp * 4u);
+        v.plane_off = (uint64_t)(size_t)p->dev.attrs[a].plane_off;
+    }
+    return HNB_OK;
+}
+
 int hnb_effect_materialise(HnbEffect* fx, uint64_t attr_mask) {
     if (!fx) return fail(HNB_ERR_INVALID_ARG, "fx is NULL");
     HnbProgram* p = fx->prog;
@@ -2244,7 +2323,7 @@ int hnb_effect_materialise(HnbEffect* fx, uint64_t attr_mask) {
     if (p->dev.age_cohort && (attr_mask >> HNB_ATTR_AGE & 1ull)) {   // the one plane the update may leave stale: chunks whose particles share one age keep it in a word
         HIP_TRY(hipSetDevice(p->ctx->device));
         const int ai = find_attr(p, HNB_ATTR_AGE);
-        k_materialise_age<<<p->dev.chunks_per_inst, kBlock, 0, p->ctx->stream>>>(static_cast<char*>(fx->slab), p->dev.capacity, p->dev.chunks_per_inst, p->dev.lmin_off,
+        k_materialise_age<<<p->dev.chunks_per_inst, kBlock, 0, p->ctx->stream>>>(p->d_inst_base + fx->index, p->dev.capacity, p->dev.chunks_per_inst, p->dev.lmin_off,
                                                                                   p->dev.attrs[ai].plane_off, p->dev.alive_flag_off);
         HIP_TRY(hipGetLastError());
     }
@@ -2276,6 +2355,116 @@ int hnb_effect_read_dead_list(HnbEffect* fx, uint32_t* dst, size_t dst_count) {
     return HNB_OK;
 }
 
+// ---- verification on the device: invariants of one effect, bitwise comparison of two (include/hanabi_amd.h "Verification") ----------------
+// For state too large to read back and compare on the host in the time a benchmark may take (16.7M particles: 0.7 GB per effect): bench.py's
+// gate on the state its TIMED frames produced, and anything else that wants to know "is this effect consistent" without moving it.
+namespace {
+__global__ void __launch_bounds__(256)
+k_check_rows(const uint32_t* __restrict__ alive, const uint32_t* __restrict__ dead, uint32_t alive_count, uint32_t capacity,
+             const uint8_t* __restrict__ flags, const float* __restrict__ age, const float* __restrict__ life, uint32_t* __restrict__ seen, uint32_t* __restrict__ rep) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= capacity) return;
+    const bool is_alive = r < alive_count;
+    const uint32_t slot = is_alive ? alive[r] : dead[r];   // rows [0, alive_count) of the list column, rows [alive_count, capacity) of the dead stack
+    if (slot >= capacity) { atomicAdd(rep + 0, 1u); return; }
+    const uint32_t bit = 1u << (slot & 31u);
+    if (atomicOr(seen + (slot >> 5), bit) & bit) atomicAdd(rep + 1, 1u);          // listed twice
+    if ((flags[slot] == 1u) != is_alive) atomicAdd(rep + 2, 1u);                 // the byte that drives the slot-major update disagrees with the lists
+    if (is_alive && age && life && !(age[slot] < life[slot])) atomicAdd(rep + 3, 1u);   // the reaping rule of src/lib.rs:1223-1258 left it alive
+}
+__global__ void __launch_bounds__(256)
+k_compare_words(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint64_t n, unsigned long long* __restrict__ out) {   // out: {differing words, first index}
+    unsigned long long diffs = 0, first = ~0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u)
+        if (a[i] != b[i]) { diffs += 1; first = first < i ? first : i; }
+    if (diffs) { atomicAdd(out, diffs); atomicMin(out + 1, first); }
+}
+}  // namespace
+
+int hnb_effect_check(HnbEffect* fx, HnbEffectCheck* out) {
+    if (!fx || !out) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    HnbProgram* p = fx->prog;
+    memset(out, 0, sizeof *out);
+    int rc = hnb_effect_materialise(fx, p->dev.age_cohort ? (1ull << HNB_ATTR_AGE) : 0ull);
+    if (rc != HNB_OK) return rc;
+    DevMeta m;
+    rc = read_meta(fx, &m);
+    if (rc != HNB_OK) return rc;
+    const uint32_t cap = p->dev.capacity;
+    char* base = static_cast<char*>(fx->slab);
+    uint32_t* scratch = nullptr;
+    const size_t seen_words = ((size_t)cap + 31u) / 32u;
+    HIP_TRY(hipMalloc(&scratch, (seen_words + 4u) * 4u));
+    hipStream_t st = p->ctx->stream;
+    hipMemsetAsync(scratch, 0, (seen_words + 4u) * 4u, st);
+    const int ia = find_attr(p, HNB_ATTR_AGE), il = find_attr(p, HNB_ATTR_LIFETIME);
+    const bool reaps = ia >= 0 && il >= 0 && p->dev.cull_lifetime;   // (the update program starts with the AGE_TICK that tests the lifetime)
+    k_check_rows<<<(uint32_t)(((uint64_t)cap + 255u) / 256u), 256, 0, st>>>(
+        reinterpret_cast<const uint32_t*>(base + p->dev.alive_off[m.write_index & 1u]), reinterpret_cast<const uint32_t*>(base + p->dev.dead_off), m.alive_count, cap,
+        reinterpret_cast<const uint8_t*>(base + p->dev.alive_flag_off), reaps ? reinterpret_cast<const float*>(base + p->dev.attrs[ia].plane_off) : nullptr,
+        reaps ? reinterpret_cast<const float*>(base + p->dev.attrs[il].plane_off) : nullptr, scratch + 4, scratch);
+    uint32_t rep[4] = {};
+    hipError_t e = hipMemcpyAsync(rep, scratch, sizeof rep, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(scratch);
+    if (e != hipSuccess) return fail(HNB_ERR_HIP, "hnb_effect_check: %s", hipGetErrorString(e));
+    out->capacity = cap; out->alive_count = m.alive_count;
+    out->bad_slots = rep[0]; out->duplicate_slots = rep[1]; out->alive_byte_mismatches = rep[2]; out->alive_past_lifetime = rep[3];
+    if (p->d_fault) HIP_TRY(hipMemcpy(&out->fault, p->d_fault, 4, hipMemcpyDeviceToHost));
+    // (capacity rows, every slot in range, none twice: alive rows and dead rows together are a permutation of the slots)
+    out->ok = (rep[0] | rep[1] | rep[2] | rep[3] | out->fault) == 0u && m.alive_count <= cap;
+    return HNB_OK;
+}
+
+int hnb_effect_compare(HnbEffect* a, HnbEffect* b, HnbEffectDiff* out) {
+    if (!a || !b || !out) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    HnbProgram *pa = a->prog, *pb = b->prog;
+    memset(out, 0, sizeof *out);
+    out->first_section = -1;
+    if (pa->ctx->device != pb->ctx->device) return fail(HNB_ERR_INVALID_ARG, "the two effects live on different devices");
+    if (pa->dev.capacity != pb->dev.capacity || pa->attrs.size() != pb->attrs.size()) return fail(HNB_ERR_INVALID_ARG, "the two effects have different layouts");
+    for (size_t i = 0; i < pa->attrs.size(); ++i)
+        if (pa->attrs[i].attr != pb->attrs[i].attr || pa->attrs[i].ncomp != pb->attrs[i].ncomp) return fail(HNB_ERR_INVALID_ARG, "the two effects have different layouts");
+    int rc = hnb_effect_materialise(a, pa->dev.age_cohort ? (1ull << HNB_ATTR_AGE) : 0ull);
+    if (rc == HNB_OK) rc = hnb_effect_materialise(b, pb->dev.age_cohort ? (1ull << HNB_ATTR_AGE) : 0ull);
+    DevMeta ma, mb;
+    if (rc == HNB_OK) rc = read_meta(a, &ma);   // (synchronises the effect's stream: what follows on the default stream sees both effects complete)
+    if (rc == HNB_OK) rc = read_meta(b, &mb);
+    if (rc != HNB_OK) return rc;
+    const uint32_t wa[8] = {ma.alive_count, ma.particle_counter, ma.write_index & 1u, ma.max_update, ma.dead_count, ma.spawned, ma.ref_write_index & 1u, ma.instance_count};
+    const uint32_t wb[8] = {mb.alive_count, mb.particle_counter, mb.write_index & 1u, mb.max_update, mb.dead_count, mb.spawned, mb.ref_write_index & 1u, mb.instance_count};
+    for (int i = 0; i < 8; ++i) out->counter_diffs += wa[i] != wb[i] ? 1u : 0u;
+    const uint32_t cap = pa->dev.capacity;
+    const char *sa = static_cast<const char*>(a->slab), *sb = static_cast<const char*>(b->slab);
+    const size_t n_sections = 2 + pa->attrs.size();
+    unsigned long long* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, n_sections * 16));
+    std::vector<unsigned long long> init(n_sections * 2);
+    for (size_t i = 0; i < n_sections; ++i) { init[2 * i] = 0ull; init[2 * i + 1] = ~0ull; }
+    hipMemcpy(d_out, init.data(), n_sections * 16, hipMemcpyHostToDevice);
+    auto cmp = [&](size_t section, const void* x, const void* y, uint64_t words) {
+        if (!words) return;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((words + 255u) / 256u, 16384u);
+        k_compare_words<<<grid, 256, 0, nullptr>>>(static_cast<const uint32_t*>(x), static_cast<const uint32_t*>(y), words, d_out + 2 * section);
+    };
+    if (ma.alive_count == mb.alive_count) {   // (else the counters already differ and the rows do not correspond)
+        cmp(0, sa + pa->dev.alive_off[ma.write_index & 1u], sb + pb->dev.alive_off[mb.write_index & 1u], ma.alive_count);
+        cmp(1, sa + pa->dev.dead_off + (size_t)ma.alive_count * 4, sb + pb->dev.dead_off + (size_t)mb.alive_count * 4, cap - ma.alive_count);
+    }
+    for (size_t i = 0; i < pa->attrs.size(); ++i) cmp(2 + i, sa + pa->dev.attrs[i].plane_off, sb + pb->dev.attrs[i].plane_off, (uint64_t)cap * pa->attrs[i].ncomp);
+    std::vector<unsigned long long> res(n_sections * 2);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(res.data(), d_out, n_sections * 16, hipMemcpyDeviceToHost);
+    hipFree(d_out);
+    if (e != hipSuccess) return fail(HNB_ERR_HIP, "hnb_effect_compare: %s", hipGetErrorString(e));
+    out->alive_list_diffs = res[0]; out->dead_list_diffs = res[2];
+    for (size_t i = 0; i < pa->attrs.size(); ++i) out->attr_diffs += res[2 * (2 + i)];
+    for (size_t i = 0; i < n_sections && out->first_section < 0; ++i)
+        if (res[2 * i]) { out->first_section = i < 2 ? (int32_t)i : (int32_t)(2 + pa->attrs[i - 2].attr); out->first_index = res[2 * i + 1]; }
+    out->equal = out->counter_diffs == 0u && out->alive_list_diffs == 0ull && out->dead_list_diffs == 0ull && out->attr_diffs == 0ull;
+    return HNB_OK;
+}
+
 int hnb_effect_sort_ribbons(HnbEffect* fx) {
     if (!fx) return fail(HNB_ERR_INVALID_ARG, "fx is NULL");
     if (!fx->prog->has_ribbons) return fail(HNB_ERR_INVALID_ARG, "the particle layout has no RIBBON_ID attribute: nothing to sort");
@@ -2298,6 +2487,25 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
             for (uint32_t v : st) in_cohort += v == 1u ? 1u : 0u;
         }
         s += "\nage cohorts: " + std::to_string(in_cohort) + " of " + std::to_string(prog->effects.size() * (size_t)prog->dev.chunks_per_inst) + " chunks";
+        if (prog->auto_materialise) s += " (render modifiers read AGE: the plane is made current after every frame, HNB_AGE_COHORT_AUTO)";
+    }
+    if (prog->dev.nursery) {   // (debug statistics, as above: records that wait between frames - none, ever - and the buckets that have held one since the slab was zeroed)
+        hipStreamSynchronize(prog->ctx->stream);
+        const size_t groups = (size_t)prog->dev.chunks_per_inst * (kChunk / kNurseryGroup);
+        std::vector<uint32_t> cnt(groups), first(groups * 8);
+        size_t waiting = 0, used = 0;
+        for (const HnbEffect* fx : prog->effects) {
+            const char* slab = static_cast<const char*>(fx->slab);
+            if (hipMemcpy(cnt.data(), slab + prog->dev.nursery_cnt_off, groups * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+            if (hipMemcpy2D(first.data(), 32, slab + prog->dev.nursery_off, (size_t)kNurseryGroup * 32, 32, groups, hipMemcpyDeviceToHost) != hipSuccess) break;
+            for (size_t g = 0; g < groups; ++g) {
+                waiting += cnt[g];
+                bool any = false;
+                for (int w = 0; w < 8; ++w) any = any || first[g * 8 + w] != 0u;
+                used += any ? 1u : 0u;
+            }
+        }
+        s += "\nspawn nursery: " + std::to_string(used) + " of " + std::to_string(groups * prog->effects.size()) + " buckets used, " + std::to_string(waiting) + " records waiting";
     }
     if (prog->has_ribbons && prog->suffix_frames) s += "\ncasualties proven to be the list's last rows (no k_count_rows): " + std::to_string(prog->suffix_frames) + " frames";
     if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->ribbon_facts.front_static ? "" : " (not eligible)");
@@ -2379,12 +2587,13 @@ int hnb_comm_unique_id(void* out_id) {
 }
 
 int hnb_comm_set_library(const char* path, uint32_t flags) {
-    if (flags & ~(uint32_t)HNB_COMM_LIB_DUPLICATE_DEVICES) return fail(HNB_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+    if (flags & ~(uint32_t)(HNB_COMM_LIB_DUPLICATE_DEVICES | HNB_COMM_LIB_SINGLE_RANK)) return fail(HNB_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
     comm::LibraryChoice& ch = comm::library_choice();
     std::lock_guard<std::mutex> g(ch.mu);
     if (ch.loaded) return fail(HNB_ERR_INVALID_ARG, "the collective library is already loaded: hnb_comm_set_library must precede the first hnb_comm_* call of the process");
     ch.path = path ? path : "";
     ch.duplicate_devices = (flags & HNB_COMM_LIB_DUPLICATE_DEVICES) != 0u;
+    ch.single_rank = (flags & HNB_COMM_LIB_SINGLE_RANK) != 0u;
     return HNB_OK;
 }
 
@@ -2403,9 +2612,11 @@ int hnb_comm_create_local(HnbContext* const* ctxs, uint32_t n_ctx, HnbComm** out
     c->n_ranks = n_ctx;
     // one communicator per device. RCCL refuses a device twice: contexts sharing one are reduced through the host - unless the library
     // chosen with hnb_comm_set_library says it takes duplicates (the stand-in of tests/fake_rccl, which lets the collective branch run on a one-GPU box)
-    bool duplicates_ok = false;   // (asked of the CHOICE, not of the library: a one-GPU host whose contexts share a device never loads librccl)
-    { comm::LibraryChoice& ch = comm::library_choice(); std::lock_guard<std::mutex> g(ch.mu); duplicates_ok = ch.duplicate_devices; }
-    if (n_ctx > 1 && (distinct || duplicates_ok)) {
+    bool duplicates_ok = false, single_rank = false;   // (asked of the CHOICE, not of the library: a one-GPU host whose contexts share a device never loads librccl)
+    { comm::LibraryChoice& ch = comm::library_choice(); std::lock_guard<std::mutex> g(ch.mu); duplicates_ok = ch.duplicate_devices; single_rank = ch.single_rank; }
+    // (HNB_COMM_LIB_SINGLE_RANK: a communicator of ONE context goes through the library as well - ncclCommInitAll over one device, a one-rank
+    // all-reduce on the context's stream: every call of the collective branch executes for real on a one-GPU machine)
+    if ((n_ctx > 1 && (distinct || duplicates_ok)) || (n_ctx == 1 && single_rank)) {
         comm::Api& a = comm::api();
         if (!a.ok) { delete c; return fail(HNB_ERR_NOT_FOUND, "RCCL is not available: %s", a.why.c_str()); }
         c->comms.resize(n_ctx);
@@ -2422,7 +2633,9 @@ int hnb_comm_create_rank(HnbContext* ctx, const void* id, uint32_t rank, uint32_
     std::unique_ptr<HnbComm> c(new HnbComm());   // (released on every error path)
     c->ctxs.push_back(ctx);
     c->n_ranks = n_ranks; c->rank = rank;
-    if (n_ranks > 1) {
+    bool single_rank = false;
+    { comm::LibraryChoice& ch = comm::library_choice(); std::lock_guard<std::mutex> g(ch.mu); single_rank = ch.single_rank; }
+    if (n_ranks > 1 || single_rank) {
         comm::Api& a = comm::api();
         if (!a.ok) return fail(HNB_ERR_NOT_FOUND, "RCCL is not available: %s", a.why.c_str());
         HIP_TRY(hipSetDevice(ctx->device));
@@ -2434,6 +2647,18 @@ int hnb_comm_create_rank(HnbContext* ctx, const void* id, uint32_t rank, uint32_
     }
     ctx->comm_refs += 1;
     *out_comm = c.release();
+    return HNB_OK;
+}
+
+// What a communicator reduces through, as text: "rccl <file the symbols were resolved from> ranks=<n> local=<contexts>" or
+// "host-sum ranks=.. local=.." (contexts that share a device, or a single context without HNB_COMM_LIB_SINGLE_RANK).
+int hnb_comm_describe(HnbComm* c, char* buf, size_t buf_size) {
+    if (!c || !buf || !buf_size) return fail(HNB_ERR_INVALID_ARG, "NULL argument");
+    std::string s;
+    if (!c->comms.empty()) s = "rccl " + (comm::api().resolved.empty() ? std::string("?") : comm::api().resolved);
+    else s = "host-sum";
+    s += " ranks=" + std::to_string(c->n_ranks) + " local=" + std::to_string(c->ctxs.size());
+    snprintf(buf, buf_size, "%s", s.c_str());
     return HNB_OK;
 }
 

@@ -32,10 +32,11 @@ struct Api {
     bool ok = false;
     bool allows_duplicate_devices = false;   // hnb_comm_set_library(.., HNB_COMM_LIB_DUPLICATE_DEVICES): a stand-in library that accepts one device twice
     std::string why;
+    std::string resolved;                    // the file the symbols came from (dladdr of ncclAllReduce): what hnb_comm_describe reports
 };
 
 // hnb_comm_set_library: an explicit library path (and what the library tolerates), honoured by the FIRST use of the API only
-struct LibraryChoice { std::mutex mu; std::string path; bool duplicate_devices = false; bool loaded = false; };
+struct LibraryChoice { std::mutex mu; std::string path; bool duplicate_devices = false; bool single_rank = false; bool loaded = false; };
 inline LibraryChoice& library_choice() { static LibraryChoice c; return c; }
 
 inline Api load_api() {
@@ -69,6 +70,10 @@ inline Api load_api() {
     HNB_SYM(GroupEnd, "ncclGroupEnd")
     HNB_SYM(GetErrorString, "ncclGetErrorString")
 #undef HNB_SYM
+    {
+        Dl_info info;
+        if (dladdr(reinterpret_cast<const void*>(a.AllReduce), &info) && info.dli_fname) a.resolved = info.dli_fname;
+    }
     a.ok = true;
     return a;
 }

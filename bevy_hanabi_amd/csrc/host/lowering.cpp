@@ -1167,6 +1167,12 @@ std::vector<uint8_t> Lowerer::run() {
     h.flags = (asset_.simulation_space == SimulationSpace::Global ? HNB_PROG_GLOBAL_SPACE : 0u) | (has_ribbon ? HNB_PROG_HAS_RIBBONS : 0u) |
               (parent_attrs_.empty() ? 0u : HNB_PROG_READS_PARENT) | (n_event_channels_ ? HNB_PROG_EMITS_EVENTS : 0u);
     h.n_event_channels = n_event_channels_;
+    {   // what the render modifiers read every frame (their declared attribute requirements: src/modifier/output.rs impl_mod_render!)
+        uint64_t mask = 0;
+        for (const Modifier& m : asset_.render_modifiers())
+            for (const Attribute& a : m.attributes()) if (a.id < 64u) mask |= 1ull << a.id;
+        h.render_reads_lo = (uint32_t)mask; h.render_reads_hi = (uint32_t)(mask >> 32);
+    }
     h.parent_n_attrs = (uint32_t)parent_attrs_.size();
     h.n_attrs = (uint32_t)attrs_.size();
     h.n_props = (uint32_t)mod_.properties().size();

@@ -27,12 +27,12 @@ ABI_SYMBOLS = [
     "hnb_ctx_kernel_timing", "hnb_program_kernel_info", "hnb_jit_precompile", "hnb_effect_set_simulated", "hnb_ctx_set_option", "hnb_program_set_frames", "hnb_effect_index",
     "hnb_ctx_profile_marker", "hnb_program_kernel_timing",
     "hnb_comm_create_local", "hnb_comm_unique_id", "hnb_comm_create_rank", "hnb_comm_allreduce_alive", "hnb_comm_destroy", "hnb_comm_set_library",
-    "hnb_effect_device_view", "hnb_effect_materialise", "hnb_jit_precompile_set",
+    "hnb_effect_device_view", "hnb_effect_materialise", "hnb_jit_precompile_set", "hnb_effect_check", "hnb_effect_compare", "hnb_comm_describe", "hnb_program_device_view",
 ]
 
 # hnb_ctx_set_option (include/hanabi_amd.h): name -> option id
 OPTIONS = {"list_order": 1, "alternate": 2, "skip_lists": 3, "age_cohort": 4, "cull_lifetime": 5, "horizon": 6, "transpose": 7, "scene_merge": 8,
-           "suffix_proof": 9, "overlap_updates": 10, "stream_hints": 11, "set_module": 12, "jit_async": 13}
+           "suffix_proof": 9, "overlap_updates": 10, "stream_hints": 11, "set_module": 12, "jit_async": 13, "spawn_nursery": 14, "test_break_proof": 15}
 SET_MODULE_OFF, SET_MODULE_CACHED, SET_MODULE_COMPILE, SET_MODULE_BACKGROUND = 0, 1, 2, 3
 
 
@@ -61,6 +61,23 @@ class DeviceMeta(C.Structure):
                                           "indirect_write_index", "instance_count")]
 
 
+class EffectCheck(C.Structure):
+    """HnbEffectCheck (hnb_effect_check): the list / alive-byte / lifetime invariants of one effect, evaluated on the device."""
+    _fields_ = [(n, C.c_uint32) for n in ("ok", "capacity", "alive_count", "bad_slots", "duplicate_slots", "alive_byte_mismatches", "alive_past_lifetime", "fault")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class EffectDiff(C.Structure):
+    """HnbEffectDiff (hnb_effect_compare): two effects of one layout compared bit for bit on the device."""
+    _fields_ = [("equal", C.c_uint32), ("counter_diffs", C.c_uint32), ("alive_list_diffs", C.c_uint64), ("dead_list_diffs", C.c_uint64), ("attr_diffs", C.c_uint64),
+                ("first_section", C.c_int32), ("reserved", C.c_uint32), ("first_index", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+
 class DeviceAttr(C.Structure):
     _fields_ = [("attr", C.c_uint16), ("ncomp", C.c_uint8), ("scalar_type", C.c_uint8), ("stride_bytes", C.c_uint16), ("reserved", C.c_uint16),
                 ("plane", C.c_void_p)]
@@ -78,6 +95,19 @@ class DeviceView(C.Structure):
             if self.attrs[i].attr == int(attr_id):
                 return self.attrs[i]
         raise KeyError(attr_id)
+
+
+class ProgramAttr(C.Structure):
+    _fields_ = [("attr", C.c_uint16), ("ncomp", C.c_uint8), ("scalar_type", C.c_uint8), ("stride_bytes", C.c_uint16), ("reserved", C.c_uint16),
+                ("plane_off", C.c_uint64)]
+
+
+class ProgramView(C.Structure):
+    """HnbProgramView: every instance of a program behind one device-resident table (hnb_program_device_view)."""
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("stream", C.c_void_p),
+                ("capacity", C.c_uint32), ("n_instances", C.c_uint32), ("n_attrs", C.c_uint32), ("reserved", C.c_uint32),
+                ("stale_attr_mask", C.c_uint64), ("slabs", C.c_void_p), ("meta", C.c_void_p), ("meta_next", C.c_void_p),
+                ("alive_list_off", C.c_uint64 * 2), ("dead_list_off", C.c_uint64), ("attrs", ProgramAttr * 40)]
 
 
 _lib = None
@@ -128,6 +158,10 @@ def load_library():
         lib.hnb_comm_allreduce_alive.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint64)]
         lib.hnb_comm_destroy.argtypes = [C.c_void_p]
         lib.hnb_comm_set_library.argtypes = [C.c_char_p, C.c_uint32]
+        lib.hnb_program_device_view.argtypes = [C.c_void_p, C.POINTER(ProgramView)]
+        lib.hnb_comm_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        lib.hnb_effect_check.argtypes = [C.c_void_p, C.POINTER(EffectCheck)]
+        lib.hnb_effect_compare.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(EffectDiff)]
         lib.hnb_effect_device_view.argtypes = [C.c_void_p, C.POINTER(DeviceView)]
         lib.hnb_effect_materialise.argtypes = [C.c_void_p, C.c_uint64]
         lib.hnb_program_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
@@ -231,9 +265,10 @@ class Context:
         return {"update_ms_avg": u.value, "compact_ms_avg": c.value, "init_ms_avg": i.value, "frames": n.value}
 
 
-def comm_set_library(path, duplicate_devices=False):
-    """hnb_comm_set_library: which collective library hnb_comm_* binds; before the first Comm of the process."""
-    _check(load_library().hnb_comm_set_library(None if path is None else os.fsencode(path), 1 if duplicate_devices else 0))
+def comm_set_library(path, duplicate_devices=False, single_rank=False):
+    """hnb_comm_set_library: which collective library hnb_comm_* binds; before the first Comm of the process.
+    single_rank: a communicator of one context / one rank goes through the library too (HNB_COMM_LIB_SINGLE_RANK)."""
+    _check(load_library().hnb_comm_set_library(None if path is None else os.fsencode(path), (1 if duplicate_devices else 0) | (2 if single_rank else 0)))
 
 
 class Comm:
@@ -276,6 +311,12 @@ class Comm:
         _check(self._lib.hnb_comm_allreduce_alive(self._h, arr, n, out))
         return [int(v) for v in out]
 
+    def describe(self):
+        """hnb_comm_describe: 'rccl <resolved library path> ranks=N local=M' or 'host-sum ranks=N local=M'."""
+        buf = C.create_string_buffer(1024)
+        _check(self._lib.hnb_comm_describe(self._h, buf, len(buf)))
+        return buf.value.decode()
+
     def destroy(self):
         if self._h:
             self._lib.hnb_comm_destroy(self._h)
@@ -307,6 +348,12 @@ class Program:
         u, c, i, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint32()
         _check(self._lib.hnb_program_kernel_timing(self._h, C.byref(u), C.byref(c), C.byref(i), C.byref(n)))
         return {"update_ms_avg": u.value, "compact_ms_avg": c.value, "init_ms_avg": i.value, "frames": n.value}
+
+    def device_view(self):
+        """hnb_program_device_view: all instances behind one device-resident table (no synchronisation)."""
+        v = ProgramView()
+        _check(self._lib.hnb_program_device_view(self._h, C.byref(v)))
+        return v
 
     def kernel_info(self):
         """Which kernels run this program: 'init=jit|interp|none update=aot-stream:<name>|jit-stream|jit-generic|interp-*'."""
@@ -389,6 +436,18 @@ class Effect:
         for a in attr_ids:
             mask |= 1 << int(a)
         _check(self._lib.hnb_effect_materialise(self._h, mask))
+
+    def check(self):
+        """hnb_effect_check: list permutation, alive bytes, age < lifetime, fault flag - on the device; a dict with "ok"."""
+        c = EffectCheck()
+        _check(self._lib.hnb_effect_check(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def compare(self, other):
+        """hnb_effect_compare: this effect against another of the same layout on the same device, bit for bit; a dict with "equal"."""
+        d = EffectDiff()
+        _check(self._lib.hnb_effect_compare(self._h, other._h, C.byref(d)))
+        return d.as_dict()
 
     def metadata(self):
         m = EffectMetadata()

@@ -217,7 +217,11 @@ typedef struct HnbProgramHeader {
     uint32_t n_event_channels;  /* number of child event channels this program appends to */
     uint32_t parent_n_attrs;    /* HNB_PROG_READS_PARENT: u32 HnbAttr ids read from the parent particle, at parent_attrs_off */
     uint32_t parent_attrs_off;
-    uint32_t reserved[2];
+    /* Attributes the asset's RENDER modifiers read every frame, as a bit mask over HnbAttr ids (bit a of lo | hi << 32): what the reference
+     * declares with impl_mod_render!(ColorOverLifetimeModifier, &[Attribute::AGE, Attribute::LIFETIME]) (src/modifier/output.rs:310-312,
+     * 423-425, 602-611). The simulation does not execute render modifiers; the mask tells it which planes a renderer behind
+     * hnb_effect_device_view reads after every frame (HNB_AGE_COHORT_AUTO: keep AGE current). 0 in blobs written before the field existed. */
+    uint32_t render_reads_lo, render_reads_hi;
 } HnbProgramHeader;
 
 /* ---------------------------------------------------------------------------------- */
@@ -293,6 +297,10 @@ int hnb_ctx_synchronize(HnbContext* ctx);
 #define HNB_AGE_COHORT_OFF 0u
 #define HNB_AGE_COHORT_LEAN 1u
 #define HNB_AGE_COHORT_ALL 2u
+#define HNB_AGE_COHORT_AUTO 3u   /* LEAN, and a program whose render modifiers read AGE (HnbProgramHeader::render_reads_*) has its AGE plane made current
+                                  * at the end of every hnb_simulate (one more pass over the chunks that keep their ages in a word): nothing is stale
+                                  * for a renderer behind hnb_effect_device_view (stale_attr_mask = 0). THE DEFAULT. A headless host that never looks at
+                                  * AGE between frames asks for LEAN. */
 #define HNB_OPT_CULL_LIFETIME 5u
 #define HNB_OPT_HORIZON 6u
 #define HNB_OPT_TRANSPOSE 7u
@@ -312,6 +320,17 @@ int hnb_ctx_synchronize(HnbContext* ctx);
  *   and an effect whose pipelines are not ready is SKIPPED, src/render/mod.rs:3852-3900; here it is simulated from its first frame.) hnb_ctx_destroy waits
  *   for a compilation in flight. */
 #define HNB_OPT_JIT_ASYNC 13u
+/* HNB_OPT_SPAWN_NURSERY (fixed in a program when it is created; default 1): spawns into SCATTERED free slots (the dead list of an effect in a
+ *   spawn / die steady state hands its slots out in death order) do not store the planes the update rewrites: the init pass writes one 32-byte
+ *   record {slot, position, velocity, age} per spawn and the update of the same frame - which streams every line of those planes anyway -
+ *   substitutes it before its first tick (the reference runs init then update in the same frame: src/render/mod.rs:7157-7173, 7358-7366).
+ *   Spawns into consecutive slots (a fresh effect) are stored directly, as with 0. Same state after every frame either way. Eligible programs:
+ *   streamable update that stores POSITION, no spawn events out, no ribbons; costs 32 bytes per slot of slab. */
+#define HNB_OPT_SPAWN_NURSERY 14u
+/* HNB_OPT_TEST_BREAK_PROOF (default 0): a TEST HOOK, never for production. 1 = every frame that spawns nothing is treated as proven to have no
+ *   casualty (HNB_OPT_SKIP_LISTS's proof, claimed without evidence). A particle that dies in such a frame raises HnbEffectMetadata::fault and
+ *   leaves the lists stale: what hnb_effect_check, hnb_effect_compare and bench.py's parity gate exist to notice, and are tested with. */
+#define HNB_OPT_TEST_BREAK_PROOF 15u
 /* HNB_OPT_SET_MODULE (default HNB_SET_MODULE_CACHED; from the next hnb_simulate on): the launches the small programs of a context share
  *   (HNB_OPT_SCENE_MERGE) run the byte-code INTERPRETERS - the only code that fits every program - unless the context has a SET MODULE: one
  *   hiprtc module whose two kernels switch, per job, into the SPECIALISED code of each program (the counterpart of the reference compiling one
@@ -390,9 +409,11 @@ int hnb_simulate(HnbContext* ctx);
  * have completed (or the next hnb_simulate be ordered behind them, which it is on v.stream) before the planes are written again.
  * Lifetime of the pointers: planes and lists live as long as the effect; `meta` / `meta_next` ALTERNATE from frame to frame and move when an
  * effect of the program is created or destroyed - fetch the view again after each hnb_simulate (a few stores, no HIP call).
- * Attributes in stale_attr_mask (AGE under HNB_OPT_AGE_COHORT) are current only after hnb_effect_materialise(fx, mask), which is enqueued on
- * the simulation stream like a frame; programs created with HNB_AGE_COHORT_OFF have no stale attribute (ColorOverLifetime / SizeOverLifetime
- * read AGE and LIFETIME in the render shader, src/modifier/output.rs:310-312). Free slots hold the values their last particle died with. */
+ * Attributes in stale_attr_mask are current only after hnb_effect_materialise(fx, mask), which is enqueued on the simulation stream like a
+ * frame. With the default HNB_AGE_COHORT_AUTO the mask is empty for every asset whose render modifiers read AGE (ColorOverLifetime /
+ * SizeOverLifetime, src/modifier/output.rs:310-312: HnbProgramHeader::render_reads_*) - hnb_simulate leaves that plane current - and for
+ * programs created with HNB_AGE_COHORT_OFF; AGE is stale under LEAN / ALL, and under AUTO for assets whose renderer does not read it.
+ * Free slots hold the values their last particle died with. */
 typedef struct HnbDeviceMeta {          /* one 32-byte row per effect instance, device-resident; written by the frame's last kernel */
     uint32_t alive_count;               /* EffectMetadata::alive_count after the frame */
     uint32_t particle_counter;
@@ -423,6 +444,32 @@ typedef struct HnbDeviceView {
     HnbDeviceAttr attrs[HNB_VIEW_MAX_ATTRS];   /* [n_attrs], layout order */
 } HnbDeviceView;
 int hnb_effect_device_view(HnbEffect* fx, HnbDeviceView* out_view);
+/* The same for ALL instances of a program in one call: the shape the reference binds per BATCH - one particle buffer, one indirect buffer and
+ * the per-instance slices / metadata rows (src/render/batch.rs:348-386, vfx_prefix_sum.wgsl:13-43). Instance k (hnb_effect_index) lives in the
+ * slab at slabs[k]; its lists and planes are at the byte offsets below from that base; its metadata row is meta[k]. Same stream-ordering
+ * contract and pointer lifetimes as HnbDeviceView: `slabs`, `meta`, `meta_next` are device arrays that move when an instance is created or
+ * destroyed and meta / meta_next alternate every frame - fetch the view after each hnb_simulate. A consumer kernel over the whole batch:
+ *     k = blockIdx.y; base = (const char*)v.slabs[k]; m = v.meta[k]; list = (const uint32_t*)(base + v.alive_list_off[m.list_column & 1]);
+ *     row r < m.alive_count: slot = list[r]; position = (const float*)(base + v.attrs[i].plane_off) + 3 * slot */
+typedef struct HnbProgramAttr {
+    uint16_t attr;                      /* HnbAttr */
+    uint8_t ncomp, scalar_type;
+    uint16_t stride_bytes, reserved;
+    uint64_t plane_off;                 /* bytes from an instance's slab base */
+} HnbProgramAttr;
+typedef struct HnbProgramView {
+    uint32_t struct_size;
+    int32_t device;
+    void* stream;
+    uint32_t capacity, n_instances, n_attrs, reserved;
+    uint64_t stale_attr_mask;
+    const uint64_t* slabs;              /* device: [n_instances] slab base addresses */
+    const HnbDeviceMeta* meta;          /* device: [n_instances] rows after the frames enqueued so far */
+    const HnbDeviceMeta* meta_next;     /* ... the rows the next hnb_simulate will write */
+    uint64_t alive_list_off[2], dead_list_off;
+    HnbProgramAttr attrs[HNB_VIEW_MAX_ATTRS];
+} HnbProgramView;
+int hnb_program_device_view(HnbProgram* prog, HnbProgramView* out_view);
 /* Makes the planes of the attributes in `attr_mask` (bit a = HnbAttr a) current for device-side readers; enqueued on the simulation stream,
  * returns at once. A no-op for attributes that are never stale. */
 int hnb_effect_materialise(HnbEffect* fx, uint64_t attr_mask);
@@ -438,6 +485,37 @@ int hnb_effect_read_alive_list(HnbEffect* fx, uint32_t* dst, size_t dst_count);
 int hnb_effect_read_dead_list(HnbEffect* fx, uint32_t* dst, size_t dst_count);
 /* Overwrite an attribute plane / force counters (tests and state restore). */
 int hnb_effect_write_attr(HnbEffect* fx, uint32_t attr, const void* src, size_t src_size);
+
+/* ---- Verification on the device ----------------------------------------------------------------------------------------------------
+ * State too large to read back and compare on the host in reasonable time (16.7M particles: 0.7 GB per effect) is checked where it lives.
+ * Both calls materialise stale planes (hnb_effect_materialise), synchronise the effect's context and return small host structs.
+ *
+ * hnb_effect_check: the invariants the reference's passes maintain between frames (src/render/vfx_update.wgsl:148-166, vfx_init.wgsl:141-143):
+ *   rows [0, alive_count) of the alive list and rows [alive_count, capacity) of the dead list together name every slot exactly once, the alive
+ *   byte of a slot says which of the two lists it is in, every alive particle of a program that reaps by lifetime has age < lifetime
+ *   (src/lib.rs:1223-1258), and the device raised no fault (HnbEffectMetadata::fault: a host-side proof that did not hold).
+ * hnb_effect_compare: two effects of the same layout on the same device, bit for bit: the eight counter words, the alive rows, the dead rows,
+ *   every attribute plane over every slot. What bench.py holds the state its timed frames produced against: a second context that replayed the
+ *   same frames with every proof and hint of hnb_ctx_set_option switched off. */
+typedef struct HnbEffectCheck {
+    uint32_t ok;                     /* 1: every count below is zero */
+    uint32_t capacity, alive_count;
+    uint32_t bad_slots;              /* list rows that name a slot >= capacity */
+    uint32_t duplicate_slots;        /* slots named by more than one row */
+    uint32_t alive_byte_mismatches;  /* slots whose alive byte disagrees with the list that names them */
+    uint32_t alive_past_lifetime;    /* alive particles with !(age < lifetime) (0 for programs that do not reap by lifetime) */
+    uint32_t fault;                  /* HnbEffectMetadata::fault */
+} HnbEffectCheck;
+typedef struct HnbEffectDiff {
+    uint32_t equal;                  /* 1: no difference anywhere */
+    uint32_t counter_diffs;          /* of the eight counter words (alive_count, particle_counter, list column, max_update, dead_count, spawned, indirect_write_index, instance_count) */
+    uint64_t alive_list_diffs, dead_list_diffs, attr_diffs;   /* differing 32-bit words */
+    int32_t first_section;           /* -1: none; 0 alive list, 1 dead list, 2 + HNB_ATTR_*: that attribute's plane */
+    uint32_t reserved;
+    uint64_t first_index;            /* word index of the first difference inside that section */
+} HnbEffectDiff;
+int hnb_effect_check(HnbEffect* fx, HnbEffectCheck* out);
+int hnb_effect_compare(HnbEffect* a, HnbEffect* b, HnbEffectDiff* out);
 
 /* Ribbon sort by (RIBBON_ID, AGE bits) ascending, stable (vfx_sort*.wgsl, src/render/mod.rs:7372-7612).
  * hnb_simulate runs it after the update of every effect whose layout has RIBBON_ID, like the reference;
@@ -483,9 +561,16 @@ typedef struct HnbComm HnbComm;
 /* Which collective library hnb_comm_* binds (dlopen). Default (never called, or path NULL): librccl by name. Must precede the first
  * hnb_comm_* call of the process that needs the library; afterwards it fails. HNB_COMM_LIB_DUPLICATE_DEVICES: the library accepts a
  * communicator that names one device twice (real RCCL does not) - for stand-ins such as tests/fake_rccl, which let the collective
- * branch run with two contexts on a one-GPU box. */
+ * branch run with two contexts on a one-GPU box.
+ * HNB_COMM_LIB_SINGLE_RANK: a communicator of ONE context / ONE rank is built with the library too (ncclCommInitAll over one device,
+ * ncclCommInitRank with n_ranks = 1) and its all-reduce runs on the context's stream, instead of the host path such a communicator takes by
+ * default (a one-GPU host need not load librccl at all): the way to execute the collective branch for real on a one-GPU machine. */
 #define HNB_COMM_LIB_DUPLICATE_DEVICES 1u
+#define HNB_COMM_LIB_SINGLE_RANK 2u
 int hnb_comm_set_library(const char* path, uint32_t flags);
+/* What the communicator reduces through, as text: "rccl <path of the library the symbols were resolved from> ranks=<n> local=<contexts>"
+ * or "host-sum ranks=<n> local=<contexts>". */
+int hnb_comm_describe(HnbComm* comm, char* buf, size_t buf_size);
 /* one process, n contexts (ncclCommInitAll over their devices; contexts that share a device are reduced through the host).
  * A communicator holds its contexts: destroy it before them (hnb_ctx_destroy refuses otherwise). */
 int hnb_comm_create_local(HnbContext* const* ctxs, uint32_t n_ctx, HnbComm** out_comm);

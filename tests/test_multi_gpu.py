@@ -50,6 +50,25 @@ def test_collective_branch_runs_through_a_stand_in_library():
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_the_real_librccl_reduces_a_one_context_communicator():
+    """dlopen("librccl.so.1") -> ncclCommInitAll / ncclGetUniqueId + ncclCommInitRank -> grouped ncclAllReduce(ncclUint64,
+    ncclSum) on the context's stream -> ncclCommDestroy had run zero times on hardware. HNB_COMM_LIB_SINGLE_RANK makes a communicator of one
+    context take that branch: on the one-GPU box every call executes against the real library."""
+    import sys
+    env = dict(os.environ, NCCL_SOCKET_IFNAME=os.environ.get("NCCL_SOCKET_IFNAME", "lo"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "real_rccl", "run_real_comm.py")], capture_output=True, text=True, timeout=540, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["describe_local"].startswith("rccl ") and "librccl" in out["describe_local"] and out["describe_local"].endswith("ranks=1 local=1"), out
+    assert out["describe_rank"].startswith("rccl ") and out["describe_rank"].endswith("ranks=1 local=1"), out
+    assert out["totals_local"] == out["alive"] and 0 < out["alive"][0] <= 30000 and 0 < out["alive"][1] <= 12345, out
+    assert out["totals_partial"] == [out["alive"][1], 0], out
+    assert out["totals_rank"] == out["alive_rank"] and out["alive_rank"][0] <= out["alive"][0], out
+    assert out["librccl_mapped"], "librccl is not in the process's maps"
+
+
+@pytest.mark.gpu
 def test_two_contexts_two_threads_on_one_device_equal_one_effect():
     C_ = 30000   # (not a multiple of the 4096-slot chunk)
     frames = 70  # burst, flight, most of the die-off
