@@ -105,6 +105,11 @@ CONFIGS = {
                       workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst; frames 48..70 at 1/60 s: the die-off (list kernels every frame)"),
     "c2_interop": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=56, kernel="k_update_slots_stream<ProgDragAccel>",
                        workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst, all alive, hnb_ctx_set_option(HNB_OPT_AGE_COHORT, OFF) (AGE plane current every frame)"),
+    "c2_view": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=52, kernel="k_update_slots_stream<ProgDragAccel, cohort>",
+                    workload="firework.rs trails EffectAsset END TO END: capacity={cap:_} per GPU, burst, all alive, the library's default HNB_AGE_COHORT_AUTO (the asset's ColorOverLifetime / "
+                             "SizeOverLifetime read AGE: cohorts + the AGE plane made current every frame) + a consumer kernel behind every frame that gathers position / age / lifetime by list row through hnb_effect_device_view"),
+    "c2_interop_view": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=56, kernel="k_update_slots_stream<ProgDragAccel>",
+                            workload="as c2_view with HNB_AGE_COHORT_OFF (per-particle ages in the plane, nothing to materialise) + the same consumer kernel behind every frame"),
     "c2_events": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=62, kernel="k_update_slots_stream<ProgDragAccel, cohort> (trails)",
                       workload="the real examples/firework.rs: rocket (capacity 32_768, 16_000 rockets/s) -> sparkle_trail (1_048_576; 5 spawn events per rocket and frame) + "
                                "trails (capacity={cap:_}; 1000 spawn events per dying rocket), GPU spawn events, steady state"),
@@ -115,10 +120,10 @@ CONFIGS = {
     "c5": dict(capacity=1 << 22, bytes_per_update=20, bytes_per_spawn=36, model_bytes=9, kernel="k_update_slots_stream<ProgAge>",
                workload="ribbon.rs EffectAsset, capacity={cap:_} per GPU, rate spawner in steady spawn/kill churn, ribbon sort in the step"),
 }
-EXTRA_CONFIGS = ("c2_mixed", "c2_dieoff", "c2_interop", "c2_events", "c3", "c4", "c5")   # appended to the N = 1 default line
+EXTRA_CONFIGS = ("c2_mixed", "c2_dieoff", "c2_interop", "c2_view", "c2_interop_view", "c2_events", "c3", "c4", "c5")   # appended to the N = 1 default line
 # what identifies the dominant kernel of a configuration in a rocprofv3 dispatch list
 KERNEL_MATCH = {"c2_events": ("k_update_slots_stream",), "c2": ("k_update_slots_stream",), "c2_mixed": ("k_update_slots_stream",), "c2_dieoff": ("k_update_slots_stream",),
-                "c2_interop": ("k_update_slots_stream",), "c3": ("k_update_slots_stream",), "c4": ("k_update_slots_stream",), "c5": ("k_update_slots_stream",)}
+                "c2_interop": ("k_update_slots_stream",), "c2_view": ("k_update_slots_stream",), "c2_interop_view": ("k_update_slots_stream",), "c3": ("k_update_slots_stream",), "c4": ("k_update_slots_stream",), "c5": ("k_update_slots_stream",)}
 
 
 def frame_dt(total_frames, safe_seconds=MIN_LIFETIME * 0.95):
@@ -376,8 +381,10 @@ class Workload:
                 asset = effects.firework_trails(cap)
             else:
                 asset = {"c3": effects.force_field, "c5": effects.ribbon}[name](cap)
-            if name == "c2_interop":
+            if name in ("c2_interop", "c2_interop_view"):
                 self.ctx.set_option("age_cohort", 0)   # HNB_AGE_COHORT_OFF, fixed in the program at creation: the AGE plane is current after every frame
+            elif name == "c2":
+                self.ctx.set_option("age_cohort", 1)   # HNB_AGE_COHORT_LEAN: the simulation alone (a headless host: nobody reads AGE between frames). c2_view is the asset end to end
             self.prog = self.ctx.create_program(bh.lower(asset))
             self.fxs = [self.prog.create_effect(slot_base=slot_base)]
             self.assets, self.slot_base = [asset], slot_base
@@ -385,6 +392,15 @@ class Workload:
             self.sharding_desc = f"capacity slab x{n}"
             if name in ("c5", "c2_mixed"):
                 self.spawner, self.rng = bh.EffectSpawner(asset.spawner), bh.Pcg32()
+        self.consumer = self.consumer_out = None
+        if name.endswith("_view"):   # a renderer's vertex-stage reads behind every frame (tests/device_view/consumer.hip: consumer_render_like)
+            import ctypes as C
+            from bevy_hanabi_amd import runtime
+            lib = C.CDLL(os.path.join(ROOT, "tests", "device_view", "libconsumer.so"))
+            lib.consumer_render_like.argtypes = [C.POINTER(runtime.DeviceView), C.c_void_p]
+            self.consumer, self._byref = lib, C.byref
+            self.consumer_out = torch.empty(self.per_inst_cap * 4, dtype=torch.float32, device=torch.device("cuda", D.device_index))
+            torch.cuda.synchronize()
         self.dt = DT
         self.f = 0   # next frame index
 
@@ -420,6 +436,11 @@ class Workload:
             if self.shadow is not None:
                 self.shadow(f, dt, inputs)
         ctx.simulate()
+        if self.consumer is not None:   # enqueued on the simulation stream right behind the frame: no synchronisation, no host copy
+            v = self.fxs[0].device_view()
+            assert v.stale_attr_mask == 0 or self.name != "c2_view", "HNB_AGE_COHORT_AUTO left AGE stale for an asset whose render modifiers read it"
+            rc = self.consumer.consumer_render_like(self._byref(v), self.consumer_out.data_ptr())
+            assert rc == 0, f"consumer_render_like: {rc}"
         self.f += 1
 
     def alive(self):
@@ -434,7 +455,7 @@ class Workload:
 # ------------------------------------------------------------------------------------------------------------------
 PARITY_BUDGET_S = 0.5          # oracle time per configuration (the slab / the reduced capacity is sized to the oracle's measured speed)
 PARITY_KEYS = ("capacity", "alive_count", "max_update", "max_spawn", "indirect_write_index", "particle_counter", "instance_count", "dead_count")
-BURST_PARITY = ("c2", "c2_interop", "c3", "c4")
+BURST_PARITY = ("c2", "c2_interop", "c2_view", "c2_interop_view", "c3", "c4")
 _ORACLE_RATE = None
 
 
@@ -658,7 +679,7 @@ def run_config(name, args, D, strong=False, pmc=None):
     warmup = warmup_frames(name, args.warmup)
     if name == "c2_dieoff":
         steps = DIEOFF_LAST - DIEOFF_FIRST + 1           # a window is the die-off itself, not K steps
-    elif name in ("c2", "c2_interop"):
+    elif name in ("c2", "c2_interop", "c2_view", "c2_interop_view"):
         w.dt = frame_dt(1 + warmup + steps * windows)    # nobody may die in the timed frames
     elif name in BURST_SAFE_SECONDS:
         w.dt = frame_dt(1 + warmup + steps * windows, BURST_SAFE_SECONDS[name])
@@ -762,7 +783,7 @@ def run_config(name, args, D, strong=False, pmc=None):
     w.close()
 
     alive0_total, alive1_total = D.sum_counts([alive0, alive1])
-    if name in ("c2", "c2_interop", "c4"):
+    if name in ("c2", "c2_interop", "c2_view", "c2_interop_view", "c4"):
         expect = w.local_particles if not D.on else None
         assert expect is None or (alive0 == expect and alive1 == expect), f"{name}: expected every particle alive during the timed frames, got {alive0}, {alive1}"
     if D.rank != 0:

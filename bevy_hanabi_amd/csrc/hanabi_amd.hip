@@ -211,6 +211,7 @@ struct HnbContext {
     std::shared_ptr<SetBuildJob> set_job;   // HNB_SET_MODULE_BACKGROUND: the compilation in flight (joined when its result is taken, or with the context)
     plan::SetLookupState set_lookup;   // the population the last lookup / build was made for, and the one the previous merged frame had (hnb_plan.h)
     uint32_t set_frames = 0;        // statistics: frames with a launch served by the set kernels
+    uint32_t set_failed_builds = 0; // statistics: background compilations of a set module that failed (each population is tried once)
     std::string set_log;            // why the last build failed
 };
 
@@ -1763,10 +1764,18 @@ static void install_set_module(HnbContext* ctx, jit::SetResult& res);
 static void refresh_set_module(HnbContext* ctx, const std::vector<HnbProgram*>& order, const std::vector<plan::MergeFacts>& facts) {
     if (ctx->set_job && ctx->set_job->done.load(std::memory_order_acquire)) {   // a background compilation has finished: take its module, whatever the mode is now
         ctx->set_job->worker.join();
-        if (ctx->set_job->ok) install_set_module(ctx, ctx->set_job->res);
-        else ctx->set_log = ctx->set_job->res.log;
+        if (ctx->set_job->ok) {
+            install_set_module(ctx, ctx->set_job->res);
+            ctx->set_lookup.tried = 0;   // (the population may have moved on while it was compiled: look again)
+        } else {
+            // a set that does not compile (hiprtc error, a module too large) must not be compiled again and again for the life of the context:
+            // `tried` keeps naming the population the job was started for, so the lookup below is not due until the population changes, and the
+            // log keeps the compiler's message (round 4: tried was reset here too, the next merged frame found nothing in the cache and started
+            // the same compilation over - a CPU thread in hiprtc for ever, the error overwritten by "compiling ... in the background")
+            ctx->set_log = "set module: the background compilation failed, this population is not tried again: " + ctx->set_job->res.log;
+            ctx->set_failed_builds += 1;
+        }
         ctx->set_job.reset();
-        ctx->set_lookup.tried = 0;   // (the population may have moved on while it was compiled: look again)
     }
     if (ctx->set_mode == HNB_SET_MODULE_OFF || ctx->set_job) return;   // (while a compilation runs nothing is looked up: generating a module source costs a millisecond)
     std::vector<HnbProgram*> cand;
@@ -2161,9 +2170,13 @@ int hnb_simulate(HnbContext* ctx) {
         HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
     }
     rc = enqueue_init_passes(ctx, order, fj, timed);
-    if (rc != HNB_OK) return rc;
-    rc = enqueue_update_passes(ctx, order, fj, timed);
-    if (rc != HNB_OK) return rc;
+    if (rc == HNB_OK) rc = enqueue_update_passes(ctx, order, fj, timed);
+    if (rc != HNB_OK) {
+        // a launch failed somewhere behind the fork: what the side stream already holds must not be left running beside whatever the caller does
+        // next (hnb_ctx_synchronize, read-backs and hnb_program_destroy wait for the context's stream only). The frame is not advanced.
+        if (ctx->side_stream && (fj.forked || fj.heavy)) hipStreamSynchronize(ctx->side_stream);
+        return rc;
+    }
     for (HnbProgram* p : order) {
         p->ring += 1;
         p->parity ^= 1u;
@@ -2512,6 +2525,7 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
     if (prog->merged_frames) s += "\nupdate served by a merged launch (small programs of the context share one): " + std::to_string(prog->merged_frames) + " frames";
     if (prog->set_frames) s += "\n... by the context's set module (the program's specialised code behind the shared launch): " + std::to_string(prog->set_frames) + " frames";
     if (!prog->ctx->set_log.empty() && !prog->set_sig.empty()) s += "\nset module: " + prog->ctx->set_log;
+    if (prog->ctx->set_failed_builds && !prog->set_sig.empty()) s += "\nset module builds that failed: " + std::to_string(prog->ctx->set_failed_builds);
     if (prog->horizon_eligible) s += "\ndeath horizons in use: " + std::to_string(prog->hz_frames) + " frames";
     s += "\nlists skipped: " + std::to_string(prog->skipped_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->skip_facts.eligible ? "" : " (not eligible)");
     snprintf(buf, buf_size, "%s", s.c_str());

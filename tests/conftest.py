@@ -44,11 +44,7 @@ def pytest_configure(config):
 
 
     # tests/device_view: the HIP consumer kernel of the device-side output boundary
-    dv_dir = os.path.join(ROOT, "tests", "device_view")
-    dv_so, dv_src = os.path.join(dv_dir, "libconsumer.so"), os.path.join(dv_dir, "consumer.hip")
-    hdr = os.path.join(ROOT, "include", "hanabi_amd.h")
-    if (os.path.exists(hipcc) or shutil.which("hipcc")) and (not os.path.exists(dv_so) or max(os.path.getmtime(dv_src), os.path.getmtime(hdr)) > os.path.getmtime(dv_so)):
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), dv_src, "-o", dv_so])
+    hb.build_consumer()
 
 
 def _has_gpu():

@@ -193,6 +193,33 @@ def test_gpu_background_compilation_hands_the_module_over(tmp_path, monkeypatch)
 
 
 @pytest.mark.gpu
+def test_gpu_a_set_that_does_not_compile_is_tried_once_and_says_why(tmp_path, monkeypatch):
+    """a failed background build reset the lookup, the next merged frame found nothing in the cache and started the identical
+    compilation again - a CPU thread in hiprtc for the life of the context, the compiler's message overwritten by "compiling ... in the background".
+    Now the population is tried once, the frames stay on the interpreters (equal to the oracle) and the log keeps the error."""
+    monkeypatch.setenv("HNB_JIT_CACHE", str(tmp_path))
+    sc = Scene([effects.instancing(4096), effects.single_particle(16)], 3)      # (the programs' own kernels are compiled here, before the option below exists)
+    monkeypatch.setenv("HNB_JIT_EXTRA", "-DHNB_CHUNK=)")                         # a compiler option that breaks every translation unit compiled from now on
+    sc.step(4)
+    assert "in the background" in sc.runs[0].prog.kernel_info()
+    t0, info = time.time(), ""
+    while "failed" not in info and time.time() - t0 < 120:
+        sc.step(4)
+        time.sleep(0.25)
+        info = sc.runs[0].prog.kernel_info()
+    assert "the background compilation failed" in info and "set module builds that failed: 1" in info, info
+    sc.step(40)                               # many more merged frames: no second attempt
+    time.sleep(1.0)
+    sc.step(8)
+    info = sc.runs[0].prog.kernel_info()
+    assert "set module builds that failed: 1" in info and "in the background" not in info, info
+    assert sc.set_frames() == [0, 0]
+    sc.check()
+    monkeypatch.delenv("HNB_JIT_EXTRA")
+    sc.ctx.close()
+
+
+@pytest.mark.gpu
 def test_gpu_a_context_destroyed_while_its_set_compiles(tmp_path, monkeypatch):
     monkeypatch.setenv("HNB_JIT_CACHE", str(tmp_path))
     sc = Scene([effects.ribbon(4096), effects.single_particle(16)], 3)
