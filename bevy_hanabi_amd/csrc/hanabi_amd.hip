@@ -226,6 +226,8 @@ struct HnbProgram {
     bool wide_file = false;       // init_regs / update_regs above HNB_VM_MAX_REGS: generic kernels use the wide V file
     uint32_t cull_dt_operand = 0; // lifetime culling: decoded operand a of the update stream's AGE_TICK (dev.cull_lifetime)
     bool update_streams = false;  // update stream runs on the streaming kernel (macro ops, U operands)
+    bool nursery_eligible = false;  // the slab has a spawn nursery and the update kernel knows alive byte 5 (hnb_kernels.hip.h "Spawn nursery"); dev.nursery is per frame
+    uint32_t nursery_frames = 0;    // statistics: frames whose init pass was allowed to write records
     bool auto_materialise = false;  // HNB_AGE_COHORT_AUTO and the render modifiers read AGE: the plane is made current at the end of every frame
     StreamLaunchFn stream_launch = nullptr;  // specialised (or interpreted) streaming kernel for this update stream
     const char* stream_kernel_name = "";
@@ -532,17 +534,13 @@ bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgra
         gsum_off = place(align_up((size_t)8 * ((sort_chunks + kSortGroup - 1) / kSortGroup) * 256 * 4, 256));
         bits_off = place(256);
     }
-    // spawn nursery (hnb_kernels.hip.h): a counter per 256-slot group, then a bucket of 256 32-byte records per group - LAST in the slab, so that
-    // the planes the update streams keep their offsets (and their placement) whether or not a program is eligible
-    uint64_t ncnt_off = 0, nrec_off = 0;
-    if (nursery) {
-        const uint64_t groups = (uint64_t)d.chunks_per_inst * (kChunk / kNurseryGroup);
-        ncnt_off = place(align_up((size_t)groups * 4, 256));
-        nrec_off = place(groups * kNurseryGroup * 32u);
-    }
+    // spawn nursery (hnb_kernels.hip.h): one 32-byte record per slot - LAST in the slab, so that the planes the update streams keep their
+    // offsets (and their placement) whether or not a program is eligible
+    uint64_t nrec_off = 0;
+    if (nursery) nrec_off = place((uint64_t)d.chunks_per_inst * kChunk * 32u);
     if (off > ((uint64_t)0xffffffffu << 8)) return false;   // (offsets are kept in 256-byte units: 1 TiB)
     d.nursery = nursery ? 1u : 0u;
-    d.nursery_cnt_off = soff_of(ncnt_off); d.nursery_off = soff_of(nrec_off);
+    d.nursery_off = soff_of(nrec_off);
     d.alive_off[0] = soff_of(a0); d.alive_off[1] = soff_of(a1); d.dead_off = soff_of(dd);
     for (uint32_t i = 0; i < h.n_attrs; ++i) {
         d.attrs[i].plane_off = soff_of(plane[i]);
@@ -1042,7 +1040,8 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     DevProgram& d = p->dev;
     size_t slab_bytes = 0;
     p->update_streams = update_is_streamable(b, h, p->attrs.data());
-    if (!layout_slab(h, p->attrs.data(), d, p->sort, &slab_bytes, nursery_eligible(b, h, p->attrs.data(), p->update_streams, ctx->popt))) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 1 TiB (capacity %u)", h.capacity); }
+    p->nursery_eligible = nursery_eligible(b, h, p->attrs.data(), p->update_streams, ctx->popt);
+    if (!layout_slab(h, p->attrs.data(), d, p->sort, &slab_bytes, p->nursery_eligible)) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 1 TiB (capacity %u)", h.capacity); }
     p->slot_order = ctx->list_order == HNB_LIST_ORDER_SLOT && !(h.flags & HNB_PROG_HAS_RIBBONS);  // ribbons are re-sorted anyway
     p->has_ribbons = (h.flags & HNB_PROG_HAS_RIBBONS) != 0;
     p->slab_bytes = slab_bytes;
@@ -1539,7 +1538,7 @@ static SlotArgs slot_args_of(const HnbContext* ctx, const HnbProgram* p, uint32_
     sa.transpose = ctx->transpose ? 1u : 0u;
     sa.stream_hint = p->plan.stream_hint ? 1u : 0u;
     sa.store_hint = p->plan.store_hint ? 1u : 0u;
-    sa.nursery = p->dev.nursery; sa.nursery_off = p->dev.nursery_off; sa.nursery_cnt_off = p->dev.nursery_cnt_off;
+    sa.nursery = p->nursery_eligible ? 1u : 0u; sa.nursery_off = p->dev.nursery_off;   // (eligible: the instantiation that knows alive byte 5; whether THIS frame writes records is DevProgram::nursery)
     for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
         const DevAttr& at = p->dev.attrs[a];
         const int pi = at.reg == HNB_REG_POSITION ? 0 : at.reg == HNB_REG_VELOCITY ? 1 : at.reg == HNB_REG_AGE ? 2 : at.reg == HNB_REG_LIFETIME ? 3 : -1;
@@ -1720,6 +1719,14 @@ static void stage_program_frame(HnbContext* ctx, HnbProgram* p, uint32_t slot, s
     stage_off += (frame_bytes_for(p, n) + 255u) & ~(size_t)255u;
     pl.init_blocks = blocks;
     p->dev.n_inst = n;
+    {   // spawn nursery, this frame: records pay where spawns are sparse - a frame that may spawn an eighth of the slots or more (a re-burst) would
+        // make the update take several records per lane one after the other, and stores plane by plane instead (both paths leave the same state)
+        uint64_t bound = 0;
+        for (uint32_t i = 0; i < n; ++i)
+            if (inst_frames[i].simulated) bound += inst_frames[i].has_parent ? inst_frames[i].event_capacity : inst_frames[i].spawn_count;
+        p->dev.nursery = (p->nursery_eligible && bound != 0u && bound * 8u <= (uint64_t)n * p->dev.capacity) ? 1u : 0u;
+        p->nursery_frames += p->dev.nursery;
+    }
 
 }
 
@@ -1772,7 +1779,7 @@ static void refresh_set_module(HnbContext* ctx, const std::vector<HnbProgram*>& 
             // `tried` keeps naming the population the job was started for, so the lookup below is not due until the population changes, and the
             // log keeps the compiler's message (round 4: tried was reset here too, the next merged frame found nothing in the cache and started
             // the same compilation over - a CPU thread in hiprtc for ever, the error overwritten by "compiling ... in the background")
-            ctx->set_log = "set module: the background compilation failed, this population is not tried again: " + ctx->set_job->res.log;
+            ctx->set_log = "the background compilation failed, this population is not tried again: " + ctx->set_job->res.log.substr(0, 600);
             ctx->set_failed_builds += 1;
         }
         ctx->set_job.reset();
@@ -2446,7 +2453,9 @@ int hnb_effect_compare(HnbEffect* a, HnbEffect* b, HnbEffectDiff* out) {
     if (rc != HNB_OK) return rc;
     const uint32_t wa[8] = {ma.alive_count, ma.particle_counter, ma.write_index & 1u, ma.max_update, ma.dead_count, ma.spawned, ma.ref_write_index & 1u, ma.instance_count};
     const uint32_t wb[8] = {mb.alive_count, mb.particle_counter, mb.write_index & 1u, mb.max_update, mb.dead_count, mb.spawned, mb.ref_write_index & 1u, mb.instance_count};
-    for (int i = 0; i < 8; ++i) out->counter_diffs += wa[i] != wb[i] ? 1u : 0u;
+    // (word 2, the list COLUMN, is where the rows live, not what they are: a ribbon effect whose sorted list is made by rotation inside k_compact
+    // changes column in frames in which a radix-sorted one does not; the rows themselves are compared below, each list through its own column)
+    for (int i = 0; i < 8; ++i) out->counter_diffs += (i != 2 && wa[i] != wb[i]) ? 1u : 0u;
     const uint32_t cap = pa->dev.capacity;
     const char *sa = static_cast<const char*>(a->slab), *sb = static_cast<const char*>(b->slab);
     const size_t n_sections = 2 + pa->attrs.size();
@@ -2502,23 +2511,26 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
         s += "\nage cohorts: " + std::to_string(in_cohort) + " of " + std::to_string(prog->effects.size() * (size_t)prog->dev.chunks_per_inst) + " chunks";
         if (prog->auto_materialise) s += " (render modifiers read AGE: the plane is made current after every frame, HNB_AGE_COHORT_AUTO)";
     }
-    if (prog->dev.nursery) {   // (debug statistics, as above: records that wait between frames - none, ever - and the buckets that have held one since the slab was zeroed)
+    if (prog->nursery_eligible) {   // (debug statistics, as above: slots still marked "record waiting" between frames - none, ever - and how many of a sample of records have been written since the slab was zeroed)
         hipStreamSynchronize(prog->ctx->stream);
-        const size_t groups = (size_t)prog->dev.chunks_per_inst * (kChunk / kNurseryGroup);
-        std::vector<uint32_t> cnt(groups), first(groups * 8);
-        size_t waiting = 0, used = 0;
+        const uint32_t cap = prog->dev.capacity, stride = 16u, n_s = (cap + stride - 1u) / stride;
+        std::vector<uint8_t> flags(cap);
+        std::vector<uint32_t> rec((size_t)n_s * 8);
+        size_t waiting = 0, written = 0, sampled = 0;
         for (const HnbEffect* fx : prog->effects) {
             const char* slab = static_cast<const char*>(fx->slab);
-            if (hipMemcpy(cnt.data(), slab + prog->dev.nursery_cnt_off, groups * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
-            if (hipMemcpy2D(first.data(), 32, slab + prog->dev.nursery_off, (size_t)kNurseryGroup * 32, 32, groups, hipMemcpyDeviceToHost) != hipSuccess) break;
-            for (size_t g = 0; g < groups; ++g) {
-                waiting += cnt[g];
+            if (hipMemcpy(flags.data(), slab + prog->dev.alive_flag_off, cap, hipMemcpyDeviceToHost) != hipSuccess) break;
+            if (hipMemcpy2D(rec.data(), 32, slab + prog->dev.nursery_off, (size_t)stride * 32, 32, n_s, hipMemcpyDeviceToHost) != hipSuccess) break;
+            for (uint32_t i = 0; i < cap; ++i) waiting += flags[i] == kAliveRecord ? 1u : 0u;
+            for (uint32_t i = 0; i < n_s; ++i) {
                 bool any = false;
-                for (int w = 0; w < 8; ++w) any = any || first[g * 8 + w] != 0u;
-                used += any ? 1u : 0u;
+                for (int w = 0; w < 8; ++w) any = any || rec[(size_t)i * 8 + w] != 0u;
+                written += any ? 1u : 0u;
             }
+            sampled += n_s;
         }
-        s += "\nspawn nursery: " + std::to_string(used) + " of " + std::to_string(groups * prog->effects.size()) + " buckets used, " + std::to_string(waiting) + " records waiting";
+        s += "\nspawn nursery: " + std::to_string(written) + " of " + std::to_string(sampled) + " sampled records written, " + std::to_string(waiting) + " records waiting, " +
+             std::to_string(prog->nursery_frames) + " of " + std::to_string(prog->frames_run) + " frames";
     }
     if (prog->has_ribbons && prog->suffix_frames) s += "\ncasualties proven to be the list's last rows (no k_count_rows): " + std::to_string(prog->suffix_frames) + " frames";
     if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->ribbon_facts.front_static ? "" : " (not eligible)");

@@ -139,24 +139,24 @@ __device__ __forceinline__ uint32_t requested_spawn(const DevFrameInst& f) {
 // ---- spawn nursery ---------------------------------------------------------------------------------------------------------------
 // Spawning into the slots a spawn / die steady state frees is a scatter: the dead list hands the slots out in DEATH order, and with one
 // plane per attribute every 4- or 12-byte store of a spawn is a partial 32-byte sector of its own (firework: 6.5 sectors = 208 B moved per
-// 44-byte spawn, 0.049 ms for 277k spawns per frame at 16.7M slots; a 16.7M re-burst into the dead list a die-off left: 1.5 ms against
-// 0.167 ms into a fresh effect; profiles/r04y_pmc_*). But the update that follows in the same frame streams every line of the planes it
-// WRITES anyway. So for programs with a streamable update, k_init hands those planes of a scattered spawn to the update instead of storing
-// them: ONE 32-byte record {slot, position, velocity, age} - an aligned sector, written whole - into the bucket of the slot's 256-slot
-// group (one returning atomic on the group's counter; at most 256 slots of a group can be free, so a bucket of 256 records never overflows
-// and there is no fallback path). The wave of the update that owns the group reads the counter with its alive bytes, takes the records one per
-// lane (contiguous), routes them to the lanes that own the slots (a 256-byte map in LDS: slot -> lane holding its record; ds_bpermute pulls
-// the seven words) and substitutes them for what it loaded from the planes BEFORE the first tick - the reference runs init then update in the
-// same frame too (src/render/mod.rs:7157-7173, :7358-7366). The slot's alive byte is set by the update (it rewrites the word anyway).
+// 44-byte spawn, 0.049 ms for 277k spawns per frame at 16.7M slots; profiles/r04y_pmc_*). But the update that follows in the same frame
+// streams every line of the planes it WRITES anyway. So for programs with a streamable update, k_init hands those planes of a scattered
+// spawn to the update instead of storing them: ONE 32-byte record {position, velocity, age} at nursery[slot] - an aligned sector, written
+// whole - and the slot's alive byte says so (5). The lane of the update that owns the slot sees the 5 among the alive bytes it reads anyway,
+// requests the record in front of its plane loads and substitutes it for what the planes held BEFORE the first tick - the reference runs
+// init then update in the same frame too (src/render/mod.rs:7157-7173, :7358-7366); the byte becomes an ordinary 1 with the flag word the
+// update rewrites. No counters, no atomics, no workgroup hand-offs: a record is found by the slot it belongs to.
 //   * Planes the update does not store (LIFETIME: read-only; COLOR, SIZE, ...: never touched) are written by k_init as before.
 //   * Which spawn takes which path is decided per WAVE of k_init: 64 consecutive dead-list rows that hold consecutive slots (a fresh effect:
 //     dead[i] = i; a burst that died in one frame: descending) are stored directly - those stores coalesce - everything else goes through
-//     records. Both paths leave the same state: the choice is invisible (and the order of the records in a bucket, which depends on the
-//     order the atomics arrive in, carries no meaning: a record names its slot).
-//   * Between frames every counter is zero (the wave that consumes a bucket re-arms it); records never outlive the frame they were written in.
-// Eligible: streamable update that stores POSITION, no spawn events out (a child's init reads its parent's planes in the same init phase), no
-// ribbons; HNB_OPT_SPAWN_NURSERY = 0 switches it off.
-constexpr uint32_t kNurseryGroup = 256u;                      // slots per bucket = one wave step of the streaming update
+//     records; and a frame that spawns an eighth of the capacity or more (a re-burst: up to four records per lane of the update, taken one
+//     after the other) stores directly, decided on the host (DevProgram::nursery is a per-frame flag). Both paths leave the same state.
+//   * Round 5 first built this with a BUCKET of records per 256-slot group, filled through one returning atomic per spawn and routed to the owning
+//     lanes through an LDS map and ds_bpermute: bit-equal, and slower where it mattered - device-scope atomics execute beyond the XCD's L2, 16.7M of
+//     them (a re-burst) took 2.08 ms against 1.52 ms for the plane-granular stores they were meant to beat (profiles/r05a_reburst.log).
+// Eligible: lean streamable update that stores POSITION, no spawn events out (a child's init reads its parent's PLANES in the same init phase), no
+// ribbons; HNB_OPT_SPAWN_NURSERY = 0 switches it off. Costs 32 bytes per slot of slab.
+constexpr uint32_t kAliveRecord = 5u;                         // alive byte: spawned this frame, POSITION / VELOCITY / AGE wait in nursery[slot]
 __host__ __device__ __forceinline__ bool nursery_holds(uint32_t reg, uint32_t upd_flags) {   // does the record carry this pinned plane? (else k_init stores it)
     return (upd_flags & HNB_ATTR_UPD_STORE) && (reg == HNB_REG_POSITION || reg == HNB_REG_VELOCITY || reg == HNB_REG_AGE);
 }
@@ -352,12 +352,11 @@ __device__ __forceinline__ void init_workgroup(const DevProgram& prog, const uin
             if (st == 1u || st == 2u) { if (st != 2u) astate[slot / kChunk] = 2u; alive_byte = 3u; }   // (0, 4: the plane holds every age of the chunk)
         }
         if (prog.cull_lifetime) reinterpret_cast<float*>(base + prog.lmin_off)[slot / kChunk] = 0.0f;  // the chunk's lifetime bound is unknown again
-        if (scattered) {   // the record names the slot: the update marks it alive (and knows it as a fresh one) when it takes the record
-            const uint32_t g = slot / kNurseryGroup;
-            const uint32_t at = atomicAdd(reinterpret_cast<uint32_t*>(base + prog.nursery_cnt_off) + g, 1u) & (kNurseryGroup - 1u);
-            u4v* rec = reinterpret_cast<u4v*>(base + prog.nursery_off) + ((size_t)g * kNurseryGroup + at) * 2u;
-            rec[0] = u4v{slot, S.r[HNB_REG_POSITION], S.r[HNB_REG_POSITION + 1], S.r[HNB_REG_POSITION + 2]};
-            rec[1] = u4v{S.r[HNB_REG_VELOCITY], S.r[HNB_REG_VELOCITY + 1], S.r[HNB_REG_VELOCITY + 2], S.r[HNB_REG_AGE]};
+        if (scattered) {   // one aligned 32-byte sector instead of two or three partial ones; the alive byte tells the update where to look
+            u4v* rec = reinterpret_cast<u4v*>(base + prog.nursery_off) + (size_t)slot * 2u;
+            rec[0] = u4v{S.r[HNB_REG_POSITION], S.r[HNB_REG_POSITION + 1], S.r[HNB_REG_POSITION + 2], S.r[HNB_REG_VELOCITY]};
+            rec[1] = u4v{S.r[HNB_REG_VELOCITY + 1], S.r[HNB_REG_VELOCITY + 2], S.r[HNB_REG_AGE], 0u};
+            reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = (uint8_t)kAliveRecord;
             CODE::store_init_rest(prog, S, base, slot);
         } else {
             reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = alive_byte;
@@ -1066,8 +1065,8 @@ struct SlotArgs {
     uint32_t transpose;      // 1: vec3 planes of the per-particle path go through the wave's LDS transpose (xpose_load3 / xpose_store3)
     uint32_t stream_hint;    // 1: read-only planes (LIFETIME, alive bytes) are loaded with the nontemporal hint ("cache policy of streamed data")
     uint32_t store_hint;     // 1: the per-particle path stores its planes with the nontemporal hint (update_stream_chunk)
-    uint32_t nursery;        // 1: spawn records may wait in the slab's nursery ("Spawn nursery"; DevProgram::nursery)
-    soff_t nursery_off, nursery_cnt_off;
+    uint32_t nursery;        // 1: slots with alive byte 5 have their spawn record in the slab's nursery ("Spawn nursery"; DevProgram::nursery_off is laid out)
+    soff_t nursery_off;
 };
 
 // The deaths of a frame are known on the device only after its update ran, and HIP has no indirect dispatch: the list
@@ -1127,7 +1126,6 @@ struct StreamLds {
     float rem[kBlock / 64];
     uint32_t amin[kBlock / 64], amax[kBlock / 64];
     u4v xp[2][kBlock / 64][kStepRows * 3u / 4u];   // position / velocity staging of each wave's step (xpose_load3): 24 KiB per workgroup
-    uint32_t nmap[kBlock / 64][kStepRows / 4u];    // "Spawn nursery": one byte per slot of a wave's step - the lane (+ 1) that holds the slot's spawn record
 };
 __device__ __forceinline__ StreamLds& stream_lds() {
     __shared__ StreamLds s;
@@ -1136,7 +1134,7 @@ __device__ __forceinline__ StreamLds& stream_lds() {
 
 // PROBE (tools/stream_probe.hip only; 0 in the product): 4 = skip stores, 8 = skip the program.
 // COHORT: compile the age-cohort paths in (programs that are eligible: SlotArgs::age_cohort); false leaves the kernel as it was.
-// NURSERY: compile the spawn-record substitution in (programs that are eligible: SlotArgs::nursery; 11-16 more VGPRs); false leaves the kernel as it was.
+// NURSERY: compile the spawn-record substitution in (programs that are eligible: SlotArgs::nursery); false leaves the kernel as it was.
 template <class PROG, int PROBE, bool COHORT, bool NURSERY = false>
 __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
                                                     const uint32_t* __restrict__ ublocks, const CompactBufs& cb,
@@ -1149,7 +1147,6 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
     uint32_t (&s_amin)[kBlock / 64] = lds.amin;
     uint32_t (&s_amax)[kBlock / 64] = lds.amax;
     u4v (&s_xp)[2][kBlock / 64][kStepRows * 3u / 4u] = lds.xp;
-    uint32_t (&s_nmap)[kBlock / 64][kStepRows / 4u] = lds.nmap;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     const uint32_t k = chunk / args.chunks_per_inst, j = chunk - k * args.chunks_per_inst;
@@ -1262,34 +1259,37 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
     }
     // ---- the per-particle path, one wave step (256 slots, 4 per lane). COH: with the age-cohort bookkeeping (a chunk that is known to hold
     // mixed ages - state 4 - runs without it: see `mixed` above)
-    auto step_body = [&](auto coh_tag, const uint32_t step, const uint32_t f4, const uint32_t n_rec, const u4v* pre_age = nullptr) {
+    auto step_body = [&](auto coh_tag, const uint32_t step, const uint32_t f4, const u4v* pre_age = nullptr) {
         constexpr bool COH = decltype(coh_tag)::value;
         const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;  // first of this lane's 4 slots
-        bool was[4], fresh[4];  // fresh: spawned this frame - its age is its own, not the chunk's (alive byte 3 in a cohort chunk, state 2 only; or a spawn record)
+        bool was[4], fresh[4];  // fresh: spawned this frame - its age is its own, not the chunk's (alive byte 3 in a cohort chunk, state 2 only; or a spawn record, byte 5)
+        uint32_t pend = 0u;     // NURSERY: bit p - slot p's POSITION / VELOCITY / AGE wait in its spawn record
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const uint32_t byte = (f4 >> (8 * p)) & 0xffu;
-            fresh[p] = COH && byte == 3u;
+            const bool rec = NURSERY && byte == kAliveRecord;
+            fresh[p] = (COH && byte == 3u) || rec;
             was[p] = byte == 1u || fresh[p];
-            if constexpr (!NURSERY) lane_alive += was[p] ? 1u : 0u;
+            lane_alive += was[p] ? 1u : 0u;
+            pend |= rec ? 1u << p : 0u;
         }
-        bool any = was[0] || was[1] || was[2] || was[3];
-        const bool recs = NURSERY && n_rec != 0u;   // (wave-uniform) spawn records wait for slots of this step: "Spawn nursery"
-        if (!recs && !__any(any)) {
+        const bool any = was[0] || was[1] || was[2] || was[3];
+        if (!__any(any)) {
             if (args.write_died) store_died_bits(reinterpret_cast<uint32_t*>(base + args.died_bits_off), s0 - lane * 4u, 0u, lane);
             return;
         }
-        // the step's records, one per lane, requested in front of the planes. Which slots they fill is known only when they have arrived: every
-        // quad of such a step is loaded (in a steady state nearly all of them hold a live particle anyway)
-        const u4v* grec = reinterpret_cast<const u4v*>(base + args.nursery_off) + (size_t)((s0 - lane * 4u) / kNurseryGroup) * (kNurseryGroup * 2u);
-        u4v rec0 = u4v{0xffffffffu, 0u, 0u, 0u}, rec1 = u4v{0u, 0u, 0u, 0u};
-        if constexpr (NURSERY) {
-            if (recs && lane < n_rec) { rec0 = grec[lane * 2u]; rec1 = grec[lane * 2u + 1u]; }
-            any = any || recs;
-        }
+        const bool full = was[0] && was[1] && was[2] && was[3];
         uint32_t slot[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) slot[p] = s0 + p;
+        // the lane's first waiting record, requested in front of the planes (a lane rarely owns more than one fresh slot of a step: the others
+        // follow one by one below)
+        const u4v* nrec = reinterpret_cast<const u4v*>(base + args.nursery_off);
+        u4v rec0 = u4v{0u, 0u, 0u, 0u}, rec1 = u4v{0u, 0u, 0u, 0u};
+        uint32_t take = pend ? (uint32_t)__builtin_ctz(pend) : 4u;
+        if constexpr (NURSERY) {
+            if (pend) { rec0 = nrec[(size_t)(s0 + take) * 2u]; rec1 = nrec[(size_t)(s0 + take) * 2u + 1u]; }
+        }
         bool lanes_on[4] = {any, any, any, any};  // loads: the whole quad whenever one of its slots is alive
         Pinned<4> X;
 #pragma unroll
@@ -1327,45 +1327,27 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         };
         const bool ask_life = cull && Lm > 0.0f && (COH || !mixed);   // (wave-uniform) "can this step lose a particle?" decides below
         if (!ask_life && any && (fl & 8u)) load_life();
-        if constexpr (NURSERY) if (recs) {   // route every record to the lane that owns its slot, 64 records per round (a group holds at most 256)
-            uint32_t* map = s_nmap[wave];
-            for (uint32_t done = 0u;;) {
-                map[lane] = 0u;
-                if (rec0.x != 0xffffffffu) reinterpret_cast<uint8_t*>(map)[(rec0.x - (s0 - lane * 4u)) & (kStepRows - 1u)] = (uint8_t)(lane + 1u);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t m4 = map[lane];
+        if constexpr (NURSERY) {
+            if (__any(pend != 0u)) {   // (wave-uniform) substitute the records for what the planes held
+                for (;;) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {   // (ds_bpermute reads the source lane's register only where that lane is active: every lane executes the pulls)
-                    const uint32_t src = (m4 >> (8 * p)) & 0xffu;
-                    const int from = src ? (int)src - 1 : (int)lane;
-                    const V3 rp = V3{u2f(__shfl(rec0.y, from, 64)), u2f(__shfl(rec0.z, from, 64)), u2f(__shfl(rec0.w, from, 64))};
-                    const V3 rv = V3{u2f(__shfl(rec1.x, from, 64)), u2f(__shfl(rec1.y, from, 64)), u2f(__shfl(rec1.z, from, 64))};
-                    const float ra = u2f(__shfl(rec1.w, from, 64));
-                    if (src) {
-                        if (fl & 16u) X.pos[p] = rp;
-                        if (fl & 32u) X.vel[p] = rv;
-                        if (fl & 64u) X.age[p] = ra;
-                        was[p] = true; fresh[p] = true;
+                    for (int p = 0; p < 4; ++p) {   // (selects: `take` is a lane's own)
+                        const bool t = pend != 0u && take == (uint32_t)p;
+                        if (fl & 16u) X.pos[p] = t ? V3{u2f(rec0.x), u2f(rec0.y), u2f(rec0.z)} : X.pos[p];
+                        if (fl & 32u) X.vel[p] = t ? V3{u2f(rec0.w), u2f(rec1.x), u2f(rec1.y)} : X.vel[p];
+                        if (fl & 64u) X.age[p] = t ? u2f(rec1.z) : X.age[p];
                     }
+                    pend &= pend - 1u;
+                    if (!__any(pend != 0u)) break;
+                    take = pend ? (uint32_t)__builtin_ctz(pend) : 4u;
+                    if (pend) { rec0 = nrec[(size_t)(s0 + take) * 2u]; rec1 = nrec[(size_t)(s0 + take) * 2u + 1u]; }
                 }
-                done += 64u;
-                if (done >= n_rec) break;
-                rec0 = u4v{0xffffffffu, 0u, 0u, 0u};
-                if (done + lane < n_rec) { rec0 = grec[(done + lane) * 2u]; rec1 = grec[(done + lane) * 2u + 1u]; }
             }
         }
-        if (COH && ast != 0u && (fl & 4u)) {   // (selects, no divergence: ast is uniform, fresh[] only ever set in state 2)
+        if (COH && ast != 0u && any && (fl & 4u)) {   // (selects, no divergence: ast is uniform, fresh[] only ever set in state 2)
 #pragma unroll
             for (int p = 0; p < 4; ++p) X.age[p] = fresh[p] ? X.age[p] : A;
         }
-        if constexpr (NURSERY) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) lane_alive += was[p] ? 1u : 0u;
-        }
-        const bool full = was[0] && was[1] && was[2] && was[3];
-        const bool was_any = was[0] || was[1] || was[2] || was[3];
         // can this step lose a particle? `age + dt` is the AGE_TICK's own arithmetic. (A chunk known to hold mixed ages does not ask: some
         // particle of a step is always near its end there, and the question makes the lifetime loads wait for the ages - a third dependent
         // memory round trip per step.)
@@ -1389,7 +1371,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
             const bool xp_pos = xp && (fl & 17u) == 17u, xp_vel = xp && (fl & 34u) == 34u;
             if (xp_pos) xpose_store3(X.pos, p_pos, step_first, s_xp[0][wave], lane, was, full, store_nt);
             if (xp_vel) xpose_store3(X.vel, p_vel, step_first, s_xp[1][wave], lane, was, full, store_nt);
-            if (was_any) {  // a full quad is stored with 16-byte stores; otherwise only the alive slots are written
+            if (any) {  // a full quad is stored with 16-byte stores; otherwise only the alive slots are written
                 if ((fl & 16u) && !xp_pos) pin_store3<4>(X.pos, p_pos, slot, was, full);
                 if ((fl & 32u) && !xp_vel) pin_store3<4>(X.vel, p_vel, slot, was, full);
                 if (fl & 64u) {
@@ -1445,7 +1427,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         for (int p = 0; p < 4; ++p) {
             const bool died = was[p] && !X.alive[p];
             if (died) { nf &= ~(0xffu << (8 * p)); nib |= 1u << p; }   // the slot is free from now on; the lists learn it from the died bit
-            else if (fresh[p]) nf = (nf & ~(0xffu << (8 * p))) | (1u << (8 * p));   // an ordinary alive slot from now on (a spawn record's slot: alive from now on)
+            else if (fresh[p]) nf = (nf & ~(0xffu << (8 * p))) | (1u << (8 * p));   // an ordinary alive slot from now on
             died_here += (uint32_t)__popcll(__ballot(died));
         }
         if (nf != f4) flags4[s0 >> 2] = nf;
@@ -1461,17 +1443,6 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
             const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;
             return chunk_full ? 0x01010101u : (s0 < args.capacity ? ld_hint(flags4 + (s0 >> 2), args.stream_hint != 0u) : 0u);  // the plane is padded: slots past the capacity read 0
         };
-        // "Spawn nursery": the records waiting for this wave's four groups (a completely alive chunk has no free slot: none). Requested in front of
-        // the alive bytes; the wave that takes a group's records re-arms its counter.
-        static_assert(kStepRows == kNurseryGroup && kWaveRows / kStepRows == 4u, "a nursery bucket is one wave step");
-        uint32_t ncs[kWaveRows / kStepRows] = {0u, 0u, 0u, 0u};
-        u4v* ncnt = reinterpret_cast<u4v*>(reinterpret_cast<uint32_t*>(base + args.nursery_cnt_off) + (j * (kChunk / kNurseryGroup) + wave * (kWaveRows / kStepRows)));
-        if (NURSERY && args.nursery && !chunk_full) {
-            const u4v c = *ncnt;
-            ncs[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.x); ncs[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.y);
-            ncs[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.z); ncs[3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.w);
-            if ((ncs[0] | ncs[1] | ncs[2] | ncs[3]) != 0u && lane == 0u) *ncnt = u4v{0u, 0u, 0u, 0u};
-        }
         if constexpr (COHORT || PROG::kFlat) {
             uint32_t f4s[kWaveRows / kStepRows];
 #pragma unroll
@@ -1488,20 +1459,20 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
                         ages[step] = s0 < args.capacity ? reinterpret_cast<const u4v*>(p_age)[s0 >> 2] : u4v{0u, 0u, 0u, 0u};   // (planes are padded to 256 B: a quad never straddles the end)
                     }
 #pragma unroll
-                    for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4s[step], ncs[step], &ages[step]);
+                    for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4s[step], &ages[step]);
                     goto steps_done;
                 }
             }
             if (mixed) {
 #pragma unroll
-                for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4s[step], ncs[step]);
+                for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4s[step]);
             } else {
 #pragma unroll
-                for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<COHORT>{}, step, f4s[step], ncs[step]);
+                for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<COHORT>{}, step, f4s[step]);
             }
         } else {
 #pragma unroll
-            for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4_of(step), ncs[step]);
+            for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4_of(step));
         }
     }
 steps_done:

@@ -508,7 +508,8 @@ typedef struct HnbEffectCheck {
 } HnbEffectCheck;
 typedef struct HnbEffectDiff {
     uint32_t equal;                  /* 1: no difference anywhere */
-    uint32_t counter_diffs;          /* of the eight counter words (alive_count, particle_counter, list column, max_update, dead_count, spawned, indirect_write_index, instance_count) */
+    uint32_t counter_diffs;          /* of the counter words alive_count, particle_counter, max_update, dead_count, spawned, indirect_write_index, instance_count
+                                      * (not the list column: where the rows live is not what they are) */
     uint64_t alive_list_diffs, dead_list_diffs, attr_diffs;   /* differing 32-bit words */
     int32_t first_section;           /* -1: none; 0 alive list, 1 dead list, 2 + HNB_ATTR_*: that attribute's plane */
     uint32_t reserved;

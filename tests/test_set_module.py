@@ -54,7 +54,7 @@ def test_a_set_module_is_keyed_by_the_set_not_by_order_or_multiplicity(tmp_path,
     bh.jit_precompile_set([a, b, big])
     assert _entries(tmp_path) == first
 
-    # the kernels of the module: one LDS object however many programs (the streaming update's 24 KiB of staging + 1 KiB of spawn-record maps), no scratch
+    # the kernels of the module: one LDS object however many programs (the streaming update's 24 KiB of staging), no scratch
     raw = open(tmp_path / first[0], "rb").read()
     hdr = struct.unpack_from("<8sIIQQQQQII", raw, 0)
     assert hdr[0].rstrip(b"\0") == b"HNBJIT2" and hdr[8] == 0        # no name expressions: the kernels are extern "C"
@@ -66,7 +66,7 @@ def test_a_set_module_is_keyed_by_the_set_not_by_order_or_multiplicity(tmp_path,
         name = re.search(r"\.name:\s+(\S+)", blk).group(1)
         kernels[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("group_segment_fixed_size", "private_segment_fixed_size", "vgpr_spill_count")}
     assert set(kernels) == {"hnb_set_init", "hnb_set_update"}
-    assert kernels["hnb_set_update"]["group_segment_fixed_size"] <= 26 * 1024 and kernels["hnb_set_init"]["group_segment_fixed_size"] <= 1024
+    assert kernels["hnb_set_update"]["group_segment_fixed_size"] <= 25 * 1024 and kernels["hnb_set_init"]["group_segment_fixed_size"] <= 1024
     for k in kernels.values():
         assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0
 

@@ -1,7 +1,8 @@
 """Spawn nursery (hnb_kernels.hip.h "Spawn nursery", HNB_OPT_SPAWN_NURSERY): spawns into scattered free slots travel to the update as
-32-byte records instead of plane-granular stores. Same state after every frame as the direct path and as the oracle, bit for bit:
-sparse spawns into a churning effect, dense re-bursts into the dead list a die-off left (up to 256 records per bucket: several rounds
-per wave step), spawns into chunks that keep their ages in a cohort word, several instances, ragged capacities.
+32-byte records (nursery[slot], announced by alive byte 5) instead of plane-granular stores. Same state after every frame as the direct path
+and as the oracle, bit for bit: sparse spawns into a churning effect, spawns of up to an eighth of the capacity into the dead list a die-off
+left (several records per lane of the update, taken one after the other), re-bursts (stored directly: the per-frame rule), spawns into chunks
+that keep their ages in a cohort word, several instances, ragged capacities.
 """
 import re
 
@@ -41,7 +42,7 @@ def _churn_asset(cap, life_lo=0.02, life_hi=0.2):
 
 
 def _stats(prog):
-    m = re.search(r"spawn nursery: (\d+) of (\d+) buckets used, (\d+) records waiting", prog.kernel_info())
+    m = re.search(r"spawn nursery: (\d+) of (\d+) sampled records written, (\d+) records waiting", prog.kernel_info())
     return None if m is None else tuple(int(x) for x in m.groups())
 
 
@@ -72,24 +73,28 @@ def test_scattered_spawns_through_records_equal_the_direct_path_and_the_oracle(c
 
 
 def test_a_dense_reburst_into_the_dead_list_of_a_die_off():
-    """Burst, die-off at random ages, then a burst of the whole capacity into the dead list in death order: every bucket holds up to 256
-    records (four rounds of 64 per wave step), every slot of the effect is filled from a record."""
+    """Burst, die-off at random ages, then (a) a burst of the whole capacity into the dead list in death order - stored plane by plane: a frame that
+    spawns more than an eighth of the slots does not use records - and (b) spawns of just under an eighth per frame, frame after frame: records,
+    many lanes of the update owning two or more of them."""
     cap = 3 * 4096 + 1234
     asset = _churn_asset(cap, 0.05, 0.4)
     on = _ctx(True)
     g, o = GpuRunner(asset, ctx=on), OracleRunner(asset)
     frames = [Frame(1 / 60, cap, frame_seed(0))] + [Frame(1 / 60, 0, frame_seed(f), time=f / 60) for f in range(1, 30)]
     frames += [Frame(1 / 60, cap, frame_seed(30), time=0.5)] + [Frame(1 / 60, 0, frame_seed(f), time=f / 60) for f in range(31, 36)]
-    frames += [Frame(1 / 60, cap // 2, frame_seed(36), time=0.6)] + [Frame(1 / 60, 0, frame_seed(f), time=f / 60) for f in range(37, 40)]
+    frames += [Frame(1 / 60, 0, frame_seed(f), time=f / 60) for f in range(36, 60)]                       # ... and dies off again
+    frames += [Frame(1 / 60, cap // 8, frame_seed(f), time=f / 60) for f in range(60, 72)]                # an eighth per frame into the second dead list
     for i, fr in enumerate(frames):
         g.step(fr)
         o.step(fr)
-        if i in (0, 12, 29, 30, 31, 35, 36, 39):
+        if i in (0, 12, 29, 30, 31, 35, 59, 60, 61, 65, 71):
             assert_same_state(o.state(), g.state(), f"frame {i}")
-        if i == 29:
+        if i in (29, 59):
             assert g.fx.alive_count() == 0, "the die-off must be complete before the re-burst"
-    used, groups, waiting = _stats(g.prog)
-    assert waiting == 0 and used >= groups - 1 - (4096 * 4 - cap) // 256 - 1, (used, groups)
+        if i == 35:
+            assert _stats(g.prog)[0] == 0, "the re-burst must not have gone through records"
+    used, sampled, waiting = _stats(g.prog)
+    assert waiting == 0 and used > sampled // 4, (used, sampled)
     on.close()
 
 
