@@ -539,7 +539,7 @@ def parity_burst_slab(w, D):
 
 # every proof, hint and shortcut hnb_ctx_set_option can switch off: what is left is one init, one update, k_count_rows + k_compact per
 # program and frame, per-particle ages and lifetimes, direct spawn stores, one stream
-PLAIN_OPTIONS = {"horizon": 0, "age_cohort": 0, "cull_lifetime": 0, "skip_lists": 0, "stream_hints": 0, "overlap_updates": 0, "spawn_nursery": 0,
+PLAIN_OPTIONS = {"horizon": 0, "age_cohort": 0, "cull_lifetime": 0, "skip_lists": 0, "stream_hints": 0, "overlap_updates": 0,
                  "suffix_proof": 0, "alternate": 0, "transpose": 0, "scene_merge": 0}
 
 
@@ -1132,6 +1132,7 @@ def main():
     if args.comm and not D.on:   # (before the first hnb_comm_* call of the process)
         try:
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # (RCCL's own messages: not into the stream whose last line is the result)
             from bevy_hanabi_amd import runtime as _rt
             _rt.comm_set_library(None, single_rank=True)
         except Exception as e:
@@ -1224,7 +1225,8 @@ def main():
             except OSError as e:
                 print(f"note: could not write {path}: {e}", file=sys.stderr)
         print(text, file=sys.stderr, flush=True)          # the complete record, for a log; stdout carries the short line LAST
-        print(encode_line(short), flush=True)
+        # (the collective library writes its warnings to stdout, some without a trailing newline: the line the driver parses starts on a line of its own)
+        print("\n" + encode_line(short), flush=True)
         rc = 0 if short["parity"]["ok"] is not False else 1
     D.close()
     if _COMM_STUCK:   # (a thread is still inside the collective library: do not wait for it at interpreter shutdown)

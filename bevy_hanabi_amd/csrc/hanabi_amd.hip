@@ -72,20 +72,13 @@ typedef void (*StreamLaunchFn)(uint32_t grid, hipStream_t stream, const SlotArgs
 #ifndef HNB_STREAM_WAVES_COHORT
 #define HNB_STREAM_WAVES_COHORT 4   // 97 VGPRs, no scratch (a 5-wave budget: 96 + 8 bytes of scratch; A/B on one box, profiles/r03f_waves_ab.log: c2 the same, c2_mixed 0.215 vs 0.228 ms)
 #endif
-#ifndef HNB_STREAM_WAVES_NURSERY
-#define HNB_STREAM_WAVES_NURSERY 5   // the plain instantiations with the spawn-record substitution: 96 VGPRs (budgeted for 6 waves they spilled 44 bytes per lane)
-#endif
 template <class PROG, int WAVES>
 void launch_stream(uint32_t grid, hipStream_t stream, const SlotArgs& sa, const uint64_t* inst_base, const DevFrameInst* fi,
                    const uint32_t* ublocks, const CompactBufs& cb) {
     // (the age-cohort paths need more registers: budgeted for 6 waves (80 VGPRs) the per-particle path of the firework kernel spilled 48 bytes
     // per lane to scratch; see HNB_STREAM_WAVES_COHORT)
-    // (... and so does the spawn-record substitution, SlotArgs::nursery: the instantiations without it are the kernels as they were)
-    constexpr int WC = WAVES > HNB_STREAM_WAVES_COHORT ? HNB_STREAM_WAVES_COHORT : WAVES, WN = WAVES > HNB_STREAM_WAVES_NURSERY ? HNB_STREAM_WAVES_NURSERY : WAVES;
-    if (sa.age_cohort && sa.nursery) k_update_slots_stream<PROG, WC, 0, true, true><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
-    else if (sa.age_cohort) k_update_slots_stream<PROG, WC, 0, true, false><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
-    else if (sa.nursery) k_update_slots_stream<PROG, WN, 0, false, true><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
-    else k_update_slots_stream<PROG, WAVES, 0, false, false><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
+    if (sa.age_cohort) k_update_slots_stream<PROG, (WAVES > HNB_STREAM_WAVES_COHORT ? HNB_STREAM_WAVES_COHORT : WAVES), 0, true><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
+    else k_update_slots_stream<PROG, WAVES, 0, false><<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
 }
 #define OP_(x) (uint32_t)HNB_OP_M_##x
 typedef ProgStatic<OP_(AGE_TICK)> ProgAge;                                                        // ribbon.rs
@@ -124,7 +117,6 @@ struct ProgramOptions {
     uint32_t age_cohort = HNB_AGE_COHORT_AUTO;   // HNB_OPT_AGE_COHORT
     bool cull_lifetime = true;                   // HNB_OPT_CULL_LIFETIME
     bool horizon = true;                         // HNB_OPT_HORIZON
-    bool nursery = true;                         // HNB_OPT_SPAWN_NURSERY
 };
 
 // A set module being compiled beside the frames (HNB_SET_MODULE_BACKGROUND). The job owns copies of everything the generated source is made from: the
@@ -226,8 +218,6 @@ struct HnbProgram {
     bool wide_file = false;       // init_regs / update_regs above HNB_VM_MAX_REGS: generic kernels use the wide V file
     uint32_t cull_dt_operand = 0; // lifetime culling: decoded operand a of the update stream's AGE_TICK (dev.cull_lifetime)
     bool update_streams = false;  // update stream runs on the streaming kernel (macro ops, U operands)
-    bool nursery_eligible = false;  // the slab has a spawn nursery and the update kernel knows alive byte 5 (hnb_kernels.hip.h "Spawn nursery"); dev.nursery is per frame
-    uint32_t nursery_frames = 0;    // statistics: frames whose init pass was allowed to write records
     bool auto_materialise = false;  // HNB_AGE_COHORT_AUTO and the render modifiers read AGE: the plane is made current at the end of every frame
     StreamLaunchFn stream_launch = nullptr;  // specialised (or interpreted) streaming kernel for this update stream
     const char* stream_kernel_name = "";
@@ -504,7 +494,7 @@ int validate_stream(const uint8_t* blob_base, const uint8_t* code, uint32_t len,
 // The alive list moves to the other column only in frames where particles died (k_compact). Every section offset is a
 // u32 in the device structs: the layout is computed in 64 bits and rejected as a whole when it does not fit (offsets grow
 // monotonically, so the total bounds every one of them).
-bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgram& d, SortArgs& so, size_t* out_bytes, bool nursery = false) {
+bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgram& d, SortArgs& so, size_t* out_bytes) {
     d.capacity = h.capacity;
     d.n_attrs = h.n_attrs;
     d.n_uregs = h.n_uregs;
@@ -534,13 +524,7 @@ bool layout_slab(const HnbProgramHeader& h, const HnbAttrEntry* attrs, DevProgra
         gsum_off = place(align_up((size_t)8 * ((sort_chunks + kSortGroup - 1) / kSortGroup) * 256 * 4, 256));
         bits_off = place(256);
     }
-    // spawn nursery (hnb_kernels.hip.h): one 32-byte record per slot - LAST in the slab, so that the planes the update streams keep their
-    // offsets (and their placement) whether or not a program is eligible
-    uint64_t nrec_off = 0;
-    if (nursery) nrec_off = place((uint64_t)d.chunks_per_inst * kChunk * 32u);
     if (off > ((uint64_t)0xffffffffu << 8)) return false;   // (offsets are kept in 256-byte units: 1 TiB)
-    d.nursery = nursery ? 1u : 0u;
-    d.nursery_off = soff_of(nrec_off);
     d.alive_off[0] = soff_of(a0); d.alive_off[1] = soff_of(a1); d.dead_off = soff_of(dd);
     for (uint32_t i = 0; i < h.n_attrs; ++i) {
         d.attrs[i].plane_off = soff_of(plane[i]);
@@ -651,7 +635,7 @@ int validate_blob(const void* blob, size_t size, HnbProgramHeader* out_hdr) {
         DevProgram d{};
         SortArgs so{};
         size_t bytes = 0;
-        if (!layout_slab(h, at.data(), d, so, &bytes, /*nursery=*/true)) return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 1 TiB (capacity %u)", h.capacity);
+        if (!layout_slab(h, at.data(), d, so, &bytes)) return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 1 TiB (capacity %u)", h.capacity);
     }
     if (out_hdr) *out_hdr = h;
     return HNB_OK;
@@ -801,21 +785,6 @@ bool age_cohort_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbA
     return true;
 }
 
-// Spawn nursery (hnb_kernels.hip.h): the update must be the streaming kernel and rewrite the POSITION plane (what a record saves is the
-// scattered partial-sector stores of the planes the update streams anyway); a program that emits spawn events is read by its children's
-// init passes in the same init phase (LDPARENT reads the parent's PLANES); a ribbon effect's spawns arrive in slot order, nothing to gain.
-// Only the lean (bandwidth-bound) stacks, as with the age cohorts: the substitution costs the update 11-16 VGPRs, which the force-field kernel
-// (5 waves, 96 VGPRs, VALU-bound) would pay for in scratch.
-bool nursery_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams, const ProgramOptions& opt) {
-    if (!opt.nursery || !streams || h.n_event_channels != 0 || (h.flags & HNB_PROG_HAS_RIBBONS)) return false;
-    const Ins* uc = reinterpret_cast<const Ins*>(b + h.update_off);
-    for (uint32_t i = 0; i < h.update_len; ++i)
-        if (!vm_op_is_lean(uc[i].x & 0xffu)) return false;
-    for (uint32_t a = 0; a < h.n_attrs; ++a)
-        if (attrs[a].reg == HNB_REG_POSITION && (attrs[a].update_flags & HNB_ATTR_UPD_STORE)) return true;
-    return false;
-}
-
 // What to specialise for a program (see hnb_jit.h). `aot_static`: a pre-built ProgStatic kernel matches.
 jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams, bool aot_static, const ProgramOptions& opt) {
     jit::Request rq;
@@ -831,8 +800,6 @@ jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const
     rq.stream_waves = lean ? HNB_STREAM_WAVES : HNB_STREAM_WAVES_FULL;
     rq.stream_cohort = age_cohort_eligible(b, h, attrs, streams, opt);
     if (rq.stream_cohort && rq.stream_waves > HNB_STREAM_WAVES_COHORT) rq.stream_waves = HNB_STREAM_WAVES_COHORT;
-    rq.stream_nursery = nursery_eligible(b, h, attrs, streams, opt);
-    if (rq.stream_nursery && rq.stream_waves > HNB_STREAM_WAVES_NURSERY) rq.stream_waves = HNB_STREAM_WAVES_NURSERY;
     return rq;
 }
 
@@ -908,7 +875,6 @@ jit::Request make_set_request(const Ins* init, uint32_t init_len, const Ins* upd
     rq.want_update_stream = streams;
     rq.want_update_generic = !streams;
     rq.stream_cohort = streams && cohort;
-    rq.stream_nursery = streams;   // (every streaming case carries the spawn-record substitution: whether a member uses it is SlotArgs::nursery)
     rq.wide_file = false;
     return rq;
 }
@@ -997,7 +963,6 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
             return HNB_OK;
         case HNB_OPT_CULL_LIFETIME: ctx->popt.cull_lifetime = value != 0u; return HNB_OK;
         case HNB_OPT_HORIZON: ctx->popt.horizon = value != 0u; return HNB_OK;
-        case HNB_OPT_SPAWN_NURSERY: ctx->popt.nursery = value != 0u; return HNB_OK;
         case HNB_OPT_TEST_BREAK_PROOF: ctx->break_proof = value != 0u; return HNB_OK;
         case HNB_OPT_TRANSPOSE: ctx->transpose = value != 0u; return HNB_OK;
         case HNB_OPT_SCENE_MERGE: ctx->scene_merge = value != 0u; return HNB_OK;
@@ -1040,8 +1005,7 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     DevProgram& d = p->dev;
     size_t slab_bytes = 0;
     p->update_streams = update_is_streamable(b, h, p->attrs.data());
-    p->nursery_eligible = nursery_eligible(b, h, p->attrs.data(), p->update_streams, ctx->popt);
-    if (!layout_slab(h, p->attrs.data(), d, p->sort, &slab_bytes, p->nursery_eligible)) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 1 TiB (capacity %u)", h.capacity); }
+    if (!layout_slab(h, p->attrs.data(), d, p->sort, &slab_bytes)) { delete p; return fail(HNB_ERR_BAD_PROGRAM, "effect slab exceeds 1 TiB (capacity %u)", h.capacity); }
     p->slot_order = ctx->list_order == HNB_LIST_ORDER_SLOT && !(h.flags & HNB_PROG_HAS_RIBBONS);  // ribbons are re-sorted anyway
     p->has_ribbons = (h.flags & HNB_PROG_HAS_RIBBONS) != 0;
     p->slab_bytes = slab_bytes;
@@ -1538,7 +1502,6 @@ static SlotArgs slot_args_of(const HnbContext* ctx, const HnbProgram* p, uint32_
     sa.transpose = ctx->transpose ? 1u : 0u;
     sa.stream_hint = p->plan.stream_hint ? 1u : 0u;
     sa.store_hint = p->plan.store_hint ? 1u : 0u;
-    sa.nursery = p->nursery_eligible ? 1u : 0u; sa.nursery_off = p->dev.nursery_off;   // (eligible: the instantiation that knows alive byte 5; whether THIS frame writes records is DevProgram::nursery)
     for (uint32_t a = 0; a < p->dev.n_attrs; ++a) {
         const DevAttr& at = p->dev.attrs[a];
         const int pi = at.reg == HNB_REG_POSITION ? 0 : at.reg == HNB_REG_VELOCITY ? 1 : at.reg == HNB_REG_AGE ? 2 : at.reg == HNB_REG_LIFETIME ? 3 : -1;
@@ -1719,14 +1682,6 @@ static void stage_program_frame(HnbContext* ctx, HnbProgram* p, uint32_t slot, s
     stage_off += (frame_bytes_for(p, n) + 255u) & ~(size_t)255u;
     pl.init_blocks = blocks;
     p->dev.n_inst = n;
-    {   // spawn nursery, this frame: records pay where spawns are sparse - a frame that may spawn an eighth of the slots or more (a re-burst) would
-        // make the update take several records per lane one after the other, and stores plane by plane instead (both paths leave the same state)
-        uint64_t bound = 0;
-        for (uint32_t i = 0; i < n; ++i)
-            if (inst_frames[i].simulated) bound += inst_frames[i].has_parent ? inst_frames[i].event_capacity : inst_frames[i].spawn_count;
-        p->dev.nursery = (p->nursery_eligible && bound != 0u && bound * 8u <= (uint64_t)n * p->dev.capacity) ? 1u : 0u;
-        p->nursery_frames += p->dev.nursery;
-    }
 
 }
 
@@ -2510,27 +2465,6 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
         }
         s += "\nage cohorts: " + std::to_string(in_cohort) + " of " + std::to_string(prog->effects.size() * (size_t)prog->dev.chunks_per_inst) + " chunks";
         if (prog->auto_materialise) s += " (render modifiers read AGE: the plane is made current after every frame, HNB_AGE_COHORT_AUTO)";
-    }
-    if (prog->nursery_eligible) {   // (debug statistics, as above: slots still marked "record waiting" between frames - none, ever - and how many of a sample of records have been written since the slab was zeroed)
-        hipStreamSynchronize(prog->ctx->stream);
-        const uint32_t cap = prog->dev.capacity, stride = 16u, n_s = (cap + stride - 1u) / stride;
-        std::vector<uint8_t> flags(cap);
-        std::vector<uint32_t> rec((size_t)n_s * 8);
-        size_t waiting = 0, written = 0, sampled = 0;
-        for (const HnbEffect* fx : prog->effects) {
-            const char* slab = static_cast<const char*>(fx->slab);
-            if (hipMemcpy(flags.data(), slab + prog->dev.alive_flag_off, cap, hipMemcpyDeviceToHost) != hipSuccess) break;
-            if (hipMemcpy2D(rec.data(), 32, slab + prog->dev.nursery_off, (size_t)stride * 32, 32, n_s, hipMemcpyDeviceToHost) != hipSuccess) break;
-            for (uint32_t i = 0; i < cap; ++i) waiting += flags[i] == kAliveRecord ? 1u : 0u;
-            for (uint32_t i = 0; i < n_s; ++i) {
-                bool any = false;
-                for (int w = 0; w < 8; ++w) any = any || rec[(size_t)i * 8 + w] != 0u;
-                written += any ? 1u : 0u;
-            }
-            sampled += n_s;
-        }
-        s += "\nspawn nursery: " + std::to_string(written) + " of " + std::to_string(sampled) + " sampled records written, " + std::to_string(waiting) + " records waiting, " +
-             std::to_string(prog->nursery_frames) + " of " + std::to_string(prog->frames_run) + " frames";
     }
     if (prog->has_ribbons && prog->suffix_frames) s += "\ncasualties proven to be the list's last rows (no k_count_rows): " + std::to_string(prog->suffix_frames) + " frames";
     if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->ribbon_facts.front_static ? "" : " (not eligible)");

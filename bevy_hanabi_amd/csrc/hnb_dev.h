@@ -54,12 +54,6 @@ struct DevProgram {
     uint32_t cull_lifetime;    // 1: the streaming update keeps the bounds up to date and uses them
     uint32_t age_cohort;       // 1: chunks whose alive particles share one AGE keep it in a word (hnb_kernels.hip.h "Age cohorts")
     uint32_t stream_hint;      // this frame: list traffic of k_init carries the nontemporal hint (hnb_kernels.hip.h "cache policy of streamed data")
-    // Spawn nursery (hnb_kernels.hip.h "Spawn nursery"). nursery_off: [capacity] records of 32 bytes {position, velocity, age, -}, laid out for
-    // eligible programs (lean streamable update that stores POSITION; no spawn events out, no ribbons; HNB_OPT_SPAWN_NURSERY); nursery: THIS
-    // frame's k_init writes scattered spawns as records (0: every spawn is stored plane by plane - not eligible, or a frame that spawns so
-    // much that the update would take several records per lane).
-    soff_t nursery_off;
-    uint32_t nursery;
     DevAttr attrs[kMaxAttrs];
     const Ins* init_code;
     const Ins* update_code;

@@ -136,31 +136,6 @@ __device__ __forceinline__ uint32_t requested_spawn(const DevFrameInst& f) {
     return n < ev->capacity ? n : ev->capacity;
 }
 
-// ---- spawn nursery ---------------------------------------------------------------------------------------------------------------
-// Spawning into the slots a spawn / die steady state frees is a scatter: the dead list hands the slots out in DEATH order, and with one
-// plane per attribute every 4- or 12-byte store of a spawn is a partial 32-byte sector of its own (firework: 6.5 sectors = 208 B moved per
-// 44-byte spawn, 0.049 ms for 277k spawns per frame at 16.7M slots; profiles/r04y_pmc_*). But the update that follows in the same frame
-// streams every line of the planes it WRITES anyway. So for programs with a streamable update, k_init hands those planes of a scattered
-// spawn to the update instead of storing them: ONE 32-byte record {position, velocity, age} at nursery[slot] - an aligned sector, written
-// whole - and the slot's alive byte says so (5). The lane of the update that owns the slot sees the 5 among the alive bytes it reads anyway,
-// requests the record in front of its plane loads and substitutes it for what the planes held BEFORE the first tick - the reference runs
-// init then update in the same frame too (src/render/mod.rs:7157-7173, :7358-7366); the byte becomes an ordinary 1 with the flag word the
-// update rewrites. No counters, no atomics, no workgroup hand-offs: a record is found by the slot it belongs to.
-//   * Planes the update does not store (LIFETIME: read-only; COLOR, SIZE, ...: never touched) are written by k_init as before.
-//   * Which spawn takes which path is decided per WAVE of k_init: 64 consecutive dead-list rows that hold consecutive slots (a fresh effect:
-//     dead[i] = i; a burst that died in one frame: descending) are stored directly - those stores coalesce - everything else goes through
-//     records; and a frame that spawns an eighth of the capacity or more (a re-burst: up to four records per lane of the update, taken one
-//     after the other) stores directly, decided on the host (DevProgram::nursery is a per-frame flag). Both paths leave the same state.
-//   * Round 5 first built this with a BUCKET of records per 256-slot group, filled through one returning atomic per spawn and routed to the owning
-//     lanes through an LDS map and ds_bpermute: bit-equal, and slower where it mattered - device-scope atomics execute beyond the XCD's L2, 16.7M of
-//     them (a re-burst) took 2.08 ms against 1.52 ms for the plane-granular stores they were meant to beat (profiles/r05a_reburst.log).
-// Eligible: lean streamable update that stores POSITION, no spawn events out (a child's init reads its parent's PLANES in the same init phase), no
-// ribbons; HNB_OPT_SPAWN_NURSERY = 0 switches it off. Costs 32 bytes per slot of slab.
-constexpr uint32_t kAliveRecord = 5u;                         // alive byte: spawned this frame, POSITION / VELOCITY / AGE wait in nursery[slot]
-__host__ __device__ __forceinline__ bool nursery_holds(uint32_t reg, uint32_t upd_flags) {   // does the record carry this pinned plane? (else k_init stores it)
-    return (upd_flags & HNB_ATTR_UPD_STORE) && (reg == HNB_REG_POSITION || reg == HNB_REG_VELOCITY || reg == HNB_REG_AGE);
-}
-
 // ---- code policies -----------------------------------------------------------------------------
 // How the generic kernels run a program. InterpCode interprets the bytecode (always available, any
 // program). The kernels specialised at program creation (hnb_jit.h) supply a policy with the same
@@ -188,13 +163,6 @@ struct InterpCode {
     static __device__ __forceinline__ void store_init(const DevProgram& p, const ST& S, char* base, uint32_t slot) {
         for (uint32_t a = 0; a < p.n_attrs; ++a)
             if (p.attrs[a].reg != HNB_REG_NONE) vfile_store_attr(S.r, p.attrs[a].ncomp, p.attrs[a].reg, base + p.attrs[a].plane_off, slot);
-    }
-    // ... of a spawn that went to the nursery: the pinned planes its record does not carry (nursery_holds)
-    template <class ST>
-    static __device__ __forceinline__ void store_init_rest(const DevProgram& p, const ST& S, char* base, uint32_t slot) {
-        for (uint32_t a = 0; a < p.n_attrs; ++a)
-            if (p.attrs[a].reg != HNB_REG_NONE && !nursery_holds(p.attrs[a].reg, p.attrs[a].upd_flags))
-                vfile_store_attr(S.r, p.attrs[a].ncomp, p.attrs[a].reg, base + p.attrs[a].plane_off, slot);
     }
     template <class ST>
     static __device__ __forceinline__ void load_update(const DevProgram& p, ST& S, const char* base, uint32_t slot, bool valid) {
@@ -318,15 +286,8 @@ __device__ __forceinline__ void init_workgroup(const DevProgram& prog, const uin
     for (uint32_t i0 = p0; i0 < p0 + pass_rows && i0 < n_spawn; i0 += kInitBlock) {
         const uint32_t i = i0 + threadIdx.x;
         uint32_t r_bits = 0xffffffffu;   // (an idle lane)
-        const uint32_t slot = i < n_spawn ? ld_hint(dead + (alive0 + i), prog.stream_hint != 0u) : 0u;
-        // "Spawn nursery": a wave whose 64 rows do not hold consecutive slots (wave-uniform; a wave is active from its first lane) hands the planes
-        // the update rewrites to the update as records
-        bool scattered = false;
-        if (prog.nursery) {
-            const uint32_t ln = threadIdx.x & 63u, first = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-            scattered = __any(i < n_spawn && slot != first + ln) && __any(i < n_spawn && slot != first - ln);
-        }
         if (i < n_spawn) {
+        const uint32_t slot = ld_hint(dead + (alive0 + i), prog.stream_hint != 0u);
         VmState<typename CODE::file_t> S;
         S.r = typename CODE::file_t{};  // var particle = Particle();  (vfx_init.wgsl:174)
         S.pindex = slot + fi[k].slot_base;
@@ -351,17 +312,16 @@ __device__ __forceinline__ void init_workgroup(const DevProgram& prog, const uin
             const uint32_t st = astate[slot / kChunk];
             if (st == 1u || st == 2u) { if (st != 2u) astate[slot / kChunk] = 2u; alive_byte = 3u; }   // (0, 4: the plane holds every age of the chunk)
         }
+        reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = alive_byte;
         if (prog.cull_lifetime) reinterpret_cast<float*>(base + prog.lmin_off)[slot / kChunk] = 0.0f;  // the chunk's lifetime bound is unknown again
-        if (scattered) {   // one aligned 32-byte sector instead of two or three partial ones; the alive byte tells the update where to look
-            u4v* rec = reinterpret_cast<u4v*>(base + prog.nursery_off) + (size_t)slot * 2u;
-            rec[0] = u4v{S.r[HNB_REG_POSITION], S.r[HNB_REG_POSITION + 1], S.r[HNB_REG_POSITION + 2], S.r[HNB_REG_VELOCITY]};
-            rec[1] = u4v{S.r[HNB_REG_VELOCITY + 1], S.r[HNB_REG_VELOCITY + 2], S.r[HNB_REG_AGE], 0u};
-            reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = (uint8_t)kAliveRecord;
-            CODE::store_init_rest(prog, S, base, slot);
-        } else {
-            reinterpret_cast<uint8_t*>(base + prog.alive_flag_off)[slot] = alive_byte;
-            CODE::store_init(prog, S, base, slot);
-        }
+        // (Round 5, built twice and removed: a "spawn nursery" - scattered spawns hand POSITION / VELOCITY / AGE to the same frame's update as ONE
+        // 32-byte record instead of three partial-sector plane stores, the update substitutes them before its first tick. Bit-equal to this on the
+        // whole GPU suite in both forms - records in a bucket per 256-slot group (a returning atomic per spawn, an LDS map + ds_bpermute routing in
+        // the update), and records at nursery[slot] announced by the alive byte (no atomics) - and a loss in both: c2_mixed init 0.049 -> 0.039 /
+        // 0.045 ms, update 0.205 -> 0.232 / 0.252 ms, frame 0.317 -> 0.333 / 0.363 ms on one box; c2_interop's update 0.1625 -> 0.1748 with the
+        // substitution compiled in and never used (registers: 5 waves instead of 6). The init under churn is not bound by its write amplification:
+        // 35 % fewer store sectors bought 9 %. profiles/r05_nursery/.)
+        CODE::store_init(prog, S, base, slot);
         if (prog.horizon) {   // how much clock can pass before this particle may die? (see "death horizons"; f32, rounded towards less)
             const float age0 = u2f(S.r[HNB_REG_AGE]), life = u2f(S.r[HNB_REG_LIFETIME]);
             float r0 = 0.0f;
@@ -1065,8 +1025,6 @@ struct SlotArgs {
     uint32_t transpose;      // 1: vec3 planes of the per-particle path go through the wave's LDS transpose (xpose_load3 / xpose_store3)
     uint32_t stream_hint;    // 1: read-only planes (LIFETIME, alive bytes) are loaded with the nontemporal hint ("cache policy of streamed data")
     uint32_t store_hint;     // 1: the per-particle path stores its planes with the nontemporal hint (update_stream_chunk)
-    uint32_t nursery;        // 1: slots with alive byte 5 have their spawn record in the slab's nursery ("Spawn nursery"; DevProgram::nursery_off is laid out)
-    soff_t nursery_off;
 };
 
 // The deaths of a frame are known on the device only after its update ran, and HIP has no indirect dispatch: the list
@@ -1134,8 +1092,7 @@ __device__ __forceinline__ StreamLds& stream_lds() {
 
 // PROBE (tools/stream_probe.hip only; 0 in the product): 4 = skip stores, 8 = skip the program.
 // COHORT: compile the age-cohort paths in (programs that are eligible: SlotArgs::age_cohort); false leaves the kernel as it was.
-// NURSERY: compile the spawn-record substitution in (programs that are eligible: SlotArgs::nursery); false leaves the kernel as it was.
-template <class PROG, int PROBE, bool COHORT, bool NURSERY = false>
+template <class PROG, int PROBE, bool COHORT>
 __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
                                                     const uint32_t* __restrict__ ublocks, const CompactBufs& cb,
                                                     const uint32_t wg, const uint32_t wg_total) {   // workgroup wg of the program's wg_total (k_update_slots_stream, k_update_stream_jobs)
@@ -1262,16 +1219,13 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
     auto step_body = [&](auto coh_tag, const uint32_t step, const uint32_t f4, const u4v* pre_age = nullptr) {
         constexpr bool COH = decltype(coh_tag)::value;
         const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;  // first of this lane's 4 slots
-        bool was[4], fresh[4];  // fresh: spawned this frame - its age is its own, not the chunk's (alive byte 3 in a cohort chunk, state 2 only; or a spawn record, byte 5)
-        uint32_t pend = 0u;     // NURSERY: bit p - slot p's POSITION / VELOCITY / AGE wait in its spawn record
+        bool was[4], fresh[4];  // fresh: spawned this frame into a chunk that kept its ages in the value word (alive byte 3, state 2 only)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const uint32_t byte = (f4 >> (8 * p)) & 0xffu;
-            const bool rec = NURSERY && byte == kAliveRecord;
-            fresh[p] = (COH && byte == 3u) || rec;
+            fresh[p] = COH && byte == 3u;
             was[p] = byte == 1u || fresh[p];
             lane_alive += was[p] ? 1u : 0u;
-            pend |= rec ? 1u << p : 0u;
         }
         const bool any = was[0] || was[1] || was[2] || was[3];
         if (!__any(any)) {
@@ -1282,14 +1236,6 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         uint32_t slot[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) slot[p] = s0 + p;
-        // the lane's first waiting record, requested in front of the planes (a lane rarely owns more than one fresh slot of a step: the others
-        // follow one by one below)
-        const u4v* nrec = reinterpret_cast<const u4v*>(base + args.nursery_off);
-        u4v rec0 = u4v{0u, 0u, 0u, 0u}, rec1 = u4v{0u, 0u, 0u, 0u};
-        uint32_t take = pend ? (uint32_t)__builtin_ctz(pend) : 4u;
-        if constexpr (NURSERY) {
-            if (pend) { rec0 = nrec[(size_t)(s0 + take) * 2u]; rec1 = nrec[(size_t)(s0 + take) * 2u + 1u]; }
-        }
         bool lanes_on[4] = {any, any, any, any};  // loads: the whole quad whenever one of its slots is alive
         Pinned<4> X;
 #pragma unroll
@@ -1315,53 +1261,31 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
                     else pin_load1<4>(X.age, p_age, slot, lanes_on, true);
                     for (int p = 0; p < 4; ++p) age_was[p] = X.age[p];
                 }
-            }
-        }
-        // (the lifetimes: requested here, in front of the wait for the records, wherever the step cannot do without them anyway - no bound Lm,
-        // or a chunk of mixed ages, which does not ask)
-        auto load_life = [&]() {
-            if (args.stream_hint) {   // (a read-only plane: see "cache policy of streamed data")
-                const u4v ql = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p_life) + (slot[0] >> 2));
-                X.lifetime[0] = u2f(ql.x); X.lifetime[1] = u2f(ql.y); X.lifetime[2] = u2f(ql.z); X.lifetime[3] = u2f(ql.w);
-            } else pin_load1<4>(X.lifetime, p_life, slot, lanes_on, true);
-        };
-        const bool ask_life = cull && Lm > 0.0f && (COH || !mixed);   // (wave-uniform) "can this step lose a particle?" decides below
-        if (!ask_life && any && (fl & 8u)) load_life();
-        if constexpr (NURSERY) {
-            if (__any(pend != 0u)) {   // (wave-uniform) substitute the records for what the planes held
-                for (;;) {
+                if (COH && ast != 0u) {   // (selects, no divergence: ast is uniform, fresh[] only ever set in state 2)
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {   // (selects: `take` is a lane's own)
-                        const bool t = pend != 0u && take == (uint32_t)p;
-                        if (fl & 16u) X.pos[p] = t ? V3{u2f(rec0.x), u2f(rec0.y), u2f(rec0.z)} : X.pos[p];
-                        if (fl & 32u) X.vel[p] = t ? V3{u2f(rec0.w), u2f(rec1.x), u2f(rec1.y)} : X.vel[p];
-                        if (fl & 64u) X.age[p] = t ? u2f(rec1.z) : X.age[p];
-                    }
-                    pend &= pend - 1u;
-                    if (!__any(pend != 0u)) break;
-                    take = pend ? (uint32_t)__builtin_ctz(pend) : 4u;
-                    if (pend) { rec0 = nrec[(size_t)(s0 + take) * 2u]; rec1 = nrec[(size_t)(s0 + take) * 2u + 1u]; }
+                    for (int p = 0; p < 4; ++p) X.age[p] = fresh[p] ? X.age[p] : A;
                 }
             }
-        }
-        if (COH && ast != 0u && any && (fl & 4u)) {   // (selects, no divergence: ast is uniform, fresh[] only ever set in state 2)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) X.age[p] = fresh[p] ? X.age[p] : A;
         }
         // can this step lose a particle? `age + dt` is the AGE_TICK's own arithmetic. (A chunk known to hold mixed ages does not ask: some
         // particle of a step is always near its end there, and the question makes the lifetime loads wait for the ages - a third dependent
         // memory round trip per step.)
-        if (ask_life) {
+        if (cull && Lm > 0.0f && (COH || !mixed)) {
             bool may_die = false;
 #pragma unroll
             for (int p = 0; p < 4; ++p) may_die = may_die || (was[p] && !(X.age[p] + dt_tick < Lm));
             need_life = __any(may_die);
-            if (any && (fl & 8u)) {
-                if (need_life) load_life();
-                else {
+        }
+        if (any && (fl & 8u)) {
+            if (need_life) {
+                if (args.stream_hint) {   // (a read-only plane: see "cache policy of streamed data")
+                    const u4v ql = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p_life) + (slot[0] >> 2));
+                    X.lifetime[0] = u2f(ql.x); X.lifetime[1] = u2f(ql.y); X.lifetime[2] = u2f(ql.z); X.lifetime[3] = u2f(ql.w);
+                } else pin_load1<4>(X.lifetime, p_life, slot, lanes_on, true);
+            }
+            else {
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) X.lifetime[p] = Lm;  // age + dt < Lm holds for every alive slot of the step
-                }
+                for (int p = 0; p < 4; ++p) X.lifetime[p] = Lm;  // age + dt < Lm holds for every alive slot of the step
             }
         }
         if (!need_life) loaded_all = false;
@@ -1427,7 +1351,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         for (int p = 0; p < 4; ++p) {
             const bool died = was[p] && !X.alive[p];
             if (died) { nf &= ~(0xffu << (8 * p)); nib |= 1u << p; }   // the slot is free from now on; the lists learn it from the died bit
-            else if (fresh[p]) nf = (nf & ~(0xffu << (8 * p))) | (1u << (8 * p));   // an ordinary alive slot from now on
+            else if (COH && fresh[p]) nf = (nf & ~(0xffu << (8 * p))) | (1u << (8 * p));   // an ordinary alive slot from now on
             died_here += (uint32_t)__popcll(__ballot(died));
         }
         if (nf != f4) flags4[s0 >> 2] = nf;
@@ -1536,11 +1460,11 @@ steps_done:
     }
 }
 
-template <class PROG, int WAVES, int PROBE = 0, bool COHORT = false, bool NURSERY = false>
+template <class PROG, int WAVES, int PROBE = 0, bool COHORT = false>
 __global__ void __launch_bounds__(kBlock, WAVES)
 k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
                       const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
-    update_stream_chunk<PROG, PROBE, COHORT, NURSERY>(args, inst_base, fi, ublocks, cb, blockIdx.x, gridDim.x);
+    update_stream_chunk<PROG, PROBE, COHORT>(args, inst_base, fi, ublocks, cb, blockIdx.x, gridDim.x);
 }
 
 // Any update program on the V register file: one slot per lane, same protocol.
@@ -1777,10 +1701,10 @@ k_update_jobs(const StreamJob* __restrict__ sj0, uint32_t n0, const StreamJob* _
               uint32_t b0, uint32_t b1) {
     if (blockIdx.x < b0) {
         const StreamJob& jb = job_of_workgroup_t(sj0, n0);
-        update_stream_chunk<ProgInterp, 0, false, true>(jb.args, jb.inst_base, jb.fi, jb.ublocks, jb.cb, blockIdx.x - jb.first_wg, jb.n_wg);
+        update_stream_chunk<ProgInterp, 0, false>(jb.args, jb.inst_base, jb.fi, jb.ublocks, jb.cb, blockIdx.x - jb.first_wg, jb.n_wg);
     } else if (blockIdx.x < b1) {
         const StreamJob& jb = job_of_workgroup_t(sj1, n1);
-        update_stream_chunk<ProgInterp, 0, true, true>(jb.args, jb.inst_base, jb.fi, jb.ublocks, jb.cb, blockIdx.x - jb.first_wg, jb.n_wg);
+        update_stream_chunk<ProgInterp, 0, true>(jb.args, jb.inst_base, jb.fi, jb.ublocks, jb.cb, blockIdx.x - jb.first_wg, jb.n_wg);
     } else {
         const ProgJob& jb = job_of_workgroup_t(pj, np);
         const uint32_t w = blockIdx.x - jb.first_wg, sub = w % kGenericSubs;

@@ -320,13 +320,6 @@ int hnb_ctx_synchronize(HnbContext* ctx);
  *   and an effect whose pipelines are not ready is SKIPPED, src/render/mod.rs:3852-3900; here it is simulated from its first frame.) hnb_ctx_destroy waits
  *   for a compilation in flight. */
 #define HNB_OPT_JIT_ASYNC 13u
-/* HNB_OPT_SPAWN_NURSERY (fixed in a program when it is created; default 1): spawns into SCATTERED free slots (the dead list of an effect in a
- *   spawn / die steady state hands its slots out in death order) do not store the planes the update rewrites: the init pass writes one 32-byte
- *   record {slot, position, velocity, age} per spawn and the update of the same frame - which streams every line of those planes anyway -
- *   substitutes it before its first tick (the reference runs init then update in the same frame: src/render/mod.rs:7157-7173, 7358-7366).
- *   Spawns into consecutive slots (a fresh effect) are stored directly, as with 0. Same state after every frame either way. Eligible programs:
- *   streamable update that stores POSITION, no spawn events out, no ribbons; costs 32 bytes per slot of slab. */
-#define HNB_OPT_SPAWN_NURSERY 14u
 /* HNB_OPT_TEST_BREAK_PROOF (default 0): a TEST HOOK, never for production. 1 = every frame that spawns nothing is treated as proven to have no
  *   casualty (HNB_OPT_SKIP_LISTS's proof, claimed without evidence). A particle that dies in such a frame raises HnbEffectMetadata::fault and
  *   leaves the lists stale: what hnb_effect_check, hnb_effect_compare and bench.py's parity gate exist to notice, and are tested with. */

@@ -46,7 +46,7 @@ def main():
     maps = open("/proc/self/maps").read()
     out["librccl_mapped"] = sorted({ln.split()[-1] for ln in maps.splitlines() if "librccl" in ln})
     ctx.close()
-    print(json.dumps(out))
+    print("\n" + json.dumps(out), flush=True)   # (RCCL writes warnings to stdout, some without a trailing newline)
 
 
 if __name__ == "__main__":

@@ -56,7 +56,7 @@ def test_the_real_librccl_reduces_a_one_context_communicator():
     ncclSum) on the context's stream -> ncclCommDestroy had run zero times on hardware. HNB_COMM_LIB_SINGLE_RANK makes a communicator of one
     context take that branch: on the one-GPU box every call executes against the real library."""
     import sys
-    env = dict(os.environ, NCCL_SOCKET_IFNAME=os.environ.get("NCCL_SOCKET_IFNAME", "lo"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, NCCL_SOCKET_IFNAME=os.environ.get("NCCL_SOCKET_IFNAME", "lo"), HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG_FILE="/dev/stderr")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "real_rccl", "run_real_comm.py")], capture_output=True, text=True, timeout=540, env=env)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     out = json.loads(r.stdout.strip().splitlines()[-1])

@@ -15,7 +15,7 @@ from helpers import Frame, GpuRunner, OracleRunner, assert_same_state, frame_see
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
-PLAIN = {"horizon": 0, "age_cohort": 0, "cull_lifetime": 0, "skip_lists": 0, "stream_hints": 0, "overlap_updates": 0, "spawn_nursery": 0,
+PLAIN = {"horizon": 0, "age_cohort": 0, "cull_lifetime": 0, "skip_lists": 0, "stream_hints": 0, "overlap_updates": 0,
          "suffix_proof": 0, "alternate": 0, "transpose": 0, "scene_merge": 0}
 
 
