@@ -266,6 +266,7 @@ struct HnbProgram {
     uint32_t parity = 0;
     uint32_t frames_run = 0;    // frames this program was simulated in: the chunk walk alternates its direction with it
     uint32_t merged_frames = 0;             // statistics
+    uint32_t unmerged_frames = 0;           // statistics: frames in which the program stayed out of the shared launches because the loaded set module does not know it
     bool horizon_eligible = false;          // streamable, lifetime-culled, no kill modifier, no ribbons: row-chunk death horizons are maintained (hnb_kernels.hip.h)
     uint32_t hz_parity = 0;                 // which half of the horizon arrays is current (flips in frames whose list kernels ran)
     uint32_t hz_frames = 0;                 // statistics: frames in which the horizons were in use
@@ -1825,6 +1826,18 @@ static void fill_merge_jobs(HnbContext* ctx, const std::vector<HnbProgram*>& ord
     bool any_merged = false;
     for (size_t i = 0; i < order.size(); ++i) { order[i]->plan.merge = decisions[i]; any_merged = any_merged || decisions[i].init_family >= 0 || decisions[i].update_family >= 0; }
     if (any_merged) refresh_set_module(ctx, order, facts);
+    {   // programs the loaded module does not know: out of the shared launches while they are few (plan::split_uncovered)
+        std::vector<uint8_t> has_case(order.size()), own(order.size()), out(order.size());
+        for (size_t i = 0; i < order.size(); ++i) {
+            HnbProgram* p = order[i];
+            has_case[i] = ctx->set.module && set_case_of(ctx, p) != kNoSetCase ? 1u : 0u;
+            const bool aot_static = p->update_streams && strcmp(p->stream_kernel_name, "ProgInterp") != 0;
+            own[i] = ((p->jit_init || p->hdr.init_len == 0u) && (p->jit_update || aot_static || p->hdr.update_len == 0u)) ? 1u : 0u;   // (nothing of it would be interpreted)
+        }
+        plan::split_uncovered(decisions.data(), has_case.data(), own.data(), (uint32_t)order.size(), ctx->set.module != nullptr, out.data());
+        for (size_t i = 0; i < order.size(); ++i)
+            if (out[i]) { order[i]->plan.merge = plan::MergeDecision(); order[i]->unmerged_frames += 1; }
+    }
     bool init_cased = ctx->set.module != nullptr, update_cased = ctx->set.module != nullptr;
     // k_update_jobs serves streaming (no cohorts), streaming (cohorts), V register file (narrow) in this order: first_wg runs over its whole grid
     const int seq[6][2] = {{0, 0}, {0, 1}, {2, plan::kStream}, {2, plan::kStreamCohort}, {1, plan::kGeneric}, {1, plan::kGenericWide}};   // {kind: 0 init / 1 generic / 2 stream, family}
@@ -2469,6 +2482,7 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
     if (prog->has_ribbons && prog->suffix_frames) s += "\ncasualties proven to be the list's last rows (no k_count_rows): " + std::to_string(prog->suffix_frames) + " frames";
     if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->ribbon_facts.front_static ? "" : " (not eligible)");
     if (prog->merged_frames) s += "\nupdate served by a merged launch (small programs of the context share one): " + std::to_string(prog->merged_frames) + " frames";
+    if (prog->unmerged_frames) s += "\nkept out of the shared launches (the loaded set module does not know this program; its own specialised kernels): " + std::to_string(prog->unmerged_frames) + " frames";
     if (prog->set_frames) s += "\n... by the context's set module (the program's specialised code behind the shared launch): " + std::to_string(prog->set_frames) + " frames";
     if (!prog->ctx->set_log.empty() && !prog->set_sig.empty()) s += "\nset module: " + prog->ctx->set_log;
     if (prog->ctx->set_failed_builds && !prog->set_sig.empty()) s += "\nset module builds that failed: " + std::to_string(prog->ctx->set_failed_builds);

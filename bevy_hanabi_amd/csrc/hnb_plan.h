@@ -13,6 +13,7 @@
 //   use_streaming_hints   cache policy: is the program big enough for its list traffic to be streamed past the Infinity Cache
 //   partition_init_passes which init passes stay in front of the fork behind a heavy program's own init (parents first; nobody beside its update)
 //   set_lookup_due        when a context looks the set module of its small programs up (once per population, after two merged frames)
+//   split_uncovered       which programs a loaded set module does not know stay out of the shared launches (so that the others keep their set kernels)
 //
 // What each proof assumes about the device code is stated at the device side (hnb_kernels.hip.h); a wrong proof is reported by the
 // kernels through HnbEffectMetadata::fault, never silently.
@@ -239,6 +240,29 @@ inline void plan_merged_launches(const MergeFacts* progs, MergeDecision* out, ui
         if (fi >= 0 && n_init[fi] >= 2u) out[i].init_family = (int8_t)fi;
         if (fu == kGenericWide ? n_upd[kGenericWide] >= 2u : (fu >= 0 && shared_update)) out[i].update_family = (int8_t)fu;
     }
+}
+
+// ---- a scene that has outgrown its set module (fill_merge_jobs) -----------------------------------------------------------------------------------
+// A shared launch runs on the set kernels only if EVERY job of it has a case in the loaded module; one program without a case - an effect that
+// joined a running scene - used to send the whole scene back to the byte-code interpreters until a module for the new set existed (65 s of hiprtc for
+// 27 programs). The reference compiles one pipeline per effect and an added effect costs one more pipeline, nobody else's
+// (src/render/mod.rs:3852-3900). Counterpart: a few newcomers with kernels of their own (every program is specialised at creation: hnb_jit.h) are LEFT
+// OUT of the shared launches - their own launches, their own specialised code, from their first frame - while the covered programs stay on the set
+// kernels; the module of the grown set is looked up / compiled beside the frames as before and takes everybody back in when it is there.
+// Only where the covered programs are the clear majority (>= 4x): a context whose population changed wholesale keeps sharing its launches on the
+// interpreters, which beats one launch per program. out[i] = 1: program i stays out of the shared launches this frame.
+inline void split_uncovered(const MergeDecision* dec, const uint8_t* has_case, const uint8_t* has_own_kernels, uint32_t n, bool module_loaded, uint8_t* out) {
+    for (uint32_t i = 0; i < n; ++i) out[i] = 0u;
+    if (!module_loaded) return;
+    auto in_set_launch = [&](uint32_t i) { return dec[i].init_family == 0 || (dec[i].update_family >= 0 && dec[i].update_family != kGenericWide); };
+    uint32_t covered = 0, uncovered = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!in_set_launch(i)) continue;
+        if (has_case[i]) covered += 1; else uncovered += 1;
+    }
+    if (uncovered == 0u || covered < 2u || covered < 4u * uncovered) return;
+    for (uint32_t i = 0; i < n; ++i)
+        if (in_set_launch(i) && !has_case[i] && has_own_kernels[i]) out[i] = 1u;
 }
 
 // ---- which init passes stay in front of the fork (enqueue_init_passes) -------------------------------------------------------------------------

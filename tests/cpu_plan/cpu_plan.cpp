@@ -82,6 +82,12 @@ void cpl_merge(const MergeRow* rows, uint32_t n, int option, int timed, int32_t*
 }
 
 void cpl_partition_init_passes(const uint8_t* reads, uint32_t n, int heavy, uint8_t* side) { partition_init_passes(reads, n, heavy, side); }
+// dec: [n][2] = {init_family, update_family}
+void cpl_split_uncovered(const int32_t* dec, const uint8_t* has_case, const uint8_t* own, uint32_t n, int module_loaded, uint8_t* out) {
+    MergeDecision d[64];
+    for (uint32_t i = 0; i < n && i < 64u; ++i) { d[i].init_family = (int8_t)dec[2 * i]; d[i].update_family = (int8_t)dec[2 * i + 1]; }
+    split_uncovered(d, has_case, own, n < 64u ? n : 64u, module_loaded != 0, out);
+}
 void* cpl_set_lookup_new() { return new SetLookupState(); }
 void cpl_set_lookup_free(void* h) { delete static_cast<SetLookupState*>(h); }
 void cpl_set_lookup_reset_tried(void* h) { static_cast<SetLookupState*>(h)->tried = 0; }

@@ -25,10 +25,29 @@ def worst_case_record():
         v["parity"] = par(name, True)
         v["roofline"]["kernel_ms_rocprof"] = 0.2123456789
         v["roofline"]["rocprof_detail"] = copy.deepcopy(full["roofline"]["rocprof_detail"])
+    for extra in ("c2_view", "c2_interop_view"):               # (round 5's end-to-end rows)
+        full["configs"][extra] = copy.deepcopy(full["configs"]["c2_interop"])
+        full["configs"][extra]["parity"]["config"] = extra
+    for name in ("c2_mixed", "c2_dieoff", "c2_events", "c5"):   # (round 5: the churn configurations' gate on the timed state at full size)
+        if name in full["configs"]:
+            full["configs"][name]["parity"]["timed_state"] = {"ok": True, "checks": [{"ok": 1, "alive_count": 16499355}] * 3, "diffs": [{"equal": 1, "first_section": -1}] * 3,
+                                                              "problems": [], "plain_kernels": "k" * 200, "seconds": 3.14159}
+    full["comm"] = {"library": "/usr/local/lib/python3.10/dist-packages/torch/lib/librccl.so", "ranks": 1, "effects": 1, "alive_total": 16777216}
     full["config"]["workload"] += " " + "w" * 100
+    return full
+
+
+def test_the_multi_rank_line_carries_the_strong_scaling_run():
+    """N > 1: no extra configurations, no scene, no cpu baseline - and the strong-scaling run of the same configuration."""
+    full = worst_case_record()
+    for k in ("configs", "small_effects_scene", "cpu_baseline", "comm"):
+        full.pop(k, None)
+    full["n_gpus"] = 8
     full["strong"] = {"value": 1.23456789e11, "ms_per_step": 0.123456789, "capacity_per_gpu": 2097152, "instances_per_gpu": 1, "kernel_ms_avg": 0.0123456789,
                       "algorithmic_whole_step_over_aggregate_peak": 0.123456789, "workload": "the N = 1 workload split over the ranks"}
-    return full
+    args = argparse.Namespace(parity=True, full_json=os.path.join(ROOT, "profiles", "bench_full.json"))
+    line = bench.short_line(full, args)
+    assert line["strong"]["capacity_per_gpu"] == 2097152 and "workload" not in line["strong"] and len(bench.encode_line(line)) < 4096
 
 
 def test_short_line_fits_the_driver_tail_and_carries_the_contract():
@@ -40,20 +59,23 @@ def test_short_line_fits_the_driver_tail_and_carries_the_contract():
     assert len(text) < 6000
     line = json.loads(text)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-              "roofline", "cpu_baseline", "parity", "configs", "build"):
+              "roofline", "cpu_baseline", "parity", "configs", "build", "comm"):
         assert k in line, k
     assert line["config"]["workload"] and "model" not in line["config"]
     ro = line["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg", "kernel_ms_rocprof"):
         assert k in ro, k
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
-    assert ro["algorithmic"]["bytes_per_update"] == 68 and "frac" in ro["whole_step"]
+    assert ro["algorithmic_bytes_per_update"] == 68 and "whole_step_frac" in ro and "algorithmic_whole_step_over_peak" in ro
+    assert all(not isinstance(v, (dict, list)) for v in ro.values()), "roofline must stay flat: the driver keeps its scalar members only"
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == cb["threads"] and cb["host_physical_cores"] and "cpu_model" in cb and cb["sample"]
     assert line["parity"]["ok"] is True and set(line["parity"]["checked"]) == {"c2"} | set(full["configs"])
+    assert line["parity"]["churn"].startswith("timed state: invariants + plain-path differential at full size") and line["parity"]["timed_state"]["ok"] is True
+    assert line["comm"]["ranks"] == 1 and "librccl" in line["comm"]["library"]
     assert set(line["configs"]) == set(full["configs"])
     for row in line["configs"].values():
-        assert {"value", "ms_per_step", "frac", "whole_step_frac", "kernel_ms", "kernel_ms_rocprof", "parity"} <= set(row)
+        assert {"value", "ms_per_step", "frac", "ws_frac", "ws68", "kernel_ms", "kernel_ms_rocprof"} <= set(row)
     assert len(line["windows"]["ms_per_step_min_median_max"]) == 3
     assert line["value"] == full["value"]                      # the headline is not rounded
 

@@ -50,6 +50,7 @@ def lib():
     lib.cpl_store_hints.argtypes = [C.c_uint64, C.c_uint32]
     lib.cpl_merge.argtypes = [C.POINTER(MergeRow), C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int32)]
     lib.cpl_partition_init_passes.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+    lib.cpl_split_uncovered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
     lib.cpl_set_lookup_new.restype = C.c_void_p
     lib.cpl_set_lookup_free.argtypes = [C.c_void_p]
     lib.cpl_set_lookup_reset_tried.argtypes = [C.c_void_p]
@@ -367,3 +368,29 @@ def test_a_population_is_looked_up_once_after_two_frames(lib):
     lib.cpl_set_lookup_reset_tried(h)        # a background compilation finished: look again, even at the same population
     assert due(11)
     lib.cpl_set_lookup_free(h)
+
+
+# ---- split_uncovered: a scene that has outgrown its set module ---------------------------------------------------------------------------------
+def _split(lib, progs, loaded=1):
+    """progs: (init_family, update_family, has_case, has_own_kernels) per program -> which stay out of the shared launches"""
+    n = len(progs)
+    dec = np.array([[p[0], p[1]] for p in progs], dtype=np.int32)
+    case = np.array([p[2] for p in progs], dtype=np.uint8)
+    own = np.array([p[3] for p in progs], dtype=np.uint8)
+    out = np.zeros(n, dtype=np.uint8)
+    lib.cpl_split_uncovered(dec.ctypes.data, case.ctypes.data, own.ctypes.data, n, loaded, out.ctypes.data)
+    return [int(x) for x in out]
+
+
+def test_a_newcomer_stays_out_so_that_the_covered_programs_keep_their_set_kernels(lib):
+    STREAM, COHORT, GENERIC, WIDE = 0, 1, 2, 3
+    covered = [(0, STREAM, 1, 1)] * 3 + [(0, COHORT, 1, 1)] * 2 + [(-1, GENERIC, 1, 1)]         # six programs the loaded module knows
+    assert _split(lib, covered + [(0, STREAM, 0, 1)]) == [0] * 6 + [1]                            # the 7th joined the scene: out, the six stay
+    assert _split(lib, covered + [(0, STREAM, 0, 1)], loaded=0) == [0] * 7                         # no module: everybody shares the interpreters
+    assert _split(lib, covered) == [0] * 6                                                         # everybody covered: nothing to do
+    assert _split(lib, covered + [(0, STREAM, 0, 0)]) == [0] * 7                                   # a newcomer WITHOUT kernels of its own (HNB_JIT=0, specialisation pending) would be interpreted either way: it stays in
+    assert _split(lib, covered + [(0, STREAM, 0, 1), (-1, GENERIC, 0, 1)]) == [0] * 8              # two newcomers against six: not a clear majority (< 4x), the launches stay shared
+    assert _split(lib, covered + covered[:2] + [(0, STREAM, 0, 1), (-1, GENERIC, 0, 1)]) == [0] * 8 + [1, 1]   # ... against eight: out
+    assert _split(lib, [(0, STREAM, 1, 1), (0, STREAM, 0, 1)]) == [0, 0]                            # one covered program is not a set
+    assert _split(lib, covered + [(1, WIDE, 0, 1)]) == [0] * 7                                     # the wide register file never runs on the set kernels: not its concern
+    assert _split(lib, covered + [(-1, -1, 0, 1)]) == [0] * 7                                      # a program that is not merged this frame anyway

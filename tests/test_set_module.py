@@ -153,10 +153,13 @@ def test_gpu_a_program_created_later_runs_interpreted_until_its_set_has_a_module
     sc.step(24)
     after = sc.set_frames()
     assert after[3] >= 20 and min(a - b for a, b in zip(after[:3], before)) >= 20
-    sc.add(effects.single_particle(16))          # a set of five nobody compiled: CACHED never compiles on the frame path
+    sc.add(effects.single_particle(16))          # a set of five nobody compiled: CACHED never compiles on the frame path ...
     sc.step(24)
-    stalled = sc.set_frames()
-    assert stalled[4] == 0 and max(s - a for s, a in zip(stalled[:4], after)) <= 2, (after, stalled)
+    grown = sc.set_frames()
+    # ... and (round 5) the four it knows do NOT fall back to the interpreters because a fifth joined: the newcomer runs its own specialised kernels in its
+    # own launches (plan::split_uncovered) and the shared launches stay on the set kernels
+    assert grown[4] == 0 and min(g - a for g, a in zip(grown[:4], after)) >= 20, (after, grown)
+    assert "kept out of the shared launches" in sc.runs[4].prog.kernel_info() and "kept out" not in sc.runs[0].prog.kernel_info()
     assert "no cache entry for this set of 5 programs" in sc.runs[0].prog.kernel_info()
     sc.check()
 

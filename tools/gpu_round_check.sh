@@ -1,11 +1,19 @@
 #!/bin/bash
-# Development tool (GPU box): the end-of-round check in one gpurun call: GPU tests, smoke, the default bench line, and the
-# profiles of the bench command (kernel stats + the two PMC passes -> profiles/traffic.json). Usage: gpu_round_check.sh <tag>
-TAG=${1:-r02}
+# Development tool (GPU box): the end-of-round check in one gpurun call: the GPU suite, smoke, the default bench line (its own two PMC passes kept as
+# CSVs), and the rocprofv3 kernel statistics of the headline configuration. Usage: gpu_round_check.sh <tag>   ->  gpurun_out/<tag>_*
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/${TAG}_pytest.log; cat gpurun_out/${TAG}_pytest.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -c 700 gpurun_out/${TAG}_bench.json
-timeout 300 python bench.py --gpus 2 --backend gloo --force-device 0 --steps 10 > gpurun_out/${TAG}_bench_n2_dryrun.json 2> gpurun_out/${TAG}_bench_n2_dryrun.err; tail -c 400 gpurun_out/${TAG}_bench_n2_dryrun.json
-timeout 300 python tools/scene_bench.py 1 600 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_scene.log; timeout 300 python tools/scene_bench.py 4 300 2>&1 | grep -v amdgpu.ids >> gpurun_out/${TAG}_scene.log; cat gpurun_out/${TAG}_scene.log
-bash tools/prof_bench.sh $TAG 2>&1 | tail -26
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -rf -p no:cacheprovider 2>&1 | tail -80 > gpurun_out/${TAG}_pytest.log; tail -8 gpurun_out/${TAG}_pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/${TAG}_smoke.log
+timeout 900 python bench.py --keep-pmc gpurun_out/${TAG}_pmc > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; tail -c 1500 gpurun_out/${TAG}_bench.json
+cp profiles/bench_full.json gpurun_out/${TAG}_bench_full.json 2>/dev/null
+export TMPDIR=/tmp; cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python $R/bench.py --no-extra-configs --no-scene --no-cpu-baseline --pmc off --no-comm --full-json /tmp/x.json < /dev/null > $R/gpurun_out/${TAG}_stats_bench.json 2> $R/gpurun_out/${TAG}_stats_bench.err
+f=$(find $R/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" $R/gpurun_out/${TAG}_kernel_stats.csv && python3 - "$f" <<'PY' | tee $R/gpurun_out/${TAG}_kernel_stats.txt
+import csv,sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if float(r["Percentage"]) > 0.05 or "k_" in r["Name"]:
+        print("%-90s calls %5s avg %9.2f us min %9.2f max %9.2f  %5.1f%%"%(r["Name"][:90], r["Calls"], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3, float(r["MaxNs"])/1e3, float(r["Percentage"])))
+PY
+rm -rf $R/gpurun_out/prof_$TAG
