@@ -105,11 +105,11 @@ CONFIGS = {
                       workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst; frames 48..70 at 1/60 s: the die-off (list kernels every frame)"),
     "c2_interop": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=56, kernel="k_update_slots_stream<ProgDragAccel>",
                        workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst, all alive, hnb_ctx_set_option(HNB_OPT_AGE_COHORT, OFF) (AGE plane current every frame)"),
-    "c2_view": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=52, kernel="k_update_slots_stream<ProgDragAccel, cohort>",
+    "c2_view": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=56, kernel="k_update_slots_stream<ProgDragAccel>",
                     workload="firework.rs trails EffectAsset END TO END: capacity={cap:_} per GPU, burst, all alive, the library's default HNB_AGE_COHORT_AUTO (the asset's ColorOverLifetime / "
-                             "SizeOverLifetime read AGE: cohorts + the AGE plane made current every frame) + a consumer kernel behind every frame that gathers position / age / lifetime by list row through hnb_effect_device_view"),
-    "c2_interop_view": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=56, kernel="k_update_slots_stream<ProgDragAccel>",
-                            workload="as c2_view with HNB_AGE_COHORT_OFF (per-particle ages in the plane, nothing to materialise) + the same consumer kernel behind every frame"),
+                             "SizeOverLifetime read AGE: per-particle ages stay in the plane) + a consumer kernel behind every frame that gathers position / age / lifetime by list row through hnb_effect_device_view"),
+    "c2_lean_view": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=52, kernel="k_update_slots_stream<ProgDragAccel, cohort>",
+                         workload="as c2_view with HNB_AGE_COHORT_LEAN + hnb_effect_materialise(AGE) every frame + the same consumer kernel: the alternative AUTO does not pick"),
     "c2_events": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=62, kernel="k_update_slots_stream<ProgDragAccel, cohort> (trails)",
                       workload="the real examples/firework.rs: rocket (capacity 32_768, 16_000 rockets/s) -> sparkle_trail (1_048_576; 5 spawn events per rocket and frame) + "
                                "trails (capacity={cap:_}; 1000 spawn events per dying rocket), GPU spawn events, steady state"),
@@ -120,10 +120,10 @@ CONFIGS = {
     "c5": dict(capacity=1 << 22, bytes_per_update=20, bytes_per_spawn=36, model_bytes=9, kernel="k_update_slots_stream<ProgAge>",
                workload="ribbon.rs EffectAsset, capacity={cap:_} per GPU, rate spawner in steady spawn/kill churn, ribbon sort in the step"),
 }
-EXTRA_CONFIGS = ("c2_mixed", "c2_dieoff", "c2_interop", "c2_view", "c2_interop_view", "c2_events", "c3", "c4", "c5")   # appended to the N = 1 default line
+EXTRA_CONFIGS = ("c2_mixed", "c2_dieoff", "c2_interop", "c2_view", "c2_lean_view", "c2_events", "c3", "c4", "c5")   # appended to the N = 1 default line
 # what identifies the dominant kernel of a configuration in a rocprofv3 dispatch list
 KERNEL_MATCH = {"c2_events": ("k_update_slots_stream",), "c2": ("k_update_slots_stream",), "c2_mixed": ("k_update_slots_stream",), "c2_dieoff": ("k_update_slots_stream",),
-                "c2_interop": ("k_update_slots_stream",), "c2_view": ("k_update_slots_stream",), "c2_interop_view": ("k_update_slots_stream",), "c3": ("k_update_slots_stream",), "c4": ("k_update_slots_stream",), "c5": ("k_update_slots_stream",)}
+                "c2_interop": ("k_update_slots_stream",), "c2_view": ("k_update_slots_stream",), "c2_lean_view": ("k_update_slots_stream",), "c3": ("k_update_slots_stream",), "c4": ("k_update_slots_stream",), "c5": ("k_update_slots_stream",)}
 
 
 def frame_dt(total_frames, safe_seconds=MIN_LIFETIME * 0.95):
@@ -354,12 +354,17 @@ class Workload:
         n = D.world
         base_cap = args.capacity or cfg["capacity"]
         self.ctx = bh.Context(D.device_index)
+        if name not in ("c2_view", "c2_interop"):
+            # HNB_AGE_COHORT_LEAN: the simulation alone (a headless host: nobody reads AGE between frames), as every round measured it. The library's default
+            # (AUTO) looks at the asset's render modifiers - ColorOverLifetime on these assets reads AGE - and is what c2_view runs: the asset end to end
+            self.ctx.set_option("age_cohort", 1)
         for k, v in (options or {}).items():   # (the parity gate's plain replay: every proof and hint off; a test's broken proof)
             self.ctx.set_option(k, v)
         self.per_inst_cap = base_cap
         self.spawner = self.rng = None
         self.xf_of = None
         self.family = "c2" if name.startswith("c2") else name
+
         self.shadow = None       # parity gate: callable(f, dt, [(spawn, seed, transform) per effect]) stepped in lockstep with the GPU
         self.assets, self.event_caps, self.slot_base = [], [None, None, None], 0
         if name == "c4":
@@ -407,10 +412,8 @@ class Workload:
                 asset = effects.firework_trails(cap)
             else:
                 asset = {"c3": effects.force_field, "c5": effects.ribbon}[name](cap)
-            if name in ("c2_interop", "c2_interop_view"):
+            if name == "c2_interop":
                 self.ctx.set_option("age_cohort", 0)   # HNB_AGE_COHORT_OFF, fixed in the program at creation: the AGE plane is current after every frame
-            elif name == "c2":
-                self.ctx.set_option("age_cohort", 1)   # HNB_AGE_COHORT_LEAN: the simulation alone (a headless host: nobody reads AGE between frames). c2_view is the asset end to end
             self.prog = self.ctx.create_program(bh.lower(asset))
             self.fxs = [self.prog.create_effect(slot_base=slot_base)]
             self.assets, self.slot_base = [asset], slot_base
@@ -463,6 +466,8 @@ class Workload:
                 self.shadow(f, dt, inputs)
         ctx.simulate()
         if self.consumer is not None:   # enqueued on the simulation stream right behind the frame: no synchronisation, no host copy
+            if self.name == "c2_lean_view":
+                self.fxs[0].materialise([4])   # HNB_ATTR_AGE: the cohort chunks' common age written out for the consumer
             v = self.fxs[0].device_view()
             assert v.stale_attr_mask == 0 or self.name != "c2_view", "HNB_AGE_COHORT_AUTO left AGE stale for an asset whose render modifiers read it"
             rc = self.consumer.consumer_render_like(self._byref(v), self.consumer_out.data_ptr())
@@ -481,7 +486,7 @@ class Workload:
 # ------------------------------------------------------------------------------------------------------------------
 PARITY_BUDGET_S = 0.5          # oracle time per configuration (the slab / the reduced capacity is sized to the oracle's measured speed)
 PARITY_KEYS = ("capacity", "alive_count", "max_update", "max_spawn", "indirect_write_index", "particle_counter", "instance_count", "dead_count")
-BURST_PARITY = ("c2", "c2_interop", "c2_view", "c2_interop_view", "c3", "c4")
+BURST_PARITY = ("c2", "c2_interop", "c2_view", "c2_lean_view", "c3", "c4")
 _ORACLE_RATE = None
 
 
@@ -705,7 +710,7 @@ def run_config(name, args, D, strong=False, pmc=None):
     warmup = warmup_frames(name, args.warmup)
     if name == "c2_dieoff":
         steps = DIEOFF_LAST - DIEOFF_FIRST + 1           # a window is the die-off itself, not K steps
-    elif name in ("c2", "c2_interop", "c2_view", "c2_interop_view"):
+    elif name in ("c2", "c2_interop", "c2_view", "c2_lean_view"):
         w.dt = frame_dt(1 + warmup + steps * windows)    # nobody may die in the timed frames
     elif name in BURST_SAFE_SECONDS:
         w.dt = frame_dt(1 + warmup + steps * windows, BURST_SAFE_SECONDS[name])
@@ -809,7 +814,7 @@ def run_config(name, args, D, strong=False, pmc=None):
     w.close()
 
     alive0_total, alive1_total = D.sum_counts([alive0, alive1])
-    if name in ("c2", "c2_interop", "c2_view", "c2_interop_view", "c4"):
+    if name in ("c2", "c2_interop", "c2_view", "c2_lean_view", "c4"):
         expect = w.local_particles if not D.on else None
         assert expect is None or (alive0 == expect and alive1 == expect), f"{name}: expected every particle alive during the timed frames, got {alive0}, {alive1}"
     if D.rank != 0:
@@ -1257,11 +1262,17 @@ def main():
             except OSError as e:
                 print(f"note: could not write {path}: {e}", file=sys.stderr)
         print(text, file=sys.stderr, flush=True)          # the complete record, for a log; stdout carries the short line LAST
-        # (the collective library writes its warnings to stdout, some without a trailing newline: the line the driver parses starts on a line of its own)
+        # The collective library (librccl, loaded for `comm`) prints a banner and warnings through C stdio into this process's stdout: buffered there, they
+        # would land BEHIND this line when the process exits (seen: "Librccl path : ..." as the last line of a run). Flush C stdio first, start on a fresh line.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print("\n" + encode_line(short), flush=True)
         rc = 0 if short["parity"]["ok"] is not False else 1
     D.close()
-    if _COMM_STUCK:   # (a thread is still inside the collective library: do not wait for it at interpreter shutdown)
+    if _COMM_STUCK or (args.comm and not D.on):   # (a thread may still be inside the collective library; and nothing it prints at exit may follow the result line)
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(rc)

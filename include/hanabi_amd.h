@@ -297,10 +297,11 @@ int hnb_ctx_synchronize(HnbContext* ctx);
 #define HNB_AGE_COHORT_OFF 0u
 #define HNB_AGE_COHORT_LEAN 1u
 #define HNB_AGE_COHORT_ALL 2u
-#define HNB_AGE_COHORT_AUTO 3u   /* LEAN, and a program whose render modifiers read AGE (HnbProgramHeader::render_reads_*) has its AGE plane made current
-                                  * at the end of every hnb_simulate (one more pass over the chunks that keep their ages in a word): nothing is stale
-                                  * for a renderer behind hnb_effect_device_view (stale_attr_mask = 0). THE DEFAULT. A headless host that never looks at
-                                  * AGE between frames asks for LEAN. */
+#define HNB_AGE_COHORT_AUTO 3u   /* THE DEFAULT: chosen from the asset. A program whose render modifiers read AGE after every frame
+                                  * (HnbProgramHeader::render_reads_*: ColorOverLifetime / SizeOverLifetime) keeps per-particle ages in the plane (as OFF:
+                                  * nothing is ever stale for a renderer behind hnb_effect_device_view); every other program gets LEAN. Measured on the
+                                  * reference's firework asset with a consumer behind every frame: cohorts + a materialise pass per frame 0.295 ms, ages in
+                                  * the plane 0.288 ms. A headless host that never looks at AGE between frames asks for LEAN. */
 #define HNB_OPT_CULL_LIFETIME 5u
 #define HNB_OPT_HORIZON 6u
 #define HNB_OPT_TRANSPOSE 7u
@@ -404,7 +405,7 @@ int hnb_simulate(HnbContext* ctx);
  * effect of the program is created or destroyed - fetch the view again after each hnb_simulate (a few stores, no HIP call).
  * Attributes in stale_attr_mask are current only after hnb_effect_materialise(fx, mask), which is enqueued on the simulation stream like a
  * frame. With the default HNB_AGE_COHORT_AUTO the mask is empty for every asset whose render modifiers read AGE (ColorOverLifetime /
- * SizeOverLifetime, src/modifier/output.rs:310-312: HnbProgramHeader::render_reads_*) - hnb_simulate leaves that plane current - and for
+ * SizeOverLifetime, src/modifier/output.rs:310-312: HnbProgramHeader::render_reads_*) - such a program keeps its ages in the plane - and for
  * programs created with HNB_AGE_COHORT_OFF; AGE is stale under LEAN / ALL, and under AUTO for assets whose renderer does not read it.
  * Free slots hold the values their last particle died with. */
 typedef struct HnbDeviceMeta {          /* one 32-byte row per effect instance, device-resident; written by the frame's last kernel */

@@ -46,7 +46,10 @@ def main():
     maps = open("/proc/self/maps").read()
     out["librccl_mapped"] = sorted({ln.split()[-1] for ln in maps.splitlines() if "librccl" in ln})
     ctx.close()
-    print("\n" + json.dumps(out), flush=True)   # (RCCL writes warnings to stdout, some without a trailing newline)
+    import ctypes
+    ctypes.CDLL(None).fflush(None)               # (librccl prints its banner and warnings through C stdio into stdout: out, before the result line)
+    print("\nRESULT " + json.dumps(out), flush=True)
+    os._exit(0)                                  # (nothing the library prints at exit may follow it)
 
 
 if __name__ == "__main__":

@@ -155,8 +155,9 @@ def test_age_plane_is_stale_without_materialise_and_current_with_it():
 @pytest.mark.gpu
 def test_auto_mode_keeps_age_current_for_assets_whose_render_modifiers_read_it():
     """The default, HNB_AGE_COHORT_AUTO: examples/firework.rs puts ColorOverLifetime + SizeOverLifetime on the trails (render modifiers that read
-    AGE, src/modifier/output.rs:310-312) - the lowering carries that into the blob, the view has no stale attribute and a consumer enqueued right
-    behind hnb_simulate reads current ages with NO materialise call; the same program without render modifiers keeps the cheaper stale plane."""
+    AGE, src/modifier/output.rs:310-312) - the lowering carries that into the blob, the program keeps per-particle ages in the plane, the view has no
+    stale attribute and a consumer enqueued right behind hnb_simulate reads current ages with NO materialise call; the same effect WITHOUT render
+    modifiers gets the age cohorts (stale AGE plane, 8 bytes per particle and frame less)."""
     cons = _consumer()
     cap = 20_000
     ctx = bh.Context(0)
@@ -176,7 +177,22 @@ def test_auto_mode_keeps_age_current_for_assets_whose_render_modifiers_read_it()
     ctx.synchronize()
     ref = fx.read_attr(A.AGE.id).view(np.uint32)[fx.alive_list()].reshape(-1)
     np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32)[: len(ref)], ref)
-    assert "made current after every frame" in prog.kernel_info() and "age cohorts: 5 of 5 chunks" in prog.kernel_info()   # cohorts ARE in use
+    assert "age cohorts: off (HNB_AGE_COHORT_AUTO" in prog.kernel_info()
+    # ... and the same simulation for a renderer that does not read AGE
+    w = bh.ExprWriter()
+    plain = bh.EffectAsset(cap, bh.SpawnerSettings.once(float(cap)), w.finish())
+    for m in (bh.SetAttributeModifier(A.POSITION, w.lit((0.0, 0.0, 0.0)).expr()), bh.SetAttributeModifier(A.VELOCITY, w.lit((1.0, 2.0, 3.0)).expr()),
+              bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()), bh.SetAttributeModifier(A.LIFETIME, w.lit(5.0).expr())):
+        plain.init(m)
+    plain.update(bh.LinearDragModifier(w.lit(4.0).expr()))
+    p2 = ctx.create_program(bh.lower(plain))
+    f2 = p2.create_effect()
+    assert f2.device_view().stale_attr_mask == 1 << A.AGE.id
+    for f in range(4):
+        ctx.frame_begin(1 / 60, f / 60)
+        f2.set_frame(cap if f == 0 else 0, frame_seed(f))
+        ctx.simulate()
+    assert "age cohorts: 5 of 5 chunks" in p2.kernel_info()
     ctx.close()
 
 

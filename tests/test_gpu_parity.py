@@ -18,6 +18,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def ctx():
     c = bh.Context(0)
+    c.set_option("age_cohort", 1)   # HNB_AGE_COHORT_LEAN: the headless configuration the bench times (the default, AUTO, keeps per-particle ages for assets whose
+    #                                 render modifiers read AGE - firework.rs, instancing.rs; tests/test_device_view.py covers that choice)
     yield c
     c.close()
 

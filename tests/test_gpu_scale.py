@@ -27,6 +27,8 @@ REL_TOL = 1e-5  # BASELINE.json north_star: "within 1e-5 relative fp32 on positi
 @pytest.fixture(scope="module")
 def ctx():
     c = bh.Context(0)
+    c.set_option("age_cohort", 1)   # HNB_AGE_COHORT_LEAN: the headless configuration the bench times (the default, AUTO, keeps per-particle ages for assets whose
+    #                                 render modifiers read AGE - firework.rs, instancing.rs; tests/test_device_view.py covers that choice)
     yield c
     c.close()
 

@@ -59,7 +59,7 @@ def test_the_real_librccl_reduces_a_one_context_communicator():
     env = dict(os.environ, NCCL_SOCKET_IFNAME=os.environ.get("NCCL_SOCKET_IFNAME", "lo"), HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG_FILE="/dev/stderr")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "real_rccl", "run_real_comm.py")], capture_output=True, text=True, timeout=540, env=env)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
-    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])
     assert out["describe_local"].startswith("rccl ") and "librccl" in out["describe_local"] and out["describe_local"].endswith("ranks=1 local=1"), out
     assert out["describe_rank"].startswith("rccl ") and out["describe_rank"].endswith("ranks=1 local=1"), out
     assert out["totals_local"] == out["alive"] and 0 < out["alive"][0] <= 30000 and 0 < out["alive"][1] <= 12345, out

@@ -17,3 +17,13 @@ for r in csv.DictReader(open(sys.argv[1])):
         print("%-90s calls %5s avg %9.2f us min %9.2f max %9.2f  %5.1f%%"%(r["Name"][:90], r["Calls"], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3, float(r["MaxNs"])/1e3, float(r["Percentage"])))
 PY
 rm -rf $R/gpurun_out/prof_$TAG
+cd $R
+# the N > 1 code path of the bench on one device (gloo, both ranks on GPU 0): launcher, slab sharding, the counter all-reduce, the line
+timeout 300 python bench.py --gpus 2 --backend gloo --force-device 0 --steps 10 --windows 5 --pmc off > gpurun_out/${TAG}_bench_n2_dryrun.json 2> gpurun_out/${TAG}_bench_n2_dryrun.err; tail -c 400 gpurun_out/${TAG}_bench_n2_dryrun.json
+# a short differential fuzz of the build against the oracle (random assets specialised / typed / in scenes of 8 interpreted)
+L=gpurun_out/${TAG}_fuzz.log; : > $L
+timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 1 --seeds 7000:7100 2>&1 | tail -2 >> $L
+timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 1 --typed --seeds 7400:7480 2>&1 | tail -2 >> $L
+timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 1 --capacity 9000 --frames 40 --seeds 7600:7640 2>&1 | tail -2 >> $L
+timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 0 --scene 8 --seeds 9000:9160 2>&1 | tail -2 >> $L
+cat $L
