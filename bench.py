@@ -279,14 +279,18 @@ def cpu_baseline(capacity, frames=60, check_frames=2):
             best = t if best is None else min(best, t)
         tried[threads] = capacity * frames / best
     threads = max(tried, key=tried.get)
-    return {"value": tried[threads], "unit": "particle-updates/s", "cores": threads, "threads": threads, "host_logical_cpus": hw,
+    # `cores`: what the run could actually use - the thread count, capped by the container's CPU quota (on this pool's GPU boxes cgroup cpu.max allows 16 CPUs'
+    # worth of time on a 2 x 64-core host: 64 threads then run at a quarter speed each, which is why more threads stopped helping in every earlier round)
+    quota = limits.get("cgroup_cpu_quota")
+    cores = int(min(threads, quota)) if quota else threads
+    return {"value": tried[threads], "unit": "particle-updates/s", "cores": cores, "threads": threads, "host_logical_cpus": hw,
             "host_physical_cores": host_physical_cores(), "kind": "port",
             "algorithmic_gbs": tried[threads] * CONFIGS["c2"]["bytes_per_update"] / 1e9, "bytes_per_update": CONFIGS["c2"]["bytes_per_update"],
             "threads_tried": {str(k): v for k, v in tried.items()}, "limits": limits,
             "sample": f"{capacity} particles x {frames} frames (best of 3 repeats) of the same firework update (all alive), packed-SoA OpenMP "
                       f"port (oracle/cpu_soa.c, -O3 -march=native, threads bound {os.environ['OMP_PROC_BIND']}/{os.environ['OMP_PLACES']}); "
                       f"checked bit-equal to the oracle on all {capacity} particles x {check_frames} frames first; {time.perf_counter() - t_all:.1f} s in total. "
-                      "`cores` = `threads` = the OpenMP thread count that was fastest; the 0.5 GB of state fits in the host's last-level caches (2 x 256 MB L3 on the GPU box)"}
+                      "`threads` = the OpenMP thread count that was fastest, `cores` = that count capped by the container's CPU quota (`limits`); the 0.5 GB of state fits in the host's last-level caches (2 x 256 MB L3 on the GPU box)"}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -1340,7 +1344,7 @@ def short_line(full, args):
     cb = full.get("cpu_baseline")
     if cb:
         short["cpu_baseline"] = cb if "error" in cb else {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "threads": cb["threads"], "host_physical_cores": cb.get("host_physical_cores"),
-                                                          "cpu_model": cpu_model(), "kind": cb["kind"], "sample": cb["sample"][:80]}
+                                                          "cpu_model": cpu_model(), "cpu_quota": (cb.get("limits") or {}).get("cgroup_cpu_quota"), "kind": cb["kind"], "sample": cb["sample"][:80]}
     short["parity"] = parity
     if full.get("comm"):   # (N = 1: the alive total went through hnb_comm_allreduce_alive over a one-rank communicator of the real librccl)
         short["comm"] = {k: v for k, v in full["comm"].items() if k != "effects"}

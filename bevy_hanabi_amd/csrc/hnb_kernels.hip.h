@@ -1554,11 +1554,22 @@ k_materialise_age(const uint64_t* __restrict__ inst_base, uint32_t capacity, uin
     const uint32_t* aval = astate + chunks_per_inst;
     if (astate[j] != 1u) return;
     const uint32_t v = aval[j];
-    const uint8_t* flags = reinterpret_cast<const uint8_t*>(base + alive_flag_off);
-    uint32_t* age = reinterpret_cast<uint32_t*>(base + age_plane_off);
-    for (uint32_t i = threadIdx.x; i < kChunk; i += kBlock) {
-        const uint32_t slot = j * kChunk + i;
-        if (slot < capacity && flags[slot] == 1u) age[slot] = v;
+    // a lane owns quads of 4 consecutive slots: 16-byte stores; a completely alive chunk (the flag the update maintains behind the lifetime bounds)
+    // needs no alive bytes at all. (Round 5: one byte load and one 4-byte store per slot took 34 us for 16.7M particles, a quarter of the update
+    // it follows in a host that materialises every frame.) The planes are padded to 256 B: a quad never straddles the end of the plane.
+    const bool chunk_full = (reinterpret_cast<const uint32_t*>(base + lmin_off) + chunks_per_inst)[j] == 1u;
+    const uint32_t* flags4 = reinterpret_cast<const uint32_t*>(base + alive_flag_off);
+    u4v* age4 = reinterpret_cast<u4v*>(base + age_plane_off);
+    for (uint32_t q = threadIdx.x; q < kChunk / 4u; q += kBlock) {
+        const uint32_t quad = j * (kChunk / 4u) + q, slot = quad * 4u;
+        if (slot >= capacity) break;
+        const uint32_t f4 = chunk_full ? 0x01010101u : flags4[quad];
+        if (f4 == 0x01010101u) { age4[quad] = u4v{v, v, v, v}; continue; }
+        if (f4 == 0u) continue;
+        uint32_t* a = reinterpret_cast<uint32_t*>(age4 + quad);
+#pragma unroll
+        for (uint32_t p = 0; p < 4u; ++p)
+            if (((f4 >> (8u * p)) & 0xffu) == 1u) a[p] = v;
     }
 }
 

@@ -180,11 +180,13 @@ def test_auto_mode_keeps_age_current_for_assets_whose_render_modifiers_read_it()
     assert "age cohorts: off (HNB_AGE_COHORT_AUTO" in prog.kernel_info()
     # ... and the same simulation for a renderer that does not read AGE
     w = bh.ExprWriter()
+    inits = [bh.SetAttributeModifier(A.POSITION, w.lit((0.0, 0.0, 0.0)).expr()), bh.SetAttributeModifier(A.VELOCITY, w.lit((1.0, 2.0, 3.0)).expr()),
+             bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()), bh.SetAttributeModifier(A.LIFETIME, w.lit(5.0).expr())]
+    drag = bh.LinearDragModifier(w.lit(4.0).expr())
     plain = bh.EffectAsset(cap, bh.SpawnerSettings.once(float(cap)), w.finish())
-    for m in (bh.SetAttributeModifier(A.POSITION, w.lit((0.0, 0.0, 0.0)).expr()), bh.SetAttributeModifier(A.VELOCITY, w.lit((1.0, 2.0, 3.0)).expr()),
-              bh.SetAttributeModifier(A.AGE, w.lit(0.0).expr()), bh.SetAttributeModifier(A.LIFETIME, w.lit(5.0).expr())):
+    for m in inits:
         plain.init(m)
-    plain.update(bh.LinearDragModifier(w.lit(4.0).expr()))
+    plain.update(drag)
     p2 = ctx.create_program(bh.lower(plain))
     f2 = p2.create_effect()
     assert f2.device_view().stale_attr_mask == 1 << A.AGE.id
