@@ -5,8 +5,8 @@ TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -rf -p no:cacheprovider 2>&1 | tail -80 > gpurun_out/${TAG}_pytest.log; tail -8 gpurun_out/${TAG}_pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/${TAG}_smoke.log
-timeout 900 python bench.py --keep-pmc gpurun_out/${TAG}_pmc > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; tail -c 1500 gpurun_out/${TAG}_bench.json
-cp profiles/bench_full.json gpurun_out/${TAG}_bench_full.json 2>/dev/null
+timeout 900 python bench.py --keep-pmc gpurun_out/${TAG}_pmc --write-traffic > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; tail -c 1500 gpurun_out/${TAG}_bench.json
+cp profiles/bench_full.json gpurun_out/${TAG}_bench_full.json 2>/dev/null; cp profiles/traffic.json gpurun_out/${TAG}_traffic.json 2>/dev/null
 export TMPDIR=/tmp; cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python $R/bench.py --no-extra-configs --no-scene --no-cpu-baseline --pmc off --no-comm --full-json /tmp/x.json < /dev/null > $R/gpurun_out/${TAG}_stats_bench.json 2> $R/gpurun_out/${TAG}_stats_bench.err
 f=$(find $R/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
@@ -27,3 +27,23 @@ timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 1 --typed --seeds 740
 timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 1 --capacity 9000 --frames 40 --seeds 7600:7640 2>&1 | tail -2 >> $L
 timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 0 --scene 8 --seeds 9000:9160 2>&1 | tail -2 >> $L
 cat $L
+# SQ counters of the init / update kernels (is a kernel bound by VALU issue, memory, or instruction issue?) and what the instruction cache says about the churn init
+bash tools/valu_pmc.sh 2>&1 | tail -24 > gpurun_out/${TAG}_valu_counters.txt; tail -6 gpurun_out/${TAG}_valu_counters.txt
+export TMPDIR=/tmp; cd /tmp
+rocprofv3 -L 2>/dev/null | grep -i -E "icache|ifetch|SQC_" | head -40 > $R/gpurun_out/${TAG}_counter_names.txt
+timeout 200 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAVES --output-format csv -d $R/gpurun_out/icache_$TAG -- python $R/bench.py --config c2_mixed --no-cpu-baseline --no-extra-configs --no-parity --pmc off --no-scene --no-comm --steps 10 --windows 3 --full-json /tmp/y.json > $R/gpurun_out/${TAG}_icache.log 2>&1
+python3 - <<'PY' | tee $R/gpurun_out/${TAG}_icache.txt
+import csv, glob, os, collections
+O = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out"
+fs = glob.glob(O + "/icache_*/**/*counter_collection.csv", recursive=True)
+if not fs:
+    print("no icache counters collected")
+else:
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(fs[0])):
+        k = r["Kernel_Name"].split("(")[0][:60]
+        if "hnb::" in k: per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, c in per.items():
+        print(k, {n: sorted(v)[len(v) // 2] for n, v in c.items()}, "launches", max(len(v) for v in c.values()))
+PY
+rm -rf $R/gpurun_out/icache_$TAG
