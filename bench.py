@@ -105,11 +105,11 @@ CONFIGS = {
                       workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst; frames 48..70 at 1/60 s: the die-off (list kernels every frame)"),
     "c2_interop": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=56, kernel="k_update_slots_stream<ProgDragAccel>",
                        workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst, all alive, hnb_ctx_set_option(HNB_OPT_AGE_COHORT, OFF) (AGE plane current every frame)"),
-    "c2_view": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=56, kernel="k_update_slots_stream<ProgDragAccel>",
+    "c2_view": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=52, kernel="k_update_slots_stream<ProgDragAccel, cohort>",
                     workload="firework.rs trails EffectAsset END TO END: capacity={cap:_} per GPU, burst, all alive, the library's default HNB_AGE_COHORT_AUTO (the asset's ColorOverLifetime / "
-                             "SizeOverLifetime read AGE: per-particle ages stay in the plane) + a consumer kernel behind every frame that gathers position / age / lifetime by list row through hnb_effect_device_view"),
-    "c2_lean_view": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=52, kernel="k_update_slots_stream<ProgDragAccel, cohort>",
-                         workload="as c2_view with HNB_AGE_COHORT_LEAN + hnb_effect_materialise(AGE) every frame + the same consumer kernel: the alternative AUTO does not pick"),
+                             "SizeOverLifetime read AGE; an effect this large keeps the cohorts and hnb_simulate makes the AGE plane current every frame) + a consumer kernel behind every frame that gathers position / age / lifetime by list row through hnb_effect_device_view"),
+    "c2_interop_view": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=56, kernel="k_update_slots_stream<ProgDragAccel>",
+                            workload="as c2_view with HNB_AGE_COHORT_OFF (per-particle ages in the plane, what AUTO gives SMALL effects of this asset) + the same consumer kernel: the alternative AUTO does not pick at this size"),
     "c2_events": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=62, kernel="k_update_slots_stream<ProgDragAccel, cohort> (trails)",
                       workload="the real examples/firework.rs: rocket (capacity 32_768, 16_000 rockets/s) -> sparkle_trail (1_048_576; 5 spawn events per rocket and frame) + "
                                "trails (capacity={cap:_}; 1000 spawn events per dying rocket), GPU spawn events, steady state"),
@@ -120,10 +120,10 @@ CONFIGS = {
     "c5": dict(capacity=1 << 22, bytes_per_update=20, bytes_per_spawn=36, model_bytes=9, kernel="k_update_slots_stream<ProgAge>",
                workload="ribbon.rs EffectAsset, capacity={cap:_} per GPU, rate spawner in steady spawn/kill churn, ribbon sort in the step"),
 }
-EXTRA_CONFIGS = ("c2_mixed", "c2_dieoff", "c2_interop", "c2_view", "c2_lean_view", "c2_events", "c3", "c4", "c5")   # appended to the N = 1 default line
+EXTRA_CONFIGS = ("c2_mixed", "c2_dieoff", "c2_interop", "c2_view", "c2_interop_view", "c2_events", "c3", "c4", "c5")   # appended to the N = 1 default line
 # what identifies the dominant kernel of a configuration in a rocprofv3 dispatch list
 KERNEL_MATCH = {"c2_events": ("k_update_slots_stream",), "c2": ("k_update_slots_stream",), "c2_mixed": ("k_update_slots_stream",), "c2_dieoff": ("k_update_slots_stream",),
-                "c2_interop": ("k_update_slots_stream",), "c2_view": ("k_update_slots_stream",), "c2_lean_view": ("k_update_slots_stream",), "c3": ("k_update_slots_stream",), "c4": ("k_update_slots_stream",), "c5": ("k_update_slots_stream",)}
+                "c2_interop": ("k_update_slots_stream",), "c2_view": ("k_update_slots_stream",), "c2_interop_view": ("k_update_slots_stream",), "c3": ("k_update_slots_stream",), "c4": ("k_update_slots_stream",), "c5": ("k_update_slots_stream",)}
 
 
 def frame_dt(total_frames, safe_seconds=MIN_LIFETIME * 0.95):
@@ -358,7 +358,9 @@ class Workload:
         n = D.world
         base_cap = args.capacity or cfg["capacity"]
         self.ctx = bh.Context(D.device_index)
-        if name not in ("c2_view", "c2_interop"):
+        if name in ("c2_interop", "c2_interop_view"):
+            self.ctx.set_option("age_cohort", 0)   # HNB_AGE_COHORT_OFF, fixed in the program at creation: the AGE plane is current after every frame
+        elif name != "c2_view":
             # HNB_AGE_COHORT_LEAN: the simulation alone (a headless host: nobody reads AGE between frames), as every round measured it. The library's default
             # (AUTO) looks at the asset's render modifiers - ColorOverLifetime on these assets reads AGE - and is what c2_view runs: the asset end to end
             self.ctx.set_option("age_cohort", 1)
@@ -416,8 +418,6 @@ class Workload:
                 asset = effects.firework_trails(cap)
             else:
                 asset = {"c3": effects.force_field, "c5": effects.ribbon}[name](cap)
-            if name == "c2_interop":
-                self.ctx.set_option("age_cohort", 0)   # HNB_AGE_COHORT_OFF, fixed in the program at creation: the AGE plane is current after every frame
             self.prog = self.ctx.create_program(bh.lower(asset))
             self.fxs = [self.prog.create_effect(slot_base=slot_base)]
             self.assets, self.slot_base = [asset], slot_base
@@ -470,8 +470,6 @@ class Workload:
                 self.shadow(f, dt, inputs)
         ctx.simulate()
         if self.consumer is not None:   # enqueued on the simulation stream right behind the frame: no synchronisation, no host copy
-            if self.name == "c2_lean_view":
-                self.fxs[0].materialise([4])   # HNB_ATTR_AGE: the cohort chunks' common age written out for the consumer
             v = self.fxs[0].device_view()
             assert v.stale_attr_mask == 0 or self.name != "c2_view", "HNB_AGE_COHORT_AUTO left AGE stale for an asset whose render modifiers read it"
             rc = self.consumer.consumer_render_like(self._byref(v), self.consumer_out.data_ptr())
@@ -490,7 +488,7 @@ class Workload:
 # ------------------------------------------------------------------------------------------------------------------
 PARITY_BUDGET_S = 0.5          # oracle time per configuration (the slab / the reduced capacity is sized to the oracle's measured speed)
 PARITY_KEYS = ("capacity", "alive_count", "max_update", "max_spawn", "indirect_write_index", "particle_counter", "instance_count", "dead_count")
-BURST_PARITY = ("c2", "c2_interop", "c2_view", "c2_lean_view", "c3", "c4")
+BURST_PARITY = ("c2", "c2_interop", "c2_view", "c2_interop_view", "c3", "c4")
 _ORACLE_RATE = None
 
 
@@ -714,7 +712,7 @@ def run_config(name, args, D, strong=False, pmc=None):
     warmup = warmup_frames(name, args.warmup)
     if name == "c2_dieoff":
         steps = DIEOFF_LAST - DIEOFF_FIRST + 1           # a window is the die-off itself, not K steps
-    elif name in ("c2", "c2_interop", "c2_view", "c2_lean_view"):
+    elif name in ("c2", "c2_interop", "c2_view", "c2_interop_view"):
         w.dt = frame_dt(1 + warmup + steps * windows)    # nobody may die in the timed frames
     elif name in BURST_SAFE_SECONDS:
         w.dt = frame_dt(1 + warmup + steps * windows, BURST_SAFE_SECONDS[name])
@@ -818,7 +816,7 @@ def run_config(name, args, D, strong=False, pmc=None):
     w.close()
 
     alive0_total, alive1_total = D.sum_counts([alive0, alive1])
-    if name in ("c2", "c2_interop", "c2_view", "c2_lean_view", "c4"):
+    if name in ("c2", "c2_interop", "c2_view", "c2_interop_view", "c4"):
         expect = w.local_particles if not D.on else None
         assert expect is None or (alive0 == expect and alive1 == expect), f"{name}: expected every particle alive during the timed frames, got {alive0}, {alive1}"
     if D.rank != 0:

@@ -218,6 +218,7 @@ struct HnbProgram {
     bool wide_file = false;       // init_regs / update_regs above HNB_VM_MAX_REGS: generic kernels use the wide V file
     uint32_t cull_dt_operand = 0; // lifetime culling: decoded operand a of the update stream's AGE_TICK (dev.cull_lifetime)
     bool update_streams = false;  // update stream runs on the streaming kernel (macro ops, U operands)
+    bool auto_materialise = false;  // HNB_AGE_COHORT_AUTO, the render modifiers read AGE and the effect is large: cohorts, and the plane is made current at the end of every frame
     StreamLaunchFn stream_launch = nullptr;  // specialised (or interpreted) streaming kernel for this update stream
     const char* stream_kernel_name = "";
     // kernels specialised for this program at creation (hnb_jit.h); null = the ahead-of-time kernels run
@@ -773,14 +774,17 @@ bool cull_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEnt
     if (dt_operand) *dt_operand = HNB_OPERAND_DECODE((uc[0].x >> 16) & 0xffu, uc[0].y >> 13);
     return true;
 }
+constexpr uint32_t kAutoMaterialiseMinSlots = 1u << 20;   // HNB_AGE_COHORT_AUTO: from this capacity on an AGE-reading asset keeps the cohorts (+ a materialise pass per frame)
 bool age_cohort_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams, const ProgramOptions& opt) {
     if (!cull_eligible(b, h, attrs, streams, opt, nullptr) || (h.flags & HNB_PROG_HAS_RIBBONS) || opt.age_cohort == HNB_AGE_COHORT_OFF) return false;
-    // HNB_AGE_COHORT_AUTO (the default): an asset whose RENDER modifiers read AGE after every frame (HnbProgramHeader::render_reads_*:
-    // ColorOverLifetime / SizeOverLifetime, src/modifier/output.rs:310-312) keeps per-particle ages in the plane. Measured end to end on the
-    // reference's own firework asset with a consumer kernel behind every frame (profiles/r05c_bench.json): cohorts + one k_materialise_age pass per
-    // frame 0.2946 ms, cohorts off 0.2876 ms - and the materialise pass is one more launch per program per frame, which a scene of small
-    // effects cannot afford (26 effects: 0.049 -> 0.082 ms per frame). Assets whose renderer does not read AGE get LEAN.
-    if (opt.age_cohort == HNB_AGE_COHORT_AUTO && (h.render_reads_lo >> HNB_ATTR_AGE & 1u)) return false;
+    // HNB_AGE_COHORT_AUTO (the default) chooses from the asset: where the RENDER modifiers read AGE after every frame (HnbProgramHeader::
+    // render_reads_*: ColorOverLifetime / SizeOverLifetime, src/modifier/output.rs:310-312) the plane must be current after every frame.
+    // Measured end to end on the reference's own firework asset at 16.7M particles with a consumer kernel behind every frame
+    // (profiles/r05f_bench.json): cohorts + one k_materialise_age pass per frame 0.280 ms, per-particle ages 0.297 ms - but that pass is one
+    // more launch per program per frame, which a scene of small effects cannot afford (26 effects: 0.049 -> 0.082 ms per frame,
+    // profiles/r05c_bench.json). So: effects of a million slots or more keep the cohorts and have hnb_simulate materialise (auto_materialise),
+    // smaller ones keep their ages in the plane. Assets whose renderer does not read AGE get LEAN.
+    if (opt.age_cohort == HNB_AGE_COHORT_AUTO && (h.render_reads_lo >> HNB_ATTR_AGE & 1u) && h.capacity < kAutoMaterialiseMinSlots) return false;
     // only the lean (bandwidth-bound) stacks: an update that is bound by VALU issue (ConformToSphere, Radial / TangentAccel: divisions, square
     // roots) gains nothing from 8 bytes less per particle and pays for the bookkeeping (force_field: 0.0955 -> 0.099 ms with it, measured)
     // (HNB_AGE_COHORT_ALL: every eligible stack, for A/B runs)
@@ -1032,6 +1036,7 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
         d.cull_lifetime = 1u;
         d.age_cohort = age_cohort_eligible(b, h, p->attrs.data(), p->update_streams, ctx->popt) ? 1u : 0u;
     }
+    p->auto_materialise = ctx->popt.age_cohort == HNB_AGE_COHORT_AUTO && d.age_cohort != 0u && (h.render_reads_lo >> HNB_ATTR_AGE & 1u) != 0u;
     if (p->update_streams) select_stream_kernel(reinterpret_cast<const Ins*>(b + h.update_off), h.update_len, &p->stream_launch, &p->stream_kernel_name);
     if (!p->wide_file && jit::enabled()) {
         p->h_init.assign(reinterpret_cast<const Ins*>(b + h.init_off), reinterpret_cast<const Ins*>(b + h.init_off) + h.init_len);
@@ -2040,6 +2045,10 @@ static int enqueue_program_update(HnbContext* ctx, HnbProgram* p, hipStream_t st
         if (p->wide_file) k_update_slots_generic<InterpCodeWide><<<total_chunks, kBlock, 0, st>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
         else k_update_slots_generic<InterpCode><<<total_chunks, kBlock, 0, st>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
     }
+    if (p->auto_materialise) {   // HNB_AGE_COHORT_AUTO: the render modifiers read AGE after every frame (counted with the update in timed frames)
+        const int ai = find_attr(p, HNB_ATTR_AGE);
+        k_materialise_age<<<total_chunks, kBlock, 0, st>>>(p->d_inst_base, p->dev.capacity, p->dev.chunks_per_inst, p->dev.lmin_off, p->dev.attrs[ai].plane_off, p->dev.alive_flag_off);
+    }
     if (timed) { hipEventRecord(tu.b, st); ctx->t_update.push_back(tu); }
     const CompactArgs ca = compact_args_of(p);
     const bool lists = p->plan.lists;
@@ -2259,7 +2268,7 @@ int hnb_effect_device_view(HnbEffect* fx, HnbDeviceView* out) {
     out->capacity = p->dev.capacity;
     out->slot_base = fx->slot_base;
     out->n_attrs = p->dev.n_attrs;
-    out->stale_attr_mask = p->dev.age_cohort ? (1ull << HNB_ATTR_AGE) : 0ull;   // (never set for an asset whose render modifiers read AGE under the default HNB_AGE_COHORT_AUTO)
+    out->stale_attr_mask = (p->dev.age_cohort && !p->auto_materialise) ? (1ull << HNB_ATTR_AGE) : 0ull;   // (never set for an asset whose render modifiers read AGE under the default HNB_AGE_COHORT_AUTO)
     out->alive_list[0] = reinterpret_cast<const uint32_t*>(base + p->dev.alive_off[0]);
     out->alive_list[1] = reinterpret_cast<const uint32_t*>(base + p->dev.alive_off[1]);
     out->dead_list = reinterpret_cast<const uint32_t*>(base + p->dev.dead_off);
@@ -2285,7 +2294,7 @@ int hnb_program_device_view(HnbProgram* p, HnbProgramView* out) {
     out->capacity = p->dev.capacity;
     out->n_instances = (uint32_t)p->effects.size();
     out->n_attrs = p->dev.n_attrs;
-    out->stale_attr_mask = p->dev.age_cohort ? (1ull << HNB_ATTR_AGE) : 0ull;
+    out->stale_attr_mask = (p->dev.age_cohort && !p->auto_materialise) ? (1ull << HNB_ATTR_AGE) : 0ull;
     out->slabs = p->d_inst_base;
     out->meta = reinterpret_cast<const HnbDeviceMeta*>(p->d_meta[p->parity]);
     out->meta_next = reinterpret_cast<const HnbDeviceMeta*>(p->d_meta[p->parity ^ 1u]);
@@ -2479,6 +2488,7 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
             for (uint32_t v : st) in_cohort += v == 1u ? 1u : 0u;
         }
         s += "\nage cohorts: " + std::to_string(in_cohort) + " of " + std::to_string(prog->effects.size() * (size_t)prog->dev.chunks_per_inst) + " chunks";
+        if (prog->auto_materialise) s += " (HNB_AGE_COHORT_AUTO: the asset's render modifiers read AGE, the plane is made current after every frame)";
     }
     if (prog->has_ribbons && prog->suffix_frames) s += "\ncasualties proven to be the list's last rows (no k_count_rows): " + std::to_string(prog->suffix_frames) + " frames";
     if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->ribbon_facts.front_static ? "" : " (not eligible)");

@@ -297,11 +297,13 @@ int hnb_ctx_synchronize(HnbContext* ctx);
 #define HNB_AGE_COHORT_OFF 0u
 #define HNB_AGE_COHORT_LEAN 1u
 #define HNB_AGE_COHORT_ALL 2u
-#define HNB_AGE_COHORT_AUTO 3u   /* THE DEFAULT: chosen from the asset. A program whose render modifiers read AGE after every frame
-                                  * (HnbProgramHeader::render_reads_*: ColorOverLifetime / SizeOverLifetime) keeps per-particle ages in the plane (as OFF:
-                                  * nothing is ever stale for a renderer behind hnb_effect_device_view); every other program gets LEAN. Measured on the
-                                  * reference's firework asset with a consumer behind every frame: cohorts + a materialise pass per frame 0.295 ms, ages in
-                                  * the plane 0.288 ms. A headless host that never looks at AGE between frames asks for LEAN. */
+#define HNB_AGE_COHORT_AUTO 3u   /* THE DEFAULT: chosen from the asset. Where the render modifiers read AGE after every frame (HnbProgramHeader::
+                                  * render_reads_*: ColorOverLifetime / SizeOverLifetime) nothing is ever stale for a renderer behind
+                                  * hnb_effect_device_view: an effect of 2^20 slots or more keeps the cohorts and hnb_simulate ends with a materialise pass
+                                  * (measured on the reference's firework asset at 16.7M particles with a consumer behind every frame: 0.280 ms against
+                                  * 0.297 ms with per-particle ages), a smaller one keeps per-particle ages in the plane (as OFF: one more launch per
+                                  * program and frame is what a scene of small effects cannot afford). Every other program gets LEAN. A headless host
+                                  * that never looks at AGE between frames asks for LEAN. */
 #define HNB_OPT_CULL_LIFETIME 5u
 #define HNB_OPT_HORIZON 6u
 #define HNB_OPT_TRANSPOSE 7u
@@ -405,7 +407,7 @@ int hnb_simulate(HnbContext* ctx);
  * effect of the program is created or destroyed - fetch the view again after each hnb_simulate (a few stores, no HIP call).
  * Attributes in stale_attr_mask are current only after hnb_effect_materialise(fx, mask), which is enqueued on the simulation stream like a
  * frame. With the default HNB_AGE_COHORT_AUTO the mask is empty for every asset whose render modifiers read AGE (ColorOverLifetime /
- * SizeOverLifetime, src/modifier/output.rs:310-312: HnbProgramHeader::render_reads_*) - such a program keeps its ages in the plane - and for
+ * SizeOverLifetime, src/modifier/output.rs:310-312: HnbProgramHeader::render_reads_*) - its ages are in the plane or put there by hnb_simulate - and for
  * programs created with HNB_AGE_COHORT_OFF; AGE is stale under LEAN / ALL, and under AUTO for assets whose renderer does not read it.
  * Free slots hold the values their last particle died with. */
 typedef struct HnbDeviceMeta {          /* one 32-byte row per effect instance, device-resident; written by the frame's last kernel */

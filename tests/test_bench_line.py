@@ -25,7 +25,7 @@ def worst_case_record():
         v["parity"] = par(name, True)
         v["roofline"]["kernel_ms_rocprof"] = 0.2123456789
         v["roofline"]["rocprof_detail"] = copy.deepcopy(full["roofline"]["rocprof_detail"])
-    for extra in ("c2_view", "c2_lean_view"):               # (round 5's end-to-end rows)
+    for extra in ("c2_view", "c2_interop_view"):               # (round 5's end-to-end rows)
         full["configs"][extra] = copy.deepcopy(full["configs"]["c2_interop"])
         full["configs"][extra]["parity"]["config"] = extra
     for name in ("c2_mixed", "c2_dieoff", "c2_events", "c5"):   # (round 5: the churn configurations' gate on the timed state at full size)

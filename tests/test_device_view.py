@@ -177,7 +177,25 @@ def test_auto_mode_keeps_age_current_for_assets_whose_render_modifiers_read_it()
     ctx.synchronize()
     ref = fx.read_attr(A.AGE.id).view(np.uint32)[fx.alive_list()].reshape(-1)
     np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32)[: len(ref)], ref)
-    assert "age cohorts: off (HNB_AGE_COHORT_AUTO" in prog.kernel_info()
+    assert "age cohorts: off (HNB_AGE_COHORT_AUTO" in prog.kernel_info()       # (20,000 slots: a small effect keeps per-particle ages)
+    # ... a LARGE effect of the same asset keeps the cohorts and has hnb_simulate materialise: still nothing stale, still no call
+    big = 1 << 20
+    pb = ctx.create_program(bh.lower(effects.firework_trails(big)))
+    fb = pb.create_effect()
+    assert fb.device_view().stale_attr_mask == 0
+    for f in range(6):
+        ctx.frame_begin(1 / 60, f / 60)
+        fb.set_frame(big if f == 0 else 0, frame_seed(f))
+        ctx.simulate()
+    _, gotb, _ = _gather(cons, fb, A.AGE.id, 1, big)
+    ctx.synchronize()
+    assert "age cohorts: 256 of 256 chunks (HNB_AGE_COHORT_AUTO" in pb.kernel_info()
+    refb = np.full(big, np.float32(0.0), dtype=np.float32)
+    for f in range(6):
+        refb = refb + np.float32(1 / 60)
+    np.testing.assert_array_equal(gotb.cpu().numpy().view(np.float32)[:big], refb)   # every particle: six ticks of 1/60 s, added in binary32
+    fb.destroy()
+    pb.destroy()
     # ... and the same simulation for a renderer that does not read AGE
     w = bh.ExprWriter()
     inits = [bh.SetAttributeModifier(A.POSITION, w.lit((0.0, 0.0, 0.0)).expr()), bh.SetAttributeModifier(A.VELOCITY, w.lit((1.0, 2.0, 3.0)).expr()),

@@ -20,6 +20,7 @@ rm -rf $R/gpurun_out/prof_$TAG
 cd $R
 # the N > 1 code path of the bench on one device (gloo, both ranks on GPU 0): launcher, slab sharding, the counter all-reduce, the line
 timeout 300 python bench.py --gpus 2 --backend gloo --force-device 0 --steps 10 --windows 5 --pmc off > gpurun_out/${TAG}_bench_n2_dryrun.json 2> gpurun_out/${TAG}_bench_n2_dryrun.err; tail -c 400 gpurun_out/${TAG}_bench_n2_dryrun.json
+[ -z "$FULL" ] && exit 0   # (FULL=1: + fuzz, SQ counters, instruction-cache counters)
 # a short differential fuzz of the build against the oracle (random assets specialised / typed / in scenes of 8 interpreted)
 L=gpurun_out/${TAG}_fuzz.log; : > $L
 timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 1 --seeds 7000:7100 2>&1 | tail -2 >> $L

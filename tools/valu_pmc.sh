@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp; O=$R/gpurun_out
 for CFG in c2 c2_mixed c2_dieoff c3 c4; do
   rm -rf $O/valu_$CFG
-  timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/valu_$CFG -- python $R/bench.py --config $CFG --no-cpu-baseline --no-extra-configs --no-parity --pmc off --no-scene --steps 10 > $O/valu_$CFG.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/valu_$CFG -- python $R/bench.py --config $CFG --no-cpu-baseline --no-extra-configs --no-parity --pmc off --no-scene --no-comm --steps 10 > $O/valu_$CFG.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, os, collections
