@@ -182,6 +182,7 @@ struct HnbContext {
     bool skip_lists = true;     // skip the list kernels of frames the device's no-death bound covers (HNB_OPT_SKIP_LISTS)
     bool alternate = true;      // walk the chunks in alternating directions from frame to frame (HNB_OPT_ALTERNATE)
     bool suffix_proof = true;   // ribbon programs: "the casualties are the last rows of the sorted list" replaces k_count_rows where the host can prove it (HNB_OPT_SUFFIX_PROOF)
+    bool ring_lists = true;     // ... and where in addition the spawns sort in front, the list is kept as a ring: nothing is rewritten (HNB_OPT_RING_LISTS)
     bool scene_merge = true;    // small programs share their init / update launches (ProgJob / StreamJob; HNB_OPT_SCENE_MERGE)
     bool transpose = true;      // vec3 planes of the per-particle update path through the wave's LDS transpose (HNB_OPT_TRANSPOSE)
     uint32_t timing = 0;        // 0 = off, n = time every n-th simulated frame
@@ -277,6 +278,8 @@ struct HnbProgram {
     uint32_t sort_parity = 0;               // frames in which the sort ran (its state double buffer)
     uint32_t suffix_frames = 0;             // statistics
     uint32_t sort_rotated_frames = 0;       // statistics: frames whose ribbon sort was a rotation
+    bool ring_live = false;                 // an instance's list may stand behind a non-zero head (a ring frame ran since the last rewrite)
+    uint32_t ring_frames = 0;               // statistics: frames in which the list was kept as a ring (no row rewritten)
 };
 
 struct EventChannel {
@@ -977,6 +980,7 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
         case HNB_OPT_TRANSPOSE: ctx->transpose = value != 0u; return HNB_OK;
         case HNB_OPT_SCENE_MERGE: ctx->scene_merge = value != 0u; return HNB_OK;
         case HNB_OPT_SUFFIX_PROOF: ctx->suffix_proof = value != 0u; return HNB_OK;
+        case HNB_OPT_RING_LISTS: ctx->ring_lists = value != 0u; return HNB_OK;
         case HNB_OPT_STREAM_HINTS: ctx->stream_hints = value != 0u; return HNB_OK;
         case HNB_OPT_JIT_ASYNC: ctx->jit_async = value != 0u; return HNB_OK;
         case HNB_OPT_SET_MODULE:
@@ -1536,6 +1540,8 @@ static CompactArgs compact_args_of(const HnbProgram* p) {
     ca.suffix_dead = p->plan.ribbon.suffix ? 1u : 0u;
     ca.stream_hint = p->plan.stream_hint ? 1u : 0u;
     ca.rotate_front = p->plan.ribbon.rotate ? 1u : 0u;   // k_compact writes the survivors [spawns | older ones]: see CompactArgs (ribbon programs never have slot-ordered lists)
+    ca.ring = p->plan.ribbon.ring ? 1u : 0u;
+    ca.force_rewrite = (p->ring_live && !p->plan.ribbon.ring) ? 1u : 0u;
     return ca;
 }
 
@@ -1668,8 +1674,17 @@ static void stage_program_frame(HnbContext* ctx, HnbProgram* p, uint32_t slot, s
         for (uint32_t i = 0; i < n; ++i) spawns = spawns || (inst_frames[i].simulated && (inst_frames[i].has_parent || inst_frames[i].spawn_count != 0u));
         pl.skip_lists = !spawns && p->frames_run > 0u;
     }
-    if (p->has_ribbons) pl.ribbon = plan::prove_ribbon_order(p->ribbon_facts, p->ribbon_hist, p->dev.capacity, inst_frames.data(), n, ctx->skip_lists, ctx->suffix_proof);
+    if (p->has_ribbons) {
+        // (ring lists: not for programs that emit spawn events - k_emit_* walks the rows as the update saw them - nor in timed frames of nothing: always)
+        pl.ribbon = plan::prove_ribbon_order(p->ribbon_facts, p->ribbon_hist, p->dev.capacity, inst_frames.data(), n, ctx->skip_lists, ctx->suffix_proof,
+                                             ctx->ring_lists && p->hdr.n_event_channels == 0u && p->update_streams && !p->slot_order);
+        // a list that may stand behind a head must be rewritten (linear, head 0) in the first frame that is not a ring frame: the sort kernels and the
+        // slot-ordered rebuild only know linear lists. That frame therefore runs its list kernels whatever the no-death proof says.
+        if (p->ring_live && !pl.ribbon.ring) pl.skip_lists = false;
+    }
     pl.lists = !(p->update_streams && pl.skip_lists);  // false: proven no spawn, no casualty; the update kernel rotates the counters
+    if (pl.ribbon.ring && !pl.lists) pl.ribbon.ring = false;   // (nothing spawns, nothing can die: the list stands, head and all)
+    p->dev.ring = pl.ribbon.ring ? 1u : 0u;
     pl.hz_use = plan::horizon_usable(p->horizon_eligible, p->cull_dt_operand, inst_frames.data(), n);   // k_count_rows may skip row chunks
     if (pl.hz_use && pl.lists) p->hz_frames += 1;
     p->dev.hz_parity = p->hz_parity;
@@ -2166,6 +2181,8 @@ int hnb_simulate(HnbContext* ctx) {
         p->parity ^= 1u;
         p->frames_run += 1;
         if (p->horizon_eligible && p->plan.lists) p->hz_parity ^= 1u;   // k_count_rows / k_compact moved the horizons to the other half
+        if (p->plan.ribbon.ring) { p->ring_live = true; p->ring_frames += 1; }
+        else if (p->plan.lists) p->ring_live = false;                   // (k_compact ran with force_rewrite: every instance's list is linear again)
     }
     if (!order.empty()) HIP_TRY(hipEventRecord(ctx->stage_done[slot], ctx->stream));
     for (HnbProgram* p : order)
@@ -2334,7 +2351,13 @@ int hnb_effect_read_alive_list(HnbEffect* fx, uint32_t* dst, size_t dst_count) {
     int rc = read_meta(fx, &m);
     if (rc != HNB_OK) return rc;
     if (dst_count < m.alive_count) return fail(HNB_ERR_INVALID_ARG, "destination too small");
-    HIP_TRY(hipMemcpy(dst, static_cast<char*>(fx->slab) + p->dev.alive_off[m.write_index & 1u], (size_t)m.alive_count * 4, hipMemcpyDeviceToHost));
+    {   // rows [0, alive_count) of the column, behind the list's head ("Ring lists": 0 for everything but single-ribbon trails): at most two pieces
+        const char* col = static_cast<char*>(fx->slab) + p->dev.alive_off[list_column(m.write_index)];
+        const uint32_t head = list_head(m.write_index), cap = p->dev.capacity;
+        const uint32_t first = std::min(m.alive_count, cap - std::min(head, cap));
+        HIP_TRY(hipMemcpy(dst, col + (size_t)head * 4, (size_t)first * 4, hipMemcpyDeviceToHost));
+        if (first < m.alive_count) HIP_TRY(hipMemcpy(dst + first, col, (size_t)(m.alive_count - first) * 4, hipMemcpyDeviceToHost));
+    }
     return HNB_OK;
 }
 
@@ -2357,12 +2380,12 @@ int hnb_effect_read_dead_list(HnbEffect* fx, uint32_t* dst, size_t dst_count) {
 // gate on the state its TIMED frames produced, and anything else that wants to know "is this effect consistent" without moving it.
 namespace {
 __global__ void __launch_bounds__(256)
-k_check_rows(const uint32_t* __restrict__ alive, const uint32_t* __restrict__ dead, uint32_t alive_count, uint32_t capacity,
+k_check_rows(const uint32_t* __restrict__ alive, uint32_t head, const uint32_t* __restrict__ dead, uint32_t alive_count, uint32_t capacity,
              const uint8_t* __restrict__ flags, const float* __restrict__ age, const float* __restrict__ life, uint32_t* __restrict__ seen, uint32_t* __restrict__ rep) {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= capacity) return;
     const bool is_alive = r < alive_count;
-    const uint32_t slot = is_alive ? alive[r] : dead[r];   // rows [0, alive_count) of the list column, rows [alive_count, capacity) of the dead stack
+    const uint32_t slot = is_alive ? alive[ring_row(head, r, capacity)] : dead[r];   // rows [0, alive_count) of the list column (behind its head), rows [alive_count, capacity) of the dead stack
     if (slot >= capacity) { atomicAdd(rep + 0, 1u); return; }
     const uint32_t bit = 1u << (slot & 31u);
     if (atomicOr(seen + (slot >> 5), bit) & bit) atomicAdd(rep + 1, 1u);          // listed twice
@@ -2370,10 +2393,13 @@ k_check_rows(const uint32_t* __restrict__ alive, const uint32_t* __restrict__ de
     if (is_alive && age && life && !(age[slot] < life[slot])) atomicAdd(rep + 3, 1u);   // the reaping rule of src/lib.rs:1223-1258 left it alive
 }
 __global__ void __launch_bounds__(256)
-k_compare_words(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint64_t n, unsigned long long* __restrict__ out) {   // out: {differing words, first index}
+k_compare_words(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint64_t n, unsigned long long* __restrict__ out,   // out: {differing words, first index}
+                uint32_t head_a = 0, uint32_t head_b = 0, uint32_t ring = 0) {   // ring != 0: word i of either side is at (head + i) % ring (list rows behind a head)
     unsigned long long diffs = 0, first = ~0ull;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u)
-        if (a[i] != b[i]) { diffs += 1; first = first < i ? first : i; }
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+        const uint32_t x = ring ? a[ring_row(head_a, (uint32_t)i, ring)] : a[i], y = ring ? b[ring_row(head_b, (uint32_t)i, ring)] : b[i];
+        if (x != y) { diffs += 1; first = first < i ? first : i; }
+    }
     if (diffs) { atomicAdd(out, diffs); atomicMin(out + 1, first); }
 }
 }  // namespace
@@ -2397,7 +2423,7 @@ int hnb_effect_check(HnbEffect* fx, HnbEffectCheck* out) {
     const int ia = find_attr(p, HNB_ATTR_AGE), il = find_attr(p, HNB_ATTR_LIFETIME);
     const bool reaps = ia >= 0 && il >= 0 && p->dev.cull_lifetime;   // (the update program starts with the AGE_TICK that tests the lifetime)
     k_check_rows<<<(uint32_t)(((uint64_t)cap + 255u) / 256u), 256, 0, st>>>(
-        reinterpret_cast<const uint32_t*>(base + p->dev.alive_off[m.write_index & 1u]), reinterpret_cast<const uint32_t*>(base + p->dev.dead_off), m.alive_count, cap,
+        reinterpret_cast<const uint32_t*>(base + p->dev.alive_off[list_column(m.write_index)]), list_head(m.write_index), reinterpret_cast<const uint32_t*>(base + p->dev.dead_off), m.alive_count, cap,
         reinterpret_cast<const uint8_t*>(base + p->dev.alive_flag_off), reaps ? reinterpret_cast<const float*>(base + p->dev.attrs[ia].plane_off) : nullptr,
         reaps ? reinterpret_cast<const float*>(base + p->dev.attrs[il].plane_off) : nullptr, scratch + 4, scratch);
     uint32_t rep[4] = {};
@@ -2441,13 +2467,14 @@ int hnb_effect_compare(HnbEffect* a, HnbEffect* b, HnbEffectDiff* out) {
     std::vector<unsigned long long> init(n_sections * 2);
     for (size_t i = 0; i < n_sections; ++i) { init[2 * i] = 0ull; init[2 * i + 1] = ~0ull; }
     hipMemcpy(d_out, init.data(), n_sections * 16, hipMemcpyHostToDevice);
-    auto cmp = [&](size_t section, const void* x, const void* y, uint64_t words) {
+    auto cmp = [&](size_t section, const void* x, const void* y, uint64_t words, uint32_t head_x = 0, uint32_t head_y = 0, uint32_t ring = 0) {
         if (!words) return;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((words + 255u) / 256u, 16384u);
-        k_compare_words<<<grid, 256, 0, nullptr>>>(static_cast<const uint32_t*>(x), static_cast<const uint32_t*>(y), words, d_out + 2 * section);
+        k_compare_words<<<grid, 256, 0, nullptr>>>(static_cast<const uint32_t*>(x), static_cast<const uint32_t*>(y), words, d_out + 2 * section, head_x, head_y, ring);
     };
     if (ma.alive_count == mb.alive_count) {   // (else the counters already differ and the rows do not correspond)
-        cmp(0, sa + pa->dev.alive_off[ma.write_index & 1u], sb + pb->dev.alive_off[mb.write_index & 1u], ma.alive_count);
+        // (row r of either list, through its own column and behind its own head: one effect may keep a ring where the other rewrites)
+        cmp(0, sa + pa->dev.alive_off[list_column(ma.write_index)], sb + pb->dev.alive_off[list_column(mb.write_index)], ma.alive_count, list_head(ma.write_index), list_head(mb.write_index), cap);
         cmp(1, sa + pa->dev.dead_off + (size_t)ma.alive_count * 4, sb + pb->dev.dead_off + (size_t)mb.alive_count * 4, cap - ma.alive_count);
     }
     for (size_t i = 0; i < pa->attrs.size(); ++i) cmp(2 + i, sa + pa->dev.attrs[i].plane_off, sb + pb->dev.attrs[i].plane_off, (uint64_t)cap * pa->attrs[i].ncomp);
@@ -2491,6 +2518,7 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
         if (prog->auto_materialise) s += " (HNB_AGE_COHORT_AUTO: the asset's render modifiers read AGE, the plane is made current after every frame)";
     }
     if (prog->has_ribbons && prog->suffix_frames) s += "\ncasualties proven to be the list's last rows (no k_count_rows): " + std::to_string(prog->suffix_frames) + " frames";
+    if (prog->has_ribbons && prog->ring_frames) s += "\nlist kept as a ring (no row rewritten): " + std::to_string(prog->ring_frames) + " frames";
     if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->ribbon_facts.front_static ? "" : " (not eligible)");
     if (prog->merged_frames) s += "\nupdate served by a merged launch (small programs of the context share one): " + std::to_string(prog->merged_frames) + " frames";
     if (prog->unmerged_frames) s += "\nkept out of the shared launches (the loaded set module does not know this program; its own specialised kernels): " + std::to_string(prog->unmerged_frames) + " frames";

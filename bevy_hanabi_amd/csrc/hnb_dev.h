@@ -54,6 +54,7 @@ struct DevProgram {
     uint32_t cull_lifetime;    // 1: the streaming update keeps the bounds up to date and uses them
     uint32_t age_cohort;       // 1: chunks whose alive particles share one AGE keep it in a word (hnb_kernels.hip.h "Age cohorts")
     uint32_t stream_hint;      // this frame: list traffic of k_init carries the nontemporal hint (hnb_kernels.hip.h "cache policy of streamed data")
+    uint32_t ring;             // this frame is a RING frame (hnb_kernels.hip.h "Ring lists"): k_init writes its spawns in FRONT of the list's head
     DevAttr attrs[kMaxAttrs];
     const Ins* init_code;
     const Ins* update_code;
@@ -90,7 +91,9 @@ struct DevEventBuffer {
 struct DevMeta {
     uint32_t alive_count;
     uint32_t particle_counter;
-    uint32_t write_index;     // list column that currently holds the alive list (flips only when particles died)
+    uint32_t write_index;     // bit 0: the list column that currently holds the alive list (flips only when particles died);
+                              // bits 1..31: list_head - row r of the list is column[(list_head + r) % capacity]. 0 except for ribbon effects whose
+                              // list is kept as a RING (hnb_kernels.hip.h "Ring lists"): list_of() / ring_row() below
     uint32_t max_update;
     uint32_t dead_count;
     uint32_t spawned;
@@ -98,6 +101,10 @@ struct DevMeta {
     uint32_t instance_count;
 };
 static_assert(sizeof(DevMeta) == 32, "DevMeta layout");
+HNB_HD uint32_t list_column(uint32_t write_index) { return write_index & 1u; }
+HNB_HD uint32_t list_head(uint32_t write_index) { return write_index >> 1; }
+// physical index of list row `head + r` (head < capacity, r < capacity: one conditional subtraction, no division)
+HNB_HD uint32_t ring_row(uint32_t head, uint32_t r, uint32_t capacity) { const uint32_t i = head + r; return (i >= capacity || i < head) ? i - capacity : i; }
 
 
 }  // namespace hnb

@@ -259,7 +259,10 @@ __device__ __forceinline__ void init_workgroup(const DevProgram& prog, const uin
 
     char* base = global_ptr<char>(inst_base[k]);
     const uint32_t* dead = reinterpret_cast<const uint32_t*>(base + prog.dead_off);
-    uint32_t* alive = reinterpret_cast<uint32_t*>(base + prog.alive_off[meta_in[k].write_index]);  // the column holding the list
+    uint32_t* alive = reinterpret_cast<uint32_t*>(base + prog.alive_off[list_column(meta_in[k].write_index)]);  // the column holding the list
+    // ... as a ring ("Ring lists"): row r lives at (head + r) % capacity. Appended spawns are rows alive0 + i; in a RING frame they are rows -n_spawn + i:
+    // in front of everything, where (RIBBON_ID, AGE) order wants them, and k_compact only moves the head
+    const uint32_t list_first = ring_row(list_head(meta_in[k].write_index), prog.ring ? prog.capacity - n_spawn : alive0, prog.capacity);
     VmUniforms U;
     U.u = ublocks + (size_t)k * prog.n_uregs;
     U.xf = fi[k].xf;
@@ -305,7 +308,7 @@ __device__ __forceinline__ void init_workgroup(const DevProgram& prog, const uin
         }
         CODE::zero_unassigned(prog, io);
         CODE::run_init(prog, S, U, io);
-        st_hint(slot, alive + (alive0 + i), prog.stream_hint != 0u);
+        st_hint(slot, alive + ring_row(list_first, i, prog.capacity), prog.stream_hint != 0u);
         uint8_t alive_byte = 1u;  // the update walks the slots through these bytes
         if (prog.age_cohort) {  // a chunk that keeps its particles' common age in one word: this slot's age is in the plane (state 2, byte 3)
             uint32_t* astate = reinterpret_cast<uint32_t*>(base + prog.lmin_off) + 2u * prog.chunks_per_inst;
@@ -610,7 +613,17 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     const bool has_rows = chunk_setup(c, chunk, args, inst_base, meta_in, fi);
     const HorizonView hz = horizon_view(c.base, args.horizon_off, args.chunks_per_inst);
     if (fi[c.k].skip) {  // not simulated this frame: counters carry over unchanged
-        if (c.j == 0 && tid == 0) { store_meta(meta_out + c.k, c.m); cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + c.k] = 0u; }
+        DevMeta keep = c.m;
+        if (args.force_rewrite && list_head(c.m.write_index) != 0u) {
+            // ("Ring lists") ... but a frozen instance whose list stands behind a head is moved to the other column, linear, like everybody else's in this
+            // frame: the sort kernels that may follow walk every instance of the program and know linear lists only. Same rows, same order.
+            const uint32_t hd = list_head(c.m.write_index), n_rows = c.m.alive_count;
+            const uint32_t* from = reinterpret_cast<const uint32_t*>(c.base + (list_column(c.m.write_index) ? args.alive_off[1] : args.alive_off[0]));
+            uint32_t* to = reinterpret_cast<uint32_t*>(c.base + (list_column(c.m.write_index) ? args.alive_off[0] : args.alive_off[1]));
+            for (uint32_t r = c.j * kChunk + tid; r < n_rows && r < (c.j + 1u) * kChunk; r += kBlock) to[r] = from[ring_row(hd, r, args.capacity)];
+            keep.write_index = list_column(c.m.write_index) ^ 1u;
+        }
+        if (c.j == 0 && tid == 0) { store_meta(meta_out + c.k, keep); cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + c.k] = 0u; }
         if (args.hz && tid == 0) { hz.D(args.hz_parity ^ 1u)[c.j] = hz.D(args.hz_parity)[c.j]; hz.BF(args.hz_parity ^ 1u)[c.j] = hz.BF(args.hz_parity)[c.j]; }   // the rows stand: so do their horizons
         return;
     }
@@ -619,7 +632,43 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     if (c.j == 0 && tid == 0) cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + c.k] = 0u;  // next frame's counter
     const bool last = c.n == 0 ? c.j == 0 : (c.start < c.n && c.start + kChunk >= c.n);
     const bool rotate = args.rotate_front != 0u && c.n_spawn != 0u;   // (uniform per instance; never set together with slot_order)
-    if (total_dead == 0u && !rotate) {
+    const uint32_t head = list_head(c.m.write_index);
+    // ---- Ring lists -----------------------------------------------------------------------------------------------------------------------------
+    // A single-ribbon trail (C5: ribbon.rs) keeps its list in (RIBBON_ID, AGE) order = youngest first: every frame a few spawns go in FRONT and,
+    // where all particles live equally long, the casualties are the LAST rows (CompactArgs::rotate_front / suffix_dead: host-proven). Rotating
+    // the spawns in by rewriting the list moved every row of it every frame (4.19M rows = 33.8 MB to place 46 k: 11 us of C5's 37). As a ring the
+    // list stays where it is: k_init has written the spawns in front of the head (DevProgram::ring), the head moves back by n_spawn, the count
+    // drops by the casualties, and only the casualties' rows are READ (to push their slots on the dead list, and to check the host's proof against
+    // their died bits). DevMeta::write_index carries the head in bits 1..31 (HnbDeviceMeta::list_column: readers use
+    // column[(head + row) % capacity]); every other path reads rows through ring_row() and writes its result linear (head 0) - a frame that
+    // cannot be a ring frame while a head is set is told to rewrite (CompactArgs::force_rewrite), so the sort kernels only ever see head 0.
+    if (args.ring && !fi[c.k].skip) {
+        if (!has_rows && !(c.n == 0u && c.j == 0u)) return;
+        const uint32_t alive0 = c.m.alive_count;                                   // rows the frame started with (logical rows of the OLD head)
+        if (total_dead > alive0 && tid == 0u && args.fault) *args.fault = 1u;
+        const uint32_t dead_n = total_dead < alive0 ? total_dead : alive0;
+        const uint32_t first_dead = alive0 - dead_n;                                // old rows [first_dead, alive0): the oldest = the frame's casualties
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(c.base + (list_column(c.m.write_index) ? args.alive_off[1] : args.alive_off[0]));
+        uint32_t* dead = reinterpret_cast<uint32_t*>(c.base + args.dead_off);
+        const uint32_t* died = reinterpret_cast<const uint32_t*>(c.base + args.died_bits_off);
+        for (uint32_t d = c.j * kChunk + tid; d < dead_n && d < (c.j + 1u) * kChunk; d += kBlock) {
+            const uint32_t slot = src[ring_row(head, first_dead + d, args.capacity)];
+            dead[c.n - 1u - d] = slot;                                             // the d-th casualty in serial order lands on dead row n-1-d (vfx_update.wgsl:150-151)
+            if (((died[slot >> 5] >> (slot & 31u)) & 1u) == 0u && args.fault) *args.fault = 1u;   // the host's proof, checked (as the suffix path does)
+        }
+        if (last && tid == 0) {
+            const uint32_t survivors = c.n - dead_n;
+            DevMeta o = c.m;
+            o.alive_count = survivors;
+            o.particle_counter = c.m.particle_counter + c.n_spawn;
+            o.write_index = (ring_row(head, args.capacity - c.n_spawn, args.capacity) << 1) | list_column(c.m.write_index);   // the spawns are rows 0 .. n_spawn - 1 now
+            o.ref_write_index = c.m.ref_write_index ^ 1u;
+            o.max_update = c.n; o.dead_count = dead_n; o.spawned = c.n_spawn; o.instance_count = survivors;
+            store_meta(meta_out + c.k, o);
+        }
+        return;
+    }
+    if (total_dead == 0u && !rotate && !(args.force_rewrite && head != 0u)) {
         if (args.hz && tid == 0) { hz.D(args.hz_parity ^ 1u)[c.j] = hz.D(args.hz_parity)[c.j]; hz.BF(args.hz_parity ^ 1u)[c.j] = hz.BF(args.hz_parity)[c.j]; }   // no row moved
         if (last && tid == 0) {
             DevMeta o = c.m;
@@ -652,15 +701,16 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     // lane) and the chunk's row-mask words. (The prefix ends in a barrier; issued behind it, the rows were a further dependent round trip
     // in a kernel that is a chain of them: metadata -> counts -> mask -> rows -> stores.)
     constexpr uint32_t kSteps = kWaveRows / 64u;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(c.base + ((c.m.write_index & 1u) ? args.alive_off[1] : args.alive_off[0])) + c.start;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(c.base + ((c.m.write_index & 1u) ? args.alive_off[1] : args.alive_off[0]));
+    const uint32_t row0 = ring_row(head, c.start, args.capacity);   // (head 0 everywhere but behind ring frames: rows are read through the ring, written linear)
     uint32_t v[kSteps];
     const bool nt = args.stream_hint != 0u;   // (uniform: one scalar branch around each unrolled run of accesses)
     if (nt) {
 #pragma unroll
-        for (uint32_t q = 0; q < kSteps; ++q) { const uint32_t i = wave * kWaveRows + q * 64u + lane; v[q] = i < rows ? __builtin_nontemporal_load(src + i) : 0u; }
+        for (uint32_t q = 0; q < kSteps; ++q) { const uint32_t i = wave * kWaveRows + q * 64u + lane; v[q] = i < rows ? __builtin_nontemporal_load(src + ring_row(row0, i, args.capacity)) : 0u; }
     } else {
 #pragma unroll
-        for (uint32_t q = 0; q < kSteps; ++q) { const uint32_t i = wave * kWaveRows + q * 64u + lane; v[q] = i < rows ? src[i] : 0u; }
+        for (uint32_t q = 0; q < kSteps; ++q) { const uint32_t i = wave * kWaveRows + q * 64u + lane; v[q] = i < rows ? src[ring_row(row0, i, args.capacity)] : 0u; }
     }
     unsigned long long word;   // (bit r of word i: row 64 i + r survives; nothing died in the instance: every row that exists survives)
     const bool suffix = args.suffix_dead != 0u && total_dead != 0u;
@@ -751,7 +801,7 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
         DevMeta o = c.m;
         o.alive_count = survivors;
         o.particle_counter = c.m.particle_counter + c.n_spawn;
-        o.write_index = c.m.write_index ^ 1u;  // the list now lives in the other column
+        o.write_index = list_column(c.m.write_index) ^ 1u;  // the list now lives in the other column, linear (head 0)
         o.ref_write_index = c.m.ref_write_index ^ 1u;
         o.max_update = c.n;
         o.dead_count = c.n - survivors;
@@ -777,6 +827,8 @@ struct CompactArgs {
     uint32_t stream_hint;      // 1: list rows are read and written with the nontemporal hint ("cache policy of streamed data")
     uint32_t rotate_front;     // ribbon programs, host-proven (HnbProgram::sort_front_*): this frame's spawns sort in front of every older
                                // particle, so the survivors are written [spawns | older ones] and the list needs no sort afterwards
+    uint32_t ring;             // "Ring lists": rotate_front (or no spawn) AND suffix_dead hold: nothing is rewritten, the head moves (DevProgram::ring for k_init)
+    uint32_t force_rewrite;    // a list with a head may be standing in a frame that is not a ring frame: rewrite it linear whatever died
 };
 #ifndef HNB_JIT_TU
 __global__ void __launch_bounds__(kBlock)
@@ -930,7 +982,7 @@ k_emit_events(const DevProgram prog, const uint64_t* __restrict__ inst_base, con
         const uint32_t capacity = ev->capacity;
         if (mine == 0u || excl >= capacity) continue;   // (uniform: every thread of the workgroup takes the same way)
         const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c.base + prog.ev_cnt_off[ch]);                 // per slot
-        const uint32_t* slots = reinterpret_cast<const uint32_t*>(c.base + prog.alive_off[c.m.write_index]) + c.start;  // rows as the update saw them
+        const uint32_t* slots = reinterpret_cast<const uint32_t*>(c.base + prog.alive_off[list_column(c.m.write_index)]) + c.start;  // rows as the update saw them (programs that emit events never keep a ring: head 0)
         uint32_t slot[kPer], n_ev[kPer], local = 0;
 #pragma unroll
         for (uint32_t r = 0; r < kPer; ++r) {
@@ -1602,7 +1654,8 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
             return;
         }
     }
-    const uint32_t* list = reinterpret_cast<const uint32_t*>(c.base + ((c.m.write_index & 1u) ? args.alive_off[1] : args.alive_off[0])) + c.start;
+    const uint32_t* list = reinterpret_cast<const uint32_t*>(c.base + ((c.m.write_index & 1u) ? args.alive_off[1] : args.alive_off[0]));
+    const uint32_t row0 = ring_row(list_head(c.m.write_index), c.start, args.capacity);   // ("Ring lists": the rows may stand behind a head)
     const uint32_t* died = reinterpret_cast<const uint32_t*>(c.base + args.died_bits_off);
     unsigned long long* rmask = reinterpret_cast<unsigned long long*>(c.base + args.row_mask_off) + (size_t)c.j * (kChunk / 64u);
     const uint32_t rows = (c.n - c.start) < kChunk ? (c.n - c.start) : kChunk;
@@ -1613,7 +1666,7 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
 #pragma unroll
     for (uint32_t s = 0; s < kSteps; ++s) {
         const uint32_t i = wave * kWaveRows + s * 64u + lane;
-        slot[s] = i < rows ? ld_hint(list + i, args.stream_hint != 0u) : 0xffffffffu;
+        slot[s] = i < rows ? ld_hint(list + ring_row(row0, i, args.capacity), args.stream_hint != 0u) : 0xffffffffu;
     }
 #pragma unroll
     for (uint32_t s = 0; s < kSteps; ++s) bits[s] = slot[s] != 0xffffffffu ? died[slot[s] >> 5] : 0xffffffffu;   // (nontemporal loads: 1.8x slower; agent-scope atomic loads: the same, profiles/r03c_count_load.log)
@@ -1740,7 +1793,7 @@ k_emit_count(const DevProgram prog, const uint64_t* __restrict__ inst_base, cons
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap);
     ChunkCtx c;
     if (!chunk_setup(c, chunk, prog, inst_base, meta_in, fi)) return;
-    const uint32_t* list = reinterpret_cast<const uint32_t*>(c.base + prog.alive_off[c.m.write_index]);
+    const uint32_t* list = reinterpret_cast<const uint32_t*>(c.base + prog.alive_off[list_column(c.m.write_index)]);   // (programs that emit events never keep a ring: head 0)
     const uint32_t rows = (c.n - c.start) < kChunk ? (c.n - c.start) : kChunk;
     // a thread's 16 rows are requested together, then their 16 counts per channel (row by row it was a chain of 32 dependent accesses per
     // channel: 20 us for the one chunk of the firework's rocket effect, profiles/r03zz_kernel_stats.csv)

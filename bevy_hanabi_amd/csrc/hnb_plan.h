@@ -109,9 +109,11 @@ struct RibbonDecision {
     bool head_sorted = false;           // values_ok + no host write + the option: the sort may be partial / skipped without spawns
     bool rotate = false;                // k_compact writes [spawns | older ones]: no sort kernel
     bool suffix = false;                // k_count_rows does not run
+    bool ring = false;                  // both hold (or nothing spawns): the list is kept as a ring - k_init writes the spawns in front of the head, k_compact
+                                        // moves the head and drops the last rows; nothing is rewritten (hnb_kernels.hip.h "Ring lists")
 };
 inline RibbonDecision prove_ribbon_order(const RibbonFacts& facts, RibbonHistory& h, uint32_t capacity, const InstanceFrame* inst, uint32_t n,
-                                         bool option_skip_lists, bool option_suffix) {
+                                         bool option_skip_lists, bool option_suffix, bool option_ring = false) {
     RibbonDecision d;
     bool ok = facts.provable;
     for (uint32_t i = 0; i < n; ++i) {
@@ -161,6 +163,7 @@ inline RibbonDecision prove_ribbon_order(const RibbonFacts& facts, RibbonHistory
     d.head_sorted = facts.provable && d.values_ok && !h.dirty && option_skip_lists;
     d.rotate = front && d.head_sorted && d.max_spawn > 0u;
     d.suffix = front && d.head_sorted && !h.life_changed && option_suffix;
+    d.ring = option_ring && d.suffix && (d.rotate || d.max_spawn == 0u);
     return d;
 }
 

@@ -88,7 +88,7 @@ typedef enum HnbScalarType { HNB_BOOL = 0, HNB_F32 = 1, HNB_I32 = 2, HNB_U32 = 3
                                     HNB_VM_MAX_REGS run on the wide file: specialised kernels scalarise it, the
                                     interpreter kernels index it in scratch memory (correct, slower). */
 #define HNB_VM_MAX_UREGS 256u  /* U registers per instance */
-#define HNB_MAX_EVENT_CHANNELS 8u /* child event channels per parent effect (EmitSpawnEventModifier::child_index < 4) */
+#define HNB_MAX_EVENT_CHANNELS 8u /* child event channels per parent effect (EmitSpawnEventModifier::child_index < 8; the reference loops over any number: src/lib.rs:964-1002) */
 #define HNB_OPERAND_U 0x80u
 /* Decoded operand of a varying stream (what the VM works with): bit 8 = U register, bits 7:0 = index. */
 #define HNB_OPERAND_DECODED_U 0x100u
@@ -309,6 +309,11 @@ int hnb_ctx_synchronize(HnbContext* ctx);
 #define HNB_OPT_TRANSPOSE 7u
 #define HNB_OPT_SCENE_MERGE 8u
 #define HNB_OPT_SUFFIX_PROOF 9u
+/* HNB_OPT_RING_LISTS (default 1; from the next hnb_simulate on): a ribbon effect for which the host can prove both that this frame's spawns sort in
+ *   front of every older particle and that the frame's casualties are the list's last rows (one ribbon id, ages from +0, one lifetime: examples/
+ *   ribbon.rs) keeps its alive list as a RING: the init pass writes the spawns in front of the list's head, the head moves, the count drops - no row is
+ *   rewritten (HnbDeviceMeta::list_column carries the head). 0: the list is rotated by rewriting it, as before round 5. Same list either way. */
+#define HNB_OPT_RING_LISTS 16u
 /* HNB_OPT_OVERLAP_UPDATES (default 1; from the next hnb_simulate on): when one program of the context holds at least four times the slots
  *   of all the others together (and >= 1M), the update phase of the others - update, spawn-event ordering, lists, sort: independent chains -
  *   runs on an internal second stream next to the heavy program's update and joins the context's stream before hnb_simulate returns.
@@ -398,7 +403,7 @@ int hnb_simulate(HnbContext* ctx);
  * same GPU (a renderer through external-memory interop, a baking kernel, a physics query) gets the same three things as device pointers,
  * without a copy and without a synchronisation:
  *     HnbDeviceView v; hnb_effect_device_view(fx, &v);
- *     consumer<<<.., (hipStream_t)v.stream>>>(v);    // row r < v.meta->alive_count: slot = v.alive_list[v.meta->list_column][r];
+ *     consumer<<<.., (hipStream_t)v.stream>>>(v);    // row r < v.meta->alive_count: slot = v.alive_list[v.meta->list_column & 1][((v.meta->list_column >> 1) + r) % v.capacity];
  *                                                    //   position = ((const float*)v.attrs[i].plane) + 3 * slot   (attrs[i].attr == HNB_ATTR_POSITION)
  * Stream-ordering contract: the view describes the effect AFTER every hnb_simulate enqueued so far. Kernels enqueued on v.stream (or on
  * another stream behind an event recorded on v.stream) after the call and before the next hnb_simulate see exactly that state; they must
@@ -413,7 +418,11 @@ int hnb_simulate(HnbContext* ctx);
 typedef struct HnbDeviceMeta {          /* one 32-byte row per effect instance, device-resident; written by the frame's last kernel */
     uint32_t alive_count;               /* EffectMetadata::alive_count after the frame */
     uint32_t particle_counter;
-    uint32_t list_column;               /* which of HnbDeviceView::alive_list[2] holds the alive list (changes only in frames with casualties) */
+    uint32_t list_column;               /* bit 0: which of HnbDeviceView::alive_list[2] holds the alive list (changes only in frames with casualties);
+                                         * bits 1..31: list_head - row r of the list is alive_list[list_column & 1][(list_head + r) % capacity]. The head is 0
+                                         * for every effect except single-ribbon trails whose list is kept as a RING (HNB_OPT_RING_LISTS): their spawns go in
+                                         * front of the head and their casualties drop off the end, so nothing is rewritten. A reader that always applies the
+                                         * formula is right for every effect. */
     uint32_t max_update;                /* rows the frame's update pass processed */
     uint32_t dead_count, spawned;
     uint32_t indirect_write_index;      /* EffectMetadata::indirect_write_index as the reference counts it (flips every frame) */

@@ -44,12 +44,12 @@ void cpl_ribbon_host_write(void* h, int wrote_age) {                            
     r->hist.dirty = true; r->hist.front_broken = true;
     if (wrote_age) r->hist.values_broken = true;
 }
-// out: max_spawn, values_ok, front, head_sorted, rotate, suffix
+// out: max_spawn, values_ok, front, head_sorted, rotate, suffix, ring (opt_ring: bit 1 of opt_suffix)
 void cpl_ribbon_step(void* h, uint32_t capacity, const Row* rows, uint32_t n, int opt_skip_lists, int opt_suffix, uint32_t* out) {
     Ribbon* r = static_cast<Ribbon*>(h);
     const std::vector<InstanceFrame> v = frames_of(rows, n);
-    const RibbonDecision d = prove_ribbon_order(r->facts, r->hist, capacity, v.data(), n, opt_skip_lists != 0, opt_suffix != 0);
-    out[0] = d.max_spawn; out[1] = d.values_ok; out[2] = d.front; out[3] = d.head_sorted; out[4] = d.rotate; out[5] = d.suffix;
+    const RibbonDecision d = prove_ribbon_order(r->facts, r->hist, capacity, v.data(), n, opt_skip_lists != 0, (opt_suffix & 1) != 0, (opt_suffix & 2) != 0);
+    out[0] = d.max_spawn; out[1] = d.values_ok; out[2] = d.front; out[3] = d.head_sorted; out[4] = d.rotate; out[5] = d.suffix; out[6] = d.ring;
 }
 
 int cpl_horizon_usable(int eligible, uint32_t dt_operand, const Row* rows, uint32_t n) {

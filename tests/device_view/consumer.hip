@@ -8,11 +8,12 @@
 __global__ void k_gather_rows(HnbDeviceView v, uint32_t attr_index, uint32_t* __restrict__ out, uint32_t* __restrict__ out_count) {
     const HnbDeviceMeta m = *v.meta;                                   // device-resident counters: no host knows alive_count here
     const uint32_t* list = v.alive_list[m.list_column & 1u];
+    const uint32_t head = m.list_column >> 1;                          // 0 except for effects whose list is kept as a ring (HNB_OPT_RING_LISTS)
     const HnbDeviceAttr a = v.attrs[attr_index];
     const uint32_t nc = a.ncomp;
     if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = m.instance_count;
     for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < m.alive_count; row += gridDim.x * blockDim.x) {
-        const uint32_t slot = list[row];
+        const uint32_t slot = list[(head + row) % v.capacity];
         const uint32_t* src = reinterpret_cast<const uint32_t*>(static_cast<const char*>(a.plane) + (size_t)slot * a.stride_bytes);
         for (uint32_t c = 0; c < nc; ++c) out[(size_t)row * nc + c] = src[c];
     }
@@ -25,11 +26,12 @@ __global__ void k_gather_rows_program(HnbProgramView v, uint32_t attr_index, uin
     const HnbDeviceMeta m = v.meta[k];
     const char* base = reinterpret_cast<const char*>(v.slabs[k]);
     const uint32_t* list = reinterpret_cast<const uint32_t*>(base + v.alive_list_off[m.list_column & 1u]);
+    const uint32_t head = m.list_column >> 1;
     const HnbProgramAttr a = v.attrs[attr_index];
     const uint32_t nc = a.ncomp;
     if (blockIdx.x == 0 && threadIdx.x == 0) out_count[k] = m.instance_count;
     for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < m.alive_count; row += gridDim.x * blockDim.x) {
-        const uint32_t slot = list[row];
+        const uint32_t slot = list[(head + row) % v.capacity];
         const uint32_t* src = reinterpret_cast<const uint32_t*>(base + a.plane_off + (size_t)slot * a.stride_bytes);
         for (uint32_t c = 0; c < nc; ++c) out[((size_t)k * v.capacity + row) * nc + c] = src[c];
     }
@@ -49,11 +51,12 @@ extern "C" int consumer_gather_program(const HnbProgramView* view, uint32_t attr
 __global__ void k_render_like(HnbDeviceView v, uint32_t i_pos, uint32_t i_age, uint32_t i_life, float4* __restrict__ out) {
     const HnbDeviceMeta m = *v.meta;
     const uint32_t* list = v.alive_list[m.list_column & 1u];
+    const uint32_t head = m.list_column >> 1;
     const float* pos = static_cast<const float*>(v.attrs[i_pos].plane);
     const float* age = static_cast<const float*>(v.attrs[i_age].plane);
     const float* life = static_cast<const float*>(v.attrs[i_life].plane);
     for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < m.alive_count; row += gridDim.x * blockDim.x) {
-        const uint32_t slot = list[row];
+        const uint32_t slot = list[(head + row) % v.capacity];
         out[row] = make_float4(pos[3 * (size_t)slot], pos[3 * (size_t)slot + 1], pos[3 * (size_t)slot + 2], age[slot] / life[slot]);
     }
 }

@@ -150,13 +150,13 @@ class RibbonRunner:
         self.lib = lib
         self.h = lib.cpl_ribbon_new(provable, front_static, age_init_set, rid_set, TICK, AGE0, RID, LIFE)
 
-    def frame(self, *specs, capacity=4096, opt_skip=1, opt_suffix=1, sorted_after=True):
+    def frame(self, *specs, capacity=4096, opt_skip=1, opt_suffix=1, opt_ring=1, sorted_after=True):
         arr, n = rows(*specs)
-        out = (C.c_uint32 * 6)()
-        self.lib.cpl_ribbon_step(self.h, capacity, arr, n, opt_skip, opt_suffix, out)
+        out = (C.c_uint32 * 7)()
+        self.lib.cpl_ribbon_step(self.h, capacity, arr, n, opt_skip, (opt_suffix & 1) | (2 if opt_ring else 0), out)
         if sorted_after:
             self.lib.cpl_ribbon_sorted(self.h)     # the frame ran its sort (or proved it unnecessary): the list is in key order again
-        return dict(zip(("max_spawn", "values_ok", "front", "head_sorted", "rotate", "suffix"), (int(x) for x in out)))
+        return dict(zip(("max_spawn", "values_ok", "front", "head_sorted", "rotate", "suffix", "ring"), (int(x) for x in out)))
 
 
 def trail(spawn=8, tick=DT, age0=0.0, rid=7, life=1.5, **kw):
@@ -169,7 +169,7 @@ def test_ribbon_proofs_hold_for_the_usual_trail(lib):
     assert d["values_ok"] and not d["head_sorted"] and not d["rotate"]      # first frame: nothing sorted yet (history starts dirty)
     assert d["front"]                                                        # (vacuously: no older particle exists; min_tick starts at +inf)
     d = r.frame(trail())
-    assert d == dict(max_spawn=8, values_ok=1, front=1, head_sorted=1, rotate=1, suffix=1)
+    assert d == dict(max_spawn=8, values_ok=1, front=1, head_sorted=1, rotate=1, suffix=1, ring=1)
     d = r.frame(trail(spawn=0))
     assert d["front"] and d["head_sorted"] and not d["rotate"] and d["suffix"] and d["max_spawn"] == 0     # nothing to rotate without spawns
     d = r.frame(trail(spawn=100000), capacity=4096)
@@ -237,7 +237,7 @@ def test_ribbon_premise_violations(lib):
     assert not r.frame(trail())["values_ok"]
     # static facts missing
     r = RibbonRunner(lib, provable=0, front_static=0); r.frame(trail())
-    assert r.frame(trail()) == dict(max_spawn=8, values_ok=0, front=0, head_sorted=0, rotate=0, suffix=0)
+    assert r.frame(trail()) == dict(max_spawn=8, values_ok=0, front=0, head_sorted=0, rotate=0, suffix=0, ring=0)
     r = RibbonRunner(lib, provable=1, front_static=0); r.frame(trail())
     d = r.frame(trail())
     assert d["values_ok"] and d["head_sorted"] and not d["front"]
@@ -394,3 +394,22 @@ def test_a_newcomer_stays_out_so_that_the_covered_programs_keep_their_set_kernel
     assert _split(lib, [(0, STREAM, 1, 1), (0, STREAM, 0, 1)]) == [0, 0]                            # one covered program is not a set
     assert _split(lib, covered + [(1, WIDE, 0, 1)]) == [0] * 7                                     # the wide register file never runs on the set kernels: not its concern
     assert _split(lib, covered + [(-1, -1, 0, 1)]) == [0] * 7                                      # a program that is not merged this frame anyway
+
+
+def test_ring_frames_need_both_ribbon_proofs(lib):
+    """A list is kept as a ring (nothing rewritten: hnb_kernels.hip.h "Ring lists") in exactly the frames in which the spawns provably sort in front AND the
+    casualties are provably the last rows - or nothing spawns at all."""
+    r = RibbonRunner(lib)
+    r.frame(trail(spawn=8))                                       # the first frame: nothing sorted yet
+    d = r.frame(trail(spawn=8))
+    assert d["rotate"] and d["suffix"] and d["ring"]
+    d = r.frame(trail(spawn=0))                                   # nothing spawns: the casualties still drop off the end
+    assert not d["rotate"] and d["suffix"] and d["ring"]
+    assert not r.frame(trail(spawn=8), opt_ring=0)["ring"]        # HNB_OPT_RING_LISTS off
+    assert not r.frame(trail(spawn=8), opt_suffix=0)["ring"]      # no suffix proof: the casualties must be looked for, the list is rewritten
+    d = r.frame(trail(spawn=8, life=2.5))                         # a lifetime that changed: older particles die out of order from now on
+    assert d["rotate"] and not d["suffix"] and not d["ring"]
+    r2 = RibbonRunner(lib)
+    r2.frame(trail(spawn=8)); r2.frame(trail(spawn=8))
+    d = r2.frame(trail(spawn=8, age0=0.5))                        # spawns that do not start at +0: they do not sort in front
+    assert not d["rotate"] and not d["ring"]

@@ -706,6 +706,61 @@ def test_ribbon_sort_is_a_rotation_where_the_spawns_provably_go_in_front(ctx):
     prog.destroy()
 
 
+def _ring_frames(prog):
+    line = [l for l in prog.kernel_info().split("\n") if l.startswith("list kept as a ring")]
+    return int(line[0].split(":")[1].split()[0]) if line else 0
+
+
+def test_ribbon_list_kept_as_a_ring_equals_the_rewritten_list_and_the_oracle():
+    """Ring lists (round 5, HNB_OPT_RING_LISTS): where both ribbon proofs hold the list is never rewritten - k_init writes the spawns in front of the head,
+    k_compact moves the head and drops the last rows. Same list as with the option off and as the oracle's, frame after frame, through several
+    wrap-arounds of the head, frames without spawns, a frozen stretch and a lifetime change that ends the suffix proof (the first frame behind it
+    rewrites the list linear); a HIP consumer reads it through the view (HnbDeviceMeta::list_column carries the head); hnb_effect_check /
+    hnb_effect_compare know about heads."""
+    import ctypes as C
+    import os
+    import torch
+    from bevy_hanabi_amd import runtime
+    cons = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "device_view", "libconsumer.so"))
+    cons.consumer_gather.argtypes = [C.POINTER(runtime.DeviceView), C.c_uint32, C.c_void_p, C.c_void_p]
+    cap = 5000
+    asset = _ribbon_asset(cap, lifetime_prop=True)
+    on, off = bh.Context(0), bh.Context(0)
+    off.set_option("ring_lists", 0)
+    g_on, g_off, orc = GpuRunner(asset, ctx=on), GpuRunner(asset, ctx=off), OracleRunner(asset)
+    sp, rng = bh.EffectSpawner(asset.spawner), bh.Pcg32()
+    heads = set()
+    for f in range(260):
+        dt = [1 / 60, 1 / 30, 1 / 144][f % 3]
+        spawn = sp.tick(dt, rng) if f % 9 else 0
+        props = {"life": np.array([0.4], dtype=np.float32)} if f == 200 else {}
+        fr = Frame(dt, spawn, frame_seed(f), time=f / 60, props=props)
+        frozen = 120 <= f < 140
+        for x in (g_on, g_off):
+            x.fx.set_simulated(not frozen)
+            x.step(fr)
+        if not frozen:
+            orc.step(fr)
+        if f % 6 == 5 or f in (0, 1, 119, 120, 140, 199, 200, 201, 202):
+            ref = orc.state()
+            assert_same_state(ref, g_on.state(), f"ring, frame {f}")
+            assert_same_state(ref, g_off.state(), f"rewritten, frame {f}")
+            v = g_on.fx.device_view()
+            out = torch.zeros(cap, dtype=torch.int32, device="cuda")
+            cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            assert cons.consumer_gather(C.byref(v), A.AGE.id, out.data_ptr(), cnt.data_ptr()) == 0
+            on.synchronize()
+            n = int(cnt.item())
+            assert n == len(ref["alive"])
+            np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32)[:n], ref["attrs"]["age"].reshape(-1)[ref["alive"]], err_msg=f"consumer through the view, frame {f}")
+            assert g_on.fx.check()["ok"] == 1 and g_on.fx.compare(g_off.fx)["equal"] == 1
+    ring, plain = _ring_frames(g_on.prog), _ring_frames(g_off.prog)
+    assert plain == 0 and 150 <= ring <= 205, (ring, g_on.prog.kernel_info())       # every frame up to the lifetime change but the first and the frozen ones
+    assert _rotations(g_on.prog)[0] >= 180 and g_on.fx.metadata()["fault"] == 0 and g_off.fx.metadata()["fault"] == 0
+    on.close(); off.close()
+
+
 def test_ribbon_sort_after_a_negative_tick_does_not_trust_later_frames(ctx):
     """a negative delta_time leaves negative ages behind. The frame that had it is sorted by the device-checked path, but
     the ages cross zero in LATER frames whose own tick is fine - their bit-pattern keys change order then. Those frames must not be

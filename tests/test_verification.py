@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 PLAIN = {"horizon": 0, "age_cohort": 0, "cull_lifetime": 0, "skip_lists": 0, "stream_hints": 0, "overlap_updates": 0,
-         "suffix_proof": 0, "alternate": 0, "transpose": 0, "scene_merge": 0}
+         "suffix_proof": 0, "ring_lists": 0, "alternate": 0, "transpose": 0, "scene_merge": 0}
 
 
 def _ctx(options):
