@@ -182,7 +182,6 @@ struct HnbContext {
     bool skip_lists = true;     // skip the list kernels of frames the device's no-death bound covers (HNB_OPT_SKIP_LISTS)
     bool alternate = true;      // walk the chunks in alternating directions from frame to frame (HNB_OPT_ALTERNATE)
     bool suffix_proof = true;   // ribbon programs: "the casualties are the last rows of the sorted list" replaces k_count_rows where the host can prove it (HNB_OPT_SUFFIX_PROOF)
-    bool upload_inline = false; // HNB_OPT_UPLOAD_INLINE: the frame's parameter upload on the simulation stream instead of beside the previous frame's kernels
     bool ring_lists = true;     // ... and where in addition the spawns sort in front, the list is kept as a ring: nothing is rewritten (HNB_OPT_RING_LISTS)
     bool scene_merge = true;    // small programs share their init / update launches (ProgJob / StreamJob; HNB_OPT_SCENE_MERGE)
     bool transpose = true;      // vec3 planes of the per-particle update path through the wave's LDS transpose (HNB_OPT_TRANSPOSE)
@@ -982,7 +981,6 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
         case HNB_OPT_SCENE_MERGE: ctx->scene_merge = value != 0u; return HNB_OK;
         case HNB_OPT_SUFFIX_PROOF: ctx->suffix_proof = value != 0u; return HNB_OK;
         case HNB_OPT_RING_LISTS: ctx->ring_lists = value != 0u; return HNB_OK;
-        case HNB_OPT_UPLOAD_INLINE: ctx->upload_inline = value != 0u; return HNB_OK;
         case HNB_OPT_STREAM_HINTS: ctx->stream_hints = value != 0u; return HNB_OK;
         case HNB_OPT_JIT_ASYNC: ctx->jit_async = value != 0u; return HNB_OK;
         case HNB_OPT_SET_MODULE:
@@ -2167,12 +2165,10 @@ int hnb_simulate(HnbContext* ctx) {
     fill_lists_jobs(ctx, order, slot, stage_off, timed, fj);
     fill_merge_jobs(ctx, order, slot, stage_off, timed, fj);
     if (stage_off) {
-        if (ctx->upload_inline) {   // HNB_OPT_UPLOAD_INLINE: the copy in front of the frame's first kernel on the simulation stream (the staging slot is not reused before stage_done[slot])
-            HIP_TRY(hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], stage_off, hipMemcpyHostToDevice, ctx->stream));
-        } else {
-            HIP_TRY(hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], stage_off, hipMemcpyHostToDevice, ctx->upload_stream));
-            HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
-        }
+        // (Round 5, tried: the copy on the simulation stream in front of the frame's first kernel instead - no host wait, no copy beside the previous frame's
+        // kernels. Slower everywhere: C5 0.0359 -> 0.0378 ms, c2_mixed 0.353 -> 0.360, the 26-effect scene 0.050 -> 0.064: profiles/r05j_ab_upload.log.)
+        HIP_TRY(hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], stage_off, hipMemcpyHostToDevice, ctx->upload_stream));
+        HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
     }
     rc = enqueue_init_passes(ctx, order, fj, timed);
     if (rc == HNB_OK) rc = enqueue_update_passes(ctx, order, fj, timed);

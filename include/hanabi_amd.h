@@ -314,10 +314,6 @@ int hnb_ctx_synchronize(HnbContext* ctx);
  *   ribbon.rs) keeps its alive list as a RING: the init pass writes the spawns in front of the list's head, the head moves, the count drops - no row is
  *   rewritten (HnbDeviceMeta::list_column carries the head). 0: the list is rotated by rewriting it, as before round 5. Same list either way. */
 #define HNB_OPT_RING_LISTS 16u
-/* HNB_OPT_UPLOAD_INLINE (default 0; from the next hnb_simulate on): the frame's one parameter upload is enqueued on the simulation stream in front
- *   of the frame's first kernel instead of on the library's upload stream (where it runs beside the previous frame's kernels and the host waits
- *   for it). 1 serialises a ~3 us copy into every frame and takes its cache maintenance out from under the previous frame's kernels. */
-#define HNB_OPT_UPLOAD_INLINE 17u
 /* HNB_OPT_OVERLAP_UPDATES (default 1; from the next hnb_simulate on): when one program of the context holds at least four times the slots
  *   of all the others together (and >= 1M), the update phase of the others - update, spawn-event ordering, lists, sort: independent chains -
  *   runs on an internal second stream next to the heavy program's update and joins the context's stream before hnb_simulate returns.
