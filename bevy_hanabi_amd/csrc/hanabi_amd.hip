@@ -182,6 +182,7 @@ struct HnbContext {
     bool skip_lists = true;     // skip the list kernels of frames the device's no-death bound covers (HNB_OPT_SKIP_LISTS)
     bool alternate = true;      // walk the chunks in alternating directions from frame to frame (HNB_OPT_ALTERNATE)
     bool suffix_proof = true;   // ribbon programs: "the casualties are the last rows of the sorted list" replaces k_count_rows where the host can prove it (HNB_OPT_SUFFIX_PROOF)
+    uint32_t slot_init = 1;     // frames that spawn a large share of a program's slots run their init slot-major (k_init_slots; HNB_OPT_SLOT_INIT)
     bool ring_lists = true;     // ... and where in addition the spawns sort in front, the list is kept as a ring: nothing is rewritten (HNB_OPT_RING_LISTS)
     bool scene_merge = true;    // small programs share their init / update launches (ProgJob / StreamJob; HNB_OPT_SCENE_MERGE)
     bool transpose = true;      // vec3 planes of the per-particle update path through the wave's LDS transpose (HNB_OPT_TRANSPOSE)
@@ -219,12 +220,15 @@ struct HnbProgram {
     bool wide_file = false;       // init_regs / update_regs above HNB_VM_MAX_REGS: generic kernels use the wide V file
     uint32_t cull_dt_operand = 0; // lifetime culling: decoded operand a of the update stream's AGE_TICK (dev.cull_lifetime)
     bool update_streams = false;  // update stream runs on the streaming kernel (macro ops, U operands)
-    bool auto_materialise = false;  // HNB_AGE_COHORT_AUTO, the render modifiers read AGE and the effect is large: cohorts, and the plane is made current at the end of every frame
+    uint32_t age_cohort_mode = HNB_AGE_COHORT_AUTO;   // HNB_OPT_AGE_COHORT as it stood when the program was created (fixed in the program from then on)
+    bool auto_materialise = false;  // HNB_AGE_COHORT_AUTO, the render modifiers read AGE and the effect is large: cohorts, and the update keeps the plane current (SlotArgs::age_current)
     StreamLaunchFn stream_launch = nullptr;  // specialised (or interpreted) streaming kernel for this update stream
     const char* stream_kernel_name = "";
     // kernels specialised for this program at creation (hnb_jit.h); null = the ahead-of-time kernels run
     hipModule_t jit_module = nullptr;
-    hipFunction_t jit_init = nullptr, jit_update = nullptr;
+    hipFunction_t jit_init = nullptr, jit_update = nullptr, jit_init_slots = nullptr;
+    bool slot_init_eligible = false;   // the init reads neither PARTICLE_COUNTER nor a parent particle, no ribbons: large spawns may run slot-major (plan::plan_slot_init)
+    uint32_t slot_init_frames = 0;     // statistics
     uint64_t serial = 0;            // identity across destruction (HNB_OPT_JIT_ASYNC: a finished compilation looks its program up by it)
     bool jit_pending = false;
     std::string kernel_info, jit_log;
@@ -777,16 +781,16 @@ bool cull_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEnt
     if (dt_operand) *dt_operand = HNB_OPERAND_DECODE((uc[0].x >> 16) & 0xffu, uc[0].y >> 13);
     return true;
 }
-constexpr uint32_t kAutoMaterialiseMinSlots = 1u << 20;   // HNB_AGE_COHORT_AUTO: from this capacity on an AGE-reading asset keeps the cohorts (+ a materialise pass per frame)
+constexpr uint32_t kAutoMaterialiseMinSlots = kSceneMaxChunks * kChunk;   // HNB_AGE_COHORT_AUTO: from this capacity on (65,536: an instance no longer "small" for the merged launches) an AGE-reading asset keeps the cohorts and its update keeps the plane current
 bool age_cohort_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams, const ProgramOptions& opt) {
     if (!cull_eligible(b, h, attrs, streams, opt, nullptr) || (h.flags & HNB_PROG_HAS_RIBBONS) || opt.age_cohort == HNB_AGE_COHORT_OFF) return false;
     // HNB_AGE_COHORT_AUTO (the default) chooses from the asset: where the RENDER modifiers read AGE after every frame (HnbProgramHeader::
     // render_reads_*: ColorOverLifetime / SizeOverLifetime, src/modifier/output.rs:310-312) the plane must be current after every frame.
-    // Measured end to end on the reference's own firework asset at 16.7M particles with a consumer kernel behind every frame
-    // (profiles/r05f_bench.json): cohorts + one k_materialise_age pass per frame 0.280 ms, per-particle ages 0.297 ms - but that pass is one
-    // more launch per program per frame, which a scene of small effects cannot afford (26 effects: 0.049 -> 0.082 ms per frame,
-    // profiles/r05c_bench.json). So: effects of a million slots or more keep the cohorts and have hnb_simulate materialise (auto_materialise),
-    // smaller ones keep their ages in the plane. Assets whose renderer does not read AGE get LEAN.
+    // Effects of 65,536 slots or more per instance keep the cohorts and their update kernel writes the common age of a cohort chunk into the plane
+    // as it goes (SlotArgs::age_current: write-only, 4 of the 8 bytes per particle the cohort saves; round 5 ran a k_materialise_age pass behind
+    // every update instead - one more launch and 16 us per frame at 16.7M particles - and only from 2^20 slots on). Smaller ones - the programs
+    // that share the merged launches of a scene - keep their ages in the plane: at those sizes the bytes do not matter and the cohort
+    // instantiation only costs registers. Assets whose renderer does not read AGE get LEAN.
     if (opt.age_cohort == HNB_AGE_COHORT_AUTO && (h.render_reads_lo >> HNB_ATTR_AGE & 1u) && h.capacity < kAutoMaterialiseMinSlots) return false;
     // only the lean (bandwidth-bound) stacks: an update that is bound by VALU issue (ConformToSphere, Radial / TangentAccel: divisions, square
     // roots) gains nothing from 8 bytes less per particle and pays for the bookkeeping (force_field: 0.0955 -> 0.099 ms with it, measured)
@@ -798,6 +802,15 @@ bool age_cohort_eligible(const uint8_t* b, const HnbProgramHeader& h, const HnbA
     return true;
 }
 
+// Slot-major init of large spawns (hnb_kernels.hip.h): what a spawn writes must not depend on its rank among the frame's spawns
+bool slot_init_eligible(const uint8_t* b, const HnbProgramHeader& h) {
+    if (h.flags & (HNB_PROG_HAS_RIBBONS | HNB_PROG_READS_PARENT)) return false;
+    const Ins* ic = reinterpret_cast<const Ins*>(b + h.init_off);
+    for (uint32_t i = 0; i < h.init_len; ++i)
+        if ((ic[i].x & 0xffu) == HNB_OP_LDPC || (ic[i].x & 0xffu) == HNB_OP_LDPARENT) return false;
+    return true;
+}
+
 // What to specialise for a program (see hnb_jit.h). `aot_static`: a pre-built ProgStatic kernel matches.
 jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const HnbAttrEntry* attrs, bool streams, bool aot_static, const ProgramOptions& opt) {
     jit::Request rq;
@@ -805,6 +818,7 @@ jit::Request make_jit_request(const uint8_t* b, const HnbProgramHeader& h, const
     rq.init = reinterpret_cast<const Ins*>(b + h.init_off); rq.init_len = h.init_len;
     rq.update = reinterpret_cast<const Ins*>(b + h.update_off); rq.update_len = h.update_len;
     rq.want_init = h.init_len > 0;
+    rq.want_init_slots = slot_init_eligible(b, h);
     rq.wide_file = std::max(h.init_regs, h.update_regs) > HNB_VM_MAX_REGS;
     rq.want_update_stream = streams && !aot_static && h.update_len > 0;
     rq.want_update_generic = !streams && h.update_len > 0;
@@ -823,6 +837,8 @@ void install_program_jit(HnbProgram* p, const jit::Result& res) {
     hipFunction_t fi = nullptr, fu = nullptr;
     hipError_t je = hipModuleLoadData(&mod, res.code.data());
     if (je == hipSuccess && !res.init_name.empty()) je = hipModuleGetFunction(&fi, mod, res.init_name.c_str());
+    hipFunction_t fs = nullptr;
+    if (je == hipSuccess && !res.init_slots_name.empty()) je = hipModuleGetFunction(&fs, mod, res.init_slots_name.c_str());
     if (je == hipSuccess && !res.update_name.empty()) je = hipModuleGetFunction(&fu, mod, res.update_name.c_str());
     if (je != hipSuccess) {
         p->jit_log = std::string("loading the specialised code object failed: ") + hipGetErrorString(je);
@@ -830,7 +846,7 @@ void install_program_jit(HnbProgram* p, const jit::Result& res) {
         (void)hipGetLastError();
         return;
     }
-    p->jit_module = mod; p->jit_init = fi; p->jit_update = fu;
+    p->jit_module = mod; p->jit_init = fi; p->jit_update = fu; p->jit_init_slots = fs;
     p->kernel_info = std::string(p->wide_file ? "wide-file " : "") + "init=" + (p->jit_init ? "jit" : (p->hdr.init_len ? "interp" : "none")) + " update=" +
                      (p->jit_update ? (p->update_streams ? "jit-stream" : "jit-generic")
                                     : (p->update_streams ? (aot_static ? std::string("aot-stream:") + p->stream_kernel_name : std::string("interp-stream"))
@@ -976,11 +992,20 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
             return HNB_OK;
         case HNB_OPT_CULL_LIFETIME: ctx->popt.cull_lifetime = value != 0u; return HNB_OK;
         case HNB_OPT_HORIZON: ctx->popt.horizon = value != 0u; return HNB_OK;
-        case HNB_OPT_TEST_BREAK_PROOF: ctx->break_proof = value != 0u; return HNB_OK;
+        case HNB_OPT_TEST_BREAK_PROOF: {   // a test hook that corrupts state on purpose: only for a process that says it is a test
+            const char* e = getenv("HNB_ENABLE_TEST_HOOKS");
+            if (value != 0u && !(e && e[0] == '1')) return fail(HNB_ERR_INVALID_ARG, "HNB_OPT_TEST_BREAK_PROOF is a test hook: refused unless HNB_ENABLE_TEST_HOOKS=1 is set in the environment");
+            ctx->break_proof = value != 0u;
+            return HNB_OK;
+        }
         case HNB_OPT_TRANSPOSE: ctx->transpose = value != 0u; return HNB_OK;
         case HNB_OPT_SCENE_MERGE: ctx->scene_merge = value != 0u; return HNB_OK;
         case HNB_OPT_SUFFIX_PROOF: ctx->suffix_proof = value != 0u; return HNB_OK;
         case HNB_OPT_RING_LISTS: ctx->ring_lists = value != 0u; return HNB_OK;
+        case HNB_OPT_SLOT_INIT:
+            if (value > 2u) return fail(HNB_ERR_INVALID_ARG, "unknown slot-init mode %u", value);
+            ctx->slot_init = value;
+            return HNB_OK;
         case HNB_OPT_STREAM_HINTS: ctx->stream_hints = value != 0u; return HNB_OK;
         case HNB_OPT_JIT_ASYNC: ctx->jit_async = value != 0u; return HNB_OK;
         case HNB_OPT_SET_MODULE:
@@ -1036,10 +1061,12 @@ int hnb_program_create(HnbContext* ctx, const void* blob, size_t blob_size, HnbP
     p->uniform_code.resize(h.uniform_len);
     if (h.uniform_len) memcpy(p->uniform_code.data(), b + h.uniform_off, (size_t)h.uniform_len * 8);
     p->wide_file = std::max(h.init_regs, h.update_regs) > HNB_VM_MAX_REGS;
+    p->slot_init_eligible = slot_init_eligible(b, h);
     if (cull_eligible(b, h, p->attrs.data(), p->update_streams, ctx->popt, &p->cull_dt_operand)) {
         d.cull_lifetime = 1u;
         d.age_cohort = age_cohort_eligible(b, h, p->attrs.data(), p->update_streams, ctx->popt) ? 1u : 0u;
     }
+    p->age_cohort_mode = ctx->popt.age_cohort;
     p->auto_materialise = ctx->popt.age_cohort == HNB_AGE_COHORT_AUTO && d.age_cohort != 0u && (h.render_reads_lo >> HNB_ATTR_AGE & 1u) != 0u;
     if (p->update_streams) select_stream_kernel(reinterpret_cast<const Ins*>(b + h.update_off), h.update_len, &p->stream_launch, &p->stream_kernel_name);
     if (!p->wide_file && jit::enabled()) {
@@ -1507,6 +1534,7 @@ static SlotArgs slot_args_of(const HnbContext* ctx, const HnbProgram* p, uint32_
     sa.died_bits_off = p->dev.died_bits_off; sa.write_died = write_died;
     sa.cull_lifetime = p->dev.cull_lifetime; sa.lmin_off = p->dev.lmin_off; sa.dt_operand = p->cull_dt_operand;
     sa.age_cohort = p->dev.age_cohort;
+    sa.age_current = p->auto_materialise ? 1u : 0u;   // HNB_AGE_COHORT_AUTO: the render modifiers read AGE after every frame
     sa.frame_phase = p->frames_run & 15u;
     sa.horizon_off = p->dev.horizon_off; sa.horizon = p->horizon_eligible ? 1u : 0u;
     if (p->skip_facts.eligible) { sa.safe_words = p->d_safe; sa.safe_host = p->h_safe; sa.safe_parity = p->frames_run & 1u; sa.publish_tag = p->frames_run - 1u; sa.safe_stride = p->table_cap * p->dev.chunks_per_inst; }
@@ -1685,6 +1713,7 @@ static void stage_program_frame(HnbContext* ctx, HnbProgram* p, uint32_t slot, s
     pl.lists = !(p->update_streams && pl.skip_lists);  // false: proven no spawn, no casualty; the update kernel rotates the counters
     if (pl.ribbon.ring && !pl.lists) pl.ribbon.ring = false;   // (nothing spawns, nothing can die: the list stands, head and all)
     p->dev.ring = pl.ribbon.ring ? 1u : 0u;
+    pl.slot_init = plan::plan_slot_init(p->slot_init_eligible, ctx->slot_init, p->dev.capacity, p->dev.chunks_per_inst, inst_frames.data(), n);
     pl.hz_use = plan::horizon_usable(p->horizon_eligible, p->cull_dt_operand, inst_frames.data(), n);   // k_count_rows may skip row chunks
     if (pl.hz_use && pl.lists) p->hz_frames += 1;
     p->dev.hz_parity = p->hz_parity;
@@ -1841,7 +1870,8 @@ static void fill_merge_jobs(HnbContext* ctx, const std::vector<HnbProgram*>& ord
         plan::MergeFacts& f = facts[i];
         f.independent = p->plan.independent;
         f.total_chunks = (uint32_t)std::min<uint64_t>((uint64_t)p->effects.size() * p->dev.chunks_per_inst, 0xffffffffull);
-        f.init_blocks = p->plan.init_blocks; f.init_len = p->dev.init_len; f.update_len = p->dev.update_len;
+        f.init_blocks = p->plan.slot_init.use ? 0u : p->plan.init_blocks;   // (a slot-major init pass is the program's own launch)
+        f.init_len = p->dev.init_len; f.update_len = p->dev.update_len;
         f.wide_file = p->wide_file; f.update_streams = p->update_streams; f.age_cohort = p->dev.age_cohort != 0u;
     }
     plan::MergeLimits lim;
@@ -2002,7 +2032,17 @@ static int enqueue_init_passes(HnbContext* ctx, const std::vector<HnbProgram*>& 
             TimingPair ti{};
             ti.prog = p;
             if (timed) { ti.a = take_event(ctx); ti.b = take_event(ctx); hipEventRecord(ti.a, st); }
-            if (p->jit_init) {
+            if (p->plan.slot_init.use) {   // a large spawn: the init walks the slots (hnb_kernels.hip.h "slot-major init")
+                const uint32_t grid = n * p->dev.chunks_per_inst * (kChunk / kSlotInitWg);
+                const DevMeta* mi = p->d_meta[par];
+                if (p->plan.slot_init.marks) k_spawn_mark<<<grid, kBlock, 0, st>>>(p->dev, p->d_inst_base, mi, dfi);
+                if (p->jit_init_slots) {
+                    void* ka[] = {&p->dev, &p->d_inst_base, &mi, &dfi, &dub};
+                    HIP_TRY(hipModuleLaunchKernel(p->jit_init_slots, grid, 1, 1, kBlock, 1, 1, 0, st, ka, nullptr));
+                } else if (p->wide_file) k_init_slots<InterpCodeWide><<<grid, kBlock, 0, st>>>(p->dev, p->d_inst_base, mi, dfi, dub);
+                else k_init_slots<InterpCode><<<grid, kBlock, 0, st>>>(p->dev, p->d_inst_base, mi, dfi, dub);
+                p->slot_init_frames += 1;
+            } else if (p->jit_init) {
                 const DevMeta* mi = p->d_meta[par];
                 void* ka[] = {&p->dev, &p->d_inst_base, &mi, &dfi, &dub};
                 HIP_TRY(hipModuleLaunchKernel(p->jit_init, blocks, 1, 1, kInitBlock, 1, 1, 0, st, ka, nullptr));
@@ -2059,10 +2099,6 @@ static int enqueue_program_update(HnbContext* ctx, HnbProgram* p, hipStream_t st
     } else {
         if (p->wide_file) k_update_slots_generic<InterpCodeWide><<<total_chunks, kBlock, 0, st>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
         else k_update_slots_generic<InterpCode><<<total_chunks, kBlock, 0, st>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
-    }
-    if (p->auto_materialise) {   // HNB_AGE_COHORT_AUTO: the render modifiers read AGE after every frame (counted with the update in timed frames)
-        const int ai = find_attr(p, HNB_ATTR_AGE);
-        k_materialise_age<<<total_chunks, kBlock, 0, st>>>(p->d_inst_base, p->dev.capacity, p->dev.chunks_per_inst, p->dev.lmin_off, p->dev.attrs[ai].plane_off, p->dev.alive_flag_off);
     }
     if (timed) { hipEventRecord(tu.b, st); ctx->t_update.push_back(tu); }
     const CompactArgs ca = compact_args_of(p);
@@ -2421,7 +2457,8 @@ int hnb_effect_check(HnbEffect* fx, HnbEffectCheck* out) {
     const size_t seen_words = ((size_t)cap + 31u) / 32u;
     HIP_TRY(hipMalloc(&scratch, (seen_words + 4u) * 4u));
     hipStream_t st = p->ctx->stream;
-    hipMemsetAsync(scratch, 0, (seen_words + 4u) * 4u, st);
+    hipError_t e = hipMemsetAsync(scratch, 0, (seen_words + 4u) * 4u, st);   // (the duplicate-slot bitmap and the four counters must start from zero)
+    if (e != hipSuccess) { hipFree(scratch); return fail(HNB_ERR_HIP, "hnb_effect_check: %s", hipGetErrorString(e)); }
     const int ia = find_attr(p, HNB_ATTR_AGE), il = find_attr(p, HNB_ATTR_LIFETIME);
     const bool reaps = ia >= 0 && il >= 0 && p->dev.cull_lifetime;   // (the update program starts with the AGE_TICK that tests the lifetime)
     k_check_rows<<<(uint32_t)(((uint64_t)cap + 255u) / 256u), 256, 0, st>>>(
@@ -2429,7 +2466,8 @@ int hnb_effect_check(HnbEffect* fx, HnbEffectCheck* out) {
         reinterpret_cast<const uint8_t*>(base + p->dev.alive_flag_off), reaps ? reinterpret_cast<const float*>(base + p->dev.attrs[ia].plane_off) : nullptr,
         reaps ? reinterpret_cast<const float*>(base + p->dev.attrs[il].plane_off) : nullptr, scratch + 4, scratch);
     uint32_t rep[4] = {};
-    hipError_t e = hipMemcpyAsync(rep, scratch, sizeof rep, hipMemcpyDeviceToHost, st);
+    e = hipGetLastError();   // (the launch)
+    if (e == hipSuccess) e = hipMemcpyAsync(rep, scratch, sizeof rep, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     hipFree(scratch);
     if (e != hipSuccess) return fail(HNB_ERR_HIP, "hnb_effect_check: %s", hipGetErrorString(e));
@@ -2468,7 +2506,8 @@ int hnb_effect_compare(HnbEffect* a, HnbEffect* b, HnbEffectDiff* out) {
     HIP_TRY(hipMalloc(&d_out, n_sections * 16));
     std::vector<unsigned long long> init(n_sections * 2);
     for (size_t i = 0; i < n_sections; ++i) { init[2 * i] = 0ull; init[2 * i + 1] = ~0ull; }
-    hipMemcpy(d_out, init.data(), n_sections * 16, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(d_out, init.data(), n_sections * 16, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(d_out); return fail(HNB_ERR_HIP, "hnb_effect_compare: %s", hipGetErrorString(e)); }
     auto cmp = [&](size_t section, const void* x, const void* y, uint64_t words, uint32_t head_x = 0, uint32_t head_y = 0, uint32_t ring = 0) {
         if (!words) return;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((words + 255u) / 256u, 16384u);
@@ -2481,7 +2520,8 @@ int hnb_effect_compare(HnbEffect* a, HnbEffect* b, HnbEffectDiff* out) {
     }
     for (size_t i = 0; i < pa->attrs.size(); ++i) cmp(2 + i, sa + pa->dev.attrs[i].plane_off, sb + pb->dev.attrs[i].plane_off, (uint64_t)cap * pa->attrs[i].ncomp);
     std::vector<unsigned long long> res(n_sections * 2);
-    hipError_t e = hipDeviceSynchronize();
+    e = hipGetLastError();   // (the launches)
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(res.data(), d_out, n_sections * 16, hipMemcpyDeviceToHost);
     hipFree(d_out);
     if (e != hipSuccess) return fail(HNB_ERR_HIP, "hnb_effect_compare: %s", hipGetErrorString(e));
@@ -2506,7 +2546,7 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
     std::string s = prog->kernel_info;
     if (prog->jit_pending) s += " (specialisation pending: HNB_OPT_JIT_ASYNC)";
     if (!prog->jit_log.empty()) s += "\njit log: " + prog->jit_log;
-    if (!prog->dev.age_cohort && prog->dev.cull_lifetime && prog->ctx->popt.age_cohort == HNB_AGE_COHORT_AUTO && (prog->hdr.render_reads_lo >> HNB_ATTR_AGE & 1u))
+    if (!prog->dev.age_cohort && prog->dev.cull_lifetime && prog->age_cohort_mode == HNB_AGE_COHORT_AUTO && (prog->hdr.render_reads_lo >> HNB_ATTR_AGE & 1u))
         s += "\nage cohorts: off (HNB_AGE_COHORT_AUTO: the asset's render modifiers read AGE after every frame)";
     if (prog->dev.age_cohort) {   // (debug statistics: synchronises and reads the per-chunk state words of every instance)
         hipStreamSynchronize(prog->ctx->stream);
@@ -2517,8 +2557,9 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
             for (uint32_t v : st) in_cohort += v == 1u ? 1u : 0u;
         }
         s += "\nage cohorts: " + std::to_string(in_cohort) + " of " + std::to_string(prog->effects.size() * (size_t)prog->dev.chunks_per_inst) + " chunks";
-        if (prog->auto_materialise) s += " (HNB_AGE_COHORT_AUTO: the asset's render modifiers read AGE, the plane is made current after every frame)";
+        if (prog->auto_materialise) s += " (HNB_AGE_COHORT_AUTO: the asset's render modifiers read AGE, the update keeps the plane current)";
     }
+    if (prog->slot_init_frames) s += "\nslot-major init (large spawns): " + std::to_string(prog->slot_init_frames) + " frames";
     if (prog->has_ribbons && prog->suffix_frames) s += "\ncasualties proven to be the list's last rows (no k_count_rows): " + std::to_string(prog->suffix_frames) + " frames";
     if (prog->has_ribbons && prog->ring_frames) s += "\nlist kept as a ring (no row rewritten): " + std::to_string(prog->ring_frames) + " frames";
     if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->ribbon_facts.front_static ? "" : " (not eligible)");

@@ -363,6 +363,154 @@ k_init(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevM
        const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks) {
     init_workgroup<CODE>(prog, inst_base, meta_in, fi, ublocks, blockIdx.x, gridDim.x);
 }
+// ---- slot-major init: large spawns ---------------------------------------------------------------------------------------------------------
+// k_init is ROW-major: thread i takes slot dead[alive0 + i]. From a fresh slab that is slot i and the plane stores of a wave are contiguous; after
+// a die-off the dead stack holds the slots in the order they were killed - per frame of the die-off a descending run with a stride of ~25 slots -
+// and every lane of a wave writes a different line of every plane: a 16.7M re-burst took 2.06 ms where the first burst took 0.20
+// (profiles/r05_nursery/r05b_reburst.log; SpawnerSettings::burst(count, period), src/spawn.rs:472, pop order vfx_init.wgsl:141-143).
+// But WHAT a spawn writes into its slot does not depend on its rank: the PRNG is seeded by the slot (vfx_init.wgsl:145-146), the spawner's inputs
+// are uniform - unless the init program reads PARTICLE_COUNTER (HNB_OP_LDPC) or a parent particle. Only the alive LIST depends on the rank, and
+// that is a copy of the popped segment of the dead stack, dead[alive0 .. alive0 + n) -> rows alive0 .. alive0 + n. So for a frame that spawns a
+// large share of the capacity (host: HnbProgram plan, >= 1/8 of the program's slots; any share is CORRECT) the init walks the SLOTS like the
+// update does, a workgroup per quarter chunk of 1024 slots, lane l of a step owning slot 256 s + l: every plane store of a wave is contiguous
+// whatever order the dead stack is in. Which slots spawn:
+//   * the spawn fills every free slot (n_spawn == capacity - alive_count: every burst of `capacity` particles): the slots whose alive byte is 0;
+//   * otherwise k_spawn_mark first writes alive byte 2 into the popped slots (one scattered byte per spawn instead of six scattered plane
+//     stores), launched whenever the host cannot prove the first case (spawn request < capacity); it decides per instance from the device counters.
+// The same workgroup appends rows [1024 w, 1024 w + 1024) of the spawn to the list (coalesced copy). Serial-order semantics are untouched: the
+// state after the frame is the row-major kernel's, bit for bit (tests: re-bursts after die-offs, partial re-fills, several instances).
+// Death horizons: a slot-major workgroup does not know the lifetimes of the ROWS it appends: it makes no claim for their row chunks (D = the
+// clock: "may die now"; a burst's row chunks all hold a particle near the minimum lifetime anyway).
+constexpr uint32_t kSlotInitWg = 1024u;   // slots (and spawn rows) per workgroup
+struct SlotInitCtx {
+    uint32_t k, w;            // instance, workgroup within the instance
+    uint32_t alive0, n_spawn; // rows the list starts the frame with, spawns of the frame (capped)
+    bool full;                // the spawn takes every free slot
+    char* base;
+};
+__device__ __forceinline__ void slot_init_setup(SlotInitCtx& c, const DevProgram& prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+                                                const DevFrameInst* __restrict__ fi, const uint32_t wg) {
+    const uint32_t per_inst = prog.chunks_per_inst * (kChunk / kSlotInitWg);
+    c.k = wg / per_inst;
+    c.w = wg - c.k * per_inst;
+    c.alive0 = meta_in[c.k].alive_count;
+    const uint32_t max_spawn = prog.capacity - c.alive0;
+    const uint32_t spawn = requested_spawn(fi[c.k]);
+    c.n_spawn = spawn < max_spawn ? spawn : max_spawn;
+    c.full = c.n_spawn == max_spawn;
+    c.base = global_ptr<char>(inst_base[c.k]);
+}
+#ifndef HNB_JIT_TU
+// alive byte 2 = "spawns in this frame" for the slots a PARTIAL re-fill pops (k_init_slots turns every one of them into 1 / 3 in the same frame)
+__global__ void __launch_bounds__(kBlock)
+k_spawn_mark(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in, const DevFrameInst* __restrict__ fi) {
+    SlotInitCtx c;
+    slot_init_setup(c, prog, inst_base, meta_in, fi, blockIdx.x);
+    if (c.full || c.w * kSlotInitWg >= c.n_spawn) return;
+    const uint32_t* dead = reinterpret_cast<const uint32_t*>(c.base + prog.dead_off);
+    uint8_t* flags = reinterpret_cast<uint8_t*>(c.base + prog.alive_flag_off);
+    uint32_t slot[kSlotInitWg / kBlock];
+#pragma unroll
+    for (uint32_t q = 0; q < kSlotInitWg / kBlock; ++q) {
+        const uint32_t r = c.w * kSlotInitWg + q * kBlock + threadIdx.x;
+        slot[q] = r < c.n_spawn ? dead[c.alive0 + r] : 0xffffffffu;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kSlotInitWg / kBlock; ++q)
+        if (slot[q] != 0xffffffffu) flags[slot[q]] = 2u;
+}
+#endif
+template <class CODE>
+__device__ __forceinline__ void init_slots_workgroup(const DevProgram& prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+                                                     const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks, const uint32_t wg) {
+    SlotInitCtx c;
+    slot_init_setup(c, prog, inst_base, meta_in, fi, wg);
+    if (c.n_spawn == 0u) return;
+    const uint32_t tid = threadIdx.x, k = c.k;
+    char* base = c.base;
+    constexpr uint32_t kSubs = kSlotInitWg / kBlock;
+    // (1) the list: rows alive0 + r <- dead[alive0 + r] for this workgroup's share of the spawn, requested first, stored last
+    const uint32_t* dead = reinterpret_cast<const uint32_t*>(base + prog.dead_off);
+    uint32_t* alive = reinterpret_cast<uint32_t*>(base + prog.alive_off[list_column(meta_in[k].write_index)]);
+    const uint32_t list_first = ring_row(list_head(meta_in[k].write_index), c.alive0, prog.capacity);   // (programs that keep a ring never take this path: head 0)
+    const bool nt = prog.stream_hint != 0u;
+    uint32_t row_slot[kSubs];
+#pragma unroll
+    for (uint32_t q = 0; q < kSubs; ++q) {
+        const uint32_t r = c.w * kSlotInitWg + q * kBlock + tid;
+        row_slot[q] = r < c.n_spawn ? ld_hint(dead + (c.alive0 + r), nt) : 0xffffffffu;
+    }
+    // (2) the slots of this quarter chunk
+    uint8_t* flags = reinterpret_cast<uint8_t*>(base + prog.alive_flag_off);
+    const uint32_t slot0 = c.w * kSlotInitWg, j = slot0 / kChunk;
+    uint32_t byte[kSubs];
+#pragma unroll
+    for (uint32_t q = 0; q < kSubs; ++q) {
+        const uint32_t slot = slot0 + q * kBlock + tid;
+        byte[q] = slot < prog.capacity ? (uint32_t)flags[slot] : 1u;
+    }
+    uint8_t alive_byte = 1u;
+    uint32_t* astate = reinterpret_cast<uint32_t*>(base + prog.lmin_off) + 2u * prog.chunks_per_inst;
+    uint32_t st = 0u;
+    if (prog.age_cohort) {   // as in k_init: a chunk that keeps its particles' common age in one word - a spawn's age is in the plane (state 2, byte 3)
+        st = slot0 < prog.capacity ? astate[j] : 0u;
+        if (st == 1u || st == 2u) alive_byte = 3u;
+    }
+    VmUniforms U;
+    U.u = ublocks + (size_t)k * prog.n_uregs;
+    U.xf = fi[k].xf;
+    const uint32_t want = c.full ? 0u : 2u;
+    bool any_spawn = false;
+#pragma unroll 1
+    for (uint32_t q = 0; q < kSubs; ++q) {
+        const uint32_t b = q == 0u ? byte[0] : q == 1u ? byte[1] : q == 2u ? byte[2] : byte[3];   // (selects: no dynamically indexed array)
+        const bool here = b == want;
+        if (!__any(here)) continue;
+        any_spawn = true;
+        if (here) {
+            const uint32_t slot = slot0 + q * kBlock + tid;
+            VmState<typename CODE::file_t> S;
+            S.r = typename CODE::file_t{};  // var particle = Particle();  (vfx_init.wgsl:174)
+            S.pindex = slot + fi[k].slot_base;
+            S.seed = pcg_hash(S.pindex ^ fi[k].seed);
+            S.pcounter = 0u;                // (programs that read PARTICLE_COUNTER are not eligible: the rank is not known here)
+            S.alive = true;
+            VmAttrIO io;
+            io.slab = base; io.attrs = prog.attrs; io.slot = slot;
+            CODE::zero_unassigned(prog, io);
+            CODE::run_init(prog, S, U, io);
+            flags[slot] = alive_byte;
+            CODE::store_init(prog, S, base, slot);
+        }
+    }
+    static_assert(kSubs == 4u, "the byte select above is written for four steps");
+    if (any_spawn && (tid & 63u) == 0u) {   // (same values from every wave and every sibling workgroup of the chunk)
+        if (prog.cull_lifetime) reinterpret_cast<float*>(base + prog.lmin_off)[j] = 0.0f;   // the chunk's lifetime bound is unknown again
+        if (alive_byte == 3u && st != 2u) astate[j] = 2u;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kSubs; ++q) {
+        const uint32_t r = c.w * kSlotInitWg + q * kBlock + tid;
+        if (row_slot[q] != 0xffffffffu) st_hint(row_slot[q], alive + ring_row(list_first, r, prog.capacity), nt);
+    }
+    if (prog.horizon && tid < 2u && c.w * kSlotInitWg < c.n_spawn) {   // no claim for the row chunks this workgroup appended to (at most two)
+        const HorizonView hz = horizon_view(base, prog.horizon_off, prog.chunks_per_inst);
+        const uint32_t r_first = c.alive0 + c.w * kSlotInitWg;
+        const uint32_t r_last = c.alive0 + ((c.w + 1u) * kSlotInitWg < c.n_spawn ? (c.w + 1u) * kSlotInitWg : c.n_spawn) - 1u;
+        const uint32_t rc = tid == 0u ? r_first / kChunk : r_last / kChunk;
+        if ((tid == 0u || rc != r_first / kChunk) && rc < prog.chunks_per_inst) {
+            atomicMin(&hz.D(prog.hz_parity)[rc], d2u(*hz.clock));
+            atomicMin(&hz.BF(prog.hz_parity)[rc], prog.frame_no);
+        }
+    }
+}
+template <class CODE>
+__global__ void __launch_bounds__(kBlock)
+k_init_slots(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevMeta* __restrict__ meta_in,
+             const DevFrameInst* __restrict__ fi, const uint32_t* __restrict__ ublocks) {
+    init_slots_workgroup<CODE>(prog, inst_base, meta_in, fi, ublocks, blockIdx.x);
+}
+
 // ---- streaming-kernel pinned attribute access (P = 4) -------------------------------------------
 template <int P>
 __device__ __forceinline__ void pin_load3(V3 (&dst)[P], const char* plane, const uint32_t (&slot)[P], const bool (&valid)[P], bool dense) {
@@ -664,7 +812,8 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
             DevMeta o = c.m;
             o.alive_count = survivors;
             o.particle_counter = c.m.particle_counter + c.n_spawn;
-            o.write_index = (ring_row(head, args.capacity - c.n_spawn, args.capacity) << 1) | list_column(c.m.write_index);   // the spawns are rows 0 .. n_spawn - 1 now
+            // the spawns are rows 0 .. n_spawn - 1 now (an emptied list needs no head: 0, so that no later path has to look through one)
+            o.write_index = ((survivors == 0u ? 0u : ring_row(head, args.capacity - c.n_spawn, args.capacity)) << 1) | list_column(c.m.write_index);
             o.ref_write_index = c.m.ref_write_index ^ 1u;
             o.max_update = c.n; o.dead_count = dead_n; o.spawned = c.n_spawn; o.instance_count = survivors;
             store_meta(meta_out + c.k, o);
@@ -691,6 +840,21 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
             o.particle_counter = c.m.particle_counter + c.n_spawn;
             o.ref_write_index = c.m.ref_write_index ^ 1u;
             o.max_update = c.n; o.dead_count = total_dead; o.spawned = c.n_spawn; o.instance_count = survivors;
+            store_meta(meta_out + c.k, o);
+        }
+        return;
+    }
+    if (c.n == 0u) {
+        // An EMPTY list that still stands behind a head (a trail that died out through ring frames) in a frame that rewrites (force_rewrite): no
+        // chunk has rows, so nobody reaches the store at the end - the counters of two frames ago and the head would stay in meta_out while the
+        // host forgets that a head may be set (HnbProgram::ring_live), and the next linear append / sort would read the list through the wrong rows
+        // (ADVICE r5). Nothing to move: the head goes, the counters rotate.
+        if (c.j == 0u && tid == 0u) {
+            DevMeta o = c.m;
+            o.alive_count = 0u;
+            o.write_index = list_column(c.m.write_index);
+            o.ref_write_index = c.m.ref_write_index ^ 1u;
+            o.max_update = 0u; o.dead_count = 0u; o.spawned = 0u; o.instance_count = 0u;
             store_meta(meta_out + c.k, o);
         }
         return;
@@ -1080,6 +1244,9 @@ struct SlotArgs {
     uint32_t transpose;      // 1: vec3 planes of the per-particle path go through the wave's LDS transpose (xpose_load3 / xpose_store3)
     uint32_t stream_hint;    // 1: read-only planes (LIFETIME, alive bytes) are loaded with the nontemporal hint ("cache policy of streamed data")
     uint32_t store_hint;     // 1: the per-particle path stores its planes with the nontemporal hint (update_stream_chunk)
+    uint32_t age_current;    // 1 (with age_cohort; HNB_AGE_COHORT_AUTO for an asset whose render modifiers read AGE): a chunk that keeps its common age in the
+                             // value word ALSO writes it to the plane for its alive slots - write-only, 4 of the 8 bytes the cohort saves - so the AGE plane
+                             // is current after every frame without a second pass over it (until round 6: a k_materialise_age launch behind every update)
 };
 
 // The deaths of a frame are known on the device only after its update ran, and HIP has no indirect dispatch: the list
@@ -1246,6 +1413,12 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
             u4v* pw = reinterpret_cast<u4v*>(p_pos + (size_t)j * (kChunk * 12u)) + wave * (kWaveRows * 3u / 4u);
             u4v* vw = reinterpret_cast<u4v*>(p_vel + (size_t)j * (kChunk * 12u)) + wave * (kWaveRows * 3u / 4u);
             const uint32_t rot = lane % 3u;   // component of this lane's first float in every word it takes: (word index) mod 3 = (3 step + w + lane) mod 3, w added below
+            if (args.age_current && (fl & 64u)) {   // the plane kept current: the wave's 1024 ages, 16 bytes per lane and step, issued in front of the loads below
+                u4v* aw = reinterpret_cast<u4v*>(p_age + (size_t)j * (kChunk * 4u)) + wave * (kWaveRows / 4u);
+                const uint32_t a2 = f2u(A2);
+#pragma unroll
+                for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) aw[step * 64u + lane] = u4v{a2, a2, a2, a2};
+            }
 #pragma unroll 2   // (all four steps unrolled: 0.1313 instead of 0.1298 ms, three A/B rounds on one box)
             for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
                 float P[3][4], V[3][4];
@@ -1354,8 +1527,9 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
                 if ((fl & 16u) && !xp_pos) pin_store3<4>(X.pos, p_pos, slot, was, full);
                 if ((fl & 32u) && !xp_vel) pin_store3<4>(X.vel, p_vel, slot, was, full);
                 if (fl & 64u) {
-                    if (!COH || ast != 1u) {
-                        if ((fl & 4u) && !full) {   // loaded above: blend in registers, one 16-byte store
+                    const bool plane_loaded = !COH || ast != 1u;   // (state 1: the ages live in the value word - stored only where the plane is kept current)
+                    if (plane_loaded || args.age_current) {
+                        if (plane_loaded && (fl & 4u) && !full) {   // loaded above: blend in registers, one 16-byte store
                             float q[4];
 #pragma unroll
                             for (int p = 0; p < 4; ++p) q[p] = was[p] ? X.age[p] : age_was[p];
@@ -1393,7 +1567,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
                 // a chunk in state 1 keeps its ages in the value word; a particle that dies now leaves its last age in the plane
                 // (rare: one wave-uniform vote per step keeps the stores out of the way)
                 const bool dies = (was[0] && !X.alive[0]) || (was[1] && !X.alive[1]) || (was[2] && !X.alive[2]) || (was[3] && !X.alive[3]);
-                if (ast == 1u && (fl & 64u) && __any(dies)) {
+                if (ast == 1u && (fl & 64u) && !args.age_current && __any(dies)) {   // (age_current: stored above with everybody's)
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
                         if (was[p] && !X.alive[p]) reinterpret_cast<float*>(p_age)[slot[p]] = X.age[p];

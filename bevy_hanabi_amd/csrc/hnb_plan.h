@@ -7,6 +7,7 @@
 //   prove_ribbon_order    "the head of a ribbon effect's list is still sorted" / "this frame's spawns sort in front of everything" /
 //                         "the frame's casualties are the last rows of the list": partial sort, sort by rotation, no k_count_rows
 //   horizon_usable        "every tick of the frame is finite": k_count_rows may trust the row-chunk death horizons
+//   plan_slot_init        a frame that spawns a large share of a program's slots runs its init slot-major
 //   size_init_grid        init workgroups of one instance (HIP has no indirect dispatch: sized on the host for what the host knows)
 //   size_event_grid       splits of a chunk's spawn events over workgroups
 //   plan_merged_launches  which small, independent programs share the job-table launches of the frame
@@ -205,6 +206,30 @@ inline uint32_t size_event_grid(uint32_t max_event_capacity, uint32_t total_chun
     return splits < 1u ? 1u : (splits > 64u ? 64u : splits);
 }
 
+// ---- slot-major init (hnb_kernels.hip.h "slot-major init: large spawns") -----------------------------------------------------------------------
+// k_init_slots walks the SLOTS of every instance and is correct for any spawn; it pays when the frame spawns a large share of the program's slots
+// (a burst, a re-burst after a die-off: the row-major k_init then scatters every plane store). Eligible programs: the init does not read
+// PARTICLE_COUNTER (the rank of a spawn is not known slot-major), no ribbons (ring lists append in front), no parent particle. `marks`: some
+// instance may spawn fewer particles than it has free slots - only a request of `capacity` or more provably takes them all - so k_spawn_mark runs
+// first (it decides per instance from the device counters and leaves instances that do fill up alone).
+struct SlotInitDecision { bool use = false, marks = false; };
+constexpr uint32_t kSlotInitMinChunks = 17;   // (programs of <= 16 chunks are candidates for the merged launches)
+inline SlotInitDecision plan_slot_init(bool eligible, uint32_t option, uint32_t capacity, uint32_t chunks_per_inst, const InstanceFrame* inst, uint32_t n) {
+    SlotInitDecision d;   // option (HNB_OPT_SLOT_INIT): 0 never, 1 where it pays, 2 wherever it is correct (any size, any spawn: tests and A/B runs)
+    if (!eligible || option == 0u || n == 0u || (option == 1u && (uint64_t)n * chunks_per_inst < kSlotInitMinChunks)) return d;
+    uint64_t spawns = 0;
+    bool partial = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (inst[i].has_parent) return d;               // GPU-spawned: the init reads the parent particle of event i
+        if (!inst[i].simulated || inst[i].spawn_count == 0u) continue;
+        spawns += inst[i].spawn_count < capacity ? inst[i].spawn_count : capacity;
+        partial = partial || inst[i].spawn_count < capacity;
+    }
+    d.use = spawns != 0u && (option >= 2u || spawns * 8u >= (uint64_t)n * capacity);
+    d.marks = d.use && partial;
+    return d;
+}
+
 // ---- merged launches of small programs ----------------------------------------------------------------------------------------------------
 // A program is served by the frame's job-table launches (k_init_jobs / k_update_jobs / k_update_generic_wide_jobs: INTERPRETER
 // instantiations) if it is small this frame, independent of every other program (no spawn events in or out, no parent), its pass is
@@ -327,6 +352,7 @@ struct FramePlan {
     bool independent = false;
     MergeDecision merge;
     uint32_t init_blocks = 0;
+    SlotInitDecision slot_init;     // the init pass walks the slots (k_init_slots), behind k_spawn_mark where a partial re-fill is possible
 };
 
 }  // namespace plan

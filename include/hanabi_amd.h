@@ -284,7 +284,7 @@ int hnb_ctx_synchronize(HnbContext* ctx);
  * Both are pure scheduling choices: results are identical with either value. They apply from the next hnb_simulate on. */
 #define HNB_OPT_ALTERNATE 2u
 #define HNB_OPT_SKIP_LISTS 3u
-/* HNB_OPT_AGE_COHORT (fixed in a program when it is created; default HNB_AGE_COHORT_LEAN): a 4096-slot chunk whose alive particles share one
+/* HNB_OPT_AGE_COHORT (fixed in a program when it is created; default HNB_AGE_COHORT_AUTO): a 4096-slot chunk whose alive particles share one
  *   AGE, bit for bit - every burst effect - keeps it in one word instead of reading and writing 8 bytes per particle and frame. THE ONE OPTION
  *   THAT CHANGES DEVICE-VISIBLE STATE: the AGE plane of such a chunk is stale until hnb_effect_materialise (or a host read, which does the
  *   same) - see "Device-side output" below. OFF: the plane is current after every frame. LEAN: bandwidth-bound update stacks only
@@ -299,11 +299,10 @@ int hnb_ctx_synchronize(HnbContext* ctx);
 #define HNB_AGE_COHORT_ALL 2u
 #define HNB_AGE_COHORT_AUTO 3u   /* THE DEFAULT: chosen from the asset. Where the render modifiers read AGE after every frame (HnbProgramHeader::
                                   * render_reads_*: ColorOverLifetime / SizeOverLifetime) nothing is ever stale for a renderer behind
-                                  * hnb_effect_device_view: an effect of 2^20 slots or more keeps the cohorts and hnb_simulate ends with a materialise pass
-                                  * (measured on the reference's firework asset at 16.7M particles with a consumer behind every frame: 0.280 ms against
-                                  * 0.297 ms with per-particle ages), a smaller one keeps per-particle ages in the plane (as OFF: one more launch per
-                                  * program and frame is what a scene of small effects cannot afford). Every other program gets LEAN. A headless host
-                                  * that never looks at AGE between frames asks for LEAN. */
+                                  * hnb_effect_device_view: an effect of 65,536 slots or more keeps the cohorts and its update kernel writes a cohort
+                                  * chunk's common age into the plane as it goes (write-only: 4 of the 8 bytes per particle the cohort saves; no
+                                  * second pass, no extra launch), a smaller one keeps per-particle ages in the plane (as OFF). Every other program
+                                  * gets LEAN. A headless host that never looks at AGE between frames asks for LEAN. */
 #define HNB_OPT_CULL_LIFETIME 5u
 #define HNB_OPT_HORIZON 6u
 #define HNB_OPT_TRANSPOSE 7u
@@ -314,6 +313,12 @@ int hnb_ctx_synchronize(HnbContext* ctx);
  *   ribbon.rs) keeps its alive list as a RING: the init pass writes the spawns in front of the list's head, the head moves, the count drops - no row is
  *   rewritten (HnbDeviceMeta::list_column carries the head). 0: the list is rotated by rewriting it, as before round 5. Same list either way. */
 #define HNB_OPT_RING_LISTS 16u
+/* HNB_OPT_SLOT_INIT (default 1; from the next hnb_simulate on): a frame that spawns an eighth or more of a program's slots (a burst, the re-burst of
+ *   SpawnerSettings::burst(count, period) into slots a die-off left in killing order) runs its init pass over the SLOTS - contiguous plane stores
+ *   whatever the dead list looks like - instead of over the spawn ranks; programs whose init reads PARTICLE_COUNTER or a parent particle, and
+ *   ribbon effects, keep the rank-major pass. Same state bit for bit (the serial pop order only decides the LIST, which is copied). 0: never;
+ *   2: every eligible program in every frame that spawns anything, whatever its size (tests, A/B runs). */
+#define HNB_OPT_SLOT_INIT 17u
 /* HNB_OPT_OVERLAP_UPDATES (default 1; from the next hnb_simulate on): when one program of the context holds at least four times the slots
  *   of all the others together (and >= 1M), the update phase of the others - update, spawn-event ordering, lists, sort: independent chains -
  *   runs on an internal second stream next to the heavy program's update and joins the context's stream before hnb_simulate returns.
@@ -330,7 +335,8 @@ int hnb_ctx_synchronize(HnbContext* ctx);
 #define HNB_OPT_JIT_ASYNC 13u
 /* HNB_OPT_TEST_BREAK_PROOF (default 0): a TEST HOOK, never for production. 1 = every frame that spawns nothing is treated as proven to have no
  *   casualty (HNB_OPT_SKIP_LISTS's proof, claimed without evidence). A particle that dies in such a frame raises HnbEffectMetadata::fault and
- *   leaves the lists stale: what hnb_effect_check, hnb_effect_compare and bench.py's parity gate exist to notice, and are tested with. */
+ *   leaves the lists stale: what hnb_effect_check, hnb_effect_compare and bench.py's parity gate exist to notice, and are tested with.
+ *   REFUSED (HNB_ERR_INVALID_ARG) unless the process environment holds HNB_ENABLE_TEST_HOOKS=1: no host switches it on by accident. */
 #define HNB_OPT_TEST_BREAK_PROOF 15u
 /* HNB_OPT_SET_MODULE (default HNB_SET_MODULE_CACHED; from the next hnb_simulate on): the launches the small programs of a context share
  *   (HNB_OPT_SCENE_MERGE) run the byte-code INTERPRETERS - the only code that fits every program - unless the context has a SET MODULE: one
@@ -455,7 +461,8 @@ int hnb_effect_device_view(HnbEffect* fx, HnbDeviceView* out_view);
  * contract and pointer lifetimes as HnbDeviceView: `slabs`, `meta`, `meta_next` are device arrays that move when an instance is created or
  * destroyed and meta / meta_next alternate every frame - fetch the view after each hnb_simulate. A consumer kernel over the whole batch:
  *     k = blockIdx.y; base = (const char*)v.slabs[k]; m = v.meta[k]; list = (const uint32_t*)(base + v.alive_list_off[m.list_column & 1]);
- *     row r < m.alive_count: slot = list[r]; position = (const float*)(base + v.attrs[i].plane_off) + 3 * slot */
+ *     row r < m.alive_count: slot = list[((m.list_column >> 1) + r) % v.capacity]   (bits 1..31 of list_column: the list's head, non-zero only for
+ *     ribbon effects kept as a ring - on by default); position = (const float*)(base + v.attrs[i].plane_off) + 3 * slot */
 typedef struct HnbProgramAttr {
     uint16_t attr;                      /* HnbAttr */
     uint8_t ncomp, scalar_type;

@@ -52,6 +52,12 @@ void cpl_ribbon_step(void* h, uint32_t capacity, const Row* rows, uint32_t n, in
     out[0] = d.max_spawn; out[1] = d.values_ok; out[2] = d.front; out[3] = d.head_sorted; out[4] = d.rotate; out[5] = d.suffix; out[6] = d.ring;
 }
 
+// out: use, marks
+void cpl_slot_init(int eligible, int option, uint32_t capacity, uint32_t chunks_per_inst, const Row* rows, uint32_t n, uint32_t* out) {
+    const std::vector<InstanceFrame> v = frames_of(rows, n);
+    const SlotInitDecision d = plan_slot_init(eligible != 0, (uint32_t)option, capacity, chunks_per_inst, v.data(), n);
+    out[0] = d.use; out[1] = d.marks;
+}
 int cpl_horizon_usable(int eligible, uint32_t dt_operand, const Row* rows, uint32_t n) {
     const std::vector<InstanceFrame> v = frames_of(rows, n);
     return horizon_usable(eligible != 0, dt_operand, v.data(), n) ? 1 : 0;

@@ -139,7 +139,14 @@ def test_jit_precompile_without_a_device(tmp_path, monkeypatch):
                 good[:24] + bytes([good[24] ^ 1]) + good[25:]):         # built from something else (key hash differs)
         entries[0].write_bytes(bad)
         bh.jit_precompile(bh.lower(effects.firework_trails(2048)))
-        assert entries[0].read_bytes() == good
+        fresh = entries[0].read_bytes()
+        # replaced by a complete entry for the same key (magic, hiprtc version, both key hashes, key length: bytes 0..40). The code object itself is
+        # not compared: with two kernels in the translation unit (k_init + k_init_slots, round 6) hiprtc's output is not bit-reproducible from one
+        # compilation to the next inside a process (24 bytes of it differ; both objects are valid) ...
+        assert fresh[:40] == good[:40] and len(fresh) == len(good) and fresh != bad
+        t1 = mtime()
+        bh.jit_precompile(bh.lower(effects.firework_trails(2048)))      # ... and the entry it wrote is a hit (header, length and code hash verified on load)
+        assert mtime() == t1
     assert not list(cache.glob("*.tmp*"))
     with pytest.raises(bh.HanabiError):
         bh.jit_precompile(b"garbage")

@@ -92,6 +92,38 @@ def _gather(cons, fx, attr, ncomp, cap):
 
 
 @pytest.mark.gpu
+def test_auto_mode_update_keeps_the_age_plane_current_through_burst_die_off_and_respawn():
+    """Round 6: under the default HNB_AGE_COHORT_AUTO the update kernel itself writes a cohort chunk's common age into the plane (SlotArgs::age_current;
+    round 5 ran k_materialise_age behind every update). A consumer enqueued right behind hnb_simulate - no materialise call - must read the oracle's ages
+    for every alive row after EVERY kind of frame: the burst, the flat path (completely alive chunks), the die-off (partially alive quads of cohort
+    chunks), a partial re-fill into cohort chunks (state 2: fresh spawns beside the cohort), the mixed-age steady state, a re-burst; the whole state
+    equals the oracle's at the end."""
+    from helpers import Frame, GpuRunner, OracleRunner, assert_same_state
+    cons = _consumer()
+    cap = 300_007
+    asset = effects.firework_trails(cap)
+    ctx = bh.Context(0)                      # default options
+    g, orc = GpuRunner(asset, ctx=ctx), OracleRunner(asset, omp=True)
+    assert g.fx.device_view().stale_attr_mask == 0
+    script = [(1 / 60, cap)] + [(1 / 60, 0)] * 3 + [(0.25, 0)] * 3 + [(1 / 60, cap // 5)] + [(1 / 60, 0)] * 2 + [(0.2, 0), (0.2, 3000), (0.2, cap // 3), (1 / 60, cap), (1 / 60, 0)]
+    t = 0.0
+    for f, (dt, spawn) in enumerate(script):
+        fr = Frame(dt, spawn, frame_seed(f), time=t)
+        t += dt
+        g.step(fr)
+        orc.step(fr)
+        _, got, cnt = _gather(cons, g.fx, A.AGE.id, 1, cap)          # no materialise, no synchronisation in front of it
+        ctx.synchronize()
+        ref = orc.state()
+        n = int(cnt.item())
+        assert n == len(ref["alive"]), (f, n, len(ref["alive"]))
+        np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32)[:n], ref["attrs"]["age"].reshape(-1)[ref["alive"]], err_msg=f"frame {f}: ages of the alive rows as a device-side consumer reads them")
+    assert "HNB_AGE_COHORT_AUTO: the asset's render modifiers read AGE, the update keeps the plane current" in g.prog.kernel_info(), g.prog.kernel_info()
+    assert_same_state(orc.state(), g.state(), "end of the script")
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cohort", [1, 0])
 def test_consumer_kernel_reads_what_the_host_reads(cohort):
     cons = _consumer()

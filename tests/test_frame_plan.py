@@ -42,6 +42,7 @@ def lib():
     lib.cpl_ribbon_host_write.argtypes = [C.c_void_p, C.c_int]
     lib.cpl_ribbon_step.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Row), C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     lib.cpl_horizon_usable.argtypes = [C.c_int, C.c_uint32, C.POINTER(Row), C.c_uint32]
+    lib.cpl_slot_init.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(Row), C.c_uint32, C.POINTER(C.c_uint32)]
     lib.cpl_init_grid.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
     lib.cpl_init_grid.restype = C.c_uint32
     lib.cpl_event_grid.argtypes = [C.c_uint32, C.c_uint32]
@@ -413,3 +414,34 @@ def test_ring_frames_need_both_ribbon_proofs(lib):
     r2.frame(trail(spawn=8)); r2.frame(trail(spawn=8))
     d = r2.frame(trail(spawn=8, age0=0.5))                        # spawns that do not start at +0: they do not sort in front
     assert not d["rotate"] and not d["ring"]
+
+
+# ---- plan_slot_init ---------------------------------------------------------------------------------------------------------------------
+def _slot_init(lib, specs, capacity=1 << 20, chunks=256, eligible=1, option=1):
+    arr, n = rows(*specs)
+    out = (C.c_uint32 * 2)()
+    lib.cpl_slot_init(eligible, option, capacity, chunks, arr, n, out)
+    return int(out[0]), int(out[1])
+
+
+def test_large_spawns_run_the_init_slot_major(lib):
+    """hnb_kernels.hip.h "slot-major init": from an eighth of the program's slots on; k_spawn_mark unless every spawning instance asks for its whole capacity."""
+    cap = 1 << 20
+    assert _slot_init(lib, [dict(spawn=cap)]) == (1, 0)                     # a burst of `capacity`: every free slot, no marks
+    assert _slot_init(lib, [dict(spawn=cap + 5)]) == (1, 0)                 # more than fits: capped, still every free slot
+    assert _slot_init(lib, [dict(spawn=cap // 2)]) == (1, 1)                # half: marks (whether it fills up is the device's to say)
+    assert _slot_init(lib, [dict(spawn=cap // 8)]) == (1, 1)
+    assert _slot_init(lib, [dict(spawn=cap // 8 - 1)]) == (0, 0)            # below an eighth: row-major
+    assert _slot_init(lib, [dict(spawn=0)]) == (0, 0)
+    assert _slot_init(lib, [dict(spawn=cap)], eligible=0) == (0, 0)         # reads PARTICLE_COUNTER / ribbons / a parent particle
+    assert _slot_init(lib, [dict(spawn=cap)], option=0) == (0, 0)           # HNB_OPT_SLOT_INIT off
+    assert _slot_init(lib, [dict(spawn=cap, has_parent=1, evcap=cap)]) == (0, 0)
+    assert _slot_init(lib, [dict(spawn=cap), dict(spawn=0)] * 4) == (1, 0)  # half of the instances burst: half of the slots
+    assert _slot_init(lib, [dict(spawn=cap)] + [dict(spawn=0)] * 15) == (0, 0)   # one in sixteen
+    assert _slot_init(lib, [dict(spawn=cap), dict(spawn=cap, simulated=0)]) == (1, 0)   # a frozen instance spawns nothing
+    assert _slot_init(lib, [dict(spawn=cap), dict(spawn=100)]) == (1, 1)    # one partial request among them: marks
+    assert _slot_init(lib, [dict(spawn=65536)], capacity=65536, chunks=16) == (0, 0)     # a small program: the merged launches' candidate
+    assert _slot_init(lib, [dict(spawn=65536)] * 2, capacity=65536, chunks=16) == (1, 0)
+    assert _slot_init(lib, [dict(spawn=3)], capacity=257, chunks=1, option=2) == (1, 1)  # HNB_OPT_SLOT_INIT = 2: wherever it is correct
+    assert _slot_init(lib, [dict(spawn=0)], capacity=257, chunks=1, option=2) == (0, 0)
+    assert _slot_init(lib, [dict(spawn=3)], capacity=257, chunks=1, option=2, eligible=0) == (0, 0)

@@ -4,6 +4,8 @@ Bit-exact on every attribute, counter and list: the arithmetic of both sides is 
 the hanabi-math definition, so the 1e-5 relative tolerance BASELINE.json allows on
 position/velocity is met with zero difference.
 """
+import struct
+
 import numpy as np
 import pytest
 
@@ -119,6 +121,108 @@ def test_zoo(ctx, name, kernels):
     run_script(g, frames, OracleRunner(asset), every=10)
     g.fx.destroy()
     g.prog.destroy()
+
+
+# ---- slot-major init of large spawns (round 6; hnb_kernels.hip.h "slot-major init") -----------------------------------------------------
+_OP_LDPC, _OP_LDPARENT = 5, 7                      # include/hanabi_amd.h: HnbOp
+_PROG_HAS_RIBBONS, _PROG_READS_PARENT = 0x2, 0x4   # ... HNB_PROG_*
+
+
+def _slot_init_frames(prog):
+    line = [l for l in prog.kernel_info().split("\n") if l.startswith("slot-major init")]
+    return int(line[0].split(":")[1].split()[0]) if line else 0
+
+
+@pytest.mark.parametrize("name", sorted(ZOO))
+def test_zoo_through_the_slot_major_init(name, kernels):
+    """HNB_OPT_SLOT_INIT = 2: every eligible program of the zoo runs EVERY init pass slot-major (k_spawn_mark + k_init_slots, specialised and
+    interpreted), through partial re-fills into recycled slots; programs that read PARTICLE_COUNTER and the ribbon programs keep the row-major
+    pass. Same state as the oracle, bit for bit."""
+    c = bh.Context(0)
+    c.set_option("age_cohort", 1)
+    c.set_option("slot_init", 2)
+    asset = ZOO[name]()
+    cap = asset.capacity
+    xf = np.array([0.0, -1.0, 0.0, 4.0, 1.0, 0.0, 0.0, -2.0, 0.0, 0.0, 1.0, 0.5], dtype=np.float32)
+    frames = [Frame(1 / 60, cap // 2, frame_seed(0), xf)]
+    for f in range(1, 60):
+        frames.append(Frame(1 / 60 if f % 7 else 1 / 30, (cap // 9) if f % 11 == 0 else (cap if f == 40 else 0), frame_seed(f), xf, time=f / 60.0))
+    g = GpuRunner(asset, ctx=c)
+    run_script(g, frames, OracleRunner(asset), every=10)
+    # eligible (hanabi_amd.hip slot_init_eligible): no ribbons, no parent, the init stream reads neither PARTICLE_COUNTER nor a parent particle
+    hdr = struct.unpack_from("<24I", g.blob)
+    flags, init_len, init_off = hdr[4], hdr[9], hdr[17]
+    ops = [struct.unpack_from("<I", g.blob, init_off + 8 * i)[0] & 0xFF for i in range(init_len)]
+    eligible = not (flags & (_PROG_HAS_RIBBONS | _PROG_READS_PARENT)) and _OP_LDPC not in ops and _OP_LDPARENT not in ops
+    assert _slot_init_frames(g.prog) == (7 if eligible else 0), (eligible, g.prog.kernel_info())   # frames 0, 11, 22, 33, 40, 44, 55 spawn
+    c.close()
+
+
+def test_large_spawns_slot_major_equal_the_row_major_init_and_the_oracle():
+    """A burst, a die-off in large steps (the dead stack ends up in killing order), a partial re-fill (k_spawn_mark), a re-burst of `capacity`
+    (every free slot, host-proven), a request just below the capacity that the device finds to be a complete re-fill, small spawns in between
+    (row-major): the default context (slot-major from an eighth of the slots on), one with HNB_OPT_SLOT_INIT off and the oracle hold the same
+    state after every frame; SpawnerSettings::burst(count, period) semantics (src/spawn.rs:472; pop order vfx_init.wgsl:141-143)."""
+    cap = 300_007            # 74 chunks, the last one ragged
+    asset = effects.firework_trails(cap)
+    on, off = bh.Context(0), bh.Context(0)
+    off.set_option("slot_init", 0)
+    g_on, g_off, orc = GpuRunner(asset, ctx=on), GpuRunner(asset, ctx=off), OracleRunner(asset, omp=True)
+    script = [(1 / 60, cap), (0.3, 0), (0.3, 0), (0.3, 0),            # burst; ages 0.32, 0.62, 0.92: the short-lived third dies
+              (1 / 60, cap // 4),                                     # partial re-fill into the freed slots: marks
+              (1 / 60, 1000), (0.3, 0),                               # a small spawn (row-major); everybody of the first burst dies
+              (1 / 60, cap),                                          # re-burst: every free slot
+              (0.5, 0), (0.5, 0),                                     # ... most of them die
+              (1 / 60, cap - 5),                                      # less than the capacity, more than there are free slots: complete on the device
+              (1 / 60, 0), (0.45, cap // 7), (0.45, cap // 3), (0.45, cap)]
+    t = 0.0
+    for f, (dt, spawn) in enumerate(script):
+        fr = Frame(dt, spawn, frame_seed(f), time=t)
+        t += dt
+        for x in (g_on, g_off, orc):
+            x.step(fr)
+        ref = orc.state()
+        assert_same_state(ref, g_on.state(), f"slot-major, frame {f}")
+        assert_same_state(ref, g_off.state(), f"row-major, frame {f}")
+        assert g_on.fx.check()["ok"] == 1
+    assert _slot_init_frames(g_on.prog) == 8 and _slot_init_frames(g_off.prog) == 0, g_on.prog.kernel_info()
+    assert g_on.fx.compare(g_off.fx)["equal"] == 1
+    on.close(); off.close()
+
+
+def test_slot_major_init_over_several_instances(ctx):
+    """One launch for all instances of a program: a complete burst, a partial one, an instance that spawns nothing and a frozen one side by side
+    (the frame qualifies as a whole: half of the program's slots spawn), death horizons and age cohorts in play; translated emitters."""
+    cap = 70_000            # 18 chunks per instance
+    asset = effects.instancing(cap)
+    prog = ctx.create_program(bh.lower(asset))
+    fxs = [prog.create_effect() for _ in range(4)]
+    orcs = [OracleRunner(asset) for _ in range(4)]
+    plan = {0: [cap, cap // 2, 0, cap], 3: [0, cap, cap // 3, cap], 5: [cap // 5, 0, cap, cap], 7: [cap, cap, cap, cap]}
+    t = 0.0
+    for f in range(9):
+        dt = 1 / 60 if f in plan else 5.0     # (lifetime 12 s: three long frames kill everything spawned before)
+        ctx.frame_begin(dt, t)
+        for i, (fx, orc) in enumerate(zip(fxs, orcs)):
+            frozen = i == 3 and f in (3, 4)
+            fx.set_simulated(not frozen)
+            if frozen:
+                continue
+            n = plan.get(f, [0] * 4)[i]
+            xf = translation(10.0 * i, -5.0, 0.5 * i)
+            fx.set_frame(n, frame_seed(f * 16 + i), xf)
+            orc.step(Frame(dt, n, frame_seed(f * 16 + i), xf, time=t))
+        ctx.simulate()
+        t += dt
+        for i, (fx, orc) in enumerate(zip(fxs, orcs)):
+            ref = orc.state()
+            m = fx.metadata()
+            got = {"counters": {k: m[k] for k in ref["counters"]}, "alive": fx.alive_list(), "dead": fx.dead_list(),
+                   "attrs": {a.name: fx.read_attr(a.id).view(np.uint32) for a in (A.POSITION, A.VELOCITY, A.AGE, A.LIFETIME)}}
+            ref["attrs"] = {k: ref["attrs"][k] for k in got["attrs"]}
+            assert_same_state(ref, got, f"frame {f}, instance {i}")
+    assert _slot_init_frames(prog) == 4, prog.kernel_info()
+    prog.destroy()
 
 
 def test_kernel_selection_for_the_baseline_configs(ctx):

@@ -209,21 +209,29 @@ def test_c3_force_field_at_baseline_size(ctx):
 def test_c2_firework_full_state_at_baseline_size(ctx):
     """The headline workload itself: firework trails at 16,777,216 particles (BASELINE config 2), FULL state (counters, both lists,
     every attribute plane of every slot) against the OpenMP oracle: the burst, two frames of flight at the bench's dt = 1/60 (all
-    alive: the frames the bench times; age cohorts and list-free frames engaged), then two frames of dt = 0.45 s that carry the
-    ages past the shortest lifetimes (0.8 s) and past all of them (1.2 s): the whole effect dies in two compactions."""
+    alive: the frames the bench times; age cohorts and list-free frames engaged), then frames of dt = 0.45 s that carry the
+    ages past the shortest lifetimes (0.8 s) and past all of them (1.2 s): the whole effect dies in two compactions. Then (round 6) the
+    RE-BURST of SpawnerSettings::burst(count, period) (src/spawn.rs:472): 16,777,216 spawns into a dead stack that holds the slots in
+    killing order (vfx_init.wgsl:141-143: last killed first) - the slot-major init -, another partial die-off, a partial re-fill of a
+    quarter of the capacity (k_spawn_mark) and a last complete one."""
     cap = 1 << 24
     asset = effects.firework_trails(cap)
     gpu, orc = GpuRunner(asset, ctx=ctx), OracleRunner(asset, omp=True)
     alive, t = [], 0.0
-    for f, dt in enumerate([1 / 60, 1 / 60, 1 / 60, 0.45, 0.45, 0.45]):
-        fr = Frame(dt, cap if f == 0 else 0, frame_seed(f), time=t)
+    script = [(1 / 60, cap), (1 / 60, 0), (1 / 60, 0), (0.45, 0), (0.45, 0), (0.45, 0),
+              (1 / 60, cap), (0.45, 0), (0.45, 0), (1 / 60, cap // 4), (1 / 60, cap)]
+    for f, (dt, spawn) in enumerate(script):
+        fr = Frame(dt, spawn, frame_seed(f), time=t)
         t += dt
         gpu.step(fr)
         orc.step(fr)
-        if f in (0, 2, 4, 5):
+        if f in (0, 2, 4, 5, 6, 9, 10):
             assert_same_state(orc.state(), gpu.state(), f"C2 16.7M frame {f}")
         alive.append(gpu.fx.alive_count())
-    assert alive[:3] == [cap] * 3 and 0 < alive[4] < cap and alive[5] == 0, alive
+    assert alive[:3] == [cap] * 3 and 0 < alive[4] < cap and alive[5] == 0 and alive[6] == cap and 0 < alive[8] < cap - cap // 4 and alive[10] == cap, alive
+    info = gpu.prog.kernel_info()
+    assert "slot-major init (large spawns): 4 frames" in info, info
+    assert gpu.fx.metadata()["fault"] == 0
     print("C2 16,777,216: alive per frame", alive)
     gpu.fx.destroy(); gpu.prog.destroy()
 
@@ -759,6 +767,55 @@ def test_ribbon_list_kept_as_a_ring_equals_the_rewritten_list_and_the_oracle():
     assert plain == 0 and 150 <= ring <= 205, (ring, g_on.prog.kernel_info())       # every frame up to the lifetime change but the first and the frozen ones
     assert _rotations(g_on.prog)[0] >= 180 and g_on.fx.metadata()["fault"] == 0 and g_off.fx.metadata()["fault"] == 0
     on.close(); off.close()
+
+
+@pytest.mark.parametrize("trigger", ["ring_lists_off", "host_write", "frozen_neighbour_thaws"])
+def test_an_emptied_ring_list_is_rewritten_with_everybody_elses(trigger):
+    """a trail that died out completely THROUGH ring frames keeps a non-zero head over an empty list. The first frame that is not a
+    ring frame rewrites every list of the program linear (force_rewrite) and the host forgets that heads may be set - the emptied instance has no
+    chunk with rows, and used to be left with the counters of two frames ago and its head. Then it spawns again in a non-rotating frame (linear
+    append behind a stale head) and the sort reads the wrong rows. Several instances, one emptied, three triggers of the rewrite."""
+    cap = 5000
+    asset = _ribbon_asset(cap, lifetime=0.5)
+    c = bh.Context(0)
+    prog = c.create_program(bh.lower(asset))
+    fxs = [prog.create_effect() for _ in range(3)]
+    orcs = [OracleRunner(asset) for _ in range(3)]
+    sps = [bh.EffectSpawner(asset.spawner) for _ in range(3)]
+    rng = bh.Pcg32()
+    dt = 1 / 60
+    for f in range(150):
+        c.frame_begin(dt, f / 60)
+        if f == 80:
+            assert fxs[1].alive_count() == 0 and _ring_frames(prog) >= 60, prog.kernel_info()   # died out through ring frames: an empty list behind a head
+            if trigger == "ring_lists_off":
+                c.set_option("ring_lists", 0)
+            elif trigger == "host_write":
+                fxs[0].write_attr(A.SIZE.id, fxs[0].read_attr(A.SIZE.id))
+        for i, (fx, orc, sp) in enumerate(zip(fxs, orcs, sps)):
+            n = sp.tick(dt, rng)
+            if i == 1 and 20 <= f < 84:
+                n = 0                                  # instance 1 stops spawning: its trail dies out by frame ~52
+            if trigger == "frozen_neighbour_thaws":    # (a ring frame needs every instance's premises: a frozen one thawing with a changed tick breaks them)
+                fx.set_simulated(not (i == 2 and 60 <= f < 80))
+                if i == 2 and 60 <= f < 80:
+                    continue
+            fx.set_frame(n, frame_seed(f * 8 + i))
+            orc.step(Frame(dt, n, frame_seed(f * 8 + i), time=f / 60))
+        if trigger == "frozen_neighbour_thaws" and f == 80:
+            c.set_option("suffix_proof", 0)            # ... and from here on no ring frame at all
+        c.simulate()
+        if f % 4 == 3 or 78 <= f <= 90:
+            for i, (fx, orc) in enumerate(zip(fxs, orcs)):
+                ref = orc.state()
+                m = fx.metadata()
+                assert m["alive_count"] == ref["counters"]["alive_count"] and m["particle_counter"] == ref["counters"]["particle_counter"] and \
+                    m["indirect_write_index"] == ref["counters"]["indirect_write_index"], (trigger, f, i, m, ref["counters"])
+                np.testing.assert_array_equal(ref["alive"], fx.alive_list(), err_msg=f"{trigger}: frame {f}, instance {i}")
+                np.testing.assert_array_equal(ref["dead"], fx.dead_list(), err_msg=f"{trigger}: frame {f}, instance {i}")
+                assert fx.check()["ok"] == 1, (trigger, f, i, fx.check())
+    assert all(fx.metadata()["fault"] == 0 for fx in fxs)
+    c.close()
 
 
 def test_ribbon_sort_after_a_negative_tick_does_not_trust_later_frames(ctx):

@@ -19,6 +19,20 @@ PLAIN = {"horizon": 0, "age_cohort": 0, "cull_lifetime": 0, "skip_lists": 0, "st
          "suffix_proof": 0, "ring_lists": 0, "alternate": 0, "transpose": 0, "scene_merge": 0}
 
 
+@pytest.fixture(autouse=True)
+def _test_hooks(monkeypatch):
+    monkeypatch.setenv("HNB_ENABLE_TEST_HOOKS", "1")   # HNB_OPT_TEST_BREAK_PROOF is refused without it
+
+
+def test_the_test_hook_is_refused_outside_a_test_process(monkeypatch):
+    monkeypatch.delenv("HNB_ENABLE_TEST_HOOKS")
+    c = bh.Context(0)
+    with pytest.raises(bh.HanabiError):
+        c.set_option("test_break_proof", 1)
+    c.set_option("test_break_proof", 0)    # switching it OFF is always allowed
+    c.close()
+
+
 def _ctx(options):
     c = bh.Context(0)
     for k, v in options.items():
