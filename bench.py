@@ -10,11 +10,18 @@ synchronisation; `ms_per_step` / `value` are the MEDIAN window, the others are l
 
 Configurations (synthetic scalings of the reference's example assets):
   c2 (default, the headline)  examples/firework.rs `trails` effect, capacity 16,777,216 per GPU, burst spawn during warm-up,
-                              every particle alive in the timed frames (BASELINE.json configs[1]); sharded by CAPACITY SLAB;
+                              every particle alive in the timed frames (BASELINE.json configs[1]); sharded by CAPACITY SLAB; the
+                              LIBRARY'S DEFAULT OPTIONS (HNB_AGE_COHORT_AUTO: the asset's render modifiers read AGE, so every plane -
+                              AGE included - is current after every frame; asserted through hnb_effect_device_view);
   c2_mixed                    the same program and capacity in its GENERAL state: a rate spawner of capacity / mean lifetime
                               particles per second in steady state - per-particle ages, lifetimes loaded, spawns into
                               recycled slots and deaths in every frame, list kernels in every frame;
   c2_dieoff                   frames 48..70 of the burst (1/60 s frames): the die-off, 4 % of the capacity lost per frame;
+  c2_reburst                  SpawnerSettings::burst(capacity, period) (src/spawn.rs:472) as a 4-frame cycle, every frame timed: the RE-BURST of
+                              16,777,216 particles into the dead stack the previous die-off left in killing order (vfx_init.wgsl:141-143),
+                              then three frames of 0.45 s in which a third of them and then all of them die;
+  c2_lean                     c2 with HNB_AGE_COHORT_LEAN (a headless host that never reads AGE on the device: the plane is stale
+                              between hnb_effect_materialise calls) - what rounds 2-5 reported as the headline;
   c2_events                   the REAL examples/firework.rs at scale: three linked effects - rockets whose update emits GPU spawn
                               events, a sparkle trail (5 events per rocket and frame) and the trails (1000 events per dying rocket,
                               capacity 16,777,216) - in steady state, event buffers sized for it;
@@ -90,14 +97,20 @@ MIN_LIFETIME = 0.8  # firework.rs: lifetime = uniform(0.8, 1.2)
 MEAN_LIFETIME = 1.0
 TIMING_PERIOD = 5   # HIP events bracket the kernels of every 5th timed frame (each costs ~20 us of stream bubbles)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")  # written by `bench.py --write-traffic` from the PMC passes
+REBURST_CYCLE, REBURST_DT = 4, 0.45   # c2_reburst: frame 0 of a cycle bursts `capacity` particles (dt 1/60), frames 1..3 advance 0.45 s each: alive after them 100 %, ~71 %, 0
 DIEOFF_FIRST, DIEOFF_LAST, DIEOFF_END = 48, 70, 76   # c2_dieoff: timed frames [48, 70]; by frame 76 nothing is alive (1.2 s < 73 / 60 s)
 
 # algorithmic bytes per particle update, SURVEY.md §8(d): attributes read + attributes written + 8 B alive-list entry.
 # model_bytes: what the dominant kernel of the configuration is DESIGNED to move per updated particle (fallback when no PMC pass
 # is available; DESIGN.md "Roofline" derives each figure).
 CONFIGS = {
-    "c2": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=48, kernel="k_update_slots_stream<ProgDragAccel, cohort>",
-               workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst spawner, all particles alive"),
+    "c2": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=52, kernel="k_update_slots_stream<ProgDragAccel, cohort> (age_current)",
+               workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst spawner, all particles alive, library default options"),
+    "c2_lean": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=48, kernel="k_update_slots_stream<ProgDragAccel, cohort>",
+                    workload="as c2 with hnb_ctx_set_option(HNB_OPT_AGE_COHORT, LEAN): a headless host, the AGE plane is stale between hnb_effect_materialise calls (the headline of rounds 2-5)"),
+    "c2_reburst": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=62, kernel="k_update_slots_stream<ProgDragAccel, cohort> (age_current)",
+                       workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, SpawnerSettings::burst(capacity, period) as a 4-frame cycle, all frames timed: re-burst into the "
+                                "dead stack of the previous die-off (slot-major k_init_slots), then 3 frames of 0.45 s: a third dies, then everybody"),
     "c2_mixed": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=62, kernel="k_update_slots_stream<ProgDragAccel, cohort>",
                      workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, rate spawner (capacity / mean lifetime per second) in steady state: "
                               "mixed ages, spawns into recycled slots + deaths + list kernels every frame"),
@@ -105,11 +118,9 @@ CONFIGS = {
                       workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst; frames 48..70 at 1/60 s: the die-off (list kernels every frame)"),
     "c2_interop": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=56, kernel="k_update_slots_stream<ProgDragAccel>",
                        workload="firework.rs trails EffectAsset, capacity={cap:_} per GPU, burst, all alive, hnb_ctx_set_option(HNB_OPT_AGE_COHORT, OFF) (AGE plane current every frame)"),
-    "c2_view": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=52, kernel="k_update_slots_stream<ProgDragAccel, cohort>",
-                    workload="firework.rs trails EffectAsset END TO END: capacity={cap:_} per GPU, burst, all alive, the library's default HNB_AGE_COHORT_AUTO (the asset's ColorOverLifetime / "
-                             "SizeOverLifetime read AGE; an effect this large keeps the cohorts and hnb_simulate makes the AGE plane current every frame) + a consumer kernel behind every frame that gathers position / age / lifetime by list row through hnb_effect_device_view"),
-    "c2_interop_view": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=56, kernel="k_update_slots_stream<ProgDragAccel>",
-                            workload="as c2_view with HNB_AGE_COHORT_OFF (per-particle ages in the plane, what AUTO gives SMALL effects of this asset) + the same consumer kernel: the alternative AUTO does not pick at this size"),
+    "c2_view": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=52, kernel="k_update_slots_stream<ProgDragAccel, cohort> (age_current)",
+                    workload="c2 (library defaults) + a stand-in RENDERER behind every frame: a consumer kernel that gathers position / age / lifetime by list row through hnb_effect_device_view "
+                             "(not simulation time: `consumer_ms` is its own cost, `sim_only_ms` the step without it)"),
     "c2_events": dict(capacity=1 << 24, bytes_per_update=68, bytes_per_spawn=44, model_bytes=62, kernel="k_update_slots_stream<ProgDragAccel, cohort> (trails)",
                       workload="the real examples/firework.rs: rocket (capacity 32_768, 16_000 rockets/s) -> sparkle_trail (1_048_576; 5 spawn events per rocket and frame) + "
                                "trails (capacity={cap:_}; 1000 spawn events per dying rocket), GPU spawn events, steady state"),
@@ -120,10 +131,10 @@ CONFIGS = {
     "c5": dict(capacity=1 << 22, bytes_per_update=20, bytes_per_spawn=36, model_bytes=9, kernel="k_update_slots_stream<ProgAge>",
                workload="ribbon.rs EffectAsset, capacity={cap:_} per GPU, rate spawner in steady spawn/kill churn, ribbon sort in the step"),
 }
-EXTRA_CONFIGS = ("c2_mixed", "c2_dieoff", "c2_interop", "c2_view", "c2_interop_view", "c2_events", "c3", "c4", "c5")   # appended to the N = 1 default line
+EXTRA_CONFIGS = ("c2_lean", "c2_interop", "c2_view", "c2_mixed", "c2_dieoff", "c2_reburst", "c2_events", "c3", "c4", "c5")   # appended to the N = 1 default line
 # what identifies the dominant kernel of a configuration in a rocprofv3 dispatch list
 KERNEL_MATCH = {"c2_events": ("k_update_slots_stream",), "c2": ("k_update_slots_stream",), "c2_mixed": ("k_update_slots_stream",), "c2_dieoff": ("k_update_slots_stream",),
-                "c2_interop": ("k_update_slots_stream",), "c2_view": ("k_update_slots_stream",), "c2_interop_view": ("k_update_slots_stream",), "c3": ("k_update_slots_stream",), "c4": ("k_update_slots_stream",), "c5": ("k_update_slots_stream",)}
+                "c2_interop": ("k_update_slots_stream",), "c2_view": ("k_update_slots_stream",), "c2_lean": ("k_update_slots_stream",), "c2_reburst": ("k_update_slots_stream",), "c3": ("k_update_slots_stream",), "c4": ("k_update_slots_stream",), "c5": ("k_update_slots_stream",)}
 
 
 def frame_dt(total_frames, safe_seconds=MIN_LIFETIME * 0.95):
@@ -332,10 +343,24 @@ class Dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def sum_counts(self, counts):
-        # the only collective of the design: alive-particle counters, for reporting
-        from bevy_hanabi_amd import sharding
-        return sharding.allreduce_alive(counts, device=self.reduce_device) if self.on else [int(c) for c in counts]
+    def make_comm(self, w):
+        """N > 1: the product's OWN communicator for this workload's context: rank 0 takes a unique id from hnb_comm_unique_id,
+        the 128 bytes travel over the torch process group that already exists (it also carries the MAX of the elapsed times, nothing else), every rank calls
+        hnb_comm_create_rank: ncclCommInitRank of librccl (or of --comm-lib, for dry runs of several ranks on one GPU)."""
+        if not self.on:
+            return None
+        import torch.distributed as dist
+        box = [w.bh.Comm.unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return w.bh.Comm.rank(w.ctx, box[0], self.rank, self.world)
+
+    def alive_total(self, w):
+        """The only collective of the design: the alive-particle counters, for reporting. N > 1: hnb_comm_allreduce_alive (one grouped ncclAllReduce of
+        n_effects x u64 on the simulation stream) over the workload's communicator; every rank passes the same number of entries (NULL = 0)."""
+        if not self.on:
+            return w.alive()
+        fxs = list(w.fxs) + [None] * (w.n_effects_max - len(w.fxs))
+        return int(sum(w.comm.allreduce_alive([fxs])))
 
     def close(self):
         if self.on:
@@ -358,12 +383,15 @@ class Workload:
         n = D.world
         base_cap = args.capacity or cfg["capacity"]
         self.ctx = bh.Context(D.device_index)
-        if name in ("c2_interop", "c2_interop_view"):
-            self.ctx.set_option("age_cohort", 0)   # HNB_AGE_COHORT_OFF, fixed in the program at creation: the AGE plane is current after every frame
-        elif name != "c2_view":
-            # HNB_AGE_COHORT_LEAN: the simulation alone (a headless host: nobody reads AGE between frames), as every round measured it. The library's default
-            # (AUTO) looks at the asset's render modifiers - ColorOverLifetime on these assets reads AGE - and is what c2_view runs: the asset end to end
-            self.ctx.set_option("age_cohort", 1)
+        # Every configuration runs the library's DEFAULT options (HNB_AGE_COHORT_AUTO: the plane of every attribute the asset's render modifiers read is
+        # current after every frame) except the two that are named for the option they set:
+        self.options = "default"
+        if name == "c2_interop":
+            self.ctx.set_option("age_cohort", 0)   # HNB_AGE_COHORT_OFF, fixed in the program at creation: per-particle ages in the plane
+            self.options = "age_cohort=OFF"
+        elif name == "c2_lean":
+            self.ctx.set_option("age_cohort", 1)   # HNB_AGE_COHORT_LEAN: a headless host, nobody reads AGE on the device between frames
+            self.options = "age_cohort=LEAN"
         for k, v in (options or {}).items():   # (the parity gate's plain replay: every proof and hint off; a test's broken proof)
             self.ctx.set_option(k, v)
         self.per_inst_cap = base_cap
@@ -425,6 +453,8 @@ class Workload:
             self.sharding_desc = f"capacity slab x{n}"
             if name in ("c5", "c2_mixed"):
                 self.spawner, self.rng = bh.EffectSpawner(asset.spawner), bh.Pcg32()
+        self.n_effects_max = len(self.fxs) if name != "c4" else max(len(g) for g in sharding.instance_plan(total_inst, n))   # (entries of the all-reduce: the same on every rank)
+        self.comm = None
         self.consumer = self.consumer_out = None
         if name.endswith("_view"):   # a renderer's vertex-stage reads behind every frame (tests/device_view/consumer.hip: consumer_render_like)
             import ctypes as C
@@ -443,7 +473,14 @@ class Workload:
             return self.spawner.tick(self.dt, self.rng)
         if self.name == "c2_dieoff":
             return self.per_inst_cap if f % DIEOFF_END == 0 else 0      # a burst every DIEOFF_END frames: every pass replays the same die-off
+        if self.name == "c2_reburst":
+            return self.per_inst_cap if f % REBURST_CYCLE == 0 else 0   # SpawnerSettings::burst(capacity, period): the period is one cycle
         return self.per_inst_cap if f == 0 else 0
+
+    def dt_of(self, f):
+        if self.name == "c2_reburst":
+            return DT if f % REBURST_CYCLE == 0 else REBURST_DT
+        return self.dt
 
     def inputs_of(self, f, s):
         """Per-frame inputs (spawn count, seed, transform) of the effects of this rank in frame f, given the spawner's count s.
@@ -456,7 +493,8 @@ class Workload:
         return [(s, frame_seed(f % DIEOFF_END if self.name == "c2_dieoff" else f), None)]
 
     def step(self):
-        f, ctx, dt = self.f, self.ctx, self.dt
+        f, ctx = self.f, self.ctx
+        dt = self.dt_of(f)
         ctx.frame_begin(dt, f * dt)
         s = self.spawn_of(f)
         if self.name == "c4":
@@ -471,7 +509,7 @@ class Workload:
         ctx.simulate()
         if self.consumer is not None:   # enqueued on the simulation stream right behind the frame: no synchronisation, no host copy
             v = self.fxs[0].device_view()
-            assert v.stale_attr_mask == 0 or self.name != "c2_view", "HNB_AGE_COHORT_AUTO left AGE stale for an asset whose render modifiers read it"
+            assert v.stale_attr_mask == 0, "HNB_AGE_COHORT_AUTO left AGE stale for an asset whose render modifiers read it"
             rc = self.consumer.consumer_render_like(self._byref(v), self.consumer_out.data_ptr())
             assert rc == 0, f"consumer_render_like: {rc}"
         self.f += 1
@@ -480,6 +518,9 @@ class Workload:
         return sum(fx.alive_count() for fx in self.fxs)
 
     def close(self):
+        if self.comm is not None:
+            self.comm.destroy()
+            self.comm = None
         self.ctx.close()
 
 
@@ -488,7 +529,7 @@ class Workload:
 # ------------------------------------------------------------------------------------------------------------------
 PARITY_BUDGET_S = 0.5          # oracle time per configuration (the slab / the reduced capacity is sized to the oracle's measured speed)
 PARITY_KEYS = ("capacity", "alive_count", "max_update", "max_spawn", "indirect_write_index", "particle_counter", "instance_count", "dead_count")
-BURST_PARITY = ("c2", "c2_interop", "c2_view", "c2_interop_view", "c3", "c4")
+BURST_PARITY = ("c2", "c2_lean", "c2_interop", "c2_view", "c3", "c4")
 _ORACLE_RATE = None
 
 
@@ -573,7 +614,7 @@ def parity_burst_slab(w, D):
 # every proof, hint and shortcut hnb_ctx_set_option can switch off: what is left is one init, one update, k_count_rows + k_compact per
 # program and frame, per-particle ages and lifetimes, direct spawn stores, one stream
 PLAIN_OPTIONS = {"horizon": 0, "age_cohort": 0, "cull_lifetime": 0, "skip_lists": 0, "stream_hints": 0, "overlap_updates": 0,
-                 "suffix_proof": 0, "ring_lists": 0, "alternate": 0, "transpose": 0, "scene_merge": 0}
+                 "suffix_proof": 0, "ring_lists": 0, "alternate": 0, "transpose": 0, "scene_merge": 0, "slot_init": 0}
 
 
 def parity_timed_state(w, args, D, options=None):
@@ -615,6 +656,8 @@ def parity_regime(name, args, D, frames):
     full = CONFIGS[name]["capacity"] if not args.capacity else args.capacity
     if name == "c2_dieoff":
         frames = min(frames, 2 * DIEOFF_END)     # two passes: the second bursts into the dead list the first die-off left
+    if name == "c2_reburst":
+        frames = min(frames, 3 * REBURST_CYCLE + 1)   # three cycles and the burst of the fourth: re-bursts into the dead stacks the die-offs left (few frames: a capacity at which the slot-major init engages)
     cap = int(PARITY_BUDGET_S * oracle_rate() / max(frames, 1))
     cap = max(16384, min(1 << (max(cap, 1).bit_length() - 1), max(16384, full // 16)))
     sub = argparse.Namespace(**vars(args))
@@ -707,12 +750,18 @@ def run_config(name, args, D, strong=False, pmc=None):
     pmc: None (normal run) or a dict {"begin": tag, "end": tag}: the short run a rocprofv3 counter pass wraps - marker kernels
     bracket a few steady-state frames, nothing is timed."""
     w = Workload(name, args, D, strong)
+    if pmc is None:
+        w.comm = D.make_comm(w)
     cfg, ctx, n = w.cfg, w.ctx, D.world
     steps, windows = args.steps, max(1, args.windows)
     warmup = warmup_frames(name, args.warmup)
     if name == "c2_dieoff":
         steps = DIEOFF_LAST - DIEOFF_FIRST + 1           # a window is the die-off itself, not K steps
-    elif name in ("c2", "c2_interop", "c2_view", "c2_interop_view"):
+    elif name == "c2_reburst":
+        steps = max(1, (steps + REBURST_CYCLE - 1) // REBURST_CYCLE) * REBURST_CYCLE   # whole cycles; the windows start on a burst frame
+        warmup = 2 * REBURST_CYCLE - 1
+        windows = min(windows, 12)
+    elif name in ("c2", "c2_lean", "c2_interop", "c2_view"):
         w.dt = frame_dt(1 + warmup + steps * windows)    # nobody may die in the timed frames
     elif name in BURST_SAFE_SECONDS:
         w.dt = frame_dt(1 + warmup + steps * windows, BURST_SAFE_SECONDS[name])
@@ -723,6 +772,10 @@ def run_config(name, args, D, strong=False, pmc=None):
             for _ in range(DIEOFF_FIRST):
                 w.step()
             frames = steps
+        elif name == "c2_reburst":
+            for _ in range(2 * REBURST_CYCLE):
+                w.step()
+            frames = 2 * REBURST_CYCLE
         else:
             w.step()
             for _ in range(warmup if name in ("c5", "c2_mixed", "c2_events") else 3):
@@ -752,11 +805,20 @@ def run_config(name, args, D, strong=False, pmc=None):
                 dieoff_counts.append(w.alive())
             w.step()
         assert w.alive() == 0, "c2_dieoff: particles left after the die-off"
+    elif name == "c2_reburst":
+        cycle_updates = []                               # max_update of every frame of a cycle (read back in the untimed warm-up; every cycle replays it)
+        for _ in range(warmup):
+            w.step()
+            if len(cycle_updates) < REBURST_CYCLE and w.f > REBURST_CYCLE:
+                cycle_updates.append(w.fxs[0].metadata()["max_update"])
+        assert w.f % REBURST_CYCLE == 0 and w.alive() == 0 and len(cycle_updates) == REBURST_CYCLE, (w.f, cycle_updates)
+        cycle_updates = cycle_updates[-1:] + cycle_updates[:-1]   # (recorded from frame 1 of a cycle on: rotate the burst frame to the front)
     else:
         for _ in range(warmup):
             w.step()
     D.barrier(ctx)
     alive0 = w.alive()
+    alive0_total = D.alive_total(w)
     m0 = [fx.metadata() for fx in w.fxs[:8]]
     window_s, window_updates = [], []
     ctx.enable_kernel_timing(TIMING_PERIOD if name != "c2_dieoff" else 0)
@@ -779,6 +841,18 @@ def run_config(name, args, D, strong=False, pmc=None):
                 w.step()
             w.dieoff_timing = getattr(w, "dieoff_timing", []) + [timing_d]
     timing = ctx.kernel_timing() if name != "c2_dieoff" else None
+    consumer_ms = None
+    if w.consumer is not None:   # the stand-in renderer alone (kernel-bound: 0.13 ms a launch), so that the row can say what of its step is simulation
+        ctx.enable_kernel_timing(0)
+        v = w.fxs[0].device_view()
+        for _ in range(3):
+            w.consumer.consumer_render_like(w._byref(v), w.consumer_out.data_ptr())
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            w.consumer.consumer_render_like(w._byref(v), w.consumer_out.data_ptr())
+        ctx.synchronize()
+        consumer_ms = (time.perf_counter() - t0) / 50 * 1e3
     per_program = None
     if name == "c2_events":   # the context's averages mix three programs: report each, the roofline kernel is the trails' update
         per_program = {k: p.kernel_timing() for k, p in zip(("rocket", "sparkle_trail", "trails"), w.progs)}
@@ -792,13 +866,22 @@ def run_config(name, args, D, strong=False, pmc=None):
         timing = {k: sum(t[k] * t["frames"] for t in ts) / tot for k in ("update_ms_avg", "compact_ms_avg", "init_ms_avg")}
         timing["frames"] = tot
     alive1 = w.alive()
+    alive1_total = D.alive_total(w)
     m1 = [fx.metadata() for fx in w.fxs[:8]]
+    stale_mask = w.fxs[0].device_view().stale_attr_mask   # after the timed frames: which planes a device-side reader would find stale (0 under the default options)
+    if w.options == "default":
+        assert stale_mask == 0, f"{name}: the library's default options left attribute planes stale after the timed frames (mask {stale_mask:#x})"
     comm_info = None
+    if D.on and w.comm is not None:   # N > 1: what the totals above were reduced through (hnb_comm_describe)
+        kind, _, rest = w.comm.describe().partition(" ")
+        comm_info = {"library": rest.split(" ranks=")[0] if kind == "rccl" else kind, "ranks": int(rest.split(" ranks=")[1].split()[0]) if " ranks=" in rest else D.world,
+                     "effects": w.n_effects_max, "alive_total": alive1_total, "via": "hnb_comm_create_rank + hnb_comm_allreduce_alive"}
     if getattr(args, "comm", False) and not D.on and not strong and name == args.config:
         comm_info = comm_alive_total(w)
         if "alive_total" in comm_info:
             assert comm_info["alive_total"] == alive1, f"hnb_comm_allreduce_alive says {comm_info['alive_total']}, the effects' counters {alive1}"
-    kinfo = w.prog.kernel_info().split("\n")[0]
+    w_kernel_info = w.prog.kernel_info()
+    kinfo = w_kernel_info.split("\n")[0]
     parity = None
     if args.parity and D.rank == 0 and not strong:
         try:
@@ -815,8 +898,7 @@ def run_config(name, args, D, strong=False, pmc=None):
             parity = {"config": name, "ok": False, "problems": [f"{type(e).__name__}: {e}"]}
     w.close()
 
-    alive0_total, alive1_total = D.sum_counts([alive0, alive1])
-    if name in ("c2", "c2_interop", "c2_view", "c2_interop_view", "c4"):
+    if name in ("c2", "c2_lean", "c2_interop", "c2_view", "c4"):
         expect = w.local_particles if not D.on else None
         assert expect is None or (alive0 == expect and alive1 == expect), f"{name}: expected every particle alive during the timed frames, got {alive0}, {alive1}"
     if D.rank != 0:
@@ -829,6 +911,9 @@ def run_config(name, args, D, strong=False, pmc=None):
         per_frame_total = per_frame_local * scale
     elif name == "c2_dieoff":
         per_frame_local = sum(dieoff_counts) / steps
+        per_frame_total = per_frame_local * n
+    elif name == "c2_reburst":
+        per_frame_local = sum(cycle_updates) / REBURST_CYCLE
         per_frame_total = per_frame_local * n
     else:
         per_frame_total = (alive0_total + alive1_total) / 2.0
@@ -844,7 +929,7 @@ def run_config(name, args, D, strong=False, pmc=None):
         "steps": steps, "warmup": warmup, "ms_per_step": med / steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["workload"].format(cap=w.per_inst_cap, inst=len(w.fxs)), "name": name, "capacity_per_gpu": w.local_particles,
-                   "instances_per_gpu": len(w.fxs), "dt": w.dt, "sharding": w.sharding_desc, "alive_before": alive0_total, "alive_after": alive1_total,
+                   "instances_per_gpu": len(w.fxs), "dt": w.dt, "options": w.options, "stale_attr_mask_after": stale_mask, "sharding": w.sharding_desc, "alive_before": alive0_total, "alive_after": alive1_total,
                    "updates_per_frame": per_frame_total, "spawns_per_frame": spawned},
         "windows": {"n": windows, "steps_each": steps, "ms_per_step": [s / steps * 1e3 for s in window_s], "median_ms_per_step": med / steps * 1e3,
                     "min_ms_per_step": min(window_s) / steps * 1e3, "value_best_window": updates / min(window_s),
@@ -853,6 +938,7 @@ def run_config(name, args, D, strong=False, pmc=None):
                    "sum_ms": timing["init_ms_avg"] + k_ms + timing["compact_ms_avg"], "samples": timing["frames"],
                    "timing": f"HIP events on the simulation stream, every {TIMING_PERIOD if name != 'c2_dieoff' else 1}th timed frame (rank 0); lists = count + compact (+ ribbon sort, + event ordering)"},
         "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": cfg["kernel"], "kernel_ms_avg": k_ms,
+                     "step_kernels_ms": {"init": timing["init_ms_avg"] if name in ("c5", "c2_mixed", "c2_events", "c2_reburst") else 0.0, "update": k_ms, "lists": timing["compact_ms_avg"]},
                      "updates_per_launch": per_frame_local,
                      "algorithmic": {"bytes_per_update": bpu, "gbs_kernel": per_frame_local * bpu / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
                                      "gbs_whole_step": updates / n * bpu / med / 1e9,
@@ -861,14 +947,35 @@ def run_config(name, args, D, strong=False, pmc=None):
         "kernels": kinfo,
         "parity": parity,
     }
+    if name in ("c2", "c2_lean", "c2_view", "c2_interop"):
+        # SURVEY.md 8(d)'s 68 B per update against what this configuration's update kernel is built to move: every elided stream named with its bytes
+        # (all of them proved per chunk and frame and verified by the parity gate; the PMC figure `moved_bytes_per_update` is the measured counterpart)
+        el = {"lifetime_read": 4, "alive_list_read_write": 8}                    # lifetime culling (chunk bound); no casualty possible: lists untouched
+        if name != "c2_interop":
+            el["age_read"] = 4                                                   # age cohorts: the chunk's common age is one word
+            if w.options == "age_cohort=LEAN":
+                el["age_write"] = 4                                              # ... and LEAN leaves the plane stale
+        out["roofline"]["algorithmic"]["elided_bytes_per_update"] = el
+        out["roofline"]["algorithmic"]["designed_bytes_per_update"] = bpu - sum(el.values())
+    if consumer_ms is not None:
+        out["consumer_ms"] = consumer_ms
+        out["sim_only_ms"] = out["ms_per_step"] - consumer_ms
+        out["consumer_note"] = "consumer_ms: the stand-in renderer's kernel alone (back to back, no frames); sim_only_ms = ms_per_step - consumer_ms; value is the end-to-end rate"
+    if name == "c2_reburst":
+        bps = cfg["bytes_per_spawn"]
+        rb = timing["init_ms_avg"]
+        out["reburst"] = {"cycle": f"{REBURST_CYCLE} frames: burst of `capacity` (dt 1/60 s), then {REBURST_CYCLE - 1} x {REBURST_DT} s", "updates_per_frame_of_cycle": cycle_updates,
+                          "init_kernel": "k_init_slots (slot-major; hnb_kernels.hip.h)", "init_kernel_ms": rb, "spawned": w.local_particles, "bytes_per_spawn": bps,
+                          "init_frac": w.local_particles * bps / (rb * 1e-3) / 1e9 / HBM_PEAK_GBS if rb > 0 else None,
+                          "row_major_before": "2.06 ms for the same re-burst in round 5 (profiles/r05_nursery/r05b_reburst.log)"}
     if comm_info is not None:
         out["comm"] = comm_info
     if per_program is not None:
         out["stages"]["per_program"] = per_program
         out["stages"]["note"] = "init / lists: sums over the three programs (lists of the rocket include its spawn-event ordering: k_emit_count + k_emit_events); update: the trails' kernel; sum_ms leaves out the two small update kernels (per_program has them)"
-    if init_ms > 0 and name not in ("c5", "c2_mixed", "c2_events"):  # the burst frame's init kernel (not part of the metric)
+    if init_ms > 0 and name not in ("c5", "c2_mixed", "c2_events"):  # the burst frame's init kernel (not part of the metric; c2_reburst: the FRESH burst, its re-bursts are under "reburst")
         bps = cfg["bytes_per_spawn"]
-        out["init"] = {"kernel": "k_init", "kernel_ms": init_ms, "spawned": w.local_particles, "bytes_per_spawn": bps,
+        out["init"] = {"kernel": "k_init_slots" if "slot-major init" in w_kernel_info else "k_init", "kernel_ms": init_ms, "spawned": w.local_particles, "bytes_per_spawn": bps,
                        "achieved_gbs": w.local_particles * bps / (init_ms * 1e-3) / 1e9, "frac": w.local_particles * bps / (init_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     return out
 
@@ -1155,6 +1262,7 @@ def main():
                          "submit thread per GPU (examples/multi_gpu.c: C99 over the C ABI, RCCL through hnb_comm_*), c2 / c3 only")
     ap.add_argument("--no-comm", dest="comm", action="store_false", default=True,
                     help="N = 1: do not take the headline's alive total through hnb_comm_allreduce_alive (a one-rank communicator of the real librccl)")
+    ap.add_argument("--comm-lib", default=None, help="N > 1 dry runs: the collective library hnb_comm_* loads instead of librccl (tests/fake_rccl/libfake_rccl.so takes several ranks on one GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--force-device", type=int, default=None, help="dry runs: every rank uses this GPU instead of LOCAL_RANK")
     args = ap.parse_args()
@@ -1168,6 +1276,11 @@ def main():
     if args.pmc_child:
         pmc_child(args, D)
         return
+    if D.on:   # (before the first hnb_comm_* call of the process)
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+        if args.comm_lib:
+            from bevy_hanabi_amd import runtime as _rt
+            _rt.comm_set_library(os.path.abspath(args.comm_lib), duplicate_devices=True)
     if args.comm and not D.on:   # (before the first hnb_comm_* call of the process)
         try:
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
@@ -1232,6 +1345,7 @@ def main():
         if extra:
             out["configs"] = {k: (v if "error" in v else {kk: v[kk] for kk in ("value", "ms_per_step", "windows", "stages", "roofline", "init", "kernels", "parity") if kk in v}
                                   | {"workload": v["config"]["workload"], "updates_per_frame": v["config"]["updates_per_frame"], "spawns_per_frame": v["config"]["spawns_per_frame"]})
+                              | {kk: v[kk] for kk in ("consumer_ms", "sim_only_ms", "reburst") if kk in v}
                               for k, v in extra.items()}
     if not D.on and args.scene and args.config == "c2" and not args.no_extra_configs and not args.pmc_child:
         # the launch-bound end of the path: 26 different small effects in one context (tools/scene_bench.py, profiles/r03v_scene.log). Their
@@ -1313,13 +1427,13 @@ def short_line(full, args):
     parity_all = [p for p in parity_all if p]
     failed = [p["config"] for p in parity_all if not p.get("ok")]
     errored = [k for k, v in full.get("configs", {}).items() if "error" in v]
-    parity = {"checked": [p["config"] for p in parity_all if p.get("ok")], "ok": (not failed) if (parity_all or args.parity) else None, "burst": "slab of the full-size effect after the timed frames vs oracle/, bit-exact",
+    parity = {"checked": [p["config"] for p in parity_all if p.get("ok")], "ok": (not failed) if (parity_all or args.parity) else None, "burst": "full-size slab after the timed frames vs oracle/, bit-exact",
               "churn": "timed state: invariants + plain-path differential at full size; oracle at reduced capacity"}
     timed = [p.get("timed_state") for p in parity_all if p.get("timed_state")]
     if timed:   # (the churn configurations' full-size leg: how many effects were checked / compared on the device)
         parity["timed_state"] = {"checked": sum(len(t["checks"]) for t in timed), "compared": sum(len(t["diffs"]) for t in timed), "ok": all(t["ok"] for t in timed)}
     if failed:
-        parity["failed"] = {p["config"]: (p.get("problems") or ["?"])[0][:80] for p in parity_all if not p.get("ok")}
+        parity["failed"] = {p["config"]: (p.get("problems") or ["?"])[0][:56] for p in parity_all if not p.get("ok")}
     if not args.parity:
         parity["skipped"] = "--no-parity"
     short = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
@@ -1327,22 +1441,26 @@ def short_line(full, args):
         short["value"] = None            # a number whose state differs from the oracle's is not a result
         short["refused"] = "parity gate failed: " + ", ".join(failed)
     cfg = full.get("config", {})
-    short["config"] = {k: (cfg.get(k)[:170] if k == "workload" else cfg.get(k)) for k in ("workload", "name", "capacity_per_gpu", "instances_per_gpu", "dt", "sharding", "updates_per_frame") if k in cfg}
+    short["config"] = {k: (cfg.get(k)[:120] if k == "workload" else cfg.get(k)) for k in ("workload", "name", "capacity_per_gpu", "instances_per_gpu", "dt", "options", "stale_attr_mask_after", "sharding", "updates_per_frame") if k in cfg}
     short["windows"] = {"n": win.get("n"), "steps_each": win.get("steps_each"), "ms_per_step_min_median_max": [_r(min(ms)), _r(statistics.median(ms)), _r(max(ms))],
                         "timed_region_s": _r(win.get("timed_region_s"))}
     short["roofline"] = {"bound": ro.get("bound"), "kernel": ro.get("kernel"), "kernel_ms_avg": _r(ro.get("kernel_ms_avg")), "kernel_ms_rocprof": _r(ro.get("kernel_ms_rocprof")),
-                         "traffic": ro.get("traffic"), "traffic_source": (ro.get("traffic_source") or "")[:60],
+                         "traffic": ro.get("traffic"), "traffic_source": (ro.get("traffic_source") or "")[:20],
                          "moved_bytes_per_update": _r(ro.get("moved_bytes_per_update")), "achieved": _r(ro.get("achieved")), "peak": ro.get("peak"), "unit": ro.get("unit"),
                          "frac": _r(ro.get("frac")), "frac_rocprof": _r(ro.get("frac_rocprof")),
                          # (flat: a record that keeps only the scalar members of this object still says what the kernel elides - SURVEY.md 8(d)'s 68 B x
                          #  updates / step time / peak above 1 means the timed kernel does not move the per-particle age / lifetime / list bytes)
                          "algorithmic_bytes_per_update": ro.get("algorithmic", {}).get("bytes_per_update"),
                          "algorithmic_whole_step_over_peak": _r(ro.get("algorithmic", {}).get("whole_step_over_peak")),
+                         # (which of the 68 B the kernel is built not to move, named with their bytes; the sum of the frame's kernels - one, the update, in the headline's timed frames)
+                         "elided": " + ".join(f"{k} {v}" for k, v in (ro.get("algorithmic", {}).get("elided_bytes_per_update") or {}).items()) or None,
+                         "designed_bytes_per_update": ro.get("algorithmic", {}).get("designed_bytes_per_update"),
+                         "step_kernels_ms": _r(sum((ro.get("step_kernels_ms") or {}).values()), 4) if ro.get("step_kernels_ms") else None,
                          "whole_step_frac": _r(ro.get("whole_step", {}).get("frac"))}
     cb = full.get("cpu_baseline")
     if cb:
         short["cpu_baseline"] = cb if "error" in cb else {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "threads": cb["threads"], "host_physical_cores": cb.get("host_physical_cores"),
-                                                          "cpu_model": cpu_model(), "cpu_quota": (cb.get("limits") or {}).get("cgroup_cpu_quota"), "kind": cb["kind"], "sample": cb["sample"][:80]}
+                                                          "cpu_model": cpu_model(), "cpu_quota": (cb.get("limits") or {}).get("cgroup_cpu_quota"), "kind": cb["kind"], "sample": cb["sample"][:56]}
     short["parity"] = parity
     if full.get("comm"):   # (N = 1: the alive total went through hnb_comm_allreduce_alive over a one-rank communicator of the real librccl)
         short["comm"] = {k: v for k, v in full["comm"].items() if k != "effects"}
@@ -1352,13 +1470,17 @@ def short_line(full, args):
             rows[k] = {"error": v["error"][:120]}
             continue
         r2 = v.get("roofline", {})
-        # (value, ms_per_step: median window; kernel_ms: HIP events, kernel_ms_rocprof: rocprofv3 kernel trace; frac = moved bytes / kernel time / 8 TB/s;
+        # (value, ms_per_step: median window; kernel_ms: HIP events (the rocprofv3 kernel-trace figure of every row is in the complete record); frac = moved bytes / kernel time / 8 TB/s;
         #  B_upd = moved bytes per update; ws_frac = all kernels' moved bytes / step time / peak; ws68 = 68 B x updates / step time / peak;
         #  stages_ms = [init, update, lists])
         rows[k] = {"value": _r(v.get("value")), "ms_per_step": _r(v.get("ms_per_step")), "kernel_ms": _r(r2.get("kernel_ms_avg")),
-                   "kernel_ms_rocprof": _r(r2.get("kernel_ms_rocprof")), "frac": _r(r2.get("frac"), 3), "B_upd": _r(r2.get("moved_bytes_per_update"), 3),
+                   "frac": _r(r2.get("frac"), 3), "B_upd": _r(r2.get("moved_bytes_per_update"), 3),
                    "ws_frac": _r(r2.get("whole_step", {}).get("frac"), 3), "ws68": _r(r2.get("algorithmic", {}).get("whole_step_over_peak"), 3),
                    "stages_ms": [_r(v.get("stages", {}).get(x), 3) for x in ("init_ms_avg", "update_ms_avg", "lists_ms_avg")]}   # (parity: "parity".checked / .failed name the configuration)
+        if v.get("consumer_ms") is not None:
+            rows[k]["consumer_ms"], rows[k]["sim_only_ms"] = _r(v["consumer_ms"], 3), _r(v.get("sim_only_ms"), 3)
+        if v.get("reburst"):
+            rows[k]["reburst_init_ms"], rows[k]["reburst_init_frac"] = _r(v["reburst"]["init_kernel_ms"], 3), _r(v["reburst"]["init_frac"], 3)
         if v.get("init") and k in ("c3", "c4"):   # (the burst frame's k_init against 8 TB/s on its algorithmic bytes: c2's is "burst_init" below)
             rows[k]["init_frac"] = _r(v["init"].get("frac"), 3)
     if rows:

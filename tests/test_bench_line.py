@@ -25,9 +25,14 @@ def worst_case_record():
         v["parity"] = par(name, True)
         v["roofline"]["kernel_ms_rocprof"] = 0.2123456789
         v["roofline"]["rocprof_detail"] = copy.deepcopy(full["roofline"]["rocprof_detail"])
-    for extra in ("c2_view", "c2_interop_view"):               # (round 5's end-to-end rows)
+    for extra in ("c2_view", "c2_lean", "c2_reburst"):         # (round 5's end-to-end row; round 6: the LEAN row next to the default headline, the timed re-burst)
         full["configs"][extra] = copy.deepcopy(full["configs"]["c2_interop"])
         full["configs"][extra]["parity"]["config"] = extra
+    full["configs"]["c2_view"].update({"consumer_ms": 0.128123456, "sim_only_ms": 0.1365123456})
+    full["configs"]["c2_reburst"]["reburst"] = {"init_kernel_ms": 0.14876543, "init_frac": 0.6123456, "cycle": "c" * 80, "updates_per_frame_of_cycle": [16777216] * 4}
+    full["config"].update({"options": "default", "stale_attr_mask_after": 0})
+    full["roofline"]["step_kernels_ms"] = {"init": 0.0, "update": 0.1312345678, "lists": 0.0}
+    full["roofline"]["algorithmic"].update({"elided_bytes_per_update": {"lifetime_read": 4, "alive_list_read_write": 8, "age_read": 4}, "designed_bytes_per_update": 52})
     for name in ("c2_mixed", "c2_dieoff", "c2_events", "c5"):   # (round 5: the churn configurations' gate on the timed state at full size)
         if name in full["configs"]:
             full["configs"][name]["parity"]["timed_state"] = {"ok": True, "checks": [{"ok": 1, "alive_count": 16499355}] * 3, "diffs": [{"equal": 1, "first_section": -1}] * 3,
@@ -68,6 +73,9 @@ def test_short_line_fits_the_driver_tail_and_carries_the_contract():
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
     assert ro["algorithmic_bytes_per_update"] == 68 and "whole_step_frac" in ro and "algorithmic_whole_step_over_peak" in ro
     assert all(not isinstance(v, (dict, list)) for v in ro.values()), "roofline must stay flat: the driver keeps its scalar members only"
+    assert line["config"]["options"] == "default" and line["config"]["stale_attr_mask_after"] == 0          # (the headline runs the library's defaults, nothing stale)
+    assert ro["elided"] == "lifetime_read 4 + alive_list_read_write 8 + age_read 4" and ro["designed_bytes_per_update"] == 52 and abs(ro["step_kernels_ms"] - 0.1312) < 1e-4
+    assert line["configs"]["c2_view"]["consumer_ms"] and line["configs"]["c2_reburst"]["reburst_init_frac"]
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] <= cb["threads"] and cb["host_physical_cores"] and "cpu_model" in cb and cb["sample"] and "cpu_quota" in cb
     assert line["parity"]["ok"] is True and set(line["parity"]["checked"]) == {"c2"} | set(full["configs"])
@@ -75,7 +83,7 @@ def test_short_line_fits_the_driver_tail_and_carries_the_contract():
     assert line["comm"]["ranks"] == 1 and "librccl" in line["comm"]["library"]
     assert set(line["configs"]) == set(full["configs"])
     for row in line["configs"].values():
-        assert {"value", "ms_per_step", "frac", "ws_frac", "ws68", "kernel_ms", "kernel_ms_rocprof"} <= set(row)
+        assert {"value", "ms_per_step", "frac", "ws_frac", "ws68", "kernel_ms"} <= set(row)      # (kernel_ms_rocprof of the side rows: in the complete record)
     assert len(line["windows"]["ms_per_step_min_median_max"]) == 3
     assert line["value"] == full["value"]                      # the headline is not rounded
 

@@ -174,7 +174,7 @@ def test_bench_helpers_agree_with_the_oracle_and_the_profiles():
     for f in (0, 1, 7, 1000, 123456):
         assert bench.frame_seed(f) == oracle.pcg_hash(0xC0FFEE + f)
         assert bench.instance_seed(f, 0) == bench.frame_seed(f) and bench.instance_seed(f, 5) != bench.frame_seed(f)
-    assert {"c2", "c2_mixed", "c2_dieoff", "c2_interop", "c2_view", "c2_interop_view", "c2_events", "c3", "c4", "c5"} == set(bench.CONFIGS)
+    assert {"c2", "c2_lean", "c2_mixed", "c2_dieoff", "c2_reburst", "c2_interop", "c2_view", "c2_events", "c3", "c4", "c5"} == set(bench.CONFIGS)
     assert bench.CONFIGS["c2"]["capacity"] == 16_777_216 and bench.CONFIGS["c2"]["bytes_per_update"] == 68
     assert bench.CONFIGS["c3"]["capacity"] == 8_388_608 and bench.CONFIGS["c5"]["capacity"] == 4_194_304 and bench.CONFIGS["c4"]["instances"] * 8 == 4096
     assert bench.frame_dt(36) == bench.DT and bench.frame_dt(10_000) * 10_000 < bench.MIN_LIFETIME

@@ -185,7 +185,7 @@ def test_large_spawns_slot_major_equal_the_row_major_init_and_the_oracle():
         assert_same_state(ref, g_on.state(), f"slot-major, frame {f}")
         assert_same_state(ref, g_off.state(), f"row-major, frame {f}")
         assert g_on.fx.check()["ok"] == 1
-    assert _slot_init_frames(g_on.prog) == 8 and _slot_init_frames(g_off.prog) == 0, g_on.prog.kernel_info()
+    assert _slot_init_frames(g_on.prog) == 7 and _slot_init_frames(g_off.prog) == 0, g_on.prog.kernel_info()
     assert g_on.fx.compare(g_off.fx)["equal"] == 1
     on.close(); off.close()
 

@@ -228,7 +228,7 @@ def test_c2_firework_full_state_at_baseline_size(ctx):
         if f in (0, 2, 4, 5, 6, 9, 10):
             assert_same_state(orc.state(), gpu.state(), f"C2 16.7M frame {f}")
         alive.append(gpu.fx.alive_count())
-    assert alive[:3] == [cap] * 3 and 0 < alive[4] < cap and alive[5] == 0 and alive[6] == cap and 0 < alive[8] < cap - cap // 4 and alive[10] == cap, alive
+    assert alive[:3] == [cap] * 3 and 0 < alive[4] < cap and alive[5] == 0 and alive[6] == cap and 0 < alive[8] < cap - cap // 4 and alive[8] < alive[9] < alive[10] <= cap, alive   # (the last frame fills every free slot AND ages everybody by 1/60 s: a few of the oldest die in it)
     info = gpu.prog.kernel_info()
     assert "slot-major init (large spawns): 4 frames" in info, info
     assert gpu.fx.metadata()["fault"] == 0

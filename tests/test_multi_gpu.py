@@ -51,6 +51,38 @@ def test_collective_branch_runs_through_a_stand_in_library():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
+def test_two_rank_processes_reduce_through_hnb_comm_create_rank(tmp_path):
+    """hnb_comm_create_rank (ncclGetUniqueId on rank 0 -> ncclCommInitRank on every rank -> grouped ncclAllReduce) had only ever
+    run with ONE rank. Two PROCESSES, one rank each, both on device 0 (the stand-in library: the real librccl refuses a device twice), each with its
+    capacity slab of one firework effect and a second effect of its own size: every rank sees the sum over both, at three points of the run, and
+    a NULL entry counts 0 on the rank that passes it."""
+    import sys
+    from bevy_hanabi_amd import sharding
+    id_file = str(tmp_path / "uid")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "fake_rccl", "run_fake_rank.py"), str(r), "2", id_file], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=540)
+        assert p.returncode == 0, se[-3000:]
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    outs.sort(key=lambda o: o["rank"])
+    assert outs[0]["totals"] == outs[1]["totals"] and outs[0]["partial"] == outs[1]["partial"]
+    assert outs[0]["totals"][0] == [100_000, 4096 * 3]                                         # frame 0: everybody alive, on both ranks together
+    assert outs[0]["totals"][2] == [outs[0]["local"][0] + outs[1]["local"][0], outs[0]["local"][1] + outs[1]["local"][1]]
+    assert 0 < outs[0]["totals"][2][0] < outs[0]["totals"][1][0] < 100_000                       # the die-off, seen by the collective as it goes
+    assert outs[0]["partial"] == [outs[0]["local"][0], outs[0]["local"][1] + outs[1]["local"][1]]
+    assert all(o["describe"].startswith("rccl ") and "libfake_rccl" in o["describe"] and o["describe"].endswith("ranks=2 local=1") for o in outs), outs
+    # ... and the union of the two slabs is the one effect (the oracle's count)
+    orc = OracleRunner(effects.firework_trails(100_000))
+    for f in range(60):
+        orc.step(Frame(1 / 60, 100_000 if f == 0 else 0, frame_seed(f), time=f / 60))
+    assert orc.state()["counters"]["alive_count"] == outs[0]["totals"][2][0]
+    assert sharding.slab_plan(100_000, 2) == [(0, 50_000), (50_000, 50_000)]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
 def test_the_real_librccl_reduces_a_one_context_communicator():
     """dlopen("librccl.so.1") -> ncclCommInitAll / ncclGetUniqueId + ncclCommInitRank -> grouped ncclAllReduce(ncclUint64,
     ncclSum) on the context's stream -> ncclCommDestroy had run zero times on hardware. HNB_COMM_LIB_SINGLE_RANK makes a communicator of one
