@@ -136,6 +136,23 @@ def test_product_against_libm_oracle(ctx, name):
         rel = np.abs(sg - so) / np.abs(so)
         print(f"c3 ensemble after {len(frames)} frames vs libm: worst relative difference {rel.max():.3g}, centre of mass {np.abs(cg - co).max():.3g}")
         assert rel.max() < 1e-3 and np.abs(cg - co).max() < 1e-4, (sg, so, cg, co)
+        # ... and EVERY frame inside a <= 10-frame horizon of the libm oracle: a second run that is RE-SYNCHRONISED every 10 frames -
+        # the libm oracle's position / velocity / age / lifetime planes written into the device effect (hnb_effect_write_attr), ten frames on both
+        # sides, the 1e-5 comparison - over all 100 frames: ten windows, each starting from the same state. (The update of force_field.rs is made of
+        # IEEE operations only - the transcendental builtins sit in the init - so behind the first re-synchronisation the two sides agree exactly.)
+        gpu2, orc2 = GpuRunner(asset, ctx=ctx), OracleRunner(asset, libm=True)
+        worst_w = []
+        for w0 in range(0, len(frames), 10):
+            for i in range(w0, min(w0 + 10, len(frames))):
+                gpu2.step(frames[i])
+                orc2.step(frames[i])
+            ref = orc2.state()
+            worst_w.append(_assert_close_state(ref, gpu2.state(), f"c3 re-synchronised window [{w0}, {w0 + 10})"))
+            for a in (A.POSITION, A.VELOCITY, A.AGE, A.LIFETIME):
+                gpu2.fx.write_attr(a.id, np.ascontiguousarray(ref["attrs"][a.name]).view(np.float32))
+        assert len(worst_w) == 10 and max(worst_w) <= REL_TOL
+        print("c3 re-synchronised every 10 frames vs libm: worst relative difference per window", ["%.2g" % x for x in worst_w])
+        gpu2.fx.destroy(); gpu2.prog.destroy()
     gpu.fx.destroy(); gpu.prog.destroy()
 
 
