@@ -95,7 +95,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (guides/MI355X_MICROARCH.md)
 DT = 1.0 / 60.0
 MIN_LIFETIME = 0.8  # firework.rs: lifetime = uniform(0.8, 1.2)
 MEAN_LIFETIME = 1.0
-TIMING_PERIOD = 5   # HIP events bracket the kernels of every 5th timed frame (each costs ~20 us of stream bubbles)
+TIMING_PERIOD = 15  # HIP events bracket the kernels of every 15th timed frame (each costs ~20 us of stream bubbles: at every 5th frame, as until round 5, that was 5 % of a C5 step and 2 % of a c2 step - profiles/r06f_timing_period.log; 750 timed frames still give 50 samples)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")  # written by `bench.py --write-traffic` from the PMC passes
 REBURST_CYCLE, REBURST_DT = 4, 0.45   # c2_reburst: frame 0 of a cycle bursts `capacity` particles (dt 1/60), frames 1..3 advance 0.45 s each: alive after them 100 %, ~71 %, 0
 DIEOFF_FIRST, DIEOFF_LAST, DIEOFF_END = 48, 70, 76   # c2_dieoff: timed frames [48, 70]; by frame 76 nothing is alive (1.2 s < 73 / 60 s)
@@ -821,7 +821,7 @@ def run_config(name, args, D, strong=False, pmc=None):
     alive0_total = D.alive_total(w)
     m0 = [fx.metadata() for fx in w.fxs[:8]]
     window_s, window_updates = [], []
-    ctx.enable_kernel_timing(TIMING_PERIOD if name != "c2_dieoff" else 0)
+    ctx.enable_kernel_timing(getattr(args, "timing_period", TIMING_PERIOD) if name != "c2_dieoff" else 0)
     for _win in range(windows):
         if name == "c2_dieoff":
             while w.f % DIEOFF_END != DIEOFF_FIRST:      # untimed: burst + flight up to the first death
@@ -936,7 +936,7 @@ def run_config(name, args, D, strong=False, pmc=None):
                     "timed_region_s": sum(window_s)},
         "stages": {"init_ms_avg": timing["init_ms_avg"], "update_ms_avg": k_ms, "lists_ms_avg": timing["compact_ms_avg"],
                    "sum_ms": timing["init_ms_avg"] + k_ms + timing["compact_ms_avg"], "samples": timing["frames"],
-                   "timing": f"HIP events on the simulation stream, every {TIMING_PERIOD if name != 'c2_dieoff' else 1}th timed frame (rank 0); lists = count + compact (+ ribbon sort, + event ordering)"},
+                   "timing": f"HIP events on the simulation stream, every {getattr(args, 'timing_period', TIMING_PERIOD) if name != 'c2_dieoff' else 1}th timed frame (rank 0); lists = count + compact (+ ribbon sort, + event ordering)"},
         "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": cfg["kernel"], "kernel_ms_avg": k_ms,
                      "step_kernels_ms": {"init": timing["init_ms_avg"] if name in ("c5", "c2_mixed", "c2_events", "c2_reburst") else 0.0, "update": k_ms, "lists": timing["compact_ms_avg"]},
                      "updates_per_launch": per_frame_local,
@@ -1262,6 +1262,7 @@ def main():
                          "submit thread per GPU (examples/multi_gpu.c: C99 over the C ABI, RCCL through hnb_comm_*), c2 / c3 only")
     ap.add_argument("--no-comm", dest="comm", action="store_false", default=True,
                     help="N = 1: do not take the headline's alive total through hnb_comm_allreduce_alive (a one-rank communicator of the real librccl)")
+    ap.add_argument("--timing-period", type=int, default=TIMING_PERIOD, help="HIP events bracket the kernels of every n-th timed frame (stage / kernel times; each such frame costs ~20 us of stream bubbles)")
     ap.add_argument("--comm-lib", default=None, help="N > 1 dry runs: the collective library hnb_comm_* loads instead of librccl (tests/fake_rccl/libfake_rccl.so takes several ranks on one GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--force-device", type=int, default=None, help="dry runs: every rank uses this GPU instead of LOCAL_RANK")

@@ -182,7 +182,6 @@ struct HnbContext {
     bool skip_lists = true;     // skip the list kernels of frames the device's no-death bound covers (HNB_OPT_SKIP_LISTS)
     bool alternate = true;      // walk the chunks in alternating directions from frame to frame (HNB_OPT_ALTERNATE)
     bool suffix_proof = true;   // ribbon programs: "the casualties are the last rows of the sorted list" replaces k_count_rows where the host can prove it (HNB_OPT_SUFFIX_PROOF)
-    bool stage_kernel = true;   // the frame's parameter block reaches the device through k_stage_copy on the simulation stream; false: hipMemcpyAsync + a host wait (HNB_OPT_STAGE_KERNEL)
     uint32_t slot_init = 1;     // frames that spawn a large share of a program's slots run their init slot-major (k_init_slots; HNB_OPT_SLOT_INIT)
     bool ring_lists = true;     // ... and where in addition the spawns sort in front, the list is kept as a ring: nothing is rewritten (HNB_OPT_RING_LISTS)
     bool scene_merge = true;    // small programs share their init / update launches (ProgJob / StreamJob; HNB_OPT_SCENE_MERGE)
@@ -1003,7 +1002,6 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
         case HNB_OPT_SCENE_MERGE: ctx->scene_merge = value != 0u; return HNB_OK;
         case HNB_OPT_SUFFIX_PROOF: ctx->suffix_proof = value != 0u; return HNB_OK;
         case HNB_OPT_RING_LISTS: ctx->ring_lists = value != 0u; return HNB_OK;
-        case HNB_OPT_STAGE_KERNEL: ctx->stage_kernel = value != 0u; return HNB_OK;
         case HNB_OPT_SLOT_INIT:
             if (value > 2u) return fail(HNB_ERR_INVALID_ARG, "unknown slot-init mode %u", value);
             ctx->slot_init = value;
@@ -2205,15 +2203,12 @@ int hnb_simulate(HnbContext* ctx) {
     if (stage_off) {
         // (Round 5, tried: the copy on the simulation stream in front of the frame's first kernel instead - no host wait, no copy beside the previous frame's
         // kernels. Slower everywhere: C5 0.0359 -> 0.0378 ms, c2_mixed 0.353 -> 0.360, the 26-effect scene 0.050 -> 0.064: profiles/r05j_ab_upload.log.)
-        // (Round 6: a kernel on the simulation stream reads the pinned block and writes the device block - hnb_kernels.hip.h k_stage_copy; the host does not wait.)
-        if (ctx->stage_kernel) {
-            const uint32_t n16 = (uint32_t)((stage_off + 15u) / 16u);   // (sections are 256-byte aligned, the buffers sized in 64 KiB steps)
-            k_stage_copy<<<(n16 + 255u) / 256u, 256, 0, ctx->stream>>>(static_cast<u4v*>(ctx->d_stage[slot]), static_cast<const u4v*>(ctx->h_stage[slot]), n16);
-            HIP_TRY(hipGetLastError());
-        } else {
-            HIP_TRY(hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], stage_off, hipMemcpyHostToDevice, ctx->upload_stream));
-            HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
-        }
+        // (Round 6, tried: no host-side copy at all - one small kernel on the simulation stream reads the pinned block over the link and writes the device block,
+        // the host never waits. Slower everywhere as well: C5 0.0374 -> 0.0380 ms, c2 0.139 -> 0.142, the scene 0.051 -> 0.053, time inside hnb_simulate unchanged:
+        // the frame of a small effect is bound by its CHAIN of dependent launches on the device - the host only blocks on the staging ring - and the copy kernel
+        // is one more link of it: profiles/r06c_ab_stage_kernel.log, r06c_stage_kernel.patch.)
+        HIP_TRY(hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], stage_off, hipMemcpyHostToDevice, ctx->upload_stream));
+        HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
     }
     rc = enqueue_init_passes(ctx, order, fj, timed);
     if (rc == HNB_OK) rc = enqueue_update_passes(ctx, order, fj, timed);

@@ -79,20 +79,6 @@ __global__ void k_reset_lists(uint32_t* __restrict__ dead, uint32_t* __restrict_
 }
 #endif
 
-// ---- the frame's parameter block: pinned host memory -> device, by a kernel on the simulation stream -------------------------------------------
-// Every kernel of a frame reads its per-frame inputs (DevFrameInst rows, parameter blocks, job tables) from one device block. Until round 6 the
-// host copied it (hipMemcpyAsync on an upload stream) and WAITED for the copy - 2.7 + 10.5 us of every frame's ~23 us inside hnb_simulate for a
-// small effect (profiles/r05m_c5_hip_calls.txt), where the frame is submission-bound; the alternatives that keep the host out of it lost in round 5
-// (the copy on the simulation stream, a stream-side wait, every kernel reading the pinned block itself: profiles/r05j / r05n / r05o). This is the one
-// left: ONE small launch in front of the frame reads the pinned block over the link - once, 16 bytes per thread - and writes the device block;
-// stream order does the rest, the host never waits. (Kernel arguments live in host memory too: a by-value block would travel the same way.)
-#ifndef HNB_JIT_TU
-__global__ void __launch_bounds__(256) k_stage_copy(u4v* __restrict__ dst, const u4v* __restrict__ src, uint32_t n16) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n16) dst[i] = __builtin_nontemporal_load(src + i);
-}
-#endif
-
 // ---- placement probe ------------------------------------------------------------------------------
 // Streams through a block the way the slot-major update does (several planes read and written with 16-byte
 // accesses, far apart from each other). Used once per large block at allocation: see alloc_slab_block().
@@ -1428,6 +1414,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
             u4v* vw = reinterpret_cast<u4v*>(p_vel + (size_t)j * (kChunk * 12u)) + wave * (kWaveRows * 3u / 4u);
             const uint32_t rot = lane % 3u;   // component of this lane's first float in every word it takes: (word index) mod 3 = (3 step + w + lane) mod 3, w added below
             if (args.age_current && (fl & 64u)) {   // the plane kept current: the wave's 1024 ages, 16 bytes per lane and step, issued in front of the loads below
+                // (behind the loop, and / or with the nontemporal hint: no difference on c2 or c4, two rounds on one box - profiles/r06d_ab_age_store.log)
                 u4v* aw = reinterpret_cast<u4v*>(p_age + (size_t)j * (kChunk * 4u)) + wave * (kWaveRows / 4u);
                 const uint32_t a2 = f2u(A2);
 #pragma unroll

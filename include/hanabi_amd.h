@@ -319,10 +319,6 @@ int hnb_ctx_synchronize(HnbContext* ctx);
  *   ribbon effects, keep the rank-major pass. Same state bit for bit (the serial pop order only decides the LIST, which is copied). 0: never;
  *   2: every eligible program in every frame that spawns anything, whatever its size (tests, A/B runs). */
 #define HNB_OPT_SLOT_INIT 17u
-/* HNB_OPT_STAGE_KERNEL (default 1; from the next hnb_simulate on): the frame's parameter block (per-instance inputs, parameter blocks, job tables: a few
- *   hundred bytes to some tens of KiB) is moved from the pinned staging buffer to the device by one small kernel on the simulation stream; the host does
- *   not wait for it. 0: hipMemcpyAsync on an upload stream + a host-side wait, as until round 5. Scheduling only: same results. For A/B runs. */
-#define HNB_OPT_STAGE_KERNEL 18u
 /* HNB_OPT_OVERLAP_UPDATES (default 1; from the next hnb_simulate on): when one program of the context holds at least four times the slots
  *   of all the others together (and >= 1M), the update phase of the others - update, spawn-event ordering, lists, sort: independent chains -
  *   runs on an internal second stream next to the heavy program's update and joins the context's stream before hnb_simulate returns.
