@@ -1,7 +1,7 @@
 #!/bin/bash
 # Development tool (GPU box): the end-of-round check in one gpurun call: the GPU suite, smoke, the default bench line (its own two PMC passes kept as
 # CSVs), and the rocprofv3 kernel statistics of the headline configuration. Usage: gpu_round_check.sh <tag>   ->  gpurun_out/<tag>_*
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -rf -p no:cacheprovider 2>&1 | tail -80 > gpurun_out/${TAG}_pytest.log; tail -8 gpurun_out/${TAG}_pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/${TAG}_smoke.log
@@ -19,7 +19,8 @@ PY
 rm -rf $R/gpurun_out/prof_$TAG
 cd $R
 # the N > 1 code path of the bench on one device (gloo, both ranks on GPU 0): launcher, slab sharding, the counter all-reduce, the line
-timeout 300 python bench.py --gpus 2 --backend gloo --force-device 0 --steps 10 --windows 5 --pmc off > gpurun_out/${TAG}_bench_n2_dryrun.json 2> gpurun_out/${TAG}_bench_n2_dryrun.err; tail -c 400 gpurun_out/${TAG}_bench_n2_dryrun.json
+# (round 6: the alive totals go through the product's own collective - hnb_comm_create_rank + hnb_comm_allreduce_alive; two ranks on ONE device need the stand-in library, the real librccl refuses a device twice)
+timeout 300 python bench.py --gpus 2 --backend gloo --force-device 0 --comm-lib tests/fake_rccl/libfake_rccl.so --steps 10 --windows 5 --pmc off > gpurun_out/${TAG}_bench_n2_dryrun.json 2> gpurun_out/${TAG}_bench_n2_dryrun.err; tail -c 400 gpurun_out/${TAG}_bench_n2_dryrun.json
 [ -z "$FULL" ] && exit 0   # (FULL=1: + fuzz, SQ counters, instruction-cache counters)
 # a short differential fuzz of the build against the oracle (random assets specialised / typed / in scenes of 8 interpreted)
 L=gpurun_out/${TAG}_fuzz.log; : > $L
@@ -27,9 +28,14 @@ timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 1 --seeds 7000:7100 2
 timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 1 --typed --seeds 7400:7480 2>&1 | tail -2 >> $L
 timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 1 --capacity 9000 --frames 40 --seeds 7600:7640 2>&1 | tail -2 >> $L
 timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 0 --scene 8 --seeds 9000:9160 2>&1 | tail -2 >> $L
+# (round 6) ... and every eligible random program with EVERY init pass slot-major (HNB_OPT_SLOT_INIT = 2: k_spawn_mark + k_init_slots), specialised and interpreted
+echo "HNB_CTX_OPTIONS=slot_init=2:" >> $L
+HNB_CTX_OPTIONS=slot_init=2 timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 1 --seeds 12000:12100 2>&1 | tail -2 >> $L
+HNB_CTX_OPTIONS=slot_init=2 timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 1 --capacity 9000 --frames 40 --seeds 12600:12640 2>&1 | tail -2 >> $L
+HNB_CTX_OPTIONS=slot_init=2 timeout 300 python tests/fuzz_sweep.py --backend gpu --jit 0 --seeds 12800:12860 2>&1 | tail -2 >> $L
 cat $L
 # SQ counters of the init / update kernels (is a kernel bound by VALU issue, memory, or instruction issue?) and what the instruction cache says about the churn init
-bash tools/valu_pmc.sh 2>&1 | tail -24 > gpurun_out/${TAG}_valu_counters.txt; tail -6 gpurun_out/${TAG}_valu_counters.txt
+bash tools/valu_pmc.sh 2>&1 | tail -28 > gpurun_out/${TAG}_valu_counters.txt; tail -6 gpurun_out/${TAG}_valu_counters.txt
 export TMPDIR=/tmp; cd /tmp
 rocprofv3 -L 2>/dev/null | grep -i -E "icache|ifetch|SQC_" | head -40 > $R/gpurun_out/${TAG}_counter_names.txt
 timeout 200 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAVES --output-format csv -d $R/gpurun_out/icache_$TAG -- python $R/bench.py --config c2_mixed --no-cpu-baseline --no-extra-configs --no-parity --pmc off --no-scene --no-comm --steps 10 --windows 3 --full-json /tmp/y.json > $R/gpurun_out/${TAG}_icache.log 2>&1
