@@ -25,8 +25,8 @@ Configurations (synthetic scalings of the reference's example as
   c2_events                   the REAL examples/firework.rs at scale: three linked effects - rockets whose update emits GPU spawn
                               events, a sparkle trail (5 events per rocket and frame) and the trails (1000 events per dying rocket,
                               capacity 16,777,216) - in steady state, event buffers sized for it;
-  c2_interop                  c2 with HNB_OPT_AGE_COHORT off: the AGE plane is kept up to date for a renderer that reads it
-                              (ColorOverLifetime / SizeOverLifetime, src/modifier/output.rs:310-312);
+  c2_interop                  c2 with HNB_AGE_COHORT_OFF: per-particle ages in the plane (what AUTO gives effects below 65,536 slots);
+  c2_view                     c2 + a stand-in renderer (a consumer kernel through hnb_effect_device_view) behind every frame, reported apart;
   c3                          examples/force_field.rs, capacity 8,388,608 per GPU, burst, capacity slabs;
   c4                          examples/instancing.rs: independent instances x 65,536, sharded BY INSTANCE
                               (sharding.instance_plan: instance i on rank i mod N); 512 instances per GPU, i.e. BASELINE's
@@ -62,7 +62,9 @@ gpurun_out/bench_full.json when that directory exists) and to stderr.
 
 N > 1: `python bench.py --gpus N` launches itself under `python -m torch.distributed.run` (one process per GPU, RCCL); when the
 driver already started it that way (WORLD_SIZE in the environment) it just runs its rank. There is no data-path collective: the
-only collective is the all-reduce of the alive-particle counters for reporting (plus the MAX of the elapsed times). The JSON
+only collective is the all-reduce of the alive-particle counters for reporting - through the product's own communicator (rank 0 takes an id from
+hnb_comm_unique_id, it travels over the torch process group, every rank calls hnb_comm_create_rank; hnb_comm_allreduce_alive = one grouped
+ncclAllReduce of librccl on the simulation stream) - plus the MAX of the elapsed times (torch.distributed). The JSON
 line is the weak-scaling run (per-GPU work fixed); with N > 1 a strong-scaling run (the N = 1 workload split over the ranks) is
 reported inside it under "strong".
 """
@@ -1258,7 +1260,7 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-configs", default="c2", help=argparse.SUPPRESS)
     ap.add_argument("--launcher", choices=["ranks", "threads"], default="ranks",
-                    help="N > 1: ranks = one process per GPU (torch.distributed.run, RCCL through torch); threads = ONE process, one HnbContext and one "
+                    help="N > 1: ranks = one process per GPU (torch.distributed.run; alive totals through hnb_comm_create_rank); threads = ONE process, one HnbContext and one "
                          "submit thread per GPU (examples/multi_gpu.c: C99 over the C ABI, RCCL through hnb_comm_*), c2 / c3 only")
     ap.add_argument("--no-comm", dest="comm", action="store_false", default=True,
                     help="N = 1: do not take the headline's alive total through hnb_comm_allreduce_alive (a one-rank communicator of the real librccl)")
