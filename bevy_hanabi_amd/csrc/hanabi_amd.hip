@@ -59,6 +59,10 @@ struct TimingPair { hipEvent_t a, b; const HnbProgram* prog; };
 constexpr uint32_t kFrameRing = 4;
 constexpr uint32_t kSceneMaxChunks = 16;       // a program is "small" this frame: <= 65,536 slots over all of its instances ...
 constexpr uint32_t kSceneMaxInitBlocks = 64;   // ... and <= 16,384 spawns (hnb_simulate: merged launches)
+#ifndef HNB_GENERIC_SPLIT_MAX
+#define HNB_GENERIC_SPLIT_MAX 128
+#endif
+constexpr uint32_t kGenericSplitMaxChunks = HNB_GENERIC_SPLIT_MAX;  // a generic-update program of up to this many chunks (524,288 slots) launches one workgroup per 256 slots: 2048 workgroups, one round on 256 CUs
 constexpr uint32_t kSceneMaxCodeLen = 64;      // ... and a pass of at most this many instructions: the merged launches INTERPRET, and one long program (the
                                                // lightning bolt's 510-instruction init: 43 us interpreted, 5 us specialised) would set the latency of all
 
@@ -2092,13 +2096,16 @@ static int enqueue_program_update(HnbContext* ctx, HnbProgram* p, hipStream_t st
         } else {
             p->stream_launch(total_chunks, st, sa, p->d_inst_base, dfi, dub, cb);
         }
-    } else if (p->jit_update) {
-        uint32_t dm = write_died;
-        void* ka[] = {&p->dev, &p->d_inst_base, &dfi, &dub, &cb, &dm};
-        HIP_TRY(hipModuleLaunchKernel(p->jit_update, total_chunks, 1, 1, kBlock, 1, 1, 0, st, ka, nullptr));
     } else {
-        if (p->wide_file) k_update_slots_generic<InterpCodeWide><<<total_chunks, kBlock, 0, st>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
-        else k_update_slots_generic<InterpCode><<<total_chunks, kBlock, 0, st>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died);
+        // a generic program of a few chunks: one workgroup per 256 slots (k_update_slots_generic's `split`), while the grid still fits the GPU at once
+        uint32_t split = total_chunks <= kGenericSplitMaxChunks ? 1u : 0u;
+        const uint32_t grid = split ? total_chunks * (kChunk / kBlock) : total_chunks;
+        if (p->jit_update) {
+            uint32_t dm = write_died;
+            void* ka[] = {&p->dev, &p->d_inst_base, &dfi, &dub, &cb, &dm, &split};
+            HIP_TRY(hipModuleLaunchKernel(p->jit_update, grid, 1, 1, kBlock, 1, 1, 0, st, ka, nullptr));
+        } else if (p->wide_file) k_update_slots_generic<InterpCodeWide><<<grid, kBlock, 0, st>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died, split);
+        else k_update_slots_generic<InterpCode><<<grid, kBlock, 0, st>>>(p->dev, p->d_inst_base, dfi, dub, cb, write_died, split);
     }
     if (timed) { hipEventRecord(tu.b, st); ctx->t_update.push_back(tu); }
     const CompactArgs ca = compact_args_of(p);

@@ -1765,11 +1765,17 @@ __device__ __forceinline__ void update_generic_chunk(const DevProgram& prog, con
     }
 }
 
+// split != 0 (r6): one workgroup per 256 slots instead of per 4096-slot chunk (the grid is 16 x the chunks), as the merged launches do it. A program of a few
+// chunks is a few workgroups walking 16 groups of 256 slots one after the other - 16 dependent load / run / store rounds: the rocket effect of firework.rs,
+// 8 chunks, took 33-70 us per update. The host splits where the whole grid still fits the GPU at once (hanabi_amd.hip: kGenericSplitMaxChunks).
 template <class CODE>
 __global__ void __launch_bounds__(kBlock)
 k_update_slots_generic(const DevProgram prog, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
-                       const uint32_t* __restrict__ ublocks, const CompactBufs cb, const uint32_t write_died) {
-    update_generic_chunk<CODE>(prog, inst_base, fi, ublocks, cb, write_died, blockIdx.x, gridDim.x);
+                       const uint32_t* __restrict__ ublocks, const CompactBufs cb, const uint32_t write_died, const uint32_t split) {
+    if (split) {
+        const uint32_t w = blockIdx.x / (kChunk / kBlock), sub = blockIdx.x % (kChunk / kBlock);
+        update_generic_chunk<CODE>(prog, inst_base, fi, ublocks, cb, write_died, w, gridDim.x / (kChunk / kBlock), sub, sub + 1u);
+    } else update_generic_chunk<CODE>(prog, inst_base, fi, ublocks, cb, write_died, blockIdx.x, gridDim.x);
 }
 
 #ifndef HNB_JIT_TU

@@ -445,6 +445,25 @@ def test_slot_order_firework_life_cycle(slot_ctx):
     g.prog.destroy()
 
 
+def test_slot_order_with_large_spawns_slot_major(slot_ctx):
+    """HNB_LIST_ORDER_SLOT and the slot-major init together (round 6): the dead list holds the free slots ascending, the lists are rebuilt from the alive
+    bytes after every frame - the marks of a partial re-fill (alive byte 2) must all have become particles before that rebuild counts bytes."""
+    cap = 120_011      # 30 chunks
+    asset = effects.firework_trails(cap)
+    g, o = GpuRunner(asset, ctx=slot_ctx), _slot_oracle(asset, omp=True)
+    t = 0.0
+    for f, (dt, spawn) in enumerate([(1 / 60, cap), (0.3, 0), (0.3, 0), (0.3, 0), (1 / 60, cap // 4), (0.3, 1000), (1 / 60, cap), (0.5, 0), (0.5, cap // 3), (1 / 60, cap - 7)]):
+        fr = Frame(dt, spawn, frame_seed(f), time=t)
+        t += dt
+        g.step(fr)
+        o.step(fr)
+        assert_same_state(o.state(), g.state(), f"slot order, frame {f}")
+        alive = g.fx.alive_list().astype(np.int64)
+        assert len(alive) < 2 or (np.diff(alive) > 0).all()
+    assert _slot_init_frames(g.prog) == 5, g.prog.kernel_info()
+    g.prog.destroy()
+
+
 def test_slot_order_churn_batch(slot_ctx):
     """Steady spawn/kill churn over a batch of instances: slots are recycled last-killed-first, the list stays sorted."""
     cap, n_inst = 9000, 4
