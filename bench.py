@@ -296,7 +296,14 @@ def cpu_baseline(capacity, frames=60, check_frames=2):
     # worth of time on a 2 x 64-core host: 64 threads then run at a quarter speed each, which is why more threads stopped helping in every earlier round)
     quota = limits.get("cgroup_cpu_quota")
     cores = int(min(threads, quota)) if quota else threads
-    return {"value": tried[threads], "unit": "particle-updates/s", "cores": cores, "threads": threads, "host_logical_cpus": hw,
+    pool = None
+    try:   # the same measurement on other boxes of the pool (committed records): this one is a sample of a 5x spread, not a constant of the machine type
+        with open(os.path.join(ROOT, "profiles", "cpu_baseline_boxes.json")) as f:
+            vals = [r["value"] for r in json.load(f)["records"]] + [tried[threads]]
+        pool = {"best": max(vals), "worst": min(vals), "boxes": len(vals), "source": "profiles/cpu_baseline_boxes.json + this run"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"value": tried[threads], "unit": "particle-updates/s", "cores": cores, "threads": threads, "host_logical_cpus": hw, "pool": pool,
             "host_physical_cores": host_physical_cores(), "kind": "port",
             "algorithmic_gbs": tried[threads] * CONFIGS["c2"]["bytes_per_update"] / 1e9, "bytes_per_update": CONFIGS["c2"]["bytes_per_update"],
             "threads_tried": {str(k): v for k, v in tried.items()}, "limits": limits,
@@ -1463,7 +1470,7 @@ def short_line(full, args):
     cb = full.get("cpu_baseline")
     if cb:
         short["cpu_baseline"] = cb if "error" in cb else {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "threads": cb["threads"], "host_physical_cores": cb.get("host_physical_cores"),
-                                                          "cpu_model": cpu_model(), "cpu_quota": (cb.get("limits") or {}).get("cgroup_cpu_quota"), "kind": cb["kind"], "sample": cb["sample"][:56]}
+                                                          "cpu_model": cpu_model(), "cpu_quota": (cb.get("limits") or {}).get("cgroup_cpu_quota"), "pool_best": _r((cb.get("pool") or {}).get("best")), "pool_worst": _r((cb.get("pool") or {}).get("worst")), "kind": cb["kind"], "sample": cb["sample"][:24]}
     short["parity"] = parity
     if full.get("comm"):   # (N = 1: the alive total went through hnb_comm_allreduce_alive over a one-rank communicator of the real librccl)
         short["comm"] = {k: v for k, v in full["comm"].items() if k != "effects"}
