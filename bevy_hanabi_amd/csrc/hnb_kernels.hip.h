@@ -1588,7 +1588,105 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         if (args.write_died) store_died_bits(reinterpret_cast<uint32_t*>(base + args.died_bits_off), step_first, nib, lane);
         died_total += died_here;
     };
-    if (!flat) {
+    // ---- the age-only path (r6): an update that is ONE AGE_TICK (ribbon.rs, lightning.rs: trails that do not move; PROG::kAgeOnly) reads and writes a single
+    // scalar plane, and the per-particle path above costs it 675 VALU + 508 SALU instructions per wave of 1024 slots for `age += dt; alive = age < lifetime`
+    // (C5: 19 us for 37 MB where a plain kernel moves as much in 5, profiles/r06n_c5_counters.log, r06o_dispatch_probe.log): a frame of three dependent launches
+    // IS that chain. Here the wave requests everything it can need at once - the alive bytes (also of chunks flagged completely alive: one byte per slot buys a
+    // round trip), the ages of its four steps -, decides per step from the chunk's lifetime bound whether anybody can die (only then the lifetimes are loaded
+    // and the death bookkeeping runs), and accumulates its counters per lane (one reduction per wave, in the shared epilogue). Same protocol, same results
+    // bit for bit as the general path, which the parity gate's plain replay (lifetime culling off) keeps running beside it.
+    bool lean_done = false;
+    if constexpr (PROG::kAgeOnly && PROG::kLen == 1u && !COHORT && PROBE == 0) {
+        if (cull && (fl & 0xffu) == (4u | 8u | 64u)) {
+            lean_done = true;
+            constexpr uint32_t kSteps = kWaveRows / kStepRows;
+            const uint32_t wave0 = j * kChunk + wave * kWaveRows;
+            uint32_t* died_bits = reinterpret_cast<uint32_t*>(base + args.died_bits_off);
+            uint32_t f4s[kSteps];
+            u4v ages[kSteps];
+#pragma unroll
+            for (uint32_t step = 0; step < kSteps; ++step) {
+                const uint32_t s0 = wave0 + step * kStepRows + lane * 4u;
+                const bool in = s0 < args.capacity;   // (planes are padded to 256 B: a quad never straddles the end; slots past the capacity read 0)
+                const uint32_t ld = in ? ld_hint(flags4 + (s0 >> 2), args.stream_hint != 0u) : 0u;
+                f4s[step] = chunk_full ? 0x01010101u : ld;
+                ages[step] = in ? reinterpret_cast<const u4v*>(p_age)[s0 >> 2] : u4v{0u, 0u, 0u, 0u};
+            }
+            const bool bound_known = Lm > 0.0f;
+            float an[kSteps][4];
+            uint32_t need_mask = 0u;   // wave-uniform: steps in which somebody may die (or the bound is unknown): they load the lifetimes
+#pragma unroll
+            for (uint32_t step = 0; step < kSteps; ++step) {
+                const uint32_t w = f4s[step];
+                const uint32_t a4[4] = {ages[step].x, ages[step].y, ages[step].z, ages[step].w};
+                bool may = false;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    an[step][p] = u2f(a4[p]) + dt_tick;                                  // mac_age_tick's arithmetic
+                    const bool was = ((w >> (8 * p)) & 0xffu) == 1u;
+                    may = may || (was && !(bound_known && an[step][p] < Lm));
+                }
+                if (__any(may)) need_mask |= 1u << step;
+            }
+            u4v life[kSteps];
+#pragma unroll
+            for (uint32_t step = 0; step < kSteps; ++step) {
+                life[step] = u4v{0u, 0u, 0u, 0u};
+                if ((need_mask >> step) & 1u) {
+                    const uint32_t s0 = wave0 + step * kStepRows + lane * 4u;
+                    if (f4s[step] != 0u) {   // (lanes whose quad holds a live particle: what the general path loads)
+                        const u4v* pl = reinterpret_cast<const u4v*>(p_life) + (s0 >> 2);
+                        life[step] = args.stream_hint ? __builtin_nontemporal_load(pl) : *pl;
+                    }
+                }
+            }
+            uint32_t lane_died = 0u;
+#pragma unroll
+            for (uint32_t step = 0; step < kSteps; ++step) {
+                const uint32_t w = f4s[step];
+                const uint32_t step_first = wave0 + step * kStepRows;
+                const uint32_t s0 = step_first + lane * 4u;
+                const bool any = w != 0u;                        // (bytes are 0 or 1 here: no cohorts, and no mark outlives the init pass)
+                if (!chunk_full) lane_alive += (uint32_t)__popc(w & 0x01010101u);
+                if (!__any(any)) {
+                    if (args.write_died) store_died_bits(died_bits, step_first, 0u, lane);
+                    continue;
+                }
+                const bool need = ((need_mask >> step) & 1u) != 0u;   // wave-uniform
+                if (!need) loaded_all = false;
+                const uint32_t a4[4] = {ages[step].x, ages[step].y, ages[step].z, ages[step].w};
+                const uint32_t l4[4] = {life[step].x, life[step].y, life[step].z, life[step].w};
+                uint32_t q[4], nib = 0u, nf = w;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bool was = ((w >> (8 * p)) & 0xffu) == 1u;
+                    const float lf = need ? u2f(l4[p]) : Lm;
+                    const bool stays = was && an[step][p] < lf;   // (without the lifetimes: age + dt < Lm <= lifetime holds for every live slot of the step)
+                    q[p] = was ? f2u(an[step][p]) : a4[p];        // free slots get their own bytes back: one 16-byte store
+                    if (was && !stays) { nib |= 1u << p; nf &= ~(0xffu << (8 * p)); }
+                    if (stays) {
+                        if (need) wave_min = fminf(wave_min, lf);
+                        if (args.safe_words) rem_min = fminf(rem_min, (lf - an[step][p]) - 1.0e-5f * lf);
+                    }
+                }
+                if (any) {
+                    u4v* pa = reinterpret_cast<u4v*>(p_age) + (s0 >> 2);
+                    // (always nontemporal: nobody reads the ages again before the next frame's walk, and the plain store cost the C5 frame 0.0323 against
+                    // 0.0309 ms in three rounds on one box, profiles/r06r_ab_lean_nt.log)
+                    __builtin_nontemporal_store((u4v{q[0], q[1], q[2], q[3]}), pa);
+                }
+                if (need) {
+                    lane_died += (uint32_t)__popc(nib);
+                    if (nf != w) flags4[s0 >> 2] = nf;            // the slot is free from now on; the lists learn it from the died bit
+                }
+                if (args.write_died) store_died_bits(died_bits, step_first, nib, lane);
+            }
+#pragma unroll
+            for (uint32_t off = 32; off > 0; off >>= 1) lane_died += __shfl_xor(lane_died, off, 64);
+            died_total = lane_died;   // (wave-uniform from here on, as the epilogue expects)
+        }
+    }
+    if (!flat && !lean_done) {
         // the alive bytes of the wave's four steps, requested together (a step's own load would wait behind the previous step's stores to the
         // same plane: two dependent round trips per step)
         // (the cohort instantiations, budgeted for 4 waves, and the component-wise programs have the registers for it: -1 % on the churn
