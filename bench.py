@@ -623,7 +623,7 @@ def parity_burst_slab(w, D):
 # every proof, hint and shortcut hnb_ctx_set_option can switch off: what is left is one init, one update, k_count_rows + k_compact per
 # program and frame, per-particle ages and lifetimes, direct spawn stores, one stream
 PLAIN_OPTIONS = {"horizon": 0, "age_cohort": 0, "cull_lifetime": 0, "skip_lists": 0, "stream_hints": 0, "overlap_updates": 0,
-                 "suffix_proof": 0, "ring_lists": 0, "alternate": 0, "transpose": 0, "scene_merge": 0, "slot_init": 0}
+                 "suffix_proof": 0, "ring_lists": 0, "alternate": 0, "transpose": 0, "scene_merge": 0, "slot_init": 0, "direct_upload": 0}
 
 
 def parity_timed_state(w, args, D, options=None):

@@ -86,6 +86,17 @@ void launch_stream(uint32_t grid, hipStream_t stream, const SlotArgs& sa, const 
 }
 #define OP_(x) (uint32_t)HNB_OP_M_##x
 typedef ProgStatic<OP_(AGE_TICK)> ProgAge;                                                        // ribbon.rs
+#ifndef HNB_AGE_KERNEL
+#define HNB_AGE_KERNEL 1
+#endif
+// The update that is one AGE_TICK has a kernel of its own (k_update_slots_stream_age) for the case it is written for - lifetime culling, no cohorts, AGE
+// loaded and stored, LIFETIME loaded -; every other combination (culling off: the parity gate's plain replay) runs the general instantiation.
+void launch_stream_age(uint32_t grid, hipStream_t stream, const SlotArgs& sa, const uint64_t* inst_base, const DevFrameInst* fi,
+                       const uint32_t* ublocks, const CompactBufs& cb) {
+    if (HNB_AGE_KERNEL && !sa.age_cohort && sa.cull_lifetime && (sa.flags & 0xffu) == (4u | 8u | 64u))
+        k_update_slots_stream_age<<<grid, kBlock, 0, stream>>>(sa, inst_base, fi, ublocks, cb);
+    else launch_stream<ProgAge, 4>(grid, stream, sa, inst_base, fi, ublocks, cb);
+}
 typedef ProgStatic<OP_(AGE_TICK), OP_(EULER)> ProgAgeEuler;                                       // instancing.rs
 typedef ProgStatic<OP_(AGE_TICK), OP_(VEL_ADD), OP_(EULER)> ProgAccel;                            // AccelModifier stacks
 typedef ProgStatic<OP_(AGE_TICK), OP_(VEL_SCALE), OP_(EULER)> ProgDrag;
@@ -102,7 +113,7 @@ typedef ProgStatic<OP_(AGE_TICK), OP_(CONFORM_SPHERE), OP_(CONFORM_SPHERE), OP_(
 void select_stream_kernel(const Ins* code, uint32_t n, StreamLaunchFn* fn, const char** name) {
 #define TRY_(PROG, WAVES) if (PROG::matches(code, n)) { *fn = &launch_stream<PROG, WAVES>; *name = #PROG; return; }
     TRY_(ProgNone, HNB_STREAM_WAVES)
-    TRY_(ProgAge, 4)   // (the age prefetch of update_stream_chunk: 16 more registers, and one scalar plane never needs more than four waves per SIMD)
+    if (ProgAge::matches(code, n)) { *fn = &launch_stream_age; *name = "ProgAge"; return; }   // (its general instantiation: four waves per SIMD - the age prefetch of update_stream_chunk takes 16 more registers, and one scalar plane never needs more)
     TRY_(ProgAgeEuler, HNB_STREAM_WAVES)
     TRY_(ProgAccel, HNB_STREAM_WAVES)
     TRY_(ProgDrag, HNB_STREAM_WAVES)
@@ -174,6 +185,18 @@ struct HnbContext {
     void* h_stage[kFrameRing] = {};
     void* d_stage[kFrameRing] = {};
     size_t stage_bytes = 0;
+    // How a slot reaches the device (r6, HNB_OPT_DIRECT_UPLOAD): until round 6 hipMemcpyAsync on the upload stream and the HOST waiting for it - 10 us of every
+    // frame's submission, and the submission of a small frame (C5, a scene of small effects) is as long as its kernels: such a frame was bound by both at
+    // once, which is why neither a shorter kernel nor any of rounds 5 / 6's upload experiments (copy on the simulation stream, the stream waiting for the
+    // copy's event, kernels reading the pinned block, a copy kernel) moved it. Now, where the device's memory is host-visible (a large PCIe BAR), the slots
+    // are FINE-GRAINED device memory and the host writes the block into them itself - the way the runtime places kernel arguments: posted writes,
+    // ordered in front of the launch's doorbell by a store fence - no copy, no wait, no extra launch. tools/probes/upload_probe.hip: a frame of three
+    // dependent launches 20.8 us with copy + wait, 17.3 with an event wait on the stream, 13.8 reading pinned memory, 11.1 this way (profiles/r06w_upload_probe.log).
+    bool large_bar = false;               // hipDeviceProp_t::isLargeBar
+    bool direct_upload = true;            // HNB_OPT_DIRECT_UPLOAD
+    bool stage_direct = false;            // the slots that exist now are host-written fine-grained device memory
+    bool direct_failed = false;           // the allocation or its self-test failed once: copies from then on
+    uint64_t direct_frames = 0, copied_frames = 0;   // statistics (hnb_ctx_describe_upload)
     hipEvent_t stage_done[kFrameRing] = {};  // recorded on the simulation stream after the frame that used the slot
     uint32_t num_cus = 256;
     std::vector<HnbProgram*> programs;
@@ -939,7 +962,10 @@ int hnb_ctx_create(int device_id, HnbContext** out_ctx) {
         ctx->overlap_updates = false;   // (the frame then runs on one stream, as it did before round 4)
     }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        if (prop.multiProcessorCount > 0) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
+        ctx->large_bar = prop.isLargeBar != 0;
+    }
     *out_ctx = ctx;
     return HNB_OK;
 }
@@ -1011,6 +1037,7 @@ int hnb_ctx_set_option(HnbContext* ctx, uint32_t option, uint32_t value) {
             ctx->slot_init = value;
             return HNB_OK;
         case HNB_OPT_STREAM_HINTS: ctx->stream_hints = value != 0u; return HNB_OK;
+        case HNB_OPT_DIRECT_UPLOAD: ctx->direct_upload = value != 0u; return HNB_OK;   // (ensure_stage re-creates the slots of the other kind before the next frame)
         case HNB_OPT_JIT_ASYNC: ctx->jit_async = value != 0u; return HNB_OK;
         case HNB_OPT_SET_MODULE:
             if (value > HNB_SET_MODULE_BACKGROUND) return fail(HNB_ERR_INVALID_ARG, "unknown set-module mode %u", value);
@@ -1610,6 +1637,15 @@ static const HnbProgram* pick_heavy_program(const HnbContext* ctx, const std::ve
     return (best_chunks >= kOverlapMinChunks && best_chunks >= 4u * others) ? best : nullptr;   // ... and at least 4x the rest together
 }
 
+// The host writes `n` bytes into host-visible device memory (HnbContext::stage_direct). The mapping is write-combining: the store fence drains the
+// combining buffers, so that the writes are posted in front of whatever the caller does next - the doorbell of the frame's first launch.
+static void direct_write(void* dst, const void* src, size_t n) {
+    memcpy(dst, src, n);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_ia32_sfence();
+#endif
+}
+
 // (1) The per-frame parameters of every program are filled into the context's next ring slot and uploaded on the upload stream. The host
 // waits for the (tiny) copy itself, so the simulation stream carries no cross-stream wait: such a wait costs an ~11 us bubble in front
 // of every frame's first kernel (measured), the host has ~200 us of slack per frame.
@@ -1618,21 +1654,38 @@ static int ensure_stage(HnbContext* ctx, const std::vector<HnbProgram*>& order, 
     for (const HnbProgram* p : order) need += (frame_bytes_for(p, (uint32_t)p->effects.size()) + 255u) & ~(size_t)255u;
     need += order.size() * sizeof(ListsJob) + 256u;   // the job table of the multi-program list launches
     need += order.size() * (2u * sizeof(ProgJob) + sizeof(StreamJob)) + 6u * 256u;   // ... and of the merged init / update launches of small programs
-    if (need > ctx->stage_bytes) {  // grows rarely (a new program, more instances): nothing may still be reading the old buffers
+    const bool want_direct = ctx->direct_upload && ctx->large_bar && !ctx->direct_failed;
+    if (need > ctx->stage_bytes || (ctx->stage_bytes && want_direct != ctx->stage_direct)) {  // grows rarely (a new program, more instances): nothing may still be reading the old buffers
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        const size_t nb = std::max<size_t>(2 * need, 64u << 10);
+        const size_t nb = std::max<size_t>(std::max<size_t>(2 * need, ctx->stage_bytes), 64u << 10);
         for (uint32_t i = 0; i < kFrameRing; ++i) {
             hipFree(ctx->d_stage[i]); ctx->d_stage[i] = nullptr;
             if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
             ctx->h_stage[i] = nullptr;
         }
         ctx->stage_bytes = 0;
+        ctx->stage_direct = false;
+        bool direct = want_direct;
+        for (uint32_t i = 0; i < kFrameRing && direct; ++i) {
+            // fine-grained device memory: host-visible through the BAR, coherent for the kernels that read it. Checked once per slot: what the host writes
+            // must be what a device-side copy reads back (a device that reports a large BAR without honouring it would fault or differ here, not in a frame)
+            if (hipExtMallocWithFlags(&ctx->d_stage[i], nb, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); ctx->d_stage[i] = nullptr; direct = false; break; }
+            uint64_t probe[8], back[8] = {};
+            for (int q = 0; q < 8; ++q) probe[q] = 0x9e3779b97f4a7c15ull * (uint64_t)(q + 1 + (int)i);
+            direct_write(ctx->d_stage[i], probe, sizeof probe);
+            if (hipMemcpy(back, ctx->d_stage[i], sizeof back, hipMemcpyDeviceToHost) != hipSuccess || memcmp(back, probe, sizeof probe) != 0) { (void)hipGetLastError(); direct = false; }
+        }
+        if (want_direct && !direct) {   // not on this device after all: ordinary slots, copies (never tried again in this context)
+            ctx->direct_failed = true;
+            for (uint32_t i = 0; i < kFrameRing; ++i) { hipFree(ctx->d_stage[i]); ctx->d_stage[i] = nullptr; }
+        }
         for (uint32_t i = 0; i < kFrameRing; ++i) {
-            HIP_TRY(hipMalloc(&ctx->d_stage[i], nb));
+            if (!direct) HIP_TRY(hipMalloc(&ctx->d_stage[i], nb));
             HIP_TRY(hipHostMalloc(&ctx->h_stage[i], nb, hipHostMallocDefault));
             if (!ctx->stage_done[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
         }
         ctx->stage_bytes = nb;
+        ctx->stage_direct = direct;
     }
     if (!order.empty()) HIP_TRY(hipEventSynchronize(ctx->stage_done[slot]));  // the frame that last used this slot (kFrameRing frames ago)
     return HNB_OK;
@@ -2214,8 +2267,15 @@ int hnb_simulate(HnbContext* ctx) {
         // the host never waits. Slower everywhere as well: C5 0.0374 -> 0.0380 ms, c2 0.139 -> 0.142, the scene 0.051 -> 0.053, time inside hnb_simulate unchanged:
         // the frame of a small effect is bound by its CHAIN of dependent launches on the device - the host only blocks on the staging ring - and the copy kernel
         // is one more link of it: profiles/r06c_ab_stage_kernel.log, r06c_stage_kernel.patch.)
-        HIP_TRY(hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], stage_off, hipMemcpyHostToDevice, ctx->upload_stream));
-        HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
+        // (Round 6, what did work: no copy - HnbContext::stage_direct. The slot's previous readers are done: ensure_stage waited for the frame that last used it.)
+        if (ctx->stage_direct) {
+            direct_write(ctx->d_stage[slot], ctx->h_stage[slot], stage_off);
+            ctx->direct_frames += 1;
+        } else {
+            HIP_TRY(hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], stage_off, hipMemcpyHostToDevice, ctx->upload_stream));
+            HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
+            ctx->copied_frames += 1;
+        }
     }
     rc = enqueue_init_passes(ctx, order, fj, timed);
     if (rc == HNB_OK) rc = enqueue_update_passes(ctx, order, fj, timed);
@@ -2581,6 +2641,8 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
     if (prog->ctx->set_failed_builds && !prog->set_sig.empty()) s += "\nset module builds that failed: " + std::to_string(prog->ctx->set_failed_builds);
     if (prog->horizon_eligible) s += "\ndeath horizons in use: " + std::to_string(prog->hz_frames) + " frames";
     s += "\nlists skipped: " + std::to_string(prog->skipped_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->skip_facts.eligible ? "" : " (not eligible)");
+    s += "\nframe parameters (context): written by the host into device memory in " + std::to_string(prog->ctx->direct_frames) + " frames, copied in " + std::to_string(prog->ctx->copied_frames) +
+         (prog->ctx->large_bar ? "" : " (the device memory is not host-visible: no large BAR)") + (prog->ctx->direct_failed ? " (host-visible slots failed their check)" : "");
     snprintf(buf, buf_size, "%s", s.c_str());
     return HNB_OK;
 }

@@ -1333,7 +1333,12 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
     // Same-box A/B (profiles/r04o_ab_walk.log, r04p_ab_walk2.log): c2_mixed 0.327 -> 0.316 ms, c2_events 0.456 -> 0.438; C3 - 8.4M particles,
     // 235 MB of written planes: they FIT the cache and the next frame's walk finds them there - 0.097 -> 0.120 ms with the hint, hence the size rule.
     const bool store_nt = args.store_hint != 0u;
-    if (args.safe_words && chunk == 0u) {  // publish the previous frame's bound: its kernel has completed, every chunk's word is final
+#ifndef HNB_PUBLISH_FIRST_WG
+#define HNB_PUBLISH_FIRST_WG 1
+#endif
+    // (r6: the FIRST workgroup of the launch publishes, not chunk 0: in a frame that walks downwards chunk 0 is the last workgroup dispatched, and its
+    // store to host memory behind two barriers in front of its own chunk was the tail of the kernel)
+    if (args.safe_words && (HNB_PUBLISH_FIRST_WG ? wg == 0u : chunk == 0u)) {  // publish the previous frame's bound: its kernel has completed, every chunk's word is final
         const uint32_t* prev = args.safe_words + (size_t)(args.safe_parity ^ 1u) * args.safe_stride;
         uint32_t m = 0x7f800000u;
         for (uint32_t i = tid; i < wg_total; i += kBlock) { const uint32_t v = prev[i]; m = v < m ? v : m; }
@@ -1794,6 +1799,219 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
                       const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
     update_stream_chunk<PROG, PROBE, COHORT>(args, inst_base, fi, ublocks, cb, blockIdx.x, gridDim.x);
 }
+
+#ifndef HNB_JIT_TU
+// ---- k_update_slots_stream_age (r6): the update that is ONE AGE_TICK, as a kernel of its own ------------------------------------------------------------
+// ribbon.rs, lightning.rs: trails that do not move. `age += dt; alive = age < lifetime` over one scalar plane is 9 bytes per particle, and a 4M-particle
+// trail (C5) is ONE round of 1024 workgroups: the kernel's duration is the life of a wave, and inside k_update_slots_stream<ProgAge> that was a chain of
+// dependent round trips in front of the first plane load (kernel arguments fetched in four places, the instance row, the chunk's flags, the tick) in a
+// 30 KB instantiation whose position / velocity paths (runtime flags) are dead weight - 17-19 us for 37 MB where a plain kernel moves as much in 5
+// (profiles/r06n_c5_counters.log, r06o_dispatch_probe.log). Same protocol, same results bit for bit as update_stream_chunk<ProgAge> under lifetime culling
+// without cohorts (launch_stream_age decides; the parity gate's plain replay - culling off - keeps running the general kernel beside it), but: everything
+// a wave can need is requested in ONE round behind the instance row (alive bytes - also of chunks flagged completely alive -, the ages of its four steps,
+// the chunk's bound and flag, the tick), the lifetimes only in steps where somebody may die, counters per lane, one reduction per wave.
+__global__ void __launch_bounds__(kBlock)
+k_update_slots_stream_age(const SlotArgs args, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
+                          const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
+    __shared__ uint32_t s_died[kBlock / 64], s_alive[kBlock / 64];
+    __shared__ float s_lmin[kBlock / 64], s_rem[kBlock / 64];
+    constexpr uint32_t kSteps = kWaveRows / kStepRows;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t wg = blockIdx.x, wg_total = gridDim.x;
+    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
+    const uint32_t k = chunk / args.chunks_per_inst, j = chunk - k * args.chunks_per_inst;
+    // round 1: the instance row
+    const uint32_t frozen = fi[k].skip;
+    char* base = global_ptr<char>(inst_base[k]);
+    const float dt_tick = u2f(ublocks[(size_t)k * args.n_uregs + (args.dt_operand & 0xffu)]);   // uf(U, dt_operand)
+    // round 2: everything the chunk can need
+    char* p_age = base + args.plane_off[2];
+    const char* p_life = base + args.plane_off[3];
+    uint32_t* flags4 = reinterpret_cast<uint32_t*>(base + args.alive_flag_off);
+    float* lmin = reinterpret_cast<float*>(base + args.lmin_off);
+    uint32_t* cfull = reinterpret_cast<uint32_t*>(lmin) + args.chunks_per_inst;
+    const uint32_t wave0 = j * kChunk + wave * kWaveRows;
+    uint32_t f4s[kSteps];
+    u4v ages[kSteps];
+#pragma unroll
+    for (uint32_t step = 0; step < kSteps; ++step) {
+        const uint32_t s0 = wave0 + step * kStepRows + lane * 4u;
+        const bool in = s0 < args.capacity;   // (planes are padded to 256 B: a quad never straddles the end; slots past the capacity read 0)
+        f4s[step] = in ? ld_hint(flags4 + (s0 >> 2), args.stream_hint != 0u) : 0u;
+        ages[step] = in ? reinterpret_cast<const u4v*>(p_age)[s0 >> 2] : u4v{0u, 0u, 0u, 0u};
+    }
+    const uint32_t cf = cfull[j];
+    const float Lm = lmin[j];                 // 0 (or anything not > 0): unknown, every step loads the lifetimes
+    if (args.safe_words && wg == 0u) {        // publish the previous frame's bound: its kernel has completed, every chunk's word is final
+        // (the FIRST workgroup of the launch, not chunk 0: in a frame that walks downwards chunk 0 is the last one dispatched, and the store to host memory
+        // behind two barriers was the tail of the kernel)
+        const uint32_t* prev = args.safe_words + (size_t)(args.safe_parity ^ 1u) * args.safe_stride;
+        uint32_t m = 0x7f800000u;
+        for (uint32_t i = tid; i < wg_total; i += kBlock) { const uint32_t v = prev[i]; m = v < m ? v : m; }
+#pragma unroll
+        for (uint32_t off = 32; off > 0; off >>= 1) { const uint32_t y = __shfl_xor(m, off, 64); m = y < m ? y : m; }
+        if (lane == 0) s_alive[wave] = m;
+        __syncthreads();
+        if (tid == 0u) {
+            for (uint32_t w = 1; w < kBlock / 64; ++w) m = s_alive[w] < m ? s_alive[w] : m;
+            *reinterpret_cast<volatile unsigned long long*>(args.safe_host) = ((unsigned long long)m << 32) | (unsigned long long)args.publish_tag;
+        }
+        __syncthreads();
+    }
+    if (args.skip_lists && j == 0u && tid == 0u) {  // counter rotation of a frame without spawn and casualty (k_compact's zero-casualty path)
+        DevMeta o = args.meta_in[k];
+        if (!frozen) {
+            o.ref_write_index ^= 1u;
+            o.max_update = o.alive_count; o.dead_count = 0u; o.spawned = 0u; o.instance_count = o.alive_count;
+        }
+        args.meta_out[k] = o;
+        cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + k] = 0u;
+    }
+    if (frozen) return;
+    if (args.horizon && j == 0u && tid == 0u) {       // the instance's clock: once per simulated frame
+        double* clk = horizon_view(base, args.horizon_off, args.chunks_per_inst).clock;
+        *clk = *clk + (double)(dt_tick > 0.0f ? dt_tick : 0.0f) * (1.0 + 0x1p-16);
+    }
+    const bool chunk_full = cf == 1u;
+    const bool bound_known = Lm > 0.0f;
+    uint32_t* died_bits = reinterpret_cast<uint32_t*>(base + args.died_bits_off);
+    float an[kSteps][4];
+    uint32_t need_mask = 0u;   // wave-uniform: steps in which somebody may die (or the bound is unknown): they load the lifetimes
+#pragma unroll
+    for (uint32_t step = 0; step < kSteps; ++step) {
+        if (chunk_full) f4s[step] = 0x01010101u;   // (what the flag promises; the bytes were requested anyway: they cost no round trip of their own)
+        const uint32_t w = f4s[step];
+        const uint32_t a4[4] = {ages[step].x, ages[step].y, ages[step].z, ages[step].w};
+        bool may = false;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            an[step][p] = u2f(a4[p]) + dt_tick;                                  // mac_age_tick's arithmetic
+            const bool was = ((w >> (8 * p)) & 0xffu) == 1u;
+            may = may || (was && !(bound_known && an[step][p] < Lm));
+        }
+        if (__any(may)) need_mask |= 1u << step;
+    }
+    // The lifetimes: for a wave with a step in which somebody may die, ALL of its steps' quads in one round, no lane-dependent branch around the loads (the
+    // first version loaded per step and lane under `if`, and the compiler waited for each load inside its branch: four dependent round trips in exactly the
+    // workgroups that are the kernel's tail - the dozen chunks the frame's spawns went to and the dozen its casualties come from)
+    u4v life[kSteps];
+#pragma unroll
+    for (uint32_t step = 0; step < kSteps; ++step) life[step] = u4v{0u, 0u, 0u, 0u};
+    if (need_mask != 0u) {   // wave-uniform
+#pragma unroll
+        for (uint32_t step = 0; step < kSteps; ++step) {
+            const uint32_t s0 = wave0 + step * kStepRows + lane * 4u;
+            const u4v* pl = reinterpret_cast<const u4v*>(p_life) + (s0 < args.capacity ? (s0 >> 2) : 0u);   // (a lane past the end reads quad 0: its value is not used)
+            life[step] = args.stream_hint ? __builtin_nontemporal_load(pl) : *pl;
+        }
+    }
+    uint32_t lane_died = 0u, lane_alive = 0u;
+    float wave_min = __builtin_inff();   // minimum lifetime of the particles that stay alive (steps that loaded them)
+    float rem_min = __builtin_inff();    // min over this lane's particles that stay alive of (lifetime - age) - 1e-5 * lifetime
+    float an_max = -__builtin_inff();    // ... of the steps that did not load the lifetimes: the largest new age (see below)
+    bool loaded_all = true;              // wave-uniform: every step with alive slots loaded the lifetimes
+    // Three kinds of step (wave-uniform), because four waves share a SIMD here and the 640 VALU instructions per wave of the first version were 4 us of the
+    // kernel's 12 (the bare access pattern: 5, tools/probes/age_stream_probe.hip): (A) nobody can die and every slot is alive - a trail in its steady state -:
+    // one add per slot; (B) nobody can die: the selects; (C) somebody may: the lifetimes, the death bookkeeping.
+#pragma unroll
+    for (uint32_t step = 0; step < kSteps; ++step) {
+        const uint32_t w = f4s[step];
+        const uint32_t step_first = wave0 + step * kStepRows;
+        const bool need_s = ((need_mask >> step) & 1u) != 0u;   // wave-uniform
+        if (!need_s) {
+            // nobody dies: age + dt < Lm <= lifetime for every live slot. The no-death bound's term (Lm - an) - 1e-5 Lm is a non-increasing function of an
+            // (two correctly rounded steps, each monotonic): its minimum over the slots is its value at the largest an - one max per slot here, the term once.
+            const uint32_t s0 = step_first + lane * 4u;
+            if (!chunk_full) lane_alive += (uint32_t)__popc(w & 0x01010101u);
+            if (args.write_died && (lane & 7u) == 0u) died_bits[(step_first >> 5) + (lane >> 3)] = 0u;   // store_died_bits of no casualty
+            if (__all(w == 0x01010101u)) {   // (A)
+                an_max = fmaxf(an_max, fmaxf(fmaxf(an[step][0], an[step][1]), fmaxf(an[step][2], an[step][3])));
+                __builtin_nontemporal_store((u4v{f2u(an[step][0]), f2u(an[step][1]), f2u(an[step][2]), f2u(an[step][3])}), reinterpret_cast<u4v*>(p_age) + (s0 >> 2));
+                loaded_all = false;
+                continue;
+            }
+            if (!__any(w != 0u)) continue;
+            loaded_all = false;
+            const uint32_t a4[4] = {ages[step].x, ages[step].y, ages[step].z, ages[step].w};   // (B)
+            uint32_t q[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const bool was = ((w >> (8 * p)) & 0xffu) == 1u;
+                q[p] = was ? f2u(an[step][p]) : a4[p];        // free slots get their own bytes back: one 16-byte store
+                an_max = fmaxf(an_max, was ? an[step][p] : -__builtin_inff());
+            }
+            if (w != 0u) __builtin_nontemporal_store((u4v{q[0], q[1], q[2], q[3]}), reinterpret_cast<u4v*>(p_age) + (s0 >> 2));
+            continue;
+        }
+        const uint32_t s0 = step_first + lane * 4u;
+        const bool any = w != 0u;                        // (bytes are 0 or 1 here: no cohorts, and no mark outlives the init pass)
+        if (!chunk_full) lane_alive += (uint32_t)__popc(w & 0x01010101u);
+        if (!__any(any)) {
+            if (args.write_died) store_died_bits(died_bits, step_first, 0u, lane);
+            continue;
+        }
+        constexpr bool need = true;   // (C)
+        const uint32_t a4[4] = {ages[step].x, ages[step].y, ages[step].z, ages[step].w};
+        const uint32_t l4[4] = {life[step].x, life[step].y, life[step].z, life[step].w};
+        uint32_t q[4], nib = 0u, nf = w;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool was = ((w >> (8 * p)) & 0xffu) == 1u;
+            const float lf = need ? u2f(l4[p]) : Lm;
+            const bool stays = was && an[step][p] < lf;   // (without the lifetimes: age + dt < Lm <= lifetime holds for every live slot of the step)
+            q[p] = was ? f2u(an[step][p]) : a4[p];        // free slots get their own bytes back: one 16-byte store
+            if (was && !stays) { nib |= 1u << p; nf &= ~(0xffu << (8 * p)); }
+            if (stays) {
+                if (need) wave_min = fminf(wave_min, lf);
+                if (args.safe_words) rem_min = fminf(rem_min, (lf - an[step][p]) - 1.0e-5f * lf);
+            }
+        }
+        // (always nontemporal: the plain store cost the C5 frame 0.0323 against 0.0309 ms in three rounds on one box, profiles/r06r_ab_lean_nt.log)
+        if (any) __builtin_nontemporal_store((u4v{q[0], q[1], q[2], q[3]}), reinterpret_cast<u4v*>(p_age) + (s0 >> 2));
+        if (need) {
+            lane_died += (uint32_t)__popc(nib);
+            if (nf != w) flags4[s0 >> 2] = nf;            // the slot is free from now on; the lists learn it from the died bit
+        }
+        if (args.write_died) store_died_bits(died_bits, step_first, nib, lane);
+    }
+#pragma unroll
+    for (uint32_t off = 32; off > 0; off >>= 1) {
+        lane_died += __shfl_xor(lane_died, off, 64);
+        wave_min = fminf(wave_min, __shfl_xor(wave_min, off, 64));
+    }
+    if (!chunk_full) {
+#pragma unroll
+        for (uint32_t off = 32; off > 0; off >>= 1) lane_alive += __shfl_xor(lane_alive, off, 64);
+    }
+    if (args.safe_words) {
+        if (an_max > -__builtin_inff()) rem_min = fminf(rem_min, (Lm - an_max) - 1.0e-5f * Lm);   // the steps without lifetimes: lf = Lm there
+#pragma unroll
+        for (uint32_t off = 32; off > 0; off >>= 1) rem_min = fminf(rem_min, __shfl_xor(rem_min, off, 64));
+    }
+    // (a negative value marks a wave that skipped a load; a real negative minimum reads the same: the bound then simply stays unknown, which is always correct)
+    if (lane == 0) { s_died[wave] = lane_died; s_alive[wave] = lane_alive; s_rem[wave] = rem_min; s_lmin[wave] = loaded_all ? wave_min : -1.0f; }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t d = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kBlock / 64; ++w) d += s_died[w];
+        if (d) atomicAdd(&cb.deaths[(size_t)cb.parity * cb.table_cap + k], d);
+        if (d && args.skip_lists) *args.fault = 1u;  // the host's proof was wrong: report it (HnbEffectMetadata::fault)
+        if (args.safe_words) {  // one word per chunk and frame parity, plain store
+            float r = fminf(fminf(s_rem[0], s_rem[1]), fminf(s_rem[2], s_rem[3]));
+            r = r > 0.0f ? r : 0.0f;  // non-negative floats order like their bit patterns; +inf: no live particle in the chunk
+            args.safe_words[(size_t)args.safe_parity * args.safe_stride + chunk] = f2u(r);
+        }
+        if (chunk_full) { if (d) cfull[j] = 0u; }
+        else if (d == 0u && s_alive[0] + s_alive[1] + s_alive[2] + s_alive[3] == kChunk) cfull[j] = 1u;
+        float m = __builtin_inff();   // every step of the chunk loaded the lifetimes: the exact minimum over the particles still alive
+        bool all = true;
+#pragma unroll
+        for (uint32_t w = 0; w < kBlock / 64; ++w) { all = all && !(s_lmin[w] < 0.0f); m = fminf(m, s_lmin[w]); }
+        if (all) lmin[j] = m < 3.0e38f ? m : 3.0e38f;  // an empty chunk: any finite bound; a spawn resets it
+    }
+}
+#endif
 
 // Any update program on the V register file: one slot per lane, same protocol.
 template <class CODE>

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
 
 # hnb_ctx_set_option (include/hanabi_amd.h): name -> option id
 OPTIONS = {"list_order": 1, "alternate": 2, "skip_lists": 3, "age_cohort": 4, "cull_lifetime": 5, "horizon": 6, "transpose": 7, "scene_merge": 8,
-           "suffix_proof": 9, "overlap_updates": 10, "stream_hints": 11, "set_module": 12, "jit_async": 13, "test_break_proof": 15, "ring_lists": 16, "slot_init": 17}
+           "suffix_proof": 9, "overlap_updates": 10, "stream_hints": 11, "set_module": 12, "jit_async": 13, "test_break_proof": 15, "ring_lists": 16, "slot_init": 17, "direct_upload": 18}
 SET_MODULE_OFF, SET_MODULE_CACHED, SET_MODULE_COMPILE, SET_MODULE_BACKGROUND = 0, 1, 2, 3
 
 

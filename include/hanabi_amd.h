@@ -319,6 +319,12 @@ int hnb_ctx_synchronize(HnbContext* ctx);
  *   ribbon effects, keep the rank-major pass. Same state bit for bit (the serial pop order only decides the LIST, which is copied). 0: never;
  *   2: every eligible program in every frame that spawns anything, whatever its size (tests, A/B runs). */
 #define HNB_OPT_SLOT_INIT 17u
+/* HNB_OPT_DIRECT_UPLOAD (default 1; from the next hnb_simulate on): the frame's parameter block (instance rows, uniform blocks, job tables: a few hundred
+ *   bytes to a few KiB) is WRITTEN BY THE HOST into fine-grained device memory through the PCIe BAR - posted writes in front of the first launch's
+ *   doorbell, the way the HIP runtime places kernel arguments - where the device exposes a large BAR (hipDeviceProp_t::isLargeBar; checked against a
+ *   device-side read-back when the slots are created). 0, or a device without one: hipMemcpyAsync on an internal stream and a host wait, 10 us of every
+ *   hnb_simulate. Same results; hnb_program_kernel_info says which way the context's frames went. */
+#define HNB_OPT_DIRECT_UPLOAD 18u
 /* HNB_OPT_OVERLAP_UPDATES (default 1; from the next hnb_simulate on): when one program of the context holds at least four times the slots
  *   of all the others together (and >= 1M), the update phase of the others - update, spawn-event ordering, lists, sort: independent chains -
  *   runs on an internal second stream next to the heavy program's update and joins the context's stream before hnb_simulate returns.

@@ -190,6 +190,41 @@ def test_large_spawns_slot_major_equal_the_row_major_init_and_the_oracle():
     on.close(); off.close()
 
 
+def _upload_frames(prog):
+    line = [l for l in prog.kernel_info().split("\n") if l.startswith("frame parameters (context)")][0]
+    words = line.split()
+    return int(words[words.index("in") + 1]), int(words[words.index("copied") + 2])   # (written by the host, copied)
+
+
+def test_frame_parameters_written_by_the_host_equal_the_copied_ones():
+    """HNB_OPT_DIRECT_UPLOAD (round 6): the frame's parameter block written by the host into fine-grained device memory (the default where the device has a
+    large BAR) against hipMemcpyAsync + a host wait, and against the oracle: a program with per-frame uniforms that change EVERY frame (translated
+    emitter, a property, alternating ticks), several instances, the staging ring reused many times over (4 slots, 120 frames), and a switch of the
+    option in the middle of a run (the slots are re-created between two frames). A stale or torn block would show as a wrong transform / tick / seed."""
+    cap = 9000
+    asset = effects.instancing(cap)
+    d, c = bh.Context(0), bh.Context(0)
+    c.set_option("direct_upload", 0)
+    gd, gc, orc = GpuRunner(asset, ctx=d), GpuRunner(asset, ctx=c), OracleRunner(asset)
+    for f in range(120):
+        if f == 60:
+            d.set_option("direct_upload", 0); c.set_option("direct_upload", 1)   # the other way round from here on
+        fr = Frame(1 / 60 if f % 3 else 1 / 45, cap if f in (0, 70) else (f * 13) % 97, frame_seed(f), translation(0.01 * f, -0.02 * f, 0.5), time=f / 60.0)
+        for x in (gd, gc, orc):
+            x.step(fr)
+        if f % 10 == 9 or f in (0, 60, 61):
+            ref = orc.state()
+            assert_same_state(ref, gd.state(), f"host-written first, frame {f}")
+            assert_same_state(ref, gc.state(), f"copied first, frame {f}")
+    wd, cd = _upload_frames(gd.prog)
+    wc, cc = _upload_frames(gc.prog)
+    if "no large BAR" in gd.prog.kernel_info():
+        assert (wd, wc) == (0, 0) and cd == 120 and cc == 120
+    else:
+        assert (wd, cd) == (60, 60) and (wc, cc) == (60, 60), (gd.prog.kernel_info(), gc.prog.kernel_info())
+    d.close(); c.close()
+
+
 def test_slot_major_init_over_several_instances(ctx):
     """One launch for all instances of a program: a complete burst, a partial one, an instance that spawns nothing and a frozen one side by side
     (the frame qualifies as a whole: half of the program's slots spawn), death horizons and age cohorts in play; translated emitters."""
