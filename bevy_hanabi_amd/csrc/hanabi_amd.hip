@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -63,6 +64,9 @@ constexpr uint32_t kSceneMaxInitBlocks = 64;   // ... and <= 16,384 spawns (hnb_
 #define HNB_GENERIC_SPLIT_MAX 128
 #endif
 constexpr uint32_t kGenericSplitMaxChunks = HNB_GENERIC_SPLIT_MAX;  // a generic-update program of up to this many chunks (524,288 slots) launches one workgroup per 256 slots: 2048 workgroups, one round on 256 CUs
+#ifndef HNB_STREAM_QUARTERS
+#define HNB_STREAM_QUARTERS 1
+#endif
 constexpr uint32_t kSceneMaxCodeLen = 64;      // ... and a pass of at most this many instructions: the merged launches INTERPRET, and one long program (the
                                                // lightning bolt's 510-instruction init: 43 us interpreted, 5 us specialised) would set the latency of all
 
@@ -196,7 +200,8 @@ struct HnbContext {
     bool direct_upload = true;            // HNB_OPT_DIRECT_UPLOAD
     bool stage_direct = false;            // the slots that exist now are host-written fine-grained device memory
     bool direct_failed = false;           // the allocation or its self-test failed once: copies from then on
-    uint64_t direct_frames = 0, copied_frames = 0;   // statistics (hnb_ctx_describe_upload)
+    uint64_t direct_frames = 0, copied_frames = 0;   // statistics (hnb_program_kernel_info)
+    uint64_t ring_waits = 0, ring_wait_ns = 0;       // frames in which hnb_simulate found the device still busy with the frame kFrameRing before (it is device-bound then), and for how long it waited
     hipEvent_t stage_done[kFrameRing] = {};  // recorded on the simulation stream after the frame that used the slot
     uint32_t num_cus = 256;
     std::vector<HnbProgram*> programs;
@@ -1565,6 +1570,7 @@ static SlotArgs slot_args_of(const HnbContext* ctx, const HnbProgram* p, uint32_
     sa.died_bits_off = p->dev.died_bits_off; sa.write_died = write_died;
     sa.cull_lifetime = p->dev.cull_lifetime; sa.lmin_off = p->dev.lmin_off; sa.dt_operand = p->cull_dt_operand;
     sa.age_cohort = p->dev.age_cohort;
+    sa.quarters = 1u;
     sa.age_current = p->auto_materialise ? 1u : 0u;   // HNB_AGE_COHORT_AUTO: the render modifiers read AGE after every frame
     sa.frame_phase = p->frames_run & 15u;
     sa.horizon_off = p->dev.horizon_off; sa.horizon = p->horizon_eligible ? 1u : 0u;
@@ -1687,7 +1693,15 @@ static int ensure_stage(HnbContext* ctx, const std::vector<HnbProgram*>& order, 
         ctx->stage_bytes = nb;
         ctx->stage_direct = direct;
     }
-    if (!order.empty()) HIP_TRY(hipEventSynchronize(ctx->stage_done[slot]));  // the frame that last used this slot (kFrameRing frames ago)
+    if (!order.empty()) {   // the frame that last used this slot (kFrameRing frames ago): the one place where hnb_simulate waits for the device
+        if (hipEventQuery(ctx->stage_done[slot]) != hipSuccess) {
+            (void)hipGetLastError();
+            const auto t0 = std::chrono::steady_clock::now();
+            HIP_TRY(hipEventSynchronize(ctx->stage_done[slot]));
+            ctx->ring_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            ctx->ring_waits += 1;
+        }
+    }
     return HNB_OK;
 }
 
@@ -1968,10 +1982,13 @@ static void fill_merge_jobs(HnbContext* ctx, const std::vector<HnbProgram*>& ord
             const DevFrameInst* dfi = reinterpret_cast<const DevFrameInst*>(d);
             const uint32_t* dub = reinterpret_cast<const uint32_t*>(d + (size_t)n * sizeof(DevFrameInst));
             const uint32_t write_died = (p->plan.lists && !p->slot_order) ? 1u : 0u;
-            const uint32_t wgs = kind == 0 ? p->plan.init_blocks : n * p->dev.chunks_per_inst * (kind == 1 ? kGenericSubs : 1u);
+            // (streaming programs without cohorts: four workgroups per chunk, SlotArgs::quarters)
+            const uint32_t quarters = (kind == 2 && fam == plan::kStream && HNB_STREAM_QUARTERS) ? 4u : 1u;
+            const uint32_t wgs = kind == 0 ? p->plan.init_blocks : n * p->dev.chunks_per_inst * (kind == 1 ? kGenericSubs : quarters);
             if (kind == 2) {
                 StreamJob jb{};
                 jb.args = slot_args_of(ctx, p, n, write_died);
+                jb.args.quarters = quarters;
                 jb.inst_base = reinterpret_cast<const uint64_t*>(p->d_inst_base); jb.fi = dfi; jb.ublocks = dub;
                 jb.cb = compact_bufs_of(ctx, p, n);
                 jb.first_wg = base + f.wgs; jb.n_wg = wgs;
@@ -2643,6 +2660,8 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
     s += "\nlists skipped: " + std::to_string(prog->skipped_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->skip_facts.eligible ? "" : " (not eligible)");
     s += "\nframe parameters (context): written by the host into device memory in " + std::to_string(prog->ctx->direct_frames) + " frames, copied in " + std::to_string(prog->ctx->copied_frames) +
          (prog->ctx->large_bar ? "" : " (the device memory is not host-visible: no large BAR)") + (prog->ctx->direct_failed ? " (host-visible slots failed their check)" : "");
+    s += "\nhnb_simulate waited for the device (the frame " + std::to_string(kFrameRing) + " before still running) in " + std::to_string(prog->ctx->ring_waits) + " of " + std::to_string(prog->ctx->frame) +
+         " frames, " + std::to_string(prog->ctx->ring_wait_ns / 1000) + " us in all";
     snprintf(buf, buf_size, "%s", s.c_str());
     return HNB_OK;
 }

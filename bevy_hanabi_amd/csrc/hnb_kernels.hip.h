@@ -1244,6 +1244,10 @@ struct SlotArgs {
     uint32_t transpose;      // 1: vec3 planes of the per-particle path go through the wave's LDS transpose (xpose_load3 / xpose_store3)
     uint32_t stream_hint;    // 1: read-only planes (LIFETIME, alive bytes) are loaded with the nontemporal hint ("cache policy of streamed data")
     uint32_t store_hint;     // 1: the per-particle path stores its planes with the nontemporal hint (update_stream_chunk)
+    uint32_t quarters;       // 1, or 4 (r6, the merged launches of small programs without cohorts): FOUR workgroups per 4096-slot chunk, a wave per 256-slot step. A program
+                             // of a few chunks was a few workgroups whose waves walked four steps one after the other - four dependent load / run / store rounds, the
+                             // longest link of a small scene's frame. The per-chunk state a quarter cannot know alone is left alone (the "completely alive" flag is
+                             // only ever cleared, the lifetime bound only ever used), the no-death bound of the chunk is the minimum of four (atomicMin)
     uint32_t age_current;    // 1 (with age_cohort; HNB_AGE_COHORT_AUTO for an asset whose render modifiers read AGE): a chunk that keeps its common age in the
                              // value word ALSO writes it to the plane for its alive slots - write-only, 4 of the 8 bytes the cohort saves - so the AGE plane
                              // is current after every frame without a second pass over it (until round 6: a k_materialise_age launch behind every update)
@@ -1327,8 +1331,13 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
     uint32_t (&s_amax)[kBlock / 64] = lds.amax;
     u4v (&s_xp)[2][kBlock / 64][kStepRows * 3u / 4u] = lds.xp;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
+    const bool split = !COHORT && args.quarters == 4u;   // (SlotArgs::quarters; wave-uniform)
+    const uint32_t chunk = split ? chunk_of_workgroup(cb.xcd_remap, wg >> 2, wg_total >> 2) : chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
+    const uint32_t quarter = split ? (wg & 3u) : 0u;
     const uint32_t k = chunk / args.chunks_per_inst, j = chunk - k * args.chunks_per_inst;
+    const uint32_t wave0 = j * kChunk + (split ? (quarter * (kBlock / 64u) + wave) * kStepRows : wave * kWaveRows);   // the wave's first slot
+    const uint32_t n_steps = split ? 1u : kWaveRows / kStepRows;
+    const uint32_t n_words = split ? wg_total >> 2 : wg_total;   // chunks of the program
     // Plane stores of a program whose WRITTEN planes exceed the Infinity Cache by half (SlotArgs::store_hint, plan::use_store_hints): nontemporal.
     // Same-box A/B (profiles/r04o_ab_walk.log, r04p_ab_walk2.log): c2_mixed 0.327 -> 0.316 ms, c2_events 0.456 -> 0.438; C3 - 8.4M particles,
     // 235 MB of written planes: they FIT the cache and the next frame's walk finds them there - 0.097 -> 0.120 ms with the hint, hence the size rule.
@@ -1339,9 +1348,10 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
     // (r6: the FIRST workgroup of the launch publishes, not chunk 0: in a frame that walks downwards chunk 0 is the last workgroup dispatched, and its
     // store to host memory behind two barriers in front of its own chunk was the tail of the kernel)
     if (args.safe_words && (HNB_PUBLISH_FIRST_WG ? wg == 0u : chunk == 0u)) {  // publish the previous frame's bound: its kernel has completed, every chunk's word is final
-        const uint32_t* prev = args.safe_words + (size_t)(args.safe_parity ^ 1u) * args.safe_stride;
+        uint32_t* prev = args.safe_words + (size_t)(args.safe_parity ^ 1u) * args.safe_stride;
         uint32_t m = 0x7f800000u;
-        for (uint32_t i = tid; i < wg_total; i += kBlock) { const uint32_t v = prev[i]; m = v < m ? v : m; }
+        // (each word goes back to +inf once read: the frame after next may merge the four quarters of a chunk into it with atomicMin - SlotArgs::quarters)
+        for (uint32_t i = tid; i < n_words; i += kBlock) { const uint32_t v = prev[i]; prev[i] = 0x7f800000u; m = v < m ? v : m; }
 #pragma unroll
         for (uint32_t off = 32; off > 0; off >>= 1) { const uint32_t y = __shfl_xor(m, off, 64); m = y < m ? y : m; }
         if (lane == 0) s_alive[wave] = m;
@@ -1352,7 +1362,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         }
         __syncthreads();
     }
-    if (args.skip_lists && j == 0u && tid == 0u) {  // counter rotation of a frame without spawn and casualty (k_compact's zero-casualty path)
+    if (args.skip_lists && j == 0u && quarter == 0u && tid == 0u) {  // counter rotation of a frame without spawn and casualty (k_compact's zero-casualty path)
         DevMeta o = args.meta_in[k];
         if (!fi[k].skip) {
             o.ref_write_index ^= 1u;
@@ -1395,7 +1405,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
     float* lmin = reinterpret_cast<float*>(base + args.lmin_off);
     const float Lm = cull ? lmin[j] : 0.0f;           // 0 (or anything not > 0): unknown, every step loads the lifetimes
     const float dt_tick = cull ? uf(U, args.dt_operand) : 0.0f;
-    if (args.horizon && j == 0u && tid == 0u) {       // the instance's clock: once per simulated frame (frozen instances returned above)
+    if (args.horizon && j == 0u && quarter == 0u && tid == 0u) {       // the instance's clock: once per simulated frame (frozen instances returned above)
         double* clk = horizon_view(base, args.horizon_off, args.chunks_per_inst).clock;
         *clk = *clk + (double)(dt_tick > 0.0f ? dt_tick : 0.0f) * (1.0 + 0x1p-16);
     }
@@ -1452,7 +1462,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
     // mixed ages - state 4 - runs without it: see `mixed` above)
     auto step_body = [&](auto coh_tag, const uint32_t step, const uint32_t f4, const u4v* pre_age = nullptr) {
         constexpr bool COH = decltype(coh_tag)::value;
-        const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;  // first of this lane's 4 slots
+        const uint32_t s0 = wave0 + step * kStepRows + lane * 4u;  // first of this lane's 4 slots
         bool was[4], fresh[4];  // fresh: spawned this frame into a chunk that kept its ages in the value word (alive byte 3, state 2 only)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -1593,117 +1603,19 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         if (args.write_died) store_died_bits(reinterpret_cast<uint32_t*>(base + args.died_bits_off), step_first, nib, lane);
         died_total += died_here;
     };
-    // ---- the age-only path (r6): an update that is ONE AGE_TICK (ribbon.rs, lightning.rs: trails that do not move; PROG::kAgeOnly) reads and writes a single
-    // scalar plane, and the per-particle path above costs it 675 VALU + 508 SALU instructions per wave of 1024 slots for `age += dt; alive = age < lifetime`
-    // (C5: 19 us for 37 MB where a plain kernel moves as much in 5, profiles/r06n_c5_counters.log, r06o_dispatch_probe.log): a frame of three dependent launches
-    // IS that chain. Here the wave requests everything it can need at once - the alive bytes (also of chunks flagged completely alive: one byte per slot buys a
-    // round trip), the ages of its four steps -, decides per step from the chunk's lifetime bound whether anybody can die (only then the lifetimes are loaded
-    // and the death bookkeeping runs), and accumulates its counters per lane (one reduction per wave, in the shared epilogue). Same protocol, same results
-    // bit for bit as the general path, which the parity gate's plain replay (lifetime culling off) keeps running beside it.
-    bool lean_done = false;
-    if constexpr (PROG::kAgeOnly && PROG::kLen == 1u && !COHORT && PROBE == 0) {
-        if (cull && (fl & 0xffu) == (4u | 8u | 64u)) {
-            lean_done = true;
-            constexpr uint32_t kSteps = kWaveRows / kStepRows;
-            const uint32_t wave0 = j * kChunk + wave * kWaveRows;
-            uint32_t* died_bits = reinterpret_cast<uint32_t*>(base + args.died_bits_off);
-            uint32_t f4s[kSteps];
-            u4v ages[kSteps];
-#pragma unroll
-            for (uint32_t step = 0; step < kSteps; ++step) {
-                const uint32_t s0 = wave0 + step * kStepRows + lane * 4u;
-                const bool in = s0 < args.capacity;   // (planes are padded to 256 B: a quad never straddles the end; slots past the capacity read 0)
-                const uint32_t ld = in ? ld_hint(flags4 + (s0 >> 2), args.stream_hint != 0u) : 0u;
-                f4s[step] = chunk_full ? 0x01010101u : ld;
-                ages[step] = in ? reinterpret_cast<const u4v*>(p_age)[s0 >> 2] : u4v{0u, 0u, 0u, 0u};
-            }
-            const bool bound_known = Lm > 0.0f;
-            float an[kSteps][4];
-            uint32_t need_mask = 0u;   // wave-uniform: steps in which somebody may die (or the bound is unknown): they load the lifetimes
-#pragma unroll
-            for (uint32_t step = 0; step < kSteps; ++step) {
-                const uint32_t w = f4s[step];
-                const uint32_t a4[4] = {ages[step].x, ages[step].y, ages[step].z, ages[step].w};
-                bool may = false;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    an[step][p] = u2f(a4[p]) + dt_tick;                                  // mac_age_tick's arithmetic
-                    const bool was = ((w >> (8 * p)) & 0xffu) == 1u;
-                    may = may || (was && !(bound_known && an[step][p] < Lm));
-                }
-                if (__any(may)) need_mask |= 1u << step;
-            }
-            u4v life[kSteps];
-#pragma unroll
-            for (uint32_t step = 0; step < kSteps; ++step) {
-                life[step] = u4v{0u, 0u, 0u, 0u};
-                if ((need_mask >> step) & 1u) {
-                    const uint32_t s0 = wave0 + step * kStepRows + lane * 4u;
-                    if (f4s[step] != 0u) {   // (lanes whose quad holds a live particle: what the general path loads)
-                        const u4v* pl = reinterpret_cast<const u4v*>(p_life) + (s0 >> 2);
-                        life[step] = args.stream_hint ? __builtin_nontemporal_load(pl) : *pl;
-                    }
-                }
-            }
-            uint32_t lane_died = 0u;
-#pragma unroll
-            for (uint32_t step = 0; step < kSteps; ++step) {
-                const uint32_t w = f4s[step];
-                const uint32_t step_first = wave0 + step * kStepRows;
-                const uint32_t s0 = step_first + lane * 4u;
-                const bool any = w != 0u;                        // (bytes are 0 or 1 here: no cohorts, and no mark outlives the init pass)
-                if (!chunk_full) lane_alive += (uint32_t)__popc(w & 0x01010101u);
-                if (!__any(any)) {
-                    if (args.write_died) store_died_bits(died_bits, step_first, 0u, lane);
-                    continue;
-                }
-                const bool need = ((need_mask >> step) & 1u) != 0u;   // wave-uniform
-                if (!need) loaded_all = false;
-                const uint32_t a4[4] = {ages[step].x, ages[step].y, ages[step].z, ages[step].w};
-                const uint32_t l4[4] = {life[step].x, life[step].y, life[step].z, life[step].w};
-                uint32_t q[4], nib = 0u, nf = w;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const bool was = ((w >> (8 * p)) & 0xffu) == 1u;
-                    const float lf = need ? u2f(l4[p]) : Lm;
-                    const bool stays = was && an[step][p] < lf;   // (without the lifetimes: age + dt < Lm <= lifetime holds for every live slot of the step)
-                    q[p] = was ? f2u(an[step][p]) : a4[p];        // free slots get their own bytes back: one 16-byte store
-                    if (was && !stays) { nib |= 1u << p; nf &= ~(0xffu << (8 * p)); }
-                    if (stays) {
-                        if (need) wave_min = fminf(wave_min, lf);
-                        if (args.safe_words) rem_min = fminf(rem_min, (lf - an[step][p]) - 1.0e-5f * lf);
-                    }
-                }
-                if (any) {
-                    u4v* pa = reinterpret_cast<u4v*>(p_age) + (s0 >> 2);
-                    // (always nontemporal: nobody reads the ages again before the next frame's walk, and the plain store cost the C5 frame 0.0323 against
-                    // 0.0309 ms in three rounds on one box, profiles/r06r_ab_lean_nt.log)
-                    __builtin_nontemporal_store((u4v{q[0], q[1], q[2], q[3]}), pa);
-                }
-                if (need) {
-                    lane_died += (uint32_t)__popc(nib);
-                    if (nf != w) flags4[s0 >> 2] = nf;            // the slot is free from now on; the lists learn it from the died bit
-                }
-                if (args.write_died) store_died_bits(died_bits, step_first, nib, lane);
-            }
-#pragma unroll
-            for (uint32_t off = 32; off > 0; off >>= 1) lane_died += __shfl_xor(lane_died, off, 64);
-            died_total = lane_died;   // (wave-uniform from here on, as the epilogue expects)
-        }
-    }
-    if (!flat && !lean_done) {
+    if (!flat) {
         // the alive bytes of the wave's four steps, requested together (a step's own load would wait behind the previous step's stores to the
         // same plane: two dependent round trips per step)
         // (the cohort instantiations, budgeted for 4 waves, and the component-wise programs have the registers for it: -1 % on the churn
         // frames; the others - C3's force field at 5 waves - lost 2.5 % to it and load each step's word where it is used, profiles/r03s_ab.log)
         auto f4_of = [&](const uint32_t step) {
-            const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;
+            const uint32_t s0 = wave0 + step * kStepRows + lane * 4u;
             return chunk_full ? 0x01010101u : (s0 < args.capacity ? ld_hint(flags4 + (s0 >> 2), args.stream_hint != 0u) : 0u);  // the plane is padded: slots past the capacity read 0
         };
         if constexpr (COHORT || PROG::kFlat) {
             uint32_t f4s[kWaveRows / kStepRows];
 #pragma unroll
-            for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) f4s[step] = f4_of(step);
+            for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) f4s[step] = step < n_steps ? f4_of(step) : 0u;
             // Age-only programs (PROG::kAgeOnly: ribbon.rs - a trail that does not move): the step is two dependent round trips for 8 bytes per
             // particle - alive bytes, then the ages - four times in a row, and a 4M-particle effect is one round of workgroups: the kernel is
             // those latencies. The ages of all four steps are requested together with the alive bytes (16 registers, only in these instantiations).
@@ -1712,24 +1624,24 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
                     u4v ages[kWaveRows / kStepRows];
 #pragma unroll
                     for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) {
-                        const uint32_t s0 = j * kChunk + wave * kWaveRows + step * kStepRows + lane * 4u;
-                        ages[step] = s0 < args.capacity ? reinterpret_cast<const u4v*>(p_age)[s0 >> 2] : u4v{0u, 0u, 0u, 0u};   // (planes are padded to 256 B: a quad never straddles the end)
+                        const uint32_t s0 = wave0 + step * kStepRows + lane * 4u;
+                        ages[step] = (step < n_steps && s0 < args.capacity) ? reinterpret_cast<const u4v*>(p_age)[s0 >> 2] : u4v{0u, 0u, 0u, 0u};   // (planes are padded to 256 B: a quad never straddles the end)
                     }
 #pragma unroll
-                    for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4s[step], &ages[step]);
+                    for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) if (step < n_steps) step_body(BoolTag<false>{}, step, f4s[step], &ages[step]);
                     goto steps_done;
                 }
             }
             if (mixed) {
 #pragma unroll
-                for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4s[step]);
+                for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) if (step < n_steps) step_body(BoolTag<false>{}, step, f4s[step]);
             } else {
 #pragma unroll
-                for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<COHORT>{}, step, f4s[step]);
+                for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) if (step < n_steps) step_body(BoolTag<COHORT>{}, step, f4s[step]);
             }
         } else {
 #pragma unroll
-            for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) step_body(BoolTag<false>{}, step, f4_of(step));
+            for (uint32_t step = 0; step < kWaveRows / kStepRows; ++step) if (step < n_steps) step_body(BoolTag<false>{}, step, f4_of(step));
         }
     }
 steps_done:
@@ -1779,11 +1691,13 @@ steps_done:
         if (args.safe_words) {  // one word per chunk and frame parity, plain store (same-address atomics from 8 XCDs cost ~0.1 us EACH)
             float r = fminf(fminf(s_rem[0], s_rem[1]), fminf(s_rem[2], s_rem[3]));
             r = r > 0.0f ? r : 0.0f;  // non-negative floats order like their bit patterns; +inf: no live particle in the chunk
-            args.safe_words[(size_t)args.safe_parity * args.safe_stride + chunk] = f2u(r);
+            uint32_t* word = args.safe_words + (size_t)args.safe_parity * args.safe_stride + chunk;
+            if (split) atomicMin(word, f2u(r));   // the chunk's four quarters (the word was +inf: the publisher of the frame before left it so)
+            else *word = f2u(r);
         }
         if (chunk_full) { if (d) cfull[j] = 0u; }
-        else if (d == 0u && s_alive[0] + s_alive[1] + s_alive[2] + s_alive[3] == kChunk) cfull[j] = 1u;
-        if (cull) {  // every step of the chunk loaded the lifetimes: the exact minimum over the particles still alive
+        else if (!split && d == 0u && s_alive[0] + s_alive[1] + s_alive[2] + s_alive[3] == kChunk) cfull[j] = 1u;   // (a quarter cannot know)
+        if (cull && !split) {  // every step of the chunk loaded the lifetimes: the exact minimum over the particles still alive
             float m = __builtin_inff();
             bool all = true;
 #pragma unroll
@@ -1845,9 +1759,9 @@ k_update_slots_stream_age(const SlotArgs args, const uint64_t* __restrict__ inst
     if (args.safe_words && wg == 0u) {        // publish the previous frame's bound: its kernel has completed, every chunk's word is final
         // (the FIRST workgroup of the launch, not chunk 0: in a frame that walks downwards chunk 0 is the last one dispatched, and the store to host memory
         // behind two barriers was the tail of the kernel)
-        const uint32_t* prev = args.safe_words + (size_t)(args.safe_parity ^ 1u) * args.safe_stride;
+        uint32_t* prev = args.safe_words + (size_t)(args.safe_parity ^ 1u) * args.safe_stride;
         uint32_t m = 0x7f800000u;
-        for (uint32_t i = tid; i < wg_total; i += kBlock) { const uint32_t v = prev[i]; m = v < m ? v : m; }
+        for (uint32_t i = tid; i < wg_total; i += kBlock) { const uint32_t v = prev[i]; prev[i] = 0x7f800000u; m = v < m ? v : m; }   // (back to +inf: update_stream_chunk's publisher)
 #pragma unroll
         for (uint32_t off = 32; off > 0; off >>= 1) { const uint32_t y = __shfl_xor(m, off, 64); m = y < m ? y : m; }
         if (lane == 0) s_alive[wave] = m;

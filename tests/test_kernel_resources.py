@@ -19,7 +19,7 @@ LDS_BUDGET = {
     "k_reset_lists": 0, "k_spawn_mark": 0, "k_init_slots": 0, "k_check_rows": 0, "k_compare_words": 0, "k_probe_placement": 0, "k_materialise_age": 0, "k_marker": 0, "k_gather_alive": 0, "k_sort_merge": 0,
     "k_init": 32, "k_init_jobs": 32, "k_update_generic_wide_jobs": 32, "k_update_jobs": 24704, "k_count_rows": 16, "k_count_rows_multi": 16, "k_compact": 16, "k_compact_multi": 16, "k_emit_count": 16, "k_order_count": 16,
     "k_update_slots_generic": 32, "k_sort_hist": 1024, "k_sort_fill": 1152, "k_sort_small": 5120, "k_sort_scatter": 5120, "k_sort_tile": 6280,
-    "k_order_write": 32784, "k_emit_events": 49188, "k_update_slots_stream": 24672,
+    "k_order_write": 32784, "k_emit_events": 49188, "k_update_slots_stream": 24672, "k_update_slots_stream_age": 64,
 }
 # kernels allowed to use scratch: the interpreters (a register file indexed by the instruction stream) and the 5/6-wave streaming variants
 # (a handful of spilled words under their register budget)

@@ -90,6 +90,9 @@ def run(copies=1, frames=600, device=0, quiet=False, set_module=None):
     wall = time.perf_counter() - t0
     alive = sum(p["fx"].alive_count() for p in players)
     in_set = sum(1 for p in players if "set module (the program" in p["prog"].kernel_info())
+    waited = [l for l in players[0]["prog"].kernel_info().split("\n") if l.startswith("hnb_simulate waited")]
+    if not quiet and waited:
+        print(waited[0])
     if not quiet:
         print(f"{frames} frames: {wall / frames * 1e3:.3f} ms per frame wall (recorded inputs replayed through the C ABI), {host / frames * 1e3:.3f} ms inside simulate(); "
               f"{host / frames / len(players) * 1e6:.1f} us of simulate() per effect and frame; {alive} particles alive at the end")
