@@ -130,7 +130,7 @@ CONFIGS = {
                workload="force_field.rs EffectAsset (2x ConformToSphere + KillAabb + KillSphere), capacity={cap:_} per GPU, burst"),
     "c4": dict(capacity=65536, bytes_per_update=68, bytes_per_spawn=40, model_bytes=36, kernel="k_update_slots_stream<ProgAgeEuler, cohort>", instances=512,
                workload="instancing.rs: {inst} independent effect instances x {cap:_} per GPU (one launch), burst, all alive"),
-    "c5": dict(capacity=1 << 22, bytes_per_update=20, bytes_per_spawn=36, model_bytes=9, kernel="k_update_slots_stream<ProgAge>",
+    "c5": dict(capacity=1 << 22, bytes_per_update=20, bytes_per_spawn=36, model_bytes=9, kernel="k_update_slots_stream_age",
                workload="ribbon.rs EffectAsset, capacity={cap:_} per GPU, rate spawner in steady spawn/kill churn, ribbon sort in the step"),
 }
 EXTRA_CONFIGS = ("c2_lean", "c2_interop", "c2_view", "c2_mixed", "c2_dieoff", "c2_reburst", "c2_events", "c3", "c4", "c5")   # appended to the N = 1 default line
@@ -891,6 +891,15 @@ def run_config(name, args, D, strong=False, pmc=None):
             assert comm_info["alive_total"] == alive1, f"hnb_comm_allreduce_alive says {comm_info['alive_total']}, the effects' counters {alive1}"
     w_kernel_info = w.prog.kernel_info()
     kinfo = w_kernel_info.split("\n")[0]
+    # how the frames' parameter blocks reached the device (HNB_OPT_DIRECT_UPLOAD) and how often hnb_simulate found the device behind (it is device-bound then)
+    submission = {}
+    for ln in w_kernel_info.split("\n"):
+        if ln.startswith("frame parameters (context)"):
+            wd = ln.split()
+            submission["frames_written_by_host"] = int(wd[wd.index("in") + 1]); submission["frames_copied"] = int(wd[wd.index("copied") + 2])
+        if ln.startswith("hnb_simulate waited"):
+            wd = ln.split()
+            submission["frames_waited_for_device"] = int(wd[wd.index("in") + 1]); submission["frames"] = int(wd[wd.index("of") + 1]); submission["waited_us"] = int(wd[wd.index("frames,") + 1])
     parity = None
     if args.parity and D.rank == 0 and not strong:
         try:
@@ -939,7 +948,7 @@ def run_config(name, args, D, strong=False, pmc=None):
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["workload"].format(cap=w.per_inst_cap, inst=len(w.fxs)), "name": name, "capacity_per_gpu": w.local_particles,
                    "instances_per_gpu": len(w.fxs), "dt": w.dt, "options": w.options, "stale_attr_mask_after": stale_mask, "sharding": w.sharding_desc, "alive_before": alive0_total, "alive_after": alive1_total,
-                   "updates_per_frame": per_frame_total, "spawns_per_frame": spawned},
+                   "updates_per_frame": per_frame_total, "spawns_per_frame": spawned, "submission": submission},
         "windows": {"n": windows, "steps_each": steps, "ms_per_step": [s / steps * 1e3 for s in window_s], "median_ms_per_step": med / steps * 1e3,
                     "min_ms_per_step": min(window_s) / steps * 1e3, "value_best_window": updates / min(window_s),
                     "timed_region_s": sum(window_s)},

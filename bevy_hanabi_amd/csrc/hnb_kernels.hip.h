@@ -71,6 +71,55 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 template <class T> __device__ __forceinline__ T ld_hint(const T* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 template <class T> __device__ __forceinline__ void st_hint(T v, T* p, bool nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
 
+// A workgroup barrier that orders LDS traffic only: __syncthreads() is also a release fence for the wave's global stores (s_waitcnt vmcnt(0): the wave sits
+// until every plane store it issued is acknowledged), which the epilogues that hand four words per wave to thread 0 through LDS do not need (k_init's
+// horizon merge has used the same since round 3).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- wave reductions over DPP (r6) ------------------------------------------------------------------------------------------------------------------
+// The epilogues below reduce three to six per-lane values over the wave. As butterflies of __shfl_xor they were chains of dependent ds_bpermute
+// round trips through the LDS crossbar - 6 per value, 18 to 36 in a row per wave - and in the kernels of a small frame, where every workgroup of the
+// launch is resident at once and the kernel lasts as long as its slowest wave, 2.7 of the age kernel's 10.5 us (profiles/r06ab_age_kernel_cuts.log).
+// Here: two quad permutes, two row rotations, two row broadcasts - VALU operands, no LDS - and the total read from lane 63 into a scalar register
+// (wave-uniform). Integer sums and min / max of non-NaN floats do not depend on the order. Every lane of the wave must be active.
+#define HNB_DPP_(v, ident, ctrl, rows) ((uint32_t)__builtin_amdgcn_update_dpp((int)(ident), (int)(v), ctrl, rows, 0xf, false))
+// (the moved value is taken ONCE per step, with every lane active: an operator that names it twice - a conditional - would otherwise repeat the DPP move
+// under its own branch, where the lanes that lost the comparison are switched off and cannot be read)
+#define HNB_WAVE_STEP_(v, ident, OP, ctrl, rows) { const uint32_t t_ = HNB_DPP_(v, ident, ctrl, rows); v = OP(v, t_); }
+#define HNB_WAVE_REDUCE_(v, ident, OP)                                                          \
+    HNB_WAVE_STEP_(v, ident, OP, 0xB1, 0xf)  /* quad_perm [1,0,3,2] */                          \
+    HNB_WAVE_STEP_(v, ident, OP, 0x4E, 0xf)  /* quad_perm [2,3,0,1] */                          \
+    HNB_WAVE_STEP_(v, ident, OP, 0x124, 0xf) /* row_ror:4 */                                    \
+    HNB_WAVE_STEP_(v, ident, OP, 0x128, 0xf) /* row_ror:8: every lane holds its row's total */  \
+    HNB_WAVE_STEP_(v, ident, OP, 0x142, 0xa) /* row_bcast:15 into rows 1 and 3 */               \
+    HNB_WAVE_STEP_(v, ident, OP, 0x143, 0xc) /* row_bcast:31 into rows 2 and 3: lane 63 holds the wave's */
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#define HNB_OP_(a, b) ((a) + (b))
+    HNB_WAVE_REDUCE_(v, 0u, HNB_OP_)
+#undef HNB_OP_
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#define HNB_OP_(a, b) ((b) < (a) ? (b) : (a))
+    HNB_WAVE_REDUCE_(v, 0xffffffffu, HNB_OP_)
+#undef HNB_OP_
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define HNB_OP_(a, b) ((b) > (a) ? (b) : (a))
+    HNB_WAVE_REDUCE_(v, 0u, HNB_OP_)
+#undef HNB_OP_
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ float wave_min_f32(float x) {   // (no NaN among the operands: fminf's choice would depend on the order)
+    uint32_t v = f2u(x);
+#define HNB_OP_(a, b) f2u(fminf(u2f(a), u2f(b)))
+    HNB_WAVE_REDUCE_(v, 0x7f800000u, HNB_OP_)
+#undef HNB_OP_
+    return u2f((uint32_t)__builtin_amdgcn_readlane((int)v, 63));
+}
+
+
 // ---- reset: dead_index[i] = i (effect_cache.rs:298-323) ------------------------------------
 #ifndef HNB_JIT_TU
 __global__ void k_reset_lists(uint32_t* __restrict__ dead, uint32_t* __restrict__ alive0, uint32_t* __restrict__ alive1, uint32_t capacity) {
@@ -911,8 +960,7 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
             for (uint32_t i = tid; i < n4; i += kBlock) { const uint4 v = c4[i]; part += (v.x + v.y) + (v.z + v.w); }
             for (uint32_t i = head + n4 * 4u + tid; i < c.j; i += kBlock) part += cnt[i];
         }
-#pragma unroll
-        for (uint32_t off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        part = wave_sum_u32(part);
         if (lane == 0) s_red[wave] = part;
         __syncthreads();
         excl = 0;
@@ -1352,8 +1400,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         uint32_t m = 0x7f800000u;
         // (each word goes back to +inf once read: the frame after next may merge the four quarters of a chunk into it with atomicMin - SlotArgs::quarters)
         for (uint32_t i = tid; i < n_words; i += kBlock) { const uint32_t v = prev[i]; prev[i] = 0x7f800000u; m = v < m ? v : m; }
-#pragma unroll
-        for (uint32_t off = 32; off > 0; off >>= 1) { const uint32_t y = __shfl_xor(m, off, 64); m = y < m ? y : m; }
+        m = wave_min_u32(m);
         if (lane == 0) s_alive[wave] = m;
         __syncthreads();
         if (tid == 0u) {
@@ -1645,32 +1692,21 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         }
     }
 steps_done:
-    if (cull) {
-#pragma unroll
-        for (uint32_t off = 32; off > 0; off >>= 1) wave_min = fminf(wave_min, __shfl_xor(wave_min, off, 64));
-    }
-    if (!chunk_full) {
-#pragma unroll
-        for (uint32_t off = 32; off > 0; off >>= 1) lane_alive += __shfl_xor(lane_alive, off, 64);
-    }
+    if (cull) wave_min = wave_min_f32(wave_min);
+    if (!chunk_full) lane_alive = wave_sum_u32(lane_alive);
     if (lane == 0) s_alive[wave] = lane_alive;
     // (a negative value marks a wave that skipped a load; a real negative minimum reads the same: the bound then simply
     // stays unknown, which is always correct)
     if (args.safe_words) {
-#pragma unroll
-        for (uint32_t off = 32; off > 0; off >>= 1) rem_min = fminf(rem_min, __shfl_xor(rem_min, off, 64));
+        rem_min = wave_min_f32(rem_min);
         if (lane == 0) s_rem[wave] = rem_min;
     }
     if constexpr (COHORT) {
-#pragma unroll
-        for (uint32_t off = 32; off > 0; off >>= 1) {
-            const uint32_t lo = __shfl_xor(amin, off, 64), hi = __shfl_xor(amax, off, 64);
-            amin = lo < amin ? lo : amin; amax = hi > amax ? hi : amax;
-        }
+        amin = wave_min_u32(amin); amax = wave_max_u32(amax);
         if (lane == 0) { s_amin[wave] = amin; s_amax[wave] = amax; }
     }
     if (lane == 0) { s_died[wave] = died_total; s_lmin[wave] = loaded_all ? wave_min : -1.0f; }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
         if (COHORT && !mixed) {   // do the survivors share one age? (amin > amax: there are none)
             uint32_t lo = 0xffffffffu, hi = 0u;
@@ -1724,6 +1760,9 @@ k_update_slots_stream(const SlotArgs args, const uint64_t* __restrict__ inst_bas
 // without cohorts (launch_stream_age decides; the parity gate's plain replay - culling off - keeps running the general kernel beside it), but: everything
 // a wave can need is requested in ONE round behind the instance row (alive bytes - also of chunks flagged completely alive -, the ages of its four steps,
 // the chunk's bound and flag, the tick), the lifetimes only in steps where somebody may die, counters per lane, one reduction per wave.
+#ifndef HNB_AGEK_CUT
+#define HNB_AGEK_CUT 0   // (tools/r06ab.sh: timing-only builds that cut pieces out of the kernel; 0 in the product)
+#endif
 __global__ void __launch_bounds__(kBlock)
 k_update_slots_stream_age(const SlotArgs args, const uint64_t* __restrict__ inst_base, const DevFrameInst* __restrict__ fi,
                           const uint32_t* __restrict__ ublocks, const CompactBufs cb) {
@@ -1756,14 +1795,13 @@ k_update_slots_stream_age(const SlotArgs args, const uint64_t* __restrict__ inst
     }
     const uint32_t cf = cfull[j];
     const float Lm = lmin[j];                 // 0 (or anything not > 0): unknown, every step loads the lifetimes
-    if (args.safe_words && wg == 0u) {        // publish the previous frame's bound: its kernel has completed, every chunk's word is final
+    if (!(HNB_AGEK_CUT & 1) && args.safe_words && wg == 0u) {        // publish the previous frame's bound: its kernel has completed, every chunk's word is final
         // (the FIRST workgroup of the launch, not chunk 0: in a frame that walks downwards chunk 0 is the last one dispatched, and the store to host memory
         // behind two barriers was the tail of the kernel)
         uint32_t* prev = args.safe_words + (size_t)(args.safe_parity ^ 1u) * args.safe_stride;
         uint32_t m = 0x7f800000u;
         for (uint32_t i = tid; i < wg_total; i += kBlock) { const uint32_t v = prev[i]; prev[i] = 0x7f800000u; m = v < m ? v : m; }   // (back to +inf: update_stream_chunk's publisher)
-#pragma unroll
-        for (uint32_t off = 32; off > 0; off >>= 1) { const uint32_t y = __shfl_xor(m, off, 64); m = y < m ? y : m; }
+        m = wave_min_u32(m);
         if (lane == 0) s_alive[wave] = m;
         __syncthreads();
         if (tid == 0u) {
@@ -1782,7 +1820,7 @@ k_update_slots_stream_age(const SlotArgs args, const uint64_t* __restrict__ inst
         cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + k] = 0u;
     }
     if (frozen) return;
-    if (args.horizon && j == 0u && tid == 0u) {       // the instance's clock: once per simulated frame
+    if (!(HNB_AGEK_CUT & 2) && args.horizon && j == 0u && tid == 0u) {       // the instance's clock: once per simulated frame
         double* clk = horizon_view(base, args.horizon_off, args.chunks_per_inst).clock;
         *clk = *clk + (double)(dt_tick > 0.0f ? dt_tick : 0.0f) * (1.0 + 0x1p-16);
     }
@@ -1803,7 +1841,7 @@ k_update_slots_stream_age(const SlotArgs args, const uint64_t* __restrict__ inst
             const bool was = ((w >> (8 * p)) & 0xffu) == 1u;
             may = may || (was && !(bound_known && an[step][p] < Lm));
         }
-        if (__any(may)) need_mask |= 1u << step;
+        if (!(HNB_AGEK_CUT & 4) && __any(may)) need_mask |= 1u << step;
     }
     // The lifetimes: for a wave with a step in which somebody may die, ALL of its steps' quads in one round, no lane-dependent branch around the loads (the
     // first version loaded per step and lane under `if`, and the compiler waited for each load inside its branch: four dependent round trips in exactly the
@@ -1888,28 +1926,23 @@ k_update_slots_stream_age(const SlotArgs args, const uint64_t* __restrict__ inst
         }
         if (args.write_died) store_died_bits(died_bits, step_first, nib, lane);
     }
-#pragma unroll
-    for (uint32_t off = 32; off > 0; off >>= 1) {
-        lane_died += __shfl_xor(lane_died, off, 64);
-        wave_min = fminf(wave_min, __shfl_xor(wave_min, off, 64));
-    }
-    if (!chunk_full) {
-#pragma unroll
-        for (uint32_t off = 32; off > 0; off >>= 1) lane_alive += __shfl_xor(lane_alive, off, 64);
-    }
+    if (HNB_AGEK_CUT & 16) return;
+    lane_died = need_mask != 0u ? wave_sum_u32(lane_died) : 0u;   // (wave-uniform from here on)
+    wave_min = need_mask != 0u ? wave_min_f32(wave_min) : __builtin_inff();
+    if (!chunk_full) lane_alive = wave_sum_u32(lane_alive);
     if (args.safe_words) {
         if (an_max > -__builtin_inff()) rem_min = fminf(rem_min, (Lm - an_max) - 1.0e-5f * Lm);   // the steps without lifetimes: lf = Lm there
-#pragma unroll
-        for (uint32_t off = 32; off > 0; off >>= 1) rem_min = fminf(rem_min, __shfl_xor(rem_min, off, 64));
+        rem_min = wave_min_f32(rem_min);
     }
     // (a negative value marks a wave that skipped a load; a real negative minimum reads the same: the bound then simply stays unknown, which is always correct)
     if (lane == 0) { s_died[wave] = lane_died; s_alive[wave] = lane_alive; s_rem[wave] = rem_min; s_lmin[wave] = loaded_all ? wave_min : -1.0f; }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
         uint32_t d = 0;
 #pragma unroll
         for (uint32_t w = 0; w < kBlock / 64; ++w) d += s_died[w];
         if (d) atomicAdd(&cb.deaths[(size_t)cb.parity * cb.table_cap + k], d);
+        if (HNB_AGEK_CUT & 8) return;
         if (d && args.skip_lists) *args.fault = 1u;  // the host's proof was wrong: report it (HnbEffectMetadata::fault)
         if (args.safe_words) {  // one word per chunk and frame parity, plain store
             float r = fminf(fminf(s_rem[0], s_rem[1]), fminf(s_rem[2], s_rem[3]));

@@ -34,7 +34,7 @@ def main():
         "c2:16777216x1": ("k_update_slots_stream", sig("AGE_TICK", "VEL_SCALE", "VEL_ADD", "EULER")),
         "c3:8388608x1": ("k_update_slots_stream", sig("AGE_TICK", "CONFORM_SPHERE", "CONFORM_SPHERE", "KILL_AABB", "KILL_SPHERE", "EULER")),
         "c4:65536x512": ("k_update_slots_stream", sig("AGE_TICK", "EULER")),
-        "c5:4194304x1": ("k_update_slots_stream", "<" + sig("AGE_TICK") + ">"),
+        "c5:4194304x1": ("k_update_slots_stream_age", ""),   # (r6: the age-only update has a kernel of its own)
     }
 
     def load(path, counter):
