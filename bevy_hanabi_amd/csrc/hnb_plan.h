@@ -199,7 +199,9 @@ inline uint32_t size_init_grid(const InitGridInputs& in, uint32_t capacity, uint
     return blocks;
 }
 // gridDim.y of k_emit_events: the events of a chunk are dealt over several workgroups, 16,384 events per split, sized for the largest
-// event buffer that listens
+// event buffer that listens. (Round 6: 2048 per split - eight times the workgroups for the rocket effect of firework.rs, whose k_emit_events is the
+// longest link of the chain that runs beside the trails' update - made c2_events 2 % slower, 0.357 -> 0.363 ms in three rounds on one box: every split
+// repeats the chunk's prefix and scan. profiles/r06ae_ab_event_splits.log, r06ad_c2_events_timeline.log.)
 inline uint32_t size_event_grid(uint32_t max_event_capacity, uint32_t total_chunks) {
     const uint32_t per_chunk = max_event_capacity / (total_chunks ? total_chunks : 1u);
     const uint32_t splits = (per_chunk + 16383u) / 16384u;
