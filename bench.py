@@ -358,16 +358,44 @@ class Dist:
         hnb_comm_create_rank: ncclCommInitRank of librccl (or of --comm-lib, for dry runs of several ranks on one GPU)."""
         if not self.on:
             return None
+        import torch
         import torch.distributed as dist
-        box = [w.bh.Comm.unique_id() if self.rank == 0 else None]
+        # (a rank whose communicator cannot be created must not leave the others inside ncclCommInitRank or kill the measurement: every rank learns
+        # whether every rank succeeded; if not, the totals fall back to the torch process group and the line says so - `comm.error`)
+        err = None
+        try:
+            box = [w.bh.Comm.unique_id() if self.rank == 0 else None]
+        except Exception as e:   # noqa: BLE001
+            box, err = [None], f"hnb_comm_unique_id: {e}"
         dist.broadcast_object_list(box, src=0)
-        return w.bh.Comm.rank(w.ctx, box[0], self.rank, self.world)
+        comm = None
+        if box[0] is not None:
+            try:
+                comm = w.bh.Comm.rank(w.ctx, box[0], self.rank, self.world)
+            except Exception as e:   # noqa: BLE001
+                err = f"hnb_comm_create_rank: {e}"
+        else:
+            err = err or "rank 0 could not create a unique id"
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=self.reduce_device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.destroy()
+            self.comm_error = err or "another rank could not create its communicator"
+            return None
+        return comm
 
     def alive_total(self, w):
         """The only collective of the design: the alive-particle counters, for reporting. N > 1: hnb_comm_allreduce_alive (one grouped ncclAllReduce of
         n_effects x u64 on the simulation stream) over the workload's communicator; every rank passes the same number of entries (NULL = 0)."""
         if not self.on:
             return w.alive()
+        if w.comm is None:   # (make_comm failed on some rank: the measurement goes on, the line reports it)
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor([w.alive()], dtype=torch.int64, device=self.reduce_device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return int(t.item())
         fxs = list(w.fxs) + [None] * (w.n_effects_max - len(w.fxs))
         return int(sum(w.comm.allreduce_alive([fxs])))
 
@@ -881,6 +909,8 @@ def run_config(name, args, D, strong=False, pmc=None):
     if w.options == "default":
         assert stale_mask == 0, f"{name}: the library's default options left attribute planes stale after the timed frames (mask {stale_mask:#x})"
     comm_info = None
+    if D.on and w.comm is None:
+        comm_info = {"error": getattr(D, "comm_error", "no communicator"), "ranks": D.world, "alive_total": alive1_total, "via": "torch.distributed (fallback: hnb_comm_create_rank failed)"}
     if D.on and w.comm is not None:   # N > 1: what the totals above were reduced through (hnb_comm_describe)
         kind, _, rest = w.comm.describe().partition(" ")
         comm_info = {"library": rest.split(" ranks=")[0] if kind == "rccl" else kind, "ranks": int(rest.split(" ranks=")[1].split()[0]) if " ranks=" in rest else D.world,
