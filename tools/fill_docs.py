@@ -33,7 +33,7 @@ rows = [("**c2** firework burst 16,777,216 (headline; library defaults)", line["
 notes = {"c2_lean": "`LEAN`: AGE stale (the headline of r2–r5)", "c2_interop": "cohorts off", "c2_view": "+ consumer %.3f ms; simulation %.3f" % (c["c2_view"]["consumer_ms"], c["c2_view"]["sim_only_ms"]),
          "c2_reburst": "re-burst init %.3f ms = %.2f of HBM; stages %.3f + %.3f + %.3f" % ((c["c2_reburst"]["reburst_init_ms"], c["c2_reburst"]["reburst_init_frac"]) + tuple(c["c2_reburst"]["stages_ms"])),
          "c2_mixed": "init %.3f + update %.3f + lists %.3f" % tuple(c["c2_mixed"]["stages_ms"]), "c2_dieoff": "per SURVIVING particle",
-         "c2_events": "3 effects, trails' kernel", "c3": "burst init frac %.2f" % c["c3"].get("init_frac", 0), "c4": "burst init frac %.2f" % c["c4"].get("init_frac", 0), "c5": "three launches"}
+         "c2_events": "3 effects, trails' kernel", "c3": "burst init frac %.2f" % c["c3"].get("init_frac", 0), "c4": "burst init frac %.2f" % c["c4"].get("init_frac", 0), "c5": "three launches, device-bound"}
 names = {"c2_lean": "c2_lean", "c2_interop": "c2_interop", "c2_view": "c2_view", "c2_reburst": "**c2_reburst** burst(capacity, period), 4-frame cycle", "c2_mixed": "**c2_mixed** rate spawner steady state", "c2_dieoff": "c2_dieoff frames 48–70",
          "c2_events": "c2_events real firework.rs", "c3": "c3 force field 8.4M", "c4": "c4 512 × 65,536", "c5": "c5 ribbon 4.19M"}
 for k in ("c2_lean", "c2_interop", "c2_view", "c2_reburst", "c2_mixed", "c2_dieoff", "c2_events", "c3", "c4", "c5"):
@@ -42,7 +42,7 @@ t = "| config (1 MI355X, `python bench.py`, median of 25 windows × 30 steps) | 
 for n, m, v, k, kr, b, f, w, note in rows:
     t += f"| {n} | {ms(m)} | {v:.3g} | {ms(k)}{' / ' + ms(kr) + ' (rocprofv3)' if kr else ''} | {b:.3g} | {f:.2f} | {w:.2f} | {note} |\n"
 sc = line["small_effects_scene"]
-t += f"| 26-effect scene (set module / interpreters) | {ms(sc['ms_per_frame_wall'])} / {ms(sc['ms_interpreters'])} per frame | — | — | — | launch-bound | — | |\n"
+t += f"| 26-effect scene (set module / interpreters) | {ms(sc['ms_per_frame_wall'])} / {ms(sc['ms_interpreters'])} per frame | — | — | — | five dependent launches | — | |\n"
 t += f"\nFirst burst of c2 (`k_init_slots`): {ms(line['burst_init']['kernel_ms'])} ms = {line['burst_init']['frac']:.2f} of 8 TB/s on 44 B per spawn. CPU port: {line['cpu_baseline']['value']:.3g} updates/s with {line['cpu_baseline']['threads']} threads on a {line['cpu_baseline'].get('cpu_quota')}-CPU quota. `comm`: {line['comm']['library'].split('/')[-1]}, 1 rank, total = {line['comm']['alive_total']}.\n"
 d = open(ROOT + "/DESIGN.md").read()
 d = re.sub(r"<!-- R06_TABLE_BEGIN -->.*?<!-- R06_TABLE_END -->", "<!-- R06_TABLE_BEGIN -->\n" + t.replace("\\", "\\\\") + "<!-- R06_TABLE_END -->", d, flags=re.S)
