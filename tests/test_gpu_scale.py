@@ -576,6 +576,45 @@ def test_list_kernels_are_skipped_only_where_nothing_can_die(ctx):
     gpu.fx.destroy(); gpu.prog.destroy()
 
 
+def test_no_death_bound_through_quartered_and_whole_chunk_frames():
+    """Round 6 (SlotArgs::quarters): a small streaming program without cohorts is served by FOUR workgroups per chunk in the merged launches, and by one per
+    chunk in its own launch (frames on which kernel timing is sampled do not merge). The chunk's word of the no-death bound is the minimum of the four
+    quarters (atomicMin into a word the previous frame's publisher left at +inf) in the first kind of frame and a plain store in the second: a run that
+    alternates between them - timing sampled every third frame - with varying ticks, through the first deaths and the whole die-off, must skip list kernels
+    only where nothing can die (fault flag clear, state as the oracle has it at every checkpoint), and must still skip a good part of the frames before."""
+    cap = 20_000            # 5 chunks: a candidate for the merged launches (which take two programs or more: a second small effect beside it)
+    asset = effects.firework_trails(cap)
+    c = bh.Context(0)       # the defaults: this asset's render modifiers read AGE and it is small, so it keeps per-particle ages (no cohorts: quarters apply)
+    c.enable_kernel_timing(3)
+    gpu, orc = GpuRunner(asset, ctx=c), OracleRunner(asset)
+    other_asset = effects.firework_trails(9_000)
+    other, other_orc = GpuRunner(other_asset, ctx=c), OracleRunner(other_asset)
+    rng = np.random.default_rng(11)
+    t, f, first_death_frame = 0.0, 0, None
+    for checkpoint in (20, 40, 52, 58, 64, 70, 76, 90, 120):
+        while f < checkpoint:
+            dt = 1 / 60 if f < 6 else float(rng.uniform(1 / 200, 1 / 50))
+            fr = Frame(dt, cap if f == 0 else 0, frame_seed(f), time=t)
+            fo = Frame(dt, 9_000 if f == 10 else 0, frame_seed(1000 + f), time=t)   # (bursts ten frames later: its die-off overlaps the first one's differently)
+            c.frame_begin(dt, t)
+            gpu.fx.set_frame(fr.spawn, fr.seed, fr.transform); other.fx.set_frame(fo.spawn, fo.seed, fo.transform)
+            c.simulate()
+            orc.step(fr); other_orc.step(fo)
+            t += dt; f += 1
+        ref = orc.state()
+        assert_same_state(ref, gpu.state(), f"frame {f}")
+        assert_same_state(other_orc.state(), other.state(), f"second effect, frame {f}")
+        assert gpu.fx.metadata()["fault"] == 0 and other.fx.metadata()["fault"] == 0
+        if first_death_frame is None and ref["counters"]["alive_count"] < cap:
+            first_death_frame = f
+    info = gpu.prog.kernel_info()
+    merged = [l for l in info.split("\n") if l.startswith("update served by a merged launch")]
+    assert merged and 60 <= int(merged[0].split(":")[1].split()[0]) <= 90, info     # two frames in three
+    skipped, frames = _skipped(gpu.prog)
+    assert frames == 120 and first_death_frame is not None and 20 <= skipped <= 120 - 20, (skipped, first_death_frame, info)
+    c.close()
+
+
 def test_skipping_is_suspended_by_everything_the_bound_does_not_cover(ctx):
     """Spawns, host writes to the planes and thawed instances invalidate the published bound: the frames that follow run
     their list kernels until a bound computed after the event arrives, and the results stay exact."""
