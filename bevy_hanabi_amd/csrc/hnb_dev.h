@@ -62,20 +62,22 @@ struct DevProgram {
 
 // Per instance, per frame (uploaded with one memcpy per program per frame).
 struct DevFrameInst {
+    // The first 32 bytes are what every init and list kernel reads before anything else (requested_spawn, the `frozen` test): ONE 32-byte scalar load.
+    // (Until round 6 spawn_count / ev_in / ev_parity / skip lay at offsets 0 / 80 / 152 / 156 and were read one behind the other's test: three dependent
+    // round trips at the head of kernels that last five; the compiler sinks separately hoisted loads back behind the branches.)
     uint32_t spawn_count;       // GpuSpawnerParams::spawn
     uint32_t seed;              // GpuSpawnerParams::seed
     uint32_t slot_base;         // particle index offset for PRNG / ID (capacity-slab sharding)
     uint32_t init_block_start;  // first init workgroup of this instance (CPU prefix sum, batch.rs:348-386)
-    float xf[12];               // row-major 3x4 transform
-    // GPU spawn events (GpuSpawnerParams::parent_slab_offset, GpuChildInfo; src/render/event.rs:200-214)
-    uint64_t parent_base;       // child: slab of the parent instance, 0 = CPU-spawned effect
-    uint64_t parent_planes;     // child: u32[HNB_ATTR_COUNT] plane offsets of the parent layout in 256-byte units (kNoPlane = absent)
-    uint64_t ev_in;             // child: DevEventBuffer the init pass consumes
-    uint64_t ev_out[HNB_MAX_EVENT_CHANNELS];  // parent: DevEventBuffer per child channel, 0 = nobody listens
+    uint64_t ev_in;             // child: DevEventBuffer the init pass consumes (GPU spawn events: GpuSpawnerParams::parent_slab_offset, GpuChildInfo; src/render/event.rs:200-214)
     uint32_t ev_parity;         // context frame parity: events are appended to count[ev_parity], consumed from count[ev_parity ^ 1]
     uint32_t skip;              // 1: the instance is not simulated this frame (SimulationCondition::WhenVisible and not visible): state frozen
+    float xf[12];               // row-major 3x4 transform
+    uint64_t parent_base;       // child: slab of the parent instance, 0 = CPU-spawned effect
+    uint64_t parent_planes;     // child: u32[HNB_ATTR_COUNT] plane offsets of the parent layout in 256-byte units (kNoPlane = absent)
+    uint64_t ev_out[HNB_MAX_EVENT_CHANNELS];  // parent: DevEventBuffer per child channel, 0 = nobody listens
 };
-static_assert(sizeof(DevFrameInst) == 96 + 8 * HNB_MAX_EVENT_CHANNELS, "DevFrameInst layout");
+static_assert(sizeof(DevFrameInst) == 96 + 8 * HNB_MAX_EVENT_CHANNELS && sizeof(DevFrameInst) % 32 == 0, "DevFrameInst layout: rows are 32-byte aligned (the parameter blocks are 256-byte aligned)");
 
 // Spawn events of one (parent instance, channel). `count` keeps growing past the capacity like the
 // reference's GpuChildInfo::event_count (src/lib.rs:976-993); it is double-buffered by frame parity so

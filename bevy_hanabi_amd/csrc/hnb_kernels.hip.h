@@ -177,12 +177,21 @@ __device__ __forceinline__ Out4 vfile_load_attr(uint32_t ncomp, const char* plan
 // Particles the init pass of instance k wants to spawn this frame: the CPU spawner's count, or — for an
 // effect with a parent — the number of spawn events its parent appended during the PREVIOUS frame
 // (vfx_init.wgsl:123-129; events past the buffer capacity were never stored).
+// The compiler sinks a scalar load to its first use - behind the branches in front of it, where it becomes one more DEPENDENT round trip. An empty asm
+// that names the value pins the load (and the wait for it, shared with everything requested beside it) where the source put it. Uniform values only.
+__device__ __forceinline__ void pin_scalar(uint32_t v) { asm volatile("" ::"s"(v)); }
 __device__ __forceinline__ uint32_t requested_spawn(const DevFrameInst& f) {
-    if (f.skip) return 0u;
-    if (f.ev_in == 0ull) return f.spawn_count;
-    const DevEventBuffer* ev = global_ptr<const DevEventBuffer>(f.ev_in);
-    const uint32_t n = ev->count[f.ev_parity ^ 1u];
-    return n < ev->capacity ? n : ev->capacity;
+    // (r6: the row's first 32 bytes - spawn_count .. skip - in one scalar load: hnb_dev.h)
+    const uint4 h0 = reinterpret_cast<const uint4*>(&f)[0], h1 = reinterpret_cast<const uint4*>(&f)[1];
+    const uint32_t spawn_count = h0.x, parity = h1.z, skip = h1.w;
+    const uint64_t ev_in = (uint64_t)h1.x | ((uint64_t)h1.y << 32);
+    pin_scalar(spawn_count);
+    if (skip) return 0u;
+    if (ev_in == 0ull) return spawn_count;
+    const DevEventBuffer* ev = global_ptr<const DevEventBuffer>(ev_in);
+    const uint2 cnt = *reinterpret_cast<const uint2*>(ev->count);
+    const uint32_t n = (parity ^ 1u) ? cnt.y : cnt.x, cap = ev->capacity;
+    return n < cap ? n : cap;
 }
 
 // ---- code policies -----------------------------------------------------------------------------
@@ -289,24 +298,29 @@ __device__ __forceinline__ void init_workgroup(const DevProgram& prog, const uin
     // (find_location_from_particle, vfx_init.wgsl:51-72, at workgroup granularity). The prefix sums sit in a
     // packed array behind the parameter blocks, so the first steps of the search hit the same cached words in
     // every workgroup (searching the 128-byte DevFrameInst rows cost ~10 dependent cache misses per workgroup).
-    const uint32_t* init_start = ublocks + (size_t)prog.n_inst * prog.n_uregs;
-    uint32_t lo = 0, hi = prog.n_inst;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (blk >= init_start[mid]) lo = mid + 1; else hi = mid;
+    // (r6: a program with ONE instance - every effect of a scene, C5 - owns the whole grid: no search, no row to look the first workgroup up in. The search
+    // and the look-up were two dependent round trips in front of everything else of a kernel that lasts five)
+    uint32_t k = 0u, first_block = 0u, n_blocks = grid;
+    if (prog.n_inst != 1u) {
+        const uint32_t* init_start = ublocks + (size_t)prog.n_inst * prog.n_uregs;
+        uint32_t lo = 0, hi = prog.n_inst;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (blk >= init_start[mid]) lo = mid + 1; else hi = mid;
+        }
+        k = lo - 1;
+        // The instance's workgroups stride over its spawns: exactly one round for CPU spawners; for effects with a
+        // parent the event count is only known on the device, so the grid is capped and loops (no indirect dispatch in HIP).
+        first_block = fi[k].init_block_start;
+        n_blocks = (k + 1u < prog.n_inst ? fi[k + 1u].init_block_start : grid) - first_block;
     }
-    const uint32_t k = lo - 1;
-    // The instance's workgroups stride over its spawns: exactly one round for CPU spawners; for effects with a
-    // parent the event count is only known on the device, so the grid is capped and loops (no indirect dispatch in HIP).
-    const uint32_t first_block = fi[k].init_block_start;
-    const uint32_t n_blocks = (k + 1u < prog.n_inst ? fi[k + 1u].init_block_start : grid) - first_block;
-
+    const uint64_t slab = inst_base[k];   // (requested with the counters and the frame's row, in front of requested_spawn's tests)
     const uint32_t alive0 = meta_in[k].alive_count;
     const uint32_t max_spawn = prog.capacity - alive0;
     const uint32_t spawn = requested_spawn(fi[k]);
     const uint32_t n_spawn = spawn < max_spawn ? spawn : max_spawn;
 
-    char* base = global_ptr<char>(inst_base[k]);
+    char* base = global_ptr<char>(slab);
     const uint32_t* dead = reinterpret_cast<const uint32_t*>(base + prog.dead_off);
     uint32_t* alive = reinterpret_cast<uint32_t*>(base + prog.alive_off[list_column(meta_in[k].write_index)]);  // the column holding the list
     // ... as a ring ("Ring lists"): row r lives at (head + r) % capacity. Appended spawns are rows alive0 + i; in a RING frame they are rows -n_spawn + i:
@@ -442,12 +456,13 @@ __device__ __forceinline__ void slot_init_setup(SlotInitCtx& c, const DevProgram
     const uint32_t per_inst = prog.chunks_per_inst * (kChunk / kSlotInitWg);
     c.k = wg / per_inst;
     c.w = wg - c.k * per_inst;
+    const uint64_t slab = inst_base[c.k];
     c.alive0 = meta_in[c.k].alive_count;
     const uint32_t max_spawn = prog.capacity - c.alive0;
     const uint32_t spawn = requested_spawn(fi[c.k]);
     c.n_spawn = spawn < max_spawn ? spawn : max_spawn;
     c.full = c.n_spawn == max_spawn;
-    c.base = global_ptr<char>(inst_base[c.k]);
+    c.base = global_ptr<char>(slab);
 }
 #ifndef HNB_JIT_TU
 // alive byte 2 = "spawns in this frame" for the slots a PARTIAL re-fill pops (k_init_slots turns every one of them into 1 / 3 in the same frame)
@@ -788,14 +803,17 @@ __device__ __forceinline__ bool chunk_setup(ChunkCtx& c, uint32_t chunk, const A
                                             const DevFrameInst* fi) {
     c.k = chunk / args.chunks_per_inst;
     c.j = chunk - c.k * args.chunks_per_inst;
+    // (the instance's slab address and counters are requested in front of requested_spawn's tests: one round trip for the whole row)
+    const uint64_t slab = inst_base[c.k];
     // vfx_indirect.wgsl:57-85 folded in: max_update = alive_count after init.
     c.m = load_meta(meta_in + c.k);
+    const uint32_t frozen = fi[c.k].skip;
     const uint32_t spawn = requested_spawn(fi[c.k]);
     const uint32_t max_spawn = args.capacity - c.m.alive_count;
     c.n_spawn = spawn < max_spawn ? spawn : max_spawn;
-    c.n = fi[c.k].skip ? 0u : c.m.alive_count + c.n_spawn;  // a frozen instance has nothing to update
+    c.n = frozen ? 0u : c.m.alive_count + c.n_spawn;  // a frozen instance has nothing to update
     c.start = c.j * kChunk;
-    c.base = global_ptr<char>(inst_base[c.k]);
+    c.base = global_ptr<char>(slab);
     return c.start < c.n;
 }
 
@@ -807,7 +825,10 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     ChunkCtx c;
+    // (the instance's casualty counter: requested with its row, not behind the `frozen` test)
+    const uint32_t total_dead = cb.deaths[(size_t)cb.parity * cb.table_cap + chunk / args.chunks_per_inst];
     const bool has_rows = chunk_setup(c, chunk, args, inst_base, meta_in, fi);
+    pin_scalar(total_dead);
     const HorizonView hz = horizon_view(c.base, args.horizon_off, args.chunks_per_inst);
     if (fi[c.k].skip) {  // not simulated this frame: counters carry over unchanged
         DevMeta keep = c.m;
@@ -824,8 +845,6 @@ __device__ __forceinline__ void compact_chunk(const ARGS& args, const uint64_t* 
         if (args.hz && tid == 0) { hz.D(args.hz_parity ^ 1u)[c.j] = hz.D(args.hz_parity)[c.j]; hz.BF(args.hz_parity ^ 1u)[c.j] = hz.BF(args.hz_parity)[c.j]; }   // the rows stand: so do their horizons
         return;
     }
-    uint32_t* deaths_cur = cb.deaths + (size_t)cb.parity * cb.table_cap;
-    const uint32_t total_dead = deaths_cur[c.k];
     if (c.j == 0 && tid == 0) cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + c.k] = 0u;  // next frame's counter
     const bool last = c.n == 0 ? c.j == 0 : (c.start < c.n && c.start + kChunk >= c.n);
     const bool rotate = args.rotate_front != 0u && c.n_spawn != 0u;   // (uniform per instance; never set together with slot_order)
@@ -1386,6 +1405,10 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
     const uint32_t wave0 = j * kChunk + (split ? (quarter * (kBlock / 64u) + wave) * kStepRows : wave * kWaveRows);   // the wave's first slot
     const uint32_t n_steps = split ? 1u : kWaveRows / kStepRows;
     const uint32_t n_words = split ? wg_total >> 2 : wg_total;   // chunks of the program
+    // (r6: the instance's row - frozen or not, its slab - requested here, in front of the publisher and the counter rotation, not behind their branches:
+    // every dependent round trip at the head of a workgroup is a microsecond of a small frame)
+    const uint32_t frozen = fi[k].skip;
+    const uint64_t slab = inst_base[k];
     // Plane stores of a program whose WRITTEN planes exceed the Infinity Cache by half (SlotArgs::store_hint, plan::use_store_hints): nontemporal.
     // Same-box A/B (profiles/r04o_ab_walk.log, r04p_ab_walk2.log): c2_mixed 0.327 -> 0.316 ms, c2_events 0.456 -> 0.438; C3 - 8.4M particles,
     // 235 MB of written planes: they FIT the cache and the next frame's walk finds them there - 0.097 -> 0.120 ms with the hint, hence the size rule.
@@ -1411,15 +1434,15 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
     }
     if (args.skip_lists && j == 0u && quarter == 0u && tid == 0u) {  // counter rotation of a frame without spawn and casualty (k_compact's zero-casualty path)
         DevMeta o = args.meta_in[k];
-        if (!fi[k].skip) {
+        if (!frozen) {
             o.ref_write_index ^= 1u;
             o.max_update = o.alive_count; o.dead_count = 0u; o.spawned = 0u; o.instance_count = o.alive_count;
         }
         args.meta_out[k] = o;
         cb.deaths[(size_t)(cb.parity ^ 1u) * cb.table_cap + k] = 0u;
     }
-    if (fi[k].skip) return;  // frozen instance
-    char* base = global_ptr<char>(inst_base[k]);
+    if (frozen) return;  // frozen instance
+    char* base = global_ptr<char>(slab);
     VmUniforms U;
     U.u = ublocks + (size_t)k * args.n_uregs;
     U.xf = fi[k].xf;
@@ -2083,12 +2106,14 @@ __device__ __forceinline__ void count_rows_chunk(const CompactArgs& args, const 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = chunk_of_workgroup(cb.xcd_remap, wg, wg_total);
     ChunkCtx c;
+    const uint32_t total_dead = cb.deaths[(size_t)cb.parity * cb.table_cap + chunk / args.chunks_per_inst];   // (requested with the instance's row)
     const bool has_rows = chunk_setup(c, chunk, args, inst_base, meta_in, fi);
+    pin_scalar(total_dead);
     const HorizonView hz = horizon_view(c.base, args.horizon_off, args.chunks_per_inst);
     if (args.hz && tid == 0u) { hz.D(args.hz_parity ^ 1u)[c.j] = kHorizonNever; hz.BF(args.hz_parity ^ 1u)[c.j] = 0xffffffffu; }   // k_compact merges into these
     if (!has_rows) return;
     if (args.suffix_dead) return;   // (the job-table launch: this program's casualties are known to be its list's last rows, CompactArgs)
-    if (cb.deaths[(size_t)cb.parity * cb.table_cap + c.k] == 0u) return;  // nothing died in this instance: the list stands
+    if (total_dead == 0u) return;  // nothing died in this instance: the list stands
     if (args.hz_use) {   // can a row of this chunk have died in this frame? (see "death horizons")
         const double clock = *hz.clock;
         if (clock < u2d(hz.D(args.hz_parity)[c.j]) && args.frame_no - hz.BF(args.hz_parity)[c.j] <= kHorizonFrames) {
