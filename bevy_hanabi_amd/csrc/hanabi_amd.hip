@@ -1648,7 +1648,11 @@ static const HnbProgram* pick_heavy_program(const HnbContext* ctx, const std::ve
 static void direct_write(void* dst, const void* src, size_t n) {
     memcpy(dst, src, n);
 #if !defined(__HIP_DEVICE_COMPILE__)
+#if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_sfence();
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);   // (a full barrier: orders the device writes in front of the doorbell store on hosts without a dedicated store fence)
+#endif
 #endif
 }
 
