@@ -261,6 +261,8 @@ struct HnbProgram {
     hipFunction_t jit_init = nullptr, jit_update = nullptr, jit_init_slots = nullptr;
     bool slot_init_eligible = false;   // the init reads neither PARTICLE_COUNTER nor a parent particle, no ribbons: large spawns may run slot-major (plan::plan_slot_init)
     uint32_t slot_init_frames = 0;     // statistics
+    uint32_t sort_skipped_frames = 0;  // statistics: list-free frames of a ribbon program that did not sort (enqueue_ribbon_sort)
+    bool tick_sign_seen = false;       // sticky: some frame's AGE tick of some instance was negative, -0 or NaN (stage_program_frame; enqueue_ribbon_sort)
     uint64_t serial = 0;            // identity across destruction (HNB_OPT_JIT_ASYNC: a finished compilation looks its program up by it)
     bool jit_pending = false;
     std::string kernel_info, jit_log;
@@ -1786,6 +1788,9 @@ static void stage_program_frame(HnbContext* ctx, HnbProgram* p, uint32_t slot, s
         if (p->ring_live && !pl.ribbon.ring) pl.skip_lists = false;
     }
     pl.lists = !(p->update_streams && pl.skip_lists);  // false: proven no spawn, no casualty; the update kernel rotates the counters
+    if (p->skip_facts.eligible && !p->tick_sign_seen)
+        for (uint32_t i = 0; i < n; ++i)
+            if (inst_frames[i].simulated && !plan::nonneg_not_nan(plan::uword(inst_frames[i], p->skip_facts.dt_operand)) ) p->tick_sign_seen = true;
     if (pl.ribbon.ring && !pl.lists) pl.ribbon.ring = false;   // (nothing spawns, nothing can die: the list stands, head and all)
     p->dev.ring = pl.ribbon.ring ? 1u : 0u;
     pl.slot_init = plan::plan_slot_init(p->slot_init_eligible, ctx->slot_init, p->dev.capacity, p->dev.chunks_per_inst, inst_frames.data(), n);
@@ -2038,6 +2043,14 @@ static void enqueue_ribbon_sort(HnbContext* ctx, HnbProgram* p, hipStream_t st) 
     // for a small range. Otherwise the device decides (k_sort_fill's order check) and all launches are issued.
     const bool proven = p->plan.ribbon.head_sorted;
     if (proven && p->plan.ribbon.max_spawn == 0u) return;
+    // (r6) A frame whose list kernels were skipped - proven: nothing spawns, nothing can die, every tick finite and non-negative, no host write - leaves the
+    // list exactly as the previous frame's sort left it, and every key moved by the same tick (monotone under rounding): still sorted, whatever the
+    // program's ages and ribbon ids look like. (The lightning bolt of lightning.rs - ages and ribbon ids hashed from PARTICLE_COUNTER, nothing provable -
+    // launched a one-workgroup sort in every frame of its 1.5 s between two strikes: 5 us of a 36 us scene frame.)
+    // Keys are age BITS: a uniform tick keeps their order only while no age crosses zero. No tick of this program was ever negative or NaN
+    // (HnbProgram::tick_sign_seen, sticky), and an age that carries the sign bit makes the update publish a no-death bound of 0 (update_stream_chunk), so
+    // a frame whose lists were skipped follows a frame in which every alive age was +0 or above.
+    if (!p->plan.lists && !p->ribbon_hist.dirty && p->frames_run > 0u && !p->tick_sign_seen) { p->sort_skipped_frames += 1; return; }
     if (p->plan.ribbon.rotate) {  // the spawns go in front and k_compact has written the survivors in that order (CompactArgs::rotate_front): nothing to sort
         p->sort_rotated_frames += 1;
         return;
@@ -2654,6 +2667,7 @@ int hnb_program_kernel_info(HnbProgram* prog, char* buf, size_t buf_size) {
     if (prog->slot_init_frames) s += "\nslot-major init (large spawns): " + std::to_string(prog->slot_init_frames) + " frames";
     if (prog->has_ribbons && prog->suffix_frames) s += "\ncasualties proven to be the list's last rows (no k_count_rows): " + std::to_string(prog->suffix_frames) + " frames";
     if (prog->has_ribbons && prog->ring_frames) s += "\nlist kept as a ring (no row rewritten): " + std::to_string(prog->ring_frames) + " frames";
+    if (prog->has_ribbons && prog->sort_skipped_frames) s += "\nribbon sorts skipped in list-free frames: " + std::to_string(prog->sort_skipped_frames) + " frames";
     if (prog->has_ribbons) s += "\nribbon sorts by rotation: " + std::to_string(prog->sort_rotated_frames) + " of " + std::to_string(prog->frames_run) + " frames" + (prog->ribbon_facts.front_static ? "" : " (not eligible)");
     if (prog->merged_frames) s += "\nupdate served by a merged launch (small programs of the context share one): " + std::to_string(prog->merged_frames) + " frames";
     if (prog->unmerged_frames) s += "\nkept out of the shared launches (the loaded set module does not know this program; its own specialised kernels): " + std::to_string(prog->unmerged_frames) + " frames";

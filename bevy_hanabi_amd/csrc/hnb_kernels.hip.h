@@ -1525,7 +1525,7 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
                 reinterpret_cast<uint32_t*>(base + args.died_bits_off)[((j * kChunk + wave * kWaveRows) >> 5) + lane] = 0u;
             amin = amax = f2u(A2);                                         // the survivors' common age
             loaded_all = false;                                            // no lifetime was loaded: the chunk's bound stands
-            if (args.safe_words) rem_min = (Lm - A2) - 1.0e-5f * Lm;       // as the per-particle form computes it from X.lifetime = Lm, X.age = A2
+            if (args.safe_words) rem_min = (f2u(A2) >> 31) ? 0.0f : (Lm - A2) - 1.0e-5f * Lm;   // as the per-particle form computes it from X.lifetime = Lm, X.age = A2 (a negative age: no claim, see there)
         }
     }
     // ---- the per-particle path, one wave step (256 slots, 4 per lane). COH: with the age-cohort bookkeeping (a chunk that is known to hold
@@ -1639,7 +1639,10 @@ __device__ __forceinline__ void update_stream_chunk(const SlotArgs& args, const 
         if (args.safe_words) {  // X.lifetime holds the lifetimes, or Lm where they were not loaded (a lower bound of each of them)
 #pragma unroll
             for (int p = 0; p < 4; ++p)
-                if (was[p] && X.alive[p]) rem_min = fminf(rem_min, (X.lifetime[p] - X.age[p]) - 1.0e-5f * X.lifetime[p]);
+                // (r6: a particle whose age carries the sign bit - a negative tick, a negative initial age, -0 - makes NO claim: the bound is 0 and the frames
+                // that follow run their list kernels. A list-free frame may then also skip the ribbon sort - enqueue_ribbon_sort: keys are age BITS, and a
+                // uniform tick keeps their order only while no age crosses zero)
+                if (was[p] && X.alive[p]) rem_min = fminf(rem_min, (f2u(X.age[p]) >> 31) ? 0.0f : (X.lifetime[p] - X.age[p]) - 1.0e-5f * X.lifetime[p]);
         }
         if constexpr (COH) {
 #pragma unroll
@@ -1884,6 +1887,7 @@ k_update_slots_stream_age(const SlotArgs args, const uint64_t* __restrict__ inst
     float wave_min = __builtin_inff();   // minimum lifetime of the particles that stay alive (steps that loaded them)
     float rem_min = __builtin_inff();    // min over this lane's particles that stay alive of (lifetime - age) - 1e-5 * lifetime
     float an_max = -__builtin_inff();    // ... of the steps that did not load the lifetimes: the largest new age (see below)
+    uint32_t an_sign = 0u;               // ... and the OR of their new ages' bits (bit 31: somebody's age is negative or -0)
     bool loaded_all = true;              // wave-uniform: every step with alive slots loaded the lifetimes
     // Three kinds of step (wave-uniform), because four waves share a SIMD here and the 640 VALU instructions per wave of the first version were 4 us of the
     // kernel's 12 (the bare access pattern: 5, tools/probes/age_stream_probe.hip): (A) nobody can die and every slot is alive - a trail in its steady state -:
@@ -1901,6 +1905,7 @@ k_update_slots_stream_age(const SlotArgs args, const uint64_t* __restrict__ inst
             if (args.write_died && (lane & 7u) == 0u) died_bits[(step_first >> 5) + (lane >> 3)] = 0u;   // store_died_bits of no casualty
             if (__all(w == 0x01010101u)) {   // (A)
                 an_max = fmaxf(an_max, fmaxf(fmaxf(an[step][0], an[step][1]), fmaxf(an[step][2], an[step][3])));
+                an_sign |= (f2u(an[step][0]) | f2u(an[step][1])) | (f2u(an[step][2]) | f2u(an[step][3]));
                 __builtin_nontemporal_store((u4v{f2u(an[step][0]), f2u(an[step][1]), f2u(an[step][2]), f2u(an[step][3])}), reinterpret_cast<u4v*>(p_age) + (s0 >> 2));
                 loaded_all = false;
                 continue;
@@ -1914,6 +1919,7 @@ k_update_slots_stream_age(const SlotArgs args, const uint64_t* __restrict__ inst
                 const bool was = ((w >> (8 * p)) & 0xffu) == 1u;
                 q[p] = was ? f2u(an[step][p]) : a4[p];        // free slots get their own bytes back: one 16-byte store
                 an_max = fmaxf(an_max, was ? an[step][p] : -__builtin_inff());
+                an_sign |= was ? f2u(an[step][p]) : 0u;
             }
             if (w != 0u) __builtin_nontemporal_store((u4v{q[0], q[1], q[2], q[3]}), reinterpret_cast<u4v*>(p_age) + (s0 >> 2));
             continue;
@@ -1938,7 +1944,7 @@ k_update_slots_stream_age(const SlotArgs args, const uint64_t* __restrict__ inst
             if (was && !stays) { nib |= 1u << p; nf &= ~(0xffu << (8 * p)); }
             if (stays) {
                 if (need) wave_min = fminf(wave_min, lf);
-                if (args.safe_words) rem_min = fminf(rem_min, (lf - an[step][p]) - 1.0e-5f * lf);
+                if (args.safe_words) rem_min = fminf(rem_min, (f2u(an[step][p]) >> 31) ? 0.0f : (lf - an[step][p]) - 1.0e-5f * lf);
             }
         }
         // (always nontemporal: the plain store cost the C5 frame 0.0323 against 0.0309 ms in three rounds on one box, profiles/r06r_ab_lean_nt.log)
@@ -1954,7 +1960,7 @@ k_update_slots_stream_age(const SlotArgs args, const uint64_t* __restrict__ inst
     wave_min = need_mask != 0u ? wave_min_f32(wave_min) : __builtin_inff();
     if (!chunk_full) lane_alive = wave_sum_u32(lane_alive);
     if (args.safe_words) {
-        if (an_max > -__builtin_inff()) rem_min = fminf(rem_min, (Lm - an_max) - 1.0e-5f * Lm);   // the steps without lifetimes: lf = Lm there
+        if (an_max > -__builtin_inff()) rem_min = fminf(rem_min, (an_sign >> 31) ? 0.0f : (Lm - an_max) - 1.0e-5f * Lm);   // the steps without lifetimes: lf = Lm there; an age with the sign bit: no claim (update_stream_chunk)
         rem_min = wave_min_f32(rem_min);
     }
     // (a negative value marks a wave that skipped a load; a real negative minimum reads the same: the bound then simply stays unknown, which is always correct)

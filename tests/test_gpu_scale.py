@@ -893,6 +893,36 @@ def test_ribbon_sort_after_a_negative_tick_does_not_trust_later_frames(ctx):
     gpu.fx.destroy(); gpu.prog.destroy()
 
 
+def _sorted_frames(prog):
+    line = [l for l in prog.kernel_info().split("\n") if l.startswith("ribbon sorts skipped in list-free frames")]
+    return int(line[0].split(":")[1].split()[0]) if line else 0
+
+
+@pytest.mark.parametrize("age0", [0.0, -0.05])
+def test_list_free_frames_skip_the_ribbon_sort_only_while_no_age_can_cross_zero(age0):
+    """Round 6: a frame whose list kernels were skipped (nothing spawns, nothing can die) leaves the list as the previous frame's sort left it and moves every
+    key by the same tick - still sorted, provided no age crosses zero (the keys are age BITS). A ribbon effect nothing can be proven about (three ribbon
+    ids taken from PARTICLE_COUNTER, spawns over several frames: several ages per ribbon) skips its sort in the frames between its last spawn and its
+    first death; with NEGATIVE initial ages the update publishes a no-death bound of 0 while an age carries the sign bit, so those frames keep their
+    lists and their sort, and the ages cross zero under a sort. Bit-exact against the oracle's (RIBBON_ID, AGE) order after every frame either way."""
+    cap = 3000
+    asset = _ribbon_asset(cap, age=age0, lifetime=1.2, rid=lambda w: w.attr(A.PARTICLE_COUNTER) % w.lit(bh.Value.u32(3)))
+    c = bh.Context(0)
+    gpu, orc = GpuRunner(asset, ctx=c), OracleRunner(asset)
+    for f in range(70):
+        dt = [1 / 60, 1 / 90, 1 / 45][f % 3]
+        fr = Frame(dt, 150 if f < 6 else 0, frame_seed(f), time=f / 60)
+        gpu.step(fr); orc.step(fr)
+        assert_same_state(orc.state(), gpu.state(), f"initial age {age0}, frame {f}")
+    assert gpu.fx.metadata()["fault"] == 0
+    skipped = _sorted_frames(gpu.prog)
+    # No spawn after frame 5, nobody dies in 70 frames: frames 6 .. 69 are list-free unless an age carries the sign bit. Initial age 0: the older rule
+    # already covers them (non-negative ticks and initial ages: "sorted without spawns", not counted here). Initial age -0.05: the spawns of frame 5
+    # cross zero around frame 9 - until then the bound is 0, the lists and the sort run; the ~61 frames behind that skip both.
+    assert skipped == 0 if age0 == 0.0 else (55 <= skipped <= 62), (skipped, gpu.prog.kernel_info())
+    c.close()
+
+
 @pytest.mark.parametrize("case", ["age_not_zero", "two_ribbon_ids", "dies_in_first_frame", "zero_tick", "host_write", "per_particle_rid", "lifetime_changes"])
 def test_ribbon_rotation_is_suspended_where_its_premises_fail(ctx, case):
     """Each premise of the rotation, violated: the sort falls back to keys and stays bit-exact."""
