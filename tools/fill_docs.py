@@ -42,7 +42,7 @@ t = "| config (1 MI355X, `python bench.py`, median of 25 windows × 30 steps) | 
 for n, m, v, k, kr, b, f, w, note in rows:
     t += f"| {n} | {ms(m)} | {v:.3g} | {ms(k)}{' / ' + ms(kr) + ' (rocprofv3)' if kr else ''} | {b:.3g} | {f:.2f} | {w:.2f} | {note} |\n"
 sc = line["small_effects_scene"]
-t += f"| 26-effect scene (set module / interpreters) | {ms(sc['ms_per_frame_wall'])} / {ms(sc['ms_interpreters'])} per frame | — | — | — | five dependent launches | — | |\n"
+t += f"| 26-effect scene (set module / interpreters) | {ms(sc['ms_per_frame_wall'])} / {ms(sc['ms_interpreters'])} per frame | — | — | — | four dependent launches | — | |\n"
 t += f"\nFirst burst of c2 (`k_init_slots`): {ms(line['burst_init']['kernel_ms'])} ms = {line['burst_init']['frac']:.2f} of 8 TB/s on 44 B per spawn. CPU port: {line['cpu_baseline']['value']:.3g} updates/s with {line['cpu_baseline']['threads']} threads on a {line['cpu_baseline'].get('cpu_quota')}-CPU quota. `comm`: {line['comm']['library'].split('/')[-1]}, 1 rank, total = {line['comm']['alive_total']}.\n"
 d = open(ROOT + "/DESIGN.md").read()
 d = re.sub(r"<!-- R06_TABLE_BEGIN -->.*?<!-- R06_TABLE_END -->", "<!-- R06_TABLE_BEGIN -->\n" + t.replace("\\", "\\\\") + "<!-- R06_TABLE_END -->", d, flags=re.S)
